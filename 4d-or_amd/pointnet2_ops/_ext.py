@@ -1,0 +1,369 @@
+"""``pointnet2_ops._ext`` — MI355X drop-in for the reference's pybind11 module.
+
+The reference builds ``pointnet2_ops._ext`` from CUDA sources
+(EXT/src/bindings.cpp:6-19; EXT = scene_graph_prediction/pointnet2_dir/
+pointnet2_ops_lib/pointnet2_ops/_ext-src).  This module exports the same nine
+callables with the same argument order, dtypes, allocation behaviour and error
+behaviour, but forwards to ``libpn2_hip.so`` (hand-written gfx950 kernels behind
+the C ABI of ``include/pn2_hip.h``) through ctypes:
+
+* outputs are allocated here on the input's device (the reference allocates
+  them with ``torch::zeros`` inside the C++ wrapper, e.g. EXT/src/ball_query.cpp:19-21);
+* kernels are enqueued on torch's current HIP stream, no host sync
+  (reference: ``at::cuda::getCurrentCUDAStream()``);
+* contiguity / dtype violations and CPU tensors raise ``RuntimeError`` (the
+  reference's AT_ASSERTs, EXT/include/utils.h:5-25 and "CPU not supported" in
+  every op, e.g. EXT/src/ball_query.cpp:28).
+
+There is NO fallback: if the shared library is missing or a kernel launch
+fails this module raises.  torch is used for device memory and streams only.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libpn2_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"pointnet2_ops._ext: {LIB_PATH} not found. Build it with "
+        f"`make -C {os.path.join(_PKG_DIR, 'csrc')}` (or __graft_entry__.build()); "
+        "there is no CPU/PyTorch fallback."
+    )
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+_c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                        ctypes.c_void_p, ctypes.c_size_t)
+
+# symbol -> argtypes; every entry point returns int unless noted
+_SIGNATURES = {
+    "pn2_furthest_point_sampling": [_c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp],
+    "pn2_gather_points": [_c_int] * 4 + [_c_vp] * 4,
+    "pn2_gather_points_grad": [_c_int] * 4 + [_c_vp] * 4,
+    "pn2_ball_query": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_group_points": [_c_int] * 5 + [_c_vp] * 4,
+    "pn2_group_points_grad": [_c_int] * 5 + [_c_vp] * 4,
+    "pn2_three_nn": [_c_int] * 3 + [_c_vp] * 5,
+    "pn2_three_interpolate": [_c_int] * 4 + [_c_vp] * 5,
+    "pn2_three_interpolate_grad": [_c_int] * 4 + [_c_vp] * 5,
+    "pn2_group_concat_rows": [_c_int] * 7 + [_c_f32] + [_c_vp] * 6,
+    "pn2_group_rows_grad": [_c_int] * 7 + [_c_vp] * 4,
+    "pn2_rows_max": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_rows_max_grad": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_three_interpolate_rows": [_c_int] * 6 + [_c_vp] * 5,
+    "pn2_three_interpolate_rows_grad": [_c_int] * 6 + [_c_vp] * 5,
+    "pn2_gather_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_scatter_add_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_segment_sum_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+}
+for _name, _args in _SIGNATURES.items():
+    _fn = getattr(_lib, _name)  # AttributeError here == ABI mismatch: fail loudly
+    _fn.argtypes = _args
+    _fn.restype = _c_int
+_lib.pn2_fps_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
+_lib.pn2_fps_workspace_bytes.restype = _c_sz
+_lib.pn2_abi_version.restype = _c_int
+_lib.pn2_last_hip_error.restype = _c_int
+_lib.pn2_strerror.argtypes = [_c_int]
+_lib.pn2_strerror.restype = ctypes.c_char_p
+
+ABI_VERSION = int(_lib.pn2_abi_version())
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version",
+                                               "pn2_last_hip_error", "pn2_strerror"])
+#: the python layer may use the point-major fused entry points of this backend
+HAS_ROWS = True
+
+
+# --------------------------------------------------------------------------- checks
+def _fail(msg):
+    raise RuntimeError(msg)
+
+
+def _check_cuda(t, name):
+    if not t.is_cuda:
+        _fail("CPU not supported" if name is None else f"{name} must be a CUDA tensor")
+
+
+def _check(t, name, dtype):
+    if not isinstance(t, torch.Tensor):
+        _fail(f"{name} must be a torch.Tensor")
+    if not t.is_contiguous():
+        _fail(f"{name} must be a contiguous tensor")
+    if t.dtype != dtype:
+        kind = {torch.float32: "a float", torch.int32: "an int", torch.int64: "a long"}[dtype]
+        _fail(f"{name} must be {kind} tensor")
+
+
+def _f32(t, name):
+    _check(t, name, torch.float32)
+
+
+def _i32(t, name):
+    _check(t, name, torch.int32)
+
+
+def _i64(t, name):
+    _check(t, name, torch.int64)
+
+
+def _same_device(lead, *others):
+    # reference: `if (a.is_cuda()) CHECK_CUDA(b)` then "CPU not supported"
+    if not lead[0].is_cuda:
+        _fail("CPU not supported")
+    for t, name in others:
+        if t is None:
+            continue
+        _check_cuda(t, name)
+        if t.device != lead[0].device:
+            _fail(f"{name} must be on {lead[0].device}")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _call(name, ref, *args):
+    """Enqueue `name` on the current stream of `ref`'s device."""
+    with torch.cuda.device(ref.device):
+        stream = torch.cuda.current_stream(ref.device).cuda_stream
+        rc = getattr(_lib, name)(*args, stream)
+    if rc != 0:
+        detail = _lib.pn2_strerror(rc).decode()
+        _fail(f"{name} failed: {detail} (rc={rc}, hipError={_lib.pn2_last_hip_error()})")
+
+
+# ------------------------------------------------------------- the nine reference ops
+def furthest_point_sampling(points, nsamples):
+    """(B,N,3) f32 -> (B,nsamples) i32.  EXT/src/sampling.cpp:66-87."""
+    _f32(points, "points")
+    _same_device((points, "points"))
+    B, N = points.size(0), points.size(1)
+    nsamples = int(nsamples)
+    out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
+    ws_bytes = int(_lib.pn2_fps_workspace_bytes(B, N, nsamples))
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=points.device) if ws_bytes else None
+    _call("pn2_furthest_point_sampling", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out))
+    return out
+
+
+def gather_points(points, idx):
+    """(B,C,N), (B,m) i32 -> (B,C,m).  EXT/src/sampling.cpp:15-39."""
+    _f32(points, "points"); _i32(idx, "idx")
+    _same_device((points, "points"), (idx, "idx"))
+    B, C, N = points.shape
+    m = idx.size(1)
+    out = torch.empty(B, C, m, dtype=torch.float32, device=points.device)
+    _call("pn2_gather_points", points, B, C, N, m, _ptr(points), _ptr(idx), _ptr(out))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """(B,C,m), (B,m) -> (B,C,n).  EXT/src/sampling.cpp:40-65."""
+    _f32(grad_out, "grad_out"); _i32(idx, "idx")
+    _same_device((grad_out, "grad_out"), (idx, "idx"))
+    B, C, m = grad_out.shape
+    out = torch.zeros(B, C, int(n), dtype=torch.float32, device=grad_out.device)
+    _call("pn2_gather_points_grad", grad_out, B, C, int(n), m, _ptr(grad_out), _ptr(idx), _ptr(out))
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """(B,m,3), (B,N,3) -> (B,m,nsample) i32.  EXT/src/ball_query.cpp:8-32."""
+    _f32(new_xyz, "new_xyz"); _f32(xyz, "xyz")
+    _same_device((new_xyz, "new_xyz"), (xyz, "xyz"))
+    B, m = new_xyz.size(0), new_xyz.size(1)
+    N = xyz.size(1)
+    nsample = int(nsample)
+    idx = torch.empty(B, m, nsample, dtype=torch.int32, device=new_xyz.device)  # kernel writes every slot
+    _call("pn2_ball_query", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx))
+    return idx
+
+
+def group_points(points, idx):
+    """(B,C,N), (B,npoints,nsample) i32 -> (B,C,npoints,nsample).  EXT/src/group_points.cpp:12-37."""
+    _f32(points, "points"); _i32(idx, "idx")
+    _same_device((points, "points"), (idx, "idx"))
+    B, C, N = points.shape
+    npoints, nsample = idx.size(1), idx.size(2)
+    out = torch.empty(B, C, npoints, nsample, dtype=torch.float32, device=points.device)
+    _call("pn2_group_points", points, B, C, N, npoints, nsample, _ptr(points), _ptr(idx), _ptr(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """(B,C,npoints,nsample) -> (B,C,n).  EXT/src/group_points.cpp:39-62."""
+    _f32(grad_out, "grad_out"); _i32(idx, "idx")
+    _same_device((grad_out, "grad_out"), (idx, "idx"))
+    B, C, npoints, nsample = grad_out.shape
+    out = torch.zeros(B, C, int(n), dtype=torch.float32, device=grad_out.device)
+    _call("pn2_group_points_grad", grad_out, B, C, int(n), npoints, nsample,
+          _ptr(grad_out), _ptr(idx), _ptr(out))
+    return out
+
+
+def three_nn(unknowns, knows):
+    """(B,n,3), (B,m,3) -> [dist2 (B,n,3) f32, idx (B,n,3) i32].  EXT/src/interpolate.cpp:14-40."""
+    _f32(unknowns, "unknowns"); _f32(knows, "knows")
+    _same_device((unknowns, "unknowns"), (knows, "knows"))
+    B, n = unknowns.size(0), unknowns.size(1)
+    m = knows.size(1)
+    idx = torch.empty(B, n, 3, dtype=torch.int32, device=unknowns.device)
+    dist2 = torch.empty(B, n, 3, dtype=torch.float32, device=unknowns.device)
+    _call("pn2_three_nn", unknowns, B, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx))
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """(B,C,m), (B,n,3) i32, (B,n,3) -> (B,C,n).  EXT/src/interpolate.cpp:42-71."""
+    _f32(points, "points"); _i32(idx, "idx"); _f32(weight, "weight")
+    _same_device((points, "points"), (idx, "idx"), (weight, "weight"))
+    B, C, m = points.shape
+    n = idx.size(1)
+    out = torch.empty(B, C, n, dtype=torch.float32, device=points.device)
+    _call("pn2_three_interpolate", points, B, C, m, n, _ptr(points), _ptr(idx), _ptr(weight), _ptr(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """(B,C,n) -> (B,C,m).  EXT/src/interpolate.cpp:72-99."""
+    _f32(grad_out, "grad_out"); _i32(idx, "idx"); _f32(weight, "weight")
+    _same_device((grad_out, "grad_out"), (idx, "idx"), (weight, "weight"))
+    B, C, n = grad_out.shape
+    out = torch.zeros(B, C, int(m), dtype=torch.float32, device=grad_out.device)
+    _call("pn2_three_interpolate_grad", grad_out, B, C, n, int(m),
+          _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out))
+    return out
+
+
+# -------------------------------------------------- point-major extras (fast path)
+def group_concat_rows(xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius):
+    """xyz (B,N,3), new_xyz (B,m,3), feats_rows (B,N,C)|None, idx (B,m,ns) ->
+    (B,m,ns,Cx+C): relative (optionally radius-normalised) xyz ++ gathered features."""
+    _i32(idx, "idx")
+    B, m, ns = idx.shape
+    N = xyz.size(1)
+    C = 0
+    others = [(idx, "idx")]
+    if use_xyz:
+        _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
+        others += [(new_xyz, "new_xyz")]
+    if feats_rows is not None:
+        _f32(feats_rows, "features")
+        C = feats_rows.size(2)
+        others.append((feats_rows, "features"))
+    _same_device((xyz, "xyz"), *others)
+    W = (3 if use_xyz else 0) + C
+    out = torch.empty(B, m, ns, W, dtype=torch.float32, device=xyz.device)
+    _call("pn2_group_concat_rows", xyz, B, N, m, ns, C, int(bool(use_xyz)), int(bool(normalize)),
+          float(radius if radius is not None else 1.0), _ptr(xyz), _ptr(new_xyz), _ptr(feats_rows),
+          _ptr(idx), _ptr(out))
+    return out
+
+
+def group_rows_grad(grad_out, idx, n, c, col0):
+    """grad_out (B,m,ns,W) -> (B,n,c) gradient of the gathered feature columns."""
+    _f32(grad_out, "grad_out"); _i32(idx, "idx")
+    _same_device((grad_out, "grad_out"), (idx, "idx"))
+    B, m, ns, W = grad_out.shape
+    out = torch.zeros(B, int(n), int(c), dtype=torch.float32, device=grad_out.device)
+    _call("pn2_group_rows_grad", grad_out, B, int(n), m, ns, int(c), W, int(col0),
+          _ptr(grad_out), _ptr(idx), _ptr(out))
+    return out
+
+
+def rows_max(x):
+    """x (R,ns,C) -> (max (R,C), argmax (R,C) i32) over the ns axis."""
+    _f32(x, "x")
+    _same_device((x, "x"))
+    R, ns, C = x.shape
+    out = torch.empty(R, C, dtype=torch.float32, device=x.device)
+    arg = torch.empty(R, C, dtype=torch.int32, device=x.device)
+    _call("pn2_rows_max", x, R, ns, C, _ptr(x), _ptr(out), _ptr(arg))
+    return out, arg
+
+
+def rows_max_grad(grad_out, arg, ns):
+    _f32(grad_out, "grad_out"); _i32(arg, "arg")
+    _same_device((grad_out, "grad_out"), (arg, "arg"))
+    R, C = grad_out.shape
+    gx = torch.empty(R, int(ns), C, dtype=torch.float32, device=grad_out.device)
+    _call("pn2_rows_max_grad", grad_out, R, int(ns), C, _ptr(grad_out), _ptr(arg), _ptr(gx))
+    return gx
+
+
+def three_interpolate_rows(feats_rows, idx, weight, out=None, col0=0):
+    """feats_rows (B,m,C), idx/weight (B,n,3) -> out (B,n,ldo)[..., col0:col0+C]."""
+    _f32(feats_rows, "features"); _i32(idx, "idx"); _f32(weight, "weight")
+    _same_device((feats_rows, "features"), (idx, "idx"), (weight, "weight"))
+    B, m, C = feats_rows.shape
+    n = idx.size(1)
+    if out is None:
+        out = torch.empty(B, n, C, dtype=torch.float32, device=feats_rows.device)
+        col0 = 0
+    else:
+        _f32(out, "out")
+    _call("pn2_three_interpolate_rows", feats_rows, B, C, m, n, out.size(2), int(col0),
+          _ptr(feats_rows), _ptr(idx), _ptr(weight), _ptr(out))
+    return out
+
+
+def three_interpolate_rows_grad(grad_out, idx, weight, m, c, col0=0):
+    _f32(grad_out, "grad_out"); _i32(idx, "idx"); _f32(weight, "weight")
+    _same_device((grad_out, "grad_out"), (idx, "idx"), (weight, "weight"))
+    B, n, ldg = grad_out.shape
+    out = torch.zeros(B, int(m), int(c), dtype=torch.float32, device=grad_out.device)
+    _call("pn2_three_interpolate_rows_grad", grad_out, B, int(c), int(m), n, ldg, int(col0),
+          _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out))
+    return out
+
+
+# ------------------------------------------------------------ TripletGCN primitives
+def _check_index_range(index, n):
+    if index.numel() and (int(index.min()) < 0 or int(index.max()) >= n):
+        _fail("index out of range")
+
+
+def gather_rows(x, index, out=None, col0=0, check=True):
+    """x (N,H), index (E) i64 -> out (E,ldo)[:, col0:col0+H] (PyG __lift__)."""
+    _f32(x, "x"); _i64(index, "index")
+    _same_device((x, "x"), (index, "index"))
+    N, H = x.shape
+    E = index.numel()
+    if check:
+        _check_index_range(index, N)
+    if out is None:
+        out = torch.empty(E, H, dtype=torch.float32, device=x.device)
+        col0 = 0
+    else:
+        _f32(out, "out")
+    _call("pn2_gather_rows", x, E, H, N, out.size(1), int(col0), _ptr(x), _ptr(index), _ptr(out))
+    return out
+
+
+def scatter_add_rows(src, index, dim_size, h=None, col0=0, check=True):
+    """src (E,lds)[:, col0:col0+h], index (E) i64 -> (dim_size,h); fp32 atomics."""
+    _f32(src, "src"); _i64(index, "index")
+    _same_device((src, "src"), (index, "index"))
+    E, lds = src.shape
+    h = lds if h is None else int(h)
+    if check:
+        _check_index_range(index, int(dim_size))
+    out = torch.zeros(int(dim_size), h, dtype=torch.float32, device=src.device)
+    _call("pn2_scatter_add_rows", src, E, h, int(dim_size), lds, int(col0), _ptr(src), _ptr(index), _ptr(out))
+    return out
+
+
+def segment_sum_rows(src, order, rowptr, dim_size, h=None, col0=0):
+    """Deterministic scatter-add given a stable arg-sort `order` of the targets and
+    its CSR `rowptr` (dim_size+1)."""
+    _f32(src, "src"); _i64(order, "order"); _i64(rowptr, "rowptr")
+    _same_device((src, "src"), (order, "order"), (rowptr, "rowptr"))
+    E, lds = src.shape
+    h = lds if h is None else int(h)
+    out = torch.empty(int(dim_size), h, dtype=torch.float32, device=src.device)
+    _call("pn2_segment_sum_rows", src, E, h, int(dim_size), lds, int(col0),
+          _ptr(src), _ptr(order), _ptr(rowptr), _ptr(out))
+    return out

@@ -1,0 +1,210 @@
+"""Set-abstraction / feature-propagation modules of ``pointnet2_ops`` on MI355X.
+
+API mirror of OPS/pointnet2_modules.py (``build_shared_mlp`` :9-19,
+``_PointnetSAModuleBase`` :22-74, ``PointnetSAModuleMSG`` :77-115,
+``PointnetSAModule`` :118-146, ``PointnetFPModule`` :149-209): same constructor
+arguments, same parameter containers (``mlps.{i}.{0,1,3,4,...}`` Conv2d 1x1 +
+BatchNorm2d, so reference ``state_dict``s load strictly), same input/output
+shapes.  PointnetSAModuleMSG also reproduces the reference's in-place
+``mlp_spec[0] += 3`` side effect on the caller's list (:112-113).
+
+Two execution paths produce the same numbers (tests compare them):
+
+* literal  — the reference's staging: channel-major group -> Conv2d/BN2d/ReLU
+  -> max_pool2d.  Used when the fast path is switched off or coordinates
+  require gradients.
+* rows (default) — MI355X-first layout.  Features stay point-major
+  ``(B, N, C)`` between layers; the grouped tensor is written once as
+  ``(B*npoint*nsample, 3+C)`` rows by one fused HIP kernel; each 1x1 conv is a
+  plain ``rows @ W^T`` GEMM (K contiguous, MFMA friendly), BatchNorm runs on the
+  2-D rows tensor with the module's own running statistics, and the
+  neighbourhood max is one HIP kernel.  Module outputs are returned as
+  ``(B, C, npoint)`` *views* of the rows tensor, so the next module picks the
+  rows layout up again without a transpose copy.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pointnet2_ops import pointnet2_utils
+
+_FAST_PATH = True
+
+
+def set_fast_path(enabled: bool) -> bool:
+    """Switch the rows path on/off globally (returns the previous setting)."""
+    global _FAST_PATH
+    prev, _FAST_PATH = _FAST_PATH, bool(enabled)
+    return prev
+
+
+def fast_path_enabled() -> bool:
+    return _FAST_PATH
+
+
+def build_shared_mlp(mlp_spec: List[int], bn: bool = True):
+    """[c0, c1, ..., ck] -> Sequential(Conv2d 1x1 (bias iff no bn), [BatchNorm2d], ReLU) * k."""
+    stages = []
+    for c_in, c_out in zip(mlp_spec[:-1], mlp_spec[1:]):
+        stages.append(nn.Conv2d(c_in, c_out, kernel_size=1, bias=not bn))
+        if bn:
+            stages.append(nn.BatchNorm2d(c_out))
+        stages.append(nn.ReLU(True))
+    return nn.Sequential(*stages)
+
+
+def _batch_norm_rows(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor) -> torch.Tensor:
+    """BatchNorm over the rows of a (P, C) tensor with `bn`'s parameters and the
+    bookkeeping of torch's _BatchNorm.forward (momentum / cumulative average,
+    num_batches_tracked, batch statistics whenever running stats are absent)."""
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    use_batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
+    keep_running = bn.training or bn.track_running_stats
+    return F.batch_norm(x, bn.running_mean if keep_running else None,
+                        bn.running_var if keep_running else None,
+                        bn.weight, bn.bias, use_batch_stats, momentum, bn.eps)
+
+
+def shared_mlp_rows(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """Apply a `build_shared_mlp` stack (or any Conv2d-1x1/BN/ReLU sequence) to
+    point-major rows x (P, C_in) -> (P, C_out)."""
+    for layer in mlp:
+        if isinstance(layer, nn.Conv2d):
+            w = layer.weight.view(layer.out_channels, layer.in_channels)
+            x = F.linear(x, w, layer.bias)
+        elif isinstance(layer, nn.modules.batchnorm._BatchNorm):
+            x = _batch_norm_rows(layer, x)
+        elif isinstance(layer, nn.ReLU):
+            x = F.relu(x, inplace=layer.inplace)
+        elif isinstance(layer, nn.Sequential):
+            x = shared_mlp_rows(layer, x)
+        else:
+            raise TypeError(f"shared_mlp_rows: unsupported layer {type(layer).__name__}")
+    return x
+
+
+def _rows_path_ok(xyz: torch.Tensor, features: Optional[torch.Tensor]) -> bool:
+    if not _FAST_PATH or not getattr(pointnet2_utils._ext, "HAS_ROWS", False):
+        return False
+    if xyz.requires_grad:
+        return False  # coordinate gradients only exist on the literal path
+    return xyz.dtype == torch.float32 and (features is None or features.dtype == torch.float32)
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+
+    # -- centre selection (shared by both paths) ------------------------------
+    def _sample(self, xyz: torch.Tensor) -> Optional[torch.Tensor]:
+        if self.npoint is None:
+            return None
+        sel = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        picked = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), sel)
+        return picked.transpose(1, 2).contiguous()
+
+    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor]
+                ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+        """xyz (B,N,3), features (B,C,N)|None ->
+        (new_xyz (B,npoint,3)|None, new_features (B, sum_k mlps[k][-1], npoint))."""
+        new_xyz = self._sample(xyz)
+        if _rows_path_ok(xyz, features):
+            return new_xyz, self._forward_rows(xyz, new_xyz, features)
+
+        pooled = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            g = mlp(grouper(xyz, new_xyz, features))            # (B, C_out, npoint, nsample)
+            g = F.max_pool2d(g, kernel_size=[1, g.size(3)])     # (B, C_out, npoint, 1)
+            pooled.append(g.squeeze(-1))
+        return new_xyz, torch.cat(pooled, dim=1)
+
+    def _forward_rows(self, xyz, new_xyz, features):
+        feats_rows = pointnet2_utils.as_rows(features)
+        B = xyz.size(0)
+        pooled = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            g = grouper.forward_rows(xyz, new_xyz, feats_rows)  # (B, npoint, nsample, W)
+            _, npoint, nsample, width = g.shape
+            h = shared_mlp_rows(mlp, g.reshape(-1, width))      # (B*npoint*nsample, C_out)
+            pooled.append(pointnet2_utils.rows_max(h.view(B * npoint, nsample, -1)).view(B, npoint, -1))
+        rows = pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=2)
+        return pointnet2_utils.rows_to_channels(rows)           # (B, sum C_out, npoint) view
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """Multi-scale-grouping set abstraction: one (radius, nsample, mlp) per scale."""
+
+    def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True, normalize_xyz=False):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            if npoint is not None:
+                self.groupers.append(pointnet2_utils.QueryAndGroup(
+                    radius, nsample, use_xyz=use_xyz, normalize_xyz=normalize_xyz))
+            else:
+                self.groupers.append(pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                spec[0] += 3  # in place, like the reference: callers observe the mutation
+            self.mlps.append(build_shared_mlp(spec, bn))
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """Single-scale set abstraction; npoint=None groups the whole cloud."""
+
+    def __init__(self, mlp, npoint=None, radius=None, nsample=None, bn=True, use_xyz=True,
+                 normalize_xyz=False):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample],
+                         bn=bn, use_xyz=use_xyz, normalize_xyz=normalize_xyz)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: inverse-distance 3-NN interpolation + shared MLP."""
+
+    def __init__(self, mlp, bn=True):
+        super().__init__()
+        self.mlp = build_shared_mlp(mlp, bn=bn)
+
+    @staticmethod
+    def _weights(unknown, known):
+        dist, idx = pointnet2_utils.three_nn(unknown, known)
+        recip = 1.0 / (dist + 1e-8)
+        return idx, recip / torch.sum(recip, dim=2, keepdim=True)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        """unknown (B,n,3), known (B,m,3)|None, unknow_feats (B,C1,n)|None,
+        known_feats (B,C2,m) -> (B, mlp[-1], n)."""
+        if _rows_path_ok(unknown, known_feats) and (unknow_feats is None or unknow_feats.dtype == torch.float32):
+            return self._forward_rows(unknown, known, unknow_feats, known_feats)
+
+        if known is not None:
+            idx, weight = self._weights(unknown, known)
+            spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            spread = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))
+        stacked = spread if unknow_feats is None else torch.cat([spread, unknow_feats], dim=1)
+        return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
+
+    def _forward_rows(self, unknown, known, unknow_feats, known_feats):
+        B, n = unknown.size(0), unknown.size(1)
+        known_rows = pointnet2_utils.as_rows(known_feats)               # (B,m,C2)
+        if known is not None:
+            idx, weight = self._weights(unknown, known)
+            spread = pointnet2_utils.three_interpolate_rows(known_rows, idx, weight)
+        else:
+            spread = known_rows.expand(B, n, known_rows.size(2))
+        if unknow_feats is not None:
+            spread = torch.cat([spread, pointnet2_utils.as_rows(unknow_feats)], dim=2)
+        h = shared_mlp_rows(self.mlp, spread.reshape(B * n, -1))
+        return pointnet2_utils.rows_to_channels(h.view(B, n, -1))

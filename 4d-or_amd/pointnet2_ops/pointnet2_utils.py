@@ -1,0 +1,303 @@
+"""Operator layer of ``pointnet2_ops`` on MI355X.
+
+API mirror of the reference's OPS/pointnet2_utils.py (OPS =
+scene_graph_prediction/pointnet2_dir/pointnet2_ops_lib/pointnet2_ops): the six
+autograd functions and their functional aliases (``furthest_point_sample``,
+``gather_operation``, ``three_nn``, ``three_interpolate``,
+``grouping_operation``, ``ball_query``) and the ``QueryAndGroup`` / ``GroupAll``
+modules keep their names, argument order, tensor layouts and differentiability
+(:36-280, :283-383).  ``QueryAndGroup`` additionally accepts the keyword
+arguments of the Group-Free-3D copy (GF3D/pointnet2/pointnet2_utils.py:301-371:
+``ret_grouped_xyz``, ``normalize_xyz``; ``sample_uniformly`` is rejected).
+
+Everything numeric happens in ``_ext`` (libpn2_hip.so).  On top of the literal
+API this file adds the *point-major* ("rows") operators the SA/FP modules use
+on their fast path: the grouped tensor is produced directly as
+``(B, npoint, nsample, 3+C)`` rows by one kernel instead of two channel-major
+gathers, an in-place subtract and a ``torch.cat`` (OPS/pointnet2_utils.py:317-328
+stages four passes over the largest tensor of the network).
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from pointnet2_ops import _ext
+
+__all__ = [
+    "FurthestPointSampling", "furthest_point_sample", "GatherOperation", "gather_operation",
+    "ThreeNN", "three_nn", "ThreeInterpolate", "three_interpolate", "GroupingOperation",
+    "grouping_operation", "BallQuery", "ball_query", "QueryAndGroup", "GroupAll",
+    "group_concat_rows", "rows_max", "three_interpolate_rows", "as_rows", "rows_to_channels",
+]
+
+
+def _fp32(t):
+    """GroupingOperation runs in fp32 even under autocast
+    (reference: @custom_fwd(cast_inputs=torch.float32), OPS/pointnet2_utils.py:198)."""
+    return t if t.dtype == torch.float32 else t.float()
+
+
+# ----------------------------------------------------------------- sampling
+class FurthestPointSampling(Function):
+    """xyz (B,N,3) -> (B,npoint) int32 indices; not differentiable."""
+
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        sel = _ext.furthest_point_sampling(xyz, npoint)
+        ctx.mark_non_differentiable(sel)
+        return sel
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ()
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    """features (B,C,N), idx (B,npoint) -> (B,C,npoint)."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.n_src = features.size(2)
+        return _ext.gather_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.gather_points_grad(grad_out.contiguous(), idx, ctx.n_src), None
+
+
+gather_operation = GatherOperation.apply
+
+
+# ------------------------------------------------------------ interpolation
+class ThreeNN(Function):
+    """unknown (B,n,3), known (B,m,3) -> (dist (B,n,3) euclidean, idx (B,n,3) int32)."""
+
+    @staticmethod
+    def forward(ctx, unknown, known):
+        dist2, idx = _ext.three_nn(unknown, known)
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(dist, idx)
+        return dist, idx
+
+    @staticmethod
+    def backward(ctx, grad_dist, grad_idx):
+        return ()
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """features (B,c,m), idx (B,n,3), weight (B,n,3) -> (B,c,n)."""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        ctx.save_for_backward(idx, weight)
+        ctx.m_src = features.size(2)
+        return _ext.three_interpolate(features, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        g = _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m_src)
+        return g, torch.zeros_like(idx), torch.zeros_like(weight)
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+# ----------------------------------------------------------------- grouping
+class GroupingOperation(Function):
+    """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        features = _fp32(features)
+        ctx.save_for_backward(idx)
+        ctx.n_src = features.size(2)
+        return _ext.group_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        g = _ext.group_points_grad(_fp32(grad_out).contiguous(), idx, ctx.n_src)
+        return g, torch.zeros_like(idx)
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    """(radius, nsample, xyz (B,N,3), new_xyz (B,npoint,3)) -> (B,npoint,nsample) int32.
+    Note the python argument order differs from the native one
+    (OPS/pointnet2_utils.py:249,269 vs EXT/include/ball_query.h:4)."""
+
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        idx = _ext.ball_query(new_xyz, xyz, radius, nsample)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ()
+
+
+ball_query = BallQuery.apply
+
+
+# ---------------------------------------------------- point-major ("rows") ops
+def as_rows(features: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """(B,C,N) -> contiguous (B,N,C).  Zero-copy when `features` is already a
+    transposed view of a rows tensor (which is what the fast-path modules emit)."""
+    if features is None:
+        return None
+    return features.transpose(1, 2).contiguous()
+
+
+def rows_to_channels(rows: torch.Tensor) -> torch.Tensor:
+    """(B,N,C) rows -> (B,C,N) view with the reference's logical layout."""
+    return rows.transpose(1, 2)
+
+
+class _GroupConcatRows(Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius):
+        ctx.save_for_backward(idx)
+        ctx.n_src = xyz.size(1)
+        ctx.c = 0 if feats_rows is None else feats_rows.size(2)
+        ctx.col0 = 3 if use_xyz else 0
+        return _ext.group_concat_rows(xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        g = None
+        if ctx.c and ctx.needs_input_grad[2]:
+            g = _ext.group_rows_grad(grad_out.contiguous(), idx, ctx.n_src, ctx.c, ctx.col0)
+        return None, None, g, None, None, None, None
+
+
+def group_concat_rows(xyz, new_xyz, feats_rows, idx, use_xyz=True, normalize=False, radius=None):
+    """Fused QueryAndGroup tail: -> (B,npoint,nsample,[3+]C) rows.  Gradients flow
+    to `feats_rows` only (callers route coordinates that need grad to the literal path)."""
+    return _GroupConcatRows.apply(xyz, new_xyz, feats_rows, idx, bool(use_xyz), bool(normalize), radius)
+
+
+class _RowsMax(Function):
+    @staticmethod
+    def forward(ctx, x):
+        out, arg = _ext.rows_max(x)
+        ctx.save_for_backward(arg)
+        ctx.ns = x.size(1)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_arg):
+        (arg,) = ctx.saved_tensors
+        return _ext.rows_max_grad(grad_out.contiguous(), arg, ctx.ns)
+
+
+def rows_max(x: torch.Tensor) -> torch.Tensor:
+    """x (R,ns,C) -> (R,C): the max over each neighbourhood
+    (F.max_pool2d(kernel=[1,ns]) of OPS/pointnet2_modules.py:67-70)."""
+    return _RowsMax.apply(x.contiguous())[0]
+
+
+class _ThreeInterpolateRows(Function):
+    @staticmethod
+    def forward(ctx, feats_rows, idx, weight):
+        ctx.save_for_backward(idx, weight)
+        ctx.m_src, ctx.c = feats_rows.size(1), feats_rows.size(2)
+        return _ext.three_interpolate_rows(feats_rows, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        g = _ext.three_interpolate_rows_grad(grad_out.contiguous(), idx, weight, ctx.m_src, ctx.c)
+        return g, None, None
+
+
+def three_interpolate_rows(feats_rows, idx, weight):
+    """feats_rows (B,m,C), idx/weight (B,n,3) -> (B,n,C)."""
+    return _ThreeInterpolateRows.apply(feats_rows.contiguous(), idx, weight)
+
+
+# ------------------------------------------------------------------- modules
+class QueryAndGroup(nn.Module):
+    """Ball query + grouping around each centre.
+
+    forward(xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N) | None)
+        -> (B, 3+C, npoint, nsample)           [+ grouped_xyz when ret_grouped_xyz]
+    """
+
+    def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False,
+                 normalize_xyz=False, sample_uniformly=False, ret_unique_cnt=False):
+        super().__init__()
+        if sample_uniformly or ret_unique_cnt:
+            raise NotImplementedError(
+                "sample_uniformly / ret_unique_cnt (host-side torch.unique resampling in "
+                "GF3D/pointnet2/pointnet2_utils.py:327-336) are not on the 4D-OR hot path")
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+        self.ret_grouped_xyz = ret_grouped_xyz
+        self.normalize_xyz = normalize_xyz
+
+    def query(self, xyz, new_xyz):
+        return ball_query(self.radius, self.nsample, xyz, new_xyz)
+
+    def forward(self, xyz, new_xyz, features=None):
+        idx = self.query(xyz, new_xyz)
+        centres = new_xyz.transpose(1, 2).unsqueeze(-1)
+        rel = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+        rel -= centres
+        if self.normalize_xyz:
+            rel /= self.radius
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            grouped = rel
+        else:
+            picked = grouping_operation(features, idx)
+            grouped = torch.cat([rel, picked], dim=1) if self.use_xyz else picked
+        return (grouped, rel) if self.ret_grouped_xyz else grouped
+
+    def forward_rows(self, xyz, new_xyz, feats_rows=None):
+        """Fast path: (B,npoint,nsample,[3+]C) rows in one fused kernel."""
+        if feats_rows is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+        idx = self.query(xyz, new_xyz)
+        return group_concat_rows(xyz, new_xyz, feats_rows, idx, self.use_xyz,
+                                 self.normalize_xyz, self.radius)
+
+
+class GroupAll(nn.Module):
+    """The whole cloud as a single group: -> (B, 3+C, 1, N)."""
+
+    def __init__(self, use_xyz=True, ret_grouped_xyz=False):
+        super().__init__()
+        self.use_xyz = use_xyz
+        self.ret_grouped_xyz = ret_grouped_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        whole = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            grouped = whole
+        else:
+            f = features.unsqueeze(2)
+            grouped = torch.cat([whole, f], dim=1) if self.use_xyz else f
+        return (grouped, whole) if self.ret_grouped_xyz else grouped
+
+    def forward_rows(self, xyz, new_xyz, feats_rows=None):
+        """-> (B,1,N,[3+]C) rows."""
+        if feats_rows is None:
+            rows = xyz
+        else:
+            rows = torch.cat([xyz, feats_rows], dim=2) if self.use_xyz else feats_rows
+        return rows.unsqueeze(1)

@@ -1,0 +1,198 @@
+/*
+ * pn2_hip.h — C ABI of libpn2_hip.so, the MI355X (gfx950) implementation of
+ * 4D-OR's scene-graph-prediction hot path.
+ *
+ * This is the drop-in boundary: one extern "C" entry point per
+ * function of the reference's pybind11 module `pointnet2_ops._ext`
+ *   EXT = scene_graph_prediction/pointnet2_dir/pointnet2_ops_lib/pointnet2_ops/_ext-src
+ *   EXT/src/bindings.cpp:6-19  (nine m.def's)
+ * plus the fused / TripletGCN extras that have no native counterpart in the
+ * reference (they replace python-level compositions; cited per function).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer on the
+ *     current HIP device; tensors are dense row-major in the stated shape;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); work
+ *     is enqueued asynchronously, no host synchronisation, no allocation, no
+ *     global state => re-entrant per stream (same threading contract as the
+ *     reference, which launches on at::cuda::getCurrentCUDAStream());
+ *   - outputs are fully written by the kernels unless stated "ACCUMULATES"
+ *     (then the caller zero-fills first, like the reference's torch::zeros);
+ *   - return 0 on success, a negative PN2_E* code otherwise.  Never exits the
+ *     process (the reference's CUDA_CHECK_ERRORS does exit(-1),
+ *     EXT/include/cuda_utils.h:30-39 — deliberately not reproduced).
+ */
+#ifndef PN2_HIP_H
+#define PN2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* the library is built with -fvisibility=hidden; only this header's API is exported */
+#pragma GCC visibility push(default)
+
+#define PN2_OK 0
+#define PN2_EINVAL (-1)   /* bad size / argument combination            */
+#define PN2_ENULL (-2)    /* required pointer is NULL                   */
+#define PN2_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after launch */
+#define PN2_ENOSPC (-4)   /* workspace too small                        */
+
+/* Library identification; pn2_strerror never returns NULL. */
+int pn2_abi_version(void);
+const char *pn2_strerror(int code);
+/* Last hipError_t observed by a failing launch on this thread (0 if none). */
+int pn2_last_hip_error(void);
+
+/* ------------------------------------------------------------------ A5 ---
+ * furthest_point_sampling   (EXT/include/sampling.h:6,
+ *   EXT/src/sampling.cpp:66-87, EXT/src/sampling_gpu.cu:69-229)
+ * xyz (B,N,3) f32 -> idxs (B,m) i32.  Bit-exact with the reference kernel's
+ * selection rule: start at 0; points with |p|^2 <= 1e-3 never selected;
+ * arg-max of the running min distance with the reference's tree tie-break.
+ * `workspace` replaces the reference's internal `tmp(B,N)=1e10` scratch: it
+ * must hold pn2_fps_workspace_bytes(B,N,m) bytes (may be 0 -> NULL allowed);
+ * it needs no initialisation.
+ */
+size_t pn2_fps_workspace_bytes(int B, int N, int m);
+int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz,
+                                void *workspace, size_t workspace_bytes,
+                                int *idxs, void *stream);
+
+/* ------------------------------------------------------------------ A6 ---
+ * gather_points / gather_points_grad  (EXT/include/sampling.h:4-5,
+ *   EXT/src/sampling.cpp:15-65, EXT/src/sampling_gpu.cu:8-57)
+ * points (B,C,N), idx (B,m) -> out (B,C,m).
+ * grad: grad_out (B,C,m), idx (B,m) -> grad_points (B,C,N)  ACCUMULATES.
+ */
+int pn2_gather_points(int B, int C, int N, int m, const float *points,
+                      const int *idx, float *out, void *stream);
+int pn2_gather_points_grad(int B, int C, int N, int m, const float *grad_out,
+                           const int *idx, float *grad_points, void *stream);
+
+/* ------------------------------------------------------------------ A7 ---
+ * ball_query  (EXT/include/ball_query.h:4, EXT/src/ball_query.cpp:8-32,
+ *   EXT/src/ball_query_gpu.cu:9-54).  Argument order follows the C++ function:
+ * new_xyz (B,m,3), xyz (B,N,3) -> idx (B,m,nsample) i32: the first `nsample`
+ * points in ascending index with d^2 < radius^2 (strict, fp32), padded with
+ * the first hit; an empty ball yields a zero row.  Every slot is written.
+ */
+int pn2_ball_query(int B, int N, int m, float radius, int nsample,
+                   const float *new_xyz, const float *xyz, int *idx,
+                   void *stream);
+
+/* ------------------------------------------------------------------ A8 ---
+ * group_points / group_points_grad  (EXT/include/group_points.h:4-5,
+ *   EXT/src/group_points.cpp:12-62, EXT/src/group_points_gpu.cu:8-75)
+ * points (B,C,N), idx (B,npoints,nsample) -> out (B,C,npoints,nsample).
+ * grad: grad_out (B,C,npoints,nsample) -> grad_points (B,C,N)  ACCUMULATES.
+ */
+int pn2_group_points(int B, int C, int N, int npoints, int nsample,
+                     const float *points, const int *idx, float *out,
+                     void *stream);
+int pn2_group_points_grad(int B, int C, int N, int npoints, int nsample,
+                          const float *grad_out, const int *idx,
+                          float *grad_points, void *stream);
+
+/* ----------------------------------------------------------------- A11 ---
+ * three_nn / three_interpolate / three_interpolate_grad
+ *   (EXT/include/interpolate.h:6-10, EXT/src/interpolate.cpp:14-99,
+ *    EXT/src/interpolate_gpu.cu:9-154)
+ * three_nn: unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) f32 (SQUARED
+ *   distances, ascending), idx (B,n,3) i32; strict '<' => earliest index wins.
+ * three_interpolate: points (B,C,m), idx (B,n,3), weight (B,n,3) -> out (B,C,n).
+ * grad: grad_out (B,C,n) -> grad_points (B,C,m)  ACCUMULATES.
+ */
+int pn2_three_nn(int B, int n, int m, const float *unknown, const float *known,
+                 float *dist2, int *idx, void *stream);
+int pn2_three_interpolate(int B, int C, int m, int n, const float *points,
+                          const int *idx, const float *weight, float *out,
+                          void *stream);
+int pn2_three_interpolate_grad(int B, int C, int n, int m,
+                               const float *grad_out, const int *idx,
+                               const float *weight, float *grad_points,
+                               void *stream);
+
+/* ---------------------------------------------------------- fused extras ---
+ * Point-major ("channels-last") layout extras used by the fast path.  They
+ * replace python-level compositions of the reference and have no native
+ * counterpart there.
+ *
+ * pn2_group_concat_rows: the whole of QueryAndGroup.forward after the ball
+ *   query (OPS/pointnet2_utils.py:317-335 and, with `normalize` != 0, the
+ *   `grouped_xyz /= radius` of GF3D/pointnet2/pointnet2_utils.py:343-344) in
+ *   one pass:  out[b,j,s,0:3]   = (xyz[b,idx[b,j,s]] - new_xyz[b,j]) (/ radius)
+ *              out[b,j,s,3:3+C] = feats[b,idx[b,j,s],0:C]
+ *   xyz (B,N,3); new_xyz (B,m,3); feats (B,N,C) point-major or NULL (C=0);
+ *   idx (B,m,ns); out (B,m,ns,Cx+C) with Cx = use_xyz ? 3 : 0.
+ *   `normalize` != 0 divides the relative xyz by `radius` (IEEE division).
+ * pn2_group_rows_grad: gradient of the feature part:
+ *   grad_out (B,m,ns,ldg) rows, columns [col0, col0+C) -> grad_feats (B,N,C)
+ *   ACCUMULATES (fp32 atomics; tolerance-tested, not bitwise).
+ */
+int pn2_group_concat_rows(int B, int N, int m, int ns, int C, int use_xyz,
+                          int normalize, float radius, const float *xyz,
+                          const float *new_xyz, const float *feats,
+                          const int *idx, float *out, void *stream);
+int pn2_group_rows_grad(int B, int N, int m, int ns, int C, int ldg, int col0,
+                        const float *grad_out, const int *idx,
+                        float *grad_feats, void *stream);
+
+/* pn2_rows_max / pn2_rows_max_grad: F.max_pool2d(kernel=[1,ns]) of
+ *   OPS/pointnet2_modules.py:67-70 in point-major layout.
+ *   x (R,ns,C) -> out (R,C), arg (R,C) i32 (first maximal s, like torch's
+ *   max_pool2d argmax);  grad: grad_out (R,C), arg -> grad_x (R,ns,C), every
+ *   element written (zeros elsewhere).
+ */
+int pn2_rows_max(int64_t R, int ns, int C, const float *x, float *out,
+                 int *arg, void *stream);
+int pn2_rows_max_grad(int64_t R, int ns, int C, const float *grad_out,
+                      const int *arg, float *grad_x, void *stream);
+
+/* pn2_three_interpolate_rows / _grad: three_interpolate in point-major layout.
+ *   feats (B,m,C), idx (B,n,3), weight (B,n,3) -> out (B,n,ldo) columns
+ *   [col0, col0+C) (so the caller can write straight into the concat buffer of
+ *   OPS/pointnet2_modules.py:195-198).  grad ACCUMULATES into (B,m,C).
+ */
+int pn2_three_interpolate_rows(int B, int C, int m, int n, int ldo, int col0,
+                               const float *feats, const int *idx,
+                               const float *weight, float *out, void *stream);
+int pn2_three_interpolate_rows_grad(int B, int C, int m, int n, int ldg,
+                                    int col0, const float *grad_out,
+                                    const int *idx, const float *weight,
+                                    float *grad_feats, void *stream);
+
+/* ------------------------------------------------------------------ A12 ---
+ * TripletGCN edge primitives.  Replace torch_geometric 2.0.2
+ * MessagePassing.__lift__ (x.index_select(-2, edge_index[i])) and
+ * torch_scatter 2.0.9 scatter(reduce='add'); call sites
+ * scene_graph_prediction/scene_graph_helpers/model/gcns/network_TripletGCN.py:41,57.
+ *
+ * pn2_gather_rows: x (N,H), index (E) i64 -> out (E,ldo) columns
+ *   [col0,col0+H)  (lets the caller build cat[x_i, e, x_j] in place, :46).
+ * pn2_scatter_add_rows: src (E,lds) columns [col0,col0+H), index (E) i64 ->
+ *   out (N,H)  ACCUMULATES with fp32 atomics (order-nondeterministic).
+ * pn2_segment_sum_rows: deterministic alternative: `order` (E) i64 is a STABLE
+ *   arg-sort of `index`, `rowptr` (N+1) i64 its CSR offsets;
+ *   out[n] = sum over e in order[rowptr[n]:rowptr[n+1]] of src[e] taken in that
+ *   (= original edge) order, i.e. bit-identical to a sequential CPU
+ *   scatter_add_.  Every row of out is written.
+ * Indices out of [0,N) are the caller's error (checked on the python side).
+ */
+int pn2_gather_rows(int64_t E, int H, int64_t N, int ldo, int col0,
+                    const float *x, const int64_t *index, float *out,
+                    void *stream);
+int pn2_scatter_add_rows(int64_t E, int H, int64_t N, int lds, int col0,
+                         const float *src, const int64_t *index, float *out,
+                         void *stream);
+int pn2_segment_sum_rows(int64_t E, int H, int64_t N, int lds, int col0,
+                         const float *src, const int64_t *order,
+                         const int64_t *rowptr, float *out, void *stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* PN2_HIP_H */

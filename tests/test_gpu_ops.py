@@ -1,0 +1,174 @@
+"""GPU parity: every C-ABI entry point of libpn2_hip.so against the CPU oracle on
+the same seeded inputs.  Index outputs bit-exact; fp32 values bit-exact where the
+arithmetic is a single pinned expression, 1e-4 where atomics reorder sums."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_ext
+from test_oracle_vs_naive import cloud
+
+pytestmark = pytest.mark.gpu
+O = oracle_ext.OracleRowsExt
+
+
+@pytest.fixture(scope="module")
+def ext():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from pointnet2_ops import _ext
+    return _ext
+
+
+def dev(t):
+    return t.cuda()
+
+
+def clouds(B, N, kind, seed):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(np.stack([cloud(rng, N, kind) for _ in range(B)]))
+
+
+# every resident-kernel template, the streaming kernel, tiny and non-power-of-two sizes
+FPS_CASES = [(3, 1, 1), (2, 5, 5), (2, 37, 40), (3, 100, 30), (2, 255, 64), (2, 256, 64), (2, 511, 100),
+             (3, 512, 128), (2, 1000, 128), (2, 1024, 256), (2, 2048, 512), (2, 4000, 512), (2, 4096, 64),
+             (2, 8000, 512), (1, 16384, 300), (1, 20000, 256), (1, 24576, 64), (2, 30000, 200)]
+
+
+@pytest.mark.parametrize("B,N,m", FPS_CASES)
+@pytest.mark.parametrize("kind", ["uniform", "dup", "zero_tail", "grid"])
+def test_fps_bit_exact(ext, B, N, m, kind):
+    xyz = clouds(B, N, kind, seed=N * 31 + m)
+    want = O.furthest_point_sampling(xyz, m)
+    got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    assert torch.equal(got, want)
+
+
+def test_fps_all_skipped_and_m_zero(ext):
+    xyz = torch.full((2, 700, 3), 0.001)
+    assert torch.equal(ext.furthest_point_sampling(dev(xyz), 5).cpu(), torch.zeros(2, 5, dtype=torch.int32))
+    assert ext.furthest_point_sampling(dev(xyz), 0).shape == (2, 0)
+
+
+BQ_CASES = [(2, 50, 7, 4, 0.5), (3, 300, 33, 16, 0.3), (2, 1000, 128, 64, 0.4), (2, 4000, 512, 32, 0.2),
+            (1, 513, 5, 128, 0.9), (2, 64, 64, 2, 0.01), (2, 2048, 1024, 32, 0.4), (40, 700, 300, 16, 0.25)]
+
+
+@pytest.mark.parametrize("B,N,m,ns,r", BQ_CASES)
+@pytest.mark.parametrize("kind", ["uniform", "dup", "grid"])
+def test_ball_query_bit_exact(ext, B, N, m, ns, r, kind):
+    xyz = clouds(B, N, kind, seed=N + m)
+    sel = torch.from_numpy(np.random.default_rng(5).integers(0, N, size=(B, m)))
+    new_xyz = xyz[torch.arange(B)[:, None], sel].contiguous()
+    if kind == "uniform":
+        new_xyz = clouds(B, m, "uniform", seed=99)        # centres that are not cloud points
+    want = O.ball_query(new_xyz, xyz, r, ns)
+    got = ext.ball_query(dev(new_xyz), dev(xyz), r, ns).cpu()
+    assert torch.equal(got, want)
+
+
+def test_ball_query_empty_ball_rows_are_zero(ext):
+    xyz = torch.rand(2, 100, 3)
+    new_xyz = torch.full((2, 9, 3), 50.0)
+    assert int(ext.ball_query(dev(new_xyz), dev(xyz), 0.1, 8).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B,C,N,m,ns", [(2, 3, 100, 10, 4), (3, 7, 500, 64, 16), (2, 131, 300, 40, 8)])
+def test_group_and_gather(ext, B, C, N, m, ns):
+    g = torch.Generator().manual_seed(B * C)
+    pts = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    assert torch.equal(ext.group_points(dev(pts), dev(idx)).cpu(), O.group_points(pts, idx))
+    go = torch.randn(B, C, m, ns, generator=g)
+    torch.testing.assert_close(ext.group_points_grad(dev(go), dev(idx), N).cpu(),
+                               O.group_points_grad(go, idx, N), atol=1e-4, rtol=1e-4)
+    gi = torch.randint(0, N, (B, m), generator=g, dtype=torch.int32)
+    assert torch.equal(ext.gather_points(dev(pts), dev(gi)).cpu(), O.gather_points(pts, gi))
+    gg = torch.randn(B, C, m, generator=g)
+    torch.testing.assert_close(ext.gather_points_grad(dev(gg), dev(gi), N).cpu(),
+                               O.gather_points_grad(gg, gi, N), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,n,m", [(2, 9, 1), (2, 20, 2), (3, 300, 3), (2, 1024, 512), (2, 700, 2500)])
+@pytest.mark.parametrize("kind", ["uniform", "grid"])
+def test_three_nn_bit_exact(ext, B, n, m, kind):
+    u, k = clouds(B, n, kind, seed=n), clouds(B, m, kind, seed=m + 1)
+    d2w, iw = O.three_nn(u, k)
+    d2, idx = ext.three_nn(dev(u), dev(k))
+    assert torch.equal(idx.cpu(), iw)
+    assert torch.equal(d2.cpu(), d2w)
+
+
+@pytest.mark.parametrize("B,C,m,n", [(1, 2, 4, 2), (2, 16, 50, 120), (2, 256, 256, 512)])
+def test_three_interpolate(ext, B, C, m, n):
+    g = torch.Generator().manual_seed(C)
+    pts = torch.randn(B, C, m, generator=g)
+    idx = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32)
+    w = torch.rand(B, n, 3, generator=g)
+    assert torch.equal(ext.three_interpolate(dev(pts), dev(idx), dev(w)).cpu(), O.three_interpolate(pts, idx, w))
+    go = torch.randn(B, C, n, generator=g)
+    torch.testing.assert_close(ext.three_interpolate_grad(dev(go), dev(idx), dev(w), m).cpu(),
+                               O.three_interpolate_grad(go, idx, w, m), atol=1e-4, rtol=1e-4)
+    rows = pts.transpose(1, 2).contiguous()
+    got = ext.three_interpolate_rows(dev(rows), dev(idx), dev(w)).cpu()
+    assert torch.equal(got, O.three_interpolate_rows(rows, idx, w))
+    gr = go.transpose(1, 2).contiguous()
+    torch.testing.assert_close(ext.three_interpolate_rows_grad(dev(gr), dev(idx), dev(w), m, C).cpu(),
+                               O.three_interpolate_rows_grad(gr, idx, w, m, C), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,N,m,ns,C", [(2, 100, 10, 4, 3), (2, 400, 50, 16, 0), (3, 300, 20, 8, 128)])
+@pytest.mark.parametrize("use_xyz,normalize", [(True, False), (True, True), (False, False)])
+def test_group_concat_rows(ext, B, N, m, ns, C, use_xyz, normalize):
+    if C == 0 and not use_xyz:
+        pytest.skip("no channels")
+    g = torch.Generator().manual_seed(N)
+    xyz = torch.rand(B, N, 3, generator=g)
+    new_xyz = torch.rand(B, m, 3, generator=g)
+    feats = torch.randn(B, N, C, generator=g) if C else None
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    want = O.group_concat_rows(xyz, new_xyz, feats, idx, use_xyz, normalize, 0.2)
+    got = ext.group_concat_rows(dev(xyz), dev(new_xyz), None if feats is None else dev(feats), dev(idx),
+                                use_xyz, normalize, 0.2).cpu()
+    assert torch.equal(got, want)
+    if C:
+        go = torch.randn(*want.shape, generator=g)
+        col0 = 3 if use_xyz else 0
+        torch.testing.assert_close(ext.group_rows_grad(dev(go), dev(idx), N, C, col0).cpu(),
+                                   O.group_rows_grad(go, idx, N, C, col0), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("R,ns,C", [(5, 1, 3), (100, 16, 64), (33, 64, 131)])
+def test_rows_max(ext, R, ns, C):
+    g = torch.Generator().manual_seed(R)
+    x = torch.randn(R, ns, C, generator=g).round(decimals=1)      # plenty of ties
+    out, arg = ext.rows_max(dev(x))
+    wo, wa = O.rows_max(x)
+    assert torch.equal(out.cpu(), wo) and torch.equal(arg.cpu(), wa)
+    go = torch.randn(R, C, generator=g)
+    assert torch.equal(ext.rows_max_grad(dev(go), arg, ns).cpu(), O.rows_max_grad(go, wa, ns))
+
+
+@pytest.mark.parametrize("N,E,H", [(3, 3, 2), (9, 72, 256), (576, 4608, 512)])
+def test_gcn_rows(ext, N, E, H):
+    g = torch.Generator().manual_seed(E)
+    x = torch.randn(N, H, generator=g)
+    index = torch.randint(0, N, (E,), generator=g)
+    assert torch.equal(ext.gather_rows(dev(x), dev(index)).cpu(), O.gather_rows(x, index))
+    src = torch.randn(E, H, generator=g)
+    want = O.scatter_add_rows(src, index, N)
+    torch.testing.assert_close(ext.scatter_add_rows(dev(src), dev(index), N).cpu(), want, atol=1e-4, rtol=1e-4)
+    order = torch.sort(index, stable=True).indices
+    rowptr = torch.zeros(N + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(index, minlength=N), 0)
+    got = ext.segment_sum_rows(dev(src), dev(order), dev(rowptr), N).cpu()
+    assert torch.equal(got, want)                                  # deterministic == sequential CPU order
+    wide = torch.zeros(E, 3 * H + 5)
+    ext_out = ext.gather_rows(dev(x), dev(index), out=dev(wide), col0=H + 5).cpu()
+    assert torch.equal(ext_out[:, H + 5:2 * H + 5], O.gather_rows(x, index)) and ext_out[:, :H + 5].abs().sum() == 0
+
+
+def test_errors_are_exceptions_not_exits(ext):
+    with pytest.raises(RuntimeError):
+        ext.gather_rows(dev(torch.zeros(3, 4)), dev(torch.tensor([0, 7])))     # index out of range
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ext.three_nn(torch.zeros(1, 2, 3), torch.zeros(1, 2, 3))
