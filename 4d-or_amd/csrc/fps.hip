@@ -6,7 +6,7 @@
 //  * The reference streams xyz + temp from memory every round with one
 //    512-thread block per cloud.  Here a cloud's points live in VGPRs for the
 //    whole kernel (xyz + running min distance = 4 registers per point, up to
-//    24 points per lane x 1024 lanes), so a round is pure VALU + one wave64 DPP
+//    24 points per lane x 1024 lanes, or a cluster of workgroups per cloud), so a round is pure VALU + one wave64 DPP
 //    reduction + one LDS exchange + ONE barrier.
 //  * The reference's shared-memory tree (:115-166) breaks ties by tree shape.
 //    We reduce a 64-bit totally ordered key instead,
@@ -23,6 +23,10 @@
 //  * Clouds too large for the register file use the streaming kernel with the
 //    running distances in a caller-provided workspace.
 #include "pn2_common.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -213,6 +217,167 @@ __global__ __launch_bounds__(BS) void fps_stream_kernel(int N, int m, int L,
   }
 }
 
+
+// ---- cooperative kernel: G workgroups per cloud, points still register-resident ----
+// A 50k-point cloud does not fit one workgroup's registers, and a batch of 32
+// clouds would leave 224 of the 256 CUs idle anyway.  A cluster of G workgroups
+// (G*B <= 256 so that every workgroup is resident) shares one cloud: workgroup g,
+// thread t owns points k = g*BS + t + i*G*BS (same reference tid for all of a
+// thread's points, ascending k).  Per round each workgroup reduces its own slice
+// exactly like the resident kernel, then wave 0 publishes (packed, x, y, z) as
+// five 8-byte {round, value} granules written with ONE agent-scope store each and
+// sweeps the cluster's granules until every tag equals the round (the data is the
+// flag; placement-independent; MI355X_MICROARCH "handoff" recipe R2).  Slots are
+// double-buffered by round parity and zeroed by a memset node before every
+// launch; spins are bounded and raise `status` instead of hanging the GPU.
+typedef __attribute__((address_space(1))) u64 gu64;
+
+constexpr int kCoopMaxG = 32;
+constexpr int kCoopFields = 5;                                      // hi, lo, x, y, z
+constexpr size_t kCoopCloudBytes = 2ull * kCoopFields * kCoopMaxG * sizeof(u64);
+constexpr unsigned kCoopSpinLimit = 1u << 22;
+
+__device__ __forceinline__ void coop_store(u64 *p, u64 v) {
+  __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 coop_load(const u64 *p) {
+  return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct __attribute__((aligned(16))) FpsFinal {
+  float x, y, z;
+  int k;
+  int abort;
+  int pad[3];
+};
+
+template <int BS, int PPT>
+__global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L, int G,
+                                                     const float *__restrict__ xyz,
+                                                     int *__restrict__ idxs,
+                                                     u64 *__restrict__ slots,
+                                                     int *__restrict__ status) {
+  constexpr int NW = BS / 64;
+  __shared__ FpsSlot lds_slots[2][16];
+  __shared__ unsigned lds_vals[kCoopFields][kCoopMaxG];
+  __shared__ FpsFinal lds_fin[2];
+
+  const int b = blockIdx.x % B;   // a cluster's workgroups share blockIdx % 8 (one XCD) when B % 8 == 0
+  const int g = blockIdx.x / B;
+  const int t = threadIdx.x;
+  const int lane = pn2_lane();
+  const int wave = t >> 6;
+  const float *P = xyz + (size_t)b * N * 3;
+  int *out = idxs + (size_t)b * m;
+  u64 *cs = slots + (size_t)b * (2 * kCoopFields * kCoopMaxG);
+
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  const int k0 = g * BS + t;
+  const int kstride = G * BS;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = k0 + i * kstride;
+    float x = 0.f, y = 0.f, z = 0.f;
+    bool valid = false;
+    if (k < N) {
+      x = P[(size_t)k * 3 + 0];
+      y = P[(size_t)k * 3 + 1];
+      z = P[(size_t)k * 3 + 2];
+      const float mag = pn2_sq3(x, y, z);
+      valid = !((double)mag <= 1e-3);
+    }
+    px[i] = x; py[i] = y; pz[i] = z;
+    td[i] = valid ? 1e10f : -1.f;
+  }
+
+  const float p0x = P[0], p0y = P[1], p0z = P[2];
+  float ox = p0x, oy = p0y, oz = p0z;
+  if (g == 0 && t == 0) out[0] = 0;
+
+  for (int j = 1; j < m; ++j) {
+    float best = -1.f;
+    int bi = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = pn2_sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
+      const float d2 = fps_min(d, td[i]);
+      td[i] = d2;
+      if (d2 > best) { best = d2; bi = i; }
+    }
+    u64 pk = 0ull;
+    if (best >= 0.f) pk = fps_pack(best, (unsigned)(k0 + bi * kstride), L);
+    const u64 wmax = pn2_wave_max_u64(pk);
+
+    float sx = p0x, sy = p0y, sz = p0z;
+    bool writer;
+    if (wmax == 0ull) {
+      writer = (lane == 0);
+    } else {
+      writer = (pk == wmax);
+      if (writer) {
+        sx = px[0]; sy = py[0]; sz = pz[0];
+#pragma unroll
+        for (int i = 1; i < PPT; ++i) {
+          if (bi == i) { sx = px[i]; sy = py[i]; sz = pz[i]; }
+        }
+      }
+    }
+    float bx, by, bz;
+    const u64 bmax = fps_block_exchange<NW>(lds_slots[j & 1], wmax, writer, sx, sy, sz, bx, by, bz);
+
+    if (wave == 0) {
+      // publish this workgroup's candidate: field f of workgroup g -> cs[parity][f][g]
+      u64 *par = cs + (size_t)(j & 1) * (kCoopFields * kCoopMaxG);
+      if (lane < kCoopFields) {
+        unsigned v = lane == 0 ? (unsigned)(bmax >> 32)
+                   : lane == 1 ? (unsigned)bmax
+                   : lane == 2 ? __float_as_uint(bx)
+                   : lane == 3 ? __float_as_uint(by) : __float_as_uint(bz);
+        coop_store(par + lane * kCoopMaxG + g, ((u64)(unsigned)j << 32) | v);
+      }
+      // sweep the cluster's granules until all carry this round's tag
+      const int total = kCoopFields * G;
+      bool failed = false;
+      for (int q = 0; q < total; q += 64) {
+        const int l = q + lane;
+        const bool act = l < total;
+        const int f = act ? l / G : 0;
+        const int gg = act ? l - f * G : 0;
+        unsigned spins = 0;
+        u64 v;
+        for (;;) {
+          v = act ? coop_load(par + f * kCoopMaxG + gg) : ((u64)(unsigned)j << 32);
+          if (__all((unsigned)(v >> 32) == (unsigned)j)) break;
+          if (++spins > kCoopSpinLimit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (failed) break;
+        if (act) lds_vals[f][gg] = (unsigned)v;
+      }
+      // cluster arg-max (same total order in every workgroup => same winner everywhere)
+      u64 cand = 0ull;
+      if (!failed && lane < G) cand = ((u64)lds_vals[0][lane] << 32) | lds_vals[1][lane];
+      const u64 cmax = pn2_wave_max_u64(cand);
+      const u64 who = __ballot(!failed && lane < G && cand == cmax);
+      const int wg = who ? (__ffsll((long long)who) - 1) : 0;
+      if (lane == 0) {
+        FpsFinal &fin = lds_fin[j & 1];
+        fin.abort = failed ? 1 : 0;
+        fin.x = __uint_as_float(lds_vals[2][wg]);
+        fin.y = __uint_as_float(lds_vals[3][wg]);
+        fin.z = __uint_as_float(lds_vals[4][wg]);
+        fin.k = cmax ? (int)fps_unrank(~(unsigned)cmax, L) : 0;
+        if (failed) atomicExch(status, 1);
+      }
+    }
+    __syncthreads();
+    const FpsFinal &fin = lds_fin[j & 1];
+    if (fin.abort) return;
+    ox = fin.x; oy = fin.y; oz = fin.z;
+    if (g == 0 && t == 0) out[j] = fin.k;
+  }
+}
+
 constexpr int kFpsResidentMaxN = 1024 * 24;
 
 // EXT/include/cuda_utils.h:15-19 (same truncating double-log expression).
@@ -224,11 +389,69 @@ int ref_opt_n_threads(int work_size) {
   return v;
 }
 
+// Kernel selection, from measured per-round costs on MI355X (tools/microbench.py
+// MB_FPS_SWEEP): resident 512-thread workgroup ~0.55 us + 0.044 us per point slot,
+// resident 1024-thread ~0.5 + 0.12 per slot, cooperative ~1.9 + 0.044 per slot
+// (the inter-workgroup hand-off costs ~1.3 us), streaming ~0.25 us per 1000 points.
+//  => one workgroup up to 16k points; above that a cluster with the SMALLEST G
+//     that keeps <= 16 point slots per lane (larger clusters sweep more granules);
+//     every cluster workgroup must be resident, hence B*G <= 256.
+struct FpsPlan {
+  int mode;  // 0 resident, 1 cooperative, 2 streaming
+  int G, BS, PPT;
+};
+
+const int kPptSteps[] = {1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 20, 24};
+
+int round_ppt(int ppt) {
+  for (int c : kPptSteps)
+    if (c >= ppt) return c;
+  return -1;
+}
+
+// PN2_FPS_MODE=resident|coop|stream and PN2_FPS_G=<power of two> override the
+// heuristic (tuning / tests only).
+FpsPlan fps_plan(int B, int N, int m) {
+  FpsPlan p = {2, 1, 1024, 0};
+  if (m <= 1) { p.mode = 0; p.BS = 512; p.PPT = 1; return p; }
+  const char *mode_env = getenv("PN2_FPS_MODE");
+  const char *g_env = getenv("PN2_FPS_G");
+  const bool want_coop = mode_env && !strcmp(mode_env, "coop");
+  const bool want_resident = mode_env && !strcmp(mode_env, "resident");
+  const bool want_stream = mode_env && !strcmp(mode_env, "stream");
+  if (want_stream) return p;
+
+  // cooperative candidate
+  FpsPlan c = {-1, 1, 512, 0};
+  {
+    int G = 2;
+    while (G < kCoopMaxG && (N + G * 512 - 1) / (G * 512) > 16) G *= 2;
+    if (g_env) {
+      const int want = atoi(g_env);
+      if (want >= 2 && want <= kCoopMaxG && (want & (want - 1)) == 0) G = want;
+    }
+    const int ppt = round_ppt((N + G * 512 - 1) / (G * 512));
+    if ((long long)B * G <= 256 && ppt > 0) { c.mode = 1; c.G = G; c.PPT = ppt; }
+  }
+  // resident candidate
+  FpsPlan r = {-1, 1, 512, 0};
+  if (N <= 512 * 16) { r.mode = 0; r.BS = 512; r.PPT = round_ppt((N + 511) / 512); }
+  else if (N <= kFpsResidentMaxN) { r.mode = 0; r.BS = 1024; r.PPT = round_ppt((N + 1023) / 1024); }
+
+  if (want_coop && c.mode == 1) return c;
+  if (want_resident && r.mode == 0) return r;
+  if (r.mode == 0 && (N <= 16384 || c.mode != 1)) return r;
+  if (c.mode == 1) return c;
+  return p;
+}
+
 }  // namespace
 
 extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int m) {
   if (B <= 0 || N <= 0 || m <= 1) return 0;
-  if (N <= kFpsResidentMaxN) return 0;
+  const FpsPlan p = fps_plan(B, N, m);
+  if (p.mode == 0) return 0;
+  if (p.mode == 1) return (size_t)B * kCoopCloudBytes + 256;
   return (size_t)B * (size_t)N * sizeof(float);
 }
 
@@ -243,23 +466,67 @@ extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz
   const int bs = ref_opt_n_threads(N);
   int L = 0;
   while ((1 << L) < bs) ++L;
-
-#define PN2_FPS_LAUNCH(BS, PPT) \
-  hipLaunchKernelGGL((fps_resident_kernel<BS, PPT>), dim3(B), dim3(BS), 0, s, N, m, L, xyz, idxs)
-  if (N <= 512) PN2_FPS_LAUNCH(512, 1);
-  else if (N <= 1024) PN2_FPS_LAUNCH(512, 2);
-  else if (N <= 2048) PN2_FPS_LAUNCH(512, 4);
-  else if (N <= 4096) PN2_FPS_LAUNCH(512, 8);
-  else if (N <= 8192) PN2_FPS_LAUNCH(1024, 8);
-  else if (N <= 16384) PN2_FPS_LAUNCH(1024, 16);
-  else if (N <= kFpsResidentMaxN) PN2_FPS_LAUNCH(1024, 24);
-  else {
-    const size_t need = (size_t)B * (size_t)N * sizeof(float);
+  const FpsPlan plan = fps_plan(B, N, m);
+  const size_t need = pn2_fps_workspace_bytes(B, N, m);
+  if (need) {
     if (!workspace) return PN2_ENULL;
     if (workspace_bytes < need) return PN2_ENOSPC;
+  }
+
+  if (plan.mode == 1) {
+    u64 *slots = (u64 *)workspace;
+    int *status = (int *)((char *)workspace + (size_t)B * kCoopCloudBytes);
+    if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return pn2_check_launch();
+    const dim3 grid((unsigned)(B * plan.G));
+#define PN2_FPS_COOP(PPT)                                                                      \
+  case PPT:                                                                                    \
+    hipLaunchKernelGGL((fps_coop_kernel<512, PPT>), grid, dim3(512), 0, s, B, N, m, L, plan.G, \
+                       xyz, idxs, slots, status);                                              \
+    break;
+    switch (plan.PPT) {
+      PN2_FPS_COOP(1) PN2_FPS_COOP(2) PN2_FPS_COOP(3) PN2_FPS_COOP(4) PN2_FPS_COOP(6) PN2_FPS_COOP(8)
+      PN2_FPS_COOP(10) PN2_FPS_COOP(12) PN2_FPS_COOP(14) PN2_FPS_COOP(16) PN2_FPS_COOP(20)
+      PN2_FPS_COOP(24)
+      default: return PN2_EINVAL;
+    }
+#undef PN2_FPS_COOP
+    return pn2_check_launch();
+  }
+
+#define PN2_FPS_RES(BS, PPT)                                                                   \
+  case PPT:                                                                                    \
+    hipLaunchKernelGGL((fps_resident_kernel<BS, PPT>), dim3(B), dim3(BS), 0, s, N, m, L, xyz,  \
+                       idxs);                                                                  \
+    break;
+  if (plan.mode == 2) {
     hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(B), dim3(1024), 0, s, N, m, L, xyz,
                        (float *)workspace, idxs);
+  } else if (plan.BS == 512) {
+    switch (plan.PPT) {
+      PN2_FPS_RES(512, 1) PN2_FPS_RES(512, 2) PN2_FPS_RES(512, 3) PN2_FPS_RES(512, 4)
+      PN2_FPS_RES(512, 6) PN2_FPS_RES(512, 8) PN2_FPS_RES(512, 10) PN2_FPS_RES(512, 12)
+      PN2_FPS_RES(512, 14) PN2_FPS_RES(512, 16)
+      default: return PN2_EINVAL;
+    }
+  } else {
+    switch (plan.PPT) {
+      PN2_FPS_RES(1024, 10) PN2_FPS_RES(1024, 12) PN2_FPS_RES(1024, 14) PN2_FPS_RES(1024, 16)
+      PN2_FPS_RES(1024, 20) PN2_FPS_RES(1024, 24)
+      default: return PN2_EINVAL;
+    }
   }
-#undef PN2_FPS_LAUNCH
+#undef PN2_FPS_RES
   return pn2_check_launch();
+}
+
+// Test hook: status word of the last cooperative launch that used `workspace`
+// (0 = ok, 1 = a bounded spin expired).  Host-synchronous; not on the hot path.
+extern "C" int pn2_fps_coop_status(int B, const void *workspace, void *stream) {
+  int v = -1;
+  if (!workspace) return -1;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+  if (hipMemcpy(&v, (const char *)workspace + (size_t)B * kCoopCloudBytes, sizeof(int),
+                hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return v;
 }

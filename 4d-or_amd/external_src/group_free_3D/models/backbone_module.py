@@ -1,0 +1,56 @@
+"""PointNet++ SA/FP backbone over whole fused OR scans (the repo's only SA+FP
+stack; BASELINE config 2 "full SA/FP stack").  Mirrors
+GF3D/models/backbone_module.py:12-129: four set-abstraction levels
+(2048/0.2/64, 1024/0.4/32, 512/0.8/16, 256/1.2/16, radius-normalised local xyz)
+and two feature-propagation levels; same constructor, same ``end_points`` keys,
+same parameter names."""
+import torch
+import torch.nn as nn
+
+from external_src.group_free_3D.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+
+
+class Pointnet2Backbone(nn.Module):
+    def __init__(self, input_feature_dim=0, width=1, depth=2):
+        super().__init__()
+        self.depth, self.width = depth, width
+        w = width
+        levels = [  # (npoint, radius, nsample, c_in, hidden, c_out)
+            (2048, 0.2, 64, input_feature_dim, 64 * w, 128 * w),
+            (1024, 0.4, 32, 128 * w, 128 * w, 256 * w),
+            (512, 0.8, 16, 256 * w, 128 * w, 256 * w),
+            (256, 1.2, 16, 256 * w, 128 * w, 256 * w),
+        ]
+        for i, (npoint, radius, nsample, c_in, hid, c_out) in enumerate(levels, start=1):
+            setattr(self, f"sa{i}", PointnetSAModuleVotes(
+                npoint=npoint, radius=radius, nsample=nsample,
+                mlp=[c_in] + [hid] * depth + [c_out], use_xyz=True, normalize_xyz=True))
+        self.fp1 = PointnetFPModule(mlp=[256 * w + 256 * w, 256 * w, 256 * w])
+        self.fp2 = PointnetFPModule(mlp=[256 * w + 256 * w, 256 * w, 288])
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud: torch.Tensor, end_points=None):
+        """pointcloud (B, N, 3 + input_feature_dim) -> end_points dict with
+        sa{1..4}_xyz / _features (/ _inds for 1,2) and fp2_{features,xyz,inds}."""
+        end_points = end_points or {}
+        xyz, features = self._break_up_pc(pointcloud)
+        for i in (1, 2, 3, 4):
+            xyz, features, inds = getattr(self, f"sa{i}")(xyz, features)
+            if i <= 2:
+                end_points[f"sa{i}_inds"] = inds
+            end_points[f"sa{i}_xyz"] = xyz
+            end_points[f"sa{i}_features"] = features
+        features = self.fp1(end_points["sa3_xyz"], end_points["sa4_xyz"],
+                            end_points["sa3_features"], end_points["sa4_features"])
+        features = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"],
+                            end_points["sa2_features"], features)
+        end_points["fp2_features"] = features
+        end_points["fp2_xyz"] = end_points["sa2_xyz"]
+        num_seed = end_points["fp2_xyz"].shape[1]
+        end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:num_seed]
+        return end_points

@@ -1,0 +1,78 @@
+"""SA / FP modules with the Group-Free-3D API (keyword-only constructors, SA
+returns the FPS indices).  Mirrors GF3D/pointnet2/pointnet2_modules.py:162-269
+(``PointnetSAModuleVotes``) and :354-414 (``PointnetFPModule``); same parameter
+names (``mlp_module.layer{i}.conv`` / ``.bn.bn``; ``mlp.layer{i}...``).  Both run
+on the rows fast path of ``pointnet2_ops`` by default and fall back to the
+reference's channel-major staging when it is switched off."""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pointnet2_ops import pointnet2_modules as _pm
+from pointnet2_ops import pointnet2_utils
+from . import pytorch_utils as pt_utils
+
+
+class PointnetSAModuleVotes(nn.Module):
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None,
+                 nsample: int = None, bn: bool = True, use_xyz: bool = True, pooling: str = "max",
+                 sigma: float = None, normalize_xyz: bool = False, sample_uniformly: bool = False,
+                 ret_unique_cnt: bool = False):
+        super().__init__()
+        if pooling not in ("max", "avg", "rbf"):
+            raise ValueError(f"unknown pooling {pooling!r}")
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.pooling, self.use_xyz = pooling, use_xyz
+        self.sigma = sigma if sigma is not None else (radius / 2 if radius is not None else None)
+        self.normalize_xyz = normalize_xyz
+        self.ret_unique_cnt = ret_unique_cnt
+        if npoint is not None:
+            self.grouper = pointnet2_utils.QueryAndGroup(
+                radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True, normalize_xyz=normalize_xyz,
+                sample_uniformly=sample_uniformly, ret_unique_cnt=ret_unique_cnt)
+        else:
+            self.grouper = pointnet2_utils.GroupAll(use_xyz, ret_grouped_xyz=True)
+        if use_xyz and len(mlp) > 0:
+            mlp[0] += 3                      # in place like the reference (:205-207)
+        self.mlp_module = pt_utils.SharedMLP(mlp, bn=bn)
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
+        """xyz (B,N,3), features (B,C,N) -> (new_xyz (B,npoint,3), new_features (B,C',npoint), inds (B,npoint))."""
+        if inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        else:
+            assert inds.shape[1] == self.npoint
+        new_xyz = None
+        if self.npoint is not None:
+            new_xyz = pointnet2_utils.gather_operation(
+                xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+
+        if self.pooling == "max" and _pm._rows_path_ok(xyz, features):
+            B = xyz.size(0)
+            g = self.grouper.forward_rows(xyz, new_xyz, pointnet2_utils.as_rows(features))
+            _, npoint, nsample, width = g.shape
+            h = _pm.shared_mlp_rows(self.mlp_module, g.reshape(-1, width))
+            rows = pointnet2_utils.rows_max(h.view(B * npoint, nsample, -1)).view(B, npoint, -1)
+            return new_xyz, pointnet2_utils.rows_to_channels(rows), inds
+
+        grouped, grouped_xyz = self.grouper(xyz, new_xyz, features)
+        h = self.mlp_module(grouped)                                   # (B, C', npoint, nsample)
+        if self.pooling == "max":
+            h = F.max_pool2d(h, kernel_size=[1, h.size(3)])
+        elif self.pooling == "avg":
+            h = F.avg_pool2d(h, kernel_size=[1, h.size(3)])
+        else:  # rbf-weighted mean over the neighbourhood (:244-248)
+            rbf = torch.exp(-1 * grouped_xyz.pow(2).sum(1, keepdim=False) / (self.sigma ** 2) / 2)
+            h = torch.sum(h * rbf.unsqueeze(1), -1, keepdim=True) / float(self.nsample)
+        return new_xyz, h.squeeze(-1), inds
+
+
+class PointnetFPModule(_pm.PointnetFPModule):
+    """Keyword-only variant: ``PointnetFPModule(mlp=[...], bn=True)``; parameters
+    live under ``mlp.layer{i}`` (GF3D SharedMLP naming)."""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        nn.Module.__init__(self)
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn)

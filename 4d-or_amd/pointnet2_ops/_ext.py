@@ -63,6 +63,8 @@ for _name, _args in _SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here == ABI mismatch: fail loudly
     _fn.argtypes = _args
     _fn.restype = _c_int
+_lib.pn2_fps_coop_status.argtypes = [_c_int, _c_vp, _c_vp]
+_lib.pn2_fps_coop_status.restype = _c_int
 _lib.pn2_fps_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_workspace_bytes.restype = _c_sz
 _lib.pn2_abi_version.restype = _c_int
@@ -71,7 +73,7 @@ _lib.pn2_strerror.argtypes = [_c_int]
 _lib.pn2_strerror.restype = ctypes.c_char_p
 
 ABI_VERSION = int(_lib.pn2_abi_version())
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version",
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
 HAS_ROWS = True
@@ -146,6 +148,12 @@ def furthest_point_sampling(points, nsamples):
     ws_bytes = int(_lib.pn2_fps_workspace_bytes(B, N, nsamples))
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=points.device) if ws_bytes else None
     _call("pn2_furthest_point_sampling", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out))
+    if ws is not None and os.environ.get("PN2_FPS_CHECK") == "1":
+        # debug/test only (host sync): did a bounded inter-workgroup wait expire?
+        with torch.cuda.device(points.device):
+            st = _lib.pn2_fps_coop_status(B, _ptr(ws), torch.cuda.current_stream(points.device).cuda_stream)
+        if ws_bytes < B * N * 4 and st != 0:
+            _fail(f"pn2_furthest_point_sampling: cooperative kernel reported status {st}")
     return out
 
 

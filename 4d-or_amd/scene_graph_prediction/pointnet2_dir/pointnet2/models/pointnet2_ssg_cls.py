@@ -1,0 +1,48 @@
+"""Single-scale-grouping PointNet++ classifier backbone (base class of the MSG
+encoder 4D-OR actually uses).  Mirrors PN2/models/pointnet2_ssg_cls.py:55-124
+(PN2 = scene_graph_prediction/pointnet2_dir/pointnet2): ``__init__(input_dim)``,
+``_build_model``, ``_break_up_pc``, ``forward(pointcloud, return_features)`` and
+the parameter layout, INCLUDING the 1024->512->256->40 ``fc_layer`` head that the
+MSG subclass inherits but never feeds (msg_cls.py:47 calls ``super()._build_model()``
+first): the paper checkpoints contain those tensors, so they must exist for a
+strict ``load_state_dict``.  Lightning / ModelNet training hooks of the upstream
+file are out of scope."""
+import torch
+import torch.nn as nn
+
+from pointnet2_ops.pointnet2_modules import PointnetSAModule
+
+
+class PointNet2ClassificationSSG(nn.Module):
+    def __init__(self, input_dim):
+        super().__init__()
+        self.input_dim = input_dim
+        self._build_model()
+
+    def _build_model(self):
+        c = self.input_dim - 3
+        self.SA_modules = nn.ModuleList([
+            PointnetSAModule(npoint=512, radius=0.2, nsample=64, mlp=[c, 64, 64, 128], use_xyz=True),
+            PointnetSAModule(npoint=128, radius=0.4, nsample=64, mlp=[128, 128, 128, 256], use_xyz=True),
+            PointnetSAModule(mlp=[256, 256, 512, 1024], use_xyz=True),
+        ])
+        self.fc_layer = nn.Sequential(
+            nn.Linear(1024, 512, bias=False), nn.BatchNorm1d(512), nn.ReLU(True),
+            nn.Linear(512, 256, bias=False), nn.BatchNorm1d(256), nn.ReLU(True),
+            nn.Dropout(0.5), nn.Linear(256, 40),
+        )
+
+    def _break_up_pc(self, pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud, return_features=False):
+        """pointcloud (B, N, 3 + C), each point (x, y, z, features...) ->
+        (B, C_last, 1) set features if `return_features` else class logits."""
+        xyz, features = self._break_up_pc(pointcloud)
+        for sa in self.SA_modules:
+            xyz, features = sa(xyz, features)
+        if return_features:
+            return features
+        return self.fc_layer(features.squeeze(-1))

@@ -1,0 +1,152 @@
+"""TripletGCN message passing on MI355X.
+
+API mirror of SGH/model/gcns/network_TripletGCN.py (SGH =
+scene_graph_prediction/scene_graph_helpers): ``build_mlp`` (:11-27),
+``TripletGCN(dim_node, dim_edge, dim_hidden, aggr='add', use_bn=True)`` (:30-58)
+and ``TripletGCNModel(num_layers, **kwargs)`` (:61-80) with identical parameter
+names (``gconvs.{l}.nn1.{0,1,3,4}`` / ``nn2.{0,1,3}``).
+
+The reference inherits torch_geometric 2.0.2's ``MessagePassing`` and calls
+torch_scatter 2.0.9's ``scatter`` — un-vendored pip dependencies (README.md:87).
+Their semantics on this call path are restated here without either package:
+
+* flow ``source_to_target``: ``x_j = x[edge_index[0]]`` (subject / source),
+  ``x_i = x[edge_index[1]]`` (object / target)  (PyG ``__lift__``);
+* ``message`` (:45-52): ``nn1(cat[x_i, e, x_j])`` -> split ``hidden | edge | hidden``;
+  node message = first + last, new edge feature = middle;
+* ``aggregate`` (:54-58): sum of node messages over ``edge_index[1]`` into ``N`` rows;
+* ``update``: identity; then ``nn2`` on the aggregated rows (:42-43).
+
+Gather and scatter run in libpn2_hip.so (``pn2_gather_rows`` writes straight into
+the concatenation buffer; ``pn2_segment_sum_rows`` is a deterministic CSR sum that
+adds in edge order, i.e. bit-identical to a sequential CPU ``scatter_add_``).
+BatchNorm1d layers use batch statistics in train AND eval
+(``track_running_stats=False``, :20), like the reference.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from pointnet2_ops import _ext
+from scene_graph_prediction.scene_graph_helpers.model.pointnets.networks_base import BaseNetwork
+
+
+def build_mlp(dim_list, activation="relu", do_bn=False, dropout=0, on_last=False):
+    layers = []
+    last = len(dim_list) - 2
+    for i, (d_in, d_out) in enumerate(zip(dim_list[:-1], dim_list[1:])):
+        layers.append(torch.nn.Linear(d_in, d_out))
+        if i != last or on_last:
+            if do_bn:
+                layers.append(torch.nn.BatchNorm1d(d_out, track_running_stats=False))
+            if activation == "relu":
+                layers.append(torch.nn.ReLU())
+            elif activation == "leakyrelu":
+                layers.append(torch.nn.LeakyReLU())
+        if dropout > 0:
+            layers.append(torch.nn.Dropout(p=dropout))
+    return torch.nn.Sequential(*layers)
+
+
+class EdgeCSR:
+    """Stable sort of the edge targets, computed once per graph and shared by all layers."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise RuntimeError("edge_index must have shape (2, E)")
+        self.src = edge_index[0].contiguous()
+        self.dst = edge_index[1].contiguous()
+        self.num_nodes = int(num_nodes)
+        if self.dst.numel() and (int(edge_index.min()) < 0 or int(edge_index.max()) >= num_nodes):
+            raise RuntimeError("edge_index out of range")
+        self.order = torch.sort(self.dst, stable=True).indices.contiguous()
+        counts = torch.bincount(self.dst, minlength=self.num_nodes)
+        self.rowptr = torch.zeros(self.num_nodes + 1, dtype=torch.int64, device=edge_index.device)
+        self.rowptr[1:] = torch.cumsum(counts, 0)
+        # CSR by source, for the backward of the x_j gather
+        self.order_src = torch.sort(self.src, stable=True).indices.contiguous()
+        self.rowptr_src = torch.zeros_like(self.rowptr)
+        self.rowptr_src[1:] = torch.cumsum(torch.bincount(self.src, minlength=self.num_nodes), 0)
+
+
+class _TripletConcat(Function):
+    """cat[x[dst], e, x[src]] -> (E, 2*dn + de), gathers written in place."""
+
+    @staticmethod
+    def forward(ctx, x, e, csr):
+        E, dn, de = e.size(0), x.size(1), e.size(1)
+        buf = torch.empty(E, 2 * dn + de, dtype=torch.float32, device=x.device)
+        _ext.gather_rows(x.contiguous(), csr.dst, out=buf, col0=0, check=False)
+        buf[:, dn:dn + de] = e
+        _ext.gather_rows(x.contiguous(), csr.src, out=buf, col0=dn + de, check=False)
+        ctx.csr, ctx.dn, ctx.de = csr, dn, de
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        csr, dn, de = ctx.csr, ctx.dn, ctx.de
+        g = g.contiguous()
+        gx = _ext.segment_sum_rows(g, csr.order, csr.rowptr, csr.num_nodes, h=dn, col0=0)
+        gx = gx + _ext.segment_sum_rows(g, csr.order_src, csr.rowptr_src, csr.num_nodes, h=dn, col0=dn + de)
+        return gx, g[:, dn:dn + de], None
+
+
+class _AggregateAdd(Function):
+    """scatter(msg, index=edge_index[1], dim=-2, dim_size=N, reduce='add')."""
+
+    @staticmethod
+    def forward(ctx, msg, csr):
+        ctx.csr = csr
+        return _ext.segment_sum_rows(msg.contiguous(), csr.order, csr.rowptr, csr.num_nodes)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ext.gather_rows(g.contiguous(), ctx.csr.dst, check=False), None
+
+
+class TripletGCN(torch.nn.Module):
+    def __init__(self, dim_node, dim_edge, dim_hidden, aggr="add", use_bn=True):
+        super().__init__()
+        if aggr != "add":
+            raise NotImplementedError("the reference only ever aggregates with 'add' (GCN_AGGR is ignored)")
+        self.aggr = aggr
+        self.dim_node, self.dim_edge, self.dim_hidden = dim_node, dim_edge, dim_hidden
+        self.nn1 = build_mlp([dim_node * 2 + dim_edge, dim_hidden, dim_hidden * 2 + dim_edge],
+                             do_bn=use_bn, on_last=True)
+        self.nn2 = build_mlp([dim_hidden, dim_hidden, dim_node], do_bn=use_bn)
+
+    def forward(self, x, edge_feature, edge_index, csr: Optional[EdgeCSR] = None):
+        csr = csr if csr is not None else EdgeCSR(edge_index, x.size(0))
+        gcn_x, gcn_e = self.propagate(csr, x=x, edge_feature=edge_feature)
+        return self.nn2(gcn_x), gcn_e
+
+    def propagate(self, csr, x, edge_feature):
+        node_msg, new_e = self.message(csr, x, edge_feature)
+        return self.aggregate(node_msg, csr), new_e
+
+    def message(self, csr, x, edge_feature):
+        h = self.nn1(_TripletConcat.apply(x, edge_feature, csr))
+        dh, de = self.dim_hidden, self.dim_edge
+        return h[:, :dh] + h[:, dh + de:], h[:, dh:dh + de]
+
+    def aggregate(self, node_msg, csr):
+        return _AggregateAdd.apply(node_msg, csr)
+
+
+class TripletGCNModel(BaseNetwork):
+    """`num_layers` TripletGCN layers; ReLU on node and edge features between layers only."""
+
+    def __init__(self, num_layers, **kwargs):
+        super().__init__()
+        self.num_layers = num_layers
+        self.gconvs = torch.nn.ModuleList(TripletGCN(**kwargs) for _ in range(num_layers))
+
+    def forward(self, node_feature, edge_feature, edges_indices) -> Tuple[torch.Tensor, torch.Tensor]:
+        csr = EdgeCSR(edges_indices, node_feature.size(0))
+        for i, gconv in enumerate(self.gconvs):
+            node_feature, edge_feature = gconv(node_feature, edge_feature, edges_indices, csr)
+            if i < self.num_layers - 1:
+                node_feature = torch.nn.functional.relu(node_feature)
+                edge_feature = torch.nn.functional.relu(edge_feature)
+        return node_feature, edge_feature

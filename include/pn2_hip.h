@@ -61,6 +61,11 @@ int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz,
                                 void *workspace, size_t workspace_bytes,
                                 int *idxs, void *stream);
 
+/* Test hook for the multi-workgroup FPS variant: returns the status word a
+ * launch left in `workspace` (0 ok, 1 a bounded inter-workgroup wait expired,
+ * <0 query failed).  Synchronises `stream`; never used on the hot path. */
+int pn2_fps_coop_status(int B, const void *workspace, void *stream);
+
 /* ------------------------------------------------------------------ A6 ---
  * gather_points / gather_points_grad  (EXT/include/sampling.h:4-5,
  *   EXT/src/sampling.cpp:15-65, EXT/src/sampling_gpu.cu:8-57)

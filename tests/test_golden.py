@@ -1,0 +1,141 @@
+"""The build's python layer against fixtures produced by the REFERENCE's python
+layer (tests/golden/make_golden.py, run once in the build container on top of the
+same CPU oracle).  CPU, oracle backend: what is pinned here is the module logic,
+parameter naming, initialisation order and BN bookkeeping — not kernel arithmetic
+(that is test_gpu_*)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pointnet2_ops import pointnet2_modules as pm
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def sd_from(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_sa_msg_matches_reference_layer(oracle_backend, fast):
+    z = load("sa_msg.npz")
+    pc = torch.from_numpy(z["pc"])
+    xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+    sa = pm.PointnetSAModuleMSG(npoint=64, radii=[0.2, 0.4], nsamples=[8, 16], mlps=[[3, 16, 16], [3, 16, 32]])
+    sa.load_state_dict(sd_from(z, "sd0/"), strict=True)          # same keys and shapes as the reference
+    prev = pm.set_fast_path(fast)
+    try:
+        sa.train()
+        f = feats.clone().requires_grad_(True)
+        nx, nf = sa(xyz, f)
+        (nf * torch.linspace(0.5, 1.5, nf.numel()).view_as(nf)).sum().backward()
+        assert np.array_equal(nx.detach().numpy(), z["new_xyz"])
+        np.testing.assert_allclose(nf.detach().numpy(), z["new_features_train"], atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(f.grad.numpy(), z["grad_features"], atol=1e-5, rtol=1e-4)
+        for k, v in sd_from(z, "sd1/").items():                    # running stats after one training step
+            np.testing.assert_allclose(sa.state_dict()[k].double().numpy(), v.double().numpy(), atol=1e-6, rtol=1e-5)
+        sa.eval()
+        _, nf_eval = sa(xyz, feats)
+        np.testing.assert_allclose(nf_eval.detach().numpy(), z["new_features_eval"], atol=1e-5, rtol=1e-4)
+    finally:
+        pm.set_fast_path(prev)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_fp_matches_reference_layer(oracle_backend, fast):
+    z = load("fp.npz")
+    u, k = torch.from_numpy(z["unknown"]), torch.from_numpy(z["known"])
+    unknown, uf = u[..., :3].contiguous(), u[..., 3:].transpose(1, 2).contiguous()
+    known, kf = k[..., :3].contiguous(), k[..., 3:].transpose(1, 2).contiguous()
+    fp = pm.PointnetFPModule(mlp=[14, 16, 8])
+    fp.load_state_dict(sd_from(z, "sd0/"), strict=True)
+    prev = pm.set_fast_path(fast)
+    try:
+        fp.train()
+        kfr = kf.clone().requires_grad_(True)
+        out = fp(unknown, known, uf, kfr)
+        out.square().sum().backward()
+        np.testing.assert_allclose(out.detach().numpy(), z["out_train"], atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(kfr.grad.numpy(), z["grad_known"], atol=1e-4, rtol=1e-3)
+    finally:
+        pm.set_fast_path(prev)
+
+
+@pytest.mark.parametrize("dim,seed", [(6, 21), (7, 22)])
+def test_msg_encoder_matches_reference_layer(oracle_backend, dim, seed):
+    from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet2 import PointNetfeat
+    z = load("msg_encoder.npz")
+    torch.manual_seed(seed)                                        # same RNG stream as the fixture script
+    enc = PointNetfeat(input_dim=dim, out_size=256, input_dropout=0.0).eval()
+    sd = enc.state_dict()
+    assert list(sd.keys()) == list(z[f"d{dim}/keys"])             # incl. the dead backbone.fc_layer.*
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(z[f"d{dim}/shapes"])
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], z[f"d{dim}/sums"], rtol=1e-12, atol=1e-12)
+    with torch.no_grad():
+        y = enc(torch.from_numpy(z[f"d{dim}/x"]))
+    assert y.shape == (2, 256)
+    np.testing.assert_allclose(y.numpy(), z[f"d{dim}/y"], atol=1e-5, rtol=1e-4)
+
+
+def test_config1_plumbing_case_20k_points(oracle_backend):
+    """BASELINE.json configs[0]: one 20k-point cloud through the MSG object encoder on CPU."""
+    from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet2 import PointNetfeat
+    z = load("msg_encoder.npz")
+    torch.manual_seed(23)
+    enc = PointNetfeat(input_dim=6, out_size=256, input_dropout=0.0).eval()
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(1, 20000, 3, generator=g)
+    p = p / p.norm(dim=2, keepdim=True) * torch.rand(1, 20000, 1, generator=g).pow(1 / 3)
+    p = p - p.mean(dim=1, keepdim=True)
+    p = p / p.norm(dim=2).max()
+    pc = torch.cat([p, torch.rand(1, 20000, 3, generator=g)], dim=2)
+    assert abs(float(pc.double().sum()) - float(z["cfg1/pc_checksum"][0])) < 1e-9
+    with torch.no_grad():
+        y = enc(pc.transpose(1, 2).contiguous())
+    np.testing.assert_allclose(y.numpy(), z["cfg1/y"], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_gf3d_backbone_matches_reference_layer(oracle_backend, fast):
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    z = load("gf3d_backbone.npz")
+    torch.manual_seed(31)
+    net = Pointnet2Backbone(input_feature_dim=3)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(z["keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(z["shapes"])
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], z["sums"], rtol=1e-12, atol=1e-12)
+    prev = pm.set_fast_path(fast)
+    try:
+        net.train()
+        ep = net(torch.from_numpy(z["pc"]))
+        feats = ep["fp2_features"]
+        loss = (feats * torch.linspace(0.5, 1.5, feats.numel()).view_as(feats)).mean()
+        loss.backward()
+        assert np.array_equal(ep["sa1_inds"][:, :256].numpy(), z["sa1_inds"])
+        assert np.array_equal(ep["sa2_inds"][:, :64].numpy(), z["sa2_inds"])
+        assert np.array_equal(ep["sa4_xyz"].detach().numpy(), z["sa4_xyz"])
+        # literal path: same torch ops as the reference => tight.  rows path: every 1x1 conv is a
+        # differently-ordered fp32 GEMM and four levels of train-mode BatchNorm re-normalise the
+        # rounding noise, so the 6-level stack is compared at 1e-3 (single modules: 1e-5 above).
+        tol = dict(atol=1e-3, rtol=1e-3) if fast else dict(atol=2e-5, rtol=1e-3)
+        np.testing.assert_allclose(ep["sa4_features"].detach().numpy()[:, ::4], z["sa4_features"], **tol)
+        np.testing.assert_allclose(feats.detach().numpy()[:, ::8, ::4], z["fp2_features"], **tol)
+        assert abs(float(loss.detach()) - float(z["loss"][0])) < 1e-5
+        g0, g1 = net.sa1.mlp_module.layer0.conv.weight.grad.numpy(), net.fp2.mlp.layer1.conv.weight.grad.numpy()[::4]
+        if fast:
+            # weight gradients six levels up pass through discrete max-pool arg-max choices and
+            # BN-cancelled sums: compare in norm (measured 2.4e-2 / 7e-3 relative L2), not element-wise
+            for got, want in ((g0, z["grad_sa1_conv0"]), (g1, z["grad_fp2_conv1"])):
+                assert np.linalg.norm(got - want) / np.linalg.norm(want) < 8e-2
+        else:
+            np.testing.assert_allclose(g0, z["grad_sa1_conv0"], atol=1e-5, rtol=2e-2)
+            np.testing.assert_allclose(g1, z["grad_fp2_conv1"], atol=1e-5, rtol=2e-2)
+    finally:
+        pm.set_fast_path(prev)

@@ -18,7 +18,7 @@ def _run(module, inputs, device, backend, fast):
     pu._ext = backend
     try:
         m = copy.deepcopy(module).to(device)
-        args = [None if a is None else a.to(device) for a in inputs]
+        args = [None if a is None else a.detach().clone().to(device) for a in inputs]
         leaf = args[-1].requires_grad_(True)
         out = m(*args)
         out = out[1] if isinstance(out, tuple) else out

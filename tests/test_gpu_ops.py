@@ -43,6 +43,27 @@ def test_fps_bit_exact(ext, B, N, m, kind):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("mode,g", [("resident", None), ("stream", None), ("coop", 2), ("coop", 8), ("coop", 32), (None, None)])
+@pytest.mark.parametrize("B,N,m,kind", [(2, 9000, 300, "uniform"), (3, 20000, 150, "dup"), (1, 50000, 200, "zero_tail"),
+                                        (32, 50000, 40, "uniform"), (5, 5000, 64, "grid")])
+def test_fps_every_kernel_variant_agrees_with_oracle(ext, monkeypatch, mode, g, B, N, m, kind):
+    """resident / streaming / cooperative (G workgroups per cloud) kernels are
+    interchangeable: identical indices for identical input."""
+    if mode == "resident" and N > 24576:
+        pytest.skip("does not fit the register file of one workgroup")
+    if mode == "coop" and (B * g > 256 or (N + g - 1) // g > 512 * 24):
+        pytest.skip("cluster does not fit")
+    monkeypatch.setenv("PN2_FPS_CHECK", "1")
+    if mode:
+        monkeypatch.setenv("PN2_FPS_MODE", mode)
+    if g:
+        monkeypatch.setenv("PN2_FPS_G", str(g))
+    xyz = clouds(B, N, kind, seed=N + B)
+    want = O.furthest_point_sampling(xyz, m)
+    got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    assert torch.equal(got, want)
+
+
 def test_fps_all_skipped_and_m_zero(ext):
     xyz = torch.full((2, 700, 3), 0.001)
     assert torch.equal(ext.furthest_point_sampling(dev(xyz), 5).cpu(), torch.zeros(2, 5, dtype=torch.int32))
