@@ -127,11 +127,39 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _call(name, ref, *args):
+class KernelTimer:
+    """Optional per-entry-point HIP-event timing (bench.py): events are recorded on the
+    stream the kernels are enqueued on, resolved lazily by `summary()` after a sync."""
+
+    def __init__(self):
+        self.records = []          # (name, start_event, end_event, algorithmic_bytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, nbytes in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "alg_bytes": 0})
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["alg_bytes"] += nbytes
+        return out
+
+
+TIMER = None  # set to a KernelTimer() to profile
+
+
+def _call(name, ref, *args, alg_bytes=0):
     """Enqueue `name` on the current stream of `ref`'s device."""
     with torch.cuda.device(ref.device):
         stream = torch.cuda.current_stream(ref.device).cuda_stream
-        rc = getattr(_lib, name)(*args, stream)
+        if TIMER is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            rc = getattr(_lib, name)(*args, stream)
+            ev1.record()
+            TIMER.records.append((name, ev0, ev1, int(alg_bytes)))
+        else:
+            rc = getattr(_lib, name)(*args, stream)
     if rc != 0:
         detail = _lib.pn2_strerror(rc).decode()
         _fail(f"{name} failed: {detail} (rc={rc}, hipError={_lib.pn2_last_hip_error()})")
@@ -147,7 +175,8 @@ def furthest_point_sampling(points, nsamples):
     out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
     ws_bytes = int(_lib.pn2_fps_workspace_bytes(B, N, nsamples))
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=points.device) if ws_bytes else None
-    _call("pn2_furthest_point_sampling", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out))
+    _call("pn2_furthest_point_sampling", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
+          alg_bytes=B * (12 * N + 4 * nsamples))
     if ws is not None and os.environ.get("PN2_FPS_CHECK") == "1":
         # debug/test only (host sync): did a bounded inter-workgroup wait expire?
         with torch.cuda.device(points.device):
@@ -164,7 +193,8 @@ def gather_points(points, idx):
     B, C, N = points.shape
     m = idx.size(1)
     out = torch.empty(B, C, m, dtype=torch.float32, device=points.device)
-    _call("pn2_gather_points", points, B, C, N, m, _ptr(points), _ptr(idx), _ptr(out))
+    _call("pn2_gather_points", points, B, C, N, m, _ptr(points), _ptr(idx), _ptr(out),
+          alg_bytes=B * (4 * m + 8 * C * m))
     return out
 
 
@@ -174,7 +204,8 @@ def gather_points_grad(grad_out, idx, n):
     _same_device((grad_out, "grad_out"), (idx, "idx"))
     B, C, m = grad_out.shape
     out = torch.zeros(B, C, int(n), dtype=torch.float32, device=grad_out.device)
-    _call("pn2_gather_points_grad", grad_out, B, C, int(n), m, _ptr(grad_out), _ptr(idx), _ptr(out))
+    _call("pn2_gather_points_grad", grad_out, B, C, int(n), m, _ptr(grad_out), _ptr(idx), _ptr(out),
+          alg_bytes=B * (4 * m + 4 * C * m + 4 * C * int(n)))
     return out
 
 
@@ -186,7 +217,8 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.size(1)
     nsample = int(nsample)
     idx = torch.empty(B, m, nsample, dtype=torch.int32, device=new_xyz.device)  # kernel writes every slot
-    _call("pn2_ball_query", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx))
+    _call("pn2_ball_query", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx),
+          alg_bytes=B * (12 * N + 12 * m + 4 * m * nsample))
     return idx
 
 
@@ -197,7 +229,8 @@ def group_points(points, idx):
     B, C, N = points.shape
     npoints, nsample = idx.size(1), idx.size(2)
     out = torch.empty(B, C, npoints, nsample, dtype=torch.float32, device=points.device)
-    _call("pn2_group_points", points, B, C, N, npoints, nsample, _ptr(points), _ptr(idx), _ptr(out))
+    _call("pn2_group_points", points, B, C, N, npoints, nsample, _ptr(points), _ptr(idx), _ptr(out),
+          alg_bytes=B * (4 * npoints * nsample + 4 * C * N + 4 * C * npoints * nsample))
     return out
 
 
@@ -208,7 +241,8 @@ def group_points_grad(grad_out, idx, n):
     B, C, npoints, nsample = grad_out.shape
     out = torch.zeros(B, C, int(n), dtype=torch.float32, device=grad_out.device)
     _call("pn2_group_points_grad", grad_out, B, C, int(n), npoints, nsample,
-          _ptr(grad_out), _ptr(idx), _ptr(out))
+          _ptr(grad_out), _ptr(idx), _ptr(out),
+          alg_bytes=B * (4 * npoints * nsample + 4 * C * npoints * nsample + 4 * C * int(n)))
     return out
 
 
@@ -220,7 +254,8 @@ def three_nn(unknowns, knows):
     m = knows.size(1)
     idx = torch.empty(B, n, 3, dtype=torch.int32, device=unknowns.device)
     dist2 = torch.empty(B, n, 3, dtype=torch.float32, device=unknowns.device)
-    _call("pn2_three_nn", unknowns, B, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx))
+    _call("pn2_three_nn", unknowns, B, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx),
+          alg_bytes=B * (12 * n + 12 * m + 24 * n))
     return [dist2, idx]
 
 
@@ -231,7 +266,8 @@ def three_interpolate(points, idx, weight):
     B, C, m = points.shape
     n = idx.size(1)
     out = torch.empty(B, C, n, dtype=torch.float32, device=points.device)
-    _call("pn2_three_interpolate", points, B, C, m, n, _ptr(points), _ptr(idx), _ptr(weight), _ptr(out))
+    _call("pn2_three_interpolate", points, B, C, m, n, _ptr(points), _ptr(idx), _ptr(weight), _ptr(out),
+          alg_bytes=B * (4 * C * m + 24 * n + 4 * C * n))
     return out
 
 
@@ -242,7 +278,8 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     B, C, n = grad_out.shape
     out = torch.zeros(B, C, int(m), dtype=torch.float32, device=grad_out.device)
     _call("pn2_three_interpolate_grad", grad_out, B, C, n, int(m),
-          _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out))
+          _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out),
+          alg_bytes=B * (4 * C * n + 24 * n + 4 * C * int(m)))
     return out
 
 
@@ -267,7 +304,8 @@ def group_concat_rows(xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius)
     out = torch.empty(B, m, ns, W, dtype=torch.float32, device=xyz.device)
     _call("pn2_group_concat_rows", xyz, B, N, m, ns, C, int(bool(use_xyz)), int(bool(normalize)),
           float(radius if radius is not None else 1.0), _ptr(xyz), _ptr(new_xyz), _ptr(feats_rows),
-          _ptr(idx), _ptr(out))
+          _ptr(idx), _ptr(out),
+          alg_bytes=B * (4 * m * ns + (12 * N + 12 * m if use_xyz else 0) + 4 * C * N + 4 * W * m * ns))
     return out
 
 
@@ -278,7 +316,8 @@ def group_rows_grad(grad_out, idx, n, c, col0):
     B, m, ns, W = grad_out.shape
     out = torch.zeros(B, int(n), int(c), dtype=torch.float32, device=grad_out.device)
     _call("pn2_group_rows_grad", grad_out, B, int(n), m, ns, int(c), W, int(col0),
-          _ptr(grad_out), _ptr(idx), _ptr(out))
+          _ptr(grad_out), _ptr(idx), _ptr(out),
+          alg_bytes=B * (4 * m * ns + 4 * int(c) * m * ns + 4 * int(c) * int(n)))
     return out
 
 
@@ -289,7 +328,7 @@ def rows_max(x):
     R, ns, C = x.shape
     out = torch.empty(R, C, dtype=torch.float32, device=x.device)
     arg = torch.empty(R, C, dtype=torch.int32, device=x.device)
-    _call("pn2_rows_max", x, R, ns, C, _ptr(x), _ptr(out), _ptr(arg))
+    _call("pn2_rows_max", x, R, ns, C, _ptr(x), _ptr(out), _ptr(arg), alg_bytes=4 * R * ns * C + 8 * R * C)
     return out, arg
 
 
@@ -298,7 +337,8 @@ def rows_max_grad(grad_out, arg, ns):
     _same_device((grad_out, "grad_out"), (arg, "arg"))
     R, C = grad_out.shape
     gx = torch.empty(R, int(ns), C, dtype=torch.float32, device=grad_out.device)
-    _call("pn2_rows_max_grad", grad_out, R, int(ns), C, _ptr(grad_out), _ptr(arg), _ptr(gx))
+    _call("pn2_rows_max_grad", grad_out, R, int(ns), C, _ptr(grad_out), _ptr(arg), _ptr(gx),
+          alg_bytes=4 * R * int(ns) * C + 8 * R * C)
     return gx
 
 
@@ -314,7 +354,7 @@ def three_interpolate_rows(feats_rows, idx, weight, out=None, col0=0):
     else:
         _f32(out, "out")
     _call("pn2_three_interpolate_rows", feats_rows, B, C, m, n, out.size(2), int(col0),
-          _ptr(feats_rows), _ptr(idx), _ptr(weight), _ptr(out))
+          _ptr(feats_rows), _ptr(idx), _ptr(weight), _ptr(out), alg_bytes=B * (4 * C * m + 24 * n + 4 * C * n))
     return out
 
 
@@ -324,7 +364,8 @@ def three_interpolate_rows_grad(grad_out, idx, weight, m, c, col0=0):
     B, n, ldg = grad_out.shape
     out = torch.zeros(B, int(m), int(c), dtype=torch.float32, device=grad_out.device)
     _call("pn2_three_interpolate_rows_grad", grad_out, B, int(c), int(m), n, ldg, int(col0),
-          _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out))
+          _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out),
+          alg_bytes=B * (4 * int(c) * n + 24 * n + 4 * int(c) * int(m)))
     return out
 
 
@@ -347,7 +388,8 @@ def gather_rows(x, index, out=None, col0=0, check=True):
         col0 = 0
     else:
         _f32(out, "out")
-    _call("pn2_gather_rows", x, E, H, N, out.size(1), int(col0), _ptr(x), _ptr(index), _ptr(out))
+    _call("pn2_gather_rows", x, E, H, N, out.size(1), int(col0), _ptr(x), _ptr(index), _ptr(out),
+          alg_bytes=8 * E + 8 * E * H)
     return out
 
 
@@ -360,7 +402,8 @@ def scatter_add_rows(src, index, dim_size, h=None, col0=0, check=True):
     if check:
         _check_index_range(index, int(dim_size))
     out = torch.zeros(int(dim_size), h, dtype=torch.float32, device=src.device)
-    _call("pn2_scatter_add_rows", src, E, h, int(dim_size), lds, int(col0), _ptr(src), _ptr(index), _ptr(out))
+    _call("pn2_scatter_add_rows", src, E, h, int(dim_size), lds, int(col0), _ptr(src), _ptr(index), _ptr(out),
+          alg_bytes=4 * E * h + 8 * E + 4 * int(dim_size) * h)
     return out
 
 
@@ -373,5 +416,5 @@ def segment_sum_rows(src, order, rowptr, dim_size, h=None, col0=0):
     h = lds if h is None else int(h)
     out = torch.empty(int(dim_size), h, dtype=torch.float32, device=src.device)
     _call("pn2_segment_sum_rows", src, E, h, int(dim_size), lds, int(col0),
-          _ptr(src), _ptr(order), _ptr(rowptr), _ptr(out))
+          _ptr(src), _ptr(order), _ptr(rowptr), _ptr(out), alg_bytes=4 * E * h + 16 * E + 4 * int(dim_size) * h)
     return out

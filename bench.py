@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the 4D-OR scene-graph hot path on MI355X.
+
+Metric (BASELINE.json): OR scenes/sec, forward + backward, 50k points per scene,
+batch 32 per GPU, fp32, through the full SA/FP stack (BASELINE configs[1]:
+Group-Free `Pointnet2Backbone` shapes: SA 2048/0.2/64, 1024/0.4/32, 512/0.8/16,
+256/1.2/16 + 2 FP levels).  A "step" = forward, loss, backward (gradient
+all-reduce over RCCL when N > 1) and the AdamW update on one resident synthetic
+batch.  Weak scaling: every rank processes its own 32 scenes.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+  "roofline":     the dominant hand-written HIP kernel of the timed region, measured
+                  live with HIP events on the launch stream (algorithmic bytes from
+                  SURVEY.md §8d / DESIGN.md), plus the per-kernel table in "kernels";
+  "cpu_baseline": the same workload on the host CPU through the oracle port (N=1 only,
+                  bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(REPO, "4d-or_amd"), REPO, os.path.join(REPO, "tests")]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md chip table (spec; ~6300 achievable)
+
+
+def synthetic_scenes(batch, points, seed, device):
+    """xyz uniform in the unit ball, zero-mean, max-norm 1 (zero_mean of
+    data_preparation_utils.py:12-18), rgb ~ U[0,1]  (BASELINE.md §3)."""
+    g = torch.Generator().manual_seed(seed)
+    p = torch.randn(batch, points, 3, generator=g)
+    p = p / p.norm(dim=2, keepdim=True) * torch.rand(batch, points, 1, generator=g).pow(1.0 / 3.0)
+    p = p - p.mean(dim=1, keepdim=True)
+    p = p / p.norm(dim=2).amax(dim=1).view(batch, 1, 1)
+    rgb = torch.rand(batch, points, 3, generator=g)
+    return torch.cat([p, rgb], dim=2).contiguous().to(device)
+
+
+def build_model(device):
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    torch.manual_seed(0)
+    return Pointnet2Backbone(input_feature_dim=3).to(device)
+
+
+def train_step(model, opt, pc):
+    opt.zero_grad(set_to_none=True)
+    feats = model(pc)["fp2_features"]
+    loss = feats.square().mean()
+    loss.backward()
+    opt.step()
+    return loss
+
+
+def cpu_baseline(points, sample_scenes, threads):
+    """Same stack, same step, on the host: oracle port (C/OpenMP restatement of the nine
+    native ops) + stock-torch CPU MLPs.  Bounded sample; reported, never optimised."""
+    from pointnet2_ops import pointnet2_utils as pu
+    import oracle_ext
+    torch.set_num_threads(threads)
+    saved = pu._ext
+    pu._ext = oracle_ext.OracleRowsExt
+    try:
+        model = build_model("cpu")
+        opt = torch.optim.AdamW(model.parameters(), lr=3e-5, weight_decay=1e-3)
+        pc = synthetic_scenes(sample_scenes, points, seed=1234, device="cpu")
+        t0 = time.perf_counter()
+        train_step(model, opt, pc)
+        dt = time.perf_counter() - t0
+    finally:
+        pu._ext = saved
+    return {"value": round(sample_scenes / dt, 4), "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_scenes} scenes x {points} pts, 1 fwd+bwd+AdamW step, {dt:.1f} s wall "
+                      f"(oracle ops are OpenMP-parallel over scenes; MLPs torch CPU with {threads} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="scenes per GPU")
+    ap.add_argument("--points", type=int, default=50000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-scenes", type=int, default=4)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from pointnet2_ops import _ext
+
+    model = build_model(device)
+    net = model
+    if distributed:
+        # gradients only: one flat bucket (650k params = 2.6 MB, latency-bound over xGMI)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=64,
+                                                        gradient_as_bucket_view=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-5, weight_decay=1e-3)
+    pc = synthetic_scenes(args.batch, args.points, seed=1000 + rank, device=device)   # resident in HBM
+
+    for _ in range(args.warmup):
+        train_step(net, opt, pc)
+    torch.cuda.synchronize()
+
+    timer = None
+    if not args.no_kernel_timing:
+        timer = _ext.KernelTimer()
+        _ext.TIMER = timer
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_step(net, opt, pc)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _ext.TIMER = None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        scenes = args.batch * world * args.steps
+        out = {
+            "metric": "OR scenes/sec fwd+bwd (50k pts, batch 32)",
+            "value": round(scenes / elapsed, 3),
+            "unit": "scenes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: {args.batch} scenes/GPU x {args.points} pts x (3 xyz + 3 rgb) fp32, "
+                            "full SA/FP stack (Pointnet2Backbone: SA 2048/0.2/64, 1024/0.4/32, 512/0.8/16, "
+                            "256/1.2/16, FP x2), train mode, fwd + bwd + AdamW",
+                "global_batch": args.batch * world,
+                "points_per_scene": args.points,
+                "parallelism": f"dp{world}",
+            },
+        }
+        if timer is not None:
+            table = timer.summary()
+            rows = []
+            for name, d in table.items():
+                per_launch_ms = d["ms"] / d["calls"]
+                per_launch_bytes = d["alg_bytes"] / d["calls"]
+                gbps = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+                rows.append({"kernel": name, "calls_per_step": d["calls"] / args.steps,
+                             "ms_per_step": round(d["ms"] / args.steps, 4),
+                             "avg_launch_us": round(per_launch_ms * 1e3, 2),
+                             "alg_MB_per_launch": round(per_launch_bytes / 1e6, 3),
+                             "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 5)})
+            rows.sort(key=lambda r: -r["ms_per_step"])
+            out["kernels"] = rows
+            hip_ms = sum(r["ms_per_step"] for r in rows)
+            out["hip_kernel_ms_per_step"] = round(hip_ms, 3)
+            if rows:
+                top = rows[0]
+                out["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
+                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"], "traffic": None,
+                                   "avg_launch_us": top["avg_launch_us"],
+                                   "alg_bytes_per_launch": int(top["alg_MB_per_launch"] * 1e6)}
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, 64)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.points, args.cpu_sample_scenes, threads)
+            except Exception as e:  # the baseline is informational; never lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "scenes/s", "cores": threads, "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(out), flush=True)
+
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
