@@ -1,0 +1,748 @@
+// mlp_gemm.hip — fused fp32-MFMA kernels for the shared per-point MLPs.
+//
+// The reference runs each SA/FP "shared MLP" as nn.Conv2d(1x1, bias=False) +
+// BatchNorm2d + ReLU per layer (OPS/pointnet2_modules.py:9-19) followed by
+// F.max_pool2d (:67-70): per layer that is one GEMM plus 3-4 full passes over a
+// (B*npoint*nsample, C) tensor in the forward and 5 more in the backward.  On
+// MI355X those passes, not the FLOPs, dominate (profiles/r01_bench_v1_summary.md:
+// 25 ms of BN/ReLU kernels + 30 ms of extremely skinny hipBLASLt GEMMs per step).
+//
+// Here a layer is ONE tall-skinny GEMM kernel on the f32 MFMA path
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, 157 TF peak):
+//
+//     out[M, N] = pro(X)[M, K] * W[N, K]^T        M = rows (10^5..10^7), K, N <= 512
+//
+//   prologue `pro` (applied while staging the A tile into LDS, never materialised):
+//     PRO_NONE    x
+//     PRO_BNRELU  relu(x * p0[k] + p1[k])            = ReLU(BatchNorm(y_{l-1})) of the previous layer
+//     PRO_GY      p0[k]*g + p1[k]*y + p2[k]          = dL/dy_l from dL/dz_l (BatchNorm backward, see below)
+//     PRO_POOLG   same, with g gathered from the pooled gradient through the arg-max
+//   epilogue:
+//     EPI_STATS   column sums of out and out^2 (fp64 atomics)  -> BatchNorm batch statistics
+//     EPI_MASK    out *= [BN(yprev) > 0]; column sums of out and out * yhat_prev
+//                                                             -> ReLU backward + BN-backward reductions
+//
+// BatchNorm backward in this formulation: with yhat = (y-mean)*rstd, z = gamma*yhat+beta,
+// g = dL/dz, dbeta = sum g, dgamma = sum g*yhat (both produced by the previous kernel's
+// epilogue), dL/dy = gamma*rstd*(g - dbeta/M - yhat*dgamma/M) = c1*g + c2*y + c3 with
+// per-channel constants — so it folds into the next GEMM's prologue.
+//
+// Tiling: workgroup = 4 waves = 128 rows x (NT*32) columns; each wave owns 32 rows
+// and NT accumulators of 32x32 (16 VGPRs each); K is walked in chunks of 16/32 staged
+// through double-buffered LDS with +1 padding (conflict-free ds_read_b32 fragment
+// reads), global loads of the next chunk in flight behind the current chunk's MFMAs.
+#include "pn2_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_GY = 2, PRO_POOLG = 3 };
+enum { EPI_NONE = 0, EPI_STATS = 1, EPI_MASK = 2 };
+
+struct GemmArgs {
+  const float *X;    // [M][K]  (PRO_GY: g = dL/dz [M][K]; PRO_POOLG: unused)
+  const float *X2;   // PRO_GY / PRO_POOLG: y [M][K]
+  const float *p0, *p1, *p2;
+  const int *arg;    // PRO_POOLG: [M/ns][K] arg-max sample per (row group, channel)
+  const float *gP;   // PRO_POOLG: [M/ns][K] pooled gradient (already masked by pooled > 0)
+  const float *W;    // [N][K]
+  float *Y;          // [M][N]
+  double *stats;     // [2][N]
+  const float *Yprev;                              // EPI_MASK: [M][N]
+  const float *e_scale, *e_shift, *e_mean, *e_rstd;  // EPI_MASK: per output column
+  long long M;
+  int K, N, ns, pro, epi;
+};
+
+constexpr int BM = 128;
+
+// Persistent, software-pipelined workgroups.  A workgroup walks row tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... and the (tile, K-chunk) steps form ONE
+// pipeline: the global loads of step s+1 — possibly the first chunk of the NEXT
+// tile — are issued into registers before the MFMAs of step s run out of LDS buffer
+// s&1, then transformed (prologue) and written to buffer (s+1)&1; one barrier per
+// step, no exposed load latency at tile boundaries.  Column sums for the epilogue
+// reductions stay in registers across tiles and are flushed once per workgroup.
+// CW = wave columns: the workgroup is 4 x CW waves; wave (wr, wc) owns rows wr*32.. and the
+// NT column tiles wc*NT.. (CW = 2 keeps N = 256/288 at 64-80 accumulator registers per wave).
+// MASKE: the EPI_MASK variant; it prefetches the Yprev tile into registers behind the last
+// chunk's MFMAs so the epilogue never waits on HBM.
+template <int NT, int KC, int CW, bool MASKE>
+__global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a) {
+  constexpr int THREADS = 256 * CW;
+  constexpr int NTT = NT * CW;                // column tiles per workgroup
+  constexpr int LD = KC + 1;
+  constexpr int APT = BM * KC / THREADS;      // A elements per thread per chunk
+  constexpr int WPT = NTT * 32 * KC / THREADS; // W elements per thread per chunk
+  constexpr int RSTEP = THREADS / KC;         // rows covered by one pass of the workgroup
+  __shared__ float As[2][BM * LD];
+  __shared__ float Ws[2][NTT * 32 * LD];
+  __shared__ float red[2][NTT * 32];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = (tid >> 6) & 3;            // row block of this wave
+  const int wcol = tid >> 8;                  // column block of this wave
+  const int n0 = blockIdx.y * (NTT * 32);
+  const int K = a.K, N = a.N;
+  const long long M = a.M;
+  const int pro = a.pro;
+  const int epi = MASKE ? (int)EPI_MASK : a.epi;
+  const int nchunks = (K + KC - 1) / KC;
+  const long long ntiles = (M + BM - 1) / BM;
+  const long long my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;   // >= 1 (grid <= ntiles)
+  const long long total_steps = my_tiles * nchunks;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float cs1[NT], cs2[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { cs1[t] = 0.f; cs2[t] = 0.f; }
+
+  const int kk = tid % KC;
+  const int r0 = tid / KC;
+  const unsigned voff = (unsigned)(r0 * K + kk);
+  const unsigned rstride = (unsigned)(RSTEP * K);
+  const float *Wt = a.W + (size_t)n0 * K;
+
+  float ra[APT], rb[APT], rw[WPT];
+
+  // state of the tile whose chunks are currently being LOADED
+  long long l_tile = blockIdx.x;
+  int l_chunk = 0;
+
+  auto load_step = [&]() {
+    const long long m0 = l_tile * BM;
+    const int k0 = l_chunk * KC;
+    const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
+    const float *Xt = a.X ? a.X + (size_t)m0 * K : nullptr;
+    const float *X2t = a.X2 ? a.X2 + (size_t)m0 * K : nullptr;
+    const int k = k0 + kk;
+    const bool kin = k < K;
+    unsigned grp = 0;
+    int smp = 0;
+    if (pro == PRO_POOLG) {
+      const unsigned row = (unsigned)(m0 + r0);
+      grp = row / (unsigned)a.ns;
+      smp = (int)(row - grp * (unsigned)a.ns);
+    }
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      const bool in = kin && (r0 + RSTEP * i) < mrem;
+      const unsigned off = voff + (unsigned)i * rstride + (unsigned)k0;
+      float v = 0.f, w = 0.f;
+      if (in) {
+        if (pro == PRO_POOLG) {
+          const size_t goff = (size_t)grp * K + k;
+          v = (a.arg[goff] == smp) ? a.gP[goff] : 0.f;
+        } else {
+          v = Xt[off];
+        }
+        if (pro >= PRO_GY) w = X2t[off];
+      }
+      ra[i] = v;
+      rb[i] = w;
+      if (pro == PRO_POOLG) {
+        smp += RSTEP;
+        while (smp >= a.ns) { smp -= a.ns; ++grp; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const bool in = kin && (n0 + r0 + RSTEP * i) < N;
+      rw[i] = in ? Wt[voff + (unsigned)i * rstride + (unsigned)k0] : 0.f;
+    }
+  };
+
+  // transforms the registers loaded by the LAST load_step() and writes them to LDS
+  auto store_step = [&](int buf) {
+    const long long m0 = l_tile * BM;
+    const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
+    const int k = l_chunk * KC + kk;
+    const bool kin = k < K;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (kin && pro != PRO_NONE) {
+      q0 = a.p0[k];
+      q1 = a.p1[k];
+      if (pro >= PRO_GY) q2 = a.p2[k];
+    }
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      float v = ra[i];
+      if (pro == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, q0, q1), 0.f);
+      else if (pro >= PRO_GY) v = __fmaf_rn(q0, v, __fmaf_rn(q1, rb[i], q2));
+      if (!(kin && (r0 + RSTEP * i) < mrem)) v = 0.f;
+      As[buf][(r0 + RSTEP * i) * LD + kk] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) Ws[buf][(r0 + RSTEP * i) * LD + kk] = rw[i];
+  };
+
+  auto advance_load = [&]() {
+    if (++l_chunk == nchunks) { l_chunk = 0; l_tile += gridDim.x; }
+  };
+
+  load_step();
+  store_step(0);
+  advance_load();
+  __syncthreads();
+
+  const int arow = (wave * 32 + (lane & 31)) * LD + (lane >> 5);
+  const int brow = (wcol * NT * 32 + (lane & 31)) * LD + (lane >> 5);
+  const int cl = lane & 31;
+  const int rbase = wave * 32 + 4 * (lane >> 5);
+  long long c_tile = blockIdx.x;   // tile being COMPUTED
+  int c_chunk = 0;
+  int buf = 0;
+  float yp[MASKE ? NT : 1][16];
+  for (long long step = 0; step < total_steps; ++step) {
+    const bool more = step + 1 < total_steps;
+    const bool last_chunk = c_chunk == nchunks - 1;
+    const long long m0 = c_tile * BM;
+    if (more) load_step();
+    if (MASKE && last_chunk) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = n0 + (wcol * NT + t) * 32 + cl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long row = m0 + rbase + (r & 3) + 8 * (r >> 2);
+          yp[MASKE ? t : 0][r] = (col < N && row < M) ? a.Yprev[(size_t)row * N + col] : 0.f;
+        }
+      }
+    }
+    const float *Ab = As[buf];
+    const float *Wb = Ws[buf];
+#pragma unroll
+    for (int s = 0; s < KC / 2; ++s) {
+      const float av = Ab[arow + 2 * s];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float bv = Wb[brow + t * 32 * LD + 2 * s];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    // registers of the next step -> LDS first, so that the wait on those loads does not also
+    // have to drain the epilogue's stores (vmcnt counts both on gfx9)
+    if (more) {
+      store_step(buf ^ 1);
+      advance_load();
+    }
+    if (last_chunk) {
+      // ---- tile epilogue: mask / statistics / store, straight from the accumulators ----
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = n0 + (wcol * NT + t) * 32 + cl;
+        const bool cin = col < N;
+        float es = 0.f, eh = 0.f, em = 0.f, er = 0.f;
+        if (MASKE && cin) { es = a.e_scale[col]; eh = a.e_shift[col]; em = a.e_mean[col]; er = a.e_rstd[col]; }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long row = m0 + rbase + (r & 3) + 8 * (r >> 2);
+          if (cin && row < M) {
+            float v = acc[t][r];
+            if (MASKE) {
+              const float y = yp[MASKE ? t : 0][r];
+              v = (__fmaf_rn(y, es, eh) > 0.f) ? v : 0.f;
+              s1 += v;
+              s2 = __fmaf_rn(v, (y - em) * er, s2);
+            } else if (epi == EPI_STATS) {
+              s1 += v;
+              s2 = __fmaf_rn(v, v, s2);
+            }
+            a.Y[(size_t)row * N + col] = v;
+          }
+          acc[t][r] = 0.f;
+        }
+        cs1[t] += s1;
+        cs2[t] += s2;
+      }
+      c_chunk = 0;
+      c_tile += gridDim.x;
+    } else {
+      ++c_chunk;
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- flush the column sums once per workgroup ----
+  if (epi != EPI_NONE) {
+    for (int i = tid; i < 2 * NTT * 32; i += THREADS) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      atomicAdd(&red[0][(wcol * NT + t) * 32 + cl], cs1[t]);
+      atomicAdd(&red[1][(wcol * NT + t) * 32 + cl], cs2[t]);
+    }
+    __syncthreads();
+    for (int i = tid; i < NTT * 32; i += THREADS) {
+      const int col = n0 + i;
+      if (col < N) {
+        atomicAdd(a.stats + col, (double)red[0][i]);
+        atomicAdd(a.stats + N + col, (double)red[1][i]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- wgrad ----
+// dW[N][K] += sum_r gy[r][n] * act[r][k]   (reduction over the M rows)
+// workgroup = 8 waves; a column block of <= 128 K-columns (4 k-tiles) x all n-tiles
+// (<= 10): wave w owns k-tile (w & 3) and the n-tiles of parity (w >> 2).
+struct WgradArgs {
+  // gy operand [M][N]
+  const float *G;    // PRO_GY: g = dL/dz [M][N]
+  const float *Yl;   // y_l [M][N]
+  const float *c1, *c2, *c3;
+  const int *arg;    // PRO_POOLG
+  const float *gP;
+  // activation operand [M][K]
+  const float *X;    // raw input or y_{l-1}
+  const float *a_scale, *a_shift;  // PRO_BNRELU
+  float *dW;         // [N][K], accumulated with atomics (caller zero-fills)
+  long long M, rows_per_wg;
+  int N, K, ns, gmode /* PRO_GY | PRO_POOLG */, amode /* PRO_NONE | PRO_BNRELU */;
+};
+
+constexpr int WR = 32;        // rows per LDS tile
+constexpr int WMAXN = 320;    // 10 n-tiles
+constexpr int WKB = 128;      // K columns per workgroup
+
+template <int NTW>  // n-tiles per wave (total n-tiles <= 2*NTW)
+__global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
+  constexpr int GN = 2 * NTW * 32;
+  __shared__ float Gs[WR * GN];
+  __shared__ float Xs[WR * WKB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int ktile = wave & 3;
+  const int npar = wave >> 2;
+  const int kb0 = blockIdx.y * WKB;
+  const int N = a.N, K = a.K;
+  const long long M = a.M;
+  const long long row_begin = (long long)blockIdx.x * a.rows_per_wg;
+  long long row_end = row_begin + a.rows_per_wg;
+  if (row_end > M) row_end = M;
+  const int gmode = a.gmode, amode = a.amode;
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // per-thread element coordinates inside a tile (fixed for the whole kernel): ONE gy column
+  // and ONE activation column per thread, so the per-column constants are 5 registers
+  constexpr int GRP = (512 / GN) ? (512 / GN) : 1;   // gy rows per pass (GN = 320: 1, 192 threads idle)
+  constexpr int GPT = (WR + GRP - 1) / GRP;
+  constexpr int XRP = 512 / WKB;                     // activation rows per pass (4)
+  constexpr int XPT = WR / XRP;                      // 8
+  const int gn = tid % GN, gr0 = tid / GN;
+  const bool g_thr = tid < GRP * GN && gn < N;
+  float c1 = 0.f, c2 = 0.f, c3 = 0.f;
+  if (g_thr) { c1 = a.c1[gn]; c2 = a.c2[gn]; c3 = a.c3[gn]; }
+  const int xr0 = tid / WKB, xk = tid % WKB;
+  const int kx = kb0 + xk;
+  const bool kx_in = kx < K;
+  float a_sc = 1.f, a_sh = 0.f;
+  if (amode == PRO_BNRELU && kx_in) { a_sc = a.a_scale[kx]; a_sh = a.a_shift[kx]; }
+
+  float rg[GPT], ry[GPT], rx[XPT];
+
+  auto load_tile = [&](long long rt) {
+    const int rows = (int)((row_end - rt) < (long long)WR ? (row_end - rt) : (long long)WR);
+    const float *Gt = a.G ? a.G + (size_t)rt * N : nullptr;
+    const float *Yt = a.Yl + (size_t)rt * N;
+    const float *Xt = a.X + (size_t)rt * K;
+    unsigned grp = 0;
+    int smp = 0;
+    if (gmode == PRO_POOLG) {
+      const unsigned row = (unsigned)(rt + gr0);
+      grp = row / (unsigned)a.ns;
+      smp = (int)(row - grp * (unsigned)a.ns);
+    }
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      const int r = gr0 + GRP * i;
+      float g = 0.f, y = 0.f;
+      if (g_thr && r < rows) {
+        const unsigned off = (unsigned)(r * N + gn);
+        y = Yt[off];
+        if (gmode == PRO_GY) {
+          g = Gt[off];
+        } else {
+          const size_t goff = (size_t)grp * N + gn;
+          g = (a.arg[goff] == smp) ? a.gP[goff] : 0.f;
+        }
+      }
+      rg[i] = g;
+      ry[i] = y;
+      if (gmode == PRO_POOLG) {
+        smp += GRP;
+        while (smp >= a.ns) { smp -= a.ns; ++grp; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int r = xr0 + XRP * i;
+      rx[i] = (kx_in && r < rows) ? Xt[(unsigned)(r * K + kx)] : 0.f;
+    }
+  };
+
+  auto store_tile = [&](long long rt) {
+    const int rows = (int)((row_end - rt) < (long long)WR ? (row_end - rt) : (long long)WR);
+    if (tid < GRP * GN) {
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) {
+        const int r = gr0 + GRP * i;
+        if (r < WR) Gs[r * GN + gn] = (g_thr && r < rows) ? __fmaf_rn(c1, rg[i], __fmaf_rn(c2, ry[i], c3)) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int r = xr0 + XRP * i;
+      float v = rx[i];
+      if (amode == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, a_sc, a_sh), 0.f);
+      if (!(kx_in && r < rows)) v = 0.f;
+      Xs[r * WKB + xk] = v;
+    }
+  };
+
+  if (row_begin < row_end) load_tile(row_begin);
+  for (long long rt = row_begin; rt < row_end; rt += WR) {
+    store_tile(rt);
+    __syncthreads();
+    if (rt + WR < row_end) load_tile(rt + WR);   // in flight behind the MFMAs below
+    // A operand: A[i = n][k = r] = gy[r][n];  B operand: B[k = r][j = kcol] = act[r][kcol]
+#pragma unroll
+    for (int s = 0; s < WR / 2; ++s) {
+      const int rr = 2 * s + (lane >> 5);
+      const float bv = Xs[rr * WKB + ktile * 32 + (lane & 31)];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const float av = Gs[rr * GN + (npar + 2 * t) * 32 + (lane & 31)];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- flush: acc[t][reg] = dW[n = ntile*32 + rowmap][k = kb0 + ktile*32 + (lane&31)] ----
+  const int kcol = kb0 + ktile * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int nb = (npar + 2 * t) * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nb + (r & 3) + 8 * (r >> 2);
+      if (n < N && kcol < K) atomicAdd(a.dW + (size_t)n * K + kcol, acc[t][r]);
+    }
+  }
+}
+
+// ------------------------------------------------------ small helper kernels ----
+// BatchNorm finalisation: batch statistics -> (mean, rstd, scale, shift) and the
+// running-stat update of torch's _BatchNorm (momentum; unbiased variance).
+__global__ void bn_finalize_kernel(int N, double count, const double *__restrict__ stats,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float eps, float momentum, float *__restrict__ running_mean,
+                                   float *__restrict__ running_var, float *__restrict__ out /* [4][N] */) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const double mean = stats[c] / count;
+  double var = stats[N + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f;
+  const float b = beta ? beta[c] : 0.f;
+  const float scale = g * rstd;
+  out[c] = (float)mean;
+  out[N + c] = rstd;
+  out[2 * N + c] = scale;
+  out[3 * N + c] = b - (float)mean * scale;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// BN-backward constants of one layer from the epilogue sums:
+//   c1 = gamma*rstd, c2 = -c1*rstd*dgamma/M, c3 = -c1*dbeta/M - c2*mean;
+// also emits dgamma / dbeta as fp32 for the optimiser.
+__global__ void bn_bwd_consts_kernel(int N, double count, const double *__restrict__ sums /* [2][N]: dbeta, dgamma */,
+                                     const float *__restrict__ gamma, const float *__restrict__ fin /* [4][N] */,
+                                     int use_batch_stats, float *__restrict__ consts /* [3][N] */,
+                                     float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const double db = sums[c], dg = sums[N + c];
+  const float mean = fin[c], rstd = fin[N + c];
+  const float g = gamma ? gamma[c] : 1.f;
+  const float c1 = g * rstd;
+  float c2 = 0.f, c3 = 0.f;
+  if (use_batch_stats) {
+    c2 = (float)(-(double)c1 * (double)rstd * dg / count);
+    c3 = (float)(-(double)c1 * db / count - (double)c2 * (double)mean);
+  }
+  consts[c] = c1;
+  consts[N + c] = c2;
+  consts[2 * N + c] = c3;
+  if (dgamma) dgamma[c] = (float)dg;
+  if (dbeta) dbeta[c] = (float)db;
+}
+
+// out = relu(y*scale + shift)  (materialised only where a module must return activations: FP)
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(size_t total, int N, const float *__restrict__ y,
+                                                           const float *__restrict__ fin, float *__restrict__ out) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % N);
+    out[e] = fmaxf(__fmaf_rn(y[e], fin[2 * N + c], fin[3 * N + c]), 0.f);
+  }
+}
+
+// g_pre = g_out * [relu(bn(y)) > 0];  sums: dbeta += g_pre, dgamma += g_pre * yhat
+__global__ __launch_bounds__(256) void bn_relu_bwd_prep_kernel(long long M, int N, const float *__restrict__ y,
+                                                              const float *__restrict__ gout,
+                                                              const float *__restrict__ fin,
+                                                              float *__restrict__ gpre, double *__restrict__ sums) {
+  // block handles 64 rows x all columns; thread t walks columns t, t+256, ...
+  const long long r0 = (long long)blockIdx.x * 64;
+  for (int c = threadIdx.x; c < N; c += 256) {
+    const float mean = fin[c], rstd = fin[N + c], sc = fin[2 * N + c], sh = fin[3 * N + c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < 64; ++r) {
+      const long long row = r0 + r;
+      if (row >= M) break;
+      const size_t off = (size_t)row * N + c;
+      const float yy = y[off];
+      const float g = (__fmaf_rn(yy, sc, sh) > 0.f) ? gout[off] : 0.f;
+      gpre[off] = g;
+      s1 += g;
+      s2 = __fmaf_rn(g, (yy - mean) * rstd, s2);
+    }
+    atomicAdd(sums + c, (double)s1);
+    atomicAdd(sums + N + c, (double)s2);
+  }
+}
+
+// Fused BN + ReLU + max over the ns rows of each group: y (R*ns, C) -> pooled (R, C), arg (R, C).
+__global__ __launch_bounds__(256) void bn_relu_rows_max_kernel(size_t total /* R*C */, int ns, int C,
+                                                              const float *__restrict__ y,
+                                                              const float *__restrict__ fin,
+                                                              float *__restrict__ out, int *__restrict__ arg) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t r = e / C;
+    const int c = (int)(e - r * C);
+    const float sc = fin[2 * C + c], sh = fin[3 * C + c];
+    const float *p = y + r * ns * C + c;
+    float best = fmaxf(__fmaf_rn(p[0], sc, sh), 0.f);
+    int bi = 0;
+    for (int s = 1; s < ns; ++s) {
+      const float v = fmaxf(__fmaf_rn(p[(size_t)s * C], sc, sh), 0.f);
+      if (v > best) { best = v; bi = s; }
+    }
+    out[e] = best;
+    arg[e] = bi;
+  }
+}
+
+// Pool backward reductions: gPm = gP * [pooled > 0]; dbeta += gPm; dgamma += gPm * yhat[argmax row].
+__global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int ns, int C, const float *__restrict__ y,
+                                                           const float *__restrict__ pooled,
+                                                           const int *__restrict__ arg,
+                                                           const float *__restrict__ gP,
+                                                           const float *__restrict__ fin,
+                                                           float *__restrict__ gPm, double *__restrict__ sums) {
+  const long long r0 = (long long)blockIdx.x * 64;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mean = fin[c], rstd = fin[C + c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < 64; ++i) {
+      const long long r = r0 + i;
+      if (r >= R) break;
+      const size_t off = (size_t)r * C + c;
+      const float g = pooled[off] > 0.f ? gP[off] : 0.f;
+      gPm[off] = g;
+      const float yy = y[((size_t)r * ns + arg[off]) * C + c];
+      s1 += g;
+      s2 = __fmaf_rn(g, (yy - mean) * rstd, s2);
+    }
+    atomicAdd(sums + c, (double)s1);
+    atomicAdd(sums + C + c, (double)s2);
+  }
+}
+
+inline unsigned capped_grid(size_t work, int block = 256, unsigned cap = 8192) {
+  size_t g = (work + block - 1) / block;
+  if (g > cap) g = cap;
+  return (unsigned)(g ? g : 1);
+}
+
+template <int NT, int KC, int CW, bool MASKE>
+void launch_gemm(const GemmArgs &a, hipStream_t s) {
+  // persistent: two workgroups per CU (256 CUs), each walking tiles with stride gridDim.x;
+  // N wider than the workgroup's NT*CW column tiles is covered by column blocks (grid.y)
+  const long long ntiles = (a.M + BM - 1) / BM;
+  const unsigned ny = (unsigned)((a.N + NT * CW * 32 - 1) / (NT * CW * 32));
+  long long gx = 512 / ny;
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  dim3 grid((unsigned)gx, ny);
+  hipLaunchKernelGGL((mlp_gemm_kernel<NT, KC, CW, MASKE>), grid, dim3(256 * CW), 0, s, a);
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------- C ABI ----
+extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const float *X,
+                            const float *X2, const float *p0, const float *p1, const float *p2,
+                            const int *arg, const float *gP, int ns, const float *W, float *Y,
+                            double *stats, const float *Yprev, const float *e_fin, void *stream) {
+  if (M < 0 || K <= 0 || N <= 0 || pro < 0 || pro > 3 || epi < 0 || epi > 2) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!W || !Y) return PN2_ENULL;
+  if ((pro == PRO_NONE || pro == PRO_BNRELU || pro == PRO_GY) && !X) return PN2_ENULL;
+  if (pro != PRO_NONE && (!p0 || !p1)) return PN2_ENULL;
+  if (pro >= PRO_GY && (!X2 || !p2)) return PN2_ENULL;
+  if (pro == PRO_POOLG && (!arg || !gP || ns <= 0 || M >= 0x7fffffffLL)) return PN2_EINVAL;
+  if (epi != EPI_NONE && !stats) return PN2_ENULL;
+  if (epi == EPI_MASK && (!Yprev || !e_fin)) return PN2_ENULL;
+  if ((M + BM - 1) / BM > 0x7fffffffLL) return PN2_EINVAL;
+  GemmArgs a;
+  a.X = X; a.X2 = X2; a.p0 = p0; a.p1 = p1; a.p2 = p2; a.arg = arg; a.gP = gP; a.W = W; a.Y = Y;
+  a.stats = stats; a.Yprev = Yprev;
+  a.e_mean = e_fin; a.e_rstd = e_fin ? e_fin + N : nullptr;
+  a.e_scale = e_fin ? e_fin + 2 * (size_t)N : nullptr;
+  a.e_shift = e_fin ? e_fin + 3 * (size_t)N : nullptr;
+  a.M = M; a.K = K; a.N = N; a.ns = ns; a.pro = pro; a.epi = epi;
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = (N + 31) / 32;
+  // KC = 32 while two workgroups still fit a CU's LDS, else 16
+  const char *cfg = getenv("PN2_GEMM_CFG");   // tuning only: "a" = 4 waves x 4 tiles for N = 128
+  if (epi == EPI_MASK) {
+    // the Yprev prefetch costs 16 registers per column tile: keep <= 2 tiles per wave
+    if (tiles <= 1) launch_gemm<1, 32, 1, true>(a, s);
+    else if (tiles <= 2) launch_gemm<2, 32, 1, true>(a, s);
+    else launch_gemm<2, 32, 2, true>(a, s);            // 4 tiles per workgroup, column blocks beyond
+  } else {
+    if (tiles <= 1) launch_gemm<1, 32, 1, false>(a, s);
+    else if (tiles <= 2) launch_gemm<2, 32, 1, false>(a, s);
+    else if (tiles <= 4) {
+      if (cfg && cfg[0] == 'a') launch_gemm<4, 32, 1, false>(a, s);
+      else launch_gemm<2, 32, 2, false>(a, s);
+    }
+    else if (tiles <= 6) launch_gemm<3, 16, 2, false>(a, s);
+    else if (tiles <= 8 || tiles > 10) launch_gemm<4, 16, 2, false>(a, s);   // > 10 tiles: column blocks of 256
+    else launch_gemm<5, 16, 2, false>(a, s);
+  }
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, const float *G,
+                             const float *Yl, const float *consts /* [3][N] */, const int *arg,
+                             const float *gP, int ns, const float *X, const float *a_fin /* [4][K] or NULL */,
+                             float *dW, void *stream) {
+  if (M < 0 || N <= 0 || K <= 0 || N > WMAXN) return PN2_EINVAL;
+  if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
+  if (amode != PRO_NONE && amode != PRO_BNRELU) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Yl || !consts || !X || !dW) return PN2_ENULL;
+  if (gmode == PRO_GY && !G) return PN2_ENULL;
+  if (gmode == PRO_POOLG && (!arg || !gP || ns <= 0 || M >= 0x7fffffffLL)) return PN2_EINVAL;
+  if (amode == PRO_BNRELU && !a_fin) return PN2_ENULL;
+  WgradArgs a;
+  a.G = G; a.Yl = Yl; a.c1 = consts; a.c2 = consts + N; a.c3 = consts + 2 * (size_t)N;
+  a.arg = arg; a.gP = gP; a.X = X;
+  a.a_scale = a_fin ? a_fin + 2 * (size_t)K : nullptr;
+  a.a_shift = a_fin ? a_fin + 3 * (size_t)K : nullptr;
+  a.dW = dW; a.M = M; a.N = N; a.K = K; a.ns = ns; a.gmode = gmode; a.amode = amode;
+  // persistent-style: ~2 workgroups per CU, each a contiguous slab of rows (multiple of WR)
+  const unsigned kblocks = (unsigned)((K + WKB - 1) / WKB);
+  long long wgs = 512 / kblocks;
+  if (wgs < 1) wgs = 1;
+  long long rows = (M + wgs - 1) / wgs;
+  rows = ((rows + WR - 1) / WR) * WR;
+  a.rows_per_wg = rows;
+  const unsigned gx = (unsigned)((M + rows - 1) / rows);
+  hipStream_t s = (hipStream_t)stream;
+  const int ntiles = (N + 31) / 32;
+  dim3 grid(gx, kblocks);
+  if (ntiles <= 2) hipLaunchKernelGGL((mlp_wgrad_kernel<1>), grid, dim3(512), 0, s, a);
+  else if (ntiles <= 4) hipLaunchKernelGGL((mlp_wgrad_kernel<2>), grid, dim3(512), 0, s, a);
+  else if (ntiles <= 8) hipLaunchKernelGGL((mlp_wgrad_kernel<4>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((mlp_wgrad_kernel<5>), grid, dim3(512), 0, s, a);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_bn_finalize(int N, double count, const double *stats, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean,
+                               float *running_var, float *fin, void *stream) {
+  if (N <= 0 || !(count > 0.0)) return PN2_EINVAL;
+  if (!stats || !fin) return PN2_ENULL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N,
+                     count, stats, gamma, beta, eps, momentum, running_mean, running_var, fin);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_bn_bwd_consts(int N, double count, const double *sums, const float *gamma,
+                                 const float *fin, int use_batch_stats, float *consts, float *dgamma,
+                                 float *dbeta, void *stream) {
+  if (N <= 0 || !(count > 0.0)) return PN2_EINVAL;
+  if (!sums || !fin || !consts) return PN2_ENULL;
+  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N,
+                     count, sums, gamma, fin, use_batch_stats, consts, dgamma, dbeta);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_bn_relu_apply(long long M, int N, const float *y, const float *fin, float *out,
+                                 void *stream) {
+  if (M < 0 || N <= 0) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!y || !fin || !out) return PN2_ENULL;
+  const size_t total = (size_t)M * N;
+  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     total, N, y, fin, out);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_bn_relu_bwd_prep(long long M, int N, const float *y, const float *gout,
+                                    const float *fin, float *gpre, double *sums, void *stream) {
+  if (M < 0 || N <= 0) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!y || !gout || !fin || !gpre || !sums) return PN2_ENULL;
+  hipLaunchKernelGGL(bn_relu_bwd_prep_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, M, N, y, gout, fin, gpre, sums);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_bn_relu_rows_max(long long R, int ns, int C, const float *y, const float *fin,
+                                    float *out, int *arg, void *stream) {
+  if (R < 0 || ns <= 0 || C <= 0) return PN2_EINVAL;
+  if (R == 0) return PN2_OK;
+  if (!y || !fin || !out || !arg) return PN2_ENULL;
+  const size_t total = (size_t)R * C;
+  hipLaunchKernelGGL(bn_relu_rows_max_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     total, ns, C, y, fin, out, arg);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_pool_bwd_prep(long long R, int ns, int C, const float *y, const float *pooled,
+                                 const int *arg, const float *gP, const float *fin, float *gPm,
+                                 double *sums, void *stream) {
+  if (R < 0 || ns <= 0 || C <= 0) return PN2_EINVAL;
+  if (R == 0) return PN2_OK;
+  if (!y || !pooled || !arg || !gP || !fin || !gPm || !sums) return PN2_ENULL;
+  hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, R, ns, C, y, pooled, arg, gP, fin, gPm, sums);
+  return pn2_check_launch();
+}

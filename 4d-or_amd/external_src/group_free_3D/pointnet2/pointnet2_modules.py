@@ -50,11 +50,8 @@ class PointnetSAModuleVotes(nn.Module):
                 xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
 
         if self.pooling == "max" and _pm._rows_path_ok(xyz, features):
-            B = xyz.size(0)
             g = self.grouper.forward_rows(xyz, new_xyz, pointnet2_utils.as_rows(features))
-            _, npoint, nsample, width = g.shape
-            h = _pm.shared_mlp_rows(self.mlp_module, g.reshape(-1, width))
-            rows = pointnet2_utils.rows_max(h.view(B * npoint, nsample, -1)).view(B, npoint, -1)
+            rows = _pm.mlp_pool_rows(self.mlp_module, g)
             return new_xyz, pointnet2_utils.rows_to_channels(rows), inds
 
         grouped, grouped_xyz = self.grouper(xyz, new_xyz, features)

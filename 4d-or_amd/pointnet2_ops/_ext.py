@@ -58,6 +58,14 @@ _SIGNATURES = {
     "pn2_gather_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_scatter_add_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_segment_sum_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_mlp_gemm": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
+    "pn2_mlp_wgrad": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
+    "pn2_bn_finalize": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_bn_bwd_consts": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_bn_relu_apply": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_bn_relu_bwd_prep": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_bn_relu_rows_max": [ctypes.c_longlong, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_pool_bwd_prep": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 8,
 }
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here == ABI mismatch: fail loudly
@@ -77,6 +85,8 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
 HAS_ROWS = True
+#: ... and the fused MFMA shared-MLP kernels (pn2_mlp_* / pn2_bn_*)
+HAS_FUSED_MLP = True
 
 
 # --------------------------------------------------------------------------- checks
@@ -132,23 +142,24 @@ class KernelTimer:
     stream the kernels are enqueued on, resolved lazily by `summary()` after a sync."""
 
     def __init__(self):
-        self.records = []          # (name, start_event, end_event, algorithmic_bytes)
+        self.records = []          # (name, start_event, end_event, algorithmic_bytes, algorithmic_flops)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, s, e, nbytes in self.records:
-            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "alg_bytes": 0})
+        for name, s, e, nbytes, nflops in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "alg_bytes": 0, "alg_flops": 0})
             d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
             d["alg_bytes"] += nbytes
+            d["alg_flops"] += nflops
         return out
 
 
 TIMER = None  # set to a KernelTimer() to profile
 
 
-def _call(name, ref, *args, alg_bytes=0):
+def _call(name, ref, *args, alg_bytes=0, alg_flops=0):
     """Enqueue `name` on the current stream of `ref`'s device."""
     with torch.cuda.device(ref.device):
         stream = torch.cuda.current_stream(ref.device).cuda_stream
@@ -157,7 +168,7 @@ def _call(name, ref, *args, alg_bytes=0):
             ev0.record()
             rc = getattr(_lib, name)(*args, stream)
             ev1.record()
-            TIMER.records.append((name, ev0, ev1, int(alg_bytes)))
+            TIMER.records.append((name, ev0, ev1, int(alg_bytes), int(alg_flops)))
         else:
             rc = getattr(_lib, name)(*args, stream)
     if rc != 0:
@@ -418,3 +429,92 @@ def segment_sum_rows(src, order, rowptr, dim_size, h=None, col0=0):
     _call("pn2_segment_sum_rows", src, E, h, int(dim_size), lds, int(col0),
           _ptr(src), _ptr(order), _ptr(rowptr), _ptr(out), alg_bytes=4 * E * h + 16 * E + 4 * int(dim_size) * h)
     return out
+
+
+# ---------------------------------------------- fused shared-MLP kernels (A10)
+PRO_NONE, PRO_BNRELU, PRO_GY, PRO_POOLG = 0, 1, 2, 3
+EPI_NONE, EPI_STATS, EPI_MASK = 0, 1, 2
+
+
+def mlp_gemm(X, W, pro=PRO_NONE, epi=EPI_NONE, X2=None, p=None, arg=None, gP=None, ns=0,
+             stats=None, Yprev=None, e_fin=None, M=None):
+    """Y (M,N) = pro(X) (M,K) @ W (N,K)^T with fused prologue / epilogue (include/pn2_hip.h).
+    `p` = (p0, p1[, p2]) per-K vectors; `stats` (2,N) float64 is accumulated into."""
+    _f32(W, "W")
+    N, K = W.shape
+    ref = X if X is not None else X2
+    M = int(M if M is not None else ref.size(0))
+    Y = torch.empty(M, N, dtype=torch.float32, device=W.device)
+    p0 = p1 = p2 = None
+    if p is not None:
+        p0, p1 = p[0], p[1]
+        p2 = p[2] if len(p) > 2 else None
+    flops = 2 * M * N * K
+    nbytes = 4 * (M * K * (2 if pro >= PRO_GY else 1) + M * N * (2 if epi == EPI_MASK else 1) + N * K)
+    _call("pn2_mlp_gemm", W, M, K, N, int(pro), int(epi), _ptr(X), _ptr(X2), _ptr(p0), _ptr(p1), _ptr(p2),
+          _ptr(arg), _ptr(gP), int(ns), _ptr(W), _ptr(Y), _ptr(stats), _ptr(Yprev), _ptr(e_fin),
+          alg_bytes=nbytes, alg_flops=flops)
+    return Y
+
+
+def mlp_wgrad(Yl, consts, X, gmode, amode, G=None, arg=None, gP=None, ns=0, a_fin=None):
+    """dW (N,K) = gy^T @ act, gy/act formed on the fly (include/pn2_hip.h)."""
+    M, N = Yl.shape
+    K = X.size(1)
+    dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
+    _call("pn2_mlp_wgrad", Yl, M, N, K, int(gmode), int(amode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg),
+          _ptr(gP), int(ns), _ptr(X), _ptr(a_fin), _ptr(dW),
+          alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + M * K + N * K), alg_flops=2 * M * N * K)
+    return dW
+
+
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
+    N = stats.size(1)
+    fin = torch.empty(4, N, dtype=torch.float32, device=stats.device)
+    _call("pn2_bn_finalize", stats, N, float(count), _ptr(stats), _ptr(gamma), _ptr(beta), float(eps),
+          float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(fin))
+    return fin
+
+
+def bn_bwd_consts(sums, count, gamma, fin, use_batch_stats, want_param_grads=True):
+    N = sums.size(1)
+    consts = torch.empty(3, N, dtype=torch.float32, device=sums.device)
+    dgamma = torch.empty(N, dtype=torch.float32, device=sums.device) if want_param_grads else None
+    dbeta = torch.empty(N, dtype=torch.float32, device=sums.device) if want_param_grads else None
+    _call("pn2_bn_bwd_consts", sums, N, float(count), _ptr(sums), _ptr(gamma), _ptr(fin), int(bool(use_batch_stats)),
+          _ptr(consts), _ptr(dgamma), _ptr(dbeta))
+    return consts, dgamma, dbeta
+
+
+def bn_relu_apply(y, fin):
+    M, N = y.shape
+    out = torch.empty_like(y)
+    _call("pn2_bn_relu_apply", y, M, N, _ptr(y), _ptr(fin), _ptr(out), alg_bytes=8 * M * N)
+    return out
+
+
+def bn_relu_bwd_prep(y, gout, fin):
+    M, N = y.shape
+    gpre = torch.empty_like(y)
+    sums = torch.zeros(2, N, dtype=torch.float64, device=y.device)
+    _call("pn2_bn_relu_bwd_prep", y, M, N, _ptr(y), _ptr(gout), _ptr(fin), _ptr(gpre), _ptr(sums), alg_bytes=12 * M * N)
+    return gpre, sums
+
+
+def bn_relu_rows_max(y, fin, ns):
+    M, C = y.shape
+    R = M // int(ns)
+    out = torch.empty(R, C, dtype=torch.float32, device=y.device)
+    arg = torch.empty(R, C, dtype=torch.int32, device=y.device)
+    _call("pn2_bn_relu_rows_max", y, R, int(ns), C, _ptr(y), _ptr(fin), _ptr(out), _ptr(arg),
+          alg_bytes=4 * M * C + 8 * R * C)
+    return out, arg
+
+
+def pool_bwd_prep(y, pooled, arg, gP, fin, ns):
+    R, C = pooled.shape
+    gPm = torch.empty_like(pooled)
+    sums = torch.zeros(2, C, dtype=torch.float64, device=y.device)
+    _call("pn2_pool_bwd_prep", y, R, int(ns), C, _ptr(y), _ptr(pooled), _ptr(arg), _ptr(gP), _ptr(fin), _ptr(gPm),
+          _ptr(sums), alg_bytes=20 * R * C)
+    return gPm, sums

@@ -1,0 +1,169 @@
+"""Fused shared-MLP (+ neighbourhood max) on the fp32 MFMA kernels of libpn2_hip.so.
+
+Runs a ``build_shared_mlp`` stack — [Conv2d 1x1 (bias=False), BatchNorm2d, ReLU] x L
+(OPS/pointnet2_modules.py:9-19) — on point-major rows, optionally followed by the max
+over each group of ``ns`` consecutive rows (``F.max_pool2d``, :67-70), with the
+BatchNorm statistics, normalisation, ReLU and their backward folded into the GEMM
+prologues / epilogues (csrc/mlp_gemm.hip).  Per layer the forward is one kernel
+(+ a 1-block finalisation), the backward two (wgrad, dgrad); only the raw pre-BN
+outputs ``y_l`` are ever written to HBM.
+
+Semantics are those of the torch modules the parameters live in: training mode uses
+batch statistics (biased variance) and updates ``running_mean`` / ``running_var``
+(unbiased) / ``num_batches_tracked`` with the module's momentum; eval mode uses the
+running statistics.  Gradients are produced for the input rows, the conv weights and
+the BatchNorm affine parameters.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from pointnet2_ops import pointnet2_utils as _pu
+
+
+def _ext():
+    return _pu._ext
+
+
+def parse_stack(mlp: nn.Module) -> Optional[List[Tuple[nn.Conv2d, nn.modules.batchnorm._BatchNorm]]]:
+    """Flatten `mlp` into [(conv1x1, bn), ...] if it is exactly (conv, bn, relu)*; else None."""
+    flat = []
+
+    def walk(m):
+        if isinstance(m, nn.Sequential):
+            for c in m:
+                walk(c)
+        else:
+            flat.append(m)
+
+    walk(mlp)
+    if not flat or len(flat) % 3:
+        return None
+    layers = []
+    for i in range(0, len(flat), 3):
+        conv, bn, act = flat[i:i + 3]
+        ok = (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.bias is None
+              and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+              and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.affine
+              and bn.num_features == conv.out_channels and isinstance(act, nn.ReLU))
+        if not ok:
+            return None
+        layers.append((conv, bn))
+    return layers
+
+
+def supported(mlp: nn.Module, x: torch.Tensor) -> bool:
+    e = _ext()
+    if not getattr(e, "HAS_FUSED_MLP", False) or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    layers = parse_stack(mlp)
+    if layers is None:
+        return False
+    return all(conv.out_channels <= 320 for conv, _ in layers)
+
+
+class _FusedMLP(Function):
+    @staticmethod
+    def forward(ctx, x, ns, layers, *params):
+        """x (M,K0) rows; ns > 0 pools groups of ns rows; layers [(conv, bn)];
+        params = (W_1, gamma_1, beta_1, W_2, ...) only so autograd tracks them."""
+        e = _ext()
+        x = x.contiguous()
+        M = x.size(0)
+        L = len(layers)
+        ys, fins, batch_flags = [], [], []
+        cur = x
+        for l, (conv, bn) in enumerate(layers):
+            W = params[3 * l].view(conv.out_channels, conv.in_channels)
+            gamma, beta = params[3 * l + 1], params[3 * l + 2]
+            use_batch = bn.training or bn.running_mean is None
+            pro = e.PRO_NONE if l == 0 else e.PRO_BNRELU
+            p = None if l == 0 else (fins[-1][2], fins[-1][3])
+            if use_batch:
+                stats = torch.zeros(2, conv.out_channels, dtype=torch.float64, device=x.device)
+                y = e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
+                momentum = 0.0
+                rm = rv = None
+                if bn.training and bn.track_running_stats and bn.running_mean is not None:
+                    rm, rv = bn.running_mean, bn.running_var
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
+                    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv)
+            else:
+                y = e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
+                rstd = torch.rsqrt(bn.running_var + bn.eps)
+                scale = gamma * rstd
+                fin = torch.stack([bn.running_mean, rstd, scale, beta - bn.running_mean * scale]).contiguous()
+            ys.append(y)
+            fins.append(fin)
+            batch_flags.append(use_batch)
+            cur = y
+        if ns:
+            out, arg = e.bn_relu_rows_max(ys[-1], fins[-1], ns)
+        else:
+            out, arg = e.bn_relu_apply(ys[-1], fins[-1]), None
+        ctx.ns, ctx.L, ctx.batch_flags = ns, L, batch_flags
+        ctx.shapes = [params[3 * l].shape for l in range(L)]
+        saved = [x] + ys + fins + [params[3 * l] for l in range(L)] + [params[3 * l + 1] for l in range(L)]
+        if ns:
+            saved += [out, arg]
+            ctx.mark_non_differentiable(arg)
+        ctx.save_for_backward(*saved)
+        return (out, arg) if ns else out
+
+    @staticmethod
+    def backward(ctx, g_out, *unused):
+        e = _ext()
+        L, ns = ctx.L, ctx.ns
+        saved = ctx.saved_tensors
+        x = saved[0]
+        ys = saved[1:1 + L]
+        fins = saved[1 + L:1 + 2 * L]
+        Ws = [w.view(w.size(0), w.size(1)) for w in saved[1 + 2 * L:1 + 3 * L]]
+        gammas = saved[1 + 3 * L:1 + 4 * L]
+        M = x.size(0)
+        g_out = g_out.contiguous()
+
+        if ns:
+            pooled, arg = saved[1 + 4 * L], saved[2 + 4 * L]
+            gPm, sums = e.pool_bwd_prep(ys[-1], pooled, arg, g_out, fins[-1], ns)
+            gmode, G = e.PRO_POOLG, None
+        else:
+            G, sums = e.bn_relu_bwd_prep(ys[-1], g_out, fins[-1])
+            gmode, arg, gPm = e.PRO_GY, None, None
+
+        grads = [None] * (3 * L)
+        gx = None
+        for l in range(L - 1, -1, -1):
+            consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
+            act = x if l == 0 else ys[l - 1]
+            dW = e.mlp_wgrad(ys[l], consts, act, gmode, e.PRO_NONE if l == 0 else e.PRO_BNRELU,
+                             G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1])
+            grads[3 * l] = dW.view(ctx.shapes[l])
+            grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            need_dgrad = l > 0 or ctx.needs_input_grad[0]
+            if need_dgrad:
+                Wt = Ws[l].t().contiguous()                       # (K_l, N_l): dgrad is out[M,K_l] = gy[M,N_l] @ Wt^T
+                p = (consts[0], consts[1], consts[2])
+                if l > 0:
+                    sums = torch.zeros(2, Wt.size(0), dtype=torch.float64, device=x.device)
+                    Gn = e.mlp_gemm(G, Wt, pro=gmode, epi=e.EPI_MASK, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns,
+                                    stats=sums, Yprev=ys[l - 1], e_fin=fins[l - 1], M=M)
+                    G, gmode, arg, gPm = Gn, e.PRO_GY, None, None
+                else:
+                    gx = e.mlp_gemm(G, Wt, pro=gmode, epi=e.EPI_NONE, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns, M=M)
+        return (gx, None, None, *grads)
+
+
+def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0) -> torch.Tensor:
+    """x (M, C_in) rows -> (M, C_out) [ns == 0] or (M // ns, C_out) max-pooled over groups of ns rows."""
+    layers = parse_stack(mlp)
+    assert layers is not None, "fused_shared_mlp: unsupported stack (call supported() first)"
+    params = []
+    for conv, bn in layers:
+        params += [conv.weight, bn.weight, bn.bias]
+    res = _FusedMLP.apply(x, int(ns), layers, *params)
+    return res[0] if ns else res

@@ -89,6 +89,35 @@ def shared_mlp_rows(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+_FUSED_MLP = True
+
+
+def set_fused_mlp(enabled: bool) -> bool:
+    """Switch the fused MFMA shared-MLP kernels on/off (off = torch GEMM/BN/ReLU on rows)."""
+    global _FUSED_MLP
+    prev, _FUSED_MLP = _FUSED_MLP, bool(enabled)
+    return prev
+
+
+def mlp_rows(mlp: nn.Module, rows: torch.Tensor) -> torch.Tensor:
+    """(M, C_in) -> (M, C_out) through a shared MLP, fused kernels when the stack allows."""
+    from pointnet2_ops import fused_mlp
+    if _FUSED_MLP and fused_mlp.supported(mlp, rows):
+        return fused_mlp.fused_shared_mlp(mlp, rows, 0)
+    return shared_mlp_rows(mlp, rows)
+
+
+def mlp_pool_rows(mlp: nn.Module, grouped: torch.Tensor) -> torch.Tensor:
+    """grouped (B, npoint, nsample, C_in) -> (B, npoint, C_out): shared MLP then max over nsample."""
+    from pointnet2_ops import fused_mlp
+    B, npoint, nsample, width = grouped.shape
+    rows = grouped.reshape(-1, width)
+    if _FUSED_MLP and fused_mlp.supported(mlp, rows):
+        return fused_mlp.fused_shared_mlp(mlp, rows, nsample).view(B, npoint, -1)
+    h = shared_mlp_rows(mlp, rows)
+    return pointnet2_utils.rows_max(h.view(B * npoint, nsample, -1)).view(B, npoint, -1)
+
+
 def _rows_path_ok(xyz: torch.Tensor, features: Optional[torch.Tensor]) -> bool:
     if not _FAST_PATH or not getattr(pointnet2_utils._ext, "HAS_ROWS", False):
         return False
@@ -133,9 +162,7 @@ class _PointnetSAModuleBase(nn.Module):
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             g = grouper.forward_rows(xyz, new_xyz, feats_rows)  # (B, npoint, nsample, W)
-            _, npoint, nsample, width = g.shape
-            h = shared_mlp_rows(mlp, g.reshape(-1, width))      # (B*npoint*nsample, C_out)
-            pooled.append(pointnet2_utils.rows_max(h.view(B * npoint, nsample, -1)).view(B, npoint, -1))
+            pooled.append(mlp_pool_rows(mlp, g))                # (B, npoint, C_out)
         rows = pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=2)
         return pointnet2_utils.rows_to_channels(rows)           # (B, sum C_out, npoint) view
 
@@ -206,5 +233,5 @@ class PointnetFPModule(nn.Module):
             spread = known_rows.expand(B, n, known_rows.size(2))
         if unknow_feats is not None:
             spread = torch.cat([spread, pointnet2_utils.as_rows(unknow_feats)], dim=2)
-        h = shared_mlp_rows(self.mlp, spread.reshape(B * n, -1))
+        h = mlp_rows(self.mlp, spread.reshape(B * n, -1))
         return pointnet2_utils.rows_to_channels(h.view(B, n, -1))

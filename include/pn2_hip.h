@@ -169,6 +169,52 @@ int pn2_three_interpolate_rows_grad(int B, int C, int m, int n, int ldg,
                                     const int *idx, const float *weight,
                                     float *grad_feats, void *stream);
 
+
+/* ------------------------------------------------------------------ A10 ---
+ * Shared per-point MLP (nn.Conv2d 1x1 bias=False + BatchNorm2d + ReLU per layer,
+ * OPS/pointnet2_modules.py:9-19, then F.max_pool2d :67-70) as fused fp32-MFMA
+ * kernels on point-major rows.  One layer's forward is ONE kernel:
+ *
+ *   pn2_mlp_gemm:  Y[M][N] = pro(X)[M][K] * W[N][K]^T, optional epilogue reductions.
+ *     pro: 0 none | 1 relu(X*p0[k]+p1[k]) | 2 p0[k]*X + p1[k]*X2 + p2[k]
+ *          | 3 like 2 with X gathered from the pooled gradient: (arg[row/ns][k]==row%ns) ? gP[row/ns][k] : 0
+ *     epi: 0 none | 1 stats[0][n] += sum Y, stats[1][n] += sum Y^2  (fp64, ACCUMULATES)
+ *          | 2 Y *= [Yprev*scale+shift > 0]; stats[0][n] += sum Y; stats[1][n] += sum Y*(Yprev-mean)*rstd
+ *     e_fin = [mean | rstd | scale | shift] x N of the layer that produced Yprev.
+ *   pn2_mlp_wgrad: dW[N][K] += sum_r gy[r][n] * act[r][k] (ACCUMULATES, fp32 atomics), with
+ *     gy = c1[n]*g + c2[n]*Yl + c3[n] (g = G, or gathered from gP/arg when gmode == 3) and
+ *     act = X (amode 0) or relu(X*scale[k]+shift[k]) (amode 1, a_fin like e_fin for K columns).  N <= 320.
+ *   pn2_bn_finalize: batch sums -> fin = [mean|rstd|gamma*rstd|beta-mean*gamma*rstd]; updates the
+ *     running statistics exactly like torch's _BatchNorm (momentum, unbiased variance) when non-NULL.
+ *   pn2_bn_bwd_consts: epilogue sums (dbeta, dgamma) -> consts [c1|c2|c3] x N (+ fp32 dgamma, dbeta).
+ *   pn2_bn_relu_apply / pn2_bn_relu_bwd_prep: materialised ReLU(BN(y)) and its backward prep
+ *     (gpre = gout*[z>0], sums ACCUMULATE) for stacks that must return activations (FP modules).
+ *   pn2_bn_relu_rows_max / pn2_pool_bwd_prep: ReLU(BN(y)) fused into the neighbourhood max
+ *     (+ first arg-max) and the matching backward reductions (gPm = gP*[pooled>0]).
+ */
+int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const float *X, const float *X2,
+                 const float *p0, const float *p1, const float *p2, const int *arg,
+                 const float *gP, int ns, const float *W, float *Y, double *stats,
+                 const float *Yprev, const float *e_fin, void *stream);
+int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, const float *G,
+                  const float *Yl, const float *consts, const int *arg, const float *gP, int ns,
+                  const float *X, const float *a_fin, float *dW, void *stream);
+int pn2_bn_finalize(int N, double count, const double *stats, const float *gamma,
+                    const float *beta, float eps, float momentum, float *running_mean,
+                    float *running_var, float *fin, void *stream);
+int pn2_bn_bwd_consts(int N, double count, const double *sums, const float *gamma,
+                      const float *fin, int use_batch_stats, float *consts, float *dgamma,
+                      float *dbeta, void *stream);
+int pn2_bn_relu_apply(long long M, int N, const float *y, const float *fin, float *out,
+                      void *stream);
+int pn2_bn_relu_bwd_prep(long long M, int N, const float *y, const float *gout,
+                         const float *fin, float *gpre, double *sums, void *stream);
+int pn2_bn_relu_rows_max(long long R, int ns, int C, const float *y, const float *fin,
+                         float *out, int *arg, void *stream);
+int pn2_pool_bwd_prep(long long R, int ns, int C, const float *y, const float *pooled,
+                      const int *arg, const float *gP, const float *fin, float *gPm,
+                      double *sums, void *stream);
+
 /* ------------------------------------------------------------------ A12 ---
  * TripletGCN edge primitives.  Replace torch_geometric 2.0.2
  * MessagePassing.__lift__ (x.index_select(-2, edge_index[i])) and

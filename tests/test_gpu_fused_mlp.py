@@ -1,0 +1,78 @@
+"""Fused fp32-MFMA shared-MLP kernels (csrc/mlp_gemm.hip) against the torch ops they
+replace (Linear/BatchNorm/ReLU/max on the same rows, same parameters): forward,
+running statistics, and every gradient."""
+import copy
+
+import pytest
+import torch
+
+from pointnet2_ops import pointnet2_modules as pm
+
+pytestmark = pytest.mark.gpu
+
+
+def _mlp(spec, seed):
+    torch.manual_seed(seed)
+    m = pm.build_shared_mlp(list(spec)).cuda()
+    with torch.no_grad():
+        for layer in m:
+            if isinstance(layer, torch.nn.BatchNorm2d):
+                layer.weight.uniform_(0.5, 1.5)
+                layer.bias.uniform_(-0.3, 0.3)
+                layer.running_mean.uniform_(-0.2, 0.2)
+                layer.running_var.uniform_(0.5, 1.5)
+    return m
+
+
+def _run(mlp, x, ns, fused, train):
+    m = copy.deepcopy(mlp)
+    m.train(train)
+    prev = pm.set_fused_mlp(fused)
+    try:
+        xx = x.clone().requires_grad_(True)
+        if ns:
+            R = x.size(0) // ns
+            out = pm.mlp_pool_rows(m, xx.view(1, R, ns, -1)).view(R, -1)
+        else:
+            out = pm.mlp_rows(m, xx)
+        w = torch.linspace(0.5, 1.5, out.numel(), device=out.device).view_as(out)
+        (out * w).sum().backward()
+        return out.detach(), xx.grad, [p.grad for p in m.parameters()], m.state_dict()
+    finally:
+        pm.set_fused_mlp(prev)
+
+
+CASES = [((6, 64, 64, 128), 64 * 40, 64), ((131, 128, 128, 256), 32 * 50, 32), ((259, 128, 128, 256), 16 * 70, 16),
+         ((512, 256, 288), 1000, 0), ((512, 256, 256), 777, 0), ((5, 16), 300, 0), ((9, 32, 40), 24 * 12, 12),
+         ((259, 256, 256), 3 * 128, 128)]
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("spec,M,ns", CASES)
+def test_fused_matches_torch(spec, M, ns, train):
+    mlp = _mlp(spec, seed=len(spec) + M)
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, spec[0], generator=g).cuda()
+    o0, gx0, gp0, sd0 = _run(mlp, x, ns, fused=False, train=train)
+    o1, gx1, gp1, sd1 = _run(mlp, x, ns, fused=True, train=train)
+    torch.testing.assert_close(o1, o0, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(gx1, gx0, atol=1e-4, rtol=1e-3)
+    for a, b in zip(gp1, gp0):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-5, (a - b).abs().max()
+    for k in sd0:
+        torch.testing.assert_close(sd1[k].float(), sd0[k].float(), atol=1e-5, rtol=1e-4)
+
+
+def test_full_size_sa1_layer_statistics_and_throughput_shape():
+    """BASELINE size: 32x2048x64 rows through the SA1 stack; checks the batch statistics path at
+    4.2M rows (fp64 accumulation) against torch."""
+    mlp = _mlp((6, 64, 64, 128), seed=3)
+    x = torch.randn(32 * 2048 * 64, 6, device="cuda")
+    o0, _, gp0, sd0 = _run(mlp, x, 64, fused=False, train=True)
+    o1, _, gp1, sd1 = _run(mlp, x, 64, fused=True, train=True)
+    torch.testing.assert_close(o1, o0, atol=2e-4, rtol=1e-3)
+    for k in sd0:
+        torch.testing.assert_close(sd1[k].float(), sd0[k].float(), atol=1e-5, rtol=1e-4)
+    for a, b in zip(gp1, gp0):
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < 5e-3

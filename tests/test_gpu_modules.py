@@ -36,8 +36,8 @@ def _check(module, inputs):
         got = _run(module, inputs, "cuda", _ext, fast=fast)
         torch.testing.assert_close(got[0], ref[0], atol=1e-4, rtol=1e-4)
         torch.testing.assert_close(got[1], ref[1], atol=1e-4, rtol=1e-3)
-        for a, b in zip(got[2], ref[2]):
-            torch.testing.assert_close(a, b, atol=2e-4, rtol=1e-3)
+        for a, b in zip(got[2], ref[2]):      # parameter grads: sums over 10^4..10^5 rows (atomics reorder them)
+            assert float((a - b).abs().max()) <= 5e-4 * float(b.abs().max()) + 1e-5, (a - b).abs().max()
 
 
 def _cloud(B, N, C, seed):

@@ -64,11 +64,46 @@ def fps_sweep(dev):
     os.environ.pop("PN2_FPS_G", None)
 
 
+def mlp_sweep(dev):
+    """Per-shape time of the fused MFMA shared-MLP kernels (fwd / dgrad / wgrad), TF/s and GB/s."""
+    B = int(os.environ.get("MB_B", 32))
+    shapes = [  # (name, M, K, N)
+        ("sa1.l1", B * 2048 * 64, 6, 64), ("sa1.l2", B * 2048 * 64, 64, 64), ("sa1.l3", B * 2048 * 64, 64, 128),
+        ("sa2.l1", B * 1024 * 32, 131, 128), ("sa2.l2", B * 1024 * 32, 128, 128), ("sa2.l3", B * 1024 * 32, 128, 256),
+        ("sa3.l1", B * 512 * 16, 259, 128), ("sa3.l3", B * 512 * 16, 128, 256),
+        ("fp2.l1", B * 1024, 512, 256), ("fp2.l2", B * 1024, 256, 288)]
+    for name, M, K, N in shapes:
+        x = torch.randn(M, K, device=dev)
+        W = torch.randn(N, K, device=dev) * 0.1
+        p = (torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1, torch.randn(K, device=dev) * 0.1)
+        stats = torch.zeros(2, N, dtype=torch.float64, device=dev)
+        fl = 2.0 * M * K * N
+        t = timeit(lambda: _ext.mlp_gemm(x, W, pro=_ext.PRO_BNRELU, epi=_ext.EPI_STATS, p=p, stats=stats), iters=5)
+        report(f"mlp_fwd {name} M{M} K{K} N{N}", t, 4 * (M * K + M * N), TFps=round(fl / t / 1e12, 1))
+        # dgrad: out[M,K] = gy[M,N] @ Wt[K,N]^T with GY prologue + MASK epilogue
+        g = torch.randn(M, N, device=dev)
+        y = torch.randn(M, N, device=dev)
+        c = (torch.rand(N, device=dev), torch.randn(N, device=dev) * 0.1, torch.randn(N, device=dev) * 0.1)
+        Wt = W.t().contiguous()
+        fin = torch.rand(4, K, device=dev)
+        s2 = torch.zeros(2, K, dtype=torch.float64, device=dev)
+        t = timeit(lambda: _ext.mlp_gemm(g, Wt, pro=_ext.PRO_GY, epi=_ext.EPI_MASK, X2=y, p=c, stats=s2, Yprev=x,
+                                         e_fin=fin), iters=5)
+        report(f"mlp_dgrad {name}", t, 4 * (2 * M * N + 2 * M * K), TFps=round(fl / t / 1e12, 1))
+        consts = torch.stack(c).contiguous()
+        t = timeit(lambda: _ext.mlp_wgrad(y, consts, x, _ext.PRO_GY, _ext.PRO_BNRELU, G=g, a_fin=fin), iters=5)
+        report(f"mlp_wgrad {name}", t, 4 * (2 * M * N + M * K), TFps=round(fl / t / 1e12, 1))
+        del x, g, y
+
+
 def main():
     B = int(os.environ.get("MB_B", 32))
     N = int(os.environ.get("MB_N", 50000))
     m, ns, r, C = 2048, 64, 0.2, 3
     dev = torch.device("cuda:0")
+    if os.environ.get("MB_MLP") == "1":
+        mlp_sweep(dev)
+        return
     if os.environ.get("MB_FPS_SWEEP") == "1":
         fps_sweep(dev)
         return
