@@ -70,8 +70,16 @@ constexpr int BM = 128;
 // NT column tiles wc*NT.. (CW = 2 keeps N = 256/288 at 64-80 accumulator registers per wave).
 // MASKE: the EPI_MASK variant; it prefetches the Yprev tile into registers behind the last
 // chunk's MFMAs so the epilogue never waits on HBM.
+// Occupancy target (waves per SIMD) by variant: small accumulator footprints are capped at 128
+// VGPRs so that TWO 8-wave workgroups (or four 4-wave ones) are resident per CU and one
+// workgroup's barriers / epilogue overlap the other's MFMAs.
+template <int NT, int CW, bool MASKE>
+constexpr int gemm_min_waves() {
+  return 2;   // measured: forcing 4 (<= 128 VGPRs) for the small variants changes nothing
+}
+
 template <int NT, int KC, int CW, bool MASKE>
-__global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, MASKE>())) void mlp_gemm_kernel(const GemmArgs a) {
   constexpr int THREADS = 256 * CW;
   constexpr int NTT = NT * CW;                // column tiles per workgroup
   constexpr int LD = KC + 1;

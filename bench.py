@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md chip table (spec; ~6300 achievable)
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA (= fp32 vector peak), same table
 
 
 def synthetic_scenes(batch, points, seed, device):
@@ -172,25 +173,39 @@ def main():
         if timer is not None:
             table = timer.summary()
             rows = []
+            ridge = F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)     # flop/byte where the rooflines cross
             for name, d in table.items():
                 per_launch_ms = d["ms"] / d["calls"]
                 per_launch_bytes = d["alg_bytes"] / d["calls"]
+                per_launch_flops = d["alg_flops"] / d["calls"]
                 gbps = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+                tfps = per_launch_flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+                mfma_bound = per_launch_bytes > 0 and per_launch_flops / per_launch_bytes >= ridge
                 rows.append({"kernel": name, "calls_per_step": d["calls"] / args.steps,
                              "ms_per_step": round(d["ms"] / args.steps, 4),
                              "avg_launch_us": round(per_launch_ms * 1e3, 2),
                              "alg_MB_per_launch": round(per_launch_bytes / 1e6, 3),
-                             "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 5)})
+                             "alg_GFLOP_per_launch": round(per_launch_flops / 1e9, 3),
+                             "GBps": round(gbps, 1), "TFLOPps": round(tfps, 2),
+                             "bound": "mfma" if mfma_bound else "hbm",
+                             "frac": round(tfps / F32_MFMA_PEAK_TFLOPS if mfma_bound else gbps / HBM_PEAK_GBPS, 5)})
             rows.sort(key=lambda r: -r["ms_per_step"])
             out["kernels"] = rows
             hip_ms = sum(r["ms_per_step"] for r in rows)
             out["hip_kernel_ms_per_step"] = round(hip_ms, 3)
             if rows:
                 top = rows[0]
-                out["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
-                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"], "traffic": None,
-                                   "avg_launch_us": top["avg_launch_us"],
-                                   "alg_bytes_per_launch": int(top["alg_MB_per_launch"] * 1e6)}
+                if top["bound"] == "mfma":
+                    out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["TFLOPps"],
+                                       "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac"]}
+                else:
+                    out["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
+                                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"]}
+                out["roofline"].update({"traffic": None, "avg_launch_us": top["avg_launch_us"],
+                                        "alg_bytes_per_launch": int(top["alg_MB_per_launch"] * 1e6),
+                                        "alg_flops_per_launch": int(top["alg_GFLOP_per_launch"] * 1e9),
+                                        "note": "entry point aggregated over its launches in the timed steps "
+                                                "(shapes differ per layer; per-shape table: tools/microbench.py MB_MLP=1)"})
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 64)
             try:

@@ -1,0 +1,74 @@
+"""Multi-process path on CPU: 2 ranks, gloo, each rank its own scenes (weak scaling),
+gradients all-reduced by DDP exactly like bench.py does over RCCL.  Checks that the
+averaged gradients equal a single-process run over the concatenated batch *per rank
+statistics* (BatchNorm stays per rank: no SyncBN), and that parameters stay in sync."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path[:0] = [os.path.join(REPO, "4d-or_amd"), REPO, os.path.join(REPO, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_ext
+    from pointnet2_ops import pointnet2_modules as pm, pointnet2_utils as pu
+    pu._ext = oracle_ext.OracleRowsExt
+    torch.manual_seed(0)                       # identical initial weights on every rank
+    net = torch.nn.ModuleList([
+        pm.PointnetSAModuleMSG(npoint=32, radii=[0.3, 0.6], nsamples=[4, 8], mlps=[[3, 8, 8], [3, 8, 16]]),
+        pm.PointnetFPModule(mlp=[24 + 3, 16]),
+    ])
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.sa, self.fp = net[0], net[1]
+
+        def forward(self, pc):
+            xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+            nx, nf = self.sa(xyz, feats)
+            return self.fp(xyz, nx, feats, nf)
+
+    model = Net()
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(100 + rank)          # different scenes per rank
+    pc = torch.rand(2, 200, 6, generator=g) * 2 - 1
+    local = Net()
+    local.load_state_dict(model.state_dict())
+    local(pc).square().mean().backward()                    # this rank's own gradient, no communication
+    local_grads = [p.grad.clone() for p in local.parameters()]
+    for _ in range(2):
+        opt.zero_grad()
+        ddp(pc).square().mean().backward()
+        if _ == 0:
+            first = [p.grad.clone() for p in model.parameters()]
+        opt.step()
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    lg = torch.cat([x.flatten() for x in local_grads])
+    lgs = [torch.zeros_like(lg) for _ in range(world)]
+    dist.all_gather(lgs, lg)
+    if rank == 0:
+        torch.save({"params": gathered, "ddp_grad": torch.cat([x.flatten() for x in first]), "local_grads": lgs}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["params"][0], res["params"][1])                    # ranks stay in sync
+    mean_local = (res["local_grads"][0] + res["local_grads"][1]) / 2          # DDP averages gradients
+    torch.testing.assert_close(res["ddp_grad"], mean_local, atol=1e-6, rtol=1e-5)

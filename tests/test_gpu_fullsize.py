@@ -1,0 +1,63 @@
+"""BASELINE-size checks through size-independent properties (the oracle would take
+minutes at these sizes): configs[1] (32 x 50 000 points) and the 200k-point stress cloud."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def unit_ball(B, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.randn(B, N, 3, generator=g)
+    p = p / p.norm(dim=2, keepdim=True) * torch.rand(B, N, 1, generator=g).pow(1 / 3)
+    p = p - p.mean(dim=1, keepdim=True)
+    return (p / p.norm(dim=2).amax(dim=1).view(B, 1, 1)).contiguous().cuda()
+
+
+@pytest.mark.parametrize("B,N,m", [(32, 50000, 2048), (2, 200000, 512)])
+def test_fps_properties(monkeypatch, B, N, m):
+    from pointnet2_ops import _ext
+    monkeypatch.setenv("PN2_FPS_CHECK", "1")
+    xyz = unit_ball(B, N, 7)
+    idx = _ext.furthest_point_sampling(xyz, m).long()
+    assert int(idx.min()) >= 0 and int(idx.max()) < N and bool((idx[:, 0] == 0).all())
+    assert all(len(torch.unique(idx[b])) == m for b in range(B))              # distinct points => distinct picks
+    sel = torch.gather(xyz, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+    # defining property: the j-th pick maximises the distance to the first j picks, so the
+    # "distance to the already chosen set" sequence is non-increasing
+    d = torch.cdist(sel[:2, :300], sel[:2, :300])
+    run = torch.stack([d[:, j, :j].min(dim=1).values for j in range(1, 300)], dim=1)
+    assert bool((run[:, 1:] <= run[:, :-1] + 1e-6).all())
+    # same answer from the kernel variant that shares no code path for the reduction
+    monkeypatch.setenv("PN2_FPS_MODE", "stream")
+    assert torch.equal(_ext.furthest_point_sampling(xyz[:2], 200).long(), idx[:2, :200])
+
+
+def test_ball_query_and_group_properties():
+    from pointnet2_ops import _ext
+    B, N, m, ns, r = 32, 50000, 2048, 64, 0.2
+    xyz = unit_ball(B, N, 8)
+    new_xyz = xyz[:, :m].contiguous()
+    idx = _ext.ball_query(new_xyz, xyz, r, ns)
+    li = idx.long()
+    assert int(li.min()) >= 0 and int(li.max()) < N
+    pts = torch.gather(xyz.unsqueeze(1).expand(-1, m, -1, -1), 2, li.unsqueeze(-1).expand(-1, -1, -1, 3))
+    d2 = (pts - new_xyz.unsqueeze(2)).square().sum(-1)
+    assert bool((d2 < r * r * (1 + 1e-5)).all())                                # every member inside the ball
+    assert bool((li[:, :, 0] <= torch.arange(m, device="cuda")).all())          # centre j is a cloud point: first hit <= j
+    inc = li[:, :, 1:] > li[:, :, :-1]
+    pad = li[:, :, 1:] == li[:, :, :1]
+    assert bool((inc | pad).all())                                              # ascending, then padded with the first hit
+    rows = _ext.group_concat_rows(xyz, new_xyz, None, idx, True, False, r)
+    torch.testing.assert_close(rows, pts - new_xyz.unsqueeze(2), atol=0, rtol=0)
+
+
+def test_backbone_step_is_finite_at_full_size():
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    torch.manual_seed(0)
+    net = Pointnet2Backbone(input_feature_dim=3).cuda().train()
+    pc = torch.cat([unit_ball(8, 50000, 9), torch.rand(8, 50000, 3, device="cuda")], dim=2)
+    out = net(pc)["fp2_features"]
+    assert out.shape == (8, 288, 1024)
+    out.square().mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())

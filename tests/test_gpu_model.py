@@ -1,0 +1,105 @@
+"""GPU parity of the full scene-graph model (two MSG encoders + TripletGCN + heads) and of
+the GF3D SA/FP backbone: HIP backend on cuda vs the oracle backend on CPU, same weights."""
+import copy
+import json
+import os
+
+import pytest
+import torch
+
+import oracle_ext
+from pointnet2_ops import pointnet2_modules as pm
+from pointnet2_ops import pointnet2_utils as pu
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scan(n_obj, pts_obj, pts_rel, seed):
+    g = torch.Generator().manual_seed(seed)
+    E = n_obj * (n_obj - 1)
+    ei = torch.tensor([[a, b] for a in range(n_obj) for b in range(n_obj) if a != b]).t().contiguous()
+    obj = torch.rand(n_obj, 6, pts_obj, generator=g) * 2 - 1
+    rel = torch.rand(E, 7, pts_rel, generator=g) * 2 - 1
+    rel[:, 6] = torch.randint(0, 3, (E, pts_rel), generator=g).float()
+    onehot = torch.zeros(E, 12)
+    onehot[torch.arange(E), torch.randint(0, 6, (E,), generator=g)] = 1
+    return dict(obj_points=obj, rel_points=rel, edge_indices=ei, relation_objects_one_hot=onehot,
+                gt_class=torch.randint(0, 12, (n_obj,), generator=g), gt_rels=torch.randint(0, 15, (E,), generator=g),
+                objs_json={i + 1: f"obj{i}" for i in range(n_obj)}, scan_id="4_000131", take_idx=4)
+
+
+def _to(batch, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def test_sgpn_model_forward_backward_matches_oracle_backend():
+    from scene_graph_prediction.scene_graph_helpers.model import scene_graph_prediction_model as sgm
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    from pointnet2_ops import _ext
+    cfg = json.load(open(os.path.join(REPO, "4d-or_amd/scene_graph_prediction/scene_graph_helpers/configs/no_gt.json")))
+    names = [f"r{i}" for i in range(14)] + ["none"]
+    torch.manual_seed(0)
+    model = sgm.SGPNModelWrapper(cfg, 12, 15, torch.ones(12), torch.ones(15), names).eval()   # eval: no dropout noise
+    batch = _scan(4, 1500, 2000, seed=1)
+
+    def run(dev, backend):
+        saved = pu._ext, gcn._ext
+        pu._ext = gcn._ext = backend
+        try:
+            m = copy.deepcopy(model).to(dev)
+            b = _to(batch, dev)
+            obj, rel, of, rf, gof, grf, _ = m(b, return_meta_data=True)
+            loss = m.loss(obj, rel, b)
+            loss.backward()
+            grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
+            return [t.detach().cpu() for t in (obj, rel, of, rf, gof, grf)], float(loss.detach()), grads, m.predict_step(b)
+        finally:
+            pu._ext, gcn._ext = saved
+
+    ref, loss_ref, g_ref, triples_ref = run("cpu", oracle_ext.OracleRowsExt)
+    got, loss_got, g_got, triples_got = run("cuda", _ext)
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, atol=2e-4, rtol=1e-3)
+    assert abs(loss_got - loss_ref) < 1e-4
+    assert triples_got == triples_ref                       # same <subject, predicate, object> triples
+    assert set(g_got) == set(g_ref)
+    assert not any(k.startswith(("obj_encoder.backbone.fc_layer", "rel_encoder.backbone.fc_layer")) for k in g_got)
+    for k in g_ref:
+        # biases that feed a BatchNorm have an exactly-zero true gradient: what both sides compute
+        # there is rounding noise (~1e-5), hence the absolute floor
+        scale = float(g_ref[k].abs().max())
+        assert float((g_got[k] - g_ref[k]).abs().max()) <= 2e-3 * scale + 5e-5, k
+
+
+def test_gf3d_backbone_gpu_matches_golden_fixture():
+    """Same fixture as the CPU test (reference python layer + oracle), now through the HIP kernels."""
+    import numpy as np
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    z = np.load(os.path.join(REPO, "tests/golden/gf3d_backbone.npz"))
+    torch.manual_seed(31)
+    net = Pointnet2Backbone(input_feature_dim=3).cuda().train()
+    ep = net(torch.from_numpy(z["pc"]).cuda())
+    feats = ep["fp2_features"]
+    loss = (feats * torch.linspace(0.5, 1.5, feats.numel(), device="cuda").view_as(feats)).mean()
+    loss.backward()
+    assert np.array_equal(ep["sa1_inds"][:, :256].cpu().numpy(), z["sa1_inds"])      # FPS indices bit-exact
+    assert np.array_equal(ep["sa2_inds"][:, :64].cpu().numpy(), z["sa2_inds"])
+    assert np.array_equal(ep["sa4_xyz"].detach().cpu().numpy(), z["sa4_xyz"])
+    np.testing.assert_allclose(ep["sa4_features"].detach().cpu().numpy()[:, ::4], z["sa4_features"], atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(feats.detach().cpu().numpy()[:, ::8, ::4], z["fp2_features"], atol=1e-3, rtol=1e-3)
+    assert abs(float(loss.detach()) - float(z["loss"][0])) < 1e-5
+    g0 = net.sa1.mlp_module.layer0.conv.weight.grad.cpu().numpy()
+    assert np.linalg.norm(g0 - z["grad_sa1_conv0"]) / np.linalg.norm(z["grad_sa1_conv0"]) < 8e-2
+
+
+def test_msg_encoder_gpu_matches_golden_fixture():
+    import numpy as np
+    from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet2 import PointNetfeat
+    z = np.load(os.path.join(REPO, "tests/golden/msg_encoder.npz"))
+    for dim, seed in ((6, 21), (7, 22)):
+        torch.manual_seed(seed)
+        enc = PointNetfeat(input_dim=dim, out_size=256).cuda().eval()
+        with torch.no_grad():
+            y = enc(torch.from_numpy(z[f"d{dim}/x"]).cuda())
+        np.testing.assert_allclose(y.cpu().numpy(), z[f"d{dim}/y"], atol=1e-4, rtol=1e-3)
