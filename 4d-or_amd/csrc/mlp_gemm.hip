@@ -61,31 +61,28 @@ constexpr int BM = 128;
 
 // Persistent, software-pipelined workgroups.  A workgroup walks row tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ... and the (tile, K-chunk) steps form ONE
-// pipeline: the global loads of step s+1 — possibly the first chunk of the NEXT
-// tile — are issued into registers before the MFMAs of step s run out of LDS buffer
-// s&1, then transformed (prologue) and written to buffer (s+1)&1; one barrier per
-// step, no exposed load latency at tile boundaries.  Column sums for the epilogue
-// reductions stay in registers across tiles and are flushed once per workgroup.
+// pipeline over a two-deep register ring: the global loads of step s+2 are issued before
+// the MFMAs of step s, the registers of step s+1 (loaded one iteration earlier) are
+// transformed (prologue) and written to LDS buffer (s+1)&1 after them; one barrier per
+// step.  Prologue / epilogue modes are TEMPLATE parameters and every load is unconditional
+// (clamped addresses, masked when written to LDS): the loop body must stay straight-line
+// code, otherwise hipcc's s_waitcnt insertion degrades to vmcnt(0) in front of the MFMA
+// block and nothing overlaps (measured: MFMA time and memory time simply added up).
+// Column sums for the epilogue reductions stay in registers across tiles and are flushed
+// once per workgroup.
+//
 // CW = wave columns: the workgroup is 4 x CW waves; wave (wr, wc) owns rows wr*32.. and the
 // NT column tiles wc*NT.. (CW = 2 keeps N = 256/288 at 64-80 accumulator registers per wave).
-// MASKE: the EPI_MASK variant; it prefetches the Yprev tile into registers behind the last
-// chunk's MFMAs so the epilogue never waits on HBM.
-// Occupancy target (waves per SIMD) by variant: small accumulator footprints are capped at 128
-// VGPRs so that TWO 8-wave workgroups (or four 4-wave ones) are resident per CU and one
-// workgroup's barriers / epilogue overlap the other's MFMAs.
-template <int NT, int CW, bool MASKE>
-constexpr int gemm_min_waves() {
-  return 2;   // measured: forcing 4 (<= 128 VGPRs) for the small variants changes nothing
-}
-
-template <int NT, int KC, int CW, bool MASKE>
-__global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, MASKE>())) void mlp_gemm_kernel(const GemmArgs a) {
+template <int NT, int KC, int CW, int PRO, int EPI>
+__global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a) {
   constexpr int THREADS = 256 * CW;
-  constexpr int NTT = NT * CW;                // column tiles per workgroup
+  constexpr int NTT = NT * CW;                 // column tiles per workgroup
   constexpr int LD = KC + 1;
-  constexpr int APT = BM * KC / THREADS;      // A elements per thread per chunk
+  constexpr int APT = BM * KC / THREADS;       // A elements per thread per chunk
   constexpr int WPT = NTT * 32 * KC / THREADS; // W elements per thread per chunk
-  constexpr int RSTEP = THREADS / KC;         // rows covered by one pass of the workgroup
+  constexpr int RSTEP = THREADS / KC;          // rows covered by one pass of the workgroup
+  constexpr bool MASKE = EPI == EPI_MASK;
+  constexpr bool TWO = PRO >= PRO_GY;          // second A matrix (y) needed
   __shared__ float As[2][BM * LD];
   __shared__ float Ws[2][NTT * 32 * LD];
   __shared__ float red[2][NTT * 32];
@@ -97,12 +94,11 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, MASKE>())) void m
   const int n0 = blockIdx.y * (NTT * 32);
   const int K = a.K, N = a.N;
   const long long M = a.M;
-  const int pro = a.pro;
-  const int epi = MASKE ? (int)EPI_MASK : a.epi;
   const int nchunks = (K + KC - 1) / KC;
   const long long ntiles = (M + BM - 1) / BM;
   const long long my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;   // >= 1 (grid <= ntiles)
   const long long total_steps = my_tiles * nchunks;
+  const long long last_tile = blockIdx.x + (my_tiles - 1) * gridDim.x;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -115,113 +111,126 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, MASKE>())) void m
 
   const int kk = tid % KC;
   const int r0 = tid / KC;
-  const unsigned voff = (unsigned)(r0 * K + kk);
-  const unsigned rstride = (unsigned)(RSTEP * K);
-  const float *Wt = a.W + (size_t)n0 * K;
+  const unsigned pool_dq = (PRO == PRO_POOLG) ? (unsigned)RSTEP / (unsigned)a.ns : 0u;
+  const int pool_dr = (PRO == PRO_POOLG) ? RSTEP % a.ns : 0;
+  const unsigned last_grp = (PRO == PRO_POOLG) ? (unsigned)((M - 1) / a.ns) : 0u;
 
-  float ra[APT], rb[APT], rw[WPT];
+  float ra0[APT], rb0[TWO ? APT : 1], rw0[WPT];
+  float ra1[APT], rb1[TWO ? APT : 1], rw1[WPT];
 
-  // state of the tile whose chunks are currently being LOADED
-  long long l_tile = blockIdx.x;
-  int l_chunk = 0;
+  // (tile, chunk) cursors: L = next step to LOAD, S = next step to STORE to LDS, C = step computed.
+  // Past the end the L/S cursors stay on the last tile: the surplus loads / LDS writes are
+  // harmless and keep the loop body free of conditionals.
+  long long l_tile = blockIdx.x, s_tile = blockIdx.x, c_tile = blockIdx.x;
+  int l_chunk = 0, s_chunk = 0, c_chunk = 0;
 
-  auto load_step = [&]() {
+  auto load_step = [&](float (&ra)[APT], float (&rb)[TWO ? APT : 1], float (&rw)[WPT]) {
     const long long m0 = l_tile * BM;
-    const int k0 = l_chunk * KC;
     const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
-    const float *Xt = a.X ? a.X + (size_t)m0 * K : nullptr;
-    const float *X2t = a.X2 ? a.X2 + (size_t)m0 * K : nullptr;
-    const int k = k0 + kk;
-    const bool kin = k < K;
-    unsigned grp = 0;
-    int smp = 0;
-    if (pro == PRO_POOLG) {
+    const int k = l_chunk * KC + kk;
+    const int kc = k < K ? k : (K - 1);
+    if (PRO == PRO_POOLG) {
+      const float *X2t = a.X2 + (size_t)m0 * K;
       const unsigned row = (unsigned)(m0 + r0);
-      grp = row / (unsigned)a.ns;
-      smp = (int)(row - grp * (unsigned)a.ns);
-    }
+      unsigned grp = row / (unsigned)a.ns;
+      int smp = (int)(row - grp * (unsigned)a.ns);
 #pragma unroll
-    for (int i = 0; i < APT; ++i) {
-      const bool in = kin && (r0 + RSTEP * i) < mrem;
-      const unsigned off = voff + (unsigned)i * rstride + (unsigned)k0;
-      float v = 0.f, w = 0.f;
-      if (in) {
-        if (pro == PRO_POOLG) {
-          const size_t goff = (size_t)grp * K + k;
-          v = (a.arg[goff] == smp) ? a.gP[goff] : 0.f;
-        } else {
-          v = Xt[off];
-        }
-        if (pro >= PRO_GY) w = X2t[off];
+      for (int i = 0; i < APT; ++i) {
+        const int rr = (r0 + RSTEP * i) < mrem ? (r0 + RSTEP * i) : (mrem - 1);
+        const size_t goff = (size_t)(grp < last_grp ? grp : last_grp) * K + kc;
+        const int am = a.arg[goff];
+        const float gv = a.gP[goff];
+        ra[i] = (am == smp) ? gv : 0.f;
+        rb[TWO ? i : 0] = X2t[(unsigned)(rr * K + kc)];
+        smp += pool_dr;
+        grp += pool_dq;
+        if (smp >= a.ns) { smp -= a.ns; ++grp; }
       }
-      ra[i] = v;
-      rb[i] = w;
-      if (pro == PRO_POOLG) {
-        smp += RSTEP;
-        while (smp >= a.ns) { smp -= a.ns; ++grp; }
+    } else {
+      const float *Xt = a.X + (size_t)m0 * K;
+#pragma unroll
+      for (int i = 0; i < APT; ++i) {
+        const int rr = (r0 + RSTEP * i) < mrem ? (r0 + RSTEP * i) : (mrem - 1);
+        ra[i] = Xt[(unsigned)(rr * K + kc)];
+      }
+      if (TWO) {
+        const float *X2t = a.X2 + (size_t)m0 * K;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+          const int rr = (r0 + RSTEP * i) < mrem ? (r0 + RSTEP * i) : (mrem - 1);
+          rb[TWO ? i : 0] = X2t[(unsigned)(rr * K + kc)];
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-      const bool in = kin && (n0 + r0 + RSTEP * i) < N;
-      rw[i] = in ? Wt[voff + (unsigned)i * rstride + (unsigned)k0] : 0.f;
+      const int j = n0 + r0 + RSTEP * i;
+      const int jc = j < N ? j : (N - 1);
+      rw[i] = a.W[(size_t)jc * K + kc];
     }
+    ++l_chunk;
+    const bool wrap = l_chunk == nchunks;
+    l_chunk = wrap ? 0 : l_chunk;
+    const long long nt = l_tile + (wrap ? (long long)gridDim.x : 0ll);
+    l_tile = nt < ntiles ? nt : last_tile;
   };
 
-  // transforms the registers loaded by the LAST load_step() and writes them to LDS
-  auto store_step = [&](int buf) {
-    const long long m0 = l_tile * BM;
+  // prologue transform + LDS write of the OLDEST loaded step
+  auto store_step = [&](float (&ra)[APT], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int buf) {
+    const long long m0 = s_tile * BM;
     const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
-    const int k = l_chunk * KC + kk;
+    const int k = s_chunk * KC + kk;
     const bool kin = k < K;
+    const int kc = kin ? k : (K - 1);
     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-    if (kin && pro != PRO_NONE) {
-      q0 = a.p0[k];
-      q1 = a.p1[k];
-      if (pro >= PRO_GY) q2 = a.p2[k];
+    if (PRO != PRO_NONE) {
+      q0 = a.p0[kc];
+      q1 = a.p1[kc];
+      if (TWO) q2 = a.p2[kc];
     }
+    float *Ad = &As[buf][r0 * LD + kk];
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
       float v = ra[i];
-      if (pro == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, q0, q1), 0.f);
-      else if (pro >= PRO_GY) v = __fmaf_rn(q0, v, __fmaf_rn(q1, rb[i], q2));
-      if (!(kin && (r0 + RSTEP * i) < mrem)) v = 0.f;
-      As[buf][(r0 + RSTEP * i) * LD + kk] = v;
+      if (PRO == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, q0, q1), 0.f);
+      if (TWO) v = __fmaf_rn(q0, v, __fmaf_rn(q1, rb[TWO ? i : 0], q2));
+      Ad[RSTEP * i * LD] = (kin && (r0 + RSTEP * i) < mrem) ? v : 0.f;
     }
+    float *Wd = &Ws[buf][r0 * LD + kk];
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) Ws[buf][(r0 + RSTEP * i) * LD + kk] = rw[i];
+    for (int i = 0; i < WPT; ++i) Wd[RSTEP * i * LD] = (kin && (n0 + r0 + RSTEP * i) < N) ? rw[i] : 0.f;
+    ++s_chunk;
+    const bool wrap = s_chunk == nchunks;
+    s_chunk = wrap ? 0 : s_chunk;
+    const long long nt = s_tile + (wrap ? (long long)gridDim.x : 0ll);
+    s_tile = nt < ntiles ? nt : last_tile;
   };
-
-  auto advance_load = [&]() {
-    if (++l_chunk == nchunks) { l_chunk = 0; l_tile += gridDim.x; }
-  };
-
-  load_step();
-  store_step(0);
-  advance_load();
-  __syncthreads();
 
   const int arow = (wave * 32 + (lane & 31)) * LD + (lane >> 5);
   const int brow = (wcol * NT * 32 + (lane & 31)) * LD + (lane >> 5);
   const int cl = lane & 31;
   const int rbase = wave * 32 + 4 * (lane >> 5);
-  long long c_tile = blockIdx.x;   // tile being COMPUTED
-  int c_chunk = 0;
-  int buf = 0;
   float yp[MASKE ? NT : 1][16];
-  for (long long step = 0; step < total_steps; ++step) {
-    const bool more = step + 1 < total_steps;
+
+  // one pipeline iteration: compute the current step from LDS buffer `buf`; (la, lb, lw) receive
+  // the loads of two steps ahead, (sa, sb, sw) hold the next step and are written to buffer buf^1
+  auto iteration = [&](int buf, float (&la)[APT], float (&lb)[TWO ? APT : 1], float (&lw)[WPT],
+                       float (&sa)[APT], float (&sb)[TWO ? APT : 1], float (&sw)[WPT]) {
     const bool last_chunk = c_chunk == nchunks - 1;
     const long long m0 = c_tile * BM;
-    if (more) load_step();
-    if (MASKE && last_chunk) {
+    load_step(la, lb, lw);
+    if (MASKE) {
+      if (last_chunk) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int col = n0 + (wcol * NT + t) * 32 + cl;
+        for (int t = 0; t < NT; ++t) {
+          const int col = n0 + (wcol * NT + t) * 32 + cl;
+          const int cc = col < N ? col : (N - 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long long row = m0 + rbase + (r & 3) + 8 * (r >> 2);
-          yp[MASKE ? t : 0][r] = (col < N && row < M) ? a.Yprev[(size_t)row * N + col] : 0.f;
+          for (int r = 0; r < 16; ++r) {
+            const long long row = m0 + rbase + (r & 3) + 8 * (r >> 2);
+            const long long rc = row < M ? row : (M - 1);
+            yp[MASKE ? t : 0][r] = a.Yprev[(size_t)rc * N + cc];
+          }
         }
       }
     }
@@ -236,37 +245,35 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, MASKE>())) void m
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
       }
     }
-    // registers of the next step -> LDS first, so that the wait on those loads does not also
-    // have to drain the epilogue's stores (vmcnt counts both on gfx9)
-    if (more) {
-      store_step(buf ^ 1);
-      advance_load();
-    }
+    // registers of the next step -> LDS before the epilogue's global stores (vmcnt counts both)
+    store_step(sa, sb, sw, buf ^ 1);
     if (last_chunk) {
       // ---- tile epilogue: mask / statistics / store, straight from the accumulators ----
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = n0 + (wcol * NT + t) * 32 + cl;
         const bool cin = col < N;
+        const int cc = cin ? col : (N - 1);
         float es = 0.f, eh = 0.f, em = 0.f, er = 0.f;
-        if (MASKE && cin) { es = a.e_scale[col]; eh = a.e_shift[col]; em = a.e_mean[col]; er = a.e_rstd[col]; }
+        if (MASKE) { es = a.e_scale[cc]; eh = a.e_shift[cc]; em = a.e_mean[cc]; er = a.e_rstd[cc]; }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const long long row = m0 + rbase + (r & 3) + 8 * (r >> 2);
-          if (cin && row < M) {
-            float v = acc[t][r];
-            if (MASKE) {
-              const float y = yp[MASKE ? t : 0][r];
-              v = (__fmaf_rn(y, es, eh) > 0.f) ? v : 0.f;
-              s1 += v;
-              s2 = __fmaf_rn(v, (y - em) * er, s2);
-            } else if (epi == EPI_STATS) {
-              s1 += v;
-              s2 = __fmaf_rn(v, v, s2);
-            }
-            a.Y[(size_t)row * N + col] = v;
+          const bool ok = cin && row < M;
+          float v = acc[t][r];
+          if (MASKE) {
+            const float y = yp[MASKE ? t : 0][r];
+            v = (__fmaf_rn(y, es, eh) > 0.f) ? v : 0.f;
+            v = ok ? v : 0.f;
+            s1 += v;
+            s2 = __fmaf_rn(v, (y - em) * er, s2);
+          } else if (EPI == EPI_STATS) {
+            v = ok ? v : 0.f;
+            s1 += v;
+            s2 = __fmaf_rn(v, v, s2);
           }
+          if (ok) a.Y[(size_t)row * N + col] = v;
           acc[t][r] = 0.f;
         }
         cs1[t] += s1;
@@ -278,11 +285,19 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, MASKE>())) void m
       ++c_chunk;
     }
     __syncthreads();
-    buf ^= 1;
+  };
+
+  load_step(ra0, rb0, rw0);            // step 0
+  load_step(ra1, rb1, rw1);            // step 1
+  store_step(ra0, rb0, rw0, 0);
+  __syncthreads();
+  for (long long step = 0; step < total_steps; step += 2) {
+    iteration(0, ra0, rb0, rw0, ra1, rb1, rw1);
+    if (step + 1 < total_steps) iteration(1, ra1, rb1, rw1, ra0, rb0, rw0);
   }
 
   // ---- flush the column sums once per workgroup ----
-  if (epi != EPI_NONE) {
+  if (EPI != EPI_NONE) {
     for (int i = tid; i < 2 * NTT * 32; i += THREADS) (&red[0][0])[i] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -324,7 +339,10 @@ constexpr int WR = 32;        // rows per LDS tile
 constexpr int WMAXN = 320;    // 10 n-tiles
 constexpr int WKB = 128;      // K columns per workgroup
 
-template <int NTW>  // n-tiles per wave (total n-tiles <= 2*NTW)
+// Same discipline as mlp_gemm_kernel: modes are template parameters, loads are unconditional
+// from clamped addresses, the tile loop is straight-line code over a two-deep register ring
+// (tile t+2 is loaded while tile t runs on the MFMAs).
+template <int NTW, int GMODE, int AMODE>  // n-tiles per wave (total n-tiles <= 2*NTW)
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   constexpr int GN = 2 * NTW * 32;
   __shared__ float Gs[WR * GN];
@@ -341,7 +359,8 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   const long long row_begin = (long long)blockIdx.x * a.rows_per_wg;
   long long row_end = row_begin + a.rows_per_wg;
   if (row_end > M) row_end = M;
-  const int gmode = a.gmode, amode = a.amode;
+  const long long ntile = (row_end - row_begin + WR - 1) / WR;     // >= 1 by construction of the grid
+  const long long last_rt = row_begin + (ntile - 1) * WR;
 
   f32x16 acc[NTW];
 #pragma unroll
@@ -357,80 +376,88 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   constexpr int XPT = WR / XRP;                      // 8
   const int gn = tid % GN, gr0 = tid / GN;
   const bool g_thr = tid < GRP * GN && gn < N;
-  float c1 = 0.f, c2 = 0.f, c3 = 0.f;
-  if (g_thr) { c1 = a.c1[gn]; c2 = a.c2[gn]; c3 = a.c3[gn]; }
+  const int gnc = gn < N ? gn : (N - 1);
+  const float c1 = a.c1[gnc], c2 = a.c2[gnc], c3 = a.c3[gnc];
   const int xr0 = tid / WKB, xk = tid % WKB;
   const int kx = kb0 + xk;
   const bool kx_in = kx < K;
+  const int kxc = kx_in ? kx : (K - 1);
   float a_sc = 1.f, a_sh = 0.f;
-  if (amode == PRO_BNRELU && kx_in) { a_sc = a.a_scale[kx]; a_sh = a.a_shift[kx]; }
+  if (AMODE == PRO_BNRELU) { a_sc = a.a_scale[kxc]; a_sh = a.a_shift[kxc]; }
+  const unsigned w_dq = (GMODE == PRO_POOLG) ? (unsigned)GRP / (unsigned)a.ns : 0u;
+  const int w_dr = (GMODE == PRO_POOLG) ? GRP % a.ns : 0;
+  const unsigned last_grp = (GMODE == PRO_POOLG) ? (unsigned)((M - 1) / a.ns) : 0u;
 
-  float rg[GPT], ry[GPT], rx[XPT];
+  float rg0[GPT], ry0[GPT], rx0[XPT];
+  float rg1[GPT], ry1[GPT], rx1[XPT];
+  long long l_rt = row_begin;     // next tile to load (clamped to the last tile past the end)
+  long long s_rt = row_begin;     // next tile to write to LDS
 
-  auto load_tile = [&](long long rt) {
+  auto load_tile = [&](float (&rg)[GPT], float (&ry)[GPT], float (&rx)[XPT]) {
+    const long long rt = l_rt;
     const int rows = (int)((row_end - rt) < (long long)WR ? (row_end - rt) : (long long)WR);
-    const float *Gt = a.G ? a.G + (size_t)rt * N : nullptr;
     const float *Yt = a.Yl + (size_t)rt * N;
     const float *Xt = a.X + (size_t)rt * K;
-    unsigned grp = 0;
-    int smp = 0;
-    if (gmode == PRO_POOLG) {
+    if (GMODE == PRO_POOLG) {
       const unsigned row = (unsigned)(rt + gr0);
-      grp = row / (unsigned)a.ns;
-      smp = (int)(row - grp * (unsigned)a.ns);
-    }
+      unsigned grp = row / (unsigned)a.ns;
+      int smp = (int)(row - grp * (unsigned)a.ns);
 #pragma unroll
-    for (int i = 0; i < GPT; ++i) {
-      const int r = gr0 + GRP * i;
-      float g = 0.f, y = 0.f;
-      if (g_thr && r < rows) {
-        const unsigned off = (unsigned)(r * N + gn);
-        y = Yt[off];
-        if (gmode == PRO_GY) {
-          g = Gt[off];
-        } else {
-          const size_t goff = (size_t)grp * N + gn;
-          g = (a.arg[goff] == smp) ? a.gP[goff] : 0.f;
-        }
+      for (int i = 0; i < GPT; ++i) {
+        const int r = (gr0 + GRP * i) < rows ? (gr0 + GRP * i) : (rows - 1);
+        const size_t goff = (size_t)(grp < last_grp ? grp : last_grp) * N + gnc;
+        const int am = a.arg[goff];
+        const float gv = a.gP[goff];
+        rg[i] = (am == smp) ? gv : 0.f;
+        ry[i] = Yt[(unsigned)(r * N + gnc)];
+        smp += w_dr;
+        grp += w_dq;
+        if (smp >= a.ns) { smp -= a.ns; ++grp; }
       }
-      rg[i] = g;
-      ry[i] = y;
-      if (gmode == PRO_POOLG) {
-        smp += GRP;
-        while (smp >= a.ns) { smp -= a.ns; ++grp; }
+    } else {
+      const float *Gt = a.G + (size_t)rt * N;
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) {
+        const int r = (gr0 + GRP * i) < rows ? (gr0 + GRP * i) : (rows - 1);
+        const unsigned off = (unsigned)(r * N + gnc);
+        rg[i] = Gt[off];
+        ry[i] = Yt[off];
       }
     }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      const int r = xr0 + XRP * i;
-      rx[i] = (kx_in && r < rows) ? Xt[(unsigned)(r * K + kx)] : 0.f;
+      const int r = (xr0 + XRP * i) < rows ? (xr0 + XRP * i) : (rows - 1);
+      rx[i] = Xt[(unsigned)(r * K + kxc)];
     }
+    const long long nt = rt + WR;
+    l_rt = nt < row_end ? nt : last_rt;
   };
 
-  auto store_tile = [&](long long rt) {
+  auto store_tile = [&](float (&rg)[GPT], float (&ry)[GPT], float (&rx)[XPT]) {
+    const long long rt = s_rt;
     const int rows = (int)((row_end - rt) < (long long)WR ? (row_end - rt) : (long long)WR);
     if (tid < GRP * GN) {
 #pragma unroll
       for (int i = 0; i < GPT; ++i) {
         const int r = gr0 + GRP * i;
-        if (r < WR) Gs[r * GN + gn] = (g_thr && r < rows) ? __fmaf_rn(c1, rg[i], __fmaf_rn(c2, ry[i], c3)) : 0.f;
+        const float v = __fmaf_rn(c1, rg[i], __fmaf_rn(c2, ry[i], c3));
+        if (r < WR) Gs[r * GN + gn] = (g_thr && r < rows) ? v : 0.f;
       }
     }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int r = xr0 + XRP * i;
       float v = rx[i];
-      if (amode == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, a_sc, a_sh), 0.f);
-      if (!(kx_in && r < rows)) v = 0.f;
-      Xs[r * WKB + xk] = v;
+      if (AMODE == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, a_sc, a_sh), 0.f);
+      Xs[r * WKB + xk] = (kx_in && r < rows) ? v : 0.f;
     }
+    s_rt += WR;
   };
 
-  if (row_begin < row_end) load_tile(row_begin);
-  for (long long rt = row_begin; rt < row_end; rt += WR) {
-    store_tile(rt);
+  auto iteration = [&](float (&rg)[GPT], float (&ry)[GPT], float (&rx)[XPT]) {
+    store_tile(rg, ry, rx);          // tile t (loaded two iterations ago) -> LDS
     __syncthreads();
-    if (rt + WR < row_end) load_tile(rt + WR);   // in flight behind the MFMAs below
+    load_tile(rg, ry, rx);           // tile t+2 into the registers just freed
     // A operand: A[i = n][k = r] = gy[r][n];  B operand: B[k = r][j = kcol] = act[r][kcol]
 #pragma unroll
     for (int s = 0; s < WR / 2; ++s) {
@@ -443,6 +470,13 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
       }
     }
     __syncthreads();
+  };
+
+  load_tile(rg0, ry0, rx0);
+  load_tile(rg1, ry1, rx1);
+  for (long long t = 0; t < ntile; t += 2) {
+    iteration(rg0, ry0, rx0);
+    if (t + 1 < ntile) iteration(rg1, ry1, rx1);
   }
   // ---- flush: acc[t][reg] = dW[n = ntile*32 + rowmap][k = kb0 + ktile*32 + (lane&31)] ----
   const int kcol = kb0 + ktile * 32 + (lane & 31);
@@ -596,8 +630,8 @@ inline unsigned capped_grid(size_t work, int block = 256, unsigned cap = 8192) {
   return (unsigned)(g ? g : 1);
 }
 
-template <int NT, int KC, int CW, bool MASKE>
-void launch_gemm(const GemmArgs &a, hipStream_t s) {
+template <int NT, int KC, int CW, int PRO, int EPI>
+void launch_one(const GemmArgs &a, hipStream_t s) {
   // persistent: two workgroups per CU (256 CUs), each walking tiles with stride gridDim.x;
   // N wider than the workgroup's NT*CW column tiles is covered by column blocks (grid.y)
   const long long ntiles = (a.M + BM - 1) / BM;
@@ -606,7 +640,26 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   dim3 grid((unsigned)gx, ny);
-  hipLaunchKernelGGL((mlp_gemm_kernel<NT, KC, CW, MASKE>), grid, dim3(256 * CW), 0, s, a);
+  hipLaunchKernelGGL((mlp_gemm_kernel<NT, KC, CW, PRO, EPI>), grid, dim3(256 * CW), 0, s, a);
+}
+
+// tile configuration by number of 32-column tiles
+template <int PRO, int EPI>
+void launch_by_width(const GemmArgs &a, int tiles, hipStream_t s) {
+  if constexpr (EPI == EPI_MASK) {
+    // the Yprev prefetch costs 16 registers per column tile and the GY/POOLG prologues a second
+    // register ring: one tile per wave up to 64 columns, two beyond (column blocks past 128)
+    if (tiles <= 1) launch_one<1, 32, 1, PRO, EPI>(a, s);
+    else if (tiles <= 2) launch_one<1, 32, 2, PRO, EPI>(a, s);
+    else launch_one<2, 32, 2, PRO, EPI>(a, s);
+  } else {
+    if (tiles <= 1) launch_one<1, 32, 1, PRO, EPI>(a, s);
+    else if (tiles <= 2) launch_one<2, 32, 1, PRO, EPI>(a, s);
+    else if (tiles <= 4) launch_one<2, 32, 2, PRO, EPI>(a, s);
+    else if (tiles <= 6) launch_one<3, 16, 2, PRO, EPI>(a, s);
+    else if (tiles <= 8 || tiles > 10) launch_one<4, 16, 2, PRO, EPI>(a, s);   // > 10: column blocks of 256
+    else launch_one<5, 16, 2, PRO, EPI>(a, s);
+  }
 }
 
 }  // namespace
@@ -636,23 +689,18 @@ extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const f
   hipStream_t s = (hipStream_t)stream;
   const int tiles = (N + 31) / 32;
   // KC = 32 while two workgroups still fit a CU's LDS, else 16
-  const char *cfg = getenv("PN2_GEMM_CFG");   // tuning only: "a" = 4 waves x 4 tiles for N = 128
-  if (epi == EPI_MASK) {
-    // the Yprev prefetch costs 16 registers per column tile: keep <= 2 tiles per wave
-    if (tiles <= 1) launch_gemm<1, 32, 1, true>(a, s);
-    else if (tiles <= 2) launch_gemm<2, 32, 1, true>(a, s);
-    else launch_gemm<2, 32, 2, true>(a, s);            // 4 tiles per workgroup, column blocks beyond
-  } else {
-    if (tiles <= 1) launch_gemm<1, 32, 1, false>(a, s);
-    else if (tiles <= 2) launch_gemm<2, 32, 1, false>(a, s);
-    else if (tiles <= 4) {
-      if (cfg && cfg[0] == 'a') launch_gemm<4, 32, 1, false>(a, s);
-      else launch_gemm<2, 32, 2, false>(a, s);
-    }
-    else if (tiles <= 6) launch_gemm<3, 16, 2, false>(a, s);
-    else if (tiles <= 8 || tiles > 10) launch_gemm<4, 16, 2, false>(a, s);   // > 10 tiles: column blocks of 256
-    else launch_gemm<5, 16, 2, false>(a, s);
-  }
+  // instantiated combinations: forward = {NONE, BNRELU} x STATS (eval mode passes epi 0 and is
+  // served by the same kernels with the reductions compiled out via EPI_NONE on NONE/BNRELU);
+  // backward = {GY, POOLG} x {MASK, NONE}
+  if (pro == PRO_NONE && epi == EPI_STATS) launch_by_width<PRO_NONE, EPI_STATS>(a, tiles, s);
+  else if (pro == PRO_BNRELU && epi == EPI_STATS) launch_by_width<PRO_BNRELU, EPI_STATS>(a, tiles, s);
+  else if (pro == PRO_NONE && epi == EPI_NONE) launch_by_width<PRO_NONE, EPI_NONE>(a, tiles, s);
+  else if (pro == PRO_BNRELU && epi == EPI_NONE) launch_by_width<PRO_BNRELU, EPI_NONE>(a, tiles, s);
+  else if (pro == PRO_GY && epi == EPI_MASK) launch_by_width<PRO_GY, EPI_MASK>(a, tiles, s);
+  else if (pro == PRO_POOLG && epi == EPI_MASK) launch_by_width<PRO_POOLG, EPI_MASK>(a, tiles, s);
+  else if (pro == PRO_GY && epi == EPI_NONE) launch_by_width<PRO_GY, EPI_NONE>(a, tiles, s);
+  else if (pro == PRO_POOLG && epi == EPI_NONE) launch_by_width<PRO_POOLG, EPI_NONE>(a, tiles, s);
+  else return PN2_EINVAL;
   return pn2_check_launch();
 }
 
@@ -685,10 +733,22 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
   hipStream_t s = (hipStream_t)stream;
   const int ntiles = (N + 31) / 32;
   dim3 grid(gx, kblocks);
-  if (ntiles <= 2) hipLaunchKernelGGL((mlp_wgrad_kernel<1>), grid, dim3(512), 0, s, a);
-  else if (ntiles <= 4) hipLaunchKernelGGL((mlp_wgrad_kernel<2>), grid, dim3(512), 0, s, a);
-  else if (ntiles <= 8) hipLaunchKernelGGL((mlp_wgrad_kernel<4>), grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((mlp_wgrad_kernel<5>), grid, dim3(512), 0, s, a);
+#define PN2_WGRAD(NTW)                                                                                   \
+  do {                                                                                                 \
+    if (gmode == PRO_GY && amode == PRO_NONE)                                                          \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_GY, PRO_NONE>), grid, dim3(512), 0, s, a);         \
+    else if (gmode == PRO_GY)                                                                          \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_GY, PRO_BNRELU>), grid, dim3(512), 0, s, a);       \
+    else if (amode == PRO_NONE)                                                                        \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_POOLG, PRO_NONE>), grid, dim3(512), 0, s, a);      \
+    else                                                                                               \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_POOLG, PRO_BNRELU>), grid, dim3(512), 0, s, a);    \
+  } while (0)
+  if (ntiles <= 2) PN2_WGRAD(1);
+  else if (ntiles <= 4) PN2_WGRAD(2);
+  else if (ntiles <= 8) PN2_WGRAD(4);
+  else PN2_WGRAD(5);
+#undef PN2_WGRAD
   return pn2_check_launch();
 }
 
