@@ -16,6 +16,8 @@
 // typical radii is a small fraction of N.
 #include "pn2_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 template <int CPW>
@@ -108,10 +110,15 @@ extern "C" int pn2_ball_query(int B, int N, int m, float radius, int nsample,
   const float r2 = radius * radius;  // fp32, EXT/src/ball_query_gpu.cu:22
   const long long centres = (long long)B * m;
   // enough waves to fill 256 CUs x 8 waves/SIMD first, then amortise loads
+  // measured at 32 x 50k / 2048 centres / ns 64: CPW 1/2/4/8 -> 0.50/0.46/0.36/0.43 ms (8 amortises loads
+  // best but its waves wait for their slowest centre)
   int cpw = 1;
-  if (centres >= 8192 * 8) cpw = 8;
-  else if (centres >= 8192 * 4) cpw = 4;
+  if (centres >= 8192 * 4) cpw = 4;
   else if (centres >= 8192 * 2) cpw = 2;
+  if (const char *e = getenv("PN2_BQ_CPW")) {   // tuning only
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8) cpw = v;
+  }
   const int per_block = 4 * cpw;
   const int bpc = (m + per_block - 1) / per_block;
   if ((long long)bpc * B > 0x7fffffffLL) return PN2_EINVAL;

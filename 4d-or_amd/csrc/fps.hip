@@ -233,6 +233,9 @@ __global__ __launch_bounds__(BS) void fps_stream_kernel(int N, int m, int L,
 typedef __attribute__((address_space(1))) u64 gu64;
 
 constexpr int kCoopMaxG = 32;
+// every cluster workgroup must be resident at once: 512 threads, < 64 VGPRs, 2 KB LDS => at least
+// 3 workgroups fit a CU; we allow 2 per CU (256 CUs)
+constexpr int kCoopMaxWorkgroups = 512;
 constexpr int kCoopFields = 5;                                      // hi, lo, x, y, z
 constexpr size_t kCoopCloudBytes = 2ull * kCoopFields * kCoopMaxG * sizeof(u64);
 constexpr unsigned kCoopSpinLimit = 1u << 22;
@@ -431,7 +434,7 @@ FpsPlan fps_plan(int B, int N, int m) {
       if (want >= 2 && want <= kCoopMaxG && (want & (want - 1)) == 0) G = want;
     }
     const int ppt = round_ppt((N + G * 512 - 1) / (G * 512));
-    if ((long long)B * G <= 256 && ppt > 0) { c.mode = 1; c.G = G; c.PPT = ppt; }
+    if ((long long)B * G <= kCoopMaxWorkgroups && ppt > 0) { c.mode = 1; c.G = G; c.PPT = ppt; }
   }
   // resident candidate
   FpsPlan r = {-1, 1, 512, 0};

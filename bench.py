@@ -102,7 +102,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    distributed = world > 1
+    distributed = world > 1 or "RANK" in os.environ     # launched by torch.distributed.run (even with 1 rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm

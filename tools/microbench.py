@@ -40,7 +40,7 @@ def report(name, t, nbytes, **kw):
 
 def fps_sweep(dev):
     """Per-round cost of each FPS kernel variant (heuristic tuning)."""
-    cases = [(32, 50000, 2048, [("coop", 8), ("coop", 4), ("stream", None)]),
+    cases = [(32, 50000, 2048, [("coop", 8), ("coop", 16), ("stream", None)]),
              (8, 200000, 512, [("coop", 32), ("stream", None)]),
              (1, 20000, 512, [("resident", None), ("coop", 4), ("coop", 16)]),
              (72, 8000, 512, [("resident", None), ("coop", 2)]),
