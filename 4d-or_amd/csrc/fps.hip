@@ -254,83 +254,109 @@ struct __attribute__((aligned(16))) FpsFinal {
   int pad[3];
 };
 
-template <int BS, int PPT>
+// NC clouds per cluster: the two synchronisation costs of a round — the intra-workgroup
+// barrier/LDS exchange (~0.5 us) and the inter-workgroup granule hand-off (~1.3-2 us) — do not
+// depend on how many candidates they carry, so a cluster of G workgroups serves NC clouds at
+// once: every workgroup owns a 1/G slice of EACH of its NC clouds (NC*PPT point slots per
+// lane), scans them back to back, and ONE barrier + ONE hand-off per round moves all NC
+// candidates.  Wave c (< NC) sweeps the granules of cloud c, so the sweeps run in parallel.
+// Cluster q = blockIdx.x % (B/NC) serves clouds q*NC .. q*NC+NC-1; workgroup g = blockIdx.x / (B/NC).
+template <int BS, int PPT, int NC>
 __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L, int G,
                                                      const float *__restrict__ xyz,
                                                      int *__restrict__ idxs,
                                                      u64 *__restrict__ slots,
                                                      int *__restrict__ status) {
   constexpr int NW = BS / 64;
-  __shared__ FpsSlot lds_slots[2][16];
-  __shared__ unsigned lds_vals[kCoopFields][kCoopMaxG];
-  __shared__ FpsFinal lds_fin[2];
+  static_assert(NC <= NW, "one sweeping wave per cloud");
+  __shared__ FpsSlot lds_slots[2][NC][16];
+  __shared__ unsigned lds_vals[NC][kCoopFields][kCoopMaxG];
+  __shared__ FpsFinal lds_fin[2][NC];
 
-  const int b = blockIdx.x % B;   // a cluster's workgroups share blockIdx % 8 (one XCD) when B % 8 == 0
-  const int g = blockIdx.x / B;
+  const int nclusters = B / NC;
+  const int q = blockIdx.x % nclusters;   // a cluster's workgroups share blockIdx % 8 (one XCD) when nclusters % 8 == 0
+  const int g = blockIdx.x / nclusters;
   const int t = threadIdx.x;
   const int lane = pn2_lane();
   const int wave = t >> 6;
-  const float *P = xyz + (size_t)b * N * 3;
-  int *out = idxs + (size_t)b * m;
-  u64 *cs = slots + (size_t)b * (2 * kCoopFields * kCoopMaxG);
 
-  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  float px[NC * PPT], py[NC * PPT], pz[NC * PPT], td[NC * PPT];
   const int k0 = g * BS + t;
   const int kstride = G * BS;
+  float p0x[NC], p0y[NC], p0z[NC], ox[NC], oy[NC], oz[NC];
 #pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    const int k = k0 + i * kstride;
-    float x = 0.f, y = 0.f, z = 0.f;
-    bool valid = false;
-    if (k < N) {
-      x = P[(size_t)k * 3 + 0];
-      y = P[(size_t)k * 3 + 1];
-      z = P[(size_t)k * 3 + 2];
-      const float mag = pn2_sq3(x, y, z);
-      valid = !((double)mag <= 1e-3);
-    }
-    px[i] = x; py[i] = y; pz[i] = z;
-    td[i] = valid ? 1e10f : -1.f;
-  }
-
-  const float p0x = P[0], p0y = P[1], p0z = P[2];
-  float ox = p0x, oy = p0y, oz = p0z;
-  if (g == 0 && t == 0) out[0] = 0;
-
-  for (int j = 1; j < m; ++j) {
-    float best = -1.f;
-    int bi = 0;
+  for (int c = 0; c < NC; ++c) {
+    const float *P = xyz + (size_t)(q * NC + c) * N * 3;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const float d = pn2_sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
-      const float d2 = fps_min(d, td[i]);
-      td[i] = d2;
-      if (d2 > best) { best = d2; bi = i; }
+      const int k = k0 + i * kstride;
+      float x = 0.f, y = 0.f, z = 0.f;
+      bool valid = false;
+      if (k < N) {
+        x = P[(size_t)k * 3 + 0];
+        y = P[(size_t)k * 3 + 1];
+        z = P[(size_t)k * 3 + 2];
+        const float mag = pn2_sq3(x, y, z);
+        valid = !((double)mag <= 1e-3);
+      }
+      px[c * PPT + i] = x; py[c * PPT + i] = y; pz[c * PPT + i] = z;
+      td[c * PPT + i] = valid ? 1e10f : -1.f;
     }
-    u64 pk = 0ull;
-    if (best >= 0.f) pk = fps_pack(best, (unsigned)(k0 + bi * kstride), L);
-    const u64 wmax = pn2_wave_max_u64(pk);
+    p0x[c] = P[0]; p0y[c] = P[1]; p0z[c] = P[2];
+    ox[c] = p0x[c]; oy[c] = p0y[c]; oz[c] = p0z[c];
+    if (g == 0 && t == 0) idxs[(size_t)(q * NC + c) * m] = 0;
+  }
 
-    float sx = p0x, sy = p0y, sz = p0z;
-    bool writer;
-    if (wmax == 0ull) {
-      writer = (lane == 0);
-    } else {
-      writer = (pk == wmax);
-      if (writer) {
-        sx = px[0]; sy = py[0]; sz = pz[0];
+  for (int j = 1; j < m; ++j) {
+    // ---- scan + wave arg-max of every cloud, winners into this round's LDS slots ----
 #pragma unroll
-        for (int i = 1; i < PPT; ++i) {
-          if (bi == i) { sx = px[i]; sy = py[i]; sz = pz[i]; }
+    for (int c = 0; c < NC; ++c) {
+      float best = -1.f;
+      int bi = 0;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int s = c * PPT + i;
+        const float d = pn2_sq3(px[s] - ox[c], py[s] - oy[c], pz[s] - oz[c]);
+        const float d2 = fps_min(d, td[s]);
+        td[s] = d2;
+        if (d2 > best) { best = d2; bi = i; }
+      }
+      u64 pk = 0ull;
+      if (best >= 0.f) pk = fps_pack(best, (unsigned)(k0 + bi * kstride), L);
+      const u64 wmax = pn2_wave_max_u64(pk);
+      float sx = p0x[c], sy = p0y[c], sz = p0z[c];
+      bool writer;
+      if (wmax == 0ull) {
+        writer = (lane == 0);
+      } else {
+        writer = (pk == wmax);
+        if (writer) {
+          sx = px[c * PPT]; sy = py[c * PPT]; sz = pz[c * PPT];
+#pragma unroll
+          for (int i = 1; i < PPT; ++i) {
+            if (bi == i) { sx = px[c * PPT + i]; sy = py[c * PPT + i]; sz = pz[c * PPT + i]; }
+          }
         }
       }
+      if (writer) {
+        FpsSlot &sl = lds_slots[j & 1][c][wave];
+        sl.packed = wmax; sl.x = sx; sl.y = sy; sl.z = sz;
+      }
     }
-    float bx, by, bz;
-    const u64 bmax = fps_block_exchange<NW>(lds_slots[j & 1], wmax, writer, sx, sy, sz, bx, by, bz);
+    __syncthreads();
 
-    if (wave == 0) {
-      // publish this workgroup's candidate: field f of workgroup g -> cs[parity][f][g]
-      u64 *par = cs + (size_t)(j & 1) * (kCoopFields * kCoopMaxG);
+    // ---- wave c: block winner of cloud c -> publish -> sweep the cluster -> final winner ----
+    if (wave < NC) {
+      const int c = wave;
+      const FpsSlot *buf = lds_slots[j & 1][c];
+      const int s16 = lane & 15;
+      const u64 mine = (s16 < NW) ? buf[s16].packed : 0ull;
+      const u64 bmax = pn2_readlane_u64(pn2_row16_max_u64(mine), 0);
+      const u64 whoB = __ballot(mine == bmax && s16 < NW);
+      const int ws = (__ffsll((long long)whoB) - 1) & 15;
+      const float bx = buf[ws].x, by = buf[ws].y, bz = buf[ws].z;
+
+      u64 *par = slots + ((size_t)(q * NC + c) * 2 + (size_t)(j & 1)) * (kCoopFields * kCoopMaxG);
       if (lane < kCoopFields) {
         unsigned v = lane == 0 ? (unsigned)(bmax >> 32)
                    : lane == 1 ? (unsigned)bmax
@@ -338,11 +364,10 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
                    : lane == 3 ? __float_as_uint(by) : __float_as_uint(bz);
         coop_store(par + lane * kCoopMaxG + g, ((u64)(unsigned)j << 32) | v);
       }
-      // sweep the cluster's granules until all carry this round's tag
       const int total = kCoopFields * G;
       bool failed = false;
-      for (int q = 0; q < total; q += 64) {
-        const int l = q + lane;
+      for (int qq = 0; qq < total; qq += 64) {
+        const int l = qq + lane;
         const bool act = l < total;
         const int f = act ? l / G : 0;
         const int gg = act ? l - f * G : 0;
@@ -355,29 +380,33 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
           __builtin_amdgcn_s_sleep(1);
         }
         if (failed) break;
-        if (act) lds_vals[f][gg] = (unsigned)v;
+        if (act) lds_vals[c][f][gg] = (unsigned)v;
       }
-      // cluster arg-max (same total order in every workgroup => same winner everywhere)
       u64 cand = 0ull;
-      if (!failed && lane < G) cand = ((u64)lds_vals[0][lane] << 32) | lds_vals[1][lane];
+      if (!failed && lane < G) cand = ((u64)lds_vals[c][0][lane] << 32) | lds_vals[c][1][lane];
       const u64 cmax = pn2_wave_max_u64(cand);
       const u64 who = __ballot(!failed && lane < G && cand == cmax);
       const int wg = who ? (__ffsll((long long)who) - 1) : 0;
       if (lane == 0) {
-        FpsFinal &fin = lds_fin[j & 1];
+        FpsFinal &fin = lds_fin[j & 1][c];
         fin.abort = failed ? 1 : 0;
-        fin.x = __uint_as_float(lds_vals[2][wg]);
-        fin.y = __uint_as_float(lds_vals[3][wg]);
-        fin.z = __uint_as_float(lds_vals[4][wg]);
+        fin.x = __uint_as_float(lds_vals[c][2][wg]);
+        fin.y = __uint_as_float(lds_vals[c][3][wg]);
+        fin.z = __uint_as_float(lds_vals[c][4][wg]);
         fin.k = cmax ? (int)fps_unrank(~(unsigned)cmax, L) : 0;
         if (failed) atomicExch(status, 1);
       }
     }
     __syncthreads();
-    const FpsFinal &fin = lds_fin[j & 1];
-    if (fin.abort) return;
-    ox = fin.x; oy = fin.y; oz = fin.z;
-    if (g == 0 && t == 0) out[j] = fin.k;
+    int aborted = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const FpsFinal &fin = lds_fin[j & 1][c];
+      aborted |= fin.abort;
+      ox[c] = fin.x; oy[c] = fin.y; oz[c] = fin.z;
+      if (g == 0 && t == 0) idxs[(size_t)(q * NC + c) * m + j] = fin.k;
+    }
+    if (aborted) return;
   }
 }
 
@@ -402,6 +431,7 @@ int ref_opt_n_threads(int work_size) {
 struct FpsPlan {
   int mode;  // 0 resident, 1 cooperative, 2 streaming
   int G, BS, PPT;
+  int NC;    // cooperative: clouds per cluster
 };
 
 const int kPptSteps[] = {1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 20, 24};
@@ -415,7 +445,7 @@ int round_ppt(int ppt) {
 // PN2_FPS_MODE=resident|coop|stream and PN2_FPS_G=<power of two> override the
 // heuristic (tuning / tests only).
 FpsPlan fps_plan(int B, int N, int m) {
-  FpsPlan p = {2, 1, 1024, 0};
+  FpsPlan p = {2, 1, 1024, 0, 1};
   if (m <= 1) { p.mode = 0; p.BS = 512; p.PPT = 1; return p; }
   const char *mode_env = getenv("PN2_FPS_MODE");
   const char *g_env = getenv("PN2_FPS_G");
@@ -424,20 +454,34 @@ FpsPlan fps_plan(int B, int N, int m) {
   const bool want_stream = mode_env && !strcmp(mode_env, "stream");
   if (want_stream) return p;
 
-  // cooperative candidate
-  FpsPlan c = {-1, 1, 512, 0};
+  // cooperative candidate: NC clouds per cluster (NC | B), G workgroups per cluster, NC*PPT <= 28
+  // point slots per lane, (B/NC)*G <= 512 resident workgroups.
+  FpsPlan c = {-1, 1, 512, 0, 1};
   {
-    int G = 2;
-    while (G < kCoopMaxG && (N + G * 512 - 1) / (G * 512) > 16) G *= 2;
+    const char *nc_env = getenv("PN2_FPS_NC");
+    int best_nc = 1, best_g = 2;
+    while (best_g < kCoopMaxG && (N + best_g * 512 - 1) / (best_g * 512) > 16) best_g *= 2;
+    // Measured at 32 x 50k -> 2048 (profiles/r01_fps_variant_sweep.jsonl): (NC,G) = (1,8) 5.3 ms,
+    // (2,8) 6.8, (2,16) 6.3, (4,16) 6.6, (4,32) 9.7: batching clouds per cluster does NOT pay (the
+    // hand-off cost grows with the cluster size and the per-cloud serial work dominates), so the
+    // default stays one cloud per cluster; NC > 1 remains available through PN2_FPS_NC.
+    int G = best_g, NC = best_nc;
+    if (nc_env) {
+      const int want = atoi(nc_env);
+      if ((want == 1 || want == 2 || want == 4) && B % want == 0) { NC = want; G = (best_g / best_nc) * want; }
+    }
     if (g_env) {
       const int want = atoi(g_env);
       if (want >= 2 && want <= kCoopMaxG && (want & (want - 1)) == 0) G = want;
     }
     const int ppt = round_ppt((N + G * 512 - 1) / (G * 512));
-    if ((long long)B * G <= kCoopMaxWorkgroups && ppt > 0) { c.mode = 1; c.G = G; c.PPT = ppt; }
+    if (NC > 1 && NC * ppt > 28) NC = 1;                  // multi-cloud kernels are built for <= 28 slots
+    if (G <= kCoopMaxG && (long long)(B / NC) * G <= kCoopMaxWorkgroups && ppt > 0 && NC * ppt <= 28) {
+      c.mode = 1; c.G = G; c.PPT = ppt; c.NC = NC;
+    }
   }
   // resident candidate
-  FpsPlan r = {-1, 1, 512, 0};
+  FpsPlan r = {-1, 1, 512, 0, 1};
   if (N <= 512 * 16) { r.mode = 0; r.BS = 512; r.PPT = round_ppt((N + 511) / 512); }
   else if (N <= kFpsResidentMaxN) { r.mode = 0; r.BS = 1024; r.PPT = round_ppt((N + 1023) / 1024); }
 
@@ -480,18 +524,43 @@ extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz
     u64 *slots = (u64 *)workspace;
     int *status = (int *)((char *)workspace + (size_t)B * kCoopCloudBytes);
     if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return pn2_check_launch();
-    const dim3 grid((unsigned)(B * plan.G));
-#define PN2_FPS_COOP(PPT)                                                                      \
-  case PPT:                                                                                    \
-    hipLaunchKernelGGL((fps_coop_kernel<512, PPT>), grid, dim3(512), 0, s, B, N, m, L, plan.G, \
-                       xyz, idxs, slots, status);                                              \
-    break;
-    switch (plan.PPT) {
-      PN2_FPS_COOP(1) PN2_FPS_COOP(2) PN2_FPS_COOP(3) PN2_FPS_COOP(4) PN2_FPS_COOP(6) PN2_FPS_COOP(8)
-      PN2_FPS_COOP(10) PN2_FPS_COOP(12) PN2_FPS_COOP(14) PN2_FPS_COOP(16) PN2_FPS_COOP(20)
-      PN2_FPS_COOP(24)
-      default: return PN2_EINVAL;
+    const dim3 grid((unsigned)((B / plan.NC) * plan.G));
+#define PN2_FPS_COOP(PPT, NC)                                                                       \
+  hipLaunchKernelGGL((fps_coop_kernel<512, PPT, NC>), grid, dim3(512), 0, s, B, N, m, L, plan.G,    \
+                     xyz, idxs, slots, status)
+#define PN2_FPS_COOP_NC(NC)                                                                         \
+  switch (plan.PPT) {                                                                               \
+    case 1: PN2_FPS_COOP(1, NC); break;                                                             \
+    case 2: PN2_FPS_COOP(2, NC); break;                                                             \
+    case 3: PN2_FPS_COOP(3, NC); break;                                                             \
+    case 4: PN2_FPS_COOP(4, NC); break;                                                             \
+    case 6: if (NC * 6 <= 28) { PN2_FPS_COOP(6, (NC * 6 <= 28 ? NC : 1)); break; } return PN2_EINVAL;   \
+    case 8: if (NC * 8 <= 28) { PN2_FPS_COOP(8, (NC * 8 <= 28 ? NC : 1)); break; } return PN2_EINVAL;   \
+    case 10: if (NC * 10 <= 28) { PN2_FPS_COOP(10, (NC * 10 <= 28 ? NC : 1)); break; } return PN2_EINVAL; \
+    case 12: if (NC * 12 <= 28) { PN2_FPS_COOP(12, (NC * 12 <= 28 ? NC : 1)); break; } return PN2_EINVAL; \
+    case 14: if (NC * 14 <= 28) { PN2_FPS_COOP(14, (NC * 14 <= 28 ? NC : 1)); break; } return PN2_EINVAL; \
+    default: return PN2_EINVAL;                                                                     \
+  }
+    if (plan.NC == 4) { PN2_FPS_COOP_NC(4) }
+    else if (plan.NC == 2) { PN2_FPS_COOP_NC(2) }
+    else {
+      switch (plan.PPT) {
+        case 1: PN2_FPS_COOP(1, 1); break;
+        case 2: PN2_FPS_COOP(2, 1); break;
+        case 3: PN2_FPS_COOP(3, 1); break;
+        case 4: PN2_FPS_COOP(4, 1); break;
+        case 6: PN2_FPS_COOP(6, 1); break;
+        case 8: PN2_FPS_COOP(8, 1); break;
+        case 10: PN2_FPS_COOP(10, 1); break;
+        case 12: PN2_FPS_COOP(12, 1); break;
+        case 14: PN2_FPS_COOP(14, 1); break;
+        case 16: PN2_FPS_COOP(16, 1); break;
+        case 20: PN2_FPS_COOP(20, 1); break;
+        case 24: PN2_FPS_COOP(24, 1); break;
+        default: return PN2_EINVAL;
+      }
     }
+#undef PN2_FPS_COOP_NC
 #undef PN2_FPS_COOP
     return pn2_check_launch();
   }

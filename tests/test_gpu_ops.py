@@ -64,6 +64,22 @@ def test_fps_every_kernel_variant_agrees_with_oracle(ext, monkeypatch, mode, g, 
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("nc,g", [(1, 8), (2, 16), (4, 32), (2, 4), (4, 8)])
+@pytest.mark.parametrize("B,N,m,kind", [(32, 50000, 48, "uniform"), (4, 20000, 100, "dup"), (8, 9000, 64, "zero_tail")])
+def test_fps_multi_cloud_clusters_agree_with_oracle(ext, monkeypatch, nc, g, B, N, m, kind):
+    """NC clouds per cluster / G workgroups per cluster: same indices as the lane-accurate oracle."""
+    if B % nc or (B // nc) * g > 512 or nc * ((N + g * 512 - 1) // (g * 512)) > 16:
+        pytest.skip("configuration does not fit")
+    monkeypatch.setenv("PN2_FPS_CHECK", "1")
+    monkeypatch.setenv("PN2_FPS_MODE", "coop")
+    monkeypatch.setenv("PN2_FPS_NC", str(nc))
+    monkeypatch.setenv("PN2_FPS_G", str(g))
+    xyz = clouds(B, N, kind, seed=N + B + nc)
+    want = O.furthest_point_sampling(xyz, m)
+    got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    assert torch.equal(got, want)
+
+
 def test_fps_all_skipped_and_m_zero(ext):
     xyz = torch.full((2, 700, 3), 0.001)
     assert torch.equal(ext.furthest_point_sampling(dev(xyz), 5).cpu(), torch.zeros(2, 5, dtype=torch.int32))

@@ -40,7 +40,7 @@ def report(name, t, nbytes, **kw):
 
 def fps_sweep(dev):
     """Per-round cost of each FPS kernel variant (heuristic tuning)."""
-    cases = [(32, 50000, 2048, [("coop", 8), ("coop", 16), ("stream", None)]),
+    cases = [(32, 50000, 2048, [("coop", (1, 8)), ("coop", (2, 16)), ("coop", (4, 32)), ("coop", (2, 8)), ("coop", (4, 16)), ("coop", None)]),
              (8, 200000, 512, [("coop", 32), ("stream", None)]),
              (1, 20000, 512, [("resident", None), ("coop", 4), ("coop", 16)]),
              (72, 8000, 512, [("resident", None), ("coop", 2)]),
@@ -50,18 +50,26 @@ def fps_sweep(dev):
         x = unit_ball(B, N, 3).to(dev)
         for mode, g in variants:
             os.environ["PN2_FPS_MODE"] = mode
+            nc = None
+            if isinstance(g, tuple):
+                nc, g = g
+            if nc:
+                os.environ["PN2_FPS_NC"] = str(nc)
+            else:
+                os.environ.pop("PN2_FPS_NC", None)
             if g:
                 os.environ["PN2_FPS_G"] = str(g)
             else:
                 os.environ.pop("PN2_FPS_G", None)
             try:
                 t = timeit(lambda: _ext.furthest_point_sampling(x, m), iters=3, warm=1)
-                report(f"fps_sweep B{B} N{N} m{m} {mode} G{g}", t, B * (12 * N + 4 * m),
+                report(f"fps_sweep B{B} N{N} m{m} {mode} NC{nc} G{g}", t, B * (12 * N + 4 * m),
                        us_per_round=round(t / (m - 1) * 1e6, 3))
             except RuntimeError as e:
                 print("fps_sweep", B, N, mode, g, "->", e, flush=True)
     os.environ.pop("PN2_FPS_MODE", None)
     os.environ.pop("PN2_FPS_G", None)
+    os.environ.pop("PN2_FPS_NC", None)
 
 
 def mlp_sweep(dev):
