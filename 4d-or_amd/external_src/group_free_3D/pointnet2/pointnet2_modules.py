@@ -50,8 +50,7 @@ class PointnetSAModuleVotes(nn.Module):
                 xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
 
         if self.pooling == "max" and _pm._rows_path_ok(xyz, features):
-            g = self.grouper.forward_rows(xyz, new_xyz, pointnet2_utils.as_rows(features))
-            rows = _pm.mlp_pool_rows(self.mlp_module, g)
+            rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, new_xyz, pointnet2_utils.as_rows(features))
             return new_xyz, pointnet2_utils.rows_to_channels(rows), inds
 
         grouped, grouped_xyz = self.grouper(xyz, new_xyz, features)

@@ -66,10 +66,22 @@ def supported(mlp: nn.Module, x: torch.Tensor) -> bool:
 
 class _FusedMLP(Function):
     @staticmethod
-    def forward(ctx, x, ns, layers, *params):
+    def forward(ctx, x, ns, layers, group, *params):
         """x (M,K0) rows; ns > 0 pools groups of ns rows; layers [(conv, bn)];
-        params = (W_1, gamma_1, beta_1, W_2, ...) only so autograd tracks them."""
+        params = (W_1, gamma_1, beta_1, W_2, ...) only so autograd tracks them.
+
+        With `group` = (xyz, new_xyz, idx, use_xyz, normalize, radius) the rows are produced HERE
+        from the point-major features `x` (B,N,C) by the fused gather kernel (QueryAndGroup tail),
+        and the backward returns the feature gradient directly: the first layer's input gradient
+        is only computed for the C feature columns (the relative-xyz columns never need one) and
+        scattered back through the neighbourhood indices in the same autograd node."""
         e = _ext()
+        ctx.group = group
+        if group is not None:
+            xyz, new_xyz, idx, use_xyz, normalize, radius = group
+            ctx.feat_shape = None if x is None else tuple(x.shape)
+            x = e.group_concat_rows(xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize,
+                                    radius).view(-1, (3 if use_xyz else 0) + (0 if x is None else x.size(2)))
         x = x.contiguous()
         M = x.size(0)
         L = len(layers)
@@ -144,9 +156,12 @@ class _FusedMLP(Function):
                              G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1])
             grads[3 * l] = dW.view(ctx.shapes[l])
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
-            need_dgrad = l > 0 or ctx.needs_input_grad[0]
+            need_dgrad = l > 0 or (ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None))
             if need_dgrad:
-                Wt = Ws[l].t().contiguous()                       # (K_l, N_l): dgrad is out[M,K_l] = gy[M,N_l] @ Wt^T
+                Wt = Ws[l].t()                                    # (K_l, N_l): dgrad is out[M,K_l] = gy[M,N_l] @ Wt^T
+                if l == 0 and ctx.group is not None and ctx.group[3]:
+                    Wt = Wt[3:]                                   # feature columns only (skip relative xyz)
+                Wt = Wt.contiguous()
                 p = (consts[0], consts[1], consts[2])
                 if l > 0:
                     sums = torch.zeros(2, Wt.size(0), dtype=torch.float64, device=x.device)
@@ -155,15 +170,35 @@ class _FusedMLP(Function):
                     G, gmode, arg, gPm = Gn, e.PRO_GY, None, None
                 else:
                     gx = e.mlp_gemm(G, Wt, pro=gmode, epi=e.EPI_NONE, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns, M=M)
-        return (gx, None, None, *grads)
+        if gx is not None and ctx.group is not None:
+            idx = ctx.group[2]
+            Bq, npoint, nsample = idx.shape
+            Bf, Nf, Cf = ctx.feat_shape
+            gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0)
+        return (gx, None, None, None, *grads)
+
+
+def _params(layers):
+    params = []
+    for conv, bn in layers:
+        params += [conv.weight, bn.weight, bn.bias]
+    return params
 
 
 def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0) -> torch.Tensor:
     """x (M, C_in) rows -> (M, C_out) [ns == 0] or (M // ns, C_out) max-pooled over groups of ns rows."""
     layers = parse_stack(mlp)
     assert layers is not None, "fused_shared_mlp: unsupported stack (call supported() first)"
-    params = []
-    for conv, bn in layers:
-        params += [conv.weight, bn.weight, bn.bias]
-    res = _FusedMLP.apply(x, int(ns), layers, *params)
+    res = _FusedMLP.apply(x, int(ns), layers, None, *_params(layers))
     return res[0] if ns else res
+
+
+def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius) -> torch.Tensor:
+    """Ball-query neighbourhoods -> shared MLP -> max, one autograd node:
+    xyz (B,N,3), new_xyz (B,m,3), feats_rows (B,N,C)|None, idx (B,m,ns) -> (B, m, C_out)."""
+    layers = parse_stack(mlp)
+    assert layers is not None
+    B, m, ns = idx.shape
+    group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius)
+    res = _FusedMLP.apply(feats_rows, int(ns), layers, group, *_params(layers))
+    return res[0].view(B, m, -1)

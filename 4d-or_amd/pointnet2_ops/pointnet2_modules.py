@@ -107,6 +107,20 @@ def mlp_rows(mlp: nn.Module, rows: torch.Tensor) -> torch.Tensor:
     return shared_mlp_rows(mlp, rows)
 
 
+def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows) -> torch.Tensor:
+    """One SA scale on the rows path: group -> shared MLP -> max -> (B, npoint, C_out).
+    Ball-query groupers with a fusable MLP run as a single autograd node (gather, MLP, pool and
+    the scatter of the feature gradient); anything else goes through forward_rows + mlp_pool_rows."""
+    from pointnet2_ops import fused_mlp
+    if (_FUSED_MLP and isinstance(grouper, pointnet2_utils.QueryAndGroup) and new_xyz is not None
+            and (grouper.use_xyz or feats_rows is not None)
+            and fused_mlp.supported(mlp, xyz if feats_rows is None else feats_rows)):
+        idx = grouper.query(xyz, new_xyz)
+        return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
+                                              grouper.normalize_xyz, grouper.radius)
+    return mlp_pool_rows(mlp, grouper.forward_rows(xyz, new_xyz, feats_rows))
+
+
 def mlp_pool_rows(mlp: nn.Module, grouped: torch.Tensor) -> torch.Tensor:
     """grouped (B, npoint, nsample, C_in) -> (B, npoint, C_out): shared MLP then max over nsample."""
     from pointnet2_ops import fused_mlp
@@ -161,8 +175,7 @@ class _PointnetSAModuleBase(nn.Module):
         B = xyz.size(0)
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            g = grouper.forward_rows(xyz, new_xyz, feats_rows)  # (B, npoint, nsample, W)
-            pooled.append(mlp_pool_rows(mlp, g))                # (B, npoint, C_out)
+            pooled.append(sa_scale_rows(grouper, mlp, xyz, new_xyz, feats_rows))   # (B, npoint, C_out)
         rows = pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=2)
         return pointnet2_utils.rows_to_channels(rows)           # (B, sum C_out, npoint) view
 
