@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   constexpr int WPT = NTT * 32 * KC / THREADS; // W elements per thread per chunk
   constexpr int RSTEP = THREADS / KC;          // rows covered by one pass of the workgroup
   constexpr bool MASKE = EPI == EPI_MASK;
-  constexpr bool TWO = PRO >= PRO_GY;          // second A matrix (y) needed
+  constexpr bool TWO = PRO == PRO_GY;          // second A matrix (y) needed
+  constexpr bool POOL = PRO == PRO_POOLG;      // dense c2*y+c3 from ONE matrix + sparse arg-max patch in LDS
   __shared__ float As[2][BM * LD];
   __shared__ float Ws[2][NTT * 32 * LD];
   __shared__ float red[2][NTT * 32];
@@ -111,12 +112,16 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
 
   const int kk = tid % KC;
   const int r0 = tid / KC;
-  const unsigned pool_dq = (PRO == PRO_POOLG) ? (unsigned)RSTEP / (unsigned)a.ns : 0u;
-  const int pool_dr = (PRO == PRO_POOLG) ? RSTEP % a.ns : 0;
-  const unsigned last_grp = (PRO == PRO_POOLG) ? (unsigned)((M - 1) / a.ns) : 0u;
+  // PRO_POOLG: dL/dz of a max-pooled layer has ONE non-zero per (row group, channel) — at the
+  // arg-max row.  The tile is staged as the dense part c2*y + c3 and thread (gi, kk) adds
+  // c1 * gP[group gi of the tile][k] at LDS row arg (if that row lies in this tile).  The patch
+  // operands ride the register ring like everything else.  PGR = patch entries per thread.
+  constexpr int PGR = POOL ? (((BM / 16 + 1) * KC + THREADS - 1) / THREADS) : 1;   // supports ns >= 16
+  const unsigned last_grp = POOL ? (unsigned)((M - 1) / a.ns) : 0u;
 
-  float ra0[APT], rb0[TWO ? APT : 1], rw0[WPT];
-  float ra1[APT], rb1[TWO ? APT : 1], rw1[WPT];
+  float ra0[APT], rb0[TWO ? APT : 1], rw0[WPT], pg0[PGR];
+  float ra1[APT], rb1[TWO ? APT : 1], rw1[WPT], pg1[PGR];
+  int pa0[PGR], pa1[PGR];
 
   // (tile, chunk) cursors: L = next step to LOAD, S = next step to STORE to LDS, C = step computed.
   // Past the end the L/S cursors stay on the last tile: the surplus loads / LDS writes are
@@ -124,27 +129,26 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   long long l_tile = blockIdx.x, s_tile = blockIdx.x, c_tile = blockIdx.x;
   int l_chunk = 0, s_chunk = 0, c_chunk = 0;
 
-  auto load_step = [&](float (&ra)[APT], float (&rb)[TWO ? APT : 1], float (&rw)[WPT]) {
+  auto load_step = [&](float (&ra)[APT], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int (&pa)[PGR],
+                       float (&pg)[PGR]) {
     const long long m0 = l_tile * BM;
     const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
     const int k = l_chunk * KC + kk;
     const int kc = k < K ? k : (K - 1);
-    if (PRO == PRO_POOLG) {
+    if (POOL) {
       const float *X2t = a.X2 + (size_t)m0 * K;
-      const unsigned row = (unsigned)(m0 + r0);
-      unsigned grp = row / (unsigned)a.ns;
-      int smp = (int)(row - grp * (unsigned)a.ns);
 #pragma unroll
       for (int i = 0; i < APT; ++i) {
         const int rr = (r0 + RSTEP * i) < mrem ? (r0 + RSTEP * i) : (mrem - 1);
+        ra[i] = X2t[(unsigned)(rr * K + kc)];
+      }
+      const unsigned g_first = (unsigned)(m0 / a.ns);
+#pragma unroll
+      for (int e = 0; e < PGR; ++e) {
+        const unsigned grp = g_first + (unsigned)(r0 + RSTEP * e);     // patch entry (group r0 + RSTEP*e, column kk)
         const size_t goff = (size_t)(grp < last_grp ? grp : last_grp) * K + kc;
-        const int am = a.arg[goff];
-        const float gv = a.gP[goff];
-        ra[i] = (am == smp) ? gv : 0.f;
-        rb[TWO ? i : 0] = X2t[(unsigned)(rr * K + kc)];
-        smp += pool_dr;
-        grp += pool_dq;
-        if (smp >= a.ns) { smp -= a.ns; ++grp; }
+        pa[e] = a.arg[goff];
+        pg[e] = a.gP[goff];
       }
     } else {
       const float *Xt = a.X + (size_t)m0 * K;
@@ -176,7 +180,11 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   };
 
   // prologue transform + LDS write of the OLDEST loaded step
+  long long p_tile = blockIdx.x;   // cursor of the step whose sparse patch is pending (PRO_POOLG)
+  int p_chunk = 0;
   auto store_step = [&](float (&ra)[APT], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int buf) {
+    p_tile = s_tile;
+    p_chunk = s_chunk;
     const long long m0 = s_tile * BM;
     const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
     const int k = s_chunk * KC + kk;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
     if (PRO != PRO_NONE) {
       q0 = a.p0[kc];
       q1 = a.p1[kc];
-      if (TWO) q2 = a.p2[kc];
+      if (TWO || POOL) q2 = a.p2[kc];
     }
     float *Ad = &As[buf][r0 * LD + kk];
 #pragma unroll
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
       float v = ra[i];
       if (PRO == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, q0, q1), 0.f);
       if (TWO) v = __fmaf_rn(q0, v, __fmaf_rn(q1, rb[TWO ? i : 0], q2));
+      if (POOL) v = __fmaf_rn(q1, v, q2);
       Ad[RSTEP * i * LD] = (kin && (r0 + RSTEP * i) < mrem) ? v : 0.f;
     }
     float *Wd = &Ws[buf][r0 * LD + kk];
@@ -206,6 +215,22 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
     s_tile = nt < ntiles ? nt : last_tile;
   };
 
+  // sparse arg-max patch of the step stored last (runs between two barriers)
+  auto patch_step = [&](int (&pa)[PGR], float (&pg)[PGR], int buf) {
+    const long long m0 = p_tile * BM;
+    const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
+    const int k = p_chunk * KC + kk;
+    const float c1 = a.p0[k < K ? k : (K - 1)];
+    const long long g_first = m0 / a.ns;
+    const int ngrp = (int)((m0 + mrem - 1) / a.ns - g_first) + 1;
+#pragma unroll
+    for (int e = 0; e < PGR; ++e) {
+      const int gi = r0 + RSTEP * e;
+      const long long row = (g_first + gi) * (long long)a.ns + pa[e] - m0;     // tile-relative arg-max row
+      if (gi < ngrp && k < K && row >= 0 && row < mrem) As[buf][(int)row * LD + kk] += c1 * pg[e];
+    }
+  };
+
   const int arow = (wave * 32 + (lane & 31)) * LD + (lane >> 5);
   const int brow = (wcol * NT * 32 + (lane & 31)) * LD + (lane >> 5);
   const int cl = lane & 31;
@@ -214,11 +239,14 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
 
   // one pipeline iteration: compute the current step from LDS buffer `buf`; (la, lb, lw) receive
   // the loads of two steps ahead, (sa, sb, sw) hold the next step and are written to buffer buf^1
-  auto iteration = [&](int buf, float (&la)[APT], float (&lb)[TWO ? APT : 1], float (&lw)[WPT],
-                       float (&sa)[APT], float (&sb)[TWO ? APT : 1], float (&sw)[WPT]) {
+  auto iteration = [&](int buf, float (&la)[APT], float (&lb)[TWO ? APT : 1], float (&lw)[WPT], int (&lpa)[PGR],
+                       float (&lpg)[PGR], float (&sa)[APT], float (&sb)[TWO ? APT : 1], float (&sw)[WPT],
+                       int (&spa)[PGR], float (&spg)[PGR]) {
     const bool last_chunk = c_chunk == nchunks - 1;
     const long long m0 = c_tile * BM;
-    load_step(la, lb, lw);
+    // the patch registers of the step about to be stored must be consumed before load_step
+    // overwrites the OTHER set only — (spa, spg) belong to the set being stored, safe
+    load_step(la, lb, lw, lpa, lpg);
     if (MASKE) {
       if (last_chunk) {
 #pragma unroll
@@ -285,15 +313,23 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
       ++c_chunk;
     }
     __syncthreads();
+    if (POOL) {
+      patch_step(spa, spg, buf ^ 1);
+      __syncthreads();
+    }
   };
 
-  load_step(ra0, rb0, rw0);            // step 0
-  load_step(ra1, rb1, rw1);            // step 1
+  load_step(ra0, rb0, rw0, pa0, pg0);            // step 0
+  load_step(ra1, rb1, rw1, pa1, pg1);            // step 1
   store_step(ra0, rb0, rw0, 0);
   __syncthreads();
+  if (POOL) {
+    patch_step(pa0, pg0, 0);
+    __syncthreads();
+  }
   for (long long step = 0; step < total_steps; step += 2) {
-    iteration(0, ra0, rb0, rw0, ra1, rb1, rw1);
-    if (step + 1 < total_steps) iteration(1, ra1, rb1, rw1, ra0, rb0, rw0);
+    iteration(0, ra0, rb0, rw0, pa0, pg0, ra1, rb1, rw1, pa1, pg1);
+    if (step + 1 < total_steps) iteration(1, ra1, rb1, rw1, pa1, pg1, ra0, rb0, rw0, pa0, pg0);
   }
 
   // ---- flush the column sums once per workgroup ----
@@ -384,44 +420,45 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   const int kxc = kx_in ? kx : (K - 1);
   float a_sc = 1.f, a_sh = 0.f;
   if (AMODE == PRO_BNRELU) { a_sc = a.a_scale[kxc]; a_sh = a.a_shift[kxc]; }
-  const unsigned w_dq = (GMODE == PRO_POOLG) ? (unsigned)GRP / (unsigned)a.ns : 0u;
-  const int w_dr = (GMODE == PRO_POOLG) ? GRP % a.ns : 0;
-  const unsigned last_grp = (GMODE == PRO_POOLG) ? (unsigned)((M - 1) / a.ns) : 0u;
+  // PRO_POOLG: dense part c2*y + c3 from ONE matrix; the single non-zero of dL/dz per (row group,
+  // column) is patched into the LDS tile at the arg-max row (see mlp_gemm_kernel).  A 32-row tile
+  // overlaps at most 3 groups (ns >= 16); patch entry e of thread (gn, gr0) is group gr0 + GRP*e.
+  constexpr bool POOL = GMODE == PRO_POOLG;
+  constexpr int WPG = POOL ? ((3 + GRP - 1) / GRP) : 1;
+  constexpr int RGN = POOL ? 1 : GPT;          // the G matrix is only read in PRO_GY mode
+  const unsigned last_grp = POOL ? (unsigned)((M - 1) / a.ns) : 0u;
 
-  float rg0[GPT], ry0[GPT], rx0[XPT];
-  float rg1[GPT], ry1[GPT], rx1[XPT];
+  float rg0[RGN], ry0[GPT], rx0[XPT], pg0[WPG];
+  float rg1[RGN], ry1[GPT], rx1[XPT], pg1[WPG];
+  int pa0[WPG], pa1[WPG];
   long long l_rt = row_begin;     // next tile to load (clamped to the last tile past the end)
   long long s_rt = row_begin;     // next tile to write to LDS
 
-  auto load_tile = [&](float (&rg)[GPT], float (&ry)[GPT], float (&rx)[XPT]) {
+  auto load_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG]) {
     const long long rt = l_rt;
     const int rows = (int)((row_end - rt) < (long long)WR ? (row_end - rt) : (long long)WR);
     const float *Yt = a.Yl + (size_t)rt * N;
     const float *Xt = a.X + (size_t)rt * K;
-    if (GMODE == PRO_POOLG) {
-      const unsigned row = (unsigned)(rt + gr0);
-      unsigned grp = row / (unsigned)a.ns;
-      int smp = (int)(row - grp * (unsigned)a.ns);
 #pragma unroll
-      for (int i = 0; i < GPT; ++i) {
-        const int r = (gr0 + GRP * i) < rows ? (gr0 + GRP * i) : (rows - 1);
+    for (int i = 0; i < GPT; ++i) {
+      const int r = (gr0 + GRP * i) < rows ? (gr0 + GRP * i) : (rows - 1);
+      ry[i] = Yt[(unsigned)(r * N + gnc)];
+    }
+    if (POOL) {
+      const unsigned g_first = (unsigned)(rt / a.ns);
+#pragma unroll
+      for (int e = 0; e < WPG; ++e) {
+        const unsigned grp = g_first + (unsigned)(gr0 + GRP * e);
         const size_t goff = (size_t)(grp < last_grp ? grp : last_grp) * N + gnc;
-        const int am = a.arg[goff];
-        const float gv = a.gP[goff];
-        rg[i] = (am == smp) ? gv : 0.f;
-        ry[i] = Yt[(unsigned)(r * N + gnc)];
-        smp += w_dr;
-        grp += w_dq;
-        if (smp >= a.ns) { smp -= a.ns; ++grp; }
+        pa[e] = a.arg[goff];
+        pg[e] = a.gP[goff];
       }
     } else {
       const float *Gt = a.G + (size_t)rt * N;
 #pragma unroll
       for (int i = 0; i < GPT; ++i) {
         const int r = (gr0 + GRP * i) < rows ? (gr0 + GRP * i) : (rows - 1);
-        const unsigned off = (unsigned)(r * N + gnc);
-        rg[i] = Gt[off];
-        ry[i] = Yt[off];
+        rg[POOL ? 0 : i] = Gt[(unsigned)(r * N + gnc)];
       }
     }
 #pragma unroll
@@ -433,14 +470,16 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     l_rt = nt < row_end ? nt : last_rt;
   };
 
-  auto store_tile = [&](float (&rg)[GPT], float (&ry)[GPT], float (&rx)[XPT]) {
+  long long p_rt = row_begin;
+  auto store_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT]) {
     const long long rt = s_rt;
+    p_rt = rt;
     const int rows = (int)((row_end - rt) < (long long)WR ? (row_end - rt) : (long long)WR);
     if (tid < GRP * GN) {
 #pragma unroll
       for (int i = 0; i < GPT; ++i) {
         const int r = gr0 + GRP * i;
-        const float v = __fmaf_rn(c1, rg[i], __fmaf_rn(c2, ry[i], c3));
+        const float v = POOL ? __fmaf_rn(c2, ry[i], c3) : __fmaf_rn(c1, rg[POOL ? 0 : i], __fmaf_rn(c2, ry[i], c3));
         if (r < WR) Gs[r * GN + gn] = (g_thr && r < rows) ? v : 0.f;
       }
     }
@@ -454,10 +493,27 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     s_rt += WR;
   };
 
-  auto iteration = [&](float (&rg)[GPT], float (&ry)[GPT], float (&rx)[XPT]) {
+  auto patch_tile = [&](int (&pa)[WPG], float (&pg)[WPG]) {
+    const long long rt = p_rt;
+    const int rows = (int)((row_end - rt) < (long long)WR ? (row_end - rt) : (long long)WR);
+    const long long g_first = rt / a.ns;
+    const int ngrp = (int)((rt + rows - 1) / a.ns - g_first) + 1;
+#pragma unroll
+    for (int e = 0; e < WPG; ++e) {
+      const int gi = gr0 + GRP * e;
+      const long long row = (g_first + gi) * (long long)a.ns + pa[e] - rt;
+      if (g_thr && gi < ngrp && row >= 0 && row < rows) Gs[(int)row * GN + gn] += c1 * pg[e];
+    }
+  };
+
+  auto iteration = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG]) {
     store_tile(rg, ry, rx);          // tile t (loaded two iterations ago) -> LDS
+    if (POOL) {
+      __syncthreads();
+      patch_tile(pa, pg);
+    }
     __syncthreads();
-    load_tile(rg, ry, rx);           // tile t+2 into the registers just freed
+    load_tile(rg, ry, rx, pa, pg);   // tile t+2 into the registers just freed
     // A operand: A[i = n][k = r] = gy[r][n];  B operand: B[k = r][j = kcol] = act[r][kcol]
 #pragma unroll
     for (int s = 0; s < WR / 2; ++s) {
@@ -472,11 +528,11 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     __syncthreads();
   };
 
-  load_tile(rg0, ry0, rx0);
-  load_tile(rg1, ry1, rx1);
+  load_tile(rg0, ry0, rx0, pa0, pg0);
+  load_tile(rg1, ry1, rx1, pa1, pg1);
   for (long long t = 0; t < ntile; t += 2) {
-    iteration(rg0, ry0, rx0);
-    if (t + 1 < ntile) iteration(rg1, ry1, rx1);
+    iteration(rg0, ry0, rx0, pa0, pg0);
+    if (t + 1 < ntile) iteration(rg1, ry1, rx1, pa1, pg1);
   }
   // ---- flush: acc[t][reg] = dW[n = ntile*32 + rowmap][k = kb0 + ktile*32 + (lane&31)] ----
   const int kcol = kb0 + ktile * 32 + (lane & 31);
@@ -675,7 +731,8 @@ extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const f
   if ((pro == PRO_NONE || pro == PRO_BNRELU || pro == PRO_GY) && !X) return PN2_ENULL;
   if (pro != PRO_NONE && (!p0 || !p1)) return PN2_ENULL;
   if (pro >= PRO_GY && (!X2 || !p2)) return PN2_ENULL;
-  if (pro == PRO_POOLG && (!arg || !gP || ns <= 0 || M >= 0x7fffffffLL)) return PN2_EINVAL;
+  if (pro == PRO_GY && !X) return PN2_ENULL;
+  if (pro == PRO_POOLG && (!arg || !gP || ns < 16 || M >= 0x7fffffffLL)) return PN2_EINVAL;   // patch sizing assumes ns >= 16
   if (epi != EPI_NONE && !stats) return PN2_ENULL;
   if (epi == EPI_MASK && (!Yprev || !e_fin)) return PN2_ENULL;
   if ((M + BM - 1) / BM > 0x7fffffffLL) return PN2_EINVAL;
@@ -714,7 +771,7 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
   if (M == 0) return PN2_OK;
   if (!Yl || !consts || !X || !dW) return PN2_ENULL;
   if (gmode == PRO_GY && !G) return PN2_ENULL;
-  if (gmode == PRO_POOLG && (!arg || !gP || ns <= 0 || M >= 0x7fffffffLL)) return PN2_EINVAL;
+  if (gmode == PRO_POOLG && (!arg || !gP || ns < 16 || M >= 0x7fffffffLL)) return PN2_EINVAL;
   if (amode == PRO_BNRELU && !a_fin) return PN2_ENULL;
   WgradArgs a;
   a.G = G; a.Yl = Yl; a.c1 = consts; a.c2 = consts + N; a.c3 = consts + 2 * (size_t)N;

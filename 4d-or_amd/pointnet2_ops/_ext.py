@@ -157,9 +157,10 @@ class KernelTimer:
 
 
 TIMER = None  # set to a KernelTimer() to profile
+DETAIL_TAGS = os.environ.get("PN2_TIMER_DETAIL") == "1"   # per-shape rows for the MLP kernels
 
 
-def _call(name, ref, *args, alg_bytes=0, alg_flops=0):
+def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None):
     """Enqueue `name` on the current stream of `ref`'s device."""
     with torch.cuda.device(ref.device):
         stream = torch.cuda.current_stream(ref.device).cuda_stream
@@ -168,7 +169,7 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0):
             ev0.record()
             rc = getattr(_lib, name)(*args, stream)
             ev1.record()
-            TIMER.records.append((name, ev0, ev1, int(alg_bytes), int(alg_flops)))
+            TIMER.records.append((name if tag is None else f"{name}[{tag}]", ev0, ev1, int(alg_bytes), int(alg_flops)))
         else:
             rc = getattr(_lib, name)(*args, stream)
     if rc != 0:
@@ -453,7 +454,7 @@ def mlp_gemm(X, W, pro=PRO_NONE, epi=EPI_NONE, X2=None, p=None, arg=None, gP=Non
     nbytes = 4 * (M * K * (2 if pro >= PRO_GY else 1) + M * N * (2 if epi == EPI_MASK else 1) + N * K)
     _call("pn2_mlp_gemm", W, M, K, N, int(pro), int(epi), _ptr(X), _ptr(X2), _ptr(p0), _ptr(p1), _ptr(p2),
           _ptr(arg), _ptr(gP), int(ns), _ptr(W), _ptr(Y), _ptr(stats), _ptr(Yprev), _ptr(e_fin),
-          alg_bytes=nbytes, alg_flops=flops)
+          alg_bytes=nbytes, alg_flops=flops, tag=(f"M{M},K{K},N{N},pro{int(pro)},epi{int(epi)}" if DETAIL_TAGS else None))
     return Y
 
 
@@ -464,7 +465,8 @@ def mlp_wgrad(Yl, consts, X, gmode, amode, G=None, arg=None, gP=None, ns=0, a_fi
     dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
     _call("pn2_mlp_wgrad", Yl, M, N, K, int(gmode), int(amode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg),
           _ptr(gP), int(ns), _ptr(X), _ptr(a_fin), _ptr(dW),
-          alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + M * K + N * K), alg_flops=2 * M * N * K)
+          alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + M * K + N * K), alg_flops=2 * M * N * K,
+          tag=(f"M{M},N{N},K{K},g{int(gmode)},a{int(amode)}" if DETAIL_TAGS else None))
     return dW
 
 

@@ -54,9 +54,11 @@ def parse_stack(mlp: nn.Module) -> Optional[List[Tuple[nn.Conv2d, nn.modules.bat
     return layers
 
 
-def supported(mlp: nn.Module, x: torch.Tensor) -> bool:
+def supported(mlp: nn.Module, x: torch.Tensor, ns: int = 0) -> bool:
     e = _ext()
     if not getattr(e, "HAS_FUSED_MLP", False) or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    if ns and ns < 16:          # the pooled-gradient patch of the backward kernels is sized for ns >= 16
         return False
     layers = parse_stack(mlp)
     if layers is None:

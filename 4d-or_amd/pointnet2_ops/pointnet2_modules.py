@@ -114,7 +114,7 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows) -> torch.Te
     from pointnet2_ops import fused_mlp
     if (_FUSED_MLP and isinstance(grouper, pointnet2_utils.QueryAndGroup) and new_xyz is not None
             and (grouper.use_xyz or feats_rows is not None)
-            and fused_mlp.supported(mlp, xyz if feats_rows is None else feats_rows)):
+            and fused_mlp.supported(mlp, xyz if feats_rows is None else feats_rows, grouper.nsample)):
         idx = grouper.query(xyz, new_xyz)
         return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
                                               grouper.normalize_xyz, grouper.radius)
@@ -126,7 +126,7 @@ def mlp_pool_rows(mlp: nn.Module, grouped: torch.Tensor) -> torch.Tensor:
     from pointnet2_ops import fused_mlp
     B, npoint, nsample, width = grouped.shape
     rows = grouped.reshape(-1, width)
-    if _FUSED_MLP and fused_mlp.supported(mlp, rows):
+    if _FUSED_MLP and fused_mlp.supported(mlp, rows, nsample):
         return fused_mlp.fused_shared_mlp(mlp, rows, nsample).view(B, npoint, -1)
     h = shared_mlp_rows(mlp, rows)
     return pointnet2_utils.rows_max(h.view(B * npoint, nsample, -1)).view(B, npoint, -1)
