@@ -633,31 +633,58 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_prep_kernel(long long M, int 
   }
 }
 
-// Fused BN + ReLU + max over the ns rows of each group: y (R*ns, C) -> pooled (R, C), arg (R, C).
-__global__ __launch_bounds__(256) void bn_relu_rows_max_kernel(size_t total /* R*C */, int ns, int C,
+// Fused BN + ReLU + max over the ns rows of each group: y (R*ns, C) -> pooled (R, C), arg (R, C)
+// and the raw pre-BN value at the arg-max (so the backward reductions need no gather from y).
+// VEC = channels per thread (4 -> dwordx4 loads when C % 4 == 0).
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_relu_rows_max_kernel(size_t total /* R*C/VEC */, int ns, int C,
                                                               const float *__restrict__ y,
                                                               const float *__restrict__ fin,
-                                                              float *__restrict__ out, int *__restrict__ arg) {
+                                                              float *__restrict__ out, int *__restrict__ arg,
+                                                              float *__restrict__ yraw) {
+  const int CV = C / VEC;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const size_t r = e / C;
-    const int c = (int)(e - r * C);
-    const float sc = fin[2 * C + c], sh = fin[3 * C + c];
+    const size_t r = e / CV;
+    const int c = (int)(e - r * CV) * VEC;
+    float sc[VEC], sh[VEC], best[VEC], braw[VEC];
+    int bi[VEC];
     const float *p = y + r * ns * C + c;
-    float best = fmaxf(__fmaf_rn(p[0], sc, sh), 0.f);
-    int bi = 0;
-    for (int s = 1; s < ns; ++s) {
-      const float v = fmaxf(__fmaf_rn(p[(size_t)s * C], sc, sh), 0.f);
-      if (v > best) { best = v; bi = s; }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      sc[v] = fin[2 * C + c + v];
+      sh[v] = fin[3 * C + c + v];
+      braw[v] = p[v];
+      best[v] = fmaxf(__fmaf_rn(braw[v], sc[v], sh[v]), 0.f);
+      bi[v] = 0;
     }
-    out[e] = best;
-    arg[e] = bi;
+    for (int s = 1; s < ns; ++s) {
+      float raw[VEC];
+      if (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(p + (size_t)s * C);
+        raw[0] = q.x; raw[1 % VEC] = q.y; raw[2 % VEC] = q.z; raw[3 % VEC] = q.w;
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) raw[v] = p[(size_t)s * C + v];
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float z = fmaxf(__fmaf_rn(raw[v], sc[v], sh[v]), 0.f);
+        if (z > best[v]) { best[v] = z; bi[v] = s; braw[v] = raw[v]; }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      out[r * C + c + v] = best[v];
+      arg[r * C + c + v] = bi[v];
+      yraw[r * C + c + v] = braw[v];
+    }
   }
 }
 
-// Pool backward reductions: gPm = gP * [pooled > 0]; dbeta += gPm; dgamma += gPm * yhat[argmax row].
-__global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int ns, int C, const float *__restrict__ y,
+// Pool backward reductions: gPm = gP * [pooled > 0]; dbeta += gPm; dgamma += gPm * yhat[arg-max row]
+// (yraw = the pre-BN value at the arg-max, saved by the forward kernel).
+__global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int C, const float *__restrict__ yraw,
                                                            const float *__restrict__ pooled,
-                                                           const int *__restrict__ arg,
                                                            const float *__restrict__ gP,
                                                            const float *__restrict__ fin,
                                                            float *__restrict__ gPm, double *__restrict__ sums) {
@@ -671,9 +698,8 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int ns,
       const size_t off = (size_t)r * C + c;
       const float g = pooled[off] > 0.f ? gP[off] : 0.f;
       gPm[off] = g;
-      const float yy = y[((size_t)r * ns + arg[off]) * C + c];
       s1 += g;
-      s2 = __fmaf_rn(g, (yy - mean) * rstd, s2);
+      s2 = __fmaf_rn(g, (yraw[off] - mean) * rstd, s2);
     }
     atomicAdd(sums + c, (double)s1);
     atomicAdd(sums + C + c, (double)s2);
@@ -851,23 +877,29 @@ extern "C" int pn2_bn_relu_bwd_prep(long long M, int N, const float *y, const fl
 }
 
 extern "C" int pn2_bn_relu_rows_max(long long R, int ns, int C, const float *y, const float *fin,
-                                    float *out, int *arg, void *stream) {
+                                    float *out, int *arg, float *yraw, void *stream) {
   if (R < 0 || ns <= 0 || C <= 0) return PN2_EINVAL;
   if (R == 0) return PN2_OK;
-  if (!y || !fin || !out || !arg) return PN2_ENULL;
-  const size_t total = (size_t)R * C;
-  hipLaunchKernelGGL(bn_relu_rows_max_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                     total, ns, C, y, fin, out, arg);
+  if (!y || !fin || !out || !arg || !yraw) return PN2_ENULL;
+  if (C % 4 == 0 && ((uintptr_t)y & 15) == 0) {
+    const size_t total = (size_t)R * (C / 4);
+    hipLaunchKernelGGL(bn_relu_rows_max_kernel<4>, dim3(capped_grid(total, 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, total, ns, C, y, fin, out, arg, yraw);
+  } else {
+    const size_t total = (size_t)R * C;
+    hipLaunchKernelGGL(bn_relu_rows_max_kernel<1>, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       total, ns, C, y, fin, out, arg, yraw);
+  }
   return pn2_check_launch();
 }
 
-extern "C" int pn2_pool_bwd_prep(long long R, int ns, int C, const float *y, const float *pooled,
-                                 const int *arg, const float *gP, const float *fin, float *gPm,
-                                 double *sums, void *stream) {
-  if (R < 0 || ns <= 0 || C <= 0) return PN2_EINVAL;
+extern "C" int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const float *pooled,
+                                 const float *gP, const float *fin, float *gPm, double *sums,
+                                 void *stream) {
+  if (R < 0 || C <= 0) return PN2_EINVAL;
   if (R == 0) return PN2_OK;
-  if (!y || !pooled || !arg || !gP || !fin || !gPm || !sums) return PN2_ENULL;
+  if (!yraw || !pooled || !gP || !fin || !gPm || !sums) return PN2_ENULL;
   hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0,
-                     (hipStream_t)stream, R, ns, C, y, pooled, arg, gP, fin, gPm, sums);
+                     (hipStream_t)stream, R, C, yraw, pooled, gP, fin, gPm, sums);
   return pn2_check_launch();
 }

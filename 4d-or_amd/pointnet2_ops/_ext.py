@@ -64,8 +64,8 @@ _SIGNATURES = {
     "pn2_bn_bwd_consts": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_apply": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_bwd_prep": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
-    "pn2_bn_relu_rows_max": [ctypes.c_longlong, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
-    "pn2_pool_bwd_prep": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 8,
+    "pn2_bn_relu_rows_max": [ctypes.c_longlong, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_pool_bwd_prep": [ctypes.c_longlong, _c_int] + [_c_vp] * 7,
 }
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here == ABI mismatch: fail loudly
@@ -508,15 +508,16 @@ def bn_relu_rows_max(y, fin, ns):
     R = M // int(ns)
     out = torch.empty(R, C, dtype=torch.float32, device=y.device)
     arg = torch.empty(R, C, dtype=torch.int32, device=y.device)
-    _call("pn2_bn_relu_rows_max", y, R, int(ns), C, _ptr(y), _ptr(fin), _ptr(out), _ptr(arg),
-          alg_bytes=4 * M * C + 8 * R * C)
-    return out, arg
+    yraw = torch.empty(R, C, dtype=torch.float32, device=y.device)
+    _call("pn2_bn_relu_rows_max", y, R, int(ns), C, _ptr(y), _ptr(fin), _ptr(out), _ptr(arg), _ptr(yraw),
+          alg_bytes=4 * M * C + 12 * R * C)
+    return out, arg, yraw
 
 
-def pool_bwd_prep(y, pooled, arg, gP, fin, ns):
+def pool_bwd_prep(yraw, pooled, gP, fin):
     R, C = pooled.shape
     gPm = torch.empty_like(pooled)
-    sums = torch.zeros(2, C, dtype=torch.float64, device=y.device)
-    _call("pn2_pool_bwd_prep", y, R, int(ns), C, _ptr(y), _ptr(pooled), _ptr(arg), _ptr(gP), _ptr(fin), _ptr(gPm),
-          _ptr(sums), alg_bytes=20 * R * C)
+    sums = torch.zeros(2, C, dtype=torch.float64, device=pooled.device)
+    _call("pn2_pool_bwd_prep", pooled, R, C, _ptr(yraw), _ptr(pooled), _ptr(gP), _ptr(fin), _ptr(gPm),
+          _ptr(sums), alg_bytes=16 * R * C)
     return gPm, sums

@@ -115,15 +115,16 @@ class _FusedMLP(Function):
             fins.append(fin)
             batch_flags.append(use_batch)
             cur = y
+        yraw = None
         if ns:
-            out, arg = e.bn_relu_rows_max(ys[-1], fins[-1], ns)
+            out, arg, yraw = e.bn_relu_rows_max(ys[-1], fins[-1], ns)
         else:
             out, arg = e.bn_relu_apply(ys[-1], fins[-1]), None
         ctx.ns, ctx.L, ctx.batch_flags = ns, L, batch_flags
         ctx.shapes = [params[3 * l].shape for l in range(L)]
         saved = [x] + ys + fins + [params[3 * l] for l in range(L)] + [params[3 * l + 1] for l in range(L)]
         if ns:
-            saved += [out, arg]
+            saved += [out, arg, yraw]
             ctx.mark_non_differentiable(arg)
         ctx.save_for_backward(*saved)
         return (out, arg) if ns else out
@@ -142,8 +143,8 @@ class _FusedMLP(Function):
         g_out = g_out.contiguous()
 
         if ns:
-            pooled, arg = saved[1 + 4 * L], saved[2 + 4 * L]
-            gPm, sums = e.pool_bwd_prep(ys[-1], pooled, arg, g_out, fins[-1], ns)
+            pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
+            gPm, sums = e.pool_bwd_prep(yraw, pooled, g_out, fins[-1])
             gmode, G = e.PRO_POOLG, None
         else:
             G, sums = e.bn_relu_bwd_prep(ys[-1], g_out, fins[-1])

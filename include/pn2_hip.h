@@ -190,7 +190,8 @@ int pn2_three_interpolate_rows_grad(int B, int C, int m, int n, int ldg,
  *   pn2_bn_relu_apply / pn2_bn_relu_bwd_prep: materialised ReLU(BN(y)) and its backward prep
  *     (gpre = gout*[z>0], sums ACCUMULATE) for stacks that must return activations (FP modules).
  *   pn2_bn_relu_rows_max / pn2_pool_bwd_prep: ReLU(BN(y)) fused into the neighbourhood max
- *     (+ first arg-max) and the matching backward reductions (gPm = gP*[pooled>0]).
+ *     (+ first arg-max, + yraw = pre-BN value at the arg-max) and the matching backward
+ *     reductions (gPm = gP*[pooled>0]; sums ACCUMULATE).
  */
 int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const float *X, const float *X2,
                  const float *p0, const float *p1, const float *p2, const int *arg,
@@ -210,10 +211,10 @@ int pn2_bn_relu_apply(long long M, int N, const float *y, const float *fin, floa
 int pn2_bn_relu_bwd_prep(long long M, int N, const float *y, const float *gout,
                          const float *fin, float *gpre, double *sums, void *stream);
 int pn2_bn_relu_rows_max(long long R, int ns, int C, const float *y, const float *fin,
-                         float *out, int *arg, void *stream);
-int pn2_pool_bwd_prep(long long R, int ns, int C, const float *y, const float *pooled,
-                      const int *arg, const float *gP, const float *fin, float *gPm,
-                      double *sums, void *stream);
+                         float *out, int *arg, float *yraw, void *stream);
+int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const float *pooled,
+                      const float *gP, const float *fin, float *gPm, double *sums,
+                      void *stream);
 
 /* ------------------------------------------------------------------ A12 ---
  * TripletGCN edge primitives.  Replace torch_geometric 2.0.2

@@ -45,7 +45,10 @@ def _check(module, inputs):
             # gradient entries off by 2 %).  Compare in norm.
             assert float((got[1] - ref[1]).norm() / ref[1].norm()) < 3e-2
         for a, b in zip(got[2], ref[2]):      # parameter grads: sums over 10^4..10^5 rows (atomics reorder them)
-            assert float((a - b).abs().max()) <= 5e-4 * float(b.abs().max()) + 1e-5, (a - b).abs().max()
+            if fast:
+                assert float((a - b).abs().max()) <= 5e-4 * float(b.abs().max()) + 1e-5, (a - b).abs().max()
+            else:                             # literal GPU path: see the arg-max note above
+                assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-5
 
 
 def _cloud(B, N, C, seed):
