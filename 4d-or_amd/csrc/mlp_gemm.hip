@@ -371,7 +371,7 @@ struct WgradArgs {
   int N, K, ns, gmode /* PRO_GY | PRO_POOLG */, amode /* PRO_NONE | PRO_BNRELU */;
 };
 
-constexpr int WR = 32;        // rows per LDS tile
+
 constexpr int WMAXN = 320;    // 10 n-tiles
 constexpr int WKB = 128;      // K columns per workgroup
 
@@ -380,6 +380,7 @@ constexpr int WKB = 128;      // K columns per workgroup
 // (tile t+2 is loaded while tile t runs on the MFMAs).
 template <int NTW, int GMODE, int AMODE>  // n-tiles per wave (total n-tiles <= 2*NTW)
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
+  constexpr int WR = 32;       // rows per LDS tile (64 for the narrow variants was measured: no gain, +60 VGPRs)
   constexpr int GN = 2 * NTW * 32;
   __shared__ float Gs[WR * GN];
   __shared__ float Xs[WR * WKB];
@@ -421,10 +422,10 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   float a_sc = 1.f, a_sh = 0.f;
   if (AMODE == PRO_BNRELU) { a_sc = a.a_scale[kxc]; a_sh = a.a_shift[kxc]; }
   // PRO_POOLG: dense part c2*y + c3 from ONE matrix; the single non-zero of dL/dz per (row group,
-  // column) is patched into the LDS tile at the arg-max row (see mlp_gemm_kernel).  A 32-row tile
-  // overlaps at most 3 groups (ns >= 16); patch entry e of thread (gn, gr0) is group gr0 + GRP*e.
+  // column) is patched into the LDS tile at the arg-max row (see mlp_gemm_kernel).  A WR-row tile
+  // overlaps at most WR/16 + 1 groups (ns >= 16); patch entry e of thread (gn, gr0) is group gr0 + GRP*e.
   constexpr bool POOL = GMODE == PRO_POOLG;
-  constexpr int WPG = POOL ? ((3 + GRP - 1) / GRP) : 1;
+  constexpr int WPG = POOL ? ((WR / 16 + 1 + GRP - 1) / GRP) : 1;
   constexpr int RGN = POOL ? 1 : GPT;          // the G matrix is only read in PRO_GY mode
   const unsigned last_grp = POOL ? (unsigned)((M - 1) / a.ns) : 0u;
 
@@ -810,7 +811,7 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
   long long wgs = 512 / kblocks;
   if (wgs < 1) wgs = 1;
   long long rows = (M + wgs - 1) / wgs;
-  rows = ((rows + WR - 1) / WR) * WR;
+  rows = ((rows + 63) / 64) * 64;     // multiple of every variant's tile height
   a.rows_per_wg = rows;
   const unsigned gx = (unsigned)((M + rows - 1) / rows);
   hipStream_t s = (hipStream_t)stream;
