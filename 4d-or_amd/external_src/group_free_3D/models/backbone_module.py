@@ -34,21 +34,42 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def forward(self, pointcloud: torch.Tensor, end_points=None):
+    @torch.no_grad()
+    def precompute_geometry(self, pointcloud: torch.Tensor):
+        """Everything in the forward that depends on the coordinates only — the FPS chain, the sampled
+        centres, the ball-query neighbourhoods and the 3-NN interpolation weights of the FP levels.
+        No parameters are involved, so a training pipeline can run this for batch i+1 on a side stream
+        while batch i is in its forward/backward (bench.py does); pass the result as `geometry=`."""
+        xyz = pointcloud[..., 0:3].contiguous()
+        geo = {"sa": [], "fp": []}
+        levels = [xyz]
+        for i in (1, 2, 3, 4):
+            g = getattr(self, f"sa{i}").sample_and_query(levels[-1])
+            geo["sa"].append(g)
+            levels.append(g["new_xyz"])
+        geo["fp"].append(self.fp1.interpolation(levels[3], levels[4]))
+        geo["fp"].append(self.fp2.interpolation(levels[2], levels[3]))
+        return geo
+
+    def forward(self, pointcloud: torch.Tensor, end_points=None, geometry=None):
         """pointcloud (B, N, 3 + input_feature_dim) -> end_points dict with
-        sa{1..4}_xyz / _features (/ _inds for 1,2) and fp2_{features,xyz,inds}."""
+        sa{1..4}_xyz / _features (/ _inds for 1,2) and fp2_{features,xyz,inds}.
+        `geometry` = precompute_geometry(pointcloud) (optional; identical results)."""
         end_points = end_points or {}
         xyz, features = self._break_up_pc(pointcloud)
         for i in (1, 2, 3, 4):
-            xyz, features, inds = getattr(self, f"sa{i}")(xyz, features)
+            xyz, features, inds = getattr(self, f"sa{i}")(
+                xyz, features, geometry=None if geometry is None else geometry["sa"][i - 1])
             if i <= 2:
                 end_points[f"sa{i}_inds"] = inds
             end_points[f"sa{i}_xyz"] = xyz
             end_points[f"sa{i}_features"] = features
         features = self.fp1(end_points["sa3_xyz"], end_points["sa4_xyz"],
-                            end_points["sa3_features"], end_points["sa4_features"])
+                            end_points["sa3_features"], end_points["sa4_features"],
+                            interp=None if geometry is None else geometry["fp"][0])
         features = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"],
-                            end_points["sa2_features"], features)
+                            end_points["sa2_features"], features,
+                            interp=None if geometry is None else geometry["fp"][1])
         end_points["fp2_features"] = features
         end_points["fp2_xyz"] = end_points["sa2_xyz"]
         num_seed = end_points["fp2_xyz"].shape[1]

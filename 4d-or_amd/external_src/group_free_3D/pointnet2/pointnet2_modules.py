@@ -38,8 +38,23 @@ class PointnetSAModuleVotes(nn.Module):
             mlp[0] += 3                      # in place like the reference (:205-207)
         self.mlp_module = pt_utils.SharedMLP(mlp, bn=bn)
 
-    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
-        """xyz (B,N,3), features (B,C,N) -> (new_xyz (B,npoint,3), new_features (B,C',npoint), inds (B,npoint))."""
+    def sample_and_query(self, xyz: torch.Tensor, inds: torch.Tensor = None):
+        """The data-only part of the module (no parameters, no features): FPS indices, sampled centres
+        and ball-query neighbourhoods.  Lets a pipeline compute the geometry of the NEXT batch on a side
+        stream while the current batch trains (see Pointnet2Backbone.precompute_geometry)."""
+        if inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        new_xyz = pointnet2_utils.gather_operation(
+            xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        return {"inds": inds, "new_xyz": new_xyz, "idx": self.grouper.query(xyz, new_xyz)}
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None, geometry=None):
+        """xyz (B,N,3), features (B,C,N) -> (new_xyz (B,npoint,3), new_features (B,C',npoint), inds (B,npoint)).
+        `geometry` = result of sample_and_query(xyz) computed earlier (optional)."""
+        if geometry is not None and self.pooling == "max" and _pm._rows_path_ok(xyz, features):
+            rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, geometry["new_xyz"],
+                                     pointnet2_utils.as_rows(features), idx=geometry["idx"])
+            return geometry["new_xyz"], pointnet2_utils.rows_to_channels(rows), geometry["inds"]
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:

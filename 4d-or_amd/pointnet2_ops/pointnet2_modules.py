@@ -107,7 +107,7 @@ def mlp_rows(mlp: nn.Module, rows: torch.Tensor) -> torch.Tensor:
     return shared_mlp_rows(mlp, rows)
 
 
-def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows) -> torch.Tensor:
+def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None) -> torch.Tensor:
     """One SA scale on the rows path: group -> shared MLP -> max -> (B, npoint, C_out).
     Ball-query groupers with a fusable MLP run as a single autograd node (gather, MLP, pool and
     the scatter of the feature gradient); anything else goes through forward_rows + mlp_pool_rows."""
@@ -115,9 +115,14 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows) -> torch.Te
     if (_FUSED_MLP and isinstance(grouper, pointnet2_utils.QueryAndGroup) and new_xyz is not None
             and (grouper.use_xyz or feats_rows is not None)
             and fused_mlp.supported(mlp, xyz if feats_rows is None else feats_rows, grouper.nsample)):
-        idx = grouper.query(xyz, new_xyz)
+        if idx is None:
+            idx = grouper.query(xyz, new_xyz)
         return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
                                               grouper.normalize_xyz, grouper.radius)
+    if idx is not None:
+        g = pointnet2_utils.group_concat_rows(xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
+                                              grouper.normalize_xyz, grouper.radius)
+        return mlp_pool_rows(mlp, g)
     return mlp_pool_rows(mlp, grouper.forward_rows(xyz, new_xyz, feats_rows))
 
 
@@ -222,11 +227,15 @@ class PointnetFPModule(nn.Module):
         recip = 1.0 / (dist + 1e-8)
         return idx, recip / torch.sum(recip, dim=2, keepdim=True)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    def interpolation(self, unknown, known):
+        """Data-only part: (idx (B,n,3) int32, weight (B,n,3)) of the inverse-distance 3-NN interpolation."""
+        return self._weights(unknown, known)
+
+    def forward(self, unknown, known, unknow_feats, known_feats, interp=None):
         """unknown (B,n,3), known (B,m,3)|None, unknow_feats (B,C1,n)|None,
-        known_feats (B,C2,m) -> (B, mlp[-1], n)."""
+        known_feats (B,C2,m) -> (B, mlp[-1], n).  `interp` = interpolation(unknown, known) computed earlier."""
         if _rows_path_ok(unknown, known_feats) and (unknow_feats is None or unknow_feats.dtype == torch.float32):
-            return self._forward_rows(unknown, known, unknow_feats, known_feats)
+            return self._forward_rows(unknown, known, unknow_feats, known_feats, interp)
 
         if known is not None:
             idx, weight = self._weights(unknown, known)
@@ -236,11 +245,11 @@ class PointnetFPModule(nn.Module):
         stacked = spread if unknow_feats is None else torch.cat([spread, unknow_feats], dim=1)
         return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
 
-    def _forward_rows(self, unknown, known, unknow_feats, known_feats):
+    def _forward_rows(self, unknown, known, unknow_feats, known_feats, interp=None):
         B, n = unknown.size(0), unknown.size(1)
         known_rows = pointnet2_utils.as_rows(known_feats)               # (B,m,C2)
         if known is not None:
-            idx, weight = self._weights(unknown, known)
+            idx, weight = interp if interp is not None else self._weights(unknown, known)
             spread = pointnet2_utils.three_interpolate_rows(known_rows, idx, weight)
         else:
             spread = known_rows.expand(B, n, known_rows.size(2))

@@ -6,7 +6,10 @@ batch 32 per GPU, fp32, through the full SA/FP stack (BASELINE configs[1]:
 Group-Free `Pointnet2Backbone` shapes: SA 2048/0.2/64, 1024/0.4/32, 512/0.8/16,
 256/1.2/16 + 2 FP levels).  A "step" = forward, loss, backward (gradient
 all-reduce over RCCL when N > 1) and the AdamW update on one resident synthetic
-batch.  Weak scaling: every rank processes its own 32 scenes.
+batch.  Weak scaling: every rank processes its own 32 scenes.  Everything, including
+the sampling / grouping geometry, runs inside the step on one stream.  (`--geometry-pipeline`
+optionally prefetches the next batch's coordinate-only work on a side stream, data-loader
+style; measured: no net gain on MI355X, so it is off by default.)
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -52,13 +55,57 @@ def build_model(device):
     return Pointnet2Backbone(input_feature_dim=3).to(device)
 
 
-def train_step(model, opt, pc):
+def train_step(model, opt, pc, geometry=None):
     opt.zero_grad(set_to_none=True)
-    feats = model(pc)["fp2_features"]
+    feats = model(pc, geometry=geometry)["fp2_features"]
     loss = feats.square().mean()
     loss.backward()
     opt.step()
     return loss
+
+
+class GeometryPrefetcher:
+    """Data-loader-style pipelining of the coordinate-only work (FPS chain, ball queries, 3-NN
+    weights: no parameters involved).  The geometry of the NEXT batch is enqueued on a side HIP
+    stream before the current batch's forward/backward is enqueued on the main stream; the
+    latency-bound cooperative FPS kernel (8 waves per CU) co-runs with the MFMA kernels.
+    Every timed step still computes one full geometry (for the following step)."""
+
+    def __init__(self, backbone, device):
+        self.backbone = backbone
+        self.side = torch.cuda.Stream(device=device)
+        self.main = torch.cuda.current_stream(device)
+
+    def launch(self, pc):
+        self.side.wait_stream(self.main)          # pc (and everything it depends on) is ready
+        with torch.cuda.stream(self.side):
+            geo = self.backbone.precompute_geometry(pc)
+        return geo
+
+    def acquire(self, geo):
+        self.main.wait_stream(self.side)
+        for part in geo["sa"]:
+            for t in part.values():
+                t.record_stream(self.main)
+        for idx, w in geo["fp"]:
+            idx.record_stream(self.main)
+            w.record_stream(self.main)
+        return geo
+
+
+def run_steps(net, backbone, opt, pc, steps, prefetcher):
+    """`steps` training steps on the resident batch; with a prefetcher, step i consumes the geometry
+    enqueued during step i-1 and enqueues the one for step i+1."""
+    if prefetcher is None:
+        for _ in range(steps):
+            train_step(net, opt, pc)
+        return
+    geo = prefetcher.launch(pc)
+    for _ in range(steps):
+        cur = prefetcher.acquire(geo)
+        geo = prefetcher.launch(pc)               # next batch's geometry, side stream
+        train_step(net, opt, pc, cur)             # this batch, main stream
+    prefetcher.acquire(geo)
 
 
 def cpu_baseline(points, sample_scenes, threads):
@@ -93,6 +140,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scenes", type=int, default=4)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--geometry-pipeline", action="store_true",
+                    help="prefetch the NEXT batch's sampling/grouping geometry on a side stream during the step "
+                         "(measured on MI355X: no net gain, the co-resident FPS workgroups halve the occupancy of the "
+                         "memory-bound SA1 GEMMs; off by default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,9 +171,20 @@ def main():
     opt = torch.optim.AdamW(model.parameters(), lr=3e-5, weight_decay=1e-3)
     pc = synthetic_scenes(args.batch, args.points, seed=1000 + rank, device=device)   # resident in HBM
 
-    for _ in range(args.warmup):
-        train_step(net, opt, pc)
+    prefetcher = GeometryPrefetcher(model, device) if args.geometry_pipeline else None
+    run_steps(net, model, opt, pc, args.warmup, prefetcher)
     torch.cuda.synchronize()
+
+    # reference number without the geometry pipeline (same build, same batch), reported alongside
+    serial_ms = None
+    if prefetcher is not None and rank == 0 and world == 1:
+        ks = max(2, min(args.steps, 5))
+        run_steps(net, model, opt, pc, 1, None)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        run_steps(net, model, opt, pc, ks, None)
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - ts) / ks * 1e3
 
     timer = None
     if not args.no_kernel_timing:
@@ -132,8 +194,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        train_step(net, opt, pc)
+    run_steps(net, model, opt, pc, args.steps, prefetcher)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -168,8 +229,12 @@ def main():
                 "global_batch": args.batch * world,
                 "points_per_scene": args.points,
                 "parallelism": f"dp{world}",
+                "geometry_pipeline": "off" if prefetcher is None else
+                "on: FPS / ball-query / 3-NN of batch i+1 run on a side stream during step i (one geometry per timed step)",
             },
         }
+        if serial_ms is not None:
+            out["ms_per_step_without_geometry_pipeline"] = round(serial_ms, 3)
         if timer is not None:
             table = timer.summary()
             rows = []

@@ -103,3 +103,34 @@ def test_msg_encoder_gpu_matches_golden_fixture():
         with torch.no_grad():
             y = enc(torch.from_numpy(z[f"d{dim}/x"]).cuda())
         np.testing.assert_allclose(y.cpu().numpy(), z[f"d{dim}/y"], atol=1e-4, rtol=1e-3)
+
+
+def test_precomputed_geometry_on_a_side_stream_gives_identical_results():
+    """Backbone.precompute_geometry (run on another stream) + forward(geometry=...) == plain forward."""
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    torch.manual_seed(5)
+    net = Pointnet2Backbone(input_feature_dim=3).cuda().eval()
+    g = torch.Generator().manual_seed(6)
+    pc = (torch.rand(4, 20000, 6, generator=g) * 2 - 1).cuda()
+    with torch.no_grad():
+        ref = net(pc)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        geo = net.precompute_geometry(pc)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.no_grad():
+        got = net(pc, geometry=geo)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+    # and with gradients
+    net.train()
+    a = net(pc)["fp2_features"].square().mean()
+    a.backward()
+    g0 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    b = net(pc, geometry=geo)["fp2_features"].square().mean()
+    b.backward()
+    assert abs(float(a.detach()) - float(b.detach())) < 1e-6
+    for x, y in zip(g0, [p.grad for p in net.parameters()]):     # two train-mode runs: atomics-order noise only
+        assert float((x - y).norm()) <= 2e-2 * float(x.norm()) + 1e-6
