@@ -73,8 +73,18 @@ constexpr int BM = 128;
 //
 // CW = wave columns: the workgroup is 4 x CW waves; wave (wr, wc) owns rows wr*32.. and the
 // NT column tiles wc*NT.. (CW = 2 keeps N = 256/288 at 64-80 accumulator registers per wave).
+template <int NT, int CW, int PRO, int EPI>
+constexpr int gemm_min_waves() {
+  // tuning hook (PN2 build flag): cap VGPRs at 128 for the narrow forward variants => 4 waves/SIMD
+#ifdef PN2_GEMM_OCC4
+  return (EPI != EPI_MASK && PRO <= PRO_BNRELU && NT <= 2) ? 4 : 2;
+#else
+  return 2;
+#endif
+}
+
 template <int NT, int KC, int CW, int PRO, int EPI>
-__global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) void mlp_gemm_kernel(const GemmArgs a) {
   constexpr int THREADS = 256 * CW;
   constexpr int NTT = NT * CW;                 // column tiles per workgroup
   constexpr int LD = KC + 1;
@@ -373,23 +383,28 @@ struct WgradArgs {
 
 
 constexpr int WMAXN = 320;    // 10 n-tiles
-constexpr int WKB = 128;      // K columns per workgroup
+
 
 // Same discipline as mlp_gemm_kernel: modes are template parameters, loads are unconditional
 // from clamped addresses, the tile loop is straight-line code over a two-deep register ring
 // (tile t+2 is loaded while tile t runs on the MFMAs).
-template <int NTW, int GMODE, int AMODE>  // n-tiles per wave (total n-tiles <= 2*NTW)
+// KT = 32-column k-tiles per workgroup column block (4 -> 128 K-columns; 2 for K <= 64 so that all
+// eight waves — and all four SIMDs — own useful output tiles): wave w owns k-tile w % KT and the
+// n-tiles (w / KT) + (8/KT)*t, t < NTW.
+template <int NTW, int GMODE, int AMODE, int KT>  // n-tiles per wave (total n-tiles <= (8/KT)*NTW)
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   constexpr int WR = 32;       // rows per LDS tile (64 for the narrow variants was measured: no gain, +60 VGPRs)
-  constexpr int GN = 2 * NTW * 32;
+  constexpr int WKB = 32 * KT;
+  constexpr int NPARS = 8 / KT;
+  constexpr int GN = NPARS * NTW * 32;
   __shared__ float Gs[WR * GN];
   __shared__ float Xs[WR * WKB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int ktile = wave & 3;
-  const int npar = wave >> 2;
+  const int ktile = wave % KT;
+  const int npar = wave / KT;
   const int kb0 = blockIdx.y * WKB;
   const int N = a.N, K = a.K;
   const long long M = a.M;
@@ -522,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
       const float bv = Xs[rr * WKB + ktile * 32 + (lane & 31)];
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
-        const float av = Gs[rr * GN + (npar + 2 * t) * 32 + (lane & 31)];
+        const float av = Gs[rr * GN + (npar + NPARS * t) * 32 + (lane & 31)];
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
       }
     }
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   const int kcol = kb0 + ktile * 32 + (lane & 31);
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
-    const int nb = (npar + 2 * t) * 32 + 4 * (lane >> 5);
+    const int nb = (npar + NPARS * t) * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = nb + (r & 3) + 8 * (r >> 2);
@@ -807,7 +822,10 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
   a.a_shift = a_fin ? a_fin + 3 * (size_t)K : nullptr;
   a.dW = dW; a.M = M; a.N = N; a.K = K; a.ns = ns; a.gmode = gmode; a.amode = amode;
   // persistent-style: ~2 workgroups per CU, each a contiguous slab of rows (multiple of WR)
-  const unsigned kblocks = (unsigned)((K + WKB - 1) / WKB);
+  // two k-tiles only pay when there are enough n-tiles to keep four wave groups busy (measured:
+  // N=128,K=64 1.48 -> 1.14 ms; N=64,K=64 0.86 -> 1.06 ms because the gy tile would be staged 128 wide)
+  const int kt = (K <= 64 && N > 64) ? 2 : 4;
+  const unsigned kblocks = (unsigned)((K + 32 * kt - 1) / (32 * kt));
   long long wgs = 512 / kblocks;
   if (wgs < 1) wgs = 1;
   long long rows = (M + wgs - 1) / wgs;
@@ -817,21 +835,27 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
   hipStream_t s = (hipStream_t)stream;
   const int ntiles = (N + 31) / 32;
   dim3 grid(gx, kblocks);
-#define PN2_WGRAD(NTW)                                                                                   \
+#define PN2_WGRAD(NTW, KT)                                                                               \
   do {                                                                                                 \
     if (gmode == PRO_GY && amode == PRO_NONE)                                                          \
-      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_GY, PRO_NONE>), grid, dim3(512), 0, s, a);         \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_GY, PRO_NONE, KT>), grid, dim3(512), 0, s, a);     \
     else if (gmode == PRO_GY)                                                                          \
-      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_GY, PRO_BNRELU>), grid, dim3(512), 0, s, a);       \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_GY, PRO_BNRELU, KT>), grid, dim3(512), 0, s, a);   \
     else if (amode == PRO_NONE)                                                                        \
-      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_POOLG, PRO_NONE>), grid, dim3(512), 0, s, a);      \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_POOLG, PRO_NONE, KT>), grid, dim3(512), 0, s, a);  \
     else                                                                                               \
-      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_POOLG, PRO_BNRELU>), grid, dim3(512), 0, s, a);    \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_POOLG, PRO_BNRELU, KT>), grid, dim3(512), 0, s, a);\
   } while (0)
-  if (ntiles <= 2) PN2_WGRAD(1);
-  else if (ntiles <= 4) PN2_WGRAD(2);
-  else if (ntiles <= 8) PN2_WGRAD(4);
-  else PN2_WGRAD(5);
+  if (kt == 2) {          // four n-groups of waves
+    if (ntiles <= 4) PN2_WGRAD(1, 2);
+    else if (ntiles <= 8) PN2_WGRAD(2, 2);
+    else PN2_WGRAD(3, 2);
+  } else {                // two n-groups of waves
+    if (ntiles <= 2) PN2_WGRAD(1, 4);
+    else if (ntiles <= 4) PN2_WGRAD(2, 4);
+    else if (ntiles <= 8) PN2_WGRAD(4, 4);
+    else PN2_WGRAD(5, 4);
+  }
 #undef PN2_WGRAD
   return pn2_check_launch();
 }

@@ -55,13 +55,14 @@ def build_model(device):
     return Pointnet2Backbone(input_feature_dim=3).to(device)
 
 
-def train_step(model, opt, pc, geometry=None):
+def train_step(model, opt, pc, geometry=None, between=None):
     opt.zero_grad(set_to_none=True)
     feats = model(pc, geometry=geometry)["fp2_features"]
     loss = feats.square().mean()
+    nxt = between() if between is not None else None     # hook between forward and backward
     loss.backward()
     opt.step()
-    return loss
+    return nxt
 
 
 class GeometryPrefetcher:
@@ -103,8 +104,9 @@ def run_steps(net, backbone, opt, pc, steps, prefetcher):
     geo = prefetcher.launch(pc)
     for _ in range(steps):
         cur = prefetcher.acquire(geo)
-        geo = prefetcher.launch(pc)               # next batch's geometry, side stream
-        train_step(net, opt, pc, cur)             # this batch, main stream
+        # the next batch's geometry is enqueued behind this batch's FORWARD, so that the latency-bound
+        # FPS kernel co-runs with the (mostly compute-bound) first half of the backward
+        geo = train_step(net, opt, pc, cur, between=lambda: prefetcher.launch(pc))
     prefetcher.acquire(geo)
 
 
