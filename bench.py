@@ -268,7 +268,23 @@ def main():
                 else:
                     out["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
                                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"]}
-                out["roofline"].update({"traffic": None, "avg_launch_us": top["avg_launch_us"],
+                traffic, traffic_src = None, None
+                tf = os.path.join(REPO, "profiles", "r01_hbm_traffic_per_kernel.json")
+                kname = {"pn2_mlp_gemm": "mlp_gemm_kernel", "pn2_mlp_wgrad": "mlp_wgrad_kernel",
+                         "pn2_bn_relu_rows_max": "bn_relu_rows_max_kernel",
+                         "pn2_group_concat_rows": "group_concat_rows_kernel",
+                         "pn2_group_rows_grad": "group_rows_grad_kernel"}.get(top["kernel"])
+                if kname and os.path.exists(tf):
+                    try:
+                        rec = json.load(open(tf))["kernels"].get(kname)
+                        if rec:
+                            traffic = int(rec["hbm_bytes_per_launch"])
+                            traffic_src = ("PMC FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE per launch, separate rocprofv3 "
+                                           "passes over this command: profiles/r01_hbm_traffic_per_kernel.json")
+                    except Exception:
+                        pass
+                out["roofline"].update({"traffic": traffic, "traffic_source": traffic_src,
+                                        "avg_launch_us": top["avg_launch_us"],
                                         "alg_bytes_per_launch": int(top["alg_MB_per_launch"] * 1e6),
                                         "alg_flops_per_launch": int(top["alg_GFLOP_per_launch"] * 1e9),
                                         "note": "entry point aggregated over its launches in the timed steps "
