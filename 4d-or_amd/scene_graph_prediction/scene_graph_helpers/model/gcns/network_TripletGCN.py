@@ -50,24 +50,40 @@ def build_mlp(dim_list, activation="relu", do_bn=False, dropout=0, on_last=False
 
 
 class EdgeCSR:
-    """Stable sort of the edge targets, computed once per graph and shared by all layers."""
+    """Stable sort of the edge targets, computed once per graph and shared by all layers.
+
+    Built without a device->host round trip: the counts come from a scatter-add (``torch.bincount``
+    would read the maximum back) and the range check of a CUDA ``edge_index`` is an asynchronous
+    device assertion, so a training step that only holds the edges on the GPU never drains the
+    stream.  A CPU ``edge_index`` is validated eagerly (RuntimeError)."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int):
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise RuntimeError("edge_index must have shape (2, E)")
         self.src = edge_index[0].contiguous()
         self.dst = edge_index[1].contiguous()
-        self.num_nodes = int(num_nodes)
-        if self.dst.numel() and (int(edge_index.min()) < 0 or int(edge_index.max()) >= num_nodes):
-            raise RuntimeError("edge_index out of range")
-        self.order = torch.sort(self.dst, stable=True).indices.contiguous()
-        counts = torch.bincount(self.dst, minlength=self.num_nodes)
-        self.rowptr = torch.zeros(self.num_nodes + 1, dtype=torch.int64, device=edge_index.device)
-        self.rowptr[1:] = torch.cumsum(counts, 0)
+        self.num_nodes = n = int(num_nodes)
+        if self.dst.numel():
+            ok = (edge_index >= 0).all() & (edge_index < n).all()
+            if edge_index.is_cuda:
+                torch._assert_async(ok)
+            elif not bool(ok):
+                raise RuntimeError("edge_index out of range")
+        self.order, self.rowptr = self._csr(self.dst, n)
         # CSR by source, for the backward of the x_j gather
-        self.order_src = torch.sort(self.src, stable=True).indices.contiguous()
-        self.rowptr_src = torch.zeros_like(self.rowptr)
-        self.rowptr_src[1:] = torch.cumsum(torch.bincount(self.src, minlength=self.num_nodes), 0)
+        self.order_src, self.rowptr_src = self._csr(self.src, n)
+
+    @staticmethod
+    def _csr(key, n):
+        order = torch.sort(key, stable=True).indices.contiguous()
+        counts = torch.zeros(n + 1, dtype=torch.int64, device=key.device)
+        counts.scatter_add_(0, key + 1, torch.ones_like(key))
+        return order, torch.cumsum(counts, 0)
+
+    def to(self, device):
+        for k in ("src", "dst", "order", "rowptr", "order_src", "rowptr_src"):
+            setattr(self, k, getattr(self, k).to(device, non_blocking=True))
+        return self
 
 
 class _TripletConcat(Function):
@@ -142,8 +158,11 @@ class TripletGCNModel(BaseNetwork):
         self.num_layers = num_layers
         self.gconvs = torch.nn.ModuleList(TripletGCN(**kwargs) for _ in range(num_layers))
 
-    def forward(self, node_feature, edge_feature, edges_indices) -> Tuple[torch.Tensor, torch.Tensor]:
-        csr = EdgeCSR(edges_indices, node_feature.size(0))
+    def forward(self, node_feature, edge_feature, edges_indices, csr: Optional[EdgeCSR] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """`csr` (optional) is an EdgeCSR of `edges_indices` prepared ahead of time (e.g. by the data
+        loader, on the host); without it the CSR is built here, sync-free, once per call."""
+        if csr is None:
+            csr = EdgeCSR(edges_indices, node_feature.size(0))
         for i, gconv in enumerate(self.gconvs):
             node_feature, edge_feature = gconv(node_feature, edge_feature, edges_indices, csr)
             if i < self.num_layers - 1:

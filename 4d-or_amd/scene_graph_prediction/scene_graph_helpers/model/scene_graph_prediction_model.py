@@ -31,7 +31,10 @@ class SGPNModelWrapper(nn.Module):
         self.config = config
         self.mconfig = config["MODEL"]
         self.n_object_types = 6
-        self.weights_obj, self.weights_rel = weights_obj, weights_rel
+        # class weights of the two NLL terms: non-persistent buffers, so they follow .to(device) once instead
+        # of being uploaded every step (reference :63-64 / :140-141) and stay out of the state_dict
+        self.register_buffer("weights_obj", torch.as_tensor(weights_obj, dtype=torch.float32), persistent=False)
+        self.register_buffer("weights_rel", torch.as_tensor(weights_rel, dtype=torch.float32), persistent=False)
         self.relationNames = relationNames
         self.lr = float(self.config["LR"])
         self.reset_metrics()
@@ -51,7 +54,7 @@ class SGPNModelWrapper(nn.Module):
     def forward(self, batch, return_meta_data=False):
         obj_feature = self.obj_encoder(batch["obj_points"])
         rel_feature = self.rel_encoder(batch["rel_points"])
-        gcn_obj_feature, gcn_rel_feature = self.gcn(obj_feature, rel_feature, batch["edge_indices"])
+        gcn_obj_feature, gcn_rel_feature = self.gcn(obj_feature, rel_feature, batch["edge_indices"], batch.get("edge_csr"))
         obj_cls = self.obj_predictor(gcn_obj_feature if self.mconfig["OBJ_PRED_FROM_GCN"] else obj_feature)
         rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=batch["relation_objects_one_hot"])
         if return_meta_data:
@@ -60,8 +63,8 @@ class SGPNModelWrapper(nn.Module):
 
     # ------------------------------------------------------------------ steps
     def loss(self, obj_pred, rel_pred, batch):
-        loss_obj = F.nll_loss(obj_pred, batch["gt_class"], weight=self.weights_obj.to(batch["gt_class"].device))
-        loss_rel = F.nll_loss(rel_pred, batch["gt_rels"], weight=self.weights_rel.to(batch["gt_rels"].device))
+        loss_obj = F.nll_loss(obj_pred, batch["gt_class"], weight=self.weights_obj.to(batch["gt_class"].device, non_blocking=True))
+        loss_rel = F.nll_loss(rel_pred, batch["gt_rels"], weight=self.weights_rel.to(batch["gt_rels"].device, non_blocking=True))
         return self.mconfig["lambda_o"] * loss_obj + loss_rel
 
     def _step(self, batch, split):

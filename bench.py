@@ -132,6 +132,75 @@ def cpu_baseline(points, sample_scenes, threads):
                       f"(oracle ops are OpenMP-parallel over scenes; MLPs torch CPU with {threads} threads)"}
 
 
+def bench_sgp(args, device, rank, world, distributed, _ext):
+    """BASELINE configs[2] shape on one or more GPUs: SGPNModelWrapper (2 MSG encoders + 2-layer
+    TripletGCN + heads), one synthetic scan per step and rank, fwd + loss + bwd + AdamW, fp32."""
+    from scene_graph_prediction.main import RELATION_NAMES, config_loader
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import synthetic_scan, to_device
+    from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+    cfg = config_loader("no_gt.json")
+    torch.manual_seed(0)
+    model = SGPNModelWrapper(cfg, 12, len(RELATION_NAMES), torch.ones(12), torch.ones(len(RELATION_NAMES)),
+                             RELATION_NAMES).to(device).train()
+    net = model
+    if distributed:
+        # the two inherited `backbone.fc_layer` heads never receive a gradient (SURVEY.md §5): freeze them
+        for n, p in model.named_parameters():
+            if ".backbone.fc_layer." in n:
+                p.requires_grad_(False)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=64)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=float(cfg["LR"]),
+                            weight_decay=float(cfg["W_DECAY"]))
+    scan = to_device(synthetic_scan(9, 4000, 8000, seed=100 + rank), device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        obj, rel = net(scan)
+        model.loss(obj, rel, scan).backward()
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timer = None
+    if not args.no_kernel_timing:
+        timer = _ext.KernelTimer()
+        _ext.TIMER = timer
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _ext.TIMER = None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        out = {"metric": "OR scans/sec fwd+bwd (9 objects x 4000 pts + 72 pairs x 8000 pts per scan)",
+               "value": round(world * args.steps / elapsed, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[2] shape: SGPNModelWrapper(no_gt.json), 1 synthetic scan per step "
+                                      "and rank, train mode, fwd + weighted NLL + bwd + AdamW",
+                          "parallelism": f"dp{world}"}}
+        if timer is not None:
+            rows = [{"kernel": k, "calls_per_step": d["calls"] / args.steps, "ms_per_step": round(d["ms"] / args.steps, 4)}
+                    for k, d in timer.summary().items()]
+            rows.sort(key=lambda r: -r["ms_per_step"])
+            out["kernels"] = rows
+            out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in rows), 3)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +211,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scenes", type=int, default=4)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--workload", choices=["backbone", "sgp"], default="backbone",
+                    help="backbone = BASELINE configs[1] (the headline metric); sgp = BASELINE configs[2] shape: the full "
+                         "scene-graph model on synthetic scans (9 objects x 4000 pts + 72 pairs x 8000 pts, one scan per "
+                         "step like the reference's DataLoader(batch_size=1)), fp32")
     ap.add_argument("--geometry-pipeline", action="store_true",
                     help="prefetch the NEXT batch's sampling/grouping geometry on a side stream during the step "
                          "(measured on MI355X: no net gain, the co-resident FPS workgroups halve the occupancy of the "
@@ -163,6 +236,9 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     from pointnet2_ops import _ext
+
+    if args.workload == "sgp":
+        return bench_sgp(args, device, rank, world, distributed, _ext)
 
     model = build_model(device)
     net = model

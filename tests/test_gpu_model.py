@@ -134,3 +134,16 @@ def test_precomputed_geometry_on_a_side_stream_gives_identical_results():
     assert abs(float(a.detach()) - float(b.detach())) < 1e-6
     for x, y in zip(g0, [p.grad for p in net.parameters()]):     # two train-mode runs: atomics-order noise only
         assert float((x - y).norm()) <= 2e-2 * float(x.norm()) + 1e-6
+
+
+def test_runner_emits_scan_relations_wire_format(tmp_path):
+    """infer mode of the thin runner: {scan_id: [[subject, predicate, object], ...]} (main.py:111-115)."""
+    import json as _json
+    from scene_graph_prediction import main as runner
+    out = tmp_path / "rels.json"
+    runner.main(["--mode", "infer", "--scans", "2", "--objects", "4", "--out", str(out)])
+    data = _json.load(open(out))
+    assert set(data) == {"synthetic_000000", "synthetic_000001"}
+    for triples in data.values():
+        for sub, pred, obj in triples:
+            assert pred in runner.RELATION_NAMES and pred != "none" and isinstance(sub, str) and isinstance(obj, str)
