@@ -1,0 +1,2 @@
+"""Host-side runtime pieces around the HIP path (no kernels here)."""
+from runtime.graphed_step import FlatGrads, GraphedTrainStep, batch_signature  # noqa: F401

@@ -1,0 +1,156 @@
+"""Whole training step as a replayed hipGraph.
+
+The scene-graph step is ~450 kernel launches of which most are a few microseconds long
+(72 pair clouds of 8000 points, 9 object clouds of 4000): enqueueing them costs the host more
+than executing them costs the GPU.  ``GraphedTrainStep`` captures
+
+    grads <- 0 ; loss, outputs = step_fn(batch) ; loss.backward() ; optimizer.step()
+
+once per batch *signature* (the shapes / dtypes of the batch's tensors, i.e. the number of
+objects and points of a scan) into a hipGraph on the capture stream and replays it afterwards;
+a new signature is run eagerly once (that call is an ordinary training step and also warms
+every lazily initialised handle) and captured on its next occurrence.
+
+Gradients live in ONE flat fp32 buffer whose slices are the parameters' ``.grad`` views, so
+  * the graph zeroes / accumulates them in place (static addresses across replays), and
+  * data parallelism is a single all-reduce of that buffer between the backward graph and the
+    optimizer graph (one process per GPU, RCCL over xGMI; the models on this path have a few MB
+    of gradients, so one unbucketed collective after the backward costs less than a
+    bucket-per-hook schedule would).  With world size 1 the two graphs are one.
+
+``capture=False`` runs the same schedule eagerly (flat gradients, one all-reduce): the
+debugging mode, and the only one available on a CPU/gloo job.
+
+Reference behaviour replaced: pytorch_lightning's ``Trainer.fit`` inner loop over
+``training_step`` / ``optimizer.step`` (scene_graph_prediction/main.py:58-66 of the reference),
+which issues every kernel from Python each step.
+"""
+from typing import Any, Callable, Dict, Iterable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def batch_signature(batch: Dict[str, Any]) -> Tuple:
+    return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+
+
+class FlatGrads:
+    """One contiguous gradient buffer; every parameter's ``.grad`` is a view of it."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("FlatGrads needs all parameters on one device with one dtype")
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, group=None):
+        world = dist.get_world_size(group)
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.mul_(1.0 / world)
+
+
+class _Captured:
+    __slots__ = ("static", "fwd_bwd", "opt", "loss", "outputs")
+
+
+class GraphedTrainStep:
+    """step_fn(batch) -> (loss, outputs) where outputs is a tensor / tuple of tensors / None.
+
+    __call__(batch) performs one optimisation step and returns (loss, outputs); with capture
+    on, both are static tensors that the next call with the same signature overwrites."""
+
+    def __init__(self, step_fn: Callable[[Dict[str, Any]], Tuple[torch.Tensor, Any]],
+                 params: Iterable[torch.nn.Parameter], optimizer: torch.optim.Optimizer,
+                 capture: bool = True, process_group=None, max_graphs: int = 32):
+        self.step_fn, self.optimizer = step_fn, optimizer
+        self.grads = FlatGrads(params)
+        self.group = process_group
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.capture = bool(capture)
+        self.max_graphs = int(max_graphs)
+        self._seen: Dict[Tuple, int] = {}
+        self._graphs: Dict[Tuple, _Captured] = {}
+        if self.capture:
+            if not self.grads.flat.is_cuda:
+                raise RuntimeError("GraphedTrainStep(capture=True) needs the model on a GPU; use capture=False on CPU")
+            for g in optimizer.param_groups:
+                if "capturable" in g and not g["capturable"]:
+                    raise ValueError("the optimizer must be built with capturable=True to be replayed in a graph")
+            self._stream = torch.cuda.Stream(device=self.grads.flat.device)
+
+    # ------------------------------------------------------------------ eager schedule
+    def _eager(self, batch):
+        self.grads.zero_()
+        loss, outputs = self.step_fn(batch)
+        loss.backward()
+        if self.distributed:
+            self.grads.all_reduce_mean(self.group)
+        self.optimizer.step()
+        return loss.detach(), outputs
+
+    # ------------------------------------------------------------------ capture
+    def _capture(self, batch, sig) -> _Captured:
+        for k, v in batch.items():
+            if not (torch.is_tensor(v) or v is None or isinstance(v, (str, int, float, bool, dict, list, tuple))):
+                raise ValueError(f"batch[{k!r}] ({type(v).__name__}) may hold device tensors whose addresses a graph "
+                                 "would freeze; pass plain tensors and let step_fn derive such objects")
+        c = _Captured()
+        c.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        c.fwd_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(c.fwd_bwd, stream=self._stream):
+            self.grads.zero_()
+            loss, outputs = self.step_fn(c.static)
+            loss.backward()
+            if not self.distributed:
+                self.optimizer.step()
+        c.loss = loss.detach()
+        c.outputs = outputs
+        c.opt = None
+        if self.distributed:
+            c.opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(c.opt, stream=self._stream):
+                self.optimizer.step()
+        return c
+
+    def __call__(self, batch: Dict[str, Any]):
+        if not self.capture:
+            return self._eager(batch)
+        sig = batch_signature(batch)
+        c = self._graphs.get(sig)
+        if c is None:
+            n = self._seen.get(sig, 0)
+            self._seen[sig] = n + 1
+            if n == 0 or len(self._graphs) >= self.max_graphs:
+                # first occurrence: an ordinary step on the capture stream (lazy handles, optimizer state)
+                self._stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._stream):
+                    out = self._eager(batch)
+                torch.cuda.current_stream().wait_stream(self._stream)
+                return out
+            c = self._graphs[sig] = self._capture(batch, sig)
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                c.static[k].copy_(v, non_blocking=True)
+            else:
+                c.static[k] = v
+        c.fwd_bwd.replay()
+        if c.opt is not None:
+            self.grads.all_reduce_mean(self.group)
+            c.opt.replay()
+        return c.loss, c.outputs
+
+    @property
+    def num_graphs(self) -> int:
+        return len(self._graphs)

@@ -37,6 +37,9 @@ def main(argv=None):
     ap.add_argument("--objects", type=int, default=9)
     ap.add_argument("--weights", type=str, default=None, help="state_dict (.pth) of the reference model")
     ap.add_argument("--out", type=str, default="scan_relations_synthetic.json")
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--graphs", action="store_true",
+                    help="train mode: replay each scan shape's whole step (fwd + loss + bwd + AdamW) as one hipGraph")
     args = ap.parse_args(argv)
 
     torch.manual_seed(42)                                     # main.py:40 seeds everything with 42
@@ -51,13 +54,29 @@ def main(argv=None):
 
     if args.mode == "train":
         model.train()
-        opt = model.configure_optimizers()
-        for i, scan in enumerate(scans):                      # batch = one scan per step, like main.py:54-56
-            opt.zero_grad(set_to_none=True)
-            loss = model.training_step(to_device(scan, "cuda"), i)
-            loss.backward()
-            opt.step()
-            print(f"step {i}: loss {float(loss.detach()):.4f}")
+        opt = model.configure_optimizers(capturable=args.graphs)
+        if args.graphs:
+            from runtime import GraphedTrainStep
+            # flat gradients are dense zeros where eager autograd leaves None: keep AdamW's weight decay off the
+            # classifier heads the encoders inherit but never call by freezing them
+            for n, p in model.named_parameters():
+                if ".backbone.fc_layer." in n:
+                    p.requires_grad_(False)
+            opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=model.lr,
+                                    weight_decay=float(config["W_DECAY"]), capturable=True)
+            graphed = GraphedTrainStep(model.pure_training_step, model.parameters(), opt)
+        for epoch in range(args.epochs):
+            for i, scan in enumerate(scans):                  # batch = one scan per step, like main.py:54-56
+                batch = to_device(scan, "cuda")
+                if args.graphs:
+                    loss, rel_pred = graphed(batch)
+                    model.update_metrics(batch, rel_pred, split="train")
+                else:
+                    opt.zero_grad(set_to_none=True)
+                    loss = model.training_step(batch, i)
+                    loss.backward()
+                    opt.step()
+                print(f"epoch {epoch} step {i}: loss {float(loss.detach()):.4f}")
         print(json.dumps({k: v for k, v in model.evaluate_predictions(0.0, "train").items() if k != "per_take"}))
         return
     model.eval()

@@ -92,8 +92,16 @@ class SGPNModelWrapper(nn.Module):
             triples.append((batch["objs_json"][start + 1], self.relationNames[rel], batch["objs_json"][end + 1]))
         return batch["scan_id"], triples
 
-    def configure_optimizers(self):
-        return optim.AdamW(params=self.parameters(), lr=self.lr, weight_decay=float(self.config["W_DECAY"]))
+    def configure_optimizers(self, capturable=False):
+        """AdamW(lr=LR, weight_decay=W_DECAY) (reference :240-242); `capturable` keeps the step counters on
+        the device so the update can be replayed inside a hipGraph (runtime.GraphedTrainStep)."""
+        return optim.AdamW(params=self.parameters(), lr=self.lr, weight_decay=float(self.config["W_DECAY"]),
+                           capturable=bool(capturable))
+
+    def pure_training_step(self, batch):
+        """(loss, rel_pred) without host-side bookkeeping: the body a graph capture needs."""
+        obj_pred, rel_pred = self(batch)
+        return self.loss(obj_pred, rel_pred, batch), rel_pred
 
     # ------------------------------------------------------------------ metrics
     def reset_metrics(self, split=None):

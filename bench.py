@@ -142,22 +142,30 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     torch.manual_seed(0)
     model = SGPNModelWrapper(cfg, 12, len(RELATION_NAMES), torch.ones(12), torch.ones(len(RELATION_NAMES)),
                              RELATION_NAMES).to(device).train()
-    net = model
-    if distributed:
-        # the two inherited `backbone.fc_layer` heads never receive a gradient: freeze them
-        for n, p in model.named_parameters():
-            if ".backbone.fc_layer." in n:
-                p.requires_grad_(False)
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=64)
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=float(cfg["LR"]),
-                            weight_decay=float(cfg["W_DECAY"]))
+    # the two inherited `backbone.fc_layer` heads never receive a gradient: freeze them
+    for n, p in model.named_parameters():
+        if ".backbone.fc_layer." in n:
+            p.requires_grad_(False)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(trainable, lr=float(cfg["LR"]), weight_decay=float(cfg["W_DECAY"]), capturable=args.graphs)
     scan = to_device(synthetic_scan(9, 4000, 8000, seed=100 + rank), device)
+    if args.graphs:
+        from runtime import GraphedTrainStep
+        graphed = GraphedTrainStep(model.pure_training_step, trainable, opt)
+        args.no_kernel_timing = True          # HIP events cannot be recorded around kernels inside a replay
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        obj, rel = net(scan)
-        model.loss(obj, rel, scan).backward()
-        opt.step()
+        def step():
+            graphed(scan)
+    else:
+        net = model
+        if distributed:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=64)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            obj, rel = net(scan)
+            model.loss(obj, rel, scan).backward()
+            opt.step()
 
     for _ in range(args.warmup):
         step()
@@ -189,7 +197,7 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[2] shape: SGPNModelWrapper(no_gt.json), 1 synthetic scan per step "
                                       "and rank, train mode, fwd + weighted NLL + bwd + AdamW",
-                          "parallelism": f"dp{world}"}}
+                          "parallelism": f"dp{world}", "hip_graphs": bool(args.graphs)}}
         if timer is not None:
             rows = [{"kernel": k, "calls_per_step": d["calls"] / args.steps, "ms_per_step": round(d["ms"] / args.steps, 4)}
                     for k, d in timer.summary().items()]
@@ -215,6 +223,9 @@ def main():
                     help="backbone = BASELINE configs[1] (the headline metric); sgp = BASELINE configs[2] shape: the full "
                          "scene-graph model on synthetic scans (9 objects x 4000 pts + 72 pairs x 8000 pts, one scan per "
                          "step like the reference's DataLoader(batch_size=1)), fp32")
+    ap.add_argument("--graphs", action="store_true",
+                    help="sgp workload: replay the whole step as one hipGraph (runtime.GraphedTrainStep); gradients are "
+                         "averaged with one flat all-reduce between the backward and the optimizer graph when N > 1")
     ap.add_argument("--geometry-pipeline", action="store_true",
                     help="prefetch the NEXT batch's sampling/grouping geometry on a side stream during the step "
                          "(measured on MI355X: no net gain, the co-resident FPS workgroups halve the occupancy of the "

@@ -1,0 +1,74 @@
+"""Whole-step hipGraph replay (runtime.GraphedTrainStep) of the scene-graph model: the gradients a
+replay leaves in the flat buffer equal an eager backward on the same scan, for two alternating scan
+shapes (two graphs), and a captured AdamW trajectory trains."""
+import copy
+
+import pytest
+import torch
+
+from runtime import GraphedTrainStep
+from scene_graph_prediction.main import RELATION_NAMES, config_loader
+from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import synthetic_scan, to_device
+from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    torch.manual_seed(0)
+    cfg = config_loader("no_gt.json")
+    m = SGPNModelWrapper(cfg, 12, len(RELATION_NAMES), torch.ones(12), torch.ones(len(RELATION_NAMES)), RELATION_NAMES)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0                                   # deterministic comparison
+    for n, p in m.named_parameters():
+        if ".backbone.fc_layer." in n:
+            p.requires_grad_(False)
+    return m.cuda().train()
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def test_replayed_gradients_equal_eager_backward_for_two_scan_shapes():
+    model = _model()
+    ref = copy.deepcopy(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.0)                 # weights frozen: every call must reproduce the eager gradient
+    stepper = GraphedTrainStep(model.pure_training_step, params, opt)
+    scans = [to_device(synthetic_scan(n, 1024, 2048, seed=s), "cuda") for n, s in ((5, 1), (6, 2), (5, 3), (6, 4), (5, 5), (6, 6))]
+    for i, scan in enumerate(scans):
+        loss, rel_pred = stepper(scan)
+        wants = []
+        for _ in range(2):                                # twice: the eager path's own run-to-run spread (fp32 atomics
+            ref.zero_grad(set_to_none=True)               # order, amplified by the BatchNorms over a handful of nodes)
+            rl, rp = ref.pure_training_step(scan)
+            rl.backward()
+            wants.append(torch.cat([p.grad.flatten() for p in ref.parameters() if p.requires_grad]))
+        want, noise = wants[0], _rel(wants[1], wants[0])
+        assert abs(float(loss) - float(rl.detach())) < 1e-3, i
+        torch.testing.assert_close(rel_pred, rp, atol=2e-3, rtol=1e-3)   # log-probs behind BatchNorms over 5-6 nodes
+        assert _rel(stepper.grads.flat, want) < max(1e-2, 10 * noise), (i, noise)   # a stale-buffer bug would be O(1)
+    assert stepper.num_graphs == 2                        # scans 0/1 ran eagerly, 2/3 captured, 4/5 replayed
+
+
+def test_captured_adamw_trajectory_trains():
+    model = _model()
+    params = [p for p in model.parameters() if p.requires_grad]
+    before = torch.cat([p.detach().flatten() for p in params]).clone()
+    opt = torch.optim.AdamW(params, lr=1e-3, capturable=True)
+    stepper = GraphedTrainStep(model.pure_training_step, params, opt)
+    scan = to_device(synthetic_scan(3, 1024, 2048, seed=7), "cuda")
+    losses = [float(stepper(scan)[0]) for _ in range(12)]
+    assert stepper.num_graphs == 1
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    after = torch.cat([p.detach().flatten() for p in params])
+    assert float((after - before).abs().max()) > 0
+
+
+def test_non_capturable_adam_is_rejected():
+    model = _model()
+    params = [p for p in model.parameters() if p.requires_grad]
+    with pytest.raises(ValueError, match="capturable=True"):
+        GraphedTrainStep(model.pure_training_step, params, torch.optim.AdamW(params, lr=1e-3))
