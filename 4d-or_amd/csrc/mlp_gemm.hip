@@ -32,7 +32,7 @@
 // through double-buffered LDS with +1 padding (conflict-free ds_read_b32 fragment
 // reads), global loads of the next chunk in flight behind the current chunk's MFMAs.
 #include "pn2_common.h"
-
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -59,32 +59,52 @@ struct GemmArgs {
 
 constexpr int BM = 128;
 
+// ---- raw buffer access (gfx950) ------------------------------------------------
+// Every global access of the GEMM goes through a buffer descriptor built from wave-uniform
+// scalars: the per-lane part of the address is a 32-bit byte offset that is CONSTANT for the
+// whole kernel, the tile / chunk part lives in the descriptor base and the SGPR offset, and rows
+// or columns outside the matrix are simply out of range — loads return 0, stores are dropped
+// (the SGPR offset takes part in the range check on gfx950: tools/ubench/buffer_oob.hip).
+// Result: zero VALU instructions per load/store.  That matters more than anything else here:
+// v_mfma_f32_32x32x2_f32 and fp32/int VALU instructions do NOT overlap on a SIMD
+// (tools/ubench/mfma_valu_overlap.hip: time(MFMA + VALU) >= time(MFMA) + time(VALU), from the
+// same wave or from different waves), so every VALU instruction in the loop is paid in full.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned kRsrcMaxBytes = 0x40000000u;          // descriptors are clamped to 1 GiB windows
+constexpr int kOobOffset = 0x40000000;                   // per-lane offset of an invalid column
+
+// `bytes` > 0 by construction at every call site (tile cursors never pass the last tile); the clamp is
+// written on the unsigned high bits so that it stays on the scalar unit (s_cmp has no signed 64-bit form)
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, long long bytes) {
+  const unsigned long long b = (unsigned long long)bytes;
+  const unsigned n = (b >> 30) ? kRsrcMaxBytes : (unsigned)b;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ int bload_i(rsrc_t r, int voff, int soff) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+__device__ __forceinline__ void bstore(float v, rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 // Persistent, software-pipelined workgroups.  A workgroup walks row tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ... and the (tile, K-chunk) steps form ONE
 // pipeline over a two-deep register ring: the global loads of step s+2 are issued before
 // the MFMAs of step s, the registers of step s+1 (loaded one iteration earlier) are
 // transformed (prologue) and written to LDS buffer (s+1)&1 after them; one barrier per
-// step.  Prologue / epilogue modes are TEMPLATE parameters and every load is unconditional
-// (clamped addresses, masked when written to LDS): the loop body must stay straight-line
-// code, otherwise hipcc's s_waitcnt insertion degrades to vmcnt(0) in front of the MFMA
-// block and nothing overlaps (measured: MFMA time and memory time simply added up).
+// step.  Prologue / epilogue modes are TEMPLATE parameters and the loop body is straight-line
+// code: with conditionals around loads hipcc's s_waitcnt insertion degrades to vmcnt(0) in
+// front of the MFMA block and nothing overlaps.
 // Column sums for the epilogue reductions stay in registers across tiles and are flushed
 // once per workgroup.
 //
 // CW = wave columns: the workgroup is 4 x CW waves; wave (wr, wc) owns rows wr*32.. and the
 // NT column tiles wc*NT.. (CW = 2 keeps N = 256/288 at 64-80 accumulator registers per wave).
-template <int NT, int CW, int PRO, int EPI>
-constexpr int gemm_min_waves() {
-  // tuning hook (PN2 build flag): cap VGPRs at 128 for the narrow forward variants => 4 waves/SIMD
-#ifdef PN2_GEMM_OCC4
-  return (EPI != EPI_MASK && PRO <= PRO_BNRELU && NT <= 2) ? 4 : 2;
-#else
-  return 2;
-#endif
-}
-
 template <int NT, int KC, int CW, int PRO, int EPI>
-__global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) void mlp_gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a) {
   constexpr int THREADS = 256 * CW;
   constexpr int NTT = NT * CW;                 // column tiles per workgroup
   constexpr int LD = KC + 1;
@@ -97,6 +117,11 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
   __shared__ float As[2][BM * LD];
   __shared__ float Ws[2][NTT * 32 * LD];
   __shared__ float red[2][NTT * 32];
+  // per-input-column prologue parameters (p0, p1, p2), staged once and ZERO beyond K: a padded
+  // column then evaluates to relu(0*x + 0) = 0 (v_max_f32 drops a NaN operand) resp. 0*g + 0*y + 0,
+  // so ragged K needs no masks.  (A global load inside the step loop would be the youngest entry of
+  // the in-order vmcnt queue and waiting for it would drain the whole prefetch ring.)
+  extern __shared__ float prm[];               // [3][Kpad], Kpad = nchunks * KC
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -106,10 +131,20 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
   const int K = a.K, N = a.N;
   const long long M = a.M;
   const int nchunks = (K + KC - 1) / KC;
+  const int Kpad = nchunks * KC;
   const long long ntiles = (M + BM - 1) / BM;
   const long long my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;   // >= 1 (grid <= ntiles)
   const long long total_steps = my_tiles * nchunks;
   const long long last_tile = blockIdx.x + (my_tiles - 1) * gridDim.x;
+
+  if (PRO != PRO_NONE) {
+    for (int i = tid; i < Kpad; i += THREADS) {
+      const bool in = i < K;
+      prm[i] = in ? a.p0[i] : 0.f;
+      prm[Kpad + i] = in ? a.p1[i] : 0.f;
+      if (TWO || POOL) prm[2 * Kpad + i] = in ? a.p2[i] : 0.f;
+    }
+  }
 
   f32x16 acc[NT];
 #pragma unroll
@@ -122,12 +157,20 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
 
   const int kk = tid % KC;
   const int r0 = tid / KC;
+  // kernel-constant per-lane byte offsets
+  int aoff[APT], woff[WPT];
+#pragma unroll
+  for (int i = 0; i < APT; ++i) aoff[i] = ((r0 + RSTEP * i) * K + kk) * 4;
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) woff[i] = ((r0 + RSTEP * i) * K + kk) * 4;
+  const rsrc_t rsW = make_rsrc(a.W + (size_t)n0 * K, (long long)(N - n0) * K * 4);
+
   // PRO_POOLG: dL/dz of a max-pooled layer has ONE non-zero per (row group, channel) — at the
   // arg-max row.  The tile is staged as the dense part c2*y + c3 and thread (gi, kk) adds
   // c1 * gP[group gi of the tile][k] at LDS row arg (if that row lies in this tile).  The patch
   // operands ride the register ring like everything else.  PGR = patch entries per thread.
   constexpr int PGR = POOL ? (((BM / 16 + 1) * KC + THREADS - 1) / THREADS) : 1;   // supports ns >= 16
-  const unsigned last_grp = POOL ? (unsigned)((M - 1) / a.ns) : 0u;
+  const long long ngroups = POOL ? (M + a.ns - 1) / a.ns : 0;
 
   float ra0[APT], rb0[TWO ? APT : 1], rw0[WPT], pg0[PGR];
   float ra1[APT], rb1[TWO ? APT : 1], rw1[WPT], pg1[PGR];
@@ -142,46 +185,33 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
   auto load_step = [&](float (&ra)[APT], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int (&pa)[PGR],
                        float (&pg)[PGR]) {
     const long long m0 = l_tile * BM;
-    const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
-    const int k = l_chunk * KC + kk;
-    const int kc = k < K ? k : (K - 1);
+    const long long left = (M - m0) * K * 4;                // bytes from the tile's first row to the end
+    const int soff = l_chunk * KC * 4;
     if (POOL) {
-      const float *X2t = a.X2 + (size_t)m0 * K;
+      const rsrc_t rs = make_rsrc(a.X2 + (size_t)m0 * K, left);
 #pragma unroll
-      for (int i = 0; i < APT; ++i) {
-        const int rr = (r0 + RSTEP * i) < mrem ? (r0 + RSTEP * i) : (mrem - 1);
-        ra[i] = X2t[(unsigned)(rr * K + kc)];
-      }
-      const unsigned g_first = (unsigned)(m0 / a.ns);
+      for (int i = 0; i < APT; ++i) ra[i] = bload(rs, aoff[i], soff);
+      const long long g_first = m0 / a.ns;
+      const rsrc_t rsa = make_rsrc(a.arg + (size_t)g_first * K, (ngroups - g_first) * K * 4);
+      const rsrc_t rsg = make_rsrc(a.gP + (size_t)g_first * K, (ngroups - g_first) * K * 4);
 #pragma unroll
-      for (int e = 0; e < PGR; ++e) {
-        const unsigned grp = g_first + (unsigned)(r0 + RSTEP * e);     // patch entry (group r0 + RSTEP*e, column kk)
-        const size_t goff = (size_t)(grp < last_grp ? grp : last_grp) * K + kc;
-        pa[e] = a.arg[goff];
-        pg[e] = a.gP[goff];
+      for (int e = 0; e < PGR; ++e) {                       // patch entry (group r0 + RSTEP*e, column kk)
+        const int goff = ((r0 + RSTEP * e) * K + kk) * 4;
+        pa[e] = bload_i(rsa, goff, soff);
+        pg[e] = bload(rsg, goff, soff);
       }
     } else {
-      const float *Xt = a.X + (size_t)m0 * K;
+      const rsrc_t rs = make_rsrc(a.X + (size_t)m0 * K, left);
 #pragma unroll
-      for (int i = 0; i < APT; ++i) {
-        const int rr = (r0 + RSTEP * i) < mrem ? (r0 + RSTEP * i) : (mrem - 1);
-        ra[i] = Xt[(unsigned)(rr * K + kc)];
-      }
+      for (int i = 0; i < APT; ++i) ra[i] = bload(rs, aoff[i], soff);
       if (TWO) {
-        const float *X2t = a.X2 + (size_t)m0 * K;
+        const rsrc_t rs2 = make_rsrc(a.X2 + (size_t)m0 * K, left);
 #pragma unroll
-        for (int i = 0; i < APT; ++i) {
-          const int rr = (r0 + RSTEP * i) < mrem ? (r0 + RSTEP * i) : (mrem - 1);
-          rb[TWO ? i : 0] = X2t[(unsigned)(rr * K + kc)];
-        }
+        for (int i = 0; i < APT; ++i) rb[TWO ? i : 0] = bload(rs2, aoff[i], soff);
       }
     }
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int j = n0 + r0 + RSTEP * i;
-      const int jc = j < N ? j : (N - 1);
-      rw[i] = a.W[(size_t)jc * K + kc];
-    }
+    for (int i = 0; i < WPT; ++i) rw[i] = bload(rsW, woff[i], soff);
     ++l_chunk;
     const bool wrap = l_chunk == nchunks;
     l_chunk = wrap ? 0 : l_chunk;
@@ -189,35 +219,36 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
     l_tile = nt < ntiles ? nt : last_tile;
   };
 
-  // prologue transform + LDS write of the OLDEST loaded step
+  // prologue transform + LDS write of the OLDEST loaded step.  No masks: rows past M and weight
+  // rows past N arrive as zeros (out-of-range loads), ragged K is absorbed by the zero-padded
+  // parameter table (PRO_NONE: one select).  Rows past M of a partial last tile do leave the
+  // prologue non-zero; the epilogue clears their accumulators before the statistics.
   long long p_tile = blockIdx.x;   // cursor of the step whose sparse patch is pending (PRO_POOLG)
   int p_chunk = 0;
   auto store_step = [&](float (&ra)[APT], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int buf) {
     p_tile = s_tile;
     p_chunk = s_chunk;
-    const long long m0 = s_tile * BM;
-    const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
     const int k = s_chunk * KC + kk;
-    const bool kin = k < K;
-    const int kc = kin ? k : (K - 1);
     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
     if (PRO != PRO_NONE) {
-      q0 = a.p0[kc];
-      q1 = a.p1[kc];
-      if (TWO || POOL) q2 = a.p2[kc];
+      q0 = prm[k];
+      q1 = prm[Kpad + k];
+      if (TWO || POOL) q2 = prm[2 * Kpad + k];
     }
+    const bool kin = k < K;
     float *Ad = &As[buf][r0 * LD + kk];
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
       float v = ra[i];
+      if (PRO == PRO_NONE) v = kin ? v : 0.f;
       if (PRO == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, q0, q1), 0.f);
       if (TWO) v = __fmaf_rn(q0, v, __fmaf_rn(q1, rb[TWO ? i : 0], q2));
       if (POOL) v = __fmaf_rn(q1, v, q2);
-      Ad[RSTEP * i * LD] = (kin && (r0 + RSTEP * i) < mrem) ? v : 0.f;
+      Ad[RSTEP * i * LD] = v;
     }
     float *Wd = &Ws[buf][r0 * LD + kk];
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) Wd[RSTEP * i * LD] = (kin && (n0 + r0 + RSTEP * i) < N) ? rw[i] : 0.f;
+    for (int i = 0; i < WPT; ++i) Wd[RSTEP * i * LD] = rw[i];
     ++s_chunk;
     const bool wrap = s_chunk == nchunks;
     s_chunk = wrap ? 0 : s_chunk;
@@ -230,7 +261,7 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
     const long long m0 = p_tile * BM;
     const int mrem = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);
     const int k = p_chunk * KC + kk;
-    const float c1 = a.p0[k < K ? k : (K - 1)];
+    const float c1 = prm[k];
     const long long g_first = m0 / a.ns;
     const int ngrp = (int)((m0 + mrem - 1) / a.ns - g_first) + 1;
 #pragma unroll
@@ -245,7 +276,27 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
   const int brow = (wcol * NT * 32 + (lane & 31)) * LD + (lane >> 5);
   const int cl = lane & 31;
   const int rbase = wave * 32 + 4 * (lane >> 5);
+  // output addressing: lane-constant byte offset per column tile (out of range for a column past N),
+  // row r of the accumulator adds the wave-uniform (r&3 + 8*(r>>2)) * N * 4
+  int yoff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = n0 + (wcol * NT + t) * 32 + cl;
+    yoff[t] = col < N ? (rbase * N + col) * 4 : kOobOffset;
+  }
+  const int rowpitch = N * 4;
   float yp[MASKE ? NT : 1][16];
+  // EPI_MASK constants of this lane's output columns (fixed for the whole kernel)
+  float e_s[MASKE ? NT : 1], e_h[MASKE ? NT : 1], e_m[MASKE ? NT : 1], e_r[MASKE ? NT : 1];
+  if (MASKE) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = n0 + (wcol * NT + t) * 32 + cl;
+      const int cc = col < N ? col : (N - 1);
+      e_s[MASKE ? t : 0] = a.e_scale[cc]; e_h[MASKE ? t : 0] = a.e_shift[cc];
+      e_m[MASKE ? t : 0] = a.e_mean[cc];  e_r[MASKE ? t : 0] = a.e_rstd[cc];
+    }
+  }
 
   // one pipeline iteration: compute the current step from LDS buffer `buf`; (la, lb, lw) receive
   // the loads of two steps ahead, (sa, sb, sw) hold the next step and are written to buffer buf^1
@@ -254,24 +305,19 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
                        int (&spa)[PGR], float (&spg)[PGR]) {
     const bool last_chunk = c_chunk == nchunks - 1;
     const long long m0 = c_tile * BM;
-    // the patch registers of the step about to be stored must be consumed before load_step
-    // overwrites the OTHER set only — (spa, spg) belong to the set being stored, safe
-    load_step(la, lb, lw, lpa, lpg);
+    // Yprev first: vmcnt retires in order, so the epilogue's wait for these loads must not also
+    // cover the ring loads issued after them
     if (MASKE) {
       if (last_chunk) {
+        const rsrc_t rsp = make_rsrc(a.Yprev + (size_t)m0 * N, (M - m0) * N * 4);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int col = n0 + (wcol * NT + t) * 32 + cl;
-          const int cc = col < N ? col : (N - 1);
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const long long row = m0 + rbase + (r & 3) + 8 * (r >> 2);
-            const long long rc = row < M ? row : (M - 1);
-            yp[MASKE ? t : 0][r] = a.Yprev[(size_t)rc * N + cc];
-          }
-        }
+          for (int r = 0; r < 16; ++r)
+            yp[MASKE ? t : 0][r] = bload(rsp, yoff[t], ((r & 3) + 8 * (r >> 2)) * rowpitch);
       }
     }
+    load_step(la, lb, lw, lpa, lpg);
     const float *Ab = As[buf];
     const float *Wb = Ws[buf];
 #pragma unroll
@@ -287,31 +333,38 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
     store_step(sa, sb, sw, buf ^ 1);
     if (last_chunk) {
       // ---- tile epilogue: mask / statistics / store, straight from the accumulators ----
+      if (EPI != EPI_NONE && PRO != PRO_NONE && m0 + BM > M) {
+        // partial last tile (wave-uniform, at most once per kernel): rows past M must not reach the sums.
+        // The empty asm keeps this a real (never taken) branch; if-converted it is 48 VALU per tile.
+        asm volatile("; partial tile");
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[t][r] = (m0 + rbase + (r & 3) + 8 * (r >> 2)) < M ? acc[t][r] : 0.f;
+      }
+      const rsrc_t rsy = make_rsrc(a.Y + (size_t)m0 * N, (M - m0) * N * 4);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int col = n0 + (wcol * NT + t) * 32 + cl;
-        const bool cin = col < N;
-        const int cc = cin ? col : (N - 1);
         float es = 0.f, eh = 0.f, em = 0.f, er = 0.f;
-        if (MASKE) { es = a.e_scale[cc]; eh = a.e_shift[cc]; em = a.e_mean[cc]; er = a.e_rstd[cc]; }
+        if (MASKE) { es = e_s[MASKE ? t : 0]; eh = e_h[MASKE ? t : 0]; em = e_m[MASKE ? t : 0]; er = e_r[MASKE ? t : 0]; }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const long long row = m0 + rbase + (r & 3) + 8 * (r >> 2);
-          const bool ok = cin && row < M;
           float v = acc[t][r];
           if (MASKE) {
             const float y = yp[MASKE ? t : 0][r];
             v = (__fmaf_rn(y, es, eh) > 0.f) ? v : 0.f;
-            v = ok ? v : 0.f;
             s1 += v;
             s2 = __fmaf_rn(v, (y - em) * er, s2);
           } else if (EPI == EPI_STATS) {
-            v = ok ? v : 0.f;
             s1 += v;
             s2 = __fmaf_rn(v, v, s2);
           }
-          if (ok) a.Y[(size_t)row * N + col] = v;
+#ifdef PN2_EXP_NOSTORE
+          if (v == 1.2345e-30f)
+#endif
+          bstore(v, rsy, yoff[t], ((r & 3) + 8 * (r >> 2)) * rowpitch);
           acc[t][r] = 0.f;
         }
         cs1[t] += s1;
@@ -331,16 +384,22 @@ __global__ __launch_bounds__(256 * CW, (gemm_min_waves<NT, CW, PRO, EPI>())) voi
 
   load_step(ra0, rb0, rw0, pa0, pg0);            // step 0
   load_step(ra1, rb1, rw1, pa1, pg1);            // step 1
+  if (PRO != PRO_NONE) __syncthreads();          // parameter table visible
   store_step(ra0, rb0, rw0, 0);
   __syncthreads();
   if (POOL) {
     patch_step(pa0, pg0, 0);
     __syncthreads();
   }
-  for (long long step = 0; step < total_steps; step += 2) {
+  // Single-exit loop over step PAIRS plus a peeled odd step: there must be no control-flow edge
+  // (not even a never-taken one, as the structurizer creates for a mid-loop break) from the end of
+  // iteration(0) back to its own start, or hipcc guards the reuse of a ring register with
+  // s_waitcnt vmcnt(0) at the loop head and the two-step prefetch distance collapses.
+  for (long long pair = total_steps >> 1; pair > 0; --pair) {
     iteration(0, ra0, rb0, rw0, pa0, pg0, ra1, rb1, rw1, pa1, pg1);
-    if (step + 1 < total_steps) iteration(1, ra1, rb1, rw1, pa1, pg1, ra0, rb0, rw0, pa0, pg0);
+    iteration(1, ra1, rb1, rw1, pa1, pg1, ra0, rb0, rw0, pa0, pg0);
   }
+  if (total_steps & 1) iteration(0, ra0, rb0, rw0, pa0, pg0, ra1, rb1, rw1, pa1, pg1);
 
   // ---- flush the column sums once per workgroup ----
   if (EPI != EPI_NONE) {
@@ -538,7 +597,11 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         const float av = Gs[rr * GN + (npar + NPARS * t) * 32 + (lane & 31)];
+#ifdef PN2_EXP_NOMFMA
+        acc[t][s & 15] = __fmaf_rn(av, bv, acc[t][s & 15]);
+#else
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+#endif
       }
     }
     __syncthreads();
@@ -735,10 +798,14 @@ void launch_one(const GemmArgs &a, hipStream_t s) {
   const long long ntiles = (a.M + BM - 1) / BM;
   const unsigned ny = (unsigned)((a.N + NT * CW * 32 - 1) / (NT * CW * 32));
   long long gx = 512 / ny;
+#ifdef PN2_EXP_CFG
+  if (const char *e = getenv("PN2_GEMM_GRID")) gx = atoi(e) / ny;
+#endif
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   dim3 grid((unsigned)gx, ny);
-  hipLaunchKernelGGL((mlp_gemm_kernel<NT, KC, CW, PRO, EPI>), grid, dim3(256 * CW), 0, s, a);
+  const size_t prm_bytes = PRO == PRO_NONE ? 0 : 3 * (size_t)((a.K + KC - 1) / KC * KC) * sizeof(float);
+  hipLaunchKernelGGL((mlp_gemm_kernel<NT, KC, CW, PRO, EPI>), grid, dim3(256 * CW), prm_bytes, s, a);
 }
 
 // tile configuration by number of 32-column tiles
@@ -768,6 +835,7 @@ extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const f
                             const int *arg, const float *gP, int ns, const float *W, float *Y,
                             double *stats, const float *Yprev, const float *e_fin, void *stream) {
   if (M < 0 || K <= 0 || N <= 0 || pro < 0 || pro > 3 || epi < 0 || epi > 2) return PN2_EINVAL;
+  if (K > 2048) return PN2_EINVAL;               // the prologue parameter table lives in LDS (3 x K floats)
   if (M == 0) return PN2_OK;
   if (!W || !Y) return PN2_ENULL;
   if ((pro == PRO_NONE || pro == PRO_BNRELU || pro == PRO_GY) && !X) return PN2_ENULL;
@@ -792,6 +860,15 @@ extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const f
   // served by the same kernels with the reductions compiled out via EPI_NONE on NONE/BNRELU);
   // backward = {GY, POOLG} x {MASK, NONE}
   if (pro == PRO_NONE && epi == EPI_STATS) launch_by_width<PRO_NONE, EPI_STATS>(a, tiles, s);
+#ifdef PN2_EXP_CFG
+  else if (pro == PRO_BNRELU && epi == EPI_STATS && getenv("PN2_GEMM_CFG")) {
+    int nt = 2, kc = 32, cw = 1;
+    sscanf(getenv("PN2_GEMM_CFG"), "%d,%d,%d", &nt, &kc, &cw);
+#define PN2_TRY(NT_, KC_, CW_) if (nt == NT_ && kc == KC_ && cw == CW_) launch_one<NT_, KC_, CW_, PRO_BNRELU, EPI_STATS>(a, s); else
+    PN2_TRY(1, 32, 1) PN2_TRY(2, 32, 1) PN2_TRY(2, 16, 1) PN2_TRY(4, 16, 1) PN2_TRY(4, 32, 1) PN2_TRY(1, 32, 2) PN2_TRY(2, 32, 2)
+    PN2_TRY(2, 16, 2) PN2_TRY(4, 16, 2) PN2_TRY(4, 8, 1) PN2_TRY(2, 8, 1) return PN2_EINVAL;
+  }
+#endif
   else if (pro == PRO_BNRELU && epi == EPI_STATS) launch_by_width<PRO_BNRELU, EPI_STATS>(a, tiles, s);
   else if (pro == PRO_NONE && epi == EPI_NONE) launch_by_width<PRO_NONE, EPI_NONE>(a, tiles, s);
   else if (pro == PRO_BNRELU && epi == EPI_NONE) launch_by_width<PRO_BNRELU, EPI_NONE>(a, tiles, s);

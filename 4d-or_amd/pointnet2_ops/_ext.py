@@ -24,7 +24,7 @@ import os
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libpn2_hip.so")
+LIB_PATH = os.environ.get("PN2_HIP_LIB") or os.path.join(_PKG_DIR, "libpn2_hip.so")   # override: kernel experiments only
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
