@@ -158,11 +158,8 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   const int kk = tid % KC;
   const int r0 = tid / KC;
   // kernel-constant per-lane byte offsets
-  int aoff[APT], woff[WPT];
-#pragma unroll
-  for (int i = 0; i < APT; ++i) aoff[i] = ((r0 + RSTEP * i) * K + kk) * 4;
-#pragma unroll
-  for (int i = 0; i < WPT; ++i) woff[i] = ((r0 + RSTEP * i) * K + kk) * 4;
+  // (the row pass i adds a wave-uniform i * RSTEP * K * 4, carried in the SGPR offset with the chunk)
+  const int aoff = (r0 * K + kk) * 4, apass = RSTEP * K * 4;
   const rsrc_t rsW = make_rsrc(a.W + (size_t)n0 * K, (long long)(N - n0) * K * 4);
 
   // PRO_POOLG: dL/dz of a max-pooled layer has ONE non-zero per (row group, channel) — at the
@@ -190,28 +187,27 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
     if (POOL) {
       const rsrc_t rs = make_rsrc(a.X2 + (size_t)m0 * K, left);
 #pragma unroll
-      for (int i = 0; i < APT; ++i) ra[i] = bload(rs, aoff[i], soff);
+      for (int i = 0; i < APT; ++i) ra[i] = bload(rs, aoff, soff + i * apass);
       const long long g_first = m0 / a.ns;
       const rsrc_t rsa = make_rsrc(a.arg + (size_t)g_first * K, (ngroups - g_first) * K * 4);
       const rsrc_t rsg = make_rsrc(a.gP + (size_t)g_first * K, (ngroups - g_first) * K * 4);
 #pragma unroll
       for (int e = 0; e < PGR; ++e) {                       // patch entry (group r0 + RSTEP*e, column kk)
-        const int goff = ((r0 + RSTEP * e) * K + kk) * 4;
-        pa[e] = bload_i(rsa, goff, soff);
-        pg[e] = bload(rsg, goff, soff);
+        pa[e] = bload_i(rsa, aoff, soff + e * apass);
+        pg[e] = bload(rsg, aoff, soff + e * apass);
       }
     } else {
       const rsrc_t rs = make_rsrc(a.X + (size_t)m0 * K, left);
 #pragma unroll
-      for (int i = 0; i < APT; ++i) ra[i] = bload(rs, aoff[i], soff);
+      for (int i = 0; i < APT; ++i) ra[i] = bload(rs, aoff, soff + i * apass);
       if (TWO) {
         const rsrc_t rs2 = make_rsrc(a.X2 + (size_t)m0 * K, left);
 #pragma unroll
-        for (int i = 0; i < APT; ++i) rb[TWO ? i : 0] = bload(rs2, aoff[i], soff);
+        for (int i = 0; i < APT; ++i) rb[TWO ? i : 0] = bload(rs2, aoff, soff + i * apass);
       }
     }
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) rw[i] = bload(rsW, woff[i], soff);
+    for (int i = 0; i < WPT; ++i) rw[i] = bload(rsW, aoff, soff + i * apass);
     ++l_chunk;
     const bool wrap = l_chunk == nchunks;
     l_chunk = wrap ? 0 : l_chunk;
@@ -361,9 +357,6 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
             s1 += v;
             s2 = __fmaf_rn(v, v, s2);
           }
-#ifdef PN2_EXP_NOSTORE
-          if (v == 1.2345e-30f)
-#endif
           bstore(v, rsy, yoff[t], ((r & 3) + 8 * (r >> 2)) * rowpitch);
           acc[t][r] = 0.f;
         }
@@ -452,7 +445,9 @@ constexpr int WMAXN = 320;    // 10 n-tiles
 // n-tiles (w / KT) + (8/KT)*t, t < NTW.
 template <int NTW, int GMODE, int AMODE, int KT>  // n-tiles per wave (total n-tiles <= (8/KT)*NTW)
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
-  constexpr int WR = 32;       // rows per LDS tile (64 for the narrow variants was measured: no gain, +60 VGPRs)
+  // rows per LDS tile: 32; 16 for the wide variants, whose two-deep ring of 32-row gy tiles (2 x 2 x 16..32
+  // registers) plus 64-80 accumulators does not fit the register file (64 for the narrow ones: no gain)
+  constexpr int WR = NTW >= 3 ? 16 : 32;
   constexpr int WKB = 32 * KT;
   constexpr int NPARS = 8 / KT;
   constexpr int GN = NPARS * NTW * 32;
@@ -491,17 +486,23 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   const float c1 = a.c1[gnc], c2 = a.c2[gnc], c3 = a.c3[gnc];
   const int xr0 = tid / WKB, xk = tid % WKB;
   const int kx = kb0 + xk;
-  const bool kx_in = kx < K;
-  const int kxc = kx_in ? kx : (K - 1);
+  const int kxc = kx < K ? kx : (K - 1);
   float a_sc = 1.f, a_sh = 0.f;
   if (AMODE == PRO_BNRELU) { a_sc = a.a_scale[kxc]; a_sh = a.a_shift[kxc]; }
+  // Addressing as in mlp_gemm_kernel: buffer descriptors per tile, kernel-constant per-lane byte
+  // offsets, no clamps and no masks.  A gy column past N or an activation column past K reads a
+  // neighbouring (finite) element or zero and only ever reaches dW entries that are not stored; rows
+  // past M read zeros, and the one tile that can contain them clears its activation rows explicitly.
+  // (the row pass i adds a wave-uniform i * rows-per-pass * pitch, carried in the SGPR offset)
+  const int goff = (gr0 * N + gn) * 4, gpass = GRP * N * 4;
+  const int xoff = (xr0 * K + kx) * 4, xpass = XRP * K * 4;
   // PRO_POOLG: dense part c2*y + c3 from ONE matrix; the single non-zero of dL/dz per (row group,
   // column) is patched into the LDS tile at the arg-max row (see mlp_gemm_kernel).  A WR-row tile
   // overlaps at most WR/16 + 1 groups (ns >= 16); patch entry e of thread (gn, gr0) is group gr0 + GRP*e.
   constexpr bool POOL = GMODE == PRO_POOLG;
   constexpr int WPG = POOL ? ((WR / 16 + 1 + GRP - 1) / GRP) : 1;
   constexpr int RGN = POOL ? 1 : GPT;          // the G matrix is only read in PRO_GY mode
-  const unsigned last_grp = POOL ? (unsigned)((M - 1) / a.ns) : 0u;
+  const long long ngroups = POOL ? (M + a.ns - 1) / a.ns : 0;
 
   float rg0[RGN], ry0[GPT], rx0[XPT], pg0[WPG];
   float rg1[RGN], ry1[GPT], rx1[XPT], pg1[WPG];
@@ -511,36 +512,26 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
 
   auto load_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG]) {
     const long long rt = l_rt;
-    const int rows = (int)((row_end - rt) < (long long)WR ? (row_end - rt) : (long long)WR);
-    const float *Yt = a.Yl + (size_t)rt * N;
-    const float *Xt = a.X + (size_t)rt * K;
+    const rsrc_t rsy = make_rsrc(a.Yl + (size_t)rt * N, (M - rt) * N * 4);
 #pragma unroll
-    for (int i = 0; i < GPT; ++i) {
-      const int r = (gr0 + GRP * i) < rows ? (gr0 + GRP * i) : (rows - 1);
-      ry[i] = Yt[(unsigned)(r * N + gnc)];
-    }
+    for (int i = 0; i < GPT; ++i) ry[i] = bload(rsy, goff, i * gpass);
     if (POOL) {
-      const unsigned g_first = (unsigned)(rt / a.ns);
+      const long long g_first = rt / a.ns;
+      const rsrc_t rsa = make_rsrc(a.arg + (size_t)g_first * N, (ngroups - g_first) * N * 4);
+      const rsrc_t rsg = make_rsrc(a.gP + (size_t)g_first * N, (ngroups - g_first) * N * 4);
 #pragma unroll
       for (int e = 0; e < WPG; ++e) {
-        const unsigned grp = g_first + (unsigned)(gr0 + GRP * e);
-        const size_t goff = (size_t)(grp < last_grp ? grp : last_grp) * N + gnc;
-        pa[e] = a.arg[goff];
-        pg[e] = a.gP[goff];
+        pa[e] = bload_i(rsa, goff, e * gpass);
+        pg[e] = bload(rsg, goff, e * gpass);
       }
     } else {
-      const float *Gt = a.G + (size_t)rt * N;
+      const rsrc_t rsgy = make_rsrc(a.G + (size_t)rt * N, (M - rt) * N * 4);
 #pragma unroll
-      for (int i = 0; i < GPT; ++i) {
-        const int r = (gr0 + GRP * i) < rows ? (gr0 + GRP * i) : (rows - 1);
-        rg[POOL ? 0 : i] = Gt[(unsigned)(r * N + gnc)];
-      }
+      for (int i = 0; i < GPT; ++i) rg[POOL ? 0 : i] = bload(rsgy, goff, i * gpass);
     }
+    const rsrc_t rsx = make_rsrc(a.X + (size_t)rt * K, (M - rt) * K * 4);
 #pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      const int r = (xr0 + XRP * i) < rows ? (xr0 + XRP * i) : (rows - 1);
-      rx[i] = Xt[(unsigned)(r * K + kxc)];
-    }
+    for (int i = 0; i < XPT; ++i) rx[i] = bload(rsx, xoff, i * xpass);
     const long long nt = rt + WR;
     l_rt = nt < row_end ? nt : last_rt;
   };
@@ -549,22 +540,29 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   auto store_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT]) {
     const long long rt = s_rt;
     p_rt = rt;
-    const int rows = (int)((row_end - rt) < (long long)WR ? (row_end - rt) : (long long)WR);
     if (tid < GRP * GN) {
 #pragma unroll
       for (int i = 0; i < GPT; ++i) {
         const int r = gr0 + GRP * i;
         const float v = POOL ? __fmaf_rn(c2, ry[i], c3) : __fmaf_rn(c1, rg[POOL ? 0 : i], __fmaf_rn(c2, ry[i], c3));
-        if (r < WR) Gs[r * GN + gn] = (g_thr && r < rows) ? v : 0.f;
+        if (r < WR) Gs[r * GN + gn] = v;
       }
     }
+    float xv[XPT];
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      const int r = xr0 + XRP * i;
-      float v = rx[i];
-      if (AMODE == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, a_sc, a_sh), 0.f);
-      Xs[r * WKB + xk] = (kx_in && r < rows) ? v : 0.f;
+      xv[i] = rx[i];
+      if (AMODE == PRO_BNRELU) xv[i] = fmaxf(__fmaf_rn(xv[i], a_sc, a_sh), 0.f);
     }
+    if (rt + WR > M) {
+      // the tile that crosses M (wave-uniform, at most one per kernel): its surplus rows carry
+      // relu(shift) / c3 instead of zero — clear the activation side.  The empty asm keeps this a branch.
+      asm volatile("; partial tile");
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) xv[i] = (rt + xr0 + XRP * i) < M ? xv[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) Xs[(xr0 + XRP * i) * WKB + xk] = xv[i];
     s_rt += WR;
   };
 
@@ -597,11 +595,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         const float av = Gs[rr * GN + (npar + NPARS * t) * 32 + (lane & 31)];
-#ifdef PN2_EXP_NOMFMA
-        acc[t][s & 15] = __fmaf_rn(av, bv, acc[t][s & 15]);
-#else
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-#endif
       }
     }
     __syncthreads();
@@ -609,10 +603,12 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
 
   load_tile(rg0, ry0, rx0, pa0, pg0);
   load_tile(rg1, ry1, rx1, pa1, pg1);
-  for (long long t = 0; t < ntile; t += 2) {
+  // single-exit pair loop + peeled odd tile (see mlp_gemm_kernel)
+  for (long long pair = ntile >> 1; pair > 0; --pair) {
     iteration(rg0, ry0, rx0, pa0, pg0);
-    if (t + 1 < ntile) iteration(rg1, ry1, rx1, pa1, pg1);
+    iteration(rg1, ry1, rx1, pa1, pg1);
   }
+  if (ntile & 1) iteration(rg0, ry0, rx0, pa0, pg0);
   // ---- flush: acc[t][reg] = dW[n = ntile*32 + rowmap][k = kb0 + ktile*32 + (lane&31)] ----
   const int kcol = kb0 + ktile * 32 + (lane & 31);
 #pragma unroll
