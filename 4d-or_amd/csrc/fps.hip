@@ -89,23 +89,46 @@ __device__ __forceinline__ u64 fps_block_exchange(FpsSlot *buf, u64 wmax, bool w
 }
 
 // ---- register-resident kernel: one workgroup per cloud ------------------------
+// A round is: PPT distance updates per lane -> wave arg-max of the (hi, lo) key by two 32-bit DPP
+// reductions -> the winning lane fetches its point from an LDS copy of the coordinates (3 ds_reads;
+// a select chain over PPT registers when the copy would not fit) -> one 32-byte slot per wave in
+// LDS -> ONE barrier -> every wave reduces the NW slots again.  Small clouds run with FEW waves
+// (256 threads = one wave per SIMD up to 2048 points): the round is a dependent chain, and a second
+// wave on the SIMD only doubles the issue time of the first (measured 0.89 -> see DESIGN.md us/round).
+struct __attribute__((aligned(32))) FpsSlot2 {
+  unsigned hi, lo;
+  float x, y, z;
+  float pad0, pad1, pad2;
+};
+
 template <int BS, int PPT>
 __global__ __launch_bounds__(BS) void fps_resident_kernel(int N, int m, int L,
                                                          const float *__restrict__ xyz,
                                                          int *__restrict__ idxs) {
   constexpr int NW = BS / 64;
-  __shared__ FpsSlot slots[2][16];
+  constexpr bool LDSXYZ = PPT * BS * 12 <= 96 * 1024;      // coordinates copy fits next to the slots
+  __shared__ FpsSlot2 slots[2][16];
+  __shared__ float lxyz[LDSXYZ ? 3 * PPT * BS : 1];
 
   const int b = blockIdx.x;
   const int t = threadIdx.x;
   const int lane = pn2_lane();
+  const int wave = t >> 6;
   const float *P = xyz + (size_t)b * N * 3;
   int *out = idxs + (size_t)b * m;
 
+  // Slot order inside a lane = priority order on equal distances.  With BS a multiple of the
+  // reference block size 2^L all of a lane's points share one reference tid and ascending k is the
+  // reference order (strict '>' at :108-109).  A 256-thread workgroup under a 512-thread reference
+  // holds TWO reference tids per lane (t and t+256, the latter with the larger bit-reversed rank):
+  // the points of tid t (even strides) come first, then those of tid t+256 (odd strides).
+  const bool two_tids = BS < (1 << L);
+  constexpr int NE = (PPT + 1) / 2;
+  auto stride_of = [&](int slot) { return two_tids ? (slot < NE ? 2 * slot : 2 * (slot - NE) + 1) : slot; };
   float px[PPT], py[PPT], pz[PPT], td[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    const int k = t + i * BS;
+    const int k = t + stride_of(i) * BS;
     float x = 0.f, y = 0.f, z = 0.f;
     bool valid = false;
     if (k < N) {
@@ -117,6 +140,9 @@ __global__ __launch_bounds__(BS) void fps_resident_kernel(int N, int m, int L,
     }
     px[i] = x; py[i] = y; pz[i] = z;
     td[i] = valid ? 1e10f : -1.f;
+    if (LDSXYZ) {                                           // only ever re-read by this thread
+      lxyz[i * BS + t] = x; lxyz[(PPT + i) * BS + t] = y; lxyz[(2 * PPT + i) * BS + t] = z;
+    }
   }
 
   const float p0x = P[0], p0y = P[1], p0z = P[2];
@@ -133,26 +159,36 @@ __global__ __launch_bounds__(BS) void fps_resident_kernel(int N, int m, int L,
       td[i] = d2;
       if (d2 > best) { best = d2; bi = i; }
     }
-    u64 pk = 0ull;
-    if (best >= 0.f) pk = fps_pack(best, (unsigned)(t + bi * BS), L);
-    const u64 wmax = pn2_wave_max_u64(pk);
-
-    float sx = p0x, sy = p0y, sz = p0z;
-    bool writer;
-    if (wmax == 0ull) {
-      writer = (lane == 0);
+    // key = (bits(best)+1, ~rank(k)); hi == 0 encodes "no candidate" (best = -1, besti = 0 at :90-91)
+    const bool has = best >= 0.f;
+    const unsigned hi = has ? __float_as_uint(best) + 1u : 0u;
+    const unsigned lo = has ? ~fps_rank((unsigned)(t + stride_of(bi) * BS), L) : 0u;
+    unsigned whi, wlo;
+    const u64 who = pn2_wave_argmax_u32x2(hi, lo, whi, wlo);
+    float sx, sy, sz;
+    if (LDSXYZ) {
+      sx = lxyz[bi * BS + t]; sy = lxyz[(PPT + bi) * BS + t]; sz = lxyz[(2 * PPT + bi) * BS + t];
     } else {
-      writer = (pk == wmax);
-      if (writer) {
-        sx = px[0]; sy = py[0]; sz = pz[0];
+      sx = px[0]; sy = py[0]; sz = pz[0];
 #pragma unroll
-        for (int i = 1; i < PPT; ++i) {
-          if (bi == i) { sx = px[i]; sy = py[i]; sz = pz[i]; }
-        }
+      for (int i = 1; i < PPT; ++i) {
+        if (bi == i) { sx = px[i]; sy = py[i]; sz = pz[i]; }
       }
     }
-    const u64 gmax = fps_block_exchange<NW>(slots[j & 1], wmax, writer, sx, sy, sz, ox, oy, oz);
-    if (t == 0) out[j] = gmax ? (int)fps_unrank(~(unsigned)gmax, L) : 0;
+    if (whi == 0u) { sx = p0x; sy = p0y; sz = p0z; }
+    FpsSlot2 *buf = slots[j & 1];
+    if (lane == (__ffsll((long long)who) - 1)) {              // unique lane (lane 0 when whi == 0)
+      buf[wave].hi = whi; buf[wave].lo = wlo;
+      buf[wave].x = sx; buf[wave].y = sy; buf[wave].z = sz;
+    }
+    __syncthreads();
+    const int s = lane & 15;
+    const unsigned shi = s < NW ? buf[s].hi : 0u, slo = s < NW ? buf[s].lo : 0u;
+    unsigned ghi, glo;
+    const u64 gwho = pn2_wave_argmax_u32x2(shi, slo, ghi, glo);
+    const int ws = (__ffsll((long long)gwho) - 1) & 15;      // lanes s, s+16, ... hold the same slot
+    ox = buf[ws].x; oy = buf[ws].y; oz = buf[ws].z;
+    if (t == 0) out[j] = ghi ? (int)fps_unrank(~glo, L) : 0;
   }
 }
 
@@ -481,9 +517,19 @@ FpsPlan fps_plan(int B, int N, int m) {
     }
   }
   // resident candidate
+  // workgroup width: a round is one dependent chain per wave, so fewer, fatter waves win until the scan
+  // itself dominates: 256 threads (one wave per SIMD) up to 2048 points, 512 up to 8192, then 1024.
+  // PN2_FPS_BS=256|512|1024 overrides (tuning only).
   FpsPlan r = {-1, 1, 512, 0, 1};
-  if (N <= 512 * 16) { r.mode = 0; r.BS = 512; r.PPT = round_ppt((N + 511) / 512); }
-  else if (N <= kFpsResidentMaxN) { r.mode = 0; r.BS = 1024; r.PPT = round_ppt((N + 1023) / 1024); }
+  {
+    int bs = N <= 2048 ? 256 : (N <= 512 * 16 ? 512 : 1024);
+    if (const char *e = getenv("PN2_FPS_BS")) {
+      const int want = atoi(e);
+      if (want == 256 || want == 512 || want == 1024) bs = want;
+    }
+    while (bs < 1024 && (N + bs - 1) / bs > (bs == 256 ? 16 : 16)) bs *= 2;
+    if (N <= kFpsResidentMaxN && (N + bs - 1) / bs <= 24) { r.mode = 0; r.BS = bs; r.PPT = round_ppt((N + bs - 1) / bs); }
+  }
 
   if (want_coop && c.mode == 1) return c;
   if (want_resident && r.mode == 0) return r;
@@ -573,6 +619,13 @@ extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz
   if (plan.mode == 2) {
     hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(B), dim3(1024), 0, s, N, m, L, xyz,
                        (float *)workspace, idxs);
+  } else if (plan.BS == 256) {
+    switch (plan.PPT) {
+      PN2_FPS_RES(256, 1) PN2_FPS_RES(256, 2) PN2_FPS_RES(256, 3) PN2_FPS_RES(256, 4)
+      PN2_FPS_RES(256, 6) PN2_FPS_RES(256, 8) PN2_FPS_RES(256, 10) PN2_FPS_RES(256, 12)
+      PN2_FPS_RES(256, 14) PN2_FPS_RES(256, 16)
+      default: return PN2_EINVAL;
+    }
   } else if (plan.BS == 512) {
     switch (plan.PPT) {
       PN2_FPS_RES(512, 1) PN2_FPS_RES(512, 2) PN2_FPS_RES(512, 3) PN2_FPS_RES(512, 4)
@@ -582,6 +635,8 @@ extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz
     }
   } else {
     switch (plan.PPT) {
+      PN2_FPS_RES(1024, 1) PN2_FPS_RES(1024, 2) PN2_FPS_RES(1024, 3) PN2_FPS_RES(1024, 4)
+      PN2_FPS_RES(1024, 6) PN2_FPS_RES(1024, 8)
       PN2_FPS_RES(1024, 10) PN2_FPS_RES(1024, 12) PN2_FPS_RES(1024, 14) PN2_FPS_RES(1024, 16)
       PN2_FPS_RES(1024, 20) PN2_FPS_RES(1024, 24)
       default: return PN2_EINVAL;

@@ -793,7 +793,9 @@ void launch_one(const GemmArgs &a, hipStream_t s) {
   // N wider than the workgroup's NT*CW column tiles is covered by column blocks (grid.y)
   const long long ntiles = (a.M + BM - 1) / BM;
   const unsigned ny = (unsigned)((a.N + NT * CW * 32 - 1) / (NT * CW * 32));
-  long long gx = 512 / ny;
+  // 8-wave workgroups: two per CU; 4-wave workgroups: three (their VGPR / LDS budgets admit it and the
+  // third hides the barrier and LDS latencies of the other two: 455 -> 418 us on the 64 -> 64 layer of SA1)
+  long long gx = (CW == 1 ? 768 : 512) / ny;
 #ifdef PN2_EXP_CFG
   if (const char *e = getenv("PN2_GEMM_GRID")) gx = atoi(e) / ny;
 #endif

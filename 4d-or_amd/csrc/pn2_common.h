@@ -74,6 +74,33 @@ __device__ __forceinline__ u64 pn2_wave_max_u64(u64 v) {
   return a > c ? a : c;
 }
 
+// Wave-wide max of a u32 (4 DPP stages inside the rows of 16 + a scalar max of the four row results);
+// the result is wave-uniform.  One VALU instruction per stage where the u64 form needs five.
+__device__ __forceinline__ unsigned pn2_wave_max_u32(unsigned v) {
+  unsigned o;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, PN2_DPP_QUAD_XOR1, 0xF, 0xF, false); v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, PN2_DPP_QUAD_XOR2, 0xF, 0xF, false); v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, PN2_DPP_ROW_HALF_MIRROR, 0xF, 0xF, false); v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, PN2_DPP_ROW_MIRROR, 0xF, 0xF, false); v = o > v ? o : v;
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+
+// Wave-wide arg-max of the totally ordered key (hi, lo): returns the wave-uniform maximum and the
+// ballot of the lanes that hold it (exactly one lane when keys are unique).
+__device__ __forceinline__ u64 pn2_wave_argmax_u32x2(unsigned hi, unsigned lo, unsigned &mhi, unsigned &mlo) {
+  mhi = pn2_wave_max_u32(hi);
+  const unsigned l2 = hi == mhi ? lo : 0u;
+  mlo = pn2_wave_max_u32(l2);
+  return __ballot(hi == mhi && lo == mlo);
+}
+
+__device__ __forceinline__ float pn2_readlane_f32(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 // ---- host-side launch error capture ---------------------------------------------
 extern thread_local int pn2_tls_hip_error;
 static inline int pn2_check_launch() {

@@ -451,7 +451,7 @@ def mlp_gemm(X, W, pro=PRO_NONE, epi=EPI_NONE, X2=None, p=None, arg=None, gP=Non
         p0, p1 = p[0], p[1]
         p2 = p[2] if len(p) > 2 else None
     flops = 2 * M * N * K
-    nbytes = 4 * (M * K * (2 if pro >= PRO_GY else 1) + M * N * (2 if epi == EPI_MASK else 1) + N * K)
+    nbytes = 4 * (M * K * (2 if pro == PRO_GY else 1) + M * N * (2 if epi == EPI_MASK else 1) + N * K)   # POOLG reads y only
     _call("pn2_mlp_gemm", W, M, K, N, int(pro), int(epi), _ptr(X), _ptr(X2), _ptr(p0), _ptr(p1), _ptr(p2),
           _ptr(arg), _ptr(gP), int(ns), _ptr(W), _ptr(Y), _ptr(stats), _ptr(Yprev), _ptr(e_fin),
           alg_bytes=nbytes, alg_flops=flops, tag=(f"M{M},K{K},N{N},pro{int(pro)},epi{int(epi)}" if DETAIL_TAGS else None))

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round profile of `python bench.py` on the GPU box: kernel-trace statistics + HBM traffic counters
+# (separate rocprofv3 passes, as MI355X_MICROARCH.md prescribes).  Usage: bash tools/profile_round.sh <tag>
+# Outputs land in gpurun_out/prof_<tag>/; copy the summaries you keep into profiles/.
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- $CMD > $O/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- $CMD > $O/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- $CMD > $O/write.log 2>&1
+python - <<PY
+import csv, glob, json, re, collections
+O = "$O"
+def short(n):
+    m = re.search(r"([A-Za-z_0-9]+_kernel)", n)
+    return m.group(1) if m else "other"
+def agg(sub, counter):
+    tot = collections.defaultdict(float); cnt = collections.Counter()
+    for f in glob.glob(f"{O}/{sub}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter: continue
+            k = short(r["Kernel_Name"]); tot[k] += float(r["Counter_Value"]); cnt[k] += 1
+    return tot, cnt
+fe, fc = agg("fetch", "FETCH_SIZE"); wr, wc = agg("write", "WRITE_SIZE")
+out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing (separate passes)",
+       "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); counters in KiB", "kernels": {}}
+for k in sorted(set(fe) | set(wr)):
+    n = max(fc[k], wc[k], 1)
+    f = fe[k] * 1024 / max(fc[k], 1); w = wr[k] * 1024 / max(wc[k], 1)
+    out["kernels"][k] = {"launches_traced": n, "fetch_bytes_per_launch_raw": f, "fetch_bytes_per_launch_corrected_x2": 2 * f,
+                         "write_bytes_per_launch": w, "hbm_bytes_per_launch": 2 * f + w}
+json.dump(out, open(f"{O}/hbm_traffic_per_kernel.json", "w"), indent=1)
+# kernel stats: name, calls, total ns, avg ns, pct
+for f in glob.glob(f"{O}/stats/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    with open(f"{O}/kernel_stats.md", "w") as g:
+        g.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        for r in rows[:40]:
+            g.write("| %s | %s | %.3f | %.1f | %s |\n" % (r["Name"][:90].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                         float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    import shutil; shutil.copy(f, f"{O}/kernel_stats.csv")
+print(open(f"{O}/kernel_stats.md").read()[:3000])
+PY
