@@ -1,0 +1,342 @@
+// mlp_bwd_fused.hip — one pass over a layer's backward: dgrad AND wgrad from one read.
+//
+// For a hidden layer l (input = ReLU(BatchNorm(y_{l-1})), output y_l) the backward needs
+//     gy      = dL/dy_l            = c1*g + c2*y_l + c3            [M][N]   (BatchNorm backward, per-column constants)
+//     dL/dz_{l-1} = [z_{l-1} > 0] * (gy * W_l)                     [M][K]   (dgrad, + the next BN-backward column sums)
+//     dW_l    = gy^T * relu(bn(y_{l-1}))                           [N][K]   (wgrad)
+// mlp_gemm_kernel (dgrad) and mlp_wgrad_kernel each stream g, y_l and y_{l-1} from HBM: 2(2MN + MK) floats read
+// per layer.  Both products share their operands, so this kernel stages ONE row tile
+//     gyT[n][row] (transposed, pitch R+1), act[row][k] = relu(bn(y_{l-1})), W_l[n][k] (resident for the whole kernel)
+// in LDS and runs both MFMA products from it: reads 2MN + MK (pooled layer: MN + MK), the memory-bound SA1/SA2
+// layers become MFMA-bound.  Both fragment read patterns are conflict-free on the transposed tile:
+//     dgrad A[i=row][k=n]:  gyT[(2s + l/32) * (R+1) + row0 + l%32]      (consecutive rows)
+//     wgrad A[i=n][k=row]:  gyT[(n0 + l%32) * (R+1) + 2s + l/32]        (stride R+1, odd)
+// Supported: 32 < N, K <= 128 with min(N, K) <= 64 (the hidden layers of the SA1 MLP at the bench shapes);
+// everything else stays on the two-kernel path.  Same addressing discipline as mlp_gemm.hip (buffer descriptors,
+// kernel-constant lane offsets, out-of-range instead of masks), same arithmetic (explicit FMAs).
+#include "pn2_common.h"
+#include "mlp_common.h"
+
+#include "../../include/pn2_hip.h"
+
+namespace {
+
+struct BwdArgs {
+  const float *G;      // PRO_GY: g = dL/dz_l [M][N]
+  const float *Yl;     // y_l [M][N]
+  const float *c1, *c2, *c3;
+  const int *arg;      // PRO_POOLG: [M/ns][N]
+  const float *gP;     // PRO_POOLG: [M/ns][N]
+  const float *W;      // [N][K]
+  const float *Yprev;  // y_{l-1} [M][K]
+  const float *a_mean, *a_rstd, *a_scale, *a_shift;   // layer l-1 BatchNorm, per column k
+  float *Gout;         // dL/dz_{l-1} [M][K]
+  double *sums;        // [2][K]: sum g', sum g' * yhat_{l-1}
+  float *dW;           // [N][K], accumulated with atomics (caller zero-fills)
+  long long M;
+  int N, K, ns;
+};
+
+template <int GMODE, int NTN, int KTN, int R>
+__global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(const BwdArgs a) {
+  constexpr bool POOL = GMODE == PRO_POOLG;
+  constexpr int NP = NTN * 32, KP = KTN * 32;
+  constexpr int LDT = R + 1;
+  constexpr int GROWS = 512 / NP;               // gy rows per pass of the workgroup
+  constexpr int GPT = R / GROWS;                // gy elements per thread per tile
+  constexpr int AROWS = 512 / KP;
+  constexpr int APT = R / AROWS;
+  constexpr int RB = R / 32;
+  constexpr int DTT = RB * KTN;                 // dgrad output tiles per row tile
+  static_assert(DTT % 8 == 0, "every wave owns the same number of dgrad tiles");
+  constexpr int DT = DTT / 8;
+  constexpr int T = NTN * KTN;                  // dW tiles
+  constexpr int TW = T >= 8 ? T / 8 : 1;        // dW tiles per wave
+  constexpr int RS = T >= 8 ? 1 : 8 / T;        // row split of a dW tile between waves
+  constexpr int WROWS = R / RS;                 // rows a wave reduces per tile
+  constexpr int PG = POOL ? ((R / 16 + 1 + GROWS - 1) / GROWS) : 1;   // patch entries per thread (ns >= 16)
+  constexpr int RGN = POOL ? 1 : GPT;
+
+  extern __shared__ float lds[];
+  float *gyT = lds;                             // [NP][LDT]
+  float *act = gyT + NP * LDT;                  // [R][KP]
+  float *Wl = act + R * KP;                     // [NP][KP]
+  float *red = Wl + NP * KP;                    // [2][KP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int N = a.N, K = a.K;
+  const long long M = a.M;
+  const long long ntiles = (M + R - 1) / R;
+
+  // ---- resident weights ----
+  for (int i = tid; i < NP * KP; i += 512) {
+    const int n = i / KP, k = i % KP;
+    Wl[i] = (n < N && k < K) ? a.W[(size_t)n * K + k] : 0.f;
+  }
+
+  // ---- per-thread staging coordinates (fixed for the whole kernel) ----
+  const int gn = tid % NP, gr0 = tid / NP;
+  const int gnc = gn < N ? gn : (N - 1);
+  const float c1 = a.c1[gnc], c2 = a.c2[gnc], c3 = a.c3[gnc];
+  const int ak = tid % KP, ar0 = tid / KP;
+  const int akc = ak < K ? ak : (K - 1);
+  const float a_sc = a.a_scale[akc], a_sh = a.a_shift[akc];
+  const int goff = (gr0 * N + gn) * 4, gpass = GROWS * N * 4;
+  const int aoff = (ar0 * K + ak) * 4, apass = AROWS * K * 4;
+  const long long ngroups = POOL ? (M + a.ns - 1) / a.ns : 0;
+
+  // ---- per-wave MFMA coordinates ----
+  const int l31 = lane & 31, lh = lane >> 5;
+  int d_rb[DT], d_kb[DT], yoff[DT];
+#pragma unroll
+  for (int j = 0; j < DT; ++j) {
+    const int d = wave + 8 * j;
+    d_rb[j] = d % RB;
+    d_kb[j] = d / RB;
+    const int col = d_kb[j] * 32 + l31;
+    yoff[j] = col < K ? ((d_rb[j] * 32 + 4 * lh) * K + col) * 4 : kOobOffset;
+  }
+  const int rowpitch = K * 4;
+  int w_nb[TW], w_kb[TW];
+#pragma unroll
+  for (int j = 0; j < TW; ++j) {
+    const int e = T >= 8 ? wave + 8 * j : wave % T;
+    w_nb[j] = e % NTN;
+    w_kb[j] = e / NTN;
+  }
+  const int w_row0 = T >= 8 ? 0 : (wave / T) * WROWS;
+
+  float e_s[DT], e_h[DT], e_m[DT], e_r[DT], cs1[DT], cs2[DT];
+#pragma unroll
+  for (int j = 0; j < DT; ++j) {
+    const int col = d_kb[j] * 32 + l31;
+    const int cc = col < K ? col : (K - 1);
+    e_s[j] = a.a_scale[cc]; e_h[j] = a.a_shift[cc]; e_m[j] = a.a_mean[cc]; e_r[j] = a.a_rstd[cc];
+    cs1[j] = 0.f; cs2[j] = 0.f;
+  }
+
+  f32x16 accd[DT], accw[TW];
+#pragma unroll
+  for (int j = 0; j < DT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accd[j][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < TW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+
+  float rg[RGN], ry[GPT], rp[APT], pg[PG];
+  int pa[PG];
+
+  // The next tile's operands are prefetched in TWO batches (before the dgrad and before the wgrad MFMAs): a wave
+  // can have at most 63 vector-memory operations outstanding (6-bit vmcnt), and one batch of 80-96 dword loads
+  // stalled the issue of everything behind it — including the MFMAs — for a memory latency per tile.
+  auto load_tile_a = [&](long long tile) {
+    const long long m0 = tile * R;
+    const rsrc_t rsy = make_rsrc(a.Yl + (size_t)m0 * N, (M - m0) * N * 4);
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) ry[i] = bload(rsy, goff, i * gpass);
+    if (POOL) {
+      const long long g_first = m0 / a.ns;
+      const rsrc_t rsa = make_rsrc(a.arg + (size_t)g_first * N, (ngroups - g_first) * N * 4);
+      const rsrc_t rsg = make_rsrc(a.gP + (size_t)g_first * N, (ngroups - g_first) * N * 4);
+#pragma unroll
+      for (int e = 0; e < PG; ++e) {
+        pa[e] = bload_i(rsa, goff, e * gpass);
+        pg[e] = bload(rsg, goff, e * gpass);
+      }
+    }
+  };
+  auto load_tile_b = [&](long long tile) {
+    const long long m0 = tile * R;
+    if (!POOL) {
+      const rsrc_t rsg = make_rsrc(a.G + (size_t)m0 * N, (M - m0) * N * 4);
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) rg[POOL ? 0 : i] = bload(rsg, goff, i * gpass);
+    }
+    const rsrc_t rsp = make_rsrc(a.Yprev + (size_t)m0 * K, (M - m0) * K * 4);
+#pragma unroll
+    for (int i = 0; i < APT; ++i) rp[i] = bload(rsp, aoff, i * apass);
+  };
+
+  long long tile = blockIdx.x;
+  load_tile_a(tile);
+  load_tile_b(tile);
+  __syncthreads();                               // resident weights visible
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long long m0 = tile * R;
+    // ---- registers of this tile -> LDS (gy transposed, activation row-major) ----
+    {
+      float gv[GPT];
+#pragma unroll
+      for (int i = 0; i < GPT; ++i)
+        gv[i] = POOL ? __fmaf_rn(c2, ry[i], c3) : __fmaf_rn(c1, rg[POOL ? 0 : i], __fmaf_rn(c2, ry[i], c3));
+      if (m0 + R > M) {
+        // the one tile that crosses M (wave-uniform): rows past M read zeros, so gy = c3 there — clear them
+        asm volatile("; partial tile");
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) gv[i] = (m0 + gr0 + GROWS * i) < M ? gv[i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) gyT[gn * LDT + gr0 + GROWS * i] = gv[i];
+#pragma unroll
+      for (int i = 0; i < APT; ++i)
+        act[(ar0 + AROWS * i) * KP + ak] = fmaxf(__fmaf_rn(rp[i], a_sc, a_sh), 0.f);
+    }
+    if (POOL) {
+      __syncthreads();
+      // sparse arg-max patch: the single non-zero of dL/dz per (row group, column)
+      const int mrem = (int)((M - m0) < (long long)R ? (M - m0) : (long long)R);
+      const long long g_first = m0 / a.ns;
+      const int ngrp = (int)((m0 + mrem - 1) / a.ns - g_first) + 1;
+#pragma unroll
+      for (int e = 0; e < PG; ++e) {
+        const int gi = gr0 + GROWS * e;
+        const long long row = (g_first + gi) * (long long)a.ns + pa[e] - m0;
+        if (gn < N && gi < ngrp && row >= 0 && row < mrem) gyT[gn * LDT + (int)row] += c1 * pg[e];
+      }
+    }
+    __syncthreads();
+
+    // ---- y_{l-1} at the dgrad output positions (mask + sums), then the next tile's operands ----
+    float yp[DT][16];
+    {
+      const rsrc_t rsq = make_rsrc(a.Yprev + (size_t)m0 * K, (M - m0) * K * 4);
+#pragma unroll
+      for (int j = 0; j < DT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yp[j][r] = bload(rsq, yoff[j], ((r & 3) + 8 * (r >> 2)) * rowpitch);
+    }
+    const long long nt = (tile + gridDim.x) < ntiles ? (tile + gridDim.x) : tile;   // past the end: harmless reload
+    load_tile_a(nt);
+
+    // ---- dgrad: out[row][k] = sum_n gy[row][n] * W[n][k] ----
+#pragma unroll
+    for (int s = 0; s < NP / 2; ++s) {
+      const int n = 2 * s + lh;
+#pragma unroll
+      for (int j = 0; j < DT; ++j) {
+        const float av = gyT[n * LDT + d_rb[j] * 32 + l31];
+        const float bv = Wl[n * KP + d_kb[j] * 32 + l31];
+        accd[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accd[j], 0, 0, 0);
+      }
+    }
+    load_tile_b(nt);
+    // ---- wgrad: dW[n][k] += sum_row gy[row][n] * act[row][k] ----
+#pragma unroll
+    for (int s = 0; s < WROWS / 2; ++s) {
+      const int row = w_row0 + 2 * s + lh;
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        const float av = gyT[(w_nb[j] * 32 + l31) * LDT + row];
+        const float bv = act[row * KP + w_kb[j] * 32 + l31];
+        accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);
+      }
+    }
+
+    // ---- dgrad epilogue: ReLU mask of layer l-1, BN-backward sums, store ----
+    const rsrc_t rso = make_rsrc(a.Gout + (size_t)m0 * K, (M - m0) * K * 4);
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float y = yp[j][r];
+        float v = accd[j][r];
+        v = (__fmaf_rn(y, e_s[j], e_h[j]) > 0.f) ? v : 0.f;
+        s1 += v;
+        s2 = __fmaf_rn(v, (y - e_m[j]) * e_r[j], s2);
+        bstore(v, rso, yoff[j], ((r & 3) + 8 * (r >> 2)) * rowpitch);
+        accd[j][r] = 0.f;
+      }
+      cs1[j] += s1;
+      cs2[j] += s2;
+    }
+    __syncthreads();                             // LDS tile free for the next iteration
+  }
+
+  // ---- flush the column sums (once per workgroup) ----
+  for (int i = tid; i < 2 * KP; i += 512) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < DT; ++j) {
+    atomicAdd(&red[d_kb[j] * 32 + l31], cs1[j]);
+    atomicAdd(&red[KP + d_kb[j] * 32 + l31], cs2[j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < KP; i += 512) {
+    if (i < K) {
+      atomicAdd(a.sums + i, (double)red[i]);
+      atomicAdd(a.sums + K + i, (double)red[KP + i]);
+    }
+  }
+  // ---- flush dW: accw[j][r] = dW[n = nb*32 + rowmap(r)][k = kb*32 + lane%32] ----
+#pragma unroll
+  for (int j = 0; j < TW; ++j) {
+    const int kcol = w_kb[j] * 32 + l31;
+    const int nb = w_nb[j] * 32 + 4 * lh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nb + (r & 3) + 8 * (r >> 2);
+      if (n < N && kcol < K) atomicAdd(a.dW + (size_t)n * K + kcol, accw[j][r]);
+    }
+  }
+}
+
+template <int GMODE, int NTN, int KTN, int R>
+int launch_fused(const BwdArgs &a, hipStream_t s) {
+  constexpr int NP = NTN * 32, KP = KTN * 32;
+  constexpr size_t lds_bytes = (size_t)(NP * (R + 1) + R * KP + NP * KP + 2 * KP) * sizeof(float);
+  static_assert(lds_bytes <= 160 * 1024, "LDS budget of one CU");
+  auto kern = mlp_bwd_fused_kernel<GMODE, NTN, KTN, R>;
+  static bool attr_set = false;                  // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+      return pn2_check_launch();
+    attr_set = true;
+  }
+  const long long ntiles = (a.M + R - 1) / R;
+  long long gx = 256;                            // one 130 KB workgroup per CU
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds_bytes, s, a);
+  return pn2_check_launch();
+}
+
+template <int GMODE>
+int dispatch_fused(const BwdArgs &a, hipStream_t s) {
+  const int ntn = a.N <= 64 ? 2 : 4, ktn = a.K <= 64 ? 2 : 4;
+  if (ntn == 2 && ktn == 2) return launch_fused<GMODE, 2, 2, 128>(a, s);
+  if (ntn == 4 && ktn == 2) return launch_fused<GMODE, 4, 2, 128>(a, s);
+  if (ntn == 2 && ktn == 4) return launch_fused<GMODE, 2, 4, 128>(a, s);
+  return PN2_EINVAL;
+}
+
+}  // namespace
+
+// N, K in (32, 128] with at least one of them <= 64: the 128 x 128 layer needs 64-row tiles to fit its weights in LDS
+// and was measured slower than the two-kernel path (0.94 vs 0.79 ms at M = 1M)
+extern "C" int pn2_mlp_bwd_fused_supported(int N, int K) {
+  return N > 32 && N <= 128 && K > 32 && K <= 128 && (N <= 64 || K <= 64);
+}
+
+extern "C" int pn2_mlp_bwd_fused(long long M, int N, int K, int gmode, const float *G, const float *Yl,
+                                 const float *consts, const int *arg, const float *gP, int ns, const float *W,
+                                 const float *Yprev, const float *a_fin, float *Gout, double *sums, float *dW,
+                                 void *stream) {
+  if (M < 0 || !pn2_mlp_bwd_fused_supported(N, K)) return PN2_EINVAL;
+  if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Yl || !consts || !W || !Yprev || !a_fin || !Gout || !sums || !dW) return PN2_ENULL;
+  if (gmode == PRO_GY && !G) return PN2_ENULL;
+  if (gmode == PRO_POOLG && (!arg || !gP || ns < 16 || M >= 0x7fffffffLL)) return PN2_EINVAL;
+  BwdArgs a;
+  a.G = G; a.Yl = Yl; a.c1 = consts; a.c2 = consts + N; a.c3 = consts + 2 * (size_t)N;
+  a.arg = arg; a.gP = gP; a.W = W; a.Yprev = Yprev;
+  a.a_mean = a_fin; a.a_rstd = a_fin + K; a.a_scale = a_fin + 2 * (size_t)K; a.a_shift = a_fin + 3 * (size_t)K;
+  a.Gout = Gout; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K; a.ns = ns;
+  hipStream_t s = (hipStream_t)stream;
+  return gmode == PRO_GY ? dispatch_fused<PRO_GY>(a, s) : dispatch_fused<PRO_POOLG>(a, s);
+}

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "pn2_segment_sum_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_mlp_gemm": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
     "pn2_mlp_wgrad": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
+    "pn2_mlp_bwd_fused": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
     "pn2_bn_finalize": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_bwd_consts": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_apply": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -75,6 +76,8 @@ _lib.pn2_fps_coop_status.argtypes = [_c_int, _c_vp, _c_vp]
 _lib.pn2_fps_coop_status.restype = _c_int
 _lib.pn2_fps_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_workspace_bytes.restype = _c_sz
+_lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
+_lib.pn2_mlp_bwd_fused_supported.restype = _c_int
 _lib.pn2_abi_version.restype = _c_int
 _lib.pn2_last_hip_error.restype = _c_int
 _lib.pn2_strerror.argtypes = [_c_int]
@@ -82,6 +85,7 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 
 ABI_VERSION = int(_lib.pn2_abi_version())
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
+                                               "pn2_mlp_bwd_fused_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
 HAS_ROWS = True
@@ -468,6 +472,24 @@ def mlp_wgrad(Yl, consts, X, gmode, amode, G=None, arg=None, gP=None, ns=0, a_fi
           alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + M * K + N * K), alg_flops=2 * M * N * K,
           tag=(f"M{M},N{N},K{K},g{int(gmode)},a{int(amode)}" if DETAIL_TAGS else None))
     return dW
+
+
+def mlp_bwd_fused_supported(N, K):
+    return bool(_lib.pn2_mlp_bwd_fused_supported(int(N), int(K)))
+
+
+def mlp_bwd_fused(Yl, consts, W, Yprev, a_fin, gmode, G=None, arg=None, gP=None, ns=0):
+    """dgrad + wgrad of one hidden layer in one pass -> (Gout (M,K), sums (2,K) f64, dW (N,K))."""
+    M, N = Yl.shape
+    K = Yprev.size(1)
+    Gout = torch.empty(M, K, dtype=torch.float32, device=Yl.device)
+    sums = torch.zeros(2, K, dtype=torch.float64, device=Yl.device)
+    dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
+    _call("pn2_mlp_bwd_fused", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP),
+          int(ns), _ptr(W), _ptr(Yprev), _ptr(a_fin), _ptr(Gout), _ptr(sums), _ptr(dW),
+          alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + 2 * M * K + N * K), alg_flops=4 * M * N * K,
+          tag=(f"M{M},N{N},K{K},g{int(gmode)}" if DETAIL_TAGS else None))
+    return Gout, sums, dW
 
 
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):

@@ -27,6 +27,10 @@ def _ext():
     return _pu._ext
 
 
+#: hidden layers with 32 < N, K <= 128 run dgrad and wgrad as one kernel (csrc/mlp_bwd_fused.hip)
+FUSED_BACKWARD = True
+
+
 def parse_stack(mlp: nn.Module) -> Optional[List[Tuple[nn.Conv2d, nn.modules.batchnorm._BatchNorm]]]:
     """Flatten `mlp` into [(conv1x1, bn), ...] if it is exactly (conv, bn, relu)*; else None."""
     flat = []
@@ -154,11 +158,18 @@ class _FusedMLP(Function):
         gx = None
         for l in range(L - 1, -1, -1):
             consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
+            grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            if l > 0 and FUSED_BACKWARD and e.mlp_bwd_fused_supported(Ws[l].size(0), Ws[l].size(1)):
+                # hidden layer: dgrad + wgrad from one read of (g, y_l, y_{l-1})
+                G, sums, dW = e.mlp_bwd_fused(ys[l], consts, Ws[l].contiguous(), ys[l - 1], fins[l - 1], gmode,
+                                              G=G, arg=arg, gP=gPm, ns=ns)
+                grads[3 * l] = dW.view(ctx.shapes[l])
+                gmode, arg, gPm = e.PRO_GY, None, None
+                continue
             act = x if l == 0 else ys[l - 1]
             dW = e.mlp_wgrad(ys[l], consts, act, gmode, e.PRO_NONE if l == 0 else e.PRO_BNRELU,
                              G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1])
             grads[3 * l] = dW.view(ctx.shapes[l])
-            grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             need_dgrad = l > 0 or (ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None))
             if need_dgrad:
                 Wt = Ws[l].t()                                    # (K_l, N_l): dgrad is out[M,K_l] = gy[M,N_l] @ Wt^T

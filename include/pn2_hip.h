@@ -197,6 +197,17 @@ int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const float *X, co
                  const float *p0, const float *p1, const float *p2, const int *arg,
                  const float *gP, int ns, const float *W, float *Y, double *stats,
                  const float *Yprev, const float *e_fin, void *stream);
+/* One-pass backward of a hidden layer (32 < N,K <= 128): what pn2_mlp_gemm(pro 2|3, epi 2) and
+ * pn2_mlp_wgrad(amode 1) compute for the same operands, from ONE read of g / y_l / y_{l-1}:
+ *   Gout[M][K] = [y_{l-1}*scale+shift > 0] * (gy * W),  sums += column sums (as epi 2),  dW[N][K] += gy^T * relu(bn(y_{l-1})).
+ * a_fin = [mean | rstd | scale | shift] x K of layer l-1.  Replaces the same reference lines as those two
+ * (autograd of Conv2d/BatchNorm2d/ReLU, OPS/pointnet2_modules.py:9-19).  pn2_mlp_bwd_fused_supported(N, K) != 0
+ * tells whether the shape is covered; otherwise the call returns PN2_EINVAL. */
+int pn2_mlp_bwd_fused_supported(int N, int K);
+int pn2_mlp_bwd_fused(long long M, int N, int K, int gmode, const float *G, const float *Yl,
+                      const float *consts, const int *arg, const float *gP, int ns, const float *W,
+                      const float *Yprev, const float *a_fin, float *Gout, double *sums, float *dW,
+                      void *stream);
 int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, const float *G,
                   const float *Yl, const float *consts, const int *arg, const float *gP, int ns,
                   const float *X, const float *a_fin, float *dW, void *stream);

@@ -44,7 +44,10 @@ def _run(mlp, x, ns, fused, train):
 
 CASES = [((6, 64, 64, 128), 64 * 40, 64), ((131, 128, 128, 256), 32 * 50, 32), ((259, 128, 128, 256), 16 * 70, 16),
          ((512, 256, 288), 1000, 0), ((512, 256, 256), 777, 0), ((5, 16), 300, 0), ((9, 32, 40), 24 * 12, 12),
-         ((259, 256, 256), 3 * 128, 128)]
+         ((259, 256, 256), 3 * 128, 128),
+         # hidden layers on the one-pass backward kernel (csrc/mlp_bwd_fused.hip) with ragged N / K and a partial
+         # last row tile, pooled (ns = 16) and unpooled
+         ((20, 72, 96, 100), 16 * 37, 16), ((30, 48, 120, 64), 777, 0), ((7, 128, 40, 128, 128), 32 * 33, 32)]
 
 
 @pytest.mark.parametrize("train", [True, False])
