@@ -143,10 +143,15 @@ def _ptr(t):
 
 class KernelTimer:
     """Optional per-entry-point HIP-event timing (bench.py): events are recorded on the
-    stream the kernels are enqueued on, resolved lazily by `summary()` after a sync."""
+    stream the kernels are enqueued on, resolved lazily by `summary()` after a sync.
+    `enabled` lets the caller sample a subset of steps (two event records per launch cost
+    ~1 ms per 200-launch step); launches on a stream other than `main_stream` are reported
+    under `name@side` (work prefetched off the critical path)."""
 
-    def __init__(self):
+    def __init__(self, main_stream=None):
         self.records = []          # (name, start_event, end_event, algorithmic_bytes, algorithmic_flops)
+        self.enabled = True
+        self.main_stream = main_stream
 
     def summary(self):
         torch.cuda.synchronize()
@@ -168,12 +173,15 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None):
     """Enqueue `name` on the current stream of `ref`'s device."""
     with torch.cuda.device(ref.device):
         stream = torch.cuda.current_stream(ref.device).cuda_stream
-        if TIMER is not None:
+        if TIMER is not None and TIMER.enabled:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
             rc = getattr(_lib, name)(*args, stream)
             ev1.record()
-            TIMER.records.append((name if tag is None else f"{name}[{tag}]", ev0, ev1, int(alg_bytes), int(alg_flops)))
+            label = name if tag is None else f"{name}[{tag}]"
+            if TIMER.main_stream is not None and stream != TIMER.main_stream:
+                label += "@side"
+            TIMER.records.append((label, ev0, ev1, int(alg_bytes), int(alg_flops)))
         else:
             rc = getattr(_lib, name)(*args, stream)
     if rc != 0:

@@ -6,10 +6,17 @@ batch 32 per GPU, fp32, through the full SA/FP stack (BASELINE configs[1]:
 Group-Free `Pointnet2Backbone` shapes: SA 2048/0.2/64, 1024/0.4/32, 512/0.8/16,
 256/1.2/16 + 2 FP levels).  A "step" = forward, loss, backward (gradient
 all-reduce over RCCL when N > 1) and the AdamW update on one resident synthetic
-batch.  Weak scaling: every rank processes its own 32 scenes.  Everything, including
-the sampling / grouping geometry, runs inside the step on one stream.  (`--geometry-pipeline`
-optionally prefetches the next batch's coordinate-only work on a side stream, data-loader
-style; measured: no net gain on MI355X, so it is off by default.)
+batch.  Weak scaling: every rank processes its own 32 scenes.
+
+Geometry pipeline (default; `--no-geometry-pipeline` turns it off): the parameter-free,
+coordinate-only part of a batch — the FPS chain, the ball queries and the 3-NN weights — is what a
+data loader can prepare ahead of the optimisation step.  Step i enqueues the geometry of batch i+1
+on a side HIP stream before its own forward, so the latency-bound cooperative FPS kernel (2.6 us per
+dependent round, < 10 % of the machine busy) co-runs with the MFMA kernels of step i instead of
+serialising in front of them.  Every timed step still computes exactly one full geometry and
+consumes the one computed during the previous step (the first one during warm-up); nothing is cached
+or skipped.  The JSON also carries `ms_per_step_without_geometry_pipeline` and the uncontended
+per-kernel table `kernels_without_geometry_pipeline` (same build, everything on one stream).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -94,20 +101,83 @@ class GeometryPrefetcher:
         return geo
 
 
-def run_steps(net, backbone, opt, pc, steps, prefetcher):
+def run_steps(net, backbone, opt, pc, steps, prefetcher, on_step=None):
     """`steps` training steps on the resident batch; with a prefetcher, step i consumes the geometry
     enqueued during step i-1 and enqueues the one for step i+1."""
     if prefetcher is None:
-        for _ in range(steps):
+        for i in range(steps):
+            if on_step is not None:
+                on_step(i)
             train_step(net, opt, pc)
         return
     geo = prefetcher.launch(pc)
-    for _ in range(steps):
+    for i in range(steps):
+        if on_step is not None:
+            on_step(i)
         cur = prefetcher.acquire(geo)
-        # the next batch's geometry is enqueued behind this batch's FORWARD, so that the latency-bound
-        # FPS kernel co-runs with the (mostly compute-bound) first half of the backward
-        geo = train_step(net, opt, pc, cur, between=lambda: prefetcher.launch(pc))
+        # the next batch's geometry is enqueued BEFORE this batch's forward: it co-runs with the whole step
+        # (enqueued behind the forward it only overlapped the backward: 23.3 vs 20.7 ms/step)
+        nxt = prefetcher.launch(pc)
+        train_step(net, opt, pc, cur)
+        geo = nxt
     prefetcher.acquire(geo)
+
+
+def kernel_table(table, steps):
+    """Per-entry-point rows from a KernelTimer summary, sorted by time."""
+    rows = []
+    ridge = F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)     # flop/byte where the rooflines cross
+    for name, d in table.items():
+        per_launch_ms = d["ms"] / d["calls"]
+        per_launch_bytes = d["alg_bytes"] / d["calls"]
+        per_launch_flops = d["alg_flops"] / d["calls"]
+        gbps = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        tfps = per_launch_flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+        mfma_bound = per_launch_bytes > 0 and per_launch_flops / per_launch_bytes >= ridge
+        rows.append({"kernel": name, "calls_per_step": d["calls"] / steps,
+                     "ms_per_step": round(d["ms"] / steps, 4),
+                     "avg_launch_us": round(per_launch_ms * 1e3, 2),
+                     "alg_MB_per_launch": round(per_launch_bytes / 1e6, 3),
+                     "alg_GFLOP_per_launch": round(per_launch_flops / 1e9, 3),
+                     "GBps": round(gbps, 1), "TFLOPps": round(tfps, 2),
+                     "bound": "mfma" if mfma_bound else "hbm",
+                     "frac": round(tfps / F32_MFMA_PEAK_TFLOPS if mfma_bound else gbps / HBM_PEAK_GBPS, 5)})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+def roofline_of(top):
+    """`roofline` object for the dominant critical-path kernel row."""
+    if top["bound"] == "mfma":
+        roof = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["TFLOPps"],
+                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac"]}
+    else:
+        roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"]}
+    traffic, traffic_src = None, None
+    tf = os.path.join(REPO, "profiles", "r01_hbm_traffic_per_kernel.json")
+    kname = {"pn2_mlp_gemm": "mlp_gemm_kernel", "pn2_mlp_wgrad": "mlp_wgrad_kernel",
+             "pn2_mlp_bwd_fused": "mlp_bwd_fused_kernel",
+             "pn2_bn_relu_rows_max": "bn_relu_rows_max_kernel",
+             "pn2_group_concat_rows": "group_concat_rows_kernel",
+             "pn2_group_rows_grad": "group_rows_grad_kernel"}.get(top["kernel"])
+    if kname and os.path.exists(tf):
+        try:
+            rec = json.load(open(tf))["kernels"].get(kname)
+            if rec:
+                traffic = int(rec["hbm_bytes_per_launch"])
+                traffic_src = ("PMC FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE per launch, separate rocprofv3 "
+                               "passes over this command: profiles/r01_hbm_traffic_per_kernel.json")
+        except Exception:
+            pass
+    roof.update({"traffic": traffic, "traffic_source": traffic_src,
+                 "avg_launch_us": top["avg_launch_us"],
+                 "alg_bytes_per_launch": int(top["alg_MB_per_launch"] * 1e6),
+                 "alg_flops_per_launch": int(top["alg_GFLOP_per_launch"] * 1e9),
+                 "note": "dominant hand-written kernel of the main (critical-path) stream; entry point aggregated over "
+                         "its launches in the timed steps (shapes differ per layer; per-shape table: "
+                         "PN2_TIMER_DETAIL=1 python bench.py)"})
+    return roof
 
 
 def cpu_baseline(points, sample_scenes, threads):
@@ -219,6 +289,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scenes", type=int, default=4)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-serial-reference", action="store_true",
+                    help="skip the short un-pipelined pass behind `ms_per_step_without_geometry_pipeline`")
     ap.add_argument("--workload", choices=["backbone", "sgp"], default="backbone",
                     help="backbone = BASELINE configs[1] (the headline metric); sgp = BASELINE configs[2] shape: the full "
                          "scene-graph model on synthetic scans (9 objects x 4000 pts + 72 pairs x 8000 pts, one scan per "
@@ -226,10 +298,11 @@ def main():
     ap.add_argument("--graphs", action="store_true",
                     help="sgp workload: replay the whole step as one hipGraph (runtime.GraphedTrainStep); gradients are "
                          "averaged with one flat all-reduce between the backward and the optimizer graph when N > 1")
-    ap.add_argument("--geometry-pipeline", action="store_true",
-                    help="prefetch the NEXT batch's sampling/grouping geometry on a side stream during the step "
-                         "(measured on MI355X: no net gain, the co-resident FPS workgroups halve the occupancy of the "
-                         "memory-bound SA1 GEMMs; off by default)")
+    ap.add_argument("--no-geometry-pipeline", dest="geometry_pipeline", action="store_false",
+                    help="run the sampling/grouping geometry inside the step on the main stream instead of prefetching "
+                         "the NEXT batch's geometry on a side stream during the step (25.0 vs 20.7 ms/step on MI355X)")
+    ap.add_argument("--geometry-pipeline", dest="geometry_pipeline", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(geometry_pipeline=True)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -264,9 +337,11 @@ def main():
     run_steps(net, model, opt, pc, args.warmup, prefetcher)
     torch.cuda.synchronize()
 
-    # reference number without the geometry pipeline (same build, same batch), reported alongside
-    serial_ms = None
-    if prefetcher is not None and rank == 0 and world == 1:
+    main_stream = torch.cuda.current_stream(device).cuda_stream
+    # reference pass without the geometry pipeline (same build, same batch): wall time and an
+    # uncontended per-kernel table, reported alongside
+    serial_ms, serial_rows = None, None
+    if prefetcher is not None and rank == 0 and world == 1 and not args.no_serial_reference:
         ks = max(2, min(args.steps, 5))
         run_steps(net, model, opt, pc, 1, None)
         torch.cuda.synchronize()
@@ -274,16 +349,31 @@ def main():
         run_steps(net, model, opt, pc, ks, None)
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - ts) / ks * 1e3
+        if not args.no_kernel_timing:
+            st = _ext.KernelTimer(main_stream)
+            _ext.TIMER = st
+            run_steps(net, model, opt, pc, 2, None)
+            _ext.TIMER = None
+            serial_rows = kernel_table(st.summary(), 2)
+        run_steps(net, model, opt, pc, 1, prefetcher)       # back to the pipelined steady state
+        torch.cuda.synchronize()
 
-    timer = None
+    # per-kernel HIP events are sampled on every 4th timed step (two event records per launch would
+    # otherwise cost ~5 % of the step); the table is normalised by the number of sampled steps
+    timer, sampled_steps, on_step = None, 0, None
     if not args.no_kernel_timing:
-        timer = _ext.KernelTimer()
+        timer = _ext.KernelTimer(main_stream)
         _ext.TIMER = timer
+        stride = 4 if args.steps >= 8 else 1
+        sampled_steps = len(range(0, args.steps, stride))
+
+        def on_step(i):
+            timer.enabled = (i % stride == 0)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(net, model, opt, pc, args.steps, prefetcher)
+    run_steps(net, model, opt, pc, args.steps, prefetcher, on_step)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -325,57 +415,22 @@ def main():
         if serial_ms is not None:
             out["ms_per_step_without_geometry_pipeline"] = round(serial_ms, 3)
         if timer is not None:
-            table = timer.summary()
-            rows = []
-            ridge = F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)     # flop/byte where the rooflines cross
-            for name, d in table.items():
-                per_launch_ms = d["ms"] / d["calls"]
-                per_launch_bytes = d["alg_bytes"] / d["calls"]
-                per_launch_flops = d["alg_flops"] / d["calls"]
-                gbps = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-                tfps = per_launch_flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-                mfma_bound = per_launch_bytes > 0 and per_launch_flops / per_launch_bytes >= ridge
-                rows.append({"kernel": name, "calls_per_step": d["calls"] / args.steps,
-                             "ms_per_step": round(d["ms"] / args.steps, 4),
-                             "avg_launch_us": round(per_launch_ms * 1e3, 2),
-                             "alg_MB_per_launch": round(per_launch_bytes / 1e6, 3),
-                             "alg_GFLOP_per_launch": round(per_launch_flops / 1e9, 3),
-                             "GBps": round(gbps, 1), "TFLOPps": round(tfps, 2),
-                             "bound": "mfma" if mfma_bound else "hbm",
-                             "frac": round(tfps / F32_MFMA_PEAK_TFLOPS if mfma_bound else gbps / HBM_PEAK_GBPS, 5)})
-            rows.sort(key=lambda r: -r["ms_per_step"])
+            rows = kernel_table(timer.summary(), sampled_steps)
             out["kernels"] = rows
-            hip_ms = sum(r["ms_per_step"] for r in rows)
-            out["hip_kernel_ms_per_step"] = round(hip_ms, 3)
-            if rows:
-                top = rows[0]
-                if top["bound"] == "mfma":
-                    out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["TFLOPps"],
-                                       "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac"]}
-                else:
-                    out["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
-                                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"]}
-                traffic, traffic_src = None, None
-                tf = os.path.join(REPO, "profiles", "r01_hbm_traffic_per_kernel.json")
-                kname = {"pn2_mlp_gemm": "mlp_gemm_kernel", "pn2_mlp_wgrad": "mlp_wgrad_kernel",
-                         "pn2_bn_relu_rows_max": "bn_relu_rows_max_kernel",
-                         "pn2_group_concat_rows": "group_concat_rows_kernel",
-                         "pn2_group_rows_grad": "group_rows_grad_kernel"}.get(top["kernel"])
-                if kname and os.path.exists(tf):
-                    try:
-                        rec = json.load(open(tf))["kernels"].get(kname)
-                        if rec:
-                            traffic = int(rec["hbm_bytes_per_launch"])
-                            traffic_src = ("PMC FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE per launch, separate rocprofv3 "
-                                           "passes over this command: profiles/r01_hbm_traffic_per_kernel.json")
-                    except Exception:
-                        pass
-                out["roofline"].update({"traffic": traffic, "traffic_source": traffic_src,
-                                        "avg_launch_us": top["avg_launch_us"],
-                                        "alg_bytes_per_launch": int(top["alg_MB_per_launch"] * 1e6),
-                                        "alg_flops_per_launch": int(top["alg_GFLOP_per_launch"] * 1e9),
-                                        "note": "entry point aggregated over its launches in the timed steps "
-                                                "(shapes differ per layer; per-shape table: tools/microbench.py MB_MLP=1)"})
+            out["kernel_timing"] = {
+                "method": "HIP events on the launch stream around every C-ABI call, inside the timed region",
+                "sampled_steps": sampled_steps, "of_steps": args.steps,
+                "note": None if prefetcher is None else
+                "entries ending in @side were enqueued on the geometry-prefetch stream: they co-run with the main-stream "
+                "kernels (their durations include waiting for CUs), are off the critical path and are not candidates "
+                "for `roofline`; `kernels_without_geometry_pipeline` is the uncontended table"}
+            main_rows = [r for r in rows if not r["kernel"].endswith("@side")]
+            out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
+            if main_rows:
+                out["roofline"] = roofline_of(main_rows[0])
+        if serial_rows is not None:
+            keep = ("kernel", "calls_per_step", "ms_per_step", "avg_launch_us", "GBps", "TFLOPps", "bound", "frac")
+            out["kernels_without_geometry_pipeline"] = [{k: r[k] for k in keep} for r in serial_rows]
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 64)
             try:
