@@ -19,6 +19,8 @@
 
 #include "../../include/pn2_hip.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct BwdArgs {
@@ -285,6 +287,286 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(const BwdArgs a) {
   }
 }
 
+// ---- version 2 (K <= 64): 64-row tiles, double-buffered LDS, role-specialised waves --------------------
+// The kernel above runs its eight waves in lockstep (stage -> barrier -> MFMA -> epilogue -> barrier): the MFMA
+// pipe idles ~40 % of the time because VALU/LDS work does not overlap with fp32 MFMAs inside a wave and both
+// waves of a SIMD are always in the same phase.  Here the row tile is 64 x N, staged into the OTHER half of a
+// double-buffered LDS while the current half is consumed, and the waves of a SIMD are given different roles
+// with opposite phase order:
+//     waves 0-3 ("dgrad"):  stage tile t+1  ->  64 x 64 dgrad tile (one 32x32 block each)  ->  mask / sums / store
+//     waves 4-7 ("wgrad"):  dW blocks (n-block w-4, both k-blocks) over the 64 rows        ->  stage tile t+1
+// (wave w and w+4 share a SIMD), so one wave's staging and epilogue run under the other's MFMAs.  Both roles
+// issue the same number of MFMAs per tile (N/2 resp. 2 * 32 for N = 128; 32 resp. 32 for N = 64).
+// One barrier per tile (+ one for the pooled-gradient patch).
+template <int GMODE, int NTN>
+__global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
+  constexpr bool POOL = GMODE == PRO_POOLG;
+  constexpr int R = 64, KTN = 2;
+  constexpr int NP = NTN * 32, KP = KTN * 32;
+  constexpr int LDT = R + 1;
+  constexpr int GROWS = 512 / NP;               // 4 (N = 128) or 8 (N = 64)
+  constexpr int GPT = R / GROWS;                // 16 or 8
+  constexpr int AROWS = 512 / KP;               // 8
+  constexpr int APT = R / AROWS;                // 8
+  constexpr int TWN = NTN == 4 ? 2 : 1;         // dW blocks per wgrad wave
+  constexpr int PG = POOL ? ((R / 16 + 1 + GROWS - 1) / GROWS) : 1;
+  constexpr int RGN = POOL ? 1 : GPT;
+  constexpr int GY_SZ = NP * LDT, ACT_SZ = R * KP;
+
+  extern __shared__ float lds[];
+  float *gyT0 = lds;                            // [2][NP][LDT]
+  float *act0 = gyT0 + 2 * GY_SZ;               // [2][R][KP]
+  float *Wl = act0 + 2 * ACT_SZ;                // [NP][KP]
+  float *red = Wl + NP * KP;                    // [2][KP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const bool dgrad_role = wave < 4;
+  const int N = a.N, K = a.K;
+  const long long M = a.M;
+  const long long ntiles = (M + R - 1) / R;
+
+  for (int i = tid; i < NP * KP; i += 512) {
+    const int n = i / KP, k = i % KP;
+    Wl[i] = (n < N && k < K) ? a.W[(size_t)n * K + k] : 0.f;
+  }
+
+  const int gn = tid % NP, gr0 = tid / NP;
+  const int gnc = gn < N ? gn : (N - 1);
+  const float c1 = a.c1[gnc], c2 = a.c2[gnc], c3 = a.c3[gnc];
+  const int ak = tid % KP, ar0 = tid / KP;
+  const int akc = ak < K ? ak : (K - 1);
+  const float a_sc = a.a_scale[akc], a_sh = a.a_shift[akc];
+  const int goff = (gr0 * N + gn) * 4, gpass = GROWS * N * 4;
+  const int aoff = (ar0 * K + ak) * 4, apass = AROWS * K * 4;
+  const unsigned ns = POOL ? (unsigned)a.ns : 1u;
+  const unsigned ngroups = POOL ? (unsigned)((M + ns - 1) / ns) : 0u;      // M < 2^31 in pooled mode
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  // dgrad role: block (rb, kb) of the 64 x 64 output tile
+  const int d_rb = wave & 1, d_kb = (wave >> 1) & 1;
+  const int dcol = d_kb * 32 + l31;
+  const int yoff = dcol < K ? ((d_rb * 32 + 4 * lh) * K + dcol) * 4 : kOobOffset;
+  const int rowpitch = K * 4;
+  const int dcc = dcol < K ? dcol : (K - 1);
+  const float e_s = a.a_scale[dcc], e_h = a.a_shift[dcc], e_m = a.a_mean[dcc], e_r = a.a_rstd[dcc];
+  float cs1 = 0.f, cs2 = 0.f;
+  // wgrad role: NTN == 4: n-block (wave-4), k-blocks 0 and 1, all 64 rows; NTN == 2: block (nb, kb) = ((w-4)&1, (w-4)>>1)
+  const int w_nb = NTN == 4 ? (wave & 3) : (wave & 1);
+  const int w_kb0 = NTN == 4 ? 0 : ((wave >> 1) & 1);
+
+  f32x16 accd, accw[TWN];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < TWN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+
+  // two register sets: the operands of tiles t+1 and t+2 are in flight / in registers while tile t is computed
+  // (a burst of one tile per CU takes ~3 us to stream at full HBM rate plus the latency: with a single set the
+  // whole transfer was exposed behind the MFMA phase and the two times simply added up)
+  float rg0[RGN], ry0[GPT], rp0[APT], pg0[PG];
+  float rg1[RGN], ry1[GPT], rp1[APT], pg1[PG];
+  int pa0[PG], pa1[PG];
+
+  auto load_tile = [&](long long tile, float (&rg)[RGN], float (&ry)[GPT], float (&rp)[APT], int (&pa)[PG],
+                       float (&pg)[PG]) {
+    const long long m0 = tile * R;
+    const rsrc_t rsy = make_rsrc(a.Yl + (size_t)m0 * N, (M - m0) * N * 4);
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) ry[i] = bload(rsy, goff, i * gpass);
+    if (POOL) {
+      const unsigned g_first = (unsigned)m0 / ns;
+      const rsrc_t rsa = make_rsrc(a.arg + (size_t)g_first * N, (long long)(ngroups - g_first) * N * 4);
+      const rsrc_t rsg = make_rsrc(a.gP + (size_t)g_first * N, (long long)(ngroups - g_first) * N * 4);
+#pragma unroll
+      for (int e = 0; e < PG; ++e) {
+        pa[e] = bload_i(rsa, goff, e * gpass);
+        pg[e] = bload(rsg, goff, e * gpass);
+      }
+    } else {
+      const rsrc_t rsg = make_rsrc(a.G + (size_t)m0 * N, (M - m0) * N * 4);
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) rg[POOL ? 0 : i] = bload(rsg, goff, i * gpass);
+    }
+    const rsrc_t rsp = make_rsrc(a.Yprev + (size_t)m0 * K, (M - m0) * K * 4);
+#pragma unroll
+    for (int i = 0; i < APT; ++i) rp[i] = bload(rsp, aoff, i * apass);
+  };
+
+  // registers (tile `st`) -> LDS buffer `buf`; keeps the patch operands of that tile in (spa, spg)
+  int spa[PG];
+  float spg[PG];
+  long long p_m0 = 0;
+  auto stage = [&](long long st, int buf, float (&rg)[RGN], float (&ry)[GPT], float (&rp)[APT], int (&pa)[PG],
+                   float (&pg)[PG]) {
+    const long long m0 = st * R;
+    float *gyT = gyT0 + buf * GY_SZ;
+    float *act = act0 + buf * ACT_SZ;
+    float gv[GPT];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i)
+      gv[i] = POOL ? __fmaf_rn(c2, ry[i], c3) : __fmaf_rn(c1, rg[POOL ? 0 : i], __fmaf_rn(c2, ry[i], c3));
+    if (m0 + R > M) {
+      asm volatile("; partial tile");            // rows past M read zeros, so gy = c3 there: clear them (real branch)
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) gv[i] = (m0 + gr0 + GROWS * i) < M ? gv[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) gyT[gn * LDT + gr0 + GROWS * i] = gv[i];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) act[(ar0 + AROWS * i) * KP + ak] = fmaxf(__fmaf_rn(rp[i], a_sc, a_sh), 0.f);
+    if (POOL) {
+#pragma unroll
+      for (int e = 0; e < PG; ++e) { spa[e] = pa[e]; spg[e] = pg[e]; }
+      p_m0 = m0;
+    }
+  };
+  auto patch = [&](int buf) {                    // sparse arg-max patch of the tile staged last
+    float *gyT = gyT0 + buf * GY_SZ;
+    const long long m0 = p_m0;
+    const int mrem = (int)((M - m0) < (long long)R ? (M - m0) : (long long)R);
+    const unsigned g_first = (unsigned)m0 / ns;
+    const int ngrp = (int)((unsigned)(m0 + mrem - 1) / ns - g_first) + 1;
+#pragma unroll
+    for (int e = 0; e < PG; ++e) {
+      const int gi = gr0 + GROWS * e;
+      const long long row = (long long)(g_first + gi) * ns + spa[e] - m0;
+      if (gn < N && gi < ngrp && row >= 0 && row < mrem) gyT[gn * LDT + (int)row] += c1 * spg[e];
+    }
+  };
+
+  const long long stride = gridDim.x;
+  const long long my_tiles = (ntiles - blockIdx.x + stride - 1) / stride;          // >= 1 (grid <= ntiles)
+  const long long last = blockIdx.x + (my_tiles - 1) * stride;
+  auto clampt = [&](long long t) { return t < ntiles ? t : last; };                // past the end: harmless reloads
+  long long tile = blockIdx.x;
+
+  // one pipeline iteration: tile `tile` is in LDS buffer `buf`, (rg, ry, ...) hold tile+stride and are staged into
+  // buf^1, then refilled with tile+3*stride (the other register set holds tile+2*stride)
+  auto iteration = [&](int buf, float (&rg)[RGN], float (&ry)[GPT], float (&rp)[APT], int (&pa)[PG], float (&pg)[PG]) {
+    const long long m0 = tile * R;
+    const long long t1 = clampt(tile + stride), t3 = clampt(tile + 3 * stride);
+    const float *gyT = gyT0 + buf * GY_SZ;
+    const float *act = act0 + buf * ACT_SZ;
+    if (dgrad_role) {
+      float yp[16];
+      const rsrc_t rsq = make_rsrc(a.Yprev + (size_t)m0 * K, (M - m0) * K * 4);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yp[r] = bload(rsq, yoff, ((r & 3) + 8 * (r >> 2)) * rowpitch);
+      stage(t1, buf ^ 1, rg, ry, rp, pa, pg);
+      load_tile(t3, rg, ry, rp, pa, pg);
+#pragma unroll
+      for (int s = 0; s < NP / 2; ++s) {
+        const int n = 2 * s + lh;
+        const float av = gyT[n * LDT + d_rb * 32 + l31];
+        const float bv = Wl[n * KP + d_kb * 32 + l31];
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accd, 0, 0, 0);
+      }
+      const rsrc_t rso = make_rsrc(a.Gout + (size_t)m0 * K, (M - m0) * K * 4);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float y = yp[r];
+        float v = accd[r];
+        v = (__fmaf_rn(y, e_s, e_h) > 0.f) ? v : 0.f;
+        s1 += v;
+        s2 = __fmaf_rn(v, (y - e_m) * e_r, s2);
+        bstore(v, rso, yoff, ((r & 3) + 8 * (r >> 2)) * rowpitch);
+        accd[r] = 0.f;
+      }
+      cs1 += s1;
+      cs2 += s2;
+    } else {
+#pragma unroll
+      for (int s = 0; s < R / 2; ++s) {
+        const int row = 2 * s + lh;
+        const float av = gyT[(w_nb * 32 + l31) * LDT + row];
+#pragma unroll
+        for (int j = 0; j < TWN; ++j) {
+          const float bv = act[row * KP + (w_kb0 + j) * 32 + l31];
+          accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);
+        }
+      }
+      stage(t1, buf ^ 1, rg, ry, rp, pa, pg);
+      load_tile(t3, rg, ry, rp, pa, pg);
+    }
+    __syncthreads();
+    if (POOL) {
+      patch(buf ^ 1);
+      __syncthreads();
+    }
+    tile += stride;
+  };
+
+  load_tile(tile, rg0, ry0, rp0, pa0, pg0);
+  load_tile(clampt(tile + stride), rg1, ry1, rp1, pa1, pg1);
+  __syncthreads();                               // resident weights visible
+  stage(tile, 0, rg0, ry0, rp0, pa0, pg0);
+  load_tile(clampt(tile + 2 * stride), rg0, ry0, rp0, pa0, pg0);
+  __syncthreads();
+  if (POOL) {
+    patch(0);
+    __syncthreads();
+  }
+  // single-exit pair loop + peeled odd iteration (see mlp_gemm_kernel): set 1 holds tile+stride, set 0 tile+2*stride
+  for (long long pair = my_tiles >> 1; pair > 0; --pair) {
+    iteration(0, rg1, ry1, rp1, pa1, pg1);
+    iteration(1, rg0, ry0, rp0, pa0, pg0);
+  }
+  if (my_tiles & 1) iteration(0, rg1, ry1, rp1, pa1, pg1);
+
+  // ---- flush the column sums (dgrad waves; both row blocks of a column add up in LDS) ----
+  for (int i = tid; i < 2 * KP; i += 512) red[i] = 0.f;
+  __syncthreads();
+  if (dgrad_role) {
+    atomicAdd(&red[dcol], cs1);
+    atomicAdd(&red[KP + dcol], cs2);
+  }
+  __syncthreads();
+  for (int i = tid; i < KP; i += 512) {
+    if (i < K) {
+      atomicAdd(a.sums + i, (double)red[i]);
+      atomicAdd(a.sums + K + i, (double)red[KP + i]);
+    }
+  }
+  // ---- flush dW (wgrad waves) ----
+  if (!dgrad_role) {
+#pragma unroll
+    for (int j = 0; j < TWN; ++j) {
+      const int kcol = (w_kb0 + j) * 32 + l31;
+      const int nb = w_nb * 32 + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nb + (r & 3) + 8 * (r >> 2);
+        if (n < N && kcol < K) atomicAdd(a.dW + (size_t)n * K + kcol, accw[j][r]);
+      }
+    }
+  }
+}
+
+template <int GMODE, int NTN>
+int launch_fused2(const BwdArgs &a, hipStream_t s) {
+  constexpr int NP = NTN * 32, KP = 64, R = 64;
+  constexpr size_t lds_bytes = (size_t)(2 * NP * (R + 1) + 2 * R * KP + NP * KP + 2 * KP) * sizeof(float);
+  static_assert(lds_bytes <= 160 * 1024, "LDS budget of one CU");
+  auto kern = mlp_bwd_fused2_kernel<GMODE, NTN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+      return pn2_check_launch();
+    attr_set = true;
+  }
+  const long long ntiles = (a.M + R - 1) / R;
+  long long gx = lds_bytes * 2 <= 160 * 1024 ? 512 : 256;      // workgroups per CU by LDS
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds_bytes, s, a);
+  return pn2_check_launch();
+}
+
 template <int GMODE, int NTN, int KTN, int R>
 int launch_fused(const BwdArgs &a, hipStream_t s) {
   constexpr int NP = NTN * 32, KP = KTN * 32;
@@ -308,6 +590,9 @@ int launch_fused(const BwdArgs &a, hipStream_t s) {
 template <int GMODE>
 int dispatch_fused(const BwdArgs &a, hipStream_t s) {
   const int ntn = a.N <= 64 ? 2 : 4, ktn = a.K <= 64 ? 2 : 4;
+  // N, K <= 64: role-specialised version 2 (1.16 vs 1.31 ms at M = 4.2M); N = 128: version 1 (1.67 vs 2.44 ms —
+  // the two register sets of 64 x 128 gy tiles push version 2 past 256 VGPRs).  PN2_BWD_FUSED_V1=1 forces version 1.
+  if (ntn == 2 && ktn == 2 && !getenv("PN2_BWD_FUSED_V1")) return launch_fused2<GMODE, 2>(a, s);
   if (ntn == 2 && ktn == 2) return launch_fused<GMODE, 2, 2, 128>(a, s);
   if (ntn == 4 && ktn == 2) return launch_fused<GMODE, 4, 2, 128>(a, s);
   if (ntn == 2 && ktn == 4) return launch_fused<GMODE, 2, 4, 128>(a, s);
