@@ -92,40 +92,116 @@ __global__ __launch_bounds__(kBlock) void group_points_grad_kernel(int C, int N,
 // ------------------------------------------------------- point-major rows ----
 // out[row, 0:Cx]   = (xyz[b, idx[row]] - new_xyz[b, j]) (/ radius)
 // out[row, Cx:W]   = feats[b, idx[row], :]          row = (b*m + j)*ns + s
-__global__ __launch_bounds__(kBlock) void group_concat_rows_kernel(
+//
+// Wide rows (C >= 32): ONE WAVE PER ROW GROUP.  A wave walks a contiguous range of rows eight at a time:
+// lanes 0..7 fetch the eight neighbour indices with one load, `readlane` turns each into a wave-uniform
+// scalar, and the row's source / destination addresses are scalar bases + lane offsets, so the column loop
+// is pure coalesced load/store with no per-element integer arithmetic.  (The first version decomposed the
+// flat element index with three 64-bit divisions per ELEMENT — ~150 VALU instructions per float moved.)
+// The (b, j, s) decomposition of a row is kept in scalar counters.
+__global__ __launch_bounds__(kBlock) void group_concat_rows_wide_kernel(
     int N, int m, int ns, int C, int Cx, int normalize, float radius,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ feats, const int *__restrict__ idx, float *__restrict__ out,
-    size_t total /* rows * W */) {
+    unsigned rows, unsigned rows_per_wave) {
+  const int lane = pn2_lane();
+  const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
   const int W = Cx + C;
-  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total;
-       e += (size_t)gridDim.x * kBlock) {
-    const size_t row = e / W;
-    const int w = (int)(e - row * W);
-    const size_t bj = row / ns;       // b*m + j
-    const size_t b = bj / m;
-    const int ii = idx[row];
-    float v;
-    if (w < Cx) {
-      v = xyz[(b * N + ii) * 3 + w] - new_xyz[bj * 3 + w];
-      if (normalize) v = __fdiv_rn(v, radius);
-    } else {
-      v = feats[(b * N + ii) * C + (w - Cx)];
+  unsigned r0 = wave * rows_per_wave;
+  if (r0 >= rows) return;
+  unsigned r1 = r0 + rows_per_wave;
+  if (r1 > rows) r1 = rows;
+  unsigned bj = r0 / (unsigned)ns;               // b*m + j of the current row (scalar)
+  unsigned s = r0 - bj * (unsigned)ns;
+  unsigned b = bj / (unsigned)m;
+  unsigned j = bj - b * (unsigned)m;
+  for (unsigned base = r0; base < r1; base += 8) {
+    const unsigned nrow = (r1 - base) < 8u ? (r1 - base) : 8u;
+    const int myi = lane < (int)nrow ? idx[base + lane] : 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if ((unsigned)q >= nrow) break;            // wave-uniform
+      const int ii = __builtin_amdgcn_readlane(myi, q);
+      const size_t src = (size_t)b * N + (size_t)ii;
+      float *o = out + (size_t)(base + q) * W;
+      if (lane < Cx) {
+        float v = xyz[src * 3 + lane] - new_xyz[(size_t)bj * 3 + lane];
+        if (normalize) v = __fdiv_rn(v, radius);
+        o[lane] = v;
+      }
+      const float *f = feats + src * C;
+      for (int c = lane; c < C; c += 64) o[Cx + c] = f[c];
+      if (++s == (unsigned)ns) {
+        s = 0; ++bj;
+        if (++j == (unsigned)m) { j = 0; ++b; }
+      }
     }
-    out[e] = v;
   }
 }
 
+// Narrow rows (W <= 16, e.g. the 3+3 columns of SA1): a lane per row, 32-bit index arithmetic, the wave's
+// 64 rows staged through LDS so that the stores are contiguous.
+__global__ __launch_bounds__(kBlock) void group_concat_rows_narrow_kernel(
+    int N, int m, int ns, int C, int Cx, int normalize, float radius,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats, const int *__restrict__ idx, float *__restrict__ out, unsigned rows) {
+  __shared__ float tile[kBlock / 64][64 * 17];
+  const int lane = pn2_lane();
+  const int wv = threadIdx.x >> 6;
+  const int W = Cx + C;
+  float *t = tile[wv];
+  const unsigned nwaves = gridDim.x * (kBlock / 64);
+  for (unsigned w0 = (blockIdx.x * (kBlock / 64) + wv) * 64u; w0 < rows; w0 += nwaves * 64u) {
+    const unsigned row = w0 + lane;
+    if (row < rows) {
+      const unsigned bj = row / (unsigned)ns;
+      const unsigned b = bj / (unsigned)m;
+      const int ii = idx[row];
+      const size_t src = (size_t)b * N + (size_t)ii;
+      for (int w = 0; w < Cx; ++w) {
+        float v = xyz[src * 3 + w] - new_xyz[(size_t)bj * 3 + w];
+        if (normalize) v = __fdiv_rn(v, radius);
+        t[lane * 17 + w] = v;
+      }
+      for (int c = 0; c < C; ++c) t[lane * 17 + Cx + c] = feats[src * C + c];
+    }
+    // same wave wrote and reads: no barrier needed, only the LDS counter
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    const unsigned nrow = (rows - w0) < 64u ? (rows - w0) : 64u;
+    float *o = out + (size_t)w0 * W;
+    for (unsigned e = lane; e < nrow * (unsigned)W; e += 64) {
+      const unsigned r = e / (unsigned)W, w = e - r * (unsigned)W;
+      o[e] = t[r * 17 + w];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+}
+
+// grad_feats[b, idx[row], :] += grad_out[row, col0 : col0 + C]   (hardware fp32 atomics), a wave per row group
 __global__ __launch_bounds__(kBlock) void group_rows_grad_kernel(
     int N, int m, int ns, int C, int ldg, int col0, const float *__restrict__ grad_out,
-    const int *__restrict__ idx, float *__restrict__ grad_feats, size_t total /* rows * C */) {
-  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total;
-       e += (size_t)gridDim.x * kBlock) {
-    const size_t row = e / C;
-    const int c = (int)(e - row * C);
-    const size_t b = row / ((size_t)m * ns);
-    const int ii = idx[row];
-    atomicAdd(grad_feats + (b * N + ii) * C + c, grad_out[row * ldg + col0 + c]);
+    const int *__restrict__ idx, float *__restrict__ grad_feats, unsigned rows, unsigned rows_per_wave) {
+  const int lane = pn2_lane();
+  const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+  unsigned r0 = wave * rows_per_wave;
+  if (r0 >= rows) return;
+  unsigned r1 = r0 + rows_per_wave;
+  if (r1 > rows) r1 = rows;
+  const unsigned mns = (unsigned)m * (unsigned)ns;
+  unsigned b = r0 / mns;
+  unsigned inb = r0 - b * mns;                   // row index inside the cloud
+  for (unsigned base = r0; base < r1; base += 8) {
+    const unsigned nrow = (r1 - base) < 8u ? (r1 - base) : 8u;
+    const int myi = lane < (int)nrow ? idx[base + lane] : 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if ((unsigned)q >= nrow) break;
+      const int ii = __builtin_amdgcn_readlane(myi, q);
+      float *dst = grad_feats + ((size_t)b * N + (size_t)ii) * C;
+      const float *g = grad_out + (size_t)(base + q) * ldg + col0;
+      for (int c = lane; c < C; c += 64) atomicAdd(dst + c, g[c]);
+      if (++inb == mns) { inb = 0; ++b; }
+    }
   }
 }
 
@@ -231,9 +307,25 @@ extern "C" int pn2_group_concat_rows(int B, int N, int m, int ns, int C, int use
   if (Cx && (!xyz || !new_xyz)) return PN2_ENULL;
   if (C && !feats) return PN2_ENULL;
   if (normalize && !(radius > 0.f)) return PN2_EINVAL;
-  hipLaunchKernelGGL(group_concat_rows_kernel, dim3(capped(total)), dim3(kBlock), 0,
-                     (hipStream_t)stream, N, m, ns, C, Cx, normalize, radius, xyz, new_xyz, feats,
-                     idx, out, total);
+  const size_t rows_sz = (size_t)B * m * ns;
+  if (rows_sz >= 0x7fffffffull) return PN2_EINVAL;
+  const unsigned rows = (unsigned)rows_sz;
+  if (Cx + C <= 16) {
+    const unsigned waves = (rows + 63) / 64;
+    unsigned grid = (waves + kBlock / 64 - 1) / (kBlock / 64);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(group_concat_rows_narrow_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns,
+                       C, Cx, normalize, radius, xyz, new_xyz, feats, idx, out, rows);
+  } else {
+    // ~16 waves per CU, each a contiguous slab of rows (multiple of 8)
+    const unsigned want_waves = 256u * 16u;
+    unsigned rpw = (rows + want_waves - 1) / want_waves;
+    rpw = (rpw + 7u) & ~7u;
+    const unsigned waves = (rows + rpw - 1) / rpw;
+    const unsigned grid = (waves + kBlock / 64 - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(group_concat_rows_wide_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C,
+                       Cx, normalize, radius, xyz, new_xyz, feats, idx, out, rows, rpw);
+  }
   return pn2_check_launch();
 }
 
@@ -244,8 +336,16 @@ extern "C" int pn2_group_rows_grad(int B, int N, int m, int ns, int C, int ldg, 
   const size_t total = (size_t)B * m * ns * (size_t)C;
   if (total == 0) return PN2_OK;
   if (!grad_out || !idx || !grad_feats) return PN2_ENULL;
-  hipLaunchKernelGGL(group_rows_grad_kernel, dim3(capped(total)), dim3(kBlock), 0,
-                     (hipStream_t)stream, N, m, ns, C, ldg, col0, grad_out, idx, grad_feats, total);
+  const size_t rows_sz = (size_t)B * m * ns;
+  if (rows_sz >= 0x7fffffffull) return PN2_EINVAL;
+  const unsigned rows = (unsigned)rows_sz;
+  const unsigned want_waves = 256u * 16u;
+  unsigned rpw = (rows + want_waves - 1) / want_waves;
+  rpw = (rpw + 7u) & ~7u;
+  const unsigned waves = (rows + rpw - 1) / rpw;
+  const unsigned grid = (waves + kBlock / 64 - 1) / (kBlock / 64);
+  hipLaunchKernelGGL(group_rows_grad_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C, ldg,
+                     col0, grad_out, idx, grad_feats, rows, rpw);
   return pn2_check_launch();
 }
 
