@@ -470,11 +470,31 @@ def mlp_gemm(X, W, pro=PRO_NONE, epi=EPI_NONE, X2=None, p=None, arg=None, gP=Non
     return Y
 
 
-def mlp_wgrad(Yl, consts, X, gmode, amode, G=None, arg=None, gP=None, ns=0, a_fin=None):
-    """dW (N,K) = gy^T @ act, gy/act formed on the fly (include/pn2_hip.h)."""
+def zero_arena(device, specs):
+    """[(shape, dtype), ...] -> zero-filled tensors carved out of ONE allocation / ONE fill kernel.  The MLP
+    autograd node needs ~6 small accumulators per layer (statistics, weight gradients); as separate torch.zeros
+    calls they were ~80 four-microsecond launches per step."""
+    offs, total = [], 0
+    for shape, dtype in specs:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        offs.append((total, n))
+        total += (n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
+    buf = torch.zeros(total, dtype=torch.uint8, device=device)
+    out = []
+    for (shape, dtype), (o, n) in zip(specs, offs):
+        nb = n * torch.empty((), dtype=dtype).element_size()
+        out.append(buf[o:o + nb].view(dtype).view(*shape))
+    return out
+
+
+def mlp_wgrad(Yl, consts, X, gmode, amode, G=None, arg=None, gP=None, ns=0, a_fin=None, dW=None):
+    """dW (N,K) = gy^T @ act, gy/act formed on the fly (include/pn2_hip.h).  `dW`: pre-zeroed output (optional)."""
     M, N = Yl.shape
     K = X.size(1)
-    dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
+    if dW is None:
+        dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
     _call("pn2_mlp_wgrad", Yl, M, N, K, int(gmode), int(amode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg),
           _ptr(gP), int(ns), _ptr(X), _ptr(a_fin), _ptr(dW),
           alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + M * K + N * K), alg_flops=2 * M * N * K,
@@ -486,13 +506,16 @@ def mlp_bwd_fused_supported(N, K):
     return bool(_lib.pn2_mlp_bwd_fused_supported(int(N), int(K)))
 
 
-def mlp_bwd_fused(Yl, consts, W, Yprev, a_fin, gmode, G=None, arg=None, gP=None, ns=0):
-    """dgrad + wgrad of one hidden layer in one pass -> (Gout (M,K), sums (2,K) f64, dW (N,K))."""
+def mlp_bwd_fused(Yl, consts, W, Yprev, a_fin, gmode, G=None, arg=None, gP=None, ns=0, sums=None, dW=None):
+    """dgrad + wgrad of one hidden layer in one pass -> (Gout (M,K), sums (2,K) f64, dW (N,K)).
+    `sums` / `dW`: pre-zeroed accumulators (optional)."""
     M, N = Yl.shape
     K = Yprev.size(1)
     Gout = torch.empty(M, K, dtype=torch.float32, device=Yl.device)
-    sums = torch.zeros(2, K, dtype=torch.float64, device=Yl.device)
-    dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
+    if sums is None:
+        sums = torch.zeros(2, K, dtype=torch.float64, device=Yl.device)
+    if dW is None:
+        dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
     _call("pn2_mlp_bwd_fused", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP),
           int(ns), _ptr(W), _ptr(Yprev), _ptr(a_fin), _ptr(Gout), _ptr(sums), _ptr(dW),
           alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + 2 * M * K + N * K), alg_flops=4 * M * N * K,
@@ -525,10 +548,11 @@ def bn_relu_apply(y, fin):
     return out
 
 
-def bn_relu_bwd_prep(y, gout, fin):
+def bn_relu_bwd_prep(y, gout, fin, sums=None):
     M, N = y.shape
     gpre = torch.empty_like(y)
-    sums = torch.zeros(2, N, dtype=torch.float64, device=y.device)
+    if sums is None:
+        sums = torch.zeros(2, N, dtype=torch.float64, device=y.device)
     _call("pn2_bn_relu_bwd_prep", y, M, N, _ptr(y), _ptr(gout), _ptr(fin), _ptr(gpre), _ptr(sums), alg_bytes=12 * M * N)
     return gpre, sums
 
@@ -544,10 +568,11 @@ def bn_relu_rows_max(y, fin, ns):
     return out, arg, yraw
 
 
-def pool_bwd_prep(yraw, pooled, gP, fin):
+def pool_bwd_prep(yraw, pooled, gP, fin, sums=None):
     R, C = pooled.shape
     gPm = torch.empty_like(pooled)
-    sums = torch.zeros(2, C, dtype=torch.float64, device=pooled.device)
+    if sums is None:
+        sums = torch.zeros(2, C, dtype=torch.float64, device=pooled.device)
     _call("pn2_pool_bwd_prep", pooled, R, C, _ptr(yraw), _ptr(pooled), _ptr(gP), _ptr(fin), _ptr(gPm),
           _ptr(sums), alg_bytes=16 * R * C)
     return gPm, sums

@@ -92,6 +92,7 @@ class _FusedMLP(Function):
         M = x.size(0)
         L = len(layers)
         ys, fins, batch_flags = [], [], []
+        stat_bufs = e.zero_arena(x.device, [((2, conv.out_channels), torch.float64) for conv, _ in layers])
         cur = x
         for l, (conv, bn) in enumerate(layers):
             W = params[3 * l].view(conv.out_channels, conv.in_channels)
@@ -100,7 +101,7 @@ class _FusedMLP(Function):
             pro = e.PRO_NONE if l == 0 else e.PRO_BNRELU
             p = None if l == 0 else (fins[-1][2], fins[-1][3])
             if use_batch:
-                stats = torch.zeros(2, conv.out_channels, dtype=torch.float64, device=x.device)
+                stats = stat_bufs[l]
                 y = e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
                 momentum = 0.0
                 rm = rv = None
@@ -146,12 +147,17 @@ class _FusedMLP(Function):
         M = x.size(0)
         g_out = g_out.contiguous()
 
+        # every zero-initialised accumulator of this backward from one allocation / one fill
+        f64, f32 = torch.float64, torch.float32
+        arena = e.zero_arena(x.device, [((2, Ws[-1].size(0)), f64)] + [((2, Ws[l].size(1)), f64) for l in range(L)] +
+                             [(tuple(Ws[l].shape), f32) for l in range(L)])
+        sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:]
         if ns:
             pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
-            gPm, sums = e.pool_bwd_prep(yraw, pooled, g_out, fins[-1])
+            gPm, sums = e.pool_bwd_prep(yraw, pooled, g_out, fins[-1], sums=sums0)
             gmode, G = e.PRO_POOLG, None
         else:
-            G, sums = e.bn_relu_bwd_prep(ys[-1], g_out, fins[-1])
+            G, sums = e.bn_relu_bwd_prep(ys[-1], g_out, fins[-1], sums=sums0)
             gmode, arg, gPm = e.PRO_GY, None, None
 
         grads = [None] * (3 * L)
@@ -162,13 +168,13 @@ class _FusedMLP(Function):
             if l > 0 and FUSED_BACKWARD and e.mlp_bwd_fused_supported(Ws[l].size(0), Ws[l].size(1)):
                 # hidden layer: dgrad + wgrad from one read of (g, y_l, y_{l-1})
                 G, sums, dW = e.mlp_bwd_fused(ys[l], consts, Ws[l].contiguous(), ys[l - 1], fins[l - 1], gmode,
-                                              G=G, arg=arg, gP=gPm, ns=ns)
+                                              G=G, arg=arg, gP=gPm, ns=ns, sums=sums_in[l], dW=dWs[l])
                 grads[3 * l] = dW.view(ctx.shapes[l])
                 gmode, arg, gPm = e.PRO_GY, None, None
                 continue
             act = x if l == 0 else ys[l - 1]
             dW = e.mlp_wgrad(ys[l], consts, act, gmode, e.PRO_NONE if l == 0 else e.PRO_BNRELU,
-                             G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1])
+                             G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1], dW=dWs[l])
             grads[3 * l] = dW.view(ctx.shapes[l])
             need_dgrad = l > 0 or (ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None))
             if need_dgrad:
@@ -178,7 +184,7 @@ class _FusedMLP(Function):
                 Wt = Wt.contiguous()
                 p = (consts[0], consts[1], consts[2])
                 if l > 0:
-                    sums = torch.zeros(2, Wt.size(0), dtype=torch.float64, device=x.device)
+                    sums = sums_in[l]
                     Gn = e.mlp_gemm(G, Wt, pro=gmode, epi=e.EPI_MASK, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns,
                                     stats=sums, Yprev=ys[l - 1], e_fin=fins[l - 1], M=M)
                     G, gmode, arg, gPm = Gn, e.PRO_GY, None, None

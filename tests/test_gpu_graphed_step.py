@@ -37,7 +37,7 @@ def test_replayed_gradients_equal_eager_backward_for_two_scan_shapes():
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=0.0)                 # weights frozen: every call must reproduce the eager gradient
     stepper = GraphedTrainStep(model.pure_training_step, params, opt)
-    scans = [to_device(synthetic_scan(n, 1024, 2048, seed=s), "cuda") for n, s in ((5, 1), (6, 2), (5, 3), (6, 4), (5, 5), (6, 6))]
+    scans = [to_device(synthetic_scan(n, 512, 1024, seed=s), "cuda") for n, s in ((9, 1), (10, 2), (9, 3), (10, 4), (9, 5), (10, 6))]   # >= 9 nodes: the GCN BatchNorms over nodes stay well conditioned
     for i, scan in enumerate(scans):
         loss, rel_pred = stepper(scan)
         wants = []
