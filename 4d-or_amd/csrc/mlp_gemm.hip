@@ -397,6 +397,7 @@ struct WgradArgs {
   float *dW;         // [N][K], accumulated with atomics (caller zero-fills)
   long long M, rows_per_wg;
   int N, K, ns, gmode /* PRO_GY | PRO_POOLG */, amode /* PRO_NONE | PRO_BNRELU */;
+  int koff;          // leading activation columns (<= 3) reduced on the VALU side, MFMA part = columns [koff, K)
 };
 
 
@@ -409,7 +410,11 @@ constexpr int WMAXN = 320;    // 10 n-tiles
 // KT = 32-column k-tiles per workgroup column block (4 -> 128 K-columns; 2 for K <= 64 so that all
 // eight waves — and all four SIMDs — own useful output tiles): wave w owns k-tile w % KT and the
 // n-tiles (w / KT) + (8/KT)*t, t < NTW.
-template <int NTW, int GMODE, int AMODE, int KT>  // n-tiles per wave (total n-tiles <= (8/KT)*NTW)
+// LEAD: the first `koff` (1..3) activation columns — the relative xyz in front of 32k feature columns, K = 3 + 128
+// or 3 + 256 in the first layer of every SA level — are reduced with plain FMAs by the threads that stage gy, so
+// that the MFMA part covers an aligned column range and the ragged K does not cost a second pass over g and y
+// (K = 131: 0.63 -> 0.38 ms at M = 1M).
+template <int NTW, int GMODE, int AMODE, int KT, bool LEAD = false>  // n-tiles per wave (total n-tiles <= (8/KT)*NTW)
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   // rows per LDS tile: 32; 16 for the wide variants, whose two-deep ring of 32-row gy tiles (2 x 2 x 16..32
   // registers) plus 64-80 accumulators does not fit the register file (64 for the narrow ones: no gain)
@@ -419,13 +424,16 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   constexpr int GN = NPARS * NTW * 32;
   __shared__ float Gs[WR * GN];
   __shared__ float Xs[WR * WKB];
+  __shared__ __attribute__((aligned(16))) float Xz[LEAD ? WR * 4 : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int ktile = wave % KT;
   const int npar = wave / KT;
-  const int kb0 = blockIdx.y * WKB;
+  const int koff = LEAD ? a.koff : 0;
+  const int kb0 = koff + blockIdx.y * WKB;
+  const bool lead_blk = LEAD && blockIdx.y == 0;   // one column block also reduces the leading columns
   const int N = a.N, K = a.K;
   const long long M = a.M;
   const long long row_begin = (long long)blockIdx.x * a.rows_per_wg;
@@ -473,10 +481,15 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   float rg0[RGN], ry0[GPT], rx0[XPT], pg0[WPG];
   float rg1[RGN], ry1[GPT], rx1[XPT], pg1[WPG];
   int pa0[WPG], pa1[WPG];
+  float rz0 = 0.f, rz1 = 0.f;                      // LEAD: one element of the WR x koff leading block per thread
+  float lead_acc[LEAD ? 3 : 1];
+#pragma unroll
+  for (int c = 0; c < (LEAD ? 3 : 1); ++c) lead_acc[c] = 0.f;
+  const int zr = tid >> 2, zc = tid & 3;           // (row, column) of that element
   long long l_rt = row_begin;     // next tile to load (clamped to the last tile past the end)
   long long s_rt = row_begin;     // next tile to write to LDS
 
-  auto load_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG]) {
+  auto load_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG], float &rz) {
     const long long rt = l_rt;
     const rsrc_t rsy = make_rsrc(a.Yl + (size_t)rt * N, (M - rt) * N * 4);
 #pragma unroll
@@ -498,12 +511,13 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     const rsrc_t rsx = make_rsrc(a.X + (size_t)rt * K, (M - rt) * K * 4);
 #pragma unroll
     for (int i = 0; i < XPT; ++i) rx[i] = bload(rsx, xoff, i * xpass);
+    if (LEAD) rz = bload(rsx, (zr < WR && zc < koff) ? (zr * K + zc) * 4 : kOobOffset, 0);
     const long long nt = rt + WR;
     l_rt = nt < row_end ? nt : last_rt;
   };
 
   long long p_rt = row_begin;
-  auto store_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT]) {
+  auto store_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], float rz) {
     const long long rt = s_rt;
     p_rt = rt;
     if (tid < GRP * GN) {
@@ -529,6 +543,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) Xs[(xr0 + XRP * i) * WKB + xk] = xv[i];
+    if (LEAD && tid < WR * 4) Xz[tid] = rz;        // rows past M arrive as zeros (out of range)
     s_rt += WR;
   };
 
@@ -545,14 +560,29 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     }
   };
 
-  auto iteration = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG]) {
-    store_tile(rg, ry, rx);          // tile t (loaded two iterations ago) -> LDS
+  auto iteration = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG], float &rz) {
+    store_tile(rg, ry, rx, rz);      // tile t (loaded two iterations ago) -> LDS
     if (POOL) {
       __syncthreads();
       patch_tile(pa, pg);
     }
     __syncthreads();
-    load_tile(rg, ry, rx, pa, pg);   // tile t+2 into the registers just freed
+    load_tile(rg, ry, rx, pa, pg, rz);   // tile t+2 into the registers just freed
+    if (lead_blk && tid < GRP * GN) {
+      // leading columns: this thread's gy elements (column gn, rows gr0 + GRP*i, patched values from LDS).
+      // Deliberately a rolled loop: unrolled, its hoisted LDS reads cost 60 VGPRs and the second workgroup per CU.
+#pragma unroll 1
+      for (int i = 0; i < GPT; ++i) {
+        const int r = gr0 + GRP * i;
+        if (r < WR) {
+          const float g = Gs[r * GN + gn];
+          const float4 xz = *reinterpret_cast<const float4 *>(&Xz[LEAD ? r * 4 : 0]);
+          lead_acc[0] = __fmaf_rn(g, xz.x, lead_acc[0]);
+          lead_acc[LEAD ? 1 : 0] = __fmaf_rn(g, xz.y, lead_acc[LEAD ? 1 : 0]);
+          lead_acc[LEAD ? 2 : 0] = __fmaf_rn(g, xz.z, lead_acc[LEAD ? 2 : 0]);
+        }
+      }
+    }
     // A operand: A[i = n][k = r] = gy[r][n];  B operand: B[k = r][j = kcol] = act[r][kcol]
 #pragma unroll
     for (int s = 0; s < WR / 2; ++s) {
@@ -567,14 +597,19 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     __syncthreads();
   };
 
-  load_tile(rg0, ry0, rx0, pa0, pg0);
-  load_tile(rg1, ry1, rx1, pa1, pg1);
+  load_tile(rg0, ry0, rx0, pa0, pg0, rz0);
+  load_tile(rg1, ry1, rx1, pa1, pg1, rz1);
   // single-exit pair loop + peeled odd tile (see mlp_gemm_kernel)
   for (long long pair = ntile >> 1; pair > 0; --pair) {
-    iteration(rg0, ry0, rx0, pa0, pg0);
-    iteration(rg1, ry1, rx1, pa1, pg1);
+    iteration(rg0, ry0, rx0, pa0, pg0, rz0);
+    iteration(rg1, ry1, rx1, pa1, pg1, rz1);
   }
-  if (ntile & 1) iteration(rg0, ry0, rx0, pa0, pg0);
+  if (ntile & 1) iteration(rg0, ry0, rx0, pa0, pg0, rz0);
+  if (lead_blk && g_thr) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (c < koff) atomicAdd(a.dW + (size_t)gn * K + c, lead_acc[LEAD ? c : 0]);
+  }
   // ---- flush: acc[t][reg] = dW[n = ntile*32 + rowmap][k = kb0 + ktile*32 + (lane&31)] ----
   const int kcol = kb0 + ktile * 32 + (lane & 31);
 #pragma unroll
@@ -866,7 +901,13 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
   // two k-tiles only pay when there are enough n-tiles to keep four wave groups busy (measured:
   // N=128,K=64 1.48 -> 1.14 ms; N=64,K=64 0.86 -> 1.06 ms because the gy tile would be staged 128 wide)
   const int kt = (K <= 64 && N > 64) ? 2 : 4;
-  const unsigned kblocks = (unsigned)((K + 32 * kt - 1) / (32 * kt));
+  // K = 32j + (1..3) raw-input columns (relative xyz in front of the features): reduce the leading columns on the
+  // VALU side and give the MFMA part the aligned rest, instead of a whole extra pass over g and y for 3 columns
+  // (measured: K = 131, M = 1M 0.79 -> 0.55 ms; K = 259, M = 256k 0.31 -> 0.28; below that the extra pass is cheaper)
+  const int koff = (amode == PRO_NONE && kt == 4 && K > 32 && K % 32 >= 1 && K % 32 <= 3 && M >= (1 << 18) &&
+                    !getenv("PN2_WGRAD_NOLEAD")) ? K % 32 : 0;
+  a.koff = koff;
+  const unsigned kblocks = (unsigned)((K - koff + 32 * kt - 1) / (32 * kt));
   long long wgs = 512 / kblocks;
   if (wgs < 1) wgs = 1;
   long long rows = (M + wgs - 1) / wgs;
@@ -887,7 +928,19 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
     else                                                                                               \
       hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_POOLG, PRO_BNRELU, KT>), grid, dim3(512), 0, s, a);\
   } while (0)
-  if (kt == 2) {          // four n-groups of waves
+#define PN2_WGRAD_LEAD(NTW)                                                                              \
+  do {                                                                                                 \
+    if (gmode == PRO_GY)                                                                               \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_GY, PRO_NONE, 4, true>), grid, dim3(512), 0, s, a);    \
+    else                                                                                               \
+      hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_POOLG, PRO_NONE, 4, true>), grid, dim3(512), 0, s, a); \
+  } while (0)
+  if (koff) {
+    if (ntiles <= 2) PN2_WGRAD_LEAD(1);
+    else if (ntiles <= 4) PN2_WGRAD_LEAD(2);
+    else if (ntiles <= 8) PN2_WGRAD_LEAD(4);
+    else PN2_WGRAD_LEAD(5);
+  } else if (kt == 2) {          // four n-groups of waves
     if (ntiles <= 4) PN2_WGRAD(1, 2);
     else if (ntiles <= 8) PN2_WGRAD(2, 2);
     else PN2_WGRAD(3, 2);
@@ -898,6 +951,7 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
     else PN2_WGRAD(5, 4);
   }
 #undef PN2_WGRAD
+#undef PN2_WGRAD_LEAD
   return pn2_check_launch();
 }
 

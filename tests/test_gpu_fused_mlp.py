@@ -47,7 +47,9 @@ CASES = [((6, 64, 64, 128), 64 * 40, 64), ((131, 128, 128, 256), 32 * 50, 32), (
          ((259, 256, 256), 3 * 128, 128),
          # hidden layers on the one-pass backward kernel (csrc/mlp_bwd_fused.hip) with ragged N / K and a partial
          # last row tile, pooled (ns = 16) and unpooled
-         ((20, 72, 96, 100), 16 * 37, 16), ((30, 48, 120, 64), 777, 0), ((7, 128, 40, 128, 128), 32 * 33, 32)]
+         ((20, 72, 96, 100), 16 * 37, 16), ((30, 48, 120, 64), 777, 0), ((7, 128, 40, 128, 128), 32 * 33, 32),
+         # first-layer wgrad with the three leading xyz columns reduced on the VALU side (needs M >= 2^18)
+         ((131, 128, 64), 8192 * 32 + 64, 32), ((258, 64, 64), 1 << 18, 0)]
 
 
 @pytest.mark.parametrize("train", [True, False])
@@ -59,10 +61,16 @@ def test_fused_matches_torch(spec, M, ns, train):
     o0, gx0, gp0, sd0 = _run(mlp, x, ns, fused=False, train=train)
     o1, gx1, gp1, sd1 = _run(mlp, x, ns, fused=True, train=train)
     torch.testing.assert_close(o1, o0, atol=1e-4, rtol=1e-4)
-    torch.testing.assert_close(gx1, gx0, atol=1e-4, rtol=1e-3)
+    if M >= (1 << 17):
+        # tens of millions of pre-activations: a handful sit within rounding of the ReLU threshold and flip their
+        # mask between two implementations (O(1) differences in single elements) — compare in norm
+        assert float((gx1 - gx0).norm() / gx0.norm()) < 2e-3
+    else:
+        torch.testing.assert_close(gx1, gx0, atol=1e-4, rtol=1e-3)
     for a, b in zip(gp1, gp0):
         scale = float(b.abs().max()) + 1e-6
-        assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-5, (a - b).abs().max()
+        tol = 5e-3 if M >= (1 << 17) else 2e-4           # large M: the mask flips above also move the sums
+        assert float((a - b).abs().max()) <= tol * scale + 1e-5, (a - b).abs().max()
     for k in sd0:
         torch.testing.assert_close(sd1[k].float(), sd0[k].float(), atol=1e-5, rtol=1e-4)
 
