@@ -684,28 +684,48 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(size_t total, int N,
   }
 }
 
+constexpr int kPrepRows = 16;   // rows per block of the two backward-prep kernels
+
 // g_pre = g_out * [relu(bn(y)) > 0];  sums: dbeta += g_pre, dgamma += g_pre * yhat
 __global__ __launch_bounds__(256) void bn_relu_bwd_prep_kernel(long long M, int N, const float *__restrict__ y,
                                                               const float *__restrict__ gout,
                                                               const float *__restrict__ fin,
                                                               float *__restrict__ gpre, double *__restrict__ sums) {
-  // block handles 64 rows x all columns; thread t walks columns t, t+256, ...
-  const long long r0 = (long long)blockIdx.x * 64;
-  for (int c = threadIdx.x; c < N; c += 256) {
-    const float mean = fin[c], rstd = fin[N + c], sc = fin[2 * N + c], sh = fin[3 * N + c];
+  // block = kPrepRows rows x all columns; with N < 256 the 256 threads split into 256/N row groups that are
+  // pre-reduced through LDS.  The kernel is latency bound (a thread's rows are a serial chain): measured
+  // 64 rows/block 0.28 ms/step, 256 rows 0.79, 16 rows 0.25 — more, smaller blocks win despite 4x the fp64 atomics.
+  __shared__ float part[2][256];
+  const long long r0 = (long long)blockIdx.x * kPrepRows;
+  const int cw = N < 256 ? N : 256;              // columns per pass
+  const int groups = 256 / cw;                   // >= 1
+  const int grp = threadIdx.x / cw;
+  const bool active = grp < groups;
+  for (int c0 = 0; c0 < N; c0 += cw) {
+    const int c = c0 + threadIdx.x - grp * cw;
     float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < 64; ++r) {
-      const long long row = r0 + r;
-      if (row >= M) break;
-      const size_t off = (size_t)row * N + c;
-      const float yy = y[off];
-      const float g = (__fmaf_rn(yy, sc, sh) > 0.f) ? gout[off] : 0.f;
-      gpre[off] = g;
-      s1 += g;
-      s2 = __fmaf_rn(g, (yy - mean) * rstd, s2);
+    if (active && c < N) {
+      const float mean = fin[c], rstd = fin[N + c], sc = fin[2 * N + c], sh = fin[3 * N + c];
+#pragma unroll 4
+      for (int r = grp; r < kPrepRows; r += groups) {
+        const long long row = r0 + r;
+        if (row >= M) break;
+        const size_t off = (size_t)row * N + c;
+        const float yy = y[off];
+        const float g = (__fmaf_rn(yy, sc, sh) > 0.f) ? gout[off] : 0.f;
+        gpre[off] = g;
+        s1 += g;
+        s2 = __fmaf_rn(g, (yy - mean) * rstd, s2);
+      }
     }
-    atomicAdd(sums + c, (double)s1);
-    atomicAdd(sums + N + c, (double)s2);
+    part[0][threadIdx.x] = s1;
+    part[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (grp == 0 && c < N) {
+      for (int q = 1; q < groups; ++q) { s1 += part[0][threadIdx.x + q * cw]; s2 += part[1][threadIdx.x + q * cw]; }
+      atomicAdd(sums + c, (double)s1);
+      atomicAdd(sums + N + c, (double)s2);
+    }
+    __syncthreads();
   }
 }
 
@@ -764,21 +784,37 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int C, 
                                                            const float *__restrict__ gP,
                                                            const float *__restrict__ fin,
                                                            float *__restrict__ gPm, double *__restrict__ sums) {
-  const long long r0 = (long long)blockIdx.x * 64;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float mean = fin[c], rstd = fin[C + c];
+  __shared__ float part[2][256];                 // see bn_relu_bwd_prep_kernel
+  const long long r0 = (long long)blockIdx.x * kPrepRows;
+  const int cw = C < 256 ? C : 256;
+  const int groups = 256 / cw;
+  const int grp = threadIdx.x / cw;
+  const bool active = grp < groups;
+  for (int c0 = 0; c0 < C; c0 += cw) {
+    const int c = c0 + threadIdx.x - grp * cw;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < 64; ++i) {
-      const long long r = r0 + i;
-      if (r >= R) break;
-      const size_t off = (size_t)r * C + c;
-      const float g = pooled[off] > 0.f ? gP[off] : 0.f;
-      gPm[off] = g;
-      s1 += g;
-      s2 = __fmaf_rn(g, (yraw[off] - mean) * rstd, s2);
+    if (active && c < C) {
+      const float mean = fin[c], rstd = fin[C + c];
+#pragma unroll 4
+      for (int i = grp; i < kPrepRows; i += groups) {
+        const long long r = r0 + i;
+        if (r >= R) break;
+        const size_t off = (size_t)r * C + c;
+        const float g = pooled[off] > 0.f ? gP[off] : 0.f;
+        gPm[off] = g;
+        s1 += g;
+        s2 = __fmaf_rn(g, (yraw[off] - mean) * rstd, s2);
+      }
     }
-    atomicAdd(sums + c, (double)s1);
-    atomicAdd(sums + C + c, (double)s2);
+    part[0][threadIdx.x] = s1;
+    part[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+      for (int q = 1; q < groups; ++q) { s1 += part[0][threadIdx.x + q * cw]; s2 += part[1][threadIdx.x + q * cw]; }
+      atomicAdd(sums + c, (double)s1);
+      atomicAdd(sums + C + c, (double)s2);
+    }
+    __syncthreads();
   }
 }
 
@@ -991,7 +1027,7 @@ extern "C" int pn2_bn_relu_bwd_prep(long long M, int N, const float *y, const fl
   if (M < 0 || N <= 0) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!y || !gout || !fin || !gpre || !sums) return PN2_ENULL;
-  hipLaunchKernelGGL(bn_relu_bwd_prep_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0,
+  hipLaunchKernelGGL(bn_relu_bwd_prep_kernel, dim3((unsigned)((M + kPrepRows - 1) / kPrepRows)), dim3(256), 0,
                      (hipStream_t)stream, M, N, y, gout, fin, gpre, sums);
   return pn2_check_launch();
 }
@@ -1019,7 +1055,7 @@ extern "C" int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const fl
   if (R < 0 || C <= 0) return PN2_EINVAL;
   if (R == 0) return PN2_OK;
   if (!yraw || !pooled || !gP || !fin || !gPm || !sums) return PN2_ENULL;
-  hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0,
+  hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3((unsigned)((R + kPrepRows - 1) / kPrepRows)), dim3(256), 0,
                      (hipStream_t)stream, R, C, yraw, pooled, gP, fin, gPm, sums);
   return pn2_check_launch();
 }
