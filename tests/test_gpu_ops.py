@@ -31,7 +31,8 @@ def clouds(B, N, kind, seed):
 # every resident-kernel template, the streaming kernel, tiny and non-power-of-two sizes
 FPS_CASES = [(3, 1, 1), (2, 5, 5), (2, 37, 40), (3, 100, 30), (2, 255, 64), (2, 256, 64), (2, 511, 100),
              (3, 512, 128), (2, 1000, 128), (2, 1024, 256), (2, 2048, 512), (2, 4000, 512), (2, 4096, 64),
-             (2, 8000, 512), (1, 16384, 300), (1, 20000, 256), (1, 24576, 64), (2, 30000, 200)]
+             (2, 8000, 512), (1, 16384, 300), (1, 20000, 256), (1, 24576, 64), (2, 30000, 200),
+             (1, 123457, 96)]      # one whole-room cloud (the shape of compute_instance_labels.py:95,195): 16-workgroup cluster
 
 
 @pytest.mark.parametrize("B,N,m", FPS_CASES)
