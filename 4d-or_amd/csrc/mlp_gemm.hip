@@ -936,7 +936,11 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
   // persistent-style: ~2 workgroups per CU, each a contiguous slab of rows (multiple of WR)
   // two k-tiles only pay when there are enough n-tiles to keep four wave groups busy (measured:
   // N=128,K=64 1.48 -> 1.14 ms; N=64,K=64 0.86 -> 1.06 ms because the gy tile would be staged 128 wide)
-  const int kt = (K <= 64 && N > 64) ? 2 : 4;
+  // N > 256 (9-10 n-tiles): four wave groups x 3 tiles (139-160 VGPRs) instead of two x 5 (197).  The 5-tile variant
+  // cannot share a CU with a workgroup of the cooperative FPS kernel that the geometry prefetch keeps resident on every
+  // CU — as the first kernel of the backward it waited 1.6 ms for the FPS to end (kernel-trace timeline) — and capping
+  // its registers spills (0.13 -> 1.6 ms).  The price is 64-column K blocks, i.e. more passes over a SMALL gy.
+  const int kt = ((K <= 64 && N > 64) || N > 256) ? 2 : 4;
   // K = 32j + (1..3) raw-input columns (relative xyz in front of the features): reduce the leading columns on the
   // VALU side and give the MFMA part the aligned rest, instead of a whole extra pass over g and y for 3 columns
   // (measured: K = 131, M = 1M 0.79 -> 0.55 ms; K = 259, M = 256k 0.31 -> 0.28; below that the extra pass is cheaper)
