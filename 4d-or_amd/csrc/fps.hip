@@ -353,6 +353,56 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
 
   for (int j = 1; j < m; ++j) {
     // ---- scan + wave arg-max of every cloud, winners into this round's LDS slots ----
+    if constexpr (NC == 1) {
+      // One cloud per cluster (the default): the scan only tracks the lane's largest running distance (v_max);
+      // WHICH slot holds it, its rank and its coordinates are worked out once per wave on the scalar unit from
+      // readlanes of the winning lane.  ~140 VALU instructions per round instead of ~230 (per-point compare +
+      // two selects, 64-bit key reduction, 3*PPT-select coordinate chain).  The FPS co-runs with the MFMA kernels of
+      // the training step and fp32 VALU time is exactly what it takes away from them.
+      float best = -1.f;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const float d = pn2_sq3(px[i] - ox[0], py[i] - oy[0], pz[i] - oz[0]);
+        const float d2 = fps_min(d, td[i]);
+        td[i] = d2;
+        best = fmaxf(best, d2);
+      }
+      const unsigned hi = best >= 0.f ? __float_as_uint(best) + 1u : 0u;
+      const unsigned whi = pn2_wave_max_u32(hi);                  // wave-uniform
+      // (threadIdx-derived values are divergent to the compiler even when they are not: without the readfirstlane
+      // the whole resolution below is compiled with exec masks and v_readfirstlane waterfalls)
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+      u64 wmax = 0ull;
+      float sx = p0x[0], sy = p0y[0], sz = p0z[0];
+      if (whi != 0u) {
+        const unsigned target = whi - 1u;                         // bits of the wave's largest distance
+        u64 tied = __ballot(hi == whi);                           // usually exactly one lane
+        unsigned best_lo = 0u;
+        int wl = 0, wbi = 0;
+        while (tied) {                                            // scalar loop over the tied lanes
+          const int l = __ffsll((long long)tied) - 1;
+          tied &= tied - 1;
+          int bi = 0;
+#pragma unroll
+          for (int i = PPT - 1; i >= 0; --i)                      // first (smallest k) slot holding the maximum
+            bi = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(td[i]), l) == target ? i : bi;
+          const unsigned k = (unsigned)(g * BS + wave_u * 64 + l + bi * kstride);
+          const unsigned lo = ~fps_rank(k, L);
+          if (lo >= best_lo) { best_lo = lo; wl = l; wbi = bi; }  // keys are unique: '>' or first
+        }
+        wmax = ((u64)whi << 32) | best_lo;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+          if (wbi == i) {                                         // wave-uniform: a scalar branch
+            sx = pn2_readlane_f32(px[i], wl); sy = pn2_readlane_f32(py[i], wl); sz = pn2_readlane_f32(pz[i], wl);
+          }
+        }
+      }
+      if (lane == 0) {
+        FpsSlot &sl = lds_slots[j & 1][0][wave];
+        sl.packed = wmax; sl.x = sx; sl.y = sy; sl.z = sz;
+      }
+    } else {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       float best = -1.f;
@@ -386,6 +436,7 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
         FpsSlot &sl = lds_slots[j & 1][c][wave];
         sl.packed = wmax; sl.x = sx; sl.y = sy; sl.z = sz;
       }
+    }
     }
     __syncthreads();
 
