@@ -360,12 +360,27 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
       // two selects, 64-bit key reduction, 3*PPT-select coordinate chain).  The FPS co-runs with the MFMA kernels of
       // the training step and fp32 VALU time is exactly what it takes away from them.
       float best = -1.f;
+      if constexpr (PPT % 2 == 0) {
+        // two points per packed instruction (v_pk_add/mul/fma_f32): the same IEEE operations in the same order as
+        // pn2_sq3 — fma(dz, dz, fma(dx, dx, dy * dy)) — on both halves
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 o2x = {ox[0], ox[0]}, o2y = {oy[0], oy[0]}, o2z = {oz[0], oz[0]};
 #pragma unroll
-      for (int i = 0; i < PPT; ++i) {
-        const float d = pn2_sq3(px[i] - ox[0], py[i] - oy[0], pz[i] - oz[0]);
-        const float d2 = fps_min(d, td[i]);
-        td[i] = d2;
-        best = fmaxf(best, d2);
+        for (int i = 0; i < PPT; i += 2) {
+          const f2 dx = f2{px[i], px[i + 1]} - o2x, dy = f2{py[i], py[i + 1]} - o2y, dz = f2{pz[i], pz[i + 1]} - o2z;
+          const f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+          const float a = fps_min(d.x, td[i]), b = fps_min(d.y, td[i + 1]);
+          td[i] = a; td[i + 1] = b;
+          best = fmaxf(best, fmaxf(a, b));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+          const float d = pn2_sq3(px[i] - ox[0], py[i] - oy[0], pz[i] - oz[0]);
+          const float d2 = fps_min(d, td[i]);
+          td[i] = d2;
+          best = fmaxf(best, d2);
+        }
       }
       const unsigned hi = best >= 0.f ? __float_as_uint(best) + 1u : 0u;
       const unsigned whi = pn2_wave_max_u32(hi);                  // wave-uniform
