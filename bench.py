@@ -432,6 +432,11 @@ def main():
         if serial_rows is not None:
             keep = ("kernel", "calls_per_step", "ms_per_step", "avg_launch_us", "GBps", "TFLOPps", "bound", "frac")
             out["kernels_without_geometry_pipeline"] = [{k: r[k] for k in keep} for r in serial_rows]
+            mlp_rows = [r for r in serial_rows if r["kernel"].startswith("pn2_mlp_")]
+            if mlp_rows:
+                # the same dominant kernel measured without the co-running prefetch stream: what the kernel itself achieves
+                top = max(mlp_rows, key=lambda r: r["ms_per_step"])
+                out["roofline_without_geometry_pipeline"] = {k: v for k, v in roofline_of(top).items() if k != "note"}
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 64)
             try:
