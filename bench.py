@@ -356,16 +356,16 @@ def main():
             run_steps(net, model, opt, pc, 2, None)
             _ext.TIMER = None
             serial_rows = kernel_table(st.summary(), 2)
-        run_steps(net, model, opt, pc, 1, prefetcher)       # back to the pipelined steady state
+        run_steps(net, model, opt, pc, 2, prefetcher)       # back to the pipelined steady state
         torch.cuda.synchronize()
 
-    # per-kernel HIP events are sampled on every 4th timed step (two event records per launch would
-    # otherwise cost ~5 % of the step); the table is normalised by the number of sampled steps
+    # per-kernel HIP events are sampled on two of the timed steps (two event records per launch cost ~1.2 ms on a
+    # step that is timed throughout); the table is normalised by the number of sampled steps
     timer, sampled_steps, on_step = None, 0, None
     if not args.no_kernel_timing:
         timer = _ext.KernelTimer(main_stream)
         _ext.TIMER = timer
-        stride = 4 if args.steps >= 8 else 1
+        stride = max(4, args.steps // 2) if args.steps >= 8 else 1      # two sampled steps for the default K = 10
         sampled_steps = len(range(0, args.steps, stride))
 
         def on_step(i):
