@@ -160,10 +160,22 @@ class _PointnetSAModuleBase(nn.Module):
         picked = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), sel)
         return picked.transpose(1, 2).contiguous()
 
-    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor]
+    def sample_and_query(self, xyz: torch.Tensor):
+        """The data-only part of the module (no parameters, no features): sampled centres and the ball-query
+        neighbourhoods of every scale.  A training loop that already holds the next clouds can run this on a side
+        stream while the current ones train and pass the result as `geometry=` (identical results)."""
+        new_xyz = self._sample(xyz)
+        idx = [g.query(xyz, new_xyz) if (new_xyz is not None and isinstance(g, pointnet2_utils.QueryAndGroup)) else None
+               for g in self.groupers]
+        return {"new_xyz": new_xyz, "idx": idx}
+
+    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor], geometry=None
                 ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
         """xyz (B,N,3), features (B,C,N)|None ->
-        (new_xyz (B,npoint,3)|None, new_features (B, sum_k mlps[k][-1], npoint))."""
+        (new_xyz (B,npoint,3)|None, new_features (B, sum_k mlps[k][-1], npoint)).
+        `geometry` = sample_and_query(xyz) computed earlier (optional; rows path only)."""
+        if geometry is not None and _rows_path_ok(xyz, features):
+            return geometry["new_xyz"], self._forward_rows(xyz, geometry["new_xyz"], features, geometry["idx"])
         new_xyz = self._sample(xyz)
         if _rows_path_ok(xyz, features):
             return new_xyz, self._forward_rows(xyz, new_xyz, features)
@@ -175,12 +187,13 @@ class _PointnetSAModuleBase(nn.Module):
             pooled.append(g.squeeze(-1))
         return new_xyz, torch.cat(pooled, dim=1)
 
-    def _forward_rows(self, xyz, new_xyz, features):
+    def _forward_rows(self, xyz, new_xyz, features, idx=None):
         feats_rows = pointnet2_utils.as_rows(features)
         B = xyz.size(0)
         pooled = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            pooled.append(sa_scale_rows(grouper, mlp, xyz, new_xyz, feats_rows))   # (B, npoint, C_out)
+        for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            pooled.append(sa_scale_rows(grouper, mlp, xyz, new_xyz, feats_rows,
+                                        idx=None if idx is None else idx[k]))        # (B, npoint, C_out)
         rows = pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=2)
         return pointnet2_utils.rows_to_channels(rows)           # (B, sum C_out, npoint) view
 

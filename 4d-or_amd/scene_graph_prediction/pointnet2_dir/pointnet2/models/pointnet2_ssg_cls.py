@@ -37,12 +37,27 @@ class PointNet2ClassificationSSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def forward(self, pointcloud, return_features=False):
-        """pointcloud (B, N, 3 + C), each point (x, y, z, features...) ->
-        (B, C_last, 1) set features if `return_features` else class logits."""
-        xyz, features = self._break_up_pc(pointcloud)
+    def precompute_geometry(self, pointcloud):
+        """The coordinate-only part of the forward (FPS chain + ball queries of every SA level; no parameters):
+        lets a loop prepare the next clouds on a side stream.  Pass the result as `geometry=`."""
+        xyz = pointcloud[..., 0:3].contiguous()
+        geo = []
         for sa in self.SA_modules:
-            xyz, features = sa(xyz, features)
+            g = sa.sample_and_query(xyz)
+            geo.append(g)
+            xyz = g["new_xyz"]
+            if xyz is None:                      # group-all level: nothing below depends on coordinates
+                break
+        return geo
+
+    def forward(self, pointcloud, return_features=False, geometry=None):
+        """pointcloud (B, N, 3 + C), each point (x, y, z, features...) ->
+        (B, C_last, 1) set features if `return_features` else class logits.
+        `geometry` = precompute_geometry(pointcloud) (optional; identical results)."""
+        xyz, features = self._break_up_pc(pointcloud)
+        for i, sa in enumerate(self.SA_modules):
+            g = geometry[i] if geometry is not None and i < len(geometry) else None
+            xyz, features = sa(xyz, features, geometry=g) if g is not None else sa(xyz, features)
         if return_features:
             return features
         return self.fc_layer(features.squeeze(-1))

@@ -14,6 +14,10 @@ class PointNetfeat(nn.Module):
         self.out_size = out_size
         self.input_dropout = input_dropout
 
-    def forward(self, x):
+    def precompute_geometry(self, x):
+        """FPS chain + ball queries of the encoder for the channel-first clouds `x` (see the backbone)."""
+        return self.backbone.precompute_geometry(x.transpose(1, 2))
+
+    def forward(self, x, geometry=None):
         assert x.ndim > 2
-        return self.backbone(x.transpose(1, 2), return_features=True)[:, :, 0]
+        return self.backbone(x.transpose(1, 2), return_features=True, geometry=geometry)[:, :, 0]

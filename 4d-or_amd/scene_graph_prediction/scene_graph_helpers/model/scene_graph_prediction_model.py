@@ -51,9 +51,16 @@ class SGPNModelWrapper(nn.Module):
                                             image_embedding_size=None, n_object_types=self.n_object_types)
 
     # ------------------------------------------------------------------ forward
+    def precompute_geometry(self, batch):
+        """Sampling / grouping geometry of both encoders for `batch` (no parameters involved): a loop that already holds
+        the next scan can run this on a side stream and store the result as batch["geometry"]."""
+        return {"obj": self.obj_encoder.precompute_geometry(batch["obj_points"]),
+                "rel": self.rel_encoder.precompute_geometry(batch["rel_points"])}
+
     def forward(self, batch, return_meta_data=False):
-        obj_feature = self.obj_encoder(batch["obj_points"])
-        rel_feature = self.rel_encoder(batch["rel_points"])
+        geo = batch.get("geometry")
+        obj_feature = self.obj_encoder(batch["obj_points"], geometry=None if geo is None else geo["obj"])
+        rel_feature = self.rel_encoder(batch["rel_points"], geometry=None if geo is None else geo["rel"])
         gcn_obj_feature, gcn_rel_feature = self.gcn(obj_feature, rel_feature, batch["edge_indices"], batch.get("edge_csr"))
         obj_cls = self.obj_predictor(gcn_obj_feature if self.mconfig["OBJ_PRED_FROM_GCN"] else obj_feature)
         rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=batch["relation_objects_one_hot"])

@@ -232,10 +232,33 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
         if distributed:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=64)
 
+        # geometry of the NEXT scan (FPS chains + ball queries of both encoders) on a side stream during this step,
+        # like the backbone workload; the scan-at-a-time loop of the reference knows its next scan from the data loader
+        side = torch.cuda.Stream(device=device) if args.geometry_pipeline else None
+        main = torch.cuda.current_stream(device)
+        state = {"geo": None}
+
+        def launch_geometry():
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                return model.precompute_geometry(scan)
+
         def step():
+            batch = scan
+            if side is not None:
+                if state["geo"] is None:
+                    state["geo"] = launch_geometry()
+                main.wait_stream(side)
+                batch = dict(scan, geometry=state["geo"])
+                for enc in batch["geometry"].values():
+                    for lvl in enc:
+                        for t in [lvl["new_xyz"]] + list(lvl["idx"]):
+                            if t is not None:
+                                t.record_stream(main)
+                state["geo"] = launch_geometry()
             opt.zero_grad(set_to_none=True)
-            obj, rel = net(scan)
-            model.loss(obj, rel, scan).backward()
+            obj, rel = net(batch)
+            model.loss(obj, rel, batch).backward()
             opt.step()
 
     for _ in range(args.warmup):
@@ -268,7 +291,8 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[2] shape: SGPNModelWrapper(no_gt.json), 1 synthetic scan per step "
                                       "and rank, train mode, fwd + weighted NLL + bwd + AdamW",
-                          "parallelism": f"dp{world}", "hip_graphs": bool(args.graphs)}}
+                          "parallelism": f"dp{world}", "hip_graphs": bool(args.graphs),
+                          "geometry_pipeline": bool(args.geometry_pipeline and not args.graphs)}}
         if timer is not None:
             rows = [{"kernel": k, "calls_per_step": d["calls"] / args.steps, "ms_per_step": round(d["ms"] / args.steps, 4)}
                     for k, d in timer.summary().items()]

@@ -147,3 +147,25 @@ def test_runner_emits_scan_relations_wire_format(tmp_path):
     for triples in data.values():
         for sub, pred, obj in triples:
             assert pred in runner.RELATION_NAMES and pred != "none" and isinstance(sub, str) and isinstance(obj, str)
+
+
+def test_scene_graph_model_with_prefetched_geometry_is_identical():
+    """SGPNModelWrapper.precompute_geometry (both MSG encoders) + batch["geometry"] == plain forward, bit for bit."""
+    from scene_graph_prediction.main import RELATION_NAMES, config_loader
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import synthetic_scan, to_device
+    from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+    torch.manual_seed(0)
+    cfg = config_loader("no_gt.json")
+    model = SGPNModelWrapper(cfg, 12, len(RELATION_NAMES), torch.ones(12), torch.ones(len(RELATION_NAMES)),
+                             RELATION_NAMES).cuda().eval()
+    scan = to_device(synthetic_scan(4, 1024, 2048, seed=3), "cuda")
+    with torch.no_grad():
+        ref = model(scan)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            geo = model.precompute_geometry(scan)
+        torch.cuda.current_stream().wait_stream(side)
+        got = model(dict(scan, geometry=geo))
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
