@@ -56,10 +56,42 @@ def synthetic_scenes(batch, points, seed, device):
     return torch.cat([p, rgb], dim=2).contiguous().to(device)
 
 
-def build_model(device):
-    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+class ObjectEncoderWorkload(torch.nn.Module):
+    """Stack 2a of SURVEY.md §8d: the scene-graph model's MSG object encoder (`PointNetfeat`: SA 512/[0.1,0.2]/[16,32],
+    128/[0.2,0.4]/[32,64], group-all) on the same 32 x 50k x (3+3) batch, behind the backbone's bench interface."""
+
+    def __init__(self):
+        super().__init__()
+        from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet2 import PointNetfeat
+        self.enc = PointNetfeat(input_dim=6, out_size=256)
+        for n, p in self.enc.named_parameters():
+            if n.startswith("backbone.fc_layer."):     # inherited classification head, never used (SURVEY.md §5)
+                p.requires_grad_(False)
+
+    def precompute_geometry(self, pc):
+        return self.enc.precompute_geometry(pc.transpose(1, 2))
+
+    def forward(self, pc, geometry=None):
+        return {"fp2_features": self.enc(pc.transpose(1, 2), geometry=geometry)}
+
+
+def build_model(device, workload="backbone"):
     torch.manual_seed(0)
+    if workload == "encoder":
+        return ObjectEncoderWorkload().to(device)
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
     return Pointnet2Backbone(input_feature_dim=3).to(device)
+
+
+def record_stream_tree(obj, stream):
+    if torch.is_tensor(obj):
+        obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            record_stream_tree(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            record_stream_tree(v, stream)
 
 
 def train_step(model, opt, pc, geometry=None, between=None):
@@ -92,12 +124,7 @@ class GeometryPrefetcher:
 
     def acquire(self, geo):
         self.main.wait_stream(self.side)
-        for part in geo["sa"]:
-            for t in part.values():
-                t.record_stream(self.main)
-        for idx, w in geo["fp"]:
-            idx.record_stream(self.main)
-            w.record_stream(self.main)
+        record_stream_tree(geo, self.main)
         return geo
 
 
@@ -124,6 +151,29 @@ def run_steps(net, backbone, opt, pc, steps, prefetcher, on_step=None):
     prefetcher.acquire(geo)
 
 
+def forward_only(net, backbone, pc, steps, prefetcher):
+    """Forward-only figure asked for beside the headline: the same train-mode forward (batch
+    statistics) without autograd, geometry prefetched like the timed steps when the pipeline is on."""
+    def run(k):
+        with torch.no_grad():
+            if prefetcher is None:
+                for _ in range(k):
+                    net(pc)
+                return
+            geo = prefetcher.launch(pc)
+            for _ in range(k):
+                cur = prefetcher.acquire(geo)
+                geo = prefetcher.launch(pc)
+                net(pc, geometry=cur)
+            prefetcher.acquire(geo)
+    run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 def kernel_table(table, steps):
     """Per-entry-point rows from a KernelTimer summary, sorted by time."""
     rows = []
@@ -147,8 +197,9 @@ def kernel_table(table, steps):
     return rows
 
 
-def roofline_of(top):
-    """`roofline` object for the dominant critical-path kernel row."""
+def roofline_of(top, pmc_applies=True):
+    """`roofline` object for the dominant critical-path kernel row (`pmc_applies`: the committed PMC traffic was
+    collected on the default command — backbone workload, 32 x 50k — and is quoted for that command only)."""
     if top["bound"] == "mfma":
         roof = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["TFLOPps"],
                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac"]}
@@ -162,7 +213,7 @@ def roofline_of(top):
              "pn2_bn_relu_rows_max": "bn_relu_rows_max_kernel",
              "pn2_group_concat_rows": "group_concat_rows_kernel",
              "pn2_group_rows_grad": "group_rows_grad_kernel"}.get(top["kernel"])
-    if kname and os.path.exists(tf):
+    if pmc_applies and kname and os.path.exists(tf):
         try:
             rec = json.load(open(tf))["kernels"].get(kname)
             if rec:
@@ -181,7 +232,7 @@ def roofline_of(top):
     return roof
 
 
-def cpu_baseline(points, sample_scenes, threads):
+def cpu_baseline(points, sample_scenes, threads, workload="backbone"):
     """Same stack, same step, on the host: oracle port (C/OpenMP restatement of the nine
     native ops) + stock-torch CPU MLPs.  Bounded sample; reported, never optimised."""
     from pointnet2_ops import pointnet2_utils as pu
@@ -190,7 +241,7 @@ def cpu_baseline(points, sample_scenes, threads):
     saved = pu._ext
     pu._ext = oracle_ext.OracleRowsExt
     try:
-        model = build_model("cpu")
+        model = build_model("cpu", workload)
         opt = torch.optim.AdamW(model.parameters(), lr=3e-5, weight_decay=1e-3)
         pc = synthetic_scenes(sample_scenes, points, seed=1234, device="cpu")
         t0 = time.perf_counter()
@@ -314,10 +365,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scenes", type=int, default=4)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the forward-only figure reported beside the headline")
     ap.add_argument("--no-serial-reference", action="store_true",
                     help="skip the short un-pipelined pass behind `ms_per_step_without_geometry_pipeline`")
-    ap.add_argument("--workload", choices=["backbone", "sgp"], default="backbone",
-                    help="backbone = BASELINE configs[1] (the headline metric); sgp = BASELINE configs[2] shape: the full "
+    ap.add_argument("--workload", choices=["backbone", "encoder", "sgp"], default="backbone",
+                    help="backbone = BASELINE configs[1] (the headline metric); encoder = the same batch through the "
+                         "scene-graph model's MSG object encoder (SURVEY 8d stack 2a); sgp = BASELINE configs[2] shape: the full "
                          "scene-graph model on synthetic scans (9 objects x 4000 pts + 72 pairs x 8000 pts, one scan per "
                          "step like the reference's DataLoader(batch_size=1)), fp32")
     ap.add_argument("--graphs", action="store_true",
@@ -349,7 +402,7 @@ def main():
     if args.workload == "sgp":
         return bench_sgp(args, device, rank, world, distributed, _ext)
 
-    model = build_model(device)
+    model = build_model(device, args.workload)
     net = model
     if distributed:
         # gradients only: one flat bucket (650k params = 2.6 MB, latency-bound over xGMI)
@@ -411,6 +464,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    fwd_ms = None
+    if world == 1 and not args.no_forward_only:
+        fwd_ms = forward_only(model, model, pc, max(3, min(args.steps, 10)), prefetcher)
+
+    pmc_default = args.workload == "backbone" and args.batch == 32 and args.points == 50000
     if rank == 0:
         scenes = args.batch * world * args.steps
         out = {
@@ -427,9 +485,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: {args.batch} scenes/GPU x {args.points} pts x (3 xyz + 3 rgb) fp32, "
-                            "full SA/FP stack (Pointnet2Backbone: SA 2048/0.2/64, 1024/0.4/32, 512/0.8/16, "
-                            "256/1.2/16, FP x2), train mode, fwd + bwd + AdamW",
+                "workload": f"BASELINE configs[1]: {args.batch} scenes/GPU x {args.points} pts x (3 xyz + 3 rgb) fp32, " + (
+                    "full SA/FP stack (Pointnet2Backbone: SA 2048/0.2/64, 1024/0.4/32, 512/0.8/16, "
+                    "256/1.2/16, FP x2), train mode, fwd + bwd + AdamW" if args.workload == "backbone" else
+                    "stack 2a = MSG object encoder (PointNetfeat: SA 512/[0.1,0.2]/[16,32], 128/[0.2,0.4]/[32,64], "
+                    "group-all), train mode, fwd + bwd + AdamW"),
                 "global_batch": args.batch * world,
                 "points_per_scene": args.points,
                 "parallelism": f"dp{world}",
@@ -452,7 +512,7 @@ def main():
             main_rows = [r for r in rows if not r["kernel"].endswith("@side")]
             out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
             if main_rows:
-                out["roofline"] = roofline_of(main_rows[0])
+                out["roofline"] = roofline_of(main_rows[0], pmc_default)
         if serial_rows is not None:
             keep = ("kernel", "calls_per_step", "ms_per_step", "avg_launch_us", "GBps", "TFLOPps", "bound", "frac")
             out["kernels_without_geometry_pipeline"] = [{k: r[k] for k in keep} for r in serial_rows]
@@ -460,11 +520,15 @@ def main():
             if mlp_rows:
                 # the same dominant kernel measured without the co-running prefetch stream: what the kernel itself achieves
                 top = max(mlp_rows, key=lambda r: r["ms_per_step"])
-                out["roofline_without_geometry_pipeline"] = {k: v for k, v in roofline_of(top).items() if k != "note"}
+                out["roofline_without_geometry_pipeline"] = {k: v for k, v in roofline_of(top, pmc_default).items() if k != "note"}
+        if fwd_ms is not None:
+            out["forward_only"] = {"ms_per_step": round(fwd_ms, 3), "scenes_per_s": round(args.batch / fwd_ms * 1e3, 1),
+                                   "note": "train-mode forward (batch statistics) under no_grad, measured after the timed region; "
+                                           "not part of `value`"}
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 64)
             try:
-                out["cpu_baseline"] = cpu_baseline(args.points, args.cpu_sample_scenes, threads)
+                out["cpu_baseline"] = cpu_baseline(args.points, args.cpu_sample_scenes, threads, args.workload)
             except Exception as e:  # the baseline is informational; never lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "scenes/s", "cores": threads, "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
