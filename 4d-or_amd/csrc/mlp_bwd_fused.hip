@@ -37,6 +37,10 @@ struct BwdArgs {
   float *dW;           // [N][K], accumulated with atomics (caller zero-fills)
   long long M;
   int N, K, ns;
+  // first-layer fold (version 2 only): X = input rows of layer l-1 [M][K0], P1 [K][K0] += (dL/dz_{l-1})^T X
+  const float *X;
+  float *P1;
+  int K0;
 };
 
 template <int GMODE, int NTN, int KTN, int R>
@@ -298,9 +302,17 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(const BwdArgs a) {
 // (wave w and w+4 share a SIMD), so one wave's staging and epilogue run under the other's MFMAs.  Both roles
 // issue the same number of MFMAs per tile (N/2 resp. 2 * 32 for N = 128; 32 resp. 32 for N = 64).
 // One barrier per tile (+ one for the pooled-gradient patch).
-template <int GMODE, int NTN>
+//
+// FOLD (layer l-1 is the FIRST layer of the stack, its input X needs no gradient and has K0 <= 8 columns): the masked
+// input gradient gz = dL/dz_{l-1} is not stored.  The first layer's weight gradient is linear in its BatchNorm-backward
+// constants,  dW_{l-1} = (c1 gz + c2 y_{l-1} + c3)^T X = diag(c1) gz^T X + diag(c2) W_{l-1} (X^T X) + c3 (1^T X),
+// so this kernel only reduces P1 = gz^T X (16 x K0 FMAs per lane and tile, X tile broadcast from LDS); X^T X and 1^T X
+// come from rows_gram_kernel and first_layer_dw_kernel combines them once the constants exist.  Saves the M x K store
+// here and the whole first-layer wgrad kernel (which re-read gz and y_{l-1}).
+template <int GMODE, int NTN, bool FOLD = false>
 __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   constexpr bool POOL = GMODE == PRO_POOLG;
+  constexpr int XW = 8;                         // padded width of the X tile
   constexpr int R = 64, KTN = 2;
   constexpr int NP = NTN * 32, KP = KTN * 32;
   constexpr int LDT = R + 1;
@@ -318,6 +330,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   float *act0 = gyT0 + 2 * GY_SZ;               // [2][R][KP]
   float *Wl = act0 + 2 * ACT_SZ;                // [NP][KP]
   float *red = Wl + NP * KP;                    // [2][KP]
+  float *Xs0 = red + 2 * KP;                    // FOLD: [2][R][XW] (+ [KP][XW] for the final reduction)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -352,17 +365,22 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   const int dcc = dcol < K ? dcol : (K - 1);
   const float e_s = a.a_scale[dcc], e_h = a.a_shift[dcc], e_m = a.a_mean[dcc], e_r = a.a_rstd[dcc];
   float cs1 = 0.f, cs2 = 0.f;
+  float px[FOLD ? XW : 1];
+#pragma unroll
+  for (int k = 0; k < (FOLD ? XW : 1); ++k) px[k] = 0.f;
+  // FOLD: thread (row tid / 8, column tid % 8) of the 64 x 8 X tile; columns past K0 are out of range (read 0)
+  const int xoff = (tid % XW) < a.K0 ? ((tid / XW) * a.K0 + (tid % XW)) * 4 : kOobOffset;
   // wgrad role: NTN == 4: n-block (wave-4), k-blocks 0 and 1, all 64 rows; NTN == 2: block (nb, kb) = ((w-4)&1, (w-4)>>1)
   const int w_nb = NTN == 4 ? (wave & 3) : (wave & 1);
   const int w_kb0 = NTN == 4 ? 0 : ((wave >> 1) & 1);
 
-  f32x16 accd, accw[TWN];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+  // one accumulator array for both roles (a wave is either dgrad or wgrad for the whole kernel; two arrays would
+  // both be live across the loop and cost 16 VGPRs of a 256-register budget)
+  f32x16 accs[TWN];
 #pragma unroll
   for (int j = 0; j < TWN; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) accs[j][r] = 0.f;
 
   // two register sets: the operands of tiles t+1 and t+2 are in flight / in registers while tile t is computed
   // (a burst of one tile per CU takes ~3 us to stream at full HBM rate plus the latency: with a single set the
@@ -370,10 +388,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   float rg0[RGN], ry0[GPT], rp0[APT], pg0[PG];
   float rg1[RGN], ry1[GPT], rp1[APT], pg1[PG];
   int pa0[PG], pa1[PG];
+  float rx0 = 0.f, rx1 = 0.f;
 
   auto load_tile = [&](long long tile, float (&rg)[RGN], float (&ry)[GPT], float (&rp)[APT], int (&pa)[PG],
-                       float (&pg)[PG]) {
+                       float (&pg)[PG], float &rx) {
     const long long m0 = tile * R;
+    if (FOLD) {
+      const rsrc_t rsx = make_rsrc(a.X + (size_t)m0 * a.K0, (M - m0) * a.K0 * 4);
+      rx = bload(rsx, xoff, 0);
+    }
     const rsrc_t rsy = make_rsrc(a.Yl + (size_t)m0 * N, (M - m0) * N * 4);
 #pragma unroll
     for (int i = 0; i < GPT; ++i) ry[i] = bload(rsy, goff, i * gpass);
@@ -401,10 +424,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   float spg[PG];
   long long p_m0 = 0;
   auto stage = [&](long long st, int buf, float (&rg)[RGN], float (&ry)[GPT], float (&rp)[APT], int (&pa)[PG],
-                   float (&pg)[PG]) {
+                   float (&pg)[PG], float &rx) {
     const long long m0 = st * R;
     float *gyT = gyT0 + buf * GY_SZ;
     float *act = act0 + buf * ACT_SZ;
+    if (FOLD) Xs0[buf * (R * XW) + tid] = rx;
     float gv[GPT];
 #pragma unroll
     for (int i = 0; i < GPT; ++i)
@@ -446,7 +470,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
 
   // one pipeline iteration: tile `tile` is in LDS buffer `buf`, (rg, ry, ...) hold tile+stride and are staged into
   // buf^1, then refilled with tile+3*stride (the other register set holds tile+2*stride)
-  auto iteration = [&](int buf, float (&rg)[RGN], float (&ry)[GPT], float (&rp)[APT], int (&pa)[PG], float (&pg)[PG]) {
+  auto iteration = [&](int buf, float (&rg)[RGN], float (&ry)[GPT], float (&rp)[APT], int (&pa)[PG], float (&pg)[PG],
+                       float &rx) {
     const long long m0 = tile * R;
     const long long t1 = clampt(tile + stride), t3 = clampt(tile + 3 * stride);
     const float *gyT = gyT0 + buf * GY_SZ;
@@ -456,26 +481,37 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
       const rsrc_t rsq = make_rsrc(a.Yprev + (size_t)m0 * K, (M - m0) * K * 4);
 #pragma unroll
       for (int r = 0; r < 16; ++r) yp[r] = bload(rsq, yoff, ((r & 3) + 8 * (r >> 2)) * rowpitch);
-      stage(t1, buf ^ 1, rg, ry, rp, pa, pg);
-      load_tile(t3, rg, ry, rp, pa, pg);
+      stage(t1, buf ^ 1, rg, ry, rp, pa, pg, rx);
+      load_tile(t3, rg, ry, rp, pa, pg, rx);
 #pragma unroll
       for (int s = 0; s < NP / 2; ++s) {
         const int n = 2 * s + lh;
         const float av = gyT[n * LDT + d_rb * 32 + l31];
         const float bv = Wl[n * KP + d_kb * 32 + l31];
-        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accd, 0, 0, 0);
+        accs[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accs[0], 0, 0, 0);
       }
       const rsrc_t rso = make_rsrc(a.Gout + (size_t)m0 * K, (M - m0) * K * 4);
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float y = yp[r];
-        float v = accd[r];
+        float v = accs[0][r];
         v = (__fmaf_rn(y, e_s, e_h) > 0.f) ? v : 0.f;
         s1 += v;
         s2 = __fmaf_rn(v, (y - e_m) * e_r, s2);
-        bstore(v, rso, yoff, ((r & 3) + 8 * (r >> 2)) * rowpitch);
-        accd[r] = 0.f;
+        if (FOLD) {
+          if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the X-tile reads from being hoisted en bloc (128 VGPRs)
+          const float4 *xr = reinterpret_cast<const float4 *>(Xs0 + buf * (R * XW) +
+                                                              (d_rb * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)) * XW);
+          const float4 xa = xr[0], xb = xr[1];
+          px[0] = __fmaf_rn(v, xa.x, px[0]); px[FOLD ? 1 : 0] = __fmaf_rn(v, xa.y, px[FOLD ? 1 : 0]);
+          px[FOLD ? 2 : 0] = __fmaf_rn(v, xa.z, px[FOLD ? 2 : 0]); px[FOLD ? 3 : 0] = __fmaf_rn(v, xa.w, px[FOLD ? 3 : 0]);
+          px[FOLD ? 4 : 0] = __fmaf_rn(v, xb.x, px[FOLD ? 4 : 0]); px[FOLD ? 5 : 0] = __fmaf_rn(v, xb.y, px[FOLD ? 5 : 0]);
+          px[FOLD ? 6 : 0] = __fmaf_rn(v, xb.z, px[FOLD ? 6 : 0]); px[FOLD ? 7 : 0] = __fmaf_rn(v, xb.w, px[FOLD ? 7 : 0]);
+        } else {
+          bstore(v, rso, yoff, ((r & 3) + 8 * (r >> 2)) * rowpitch);
+        }
+        accs[0][r] = 0.f;
       }
       cs1 += s1;
       cs2 += s2;
@@ -487,11 +523,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < TWN; ++j) {
           const float bv = act[row * KP + (w_kb0 + j) * 32 + l31];
-          accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);
+          accs[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accs[j], 0, 0, 0);
         }
       }
-      stage(t1, buf ^ 1, rg, ry, rp, pa, pg);
-      load_tile(t3, rg, ry, rp, pa, pg);
+      stage(t1, buf ^ 1, rg, ry, rp, pa, pg, rx);
+      load_tile(t3, rg, ry, rp, pa, pg, rx);
     }
     __syncthreads();
     if (POOL) {
@@ -501,11 +537,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
     tile += stride;
   };
 
-  load_tile(tile, rg0, ry0, rp0, pa0, pg0);
-  load_tile(clampt(tile + stride), rg1, ry1, rp1, pa1, pg1);
+  load_tile(tile, rg0, ry0, rp0, pa0, pg0, rx0);
+  load_tile(clampt(tile + stride), rg1, ry1, rp1, pa1, pg1, rx1);
   __syncthreads();                               // resident weights visible
-  stage(tile, 0, rg0, ry0, rp0, pa0, pg0);
-  load_tile(clampt(tile + 2 * stride), rg0, ry0, rp0, pa0, pg0);
+  stage(tile, 0, rg0, ry0, rp0, pa0, pg0, rx0);
+  load_tile(clampt(tile + 2 * stride), rg0, ry0, rp0, pa0, pg0, rx0);
   __syncthreads();
   if (POOL) {
     patch(0);
@@ -513,19 +549,29 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   }
   // single-exit pair loop + peeled odd iteration (see mlp_gemm_kernel): set 1 holds tile+stride, set 0 tile+2*stride
   for (long long pair = my_tiles >> 1; pair > 0; --pair) {
-    iteration(0, rg1, ry1, rp1, pa1, pg1);
-    iteration(1, rg0, ry0, rp0, pa0, pg0);
+    iteration(0, rg1, ry1, rp1, pa1, pg1, rx1);
+    iteration(1, rg0, ry0, rp0, pa0, pg0, rx0);
   }
-  if (my_tiles & 1) iteration(0, rg1, ry1, rp1, pa1, pg1);
+  if (my_tiles & 1) iteration(0, rg1, ry1, rp1, pa1, pg1, rx1);
 
   // ---- flush the column sums (dgrad waves; both row blocks of a column add up in LDS) ----
+  float *redP = Xs0 + 2 * R * XW;                // FOLD: [KP][XW]
   for (int i = tid; i < 2 * KP; i += 512) red[i] = 0.f;
+  if (FOLD) redP[tid] = 0.f;                     // KP * XW == 512
   __syncthreads();
   if (dgrad_role) {
     atomicAdd(&red[dcol], cs1);
     atomicAdd(&red[KP + dcol], cs2);
+    if (FOLD) {
+#pragma unroll
+      for (int k = 0; k < (FOLD ? XW : 1); ++k) atomicAdd(&redP[dcol * XW + k], px[k]);
+    }
   }
   __syncthreads();
+  if (FOLD) {
+    const int c = tid / XW, k = tid % XW;
+    if (c < K && k < a.K0) atomicAdd(a.P1 + (size_t)c * a.K0 + k, redP[tid]);
+  }
   for (int i = tid; i < KP; i += 512) {
     if (i < K) {
       atomicAdd(a.sums + i, (double)red[i]);
@@ -541,18 +587,19 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = nb + (r & 3) + 8 * (r >> 2);
-        if (n < N && kcol < K) atomicAdd(a.dW + (size_t)n * K + kcol, accw[j][r]);
+        if (n < N && kcol < K) atomicAdd(a.dW + (size_t)n * K + kcol, accs[j][r]);
       }
     }
   }
 }
 
-template <int GMODE, int NTN>
+template <int GMODE, int NTN, bool FOLD = false>
 int launch_fused2(const BwdArgs &a, hipStream_t s) {
   constexpr int NP = NTN * 32, KP = 64, R = 64;
-  constexpr size_t lds_bytes = (size_t)(2 * NP * (R + 1) + 2 * R * KP + NP * KP + 2 * KP) * sizeof(float);
+  constexpr size_t lds_bytes = (size_t)(2 * NP * (R + 1) + 2 * R * KP + NP * KP + 2 * KP +
+                                        (FOLD ? 2 * R * 8 + KP * 8 : 0)) * sizeof(float);
   static_assert(lds_bytes <= 160 * 1024, "LDS budget of one CU");
-  auto kern = mlp_bwd_fused2_kernel<GMODE, NTN>;
+  auto kern = mlp_bwd_fused2_kernel<GMODE, NTN, FOLD>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -590,6 +637,7 @@ int launch_fused(const BwdArgs &a, hipStream_t s) {
 template <int GMODE>
 int dispatch_fused(const BwdArgs &a, hipStream_t s) {
   const int ntn = a.N <= 64 ? 2 : 4, ktn = a.K <= 64 ? 2 : 4;
+  if (a.X) return (ntn == 2 && ktn == 2) ? launch_fused2<GMODE, 2, true>(a, s) : PN2_EINVAL;
   // N, K <= 64: role-specialised version 2 (1.16 vs 1.31 ms at M = 4.2M); N = 128: version 1 (1.67 vs 2.44 ms —
   // the two register sets of 64 x 128 gy tiles push version 2 past 256 VGPRs).  PN2_BWD_FUSED_V1=1 forces version 1.
   if (ntn == 2 && ktn == 2 && !getenv("PN2_BWD_FUSED_V1")) return launch_fused2<GMODE, 2>(a, s);
@@ -622,6 +670,136 @@ extern "C" int pn2_mlp_bwd_fused(long long M, int N, int K, int gmode, const flo
   a.arg = arg; a.gP = gP; a.W = W; a.Yprev = Yprev;
   a.a_mean = a_fin; a.a_rstd = a_fin + K; a.a_scale = a_fin + 2 * (size_t)K; a.a_shift = a_fin + 3 * (size_t)K;
   a.Gout = Gout; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K; a.ns = ns;
+  a.X = nullptr; a.P1 = nullptr; a.K0 = 0;
   hipStream_t s = (hipStream_t)stream;
   return gmode == PRO_GY ? dispatch_fused<PRO_GY>(a, s) : dispatch_fused<PRO_POOLG>(a, s);
+}
+
+// ---- first-layer fold -------------------------------------------------------------------------------------------
+namespace {
+
+// gram[K0*K0] = X^T X, gram[K0*K0 + k] = column sums of X  (fp64 accumulation; X is [M][K0], K0 <= 8)
+__global__ __launch_bounds__(256) void rows_gram_kernel(long long M, int K0, const float *__restrict__ X,
+                                                        double *__restrict__ gram) {
+  __shared__ double part[4][8 * 8 + 8];
+  float s[8][8], c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[i][j] = 0.f;
+  }
+  double ds[8][8], dc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    dc[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ds[i][j] = 0.0;
+  }
+  int n = 0;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = i < K0 ? X[(size_t)r * K0 + i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      c[i] += x[i];
+#pragma unroll
+      for (int j = i; j < 8; ++j) s[i][j] = __fmaf_rn(x[i], x[j], s[i][j]);
+    }
+    if (++n == 64) {                               // bound the fp32 partial sums
+      n = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        dc[i] += (double)c[i]; c[i] = 0.f;
+#pragma unroll
+        for (int j = i; j < 8; ++j) { ds[i][j] += (double)s[i][j]; s[i][j] = 0.f; }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    double v = dc[i] + (double)c[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) part[wave][64 + i] = v;
+#pragma unroll
+    for (int j = i; j < 8; ++j) {
+      double w = ds[i][j] + (double)s[i][j];
+      for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
+      if (lane == 0) part[wave][i * 8 + j] = w;
+    }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < 72) {
+    const int i = t < 64 ? t / 8 : t - 64, j = t < 64 ? t % 8 : 0;
+    if (t >= 64) {
+      if (i < K0) atomicAdd(gram + K0 * K0 + i, part[0][t] + part[1][t] + part[2][t] + part[3][t]);
+    } else if (i < K0 && j < K0) {
+      const int lo = i < j ? i : j, hi = i < j ? j : i;      // upper triangle holds the sums
+      const int u = lo * 8 + hi;
+      atomicAdd(gram + i * K0 + j, part[0][u] + part[1][u] + part[2][u] + part[3][u]);
+    }
+  }
+}
+
+// dW0[n][k] = c1[n] P1[n][k] + c2[n] sum_j W0[n][j] S[j][k] + c3[n] colsum[k]
+__global__ void first_layer_dw_kernel(int N, int K0, const float *__restrict__ consts, const float *__restrict__ P1,
+                                      const float *__restrict__ W0, const double *__restrict__ gram,
+                                      float *__restrict__ dW0) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * K0) return;
+  const int n = e / K0, k = e % K0;
+  double ws = 0.0;
+  for (int j = 0; j < K0; ++j) ws += (double)W0[n * K0 + j] * gram[j * K0 + k];
+  const double v = (double)consts[n] * (double)P1[e] + (double)consts[N + n] * ws +
+                   (double)consts[2 * N + n] * gram[K0 * K0 + k];
+  dW0[e] = (float)v;
+}
+
+}  // namespace
+
+extern "C" int pn2_mlp_bwd_fused_fold_supported(int N, int K, int K0) {
+  return N > 32 && N <= 64 && K > 32 && K <= 64 && K0 >= 1 && K0 <= 8 && !getenv("PN2_BWD_FUSED_V1") &&
+         !getenv("PN2_BWD_NOFOLD");
+}
+
+extern "C" int pn2_mlp_bwd_fused_fold(long long M, int N, int K, int gmode, const float *G, const float *Yl,
+                                      const float *consts, const int *arg, const float *gP, int ns, const float *W,
+                                      const float *Yprev, const float *a_fin, const float *X, int K0, double *sums,
+                                      float *dW, float *P1, void *stream) {
+  if (M < 0 || !pn2_mlp_bwd_fused_fold_supported(N, K, K0)) return PN2_EINVAL;
+  if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Yl || !consts || !W || !Yprev || !a_fin || !X || !sums || !dW || !P1) return PN2_ENULL;
+  if (gmode == PRO_GY && !G) return PN2_ENULL;
+  if (gmode == PRO_POOLG && (!arg || !gP || ns < 16 || M >= 0x7fffffffLL)) return PN2_EINVAL;
+  BwdArgs a;
+  a.G = G; a.Yl = Yl; a.c1 = consts; a.c2 = consts + N; a.c3 = consts + 2 * (size_t)N;
+  a.arg = arg; a.gP = gP; a.W = W; a.Yprev = Yprev;
+  a.a_mean = a_fin; a.a_rstd = a_fin + K; a.a_scale = a_fin + 2 * (size_t)K; a.a_shift = a_fin + 3 * (size_t)K;
+  a.Gout = nullptr; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K; a.ns = ns;
+  a.X = X; a.P1 = P1; a.K0 = K0;
+  hipStream_t s = (hipStream_t)stream;
+  return gmode == PRO_GY ? dispatch_fused<PRO_GY>(a, s) : dispatch_fused<PRO_POOLG>(a, s);
+}
+
+extern "C" int pn2_rows_gram(long long M, int K0, const float *X, double *gram, void *stream) {
+  if (M < 0 || K0 < 1 || K0 > 8) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!X || !gram) return PN2_ENULL;
+  long long blocks = (M + 256 * 64 - 1) / (256 * 64);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(rows_gram_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, K0, X, gram);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_first_layer_dw(int N, int K0, const float *consts, const float *P1, const float *W0,
+                                  const double *gram, float *dW0, void *stream) {
+  if (N <= 0 || K0 < 1 || K0 > 8) return PN2_EINVAL;
+  if (!consts || !P1 || !W0 || !gram || !dW0) return PN2_ENULL;
+  hipLaunchKernelGGL(first_layer_dw_kernel, dim3((N * K0 + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, K0,
+                     consts, P1, W0, gram, dW0);
+  return pn2_check_launch();
 }

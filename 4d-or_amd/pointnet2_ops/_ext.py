@@ -61,6 +61,10 @@ _SIGNATURES = {
     "pn2_mlp_gemm": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
     "pn2_mlp_wgrad": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_fused": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
+    "pn2_mlp_bwd_fused_fold": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 +
+                              [_c_int] + [_c_vp] * 4,
+    "pn2_rows_gram": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp],
+    "pn2_first_layer_dw": [_c_int, _c_int] + [_c_vp] * 6,
     "pn2_bn_finalize": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_bwd_consts": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_apply": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -78,6 +82,8 @@ _lib.pn2_fps_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_workspace_bytes.restype = _c_sz
 _lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_supported.restype = _c_int
+_lib.pn2_mlp_bwd_fused_fold_supported.argtypes = [_c_int, _c_int, _c_int]
+_lib.pn2_mlp_bwd_fused_fold_supported.restype = _c_int
 _lib.pn2_abi_version.restype = _c_int
 _lib.pn2_last_hip_error.restype = _c_int
 _lib.pn2_strerror.argtypes = [_c_int]
@@ -85,7 +91,7 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 
 ABI_VERSION = int(_lib.pn2_abi_version())
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
-                                               "pn2_mlp_bwd_fused_supported",
+                                               "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
 HAS_ROWS = True
@@ -521,6 +527,44 @@ def mlp_bwd_fused(Yl, consts, W, Yprev, a_fin, gmode, G=None, arg=None, gP=None,
           alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + 2 * M * K + N * K), alg_flops=4 * M * N * K,
           tag=(f"M{M},N{N},K{K},g{int(gmode)}" if DETAIL_TAGS else None))
     return Gout, sums, dW
+
+
+def mlp_bwd_fused_fold_supported(N, K, K0):
+    return bool(_lib.pn2_mlp_bwd_fused_fold_supported(int(N), int(K), int(K0)))
+
+
+def mlp_bwd_fused_fold(Yl, consts, W, Yprev, a_fin, X, gmode, G=None, arg=None, gP=None, ns=0, sums=None, dW=None, P1=None):
+    """As mlp_bwd_fused for the layer above the FIRST one, whose input rows X (M,K0) need no gradient: the input
+    gradient is not stored, P1 (K,K0) = gz^T X is reduced instead -> (sums (2,K) f64, dW (N,K), P1)."""
+    M, N = Yl.shape
+    K, K0 = Yprev.size(1), X.size(1)
+    if sums is None:
+        sums = torch.zeros(2, K, dtype=torch.float64, device=Yl.device)
+    if dW is None:
+        dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
+    if P1 is None:
+        P1 = torch.zeros(K, K0, dtype=torch.float32, device=Yl.device)
+    _call("pn2_mlp_bwd_fused_fold", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP),
+          int(ns), _ptr(W), _ptr(Yprev), _ptr(a_fin), _ptr(X), K0, _ptr(sums), _ptr(dW), _ptr(P1),
+          alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + M * K + M * K0 + N * K), alg_flops=4 * M * N * K,
+          tag=(f"M{M},N{N},K{K},g{int(gmode)},fold{K0}" if DETAIL_TAGS else None))
+    return sums, dW, P1
+
+
+def rows_gram(X, gram=None):
+    """gram (K0*K0 + K0,) f64 = [X^T X | column sums of X] for rows X (M,K0), K0 <= 8."""
+    M, K0 = X.shape
+    if gram is None:
+        gram = torch.zeros(K0 * K0 + K0, dtype=torch.float64, device=X.device)
+    _call("pn2_rows_gram", X, M, K0, _ptr(X), _ptr(gram), alg_bytes=4 * M * K0)
+    return gram
+
+
+def first_layer_dw(consts, P1, W0, gram):
+    N, K0 = W0.shape
+    dW0 = torch.empty(N, K0, dtype=torch.float32, device=W0.device)
+    _call("pn2_first_layer_dw", W0, N, K0, _ptr(consts), _ptr(P1), _ptr(W0), _ptr(gram), _ptr(dW0))
+    return dW0
 
 
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):

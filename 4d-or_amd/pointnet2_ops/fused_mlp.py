@@ -149,9 +149,16 @@ class _FusedMLP(Function):
 
         # every zero-initialised accumulator of this backward from one allocation / one fill
         f64, f32 = torch.float64, torch.float32
+        # first-layer fold (csrc/mlp_bwd_fused.hip): the layer above the first one reduces gz^T X instead of storing gz
+        # when the first layer's input needs no gradient (raw coordinates / colours) and is at most 8 columns wide
+        need_dgrad0 = ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None)
+        K0 = x.size(1)
+        fold = (L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0]
+                and e.mlp_bwd_fused_fold_supported(Ws[1].size(0), Ws[1].size(1), K0))
         arena = e.zero_arena(x.device, [((2, Ws[-1].size(0)), f64)] + [((2, Ws[l].size(1)), f64) for l in range(L)] +
-                             [(tuple(Ws[l].shape), f32) for l in range(L)])
-        sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:]
+                             [(tuple(Ws[l].shape), f32) for l in range(L)] +
+                             ([((Ws[0].size(0), K0), f32), ((K0 * K0 + K0,), f64)] if fold else []))
+        sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:1 + 2 * L]
         if ns:
             pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
             gPm, sums = e.pool_bwd_prep(yraw, pooled, g_out, fins[-1], sums=sums0)
@@ -165,6 +172,15 @@ class _FusedMLP(Function):
         for l in range(L - 1, -1, -1):
             consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            if l == 1 and fold:
+                sums, dW, P1 = e.mlp_bwd_fused_fold(ys[1], consts, Ws[1].contiguous(), ys[0], fins[0], x, gmode, G=G, arg=arg,
+                                                    gP=gPm, ns=ns, sums=sums_in[1], dW=dWs[1], P1=arena[1 + 2 * L])
+                grads[3] = dW.view(ctx.shapes[1])
+                continue
+            if l == 0 and fold:
+                gram = e.rows_gram(x, arena[2 + 2 * L])
+                grads[0] = e.first_layer_dw(consts, P1, Ws[0].contiguous(), gram).view(ctx.shapes[0])
+                continue
             if l > 0 and FUSED_BACKWARD and e.mlp_bwd_fused_supported(Ws[l].size(0), Ws[l].size(1)):
                 # hidden layer: dgrad + wgrad from one read of (g, y_l, y_{l-1})
                 G, sums, dW = e.mlp_bwd_fused(ys[l], consts, Ws[l].contiguous(), ys[l - 1], fins[l - 1], gmode,
@@ -176,7 +192,7 @@ class _FusedMLP(Function):
             dW = e.mlp_wgrad(ys[l], consts, act, gmode, e.PRO_NONE if l == 0 else e.PRO_BNRELU,
                              G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1], dW=dWs[l])
             grads[3 * l] = dW.view(ctx.shapes[l])
-            need_dgrad = l > 0 or (ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None))
+            need_dgrad = l > 0 or need_dgrad0
             if need_dgrad:
                 Wt = Ws[l].t()                                    # (K_l, N_l): dgrad is out[M,K_l] = gy[M,N_l] @ Wt^T
                 if l == 0 and ctx.group is not None and ctx.group[3]:

@@ -208,6 +208,21 @@ int pn2_mlp_bwd_fused(long long M, int N, int K, int gmode, const float *G, cons
                       const float *consts, const int *arg, const float *gP, int ns, const float *W,
                       const float *Yprev, const float *a_fin, float *Gout, double *sums, float *dW,
                       void *stream);
+/* First-layer fold (same reference lines): when layer l-1 is the FIRST layer of the stack, its input rows X [M][K0]
+ * (K0 <= 8: relative xyz + a few feature columns) need no gradient, and 32 < N, K <= 64, the masked input gradient
+ * gz = dL/dz_{l-1} is not stored at all.  The first layer's weight gradient is linear in its BatchNorm-backward
+ * constants:  dW_{l-1} = (c1 gz + c2 y_{l-1} + c3)^T X = diag(c1) gz^T X + diag(c2) W_{l-1} (X^T X) + c3 (1^T X).
+ *   pn2_mlp_bwd_fused_fold : as pn2_mlp_bwd_fused without Gout, plus P1[K][K0] += gz^T X (caller zero-fills);
+ *   pn2_rows_gram          : gram[K0*K0] += X^T X, gram[K0*K0 + k] += column sums of X (fp64, caller zero-fills);
+ *   pn2_first_layer_dw     : dW0[N0][K0] from the constants of layer l-1 (N0 = K above), P1, W_{l-1} and gram. */
+int pn2_mlp_bwd_fused_fold_supported(int N, int K, int K0);
+int pn2_mlp_bwd_fused_fold(long long M, int N, int K, int gmode, const float *G, const float *Yl,
+                           const float *consts, const int *arg, const float *gP, int ns, const float *W,
+                           const float *Yprev, const float *a_fin, const float *X, int K0, double *sums,
+                           float *dW, float *P1, void *stream);
+int pn2_rows_gram(long long M, int K0, const float *X, double *gram, void *stream);
+int pn2_first_layer_dw(int N, int K0, const float *consts, const float *P1, const float *W0,
+                       const double *gram, float *dW0, void *stream);
 int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, const float *G,
                   const float *Yl, const float *consts, const int *arg, const float *gP, int ns,
                   const float *X, const float *a_fin, float *dW, void *stream);

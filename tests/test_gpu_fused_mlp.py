@@ -24,12 +24,12 @@ def _mlp(spec, seed):
     return m
 
 
-def _run(mlp, x, ns, fused, train):
+def _run(mlp, x, ns, fused, train, x_grad=True):
     m = copy.deepcopy(mlp)
     m.train(train)
     prev = pm.set_fused_mlp(fused)
     try:
-        xx = x.clone().requires_grad_(True)
+        xx = x.clone().requires_grad_(x_grad)
         if ns:
             R = x.size(0) // ns
             out = pm.mlp_pool_rows(m, xx.view(1, R, ns, -1)).view(R, -1)
@@ -73,6 +73,30 @@ def test_fused_matches_torch(spec, M, ns, train):
         assert float((a - b).abs().max()) <= tol * scale + 1e-5, (a - b).abs().max()
     for k in sd0:
         torch.testing.assert_close(sd1[k].float(), sd0[k].float(), atol=1e-5, rtol=1e-4)
+
+
+# first-layer fold (csrc/mlp_bwd_fused.hip, FOLD): the input rows need no gradient and are <= 8 columns wide, the layer
+# above is 32 < N, K <= 64 -> the first layer's weight gradient comes from gz^T X, X^T X and the column sums of X.
+FOLD_CASES = [((6, 64, 64, 128), 16 * 37, 16), ((6, 64, 64), 32 * 21, 32), ((7, 64, 64, 128), 777, 0),
+              ((3, 48, 40, 64), 1000, 0), ((8, 64, 64), 64 * 3, 0), ((1, 33, 64), 130, 0),
+              ((6, 64, 64, 128), 64 * 4096 + 64 * 3, 64)]
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("spec,M,ns", FOLD_CASES)
+def test_first_layer_fold_matches_torch(spec, M, ns, train):
+    from pointnet2_ops import pointnet2_utils as pu
+    assert pu._ext.mlp_bwd_fused_fold_supported(spec[2], spec[1], spec[0])
+    mlp = _mlp(spec, seed=len(spec) + M)
+    g = torch.Generator().manual_seed(M + 1)
+    x = (torch.randn(M, spec[0], generator=g) + 0.3).cuda()        # non-zero column means: the c3 (1^T X) term matters
+    o0, _, gp0, _ = _run(mlp, x, ns, fused=False, train=train, x_grad=False)
+    o1, _, gp1, _ = _run(mlp, x, ns, fused=True, train=train, x_grad=False)
+    torch.testing.assert_close(o1, o0, atol=1e-4, rtol=1e-4)
+    for a, b in zip(gp1, gp0):
+        scale = float(b.abs().max()) + 1e-6
+        tol = 5e-3 if M >= (1 << 17) else 2e-4
+        assert float((a - b).abs().max()) <= tol * scale + 1e-5, (a - b).abs().max()
 
 
 def test_full_size_sa1_layer_statistics_and_throughput_shape():
