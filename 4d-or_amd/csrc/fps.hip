@@ -305,6 +305,10 @@ struct __attribute__((aligned(16))) FpsFinal {
 // lane), scans them back to back, and ONE barrier + ONE hand-off per round moves all NC
 // candidates.  Wave c (< NC) sweeps the granules of cloud c, so the sweeps run in parallel.
 // Cluster q = blockIdx.x % (B/NC) serves clouds q*NC .. q*NC+NC-1; workgroup g = blockIdx.x / (B/NC).
+#ifdef PN2_EXP_CFG
+__device__ unsigned g_fps_hw[2 * 1024];
+__device__ int g_fps_dbg = 0;   // experiments only: 1 = no scan, 2 = no inter-workgroup hand-off, 3 = neither
+#endif
 template <int BS, int PPT, int NC>
 __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L, int G,
                                                      const float *__restrict__ xyz,
@@ -317,6 +321,13 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
   __shared__ unsigned lds_vals[NC][kCoopFields][kCoopMaxG];
   __shared__ FpsFinal lds_fin[2][NC];
 
+#ifdef PN2_EXP_CFG
+  const int dbg = g_fps_dbg;
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_fps_hw[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    g_fps_hw[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
   const int nclusters = B / NC;
   const int q = blockIdx.x % nclusters;   // a cluster's workgroups share blockIdx % 8 (one XCD) when nclusters % 8 == 0
   const int g = blockIdx.x / nclusters;
@@ -360,6 +371,10 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
       // two selects, 64-bit key reduction, 3*PPT-select coordinate chain).  The FPS co-runs with the MFMA kernels of
       // the training step and fp32 VALU time is exactly what it takes away from them.
       float best = -1.f;
+#ifdef PN2_EXP_CFG
+      if (dbg & 1) best = lane == 0 ? td[0] : -1.f;
+      else
+#endif
       if constexpr (PPT % 2 == 0) {
         // two points per packed instruction (v_pk_add/mul/fma_f32): the same IEEE operations in the same order as
         // pn2_sq3 — fma(dz, dz, fma(dx, dx, dy * dy)) — on both halves
@@ -467,6 +482,9 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
       const float bx = buf[ws].x, by = buf[ws].y, bz = buf[ws].z;
 
       u64 *par = slots + ((size_t)(q * NC + c) * 2 + (size_t)(j & 1)) * (kCoopFields * kCoopMaxG);
+#ifdef PN2_EXP_CFG
+      if (!(dbg & 2))
+#endif
       if (lane < kCoopFields) {
         unsigned v = lane == 0 ? (unsigned)(bmax >> 32)
                    : lane == 1 ? (unsigned)bmax
@@ -474,7 +492,17 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
                    : lane == 3 ? __float_as_uint(by) : __float_as_uint(bz);
         coop_store(par + lane * kCoopMaxG + g, ((u64)(unsigned)j << 32) | v);
       }
-      const int total = kCoopFields * G;
+      int total = kCoopFields * G;
+#ifdef PN2_EXP_CFG
+      if (dbg & 2) {
+        total = 0;
+        if (lane < kCoopFields) {
+          const unsigned v = lane == 0 ? (unsigned)(bmax >> 32) : lane == 1 ? (unsigned)bmax
+                           : lane == 2 ? __float_as_uint(bx) : lane == 3 ? __float_as_uint(by) : __float_as_uint(bz);
+          for (int gg = 0; gg < G; ++gg) lds_vals[c][lane][gg] = v;
+        }
+      }
+#endif
       bool failed = false;
       for (int qq = 0; qq < total; qq += 64) {
         const int l = qq + lane;
@@ -554,7 +582,7 @@ int round_ppt(int ppt) {
 
 // PN2_FPS_MODE=resident|coop|stream and PN2_FPS_G=<power of two> override the
 // heuristic (tuning / tests only).
-FpsPlan fps_plan(int B, int N, int m) {
+FpsPlan fps_plan(int B, int N, int m, bool few_cus = false) {
   FpsPlan p = {2, 1, 1024, 0, 1};
   if (m <= 1) { p.mode = 0; p.BS = 512; p.PPT = 1; return p; }
   const char *mode_env = getenv("PN2_FPS_MODE");
@@ -584,10 +612,25 @@ FpsPlan fps_plan(int B, int N, int m) {
       const int want = atoi(g_env);
       if (want >= 2 && want <= kCoopMaxG && (want & (want - 1)) == 0) G = want;
     }
-    const int ppt = round_ppt((N + G * 512 - 1) / (G * 512));
+    // few_cus (PN2_FPS_FEW_CUS: the sampling runs on a side stream next to the MFMA kernels of a training step):
+    // half as many cluster workgroups of 1024 threads.  Alone that is slower (1024-thread scans: 5.9 vs 4.8 ms at
+    // 32 x 50k -> 2048), but a resident FPS workgroup pins 160 of the 512 VGPRs per lane on its CU for its whole
+    // run and halves the occupancy of every co-running 8-wave GEMM workgroup there; on 128 CUs instead of 256 the
+    // other half of the chip runs the step undisturbed and the step is 0.8 ms shorter (tools/corun_probe.py).
+    // PN2_FPS_COOP_BS=1024 forces the wide workgroups (tuning only).
+    int cbs = 512;
+    if (NC == 1 && !g_env && few_cus && G >= 4) {
+      const int wp = round_ppt((N + (G / 2) * 1024 - 1) / ((G / 2) * 1024));
+      if (wp >= 8 && wp <= 16) { cbs = 1024; G /= 2; }
+    }
+    if (const char *e = getenv("PN2_FPS_COOP_BS")) {
+      if (atoi(e) == 1024 && NC == 1) cbs = 1024;
+    }
+    const int ppt = round_ppt((N + G * cbs - 1) / (G * cbs));
     if (NC > 1 && NC * ppt > 28) NC = 1;                  // multi-cloud kernels are built for <= 28 slots
-    if (G <= kCoopMaxG && (long long)(B / NC) * G <= kCoopMaxWorkgroups && ppt > 0 && NC * ppt <= 28) {
-      c.mode = 1; c.G = G; c.PPT = ppt; c.NC = NC;
+    if (G <= kCoopMaxG && (long long)(B / NC) * G <= kCoopMaxWorkgroups && ppt > 0 && NC * ppt <= 28 &&
+        (cbs == 512 || (ppt >= 8 && ppt <= 16))) {
+      c.mode = 1; c.G = G; c.PPT = ppt; c.NC = NC; c.BS = cbs;
     }
   }
   // resident candidate
@@ -625,7 +668,14 @@ extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int m) {
 extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz,
                                            void *workspace, size_t workspace_bytes,
                                            int *idxs, void *stream) {
+  return pn2_furthest_point_sampling_ex(B, N, m, xyz, workspace, workspace_bytes, idxs, 0, stream);
+}
+
+extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *xyz,
+                                              void *workspace, size_t workspace_bytes,
+                                              int *idxs, int flags, void *stream) {
   if (B < 0 || N < 0) return PN2_EINVAL;
+  if (flags & ~PN2_FPS_FEW_CUS) return PN2_EINVAL;
   if (m <= 0 || B == 0) return PN2_OK;  // EXT/src/sampling_gpu.cu:73
   if (N <= 0) return PN2_EINVAL;
   if (!xyz || !idxs) return PN2_ENULL;
@@ -633,8 +683,8 @@ extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz
   const int bs = ref_opt_n_threads(N);
   int L = 0;
   while ((1 << L) < bs) ++L;
-  const FpsPlan plan = fps_plan(B, N, m);
-  const size_t need = pn2_fps_workspace_bytes(B, N, m);
+  const FpsPlan plan = fps_plan(B, N, m, (flags & PN2_FPS_FEW_CUS) != 0);
+  const size_t need = pn2_fps_workspace_bytes(B, N, m);       // same for both cooperative shapes
   if (need) {
     if (!workspace) return PN2_ENULL;
     if (workspace_bytes < need) return PN2_ENOSPC;
@@ -645,6 +695,13 @@ extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz
     int *status = (int *)((char *)workspace + (size_t)B * kCoopCloudBytes);
     if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return pn2_check_launch();
     const dim3 grid((unsigned)((B / plan.NC) * plan.G));
+#ifdef PN2_EXP_CFG
+    {
+      static int last = -1;
+      const int dbg = getenv("PN2_FPS_DBG") ? atoi(getenv("PN2_FPS_DBG")) : 0;
+      if (dbg != last) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fps_dbg), &dbg, sizeof(int)); last = dbg; }
+    }
+#endif
 #define PN2_FPS_COOP(PPT, NC)                                                                       \
   hipLaunchKernelGGL((fps_coop_kernel<512, PPT, NC>), grid, dim3(512), 0, s, B, N, m, L, plan.G,    \
                      xyz, idxs, slots, status)
@@ -661,7 +718,21 @@ extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz
     case 14: if (NC * 14 <= 28) { PN2_FPS_COOP(14, (NC * 14 <= 28 ? NC : 1)); break; } return PN2_EINVAL; \
     default: return PN2_EINVAL;                                                                     \
   }
-    if (plan.NC == 4) { PN2_FPS_COOP_NC(4) }
+    if (plan.BS == 1024) {
+#define PN2_FPS_COOP_W(PPT)                                                                           \
+  hipLaunchKernelGGL((fps_coop_kernel<1024, PPT, 1>), grid, dim3(1024), 0, s, B, N, m, L, plan.G, xyz, idxs, \
+                     slots, status)
+      switch (plan.PPT) {
+        case 8: PN2_FPS_COOP_W(8); break;
+        case 10: PN2_FPS_COOP_W(10); break;
+        case 12: PN2_FPS_COOP_W(12); break;
+        case 14: PN2_FPS_COOP_W(14); break;
+        case 16: PN2_FPS_COOP_W(16); break;
+        default: return PN2_EINVAL;
+      }
+#undef PN2_FPS_COOP_W
+    }
+    else if (plan.NC == 4) { PN2_FPS_COOP_NC(4) }
     else if (plan.NC == 2) { PN2_FPS_COOP_NC(2) }
     else {
       switch (plan.PPT) {
@@ -731,3 +802,9 @@ extern "C" int pn2_fps_coop_status(int B, const void *workspace, void *stream) {
     return -1;
   return v;
 }
+
+#ifdef PN2_EXP_CFG
+extern "C" __attribute__((visibility("default"))) int pn2_dbg_fps_dump(unsigned *out /* [2*1024] host */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fps_hw), sizeof(unsigned) * 2 * 1024);
+}
+#endif

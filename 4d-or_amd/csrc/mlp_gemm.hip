@@ -896,7 +896,8 @@ extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const f
   // backward = {GY, POOLG} x {MASK, NONE}
   if (pro == PRO_NONE && epi == EPI_STATS) launch_by_width<PRO_NONE, EPI_STATS>(a, tiles, s);
 #ifdef PN2_EXP_CFG
-  else if (pro == PRO_BNRELU && epi == EPI_STATS && getenv("PN2_GEMM_CFG")) {
+  else if (pro == PRO_BNRELU && epi == EPI_STATS && getenv("PN2_GEMM_CFG") &&
+           (!getenv("PN2_GEMM_CFG_TILES") || atoi(getenv("PN2_GEMM_CFG_TILES")) == tiles)) {
     int nt = 2, kc = 32, cw = 1;
     sscanf(getenv("PN2_GEMM_CFG"), "%d,%d,%d", &nt, &kc, &cw);
 #define PN2_TRY(NT_, KC_, CW_) if (nt == NT_ && kc == KC_ && cw == CW_) launch_one<NT_, KC_, CW_, PRO_BNRELU, EPI_STATS>(a, s); else

@@ -4,9 +4,12 @@ GF3D/models/backbone_module.py:12-129: four set-abstraction levels
 (2048/0.2/64, 1024/0.4/32, 512/0.8/16, 256/1.2/16, radius-normalised local xyz)
 and two feature-propagation levels; same constructor, same ``end_points`` keys,
 same parameter names."""
+import contextlib
+
 import torch
 import torch.nn as nn
 
+from pointnet2_ops import pointnet2_utils
 from external_src.group_free_3D.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 
 
@@ -43,12 +46,14 @@ class Pointnet2Backbone(nn.Module):
         xyz = pointcloud[..., 0:3].contiguous()
         geo = {"sa": [], "fp": []}
         levels = [xyz]
-        for i in (1, 2, 3, 4):
-            g = getattr(self, f"sa{i}").sample_and_query(levels[-1])
-            geo["sa"].append(g)
-            levels.append(g["new_xyz"])
-        geo["fp"].append(self.fp1.interpolation(levels[3], levels[4]))
-        geo["fp"].append(self.fp2.interpolation(levels[2], levels[3]))
+        # FPS shape that leaves half of the CUs to the co-running step (include/pn2_hip.h: PN2_FPS_FEW_CUS)
+        with getattr(pointnet2_utils._ext, "background_geometry", contextlib.nullcontext)():
+            for i in (1, 2, 3, 4):
+                g = getattr(self, f"sa{i}").sample_and_query(levels[-1])
+                geo["sa"].append(g)
+                levels.append(g["new_xyz"])
+            geo["fp"].append(self.fp1.interpolation(levels[3], levels[4]))
+            geo["fp"].append(self.fp2.interpolation(levels[2], levels[3]))
         return geo
 
     def forward(self, pointcloud: torch.Tensor, end_points=None, geometry=None):

@@ -18,8 +18,10 @@ the C ABI of ``include/pn2_hip.h``) through ctypes:
 There is NO fallback: if the shared library is missing or a kernel launch
 fails this module raises.  torch is used for device memory and streams only.
 """
+import contextlib
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -41,6 +43,7 @@ _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_f
 # symbol -> argtypes; every entry point returns int unless noted
 _SIGNATURES = {
     "pn2_furthest_point_sampling": [_c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp],
+    "pn2_furthest_point_sampling_ex": [_c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp, _c_int, _c_vp],
     "pn2_gather_points": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_gather_points_grad": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_ball_query": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -175,8 +178,8 @@ TIMER = None  # set to a KernelTimer() to profile
 DETAIL_TAGS = os.environ.get("PN2_TIMER_DETAIL") == "1"   # per-shape rows for the MLP kernels
 
 
-def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None):
-    """Enqueue `name` on the current stream of `ref`'s device."""
+def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None, label=None):
+    """Enqueue `name` on the current stream of `ref`'s device (`label`: row name in the kernel timer, default `name`)."""
     with torch.cuda.device(ref.device):
         stream = torch.cuda.current_stream(ref.device).cuda_stream
         if TIMER is not None and TIMER.enabled:
@@ -184,7 +187,7 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None):
             ev0.record()
             rc = getattr(_lib, name)(*args, stream)
             ev1.record()
-            label = name if tag is None else f"{name}[{tag}]"
+            label = (label or name) if tag is None else f"{label or name}[{tag}]"
             if TIMER.main_stream is not None and stream != TIMER.main_stream:
                 label += "@side"
             TIMER.records.append((label, ev0, ev1, int(alg_bytes), int(alg_flops)))
@@ -193,6 +196,22 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None):
     if rc != 0:
         detail = _lib.pn2_strerror(rc).decode()
         _fail(f"{name} failed: {detail} (rc={rc}, hipError={_lib.pn2_last_hip_error()})")
+
+
+PN2_FPS_FEW_CUS = 1
+_sched = threading.local()
+
+
+@contextlib.contextmanager
+def background_geometry():
+    """FPS calls made inside run with PN2_FPS_FEW_CUS (include/pn2_hip.h): for geometry that is prefetched on a
+    side stream while a training step runs on the main one.  Results are identical."""
+    prev = getattr(_sched, "few_cus", False)
+    _sched.few_cus = True
+    try:
+        yield
+    finally:
+        _sched.few_cus = prev
 
 
 # ------------------------------------------------------------- the nine reference ops
@@ -205,8 +224,12 @@ def furthest_point_sampling(points, nsamples):
     out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
     ws_bytes = int(_lib.pn2_fps_workspace_bytes(B, N, nsamples))
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=points.device) if ws_bytes else None
-    _call("pn2_furthest_point_sampling", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
-          alg_bytes=B * (12 * N + 4 * nsamples))
+    if getattr(_sched, "few_cus", False):
+        _call("pn2_furthest_point_sampling_ex", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
+              PN2_FPS_FEW_CUS, alg_bytes=B * (12 * N + 4 * nsamples), label="pn2_furthest_point_sampling")
+    else:
+        _call("pn2_furthest_point_sampling", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
+              alg_bytes=B * (12 * N + 4 * nsamples))
     if ws is not None and os.environ.get("PN2_FPS_CHECK") == "1":
         # debug/test only (host sync): did a bounded inter-workgroup wait expire?
         with torch.cuda.device(points.device):

@@ -325,6 +325,7 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to enqueue a step (no GPU wait)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -343,6 +344,7 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
                "config": {"workload": "BASELINE configs[2] shape: SGPNModelWrapper(no_gt.json), 1 synthetic scan per step "
                                       "and rank, train mode, fwd + weighted NLL + bwd + AdamW",
                           "parallelism": f"dp{world}", "hip_graphs": bool(args.graphs),
+                          "host_enqueue_ms_per_step": round(enqueue_ms, 3),
                           "geometry_pipeline": bool(args.geometry_pipeline and not args.graphs)}}
         if timer is not None:
             rows = [{"kernel": k, "calls_per_step": d["calls"] / args.steps, "ms_per_step": round(d["ms"] / args.steps, 4)}

@@ -61,6 +61,14 @@ int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz,
                                 void *workspace, size_t workspace_bytes,
                                 int *idxs, void *stream);
 
+/* Same operator with a scheduling hint (identical results).  PN2_FPS_FEW_CUS: the call is enqueued on a side stream
+ * next to compute kernels (geometry of the next batch prefetched during a training step): pick the cooperative shape
+ * that occupies half as many CUs (1024-thread cluster workgroups) instead of the one with the shortest latency. */
+#define PN2_FPS_FEW_CUS 1
+int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *xyz,
+                                   void *workspace, size_t workspace_bytes,
+                                   int *idxs, int flags, void *stream);
+
 /* Test hook for the multi-workgroup FPS variant: returns the status word a
  * launch left in `workspace` (0 ok, 1 a bounded inter-workgroup wait expired,
  * <0 query failed).  Synchronises `stream`; never used on the hot path. */

@@ -44,6 +44,18 @@ def test_fps_bit_exact(ext, B, N, m, kind):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("B,N,m", [(2, 50000, 300), (3, 40000, 64), (1, 123457, 96), (2, 20000, 100), (2, 4000, 128)])
+@pytest.mark.parametrize("kind", ["uniform", "dup", "zero_tail"])
+def test_fps_few_cus_hint_is_bit_exact(ext, B, N, m, kind):
+    """PN2_FPS_FEW_CUS (geometry prefetched next to a training step: 1024-thread cluster workgroups on half as
+    many CUs) only changes the schedule, never the indices."""
+    xyz = clouds(B, N, kind, seed=N * 7 + m)
+    want = O.furthest_point_sampling(xyz, m)
+    with ext.background_geometry():
+        got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("mode,g", [("resident", None), ("stream", None), ("coop", 2), ("coop", 8), ("coop", 32), (None, None)])
 @pytest.mark.parametrize("B,N,m,kind", [(2, 9000, 300, "uniform"), (3, 20000, 150, "dup"), (1, 50000, 200, "zero_tail"),
                                         (32, 50000, 40, "uniform"), (5, 5000, 64, "grid")])

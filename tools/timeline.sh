@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/timeline
 mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace -d $O/trace --output-format csv -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-serial-reference > $O/run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace -d $O/trace --output-format csv -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-serial-reference --no-forward-only "$@" > $O/run.log 2>&1
 python - <<PY
 import csv, glob, re
 f = glob.glob("$O/trace/**/*kernel_trace.csv", recursive=True)[0]
