@@ -69,8 +69,15 @@ constexpr int BM = 128;
 //
 // CW = wave columns: the workgroup is 4 x CW waves; wave (wr, wc) owns rows wr*32.. and the
 // NT column tiles wc*NT.. (CW = 2 keeps N = 256/288 at 64-80 accumulator registers per wave).
+#ifdef PN2_EXP_CFG
+// experiments only (tools/corun_probe.py): per-workgroup (start, end, HW_ID, XCC_ID) of the last launch
+__device__ unsigned long long g_gemm_dbg[4 * 4096];
+#endif
 template <int NT, int KC, int CW, int PRO, int EPI>
 __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a) {
+#ifdef PN2_EXP_CFG
+  const unsigned long long dbg_t0 = wall_clock64();
+#endif
   constexpr int THREADS = 256 * CW;
   constexpr int NTT = NT * CW;                 // column tiles per workgroup
   constexpr int LD = KC + 1;
@@ -360,6 +367,17 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   }
   if (total_steps & 1) iteration(0, ra0, rb0, rw0, pa0, pg0, ra1, rb1, rw1, pa1, pg1);
 
+#ifdef PN2_EXP_CFG
+  if (tid == 0) {
+    const unsigned w = blockIdx.x + gridDim.x * blockIdx.y;
+    if (w < 4096) {
+      g_gemm_dbg[4 * w + 0] = dbg_t0;
+      g_gemm_dbg[4 * w + 1] = wall_clock64();
+      g_gemm_dbg[4 * w + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      g_gemm_dbg[4 * w + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+  }
+#endif
   // ---- flush the column sums once per workgroup ----
   if (EPI != EPI_NONE) {
     for (int i = tid; i < 2 * NTT * 32; i += THREADS) (&red[0][0])[i] = 0.f;
@@ -1064,3 +1082,9 @@ extern "C" int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const fl
                      (hipStream_t)stream, R, C, yraw, pooled, gP, fin, gPm, sums);
   return pn2_check_launch();
 }
+
+#ifdef PN2_EXP_CFG
+extern "C" __attribute__((visibility("default"))) int pn2_dbg_gemm_dump(unsigned long long *out /* [4*4096] host */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_dbg), sizeof(unsigned long long) * 4 * 4096);
+}
+#endif
