@@ -365,9 +365,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   const int dcc = dcol < K ? dcol : (K - 1);
   const float e_s = a.a_scale[dcc], e_h = a.a_shift[dcc], e_m = a.a_mean[dcc], e_r = a.a_rstd[dcc];
   float cs1 = 0.f, cs2 = 0.f;
-  float px[FOLD ? XW : 1];
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 px[FOLD ? XW / 2 : 1];
 #pragma unroll
-  for (int k = 0; k < (FOLD ? XW : 1); ++k) px[k] = 0.f;
+  for (int k = 0; k < (FOLD ? XW / 2 : 1); ++k) px[k] = f2{0.f, 0.f};
   // FOLD: thread (row tid / 8, column tid % 8) of the 64 x 8 X tile; columns past K0 are out of range (read 0)
   const int xoff = (tid % XW) < a.K0 ? ((tid / XW) * a.K0 + (tid % XW)) * 4 : kOobOffset;
   // wgrad role: NTN == 4: n-block (wave-4), k-blocks 0 and 1, all 64 rows; NTN == 2: block (nb, kb) = ((w-4)&1, (w-4)>>1)
@@ -500,14 +501,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
         s1 += v;
         s2 = __fmaf_rn(v, (y - e_m) * e_r, s2);
         if (FOLD) {
-          if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the X-tile reads from being hoisted en bloc (128 VGPRs)
+          if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the X-tile reads from being hoisted en bloc
           const float4 *xr = reinterpret_cast<const float4 *>(Xs0 + buf * (R * XW) +
                                                               (d_rb * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)) * XW);
-          const float4 xa = xr[0], xb = xr[1];
-          px[0] = __fmaf_rn(v, xa.x, px[0]); px[FOLD ? 1 : 0] = __fmaf_rn(v, xa.y, px[FOLD ? 1 : 0]);
-          px[FOLD ? 2 : 0] = __fmaf_rn(v, xa.z, px[FOLD ? 2 : 0]); px[FOLD ? 3 : 0] = __fmaf_rn(v, xa.w, px[FOLD ? 3 : 0]);
-          px[FOLD ? 4 : 0] = __fmaf_rn(v, xb.x, px[FOLD ? 4 : 0]); px[FOLD ? 5 : 0] = __fmaf_rn(v, xb.y, px[FOLD ? 5 : 0]);
-          px[FOLD ? 6 : 0] = __fmaf_rn(v, xb.z, px[FOLD ? 6 : 0]); px[FOLD ? 7 : 0] = __fmaf_rn(v, xb.w, px[FOLD ? 7 : 0]);
+          const float4 xa = xr[0], xb = xr[1];                    // two broadcast ds_read_b128
+          const f2 v2 = {v, v};
+          px[0] = __builtin_elementwise_fma(v2, f2{xa.x, xa.y}, px[0]);   // v_pk_fma_f32
+          px[FOLD ? 1 : 0] = __builtin_elementwise_fma(v2, f2{xa.z, xa.w}, px[FOLD ? 1 : 0]);
+          px[FOLD ? 2 : 0] = __builtin_elementwise_fma(v2, f2{xb.x, xb.y}, px[FOLD ? 2 : 0]);
+          px[FOLD ? 3 : 0] = __builtin_elementwise_fma(v2, f2{xb.z, xb.w}, px[FOLD ? 3 : 0]);
         } else {
           bstore(v, rso, yoff, ((r & 3) + 8 * (r >> 2)) * rowpitch);
         }
@@ -564,7 +566,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
     atomicAdd(&red[KP + dcol], cs2);
     if (FOLD) {
 #pragma unroll
-      for (int k = 0; k < (FOLD ? XW : 1); ++k) atomicAdd(&redP[dcol * XW + k], px[k]);
+      for (int k = 0; k < (FOLD ? XW / 2 : 1); ++k) {
+        atomicAdd(&redP[dcol * XW + 2 * k], px[k].x);
+        atomicAdd(&redP[dcol * XW + 2 * k + 1], px[k].y);
+      }
     }
   }
   __syncthreads();
