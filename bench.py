@@ -209,7 +209,7 @@ def roofline_of(top, pmc_applies=True):
     traffic, traffic_src = None, None
     tf = os.path.join(REPO, "profiles", "r01_hbm_traffic_per_kernel.json")
     kname = {"pn2_mlp_gemm": "mlp_gemm_kernel", "pn2_mlp_wgrad": "mlp_wgrad_kernel",
-             "pn2_mlp_bwd_fused": "mlp_bwd_fused_kernel",
+             "pn2_mlp_bwd_fused": "mlp_bwd_fused_kernel", "pn2_mlp_bwd_fused_fold": "mlp_bwd_fused2_kernel",
              "pn2_bn_relu_rows_max": "bn_relu_rows_max_kernel",
              "pn2_group_concat_rows": "group_concat_rows_kernel",
              "pn2_group_rows_grad": "group_rows_grad_kernel"}.get(top["kernel"])
