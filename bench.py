@@ -143,8 +143,8 @@ def run_steps(net, backbone, opt, pc, steps, prefetcher, on_step=None):
             on_step(i)
         cur = prefetcher.acquire(geo)
         # the next batch's geometry is enqueued BEFORE this batch's forward: it co-runs with the whole step
-        # (measured launch positions: start of the step 20.2 ms, behind sa1's forward 20.7, behind sa2 21.5,
-        # behind the whole forward 22.2-23.3)
+        # (measured launch positions with 512-thread FPS clusters: start of the step 20.2 ms, behind sa1's forward 20.7,
+        # behind sa2 21.5, behind the whole forward 22.2-23.3; with PN2_FPS_FEW_CUS: 18.2 at the start, 18.2 behind the forward)
         nxt = prefetcher.launch(pc)
         train_step(net, opt, pc, cur)
         geo = nxt
