@@ -187,6 +187,19 @@ def test_group_concat_rows(ext, B, N, m, ns, C, use_xyz, normalize):
                                    O.group_rows_grad(go, idx, N, C, col0), atol=1e-4, rtol=1e-4)
 
 
+# high fan-in scatters (every point receives many rows, half of them the repeated first hit of a padded neighbourhood)
+@pytest.mark.parametrize("B,N,m,ns,C,col0", [(32, 512, 256, 16, 256, 3), (16, 1024, 512, 16, 131, 0), (4, 2048, 700, 32, 100, 3),
+                                             (64, 300, 128, 16, 70, 0)])
+def test_group_rows_grad_high_fan_in(ext, B, N, m, ns, C, col0):
+    g = torch.Generator().manual_seed(N + C)
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    idx[:, :, ns // 2:] = idx[:, :, :1]                              # ball-query style padding: repeated first hit
+    go = torch.randn(B, m, ns, col0 + C, generator=g)
+    want = O.group_rows_grad(go, idx, N, C, col0)
+    got = ext.group_rows_grad(dev(go), dev(idx), N, C, col0).cpu()
+    torch.testing.assert_close(got, want, atol=2e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("R,ns,C", [(5, 1, 3), (100, 16, 64), (33, 64, 131)])
 def test_rows_max(ext, R, ns, C):
     g = torch.Generator().manual_seed(R)
