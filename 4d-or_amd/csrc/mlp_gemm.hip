@@ -647,8 +647,10 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
 __global__ void bn_finalize_kernel(int N, double count, const double *__restrict__ stats,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float eps, float momentum, float *__restrict__ running_mean,
-                                   float *__restrict__ running_var, float *__restrict__ out /* [4][N] */) {
+                                   float *__restrict__ running_var, long long *__restrict__ num_batches_tracked,
+                                   float *__restrict__ out /* [4][N] */) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;     // _BatchNorm.forward: num_batches_tracked.add_(1)
   if (c >= N) return;
   const double mean = stats[c] / count;
   double var = stats[N + c] / count - mean * mean;
@@ -674,7 +676,18 @@ __global__ void bn_finalize_kernel(int N, double count, const double *__restrict
 __global__ void bn_bwd_consts_kernel(int N, double count, const double *__restrict__ sums /* [2][N]: dbeta, dgamma */,
                                      const float *__restrict__ gamma, const float *__restrict__ fin /* [4][N] */,
                                      int use_batch_stats, float *__restrict__ consts /* [3][N] */,
-                                     float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                     float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                     const float *__restrict__ W /* [N][K] or null */, int K, int k0,
+                                     float *__restrict__ Wt /* [K - k0][N] */) {
+  // the dgrad GEMM of this layer wants the weight as [K][N] rows (columns k0.. only): transposed here instead of by
+  // a separate copy kernel per layer and step
+  if (W) {
+    const int total = (K - k0) * N;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+      const int k = e / N, n = e - k * N;
+      Wt[e] = W[(size_t)n * K + k0 + k];
+    }
+  }
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N) return;
   const double db = sums[c], dg = sums[N + c];
@@ -1016,21 +1029,29 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
 
 extern "C" int pn2_bn_finalize(int N, double count, const double *stats, const float *gamma,
                                const float *beta, float eps, float momentum, float *running_mean,
-                               float *running_var, float *fin, void *stream) {
+                               float *running_var, long long *num_batches_tracked, float *fin, void *stream) {
   if (N <= 0 || !(count > 0.0)) return PN2_EINVAL;
   if (!stats || !fin) return PN2_ENULL;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N,
-                     count, stats, gamma, beta, eps, momentum, running_mean, running_var, fin);
+                     count, stats, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, fin);
   return pn2_check_launch();
 }
 
 extern "C" int pn2_bn_bwd_consts(int N, double count, const double *sums, const float *gamma,
                                  const float *fin, int use_batch_stats, float *consts, float *dgamma,
-                                 float *dbeta, void *stream) {
+                                 float *dbeta, const float *W, int K, int k0, float *Wt, void *stream) {
   if (N <= 0 || !(count > 0.0)) return PN2_EINVAL;
   if (!sums || !fin || !consts) return PN2_ENULL;
-  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N,
-                     count, sums, gamma, fin, use_batch_stats, consts, dgamma, dbeta);
+  if (W && (!Wt || K <= 0 || k0 < 0 || k0 >= K)) return PN2_EINVAL;
+  // with a weight to transpose: enough 256-thread blocks for ~16 elements per thread (N*K <= 320*2048)
+  unsigned blocks = (unsigned)((N + 127) / 128), threads = 128;
+  if (W) {
+    threads = 256;
+    blocks = (unsigned)(((size_t)N * (K - k0) + 4095) / 4096);
+    if (blocks < (unsigned)((N + 255) / 256)) blocks = (unsigned)((N + 255) / 256);
+  }
+  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, N,
+                     count, sums, gamma, fin, use_batch_stats, consts, dgamma, dbeta, W, K, k0, Wt);
   return pn2_check_launch();
 }
 

@@ -68,8 +68,9 @@ _SIGNATURES = {
                               [_c_int] + [_c_vp] * 4,
     "pn2_rows_gram": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp],
     "pn2_first_layer_dw": [_c_int, _c_int] + [_c_vp] * 6,
-    "pn2_bn_finalize": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp],
-    "pn2_bn_bwd_consts": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_bn_finalize": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_bn_bwd_consts": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int,
+                          _c_vp, _c_vp],
     "pn2_bn_relu_apply": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_bwd_prep": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_rows_max": [ctypes.c_longlong, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -590,22 +591,32 @@ def first_layer_dw(consts, P1, W0, gram):
     return dW0
 
 
-def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None):
+    """fin (4,N) = [mean | rstd | scale | shift]; updates the running statistics in place and, if given, bumps the int64
+    scalar `num_batches_tracked` (what _BatchNorm.forward does with a separate add_ kernel per layer)."""
     N = stats.size(1)
     fin = torch.empty(4, N, dtype=torch.float32, device=stats.device)
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        _fail("bn_finalize: num_batches_tracked must be int64")
     _call("pn2_bn_finalize", stats, N, float(count), _ptr(stats), _ptr(gamma), _ptr(beta), float(eps),
-          float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(fin))
+          float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(fin))
     return fin
 
 
-def bn_bwd_consts(sums, count, gamma, fin, use_batch_stats, want_param_grads=True):
+def bn_bwd_consts(sums, count, gamma, fin, use_batch_stats, want_param_grads=True, W=None, k0=0):
+    """-> (consts (3,N), dgamma, dbeta[, Wt]).  With `W` (N,K) the kernel also writes Wt (K - k0, N) = W[:, k0:]^T, the
+    weight layout the dgrad call of the layer takes."""
     N = sums.size(1)
     consts = torch.empty(3, N, dtype=torch.float32, device=sums.device)
     dgamma = torch.empty(N, dtype=torch.float32, device=sums.device) if want_param_grads else None
     dbeta = torch.empty(N, dtype=torch.float32, device=sums.device) if want_param_grads else None
+    Wt, K = None, 0
+    if W is not None:
+        K = W.size(1)
+        Wt = torch.empty(K - int(k0), N, dtype=torch.float32, device=sums.device)
     _call("pn2_bn_bwd_consts", sums, N, float(count), _ptr(sums), _ptr(gamma), _ptr(fin), int(bool(use_batch_stats)),
-          _ptr(consts), _ptr(dgamma), _ptr(dbeta))
-    return consts, dgamma, dbeta
+          _ptr(consts), _ptr(dgamma), _ptr(dbeta), _ptr(W), int(K), int(k0), _ptr(Wt))
+    return (consts, dgamma, dbeta) if W is None else (consts, dgamma, dbeta, Wt)
 
 
 def bn_relu_apply(y, fin):

@@ -104,13 +104,16 @@ class _FusedMLP(Function):
                 stats = stat_bufs[l]
                 y = e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
                 momentum = 0.0
-                rm = rv = None
+                rm = rv = nbt = None
                 if bn.training and bn.track_running_stats and bn.running_mean is not None:
                     rm, rv = bn.running_mean, bn.running_var
-                    if bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked.add_(1)
-                    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv)
+                    if bn.momentum is not None:
+                        momentum, nbt = bn.momentum, bn.num_batches_tracked       # counter bumped by the finalize kernel
+                    else:                                                       # cumulative average: needs the count on the host
+                        if bn.num_batches_tracked is not None:
+                            bn.num_batches_tracked.add_(1)
+                        momentum = 1.0 / float(bn.num_batches_tracked)
+                fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt)
             else:
                 y = e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
                 rstd = torch.rsqrt(bn.running_var + bn.eps)
@@ -170,7 +173,17 @@ class _FusedMLP(Function):
         grads = [None] * (3 * L)
         gx = None
         for l in range(L - 1, -1, -1):
-            consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
+            one_pass = (l <= 1 and fold) or (l > 0 and FUSED_BACKWARD and
+                                             e.mlp_bwd_fused_supported(Ws[l].size(0), Ws[l].size(1)))
+            Wt = None
+            if not one_pass and (l > 0 or need_dgrad0):
+                # the dgrad GEMM takes the weight as (K, N) rows (feature columns only at a grouped first layer):
+                # transposed by the constants kernel
+                k0 = 3 if (l == 0 and ctx.group is not None and ctx.group[3]) else 0
+                consts, dgamma, dbeta, Wt = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l],
+                                                            W=Ws[l].contiguous(), k0=k0)
+            else:
+                consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l == 1 and fold:
                 sums, dW, P1 = e.mlp_bwd_fused_fold(ys[1], consts, Ws[1].contiguous(), ys[0], fins[0], x, gmode, G=G, arg=arg,
@@ -194,10 +207,7 @@ class _FusedMLP(Function):
             grads[3 * l] = dW.view(ctx.shapes[l])
             need_dgrad = l > 0 or need_dgrad0
             if need_dgrad:
-                Wt = Ws[l].t()                                    # (K_l, N_l): dgrad is out[M,K_l] = gy[M,N_l] @ Wt^T
-                if l == 0 and ctx.group is not None and ctx.group[3]:
-                    Wt = Wt[3:]                                   # feature columns only (skip relative xyz)
-                Wt = Wt.contiguous()
+                # Wt (K_l [- 3], N_l): dgrad is out[M,K_l] = gy[M,N_l] @ Wt^T (feature columns only at a grouped first layer)
                 p = (consts[0], consts[1], consts[2])
                 if l > 0:
                     sums = sums_in[l]

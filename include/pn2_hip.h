@@ -236,10 +236,12 @@ int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, const float *
                   const float *X, const float *a_fin, float *dW, void *stream);
 int pn2_bn_finalize(int N, double count, const double *stats, const float *gamma,
                     const float *beta, float eps, float momentum, float *running_mean,
-                    float *running_var, float *fin, void *stream);
+                    float *running_var, long long *num_batches_tracked /* += 1 if not NULL */, float *fin,
+                    void *stream);
+/* W != NULL: additionally Wt[K - k0][N] = W[N][K0 + ..]^T (the row-major weight the dgrad call of this layer takes) */
 int pn2_bn_bwd_consts(int N, double count, const double *sums, const float *gamma,
                       const float *fin, int use_batch_stats, float *consts, float *dgamma,
-                      float *dbeta, void *stream);
+                      float *dbeta, const float *W, int K, int k0, float *Wt, void *stream);
 int pn2_bn_relu_apply(long long M, int N, const float *y, const float *fin, float *out,
                       void *stream);
 int pn2_bn_relu_bwd_prep(long long M, int N, const float *y, const float *gout,
