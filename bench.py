@@ -454,6 +454,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(net, model, opt, pc, args.steps, prefetcher, on_step)
+    enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to enqueue a step (no GPU wait)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -495,6 +496,7 @@ def main():
                 "global_batch": args.batch * world,
                 "points_per_scene": args.points,
                 "parallelism": f"dp{world}",
+                "host_enqueue_ms_per_step": round(enqueue_ms, 3),
                 "geometry_pipeline": "off" if prefetcher is None else
                 "on: FPS / ball-query / 3-NN of batch i+1 run on a side stream during step i (one geometry per timed step)",
             },
