@@ -6,8 +6,8 @@ than executing them costs the GPU.  ``GraphedTrainStep`` captures
 
     grads <- 0 ; loss, outputs = step_fn(batch) ; loss.backward() ; optimizer.step()
 
-once per batch *signature* (the shapes / dtypes of the batch's tensors, i.e. the number of
-objects and points of a scan) into a hipGraph on the capture stream and replays it afterwards;
+once per batch *signature* (the shapes / dtypes of the batch's tensors — nested dicts / lists of tensors
+such as a prefetched ``batch["geometry"]`` included —, i.e. the number of objects and points of a scan) into a hipGraph on the capture stream and replays it afterwards;
 a new signature is run eagerly once (that call is an ordinary training step and also warms
 every lazily initialised handle) and captured on its next occurrence.
 
@@ -31,8 +31,31 @@ import torch
 import torch.distributed as dist
 
 
+def _tensor_leaves(obj, path=()):
+    """(path, tensor) for every tensor in a nest of dict / list / tuple (e.g. batch["geometry"]), in a fixed order."""
+    if torch.is_tensor(obj):
+        yield path, obj
+    elif isinstance(obj, dict):
+        for k in sorted(obj, key=str):
+            yield from _tensor_leaves(obj[k], path + (k,))
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            yield from _tensor_leaves(v, path + (i,))
+
+
+def _map_tensors(obj, fn):
+    """The same nest with every tensor replaced by fn(tensor)."""
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _map_tensors(v, fn) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map_tensors(v, fn) for v in obj)
+    return obj
+
+
 def batch_signature(batch: Dict[str, Any]) -> Tuple:
-    return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+    return tuple((path, tuple(t.shape), str(t.dtype)) for path, t in _tensor_leaves(batch))
 
 
 class FlatGrads:
@@ -105,9 +128,9 @@ class GraphedTrainStep:
         for k, v in batch.items():
             if not (torch.is_tensor(v) or v is None or isinstance(v, (str, int, float, bool, dict, list, tuple))):
                 raise ValueError(f"batch[{k!r}] ({type(v).__name__}) may hold device tensors whose addresses a graph "
-                                 "would freeze; pass plain tensors and let step_fn derive such objects")
+                                 "would freeze; pass plain tensors (or dicts / lists of them) and let step_fn derive such objects")
         c = _Captured()
-        c.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        c.static = _map_tensors(batch, lambda t: t.clone())       # nested tensors too (e.g. prefetched geometry)
         c.fwd_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(c.fwd_bwd, stream=self._stream):
             self.grads.zero_()
@@ -140,11 +163,11 @@ class GraphedTrainStep:
                 torch.cuda.current_stream().wait_stream(self._stream)
                 return out
             c = self._graphs[sig] = self._capture(batch, sig)
+        for (_, dst), (_, src) in zip(_tensor_leaves(c.static), _tensor_leaves(batch)):
+            dst.copy_(src, non_blocking=True)
         for k, v in batch.items():
-            if torch.is_tensor(v):
-                c.static[k].copy_(v, non_blocking=True)
-            else:
-                c.static[k] = v
+            if not isinstance(v, (torch.Tensor, dict, list, tuple)):
+                c.static[k] = v                                   # plain metadata (scan id, ...) just rides along
         c.fwd_bwd.replay()
         if c.opt is not None:
             self.grads.all_reduce_mean(self.group)

@@ -271,42 +271,45 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     trainable = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(trainable, lr=float(cfg["LR"]), weight_decay=float(cfg["W_DECAY"]), capturable=args.graphs)
     scan = to_device(synthetic_scan(9, 4000, 8000, seed=100 + rank), device)
+    # geometry of the NEXT scan (FPS chains + ball queries of both encoders) on a side stream during this step,
+    # like the backbone workload; the scan-at-a-time loop of the reference knows its next scan from the data loader
+    side = torch.cuda.Stream(device=device) if args.geometry_pipeline else None
+    main = torch.cuda.current_stream(device)
+    state = {"geo": None}
+
+    def launch_geometry():
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            return model.precompute_geometry(scan)
+
+    def with_prefetched_geometry():
+        """This step's batch (geometry enqueued during the previous step) + enqueue the next scan's geometry."""
+        if side is None:
+            return scan
+        if state["geo"] is None:
+            state["geo"] = launch_geometry()
+        main.wait_stream(side)
+        batch = dict(scan, geometry=state["geo"])
+        record_stream_tree(batch["geometry"], main)
+        state["geo"] = launch_geometry()
+        return batch
+
     if args.graphs:
+        # the step (with the geometry as an INPUT: its tensors are copied into the graph's static buffers) is one replay;
+        # the host only enqueues the ~40 geometry kernels of the next scan, the copies and the replay
         from runtime import GraphedTrainStep
         graphed = GraphedTrainStep(model.pure_training_step, trainable, opt)
         args.no_kernel_timing = True          # HIP events cannot be recorded around kernels inside a replay
 
         def step():
-            graphed(scan)
+            graphed(with_prefetched_geometry())
     else:
         net = model
         if distributed:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=64)
 
-        # geometry of the NEXT scan (FPS chains + ball queries of both encoders) on a side stream during this step,
-        # like the backbone workload; the scan-at-a-time loop of the reference knows its next scan from the data loader
-        side = torch.cuda.Stream(device=device) if args.geometry_pipeline else None
-        main = torch.cuda.current_stream(device)
-        state = {"geo": None}
-
-        def launch_geometry():
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                return model.precompute_geometry(scan)
-
         def step():
-            batch = scan
-            if side is not None:
-                if state["geo"] is None:
-                    state["geo"] = launch_geometry()
-                main.wait_stream(side)
-                batch = dict(scan, geometry=state["geo"])
-                for enc in batch["geometry"].values():
-                    for lvl in enc:
-                        for t in [lvl["new_xyz"]] + list(lvl["idx"]):
-                            if t is not None:
-                                t.record_stream(main)
-                state["geo"] = launch_geometry()
+            batch = with_prefetched_geometry()
             opt.zero_grad(set_to_none=True)
             obj, rel = net(batch)
             model.loss(obj, rel, batch).backward()

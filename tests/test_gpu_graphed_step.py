@@ -53,6 +53,26 @@ def test_replayed_gradients_equal_eager_backward_for_two_scan_shapes():
     assert stepper.num_graphs == 2                        # scans 0/1 ran eagerly, 2/3 captured, 4/5 replayed
 
 
+def test_prefetched_geometry_is_a_graph_input():
+    """batch["geometry"] (nested dict of index tensors computed ahead of the step) is copied into the graph's static
+    buffers on every call: replays with the geometry of DIFFERENT scans must reproduce each scan's own eager gradient."""
+    model = _model()
+    ref = copy.deepcopy(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    stepper = GraphedTrainStep(model.pure_training_step, params, torch.optim.SGD(params, lr=0.0))
+    scans = [to_device(synthetic_scan(9, 512, 1024, seed=s), "cuda") for s in (11, 12, 13, 14)]
+    for i, scan in enumerate(scans):
+        batch = dict(scan, geometry=model.precompute_geometry(scan))
+        loss, _ = stepper(batch)
+        ref.zero_grad(set_to_none=True)
+        rl, _ = ref.pure_training_step(scan)              # eager, geometry computed inside the forward
+        rl.backward()
+        want = torch.cat([p.grad.flatten() for p in ref.parameters() if p.requires_grad])
+        assert abs(float(loss) - float(rl.detach())) < 1e-3, i
+        assert _rel(stepper.grads.flat, want) < 1e-2, i   # the geometry of the previous scan would give O(1)
+    assert stepper.num_graphs == 1                        # scan 0 eager, scan 1 captured, scans 2-3 replayed
+
+
 def test_captured_adamw_trajectory_trains():
     model = _model()
     params = [p for p in model.parameters() if p.requires_grad]
