@@ -65,9 +65,11 @@ def main(argv=None):
             opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=model.lr,
                                     weight_decay=float(config["W_DECAY"]), capturable=True)
             graphed = GraphedTrainStep(model.pure_training_step, model.parameters(), opt)
+        from runtime import GeometryPrefetcher
         for epoch in range(args.epochs):
-            for i, scan in enumerate(scans):                  # batch = one scan per step, like main.py:54-56
-                batch = to_device(scan, "cuda")
+            # batch = one scan per step, like main.py:54-56; the next scan's sampling geometry is prefetched on a side stream
+            device_scans = (to_device(scan, "cuda") for scan in scans)
+            for i, batch in enumerate(GeometryPrefetcher(model.precompute_geometry, device_scans)):
                 if args.graphs:
                     loss, rel_pred = graphed(batch)
                     model.update_metrics(batch, rel_pred, split="train")

@@ -92,3 +92,20 @@ def test_non_capturable_adam_is_rejected():
     params = [p for p in model.parameters() if p.requires_grad]
     with pytest.raises(ValueError, match="capturable=True"):
         GraphedTrainStep(model.pure_training_step, params, torch.optim.AdamW(params, lr=1e-3))
+
+
+def test_geometry_prefetcher_yields_identical_steps():
+    """runtime.GeometryPrefetcher: every yielded batch carries its OWN scan's geometry (computed on the side stream) and
+    a forward with it equals the plain forward."""
+    from runtime import GeometryPrefetcher
+    model = _model().eval()
+    scans = [to_device(synthetic_scan(n, 512, 1024, seed=s), "cuda") for n, s in ((9, 21), (7, 22), (9, 23))]
+    seen = 0
+    with torch.no_grad():
+        for scan, batch in zip(scans, GeometryPrefetcher(model.precompute_geometry, iter(scans))):
+            assert batch["obj_points"] is scan["obj_points"] and "geometry" in batch
+            a_obj, a_rel = model(batch)
+            b_obj, b_rel = model(scan)
+            assert torch.equal(a_obj, b_obj) and torch.equal(a_rel, b_rel)
+            seen += 1
+    assert seen == len(scans)
