@@ -77,6 +77,31 @@ def test_fps_every_kernel_variant_agrees_with_oracle(ext, monkeypatch, mode, g, 
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("g", [1, 2, 4])
+@pytest.mark.parametrize("B,N,m,kind", [(2, 100000, 48, "uniform"), (3, 60000, 64, "dup"), (1, 250000, 40, "zero_tail"),
+                                        (64, 30000, 24, "uniform"), (2, 30000, 50, "grid"), (2, 20481, 32, "uniform")])
+def test_fps_cluster_with_streamed_tail_agrees_with_oracle(ext, monkeypatch, g, B, N, m, kind):
+    """Clouds beyond the register capacity of a cluster (BASELINE stress shape 64 x 200k): 20 points per thread stay
+    in registers, the rest is streamed each round (csrc/fps.hip, TAIL) — with a tail, with a one-point tail, and
+    with a cloud that fits entirely (empty tail)."""
+    if B * g > 256:
+        pytest.skip("cluster does not fit")
+    monkeypatch.setenv("PN2_FPS_MODE", "hybrid")
+    monkeypatch.setenv("PN2_FPS_G", str(g))
+    xyz = clouds(B, N, kind, seed=N + B + g)
+    want = O.furthest_point_sampling(xyz, m)
+    got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    assert torch.equal(got, want)
+
+
+def test_fps_stress_shape_uses_the_whole_chip(ext):
+    """64 x 200k -> 64 (the planner picks the streamed-tail cluster by itself): bit-exact on two of the clouds."""
+    xyz = clouds(64, 200000, "uniform", seed=5)
+    got = ext.furthest_point_sampling(dev(xyz), 64).cpu()
+    for b in (0, 63):
+        assert torch.equal(got[b:b + 1], O.furthest_point_sampling(xyz[b:b + 1], 64))
+
+
 @pytest.mark.parametrize("nc,g", [(1, 8), (2, 16), (4, 32), (2, 4), (4, 8)])
 @pytest.mark.parametrize("B,N,m,kind", [(32, 50000, 48, "uniform"), (4, 20000, 100, "dup"), (8, 9000, 64, "zero_tail")])
 def test_fps_multi_cloud_clusters_agree_with_oracle(ext, monkeypatch, nc, g, B, N, m, kind):
