@@ -179,8 +179,24 @@ TIMER = None  # set to a KernelTimer() to profile
 DETAIL_TAGS = os.environ.get("PN2_TIMER_DETAIL") == "1"   # per-shape rows for the MLP kernels
 
 
+_FN = {}
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None, label=None):
     """Enqueue `name` on the current stream of `ref`'s device (`label`: row name in the kernel timer, default `name`)."""
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib, name)
+    dev = ref.device.index
+    # fast path (a step is several hundred of these calls and the host thread is what a scan-sized step waits for): no
+    # device context switch when the tensor's device is the current one, raw stream handle without a Stream object
+    if _raw_stream is not None and (TIMER is None or not TIMER.enabled) and dev == torch.cuda.current_device():
+        rc = fn(*args, _raw_stream(dev))
+        if rc != 0:
+            detail = _lib.pn2_strerror(rc).decode()
+            _fail(f"{name} failed: {detail} (rc={rc}, hipError={_lib.pn2_last_hip_error()})")
+        return
     with torch.cuda.device(ref.device):
         stream = torch.cuda.current_stream(ref.device).cuda_stream
         if TIMER is not None and TIMER.enabled:
