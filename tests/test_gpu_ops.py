@@ -94,6 +94,17 @@ def test_fps_cluster_with_streamed_tail_agrees_with_oracle(ext, monkeypatch, g, 
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("B", [130, 300])
+def test_fps_many_large_clouds(ext, B):
+    """More clouds than a cluster shape admits: 130 x 30k -> one 1024-thread workgroup per cloud with a streamed tail
+    (chosen by the planner itself), 300 x 30k -> the streaming fallback; three clouds checked against the oracle."""
+    xyz = clouds(3, 30000, "dup", seed=B).repeat((B + 2) // 3, 1, 1)[:B].contiguous()
+    got = ext.furthest_point_sampling(dev(xyz), 40).cpu()
+    want = O.furthest_point_sampling(xyz[:3], 40)
+    for b in range(B):
+        assert torch.equal(got[b], want[b % 3]), b
+
+
 def test_fps_stress_shape_uses_the_whole_chip(ext):
     """64 x 200k -> 64 (the planner picks the streamed-tail cluster by itself): bit-exact on two of the clouds."""
     xyz = clouds(64, 200000, "uniform", seed=5)
