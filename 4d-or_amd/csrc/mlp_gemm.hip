@@ -856,14 +856,14 @@ inline unsigned capped_grid(size_t work, int block = 256, unsigned cap = 8192) {
 }
 
 template <int NT, int KC, int CW, int PRO, int EPI>
-void launch_one(const GemmArgs &a, hipStream_t s) {
+void launch_one(const GemmArgs &a, hipStream_t s, int grid_override = 0) {
   // persistent: two workgroups per CU (256 CUs), each walking tiles with stride gridDim.x;
   // N wider than the workgroup's NT*CW column tiles is covered by column blocks (grid.y)
   const long long ntiles = (a.M + BM - 1) / BM;
   const unsigned ny = (unsigned)((a.N + NT * CW * 32 - 1) / (NT * CW * 32));
   // 8-wave workgroups: two per CU; 4-wave workgroups: three (their VGPR / LDS budgets admit it and the
   // third hides the barrier and LDS latencies of the other two: 455 -> 418 us on the 64 -> 64 layer of SA1)
-  long long gx = (CW == 1 ? 768 : 512) / ny;
+  long long gx = (grid_override ? grid_override : (CW == 1 ? 768 : 512)) / ny;
 #ifdef PN2_EXP_CFG
   if (const char *e = getenv("PN2_GEMM_GRID")) gx = atoi(e) / ny;
 #endif
@@ -886,7 +886,14 @@ void launch_by_width(const GemmArgs &a, int tiles, hipStream_t s) {
   } else {
     if (tiles <= 1) launch_one<1, 32, 1, PRO, EPI>(a, s);
     else if (tiles <= 2) launch_one<2, 32, 1, PRO, EPI>(a, s);
-    else if (tiles <= 4) launch_one<2, 32, 2, PRO, EPI>(a, s);
+    else if (tiles <= 4) {
+      // 16-wide K chunks here: 71 instead of 87 VGPRs (80 instead of 96 allocated, blocks of 16) and 36 KB of LDS, so
+      // THREE of these 8-wave workgroups fit a CU (grid 768), and two still fit next to a resident FPS workgroup of the
+      // geometry prefetch: 18.22 -> 18.08 ms/step (6-run means; PN2_GEMM_K32=1 restores the 32-wide variant, grid 512)
+      static const bool k32 = getenv("PN2_GEMM_K32") != nullptr;
+      if (k32) launch_one<2, 32, 2, PRO, EPI>(a, s);
+      else launch_one<2, 16, 2, PRO, EPI>(a, s, 768);
+    }
     else if (tiles <= 6) launch_one<3, 16, 2, PRO, EPI>(a, s);
     else if (tiles <= 8 || tiles > 10) launch_one<4, 16, 2, PRO, EPI>(a, s);   // > 10: column blocks of 256
     else launch_one<5, 16, 2, PRO, EPI>(a, s);
