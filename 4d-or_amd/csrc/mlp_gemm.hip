@@ -887,7 +887,7 @@ void launch_by_width(const GemmArgs &a, int tiles, hipStream_t s) {
     if (tiles <= 1) launch_one<1, 32, 1, PRO, EPI>(a, s);
     else if (tiles <= 2) launch_one<2, 32, 1, PRO, EPI>(a, s);
     else if (tiles <= 4) {
-      // 16-wide K chunks here: 71 instead of 87 VGPRs (80 instead of 96 allocated, blocks of 16) and 36 KB of LDS, so
+      // 16-wide K chunks here: 71 instead of 87 VGPRs and 36 KB of LDS, so
       // THREE of these 8-wave workgroups fit a CU (grid 768), and two still fit next to a resident FPS workgroup of the
       // geometry prefetch: 18.22 -> 18.08 ms/step (6-run means; PN2_GEMM_K32=1 restores the 32-wide variant, grid 512)
       static const bool k32 = getenv("PN2_GEMM_K32") != nullptr;

@@ -37,7 +37,7 @@ def fps_dump(nwg):
 
 def main():
     dev = torch.device("cuda")
-    M, K, N = 32 * 2048 * 64, 64, 128
+    M, K, N = [int(v) for v in os.environ.get("PROBE_SHAPE", "4194304,64,128").split(",")]
     x = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev) * 0.1
     p = (torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1)
