@@ -306,7 +306,8 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     else:
         net = model
         if distributed:
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=64)
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=64,
+                                                            gradient_as_bucket_view=True, broadcast_buffers=False)
 
         def step():
             batch = with_prefetched_geometry()
@@ -413,8 +414,10 @@ def main():
     net = model
     if distributed:
         # gradients only: one flat bucket (650k params = 2.6 MB, latency-bound over xGMI)
+        # BatchNorm statistics stay per rank (no SyncBN: the reference is single-GPU), so the running
+        # buffers are not re-broadcast from rank 0 before every forward either
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=64,
-                                                        gradient_as_bucket_view=True)
+                                                        gradient_as_bucket_view=True, broadcast_buffers=False)
     opt = torch.optim.AdamW(model.parameters(), lr=3e-5, weight_decay=1e-3)
     pc = synthetic_scenes(args.batch, args.points, seed=1000 + rank, device=device)   # resident in HBM
 
