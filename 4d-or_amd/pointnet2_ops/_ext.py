@@ -526,13 +526,34 @@ def zero_arena(device, specs):
         for d in shape:
             n *= int(d)
         offs.append((total, n))
-        total += (n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
-    buf = torch.zeros(total, dtype=torch.uint8, device=device)
+        total += (n * _ELEM[dtype] + 255) // 256 * 256
+    buf = _zero_slab(torch.device(device), total)
     out = []
     for (shape, dtype), (o, n) in zip(specs, offs):
-        nb = n * torch.empty((), dtype=dtype).element_size()
-        out.append(buf[o:o + nb].view(dtype).view(*shape))
+        out.append(buf[o:o + n * _ELEM[dtype]].view(dtype).view(*shape))
     return out
+
+
+_ELEM = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8}
+_SLAB_BYTES = 1 << 20
+_slabs = {}        # (device, stream) -> [zero-filled uint8 slab, bytes handed out]
+_slab_lock = threading.Lock()
+
+
+def _zero_slab(device, nbytes):
+    """`nbytes` of zeros on `device`: carved out of a 1 MB slab that is zero-filled ONCE (one fill kernel per ~50
+    arenas instead of one per arena; every piece is handed out exactly once, the slab dies with its last view)."""
+    # inside a hipGraph capture the fill must be a node of the graph (re-executed by every replay)
+    if nbytes > _SLAB_BYTES // 4 or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    with _slab_lock:                               # forward (main thread) and backward (autograd thread) both carve
+        ent = _slabs.get(key)
+        if ent is None or ent[1] + nbytes > _SLAB_BYTES:
+            ent = _slabs[key] = [torch.zeros(_SLAB_BYTES, dtype=torch.uint8, device=device), 0]
+        o = ent[1]
+        ent[1] = o + nbytes
+        return ent[0][o:o + nbytes]
 
 
 def mlp_wgrad(Yl, consts, X, gmode, amode, G=None, arg=None, gP=None, ns=0, a_fin=None, dW=None):
