@@ -115,10 +115,6 @@ extern "C" int pn2_ball_query(int B, int N, int m, float radius, int nsample,
   int cpw = 1;
   if (centres >= 8192 * 4) cpw = 4;
   else if (centres >= 8192 * 2) cpw = 2;
-  if (const char *e = getenv("PN2_BQ_CPW")) {   // tuning only
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4 || v == 8) cpw = v;
-  }
   const int per_block = 4 * cpw;
   const int bpc = (m + per_block - 1) / per_block;
   if ((long long)bpc * B > 0x7fffffffLL) return PN2_EINVAL;
@@ -129,5 +125,58 @@ extern "C" int pn2_ball_query(int B, int N, int m, float radius, int nsample,
     case 2: hipLaunchKernelGGL((ball_query_kernel<2>), grid, dim3(256), 0, s, N, m, bpc, r2, nsample, new_xyz, xyz, idx); break;
     default: hipLaunchKernelGGL((ball_query_kernel<1>), grid, dim3(256), 0, s, N, m, bpc, r2, nsample, new_xyz, xyz, idx); break;
   }
+  return pn2_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sample_uniformly / ret_unique_cnt of the Group-Free-3D QueryAndGroup (GF3D/pointnet2/pointnet2_utils.py:327-336).
+// The reference walks every (batch, region) on the HOST: torch.unique of the ball-query row, torch.randint over the
+// unique entries for the padded tail, one tiny tensor op at a time.  A ball-query row is already "unique entries in
+// ascending order, then padding with the first hit", so the unique set is the strictly ascending prefix and its length
+// is the count; the padded tail is refilled with uniformly drawn members of that prefix.  One wave per row, a
+// counter-based generator (seed, row, slot) instead of the host's Mersenne stream: same distribution, different draws.
+namespace {
+
+__device__ __forceinline__ unsigned pn2_mix32(unsigned seed, unsigned row, unsigned slot) {
+  unsigned h = seed ^ (row * 0x9E3779B9u) ^ (slot * 0x85EBCA6Bu);
+  h ^= h >> 16; h *= 0x7FEB352Du;
+  h ^= h >> 15; h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return h;
+}
+
+__global__ __launch_bounds__(256) void unique_resample_kernel(long long rows, int ns, unsigned seed,
+                                                             int *__restrict__ idx, float *__restrict__ unique_cnt) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = pn2_lane();
+  int *r = idx + row * ns;
+  int cnt = 0;
+  for (int base = 0; base < ns; base += 64) {
+    const int s = base + lane;
+    bool uniq = false;
+    if (s < ns) uniq = (s == 0) || (r[s] > r[s - 1]);
+    const u64 mask = __ballot(uniq);
+    // the unique entries are a prefix: stop counting at the first non-ascending slot
+    const u64 inv = ~mask & ((ns - base) >= 64 ? ~0ull : ((1ull << (ns - base)) - 1ull));
+    if (inv) { cnt += __ffsll((long long)inv) - 1; break; }
+    cnt += __popcll(mask);
+  }
+  if (unique_cnt && lane == 0) unique_cnt[row] = (float)cnt;
+  for (int s = cnt + lane; s < ns; s += 64)
+    r[s] = r[pn2_mix32(seed, (unsigned)row, (unsigned)s) % (unsigned)cnt];
+}
+
+}  // namespace
+
+extern "C" int pn2_ball_query_unique_resample(long long rows, int nsample, unsigned seed, int *idx, float *unique_cnt,
+                                              void *stream) {
+  if (rows < 0 || nsample < 0) return PN2_EINVAL;
+  if (rows == 0 || nsample == 0) return PN2_OK;
+  if (!idx) return PN2_ENULL;
+  const long long blocks = (rows + 3) / 4;
+  if (blocks > 0x7fffffffLL) return PN2_EINVAL;
+  hipLaunchKernelGGL(unique_resample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, nsample, seed,
+                     idx, unique_cnt);
   return pn2_check_launch();
 }

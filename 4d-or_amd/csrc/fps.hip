@@ -25,8 +25,10 @@
 #include "pn2_common.h"
 
 #include <math.h>
-#include <stdlib.h>
-#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -305,10 +307,6 @@ struct __attribute__((aligned(16))) FpsFinal {
 // lane), scans them back to back, and ONE barrier + ONE hand-off per round moves all NC
 // candidates.  Wave c (< NC) sweeps the granules of cloud c, so the sweeps run in parallel.
 // Cluster q = blockIdx.x % (B/NC) serves clouds q*NC .. q*NC+NC-1; workgroup g = blockIdx.x / (B/NC).
-#ifdef PN2_EXP_CFG
-__device__ unsigned g_fps_hw[2 * 1024];
-__device__ int g_fps_dbg = 0;   // experiments only: 1 = no scan, 2 = no inter-workgroup hand-off, 3 = neither
-#endif
 // TAIL (clouds beyond the register capacity G * BS * PPT of a cluster, e.g. 64 x 200k points on 256 CUs): the first
 // PPT slots of a thread stay in registers, its further points k0 + i * G * BS (i >= PPT — same reference tid, ascending k,
 // so the tie order is unchanged) are streamed from memory each round with their running distances in `tail_td`
@@ -328,13 +326,6 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
   __shared__ unsigned lds_vals[NC][kCoopFields][kCoopMaxG];
   __shared__ FpsFinal lds_fin[2][NC];
 
-#ifdef PN2_EXP_CFG
-  const int dbg = g_fps_dbg;
-  if (threadIdx.x == 0 && blockIdx.x < 1024) {
-    g_fps_hw[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-    g_fps_hw[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-  }
-#endif
   const int nclusters = B / NC;
   const int q = blockIdx.x % nclusters;   // a cluster's workgroups share blockIdx % 8 (one XCD) when nclusters % 8 == 0
   const int g = blockIdx.x / nclusters;
@@ -378,10 +369,6 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
       // two selects, 64-bit key reduction, 3*PPT-select coordinate chain).  The FPS co-runs with the MFMA kernels of
       // the training step and fp32 VALU time is exactly what it takes away from them.
       float best = -1.f;
-#ifdef PN2_EXP_CFG
-      if (dbg & 1) best = lane == 0 ? td[0] : -1.f;
-      else
-#endif
       if constexpr (PPT % 2 == 0) {
         // two points per packed instruction (v_pk_add/mul/fma_f32): the same IEEE operations in the same order as
         // pn2_sq3 — fma(dz, dz, fma(dx, dx, dy * dy)) — on both halves
@@ -524,9 +511,6 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
       const float bx = buf[ws].x, by = buf[ws].y, bz = buf[ws].z;
 
       u64 *par = slots + ((size_t)(q * NC + c) * 2 + (size_t)(j & 1)) * (kCoopFields * kCoopMaxG);
-#ifdef PN2_EXP_CFG
-      if (!(dbg & 2))
-#endif
       if (lane < kCoopFields) {
         unsigned v = lane == 0 ? (unsigned)(bmax >> 32)
                    : lane == 1 ? (unsigned)bmax
@@ -535,16 +519,6 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
         coop_store(par + lane * kCoopMaxG + g, ((u64)(unsigned)j << 32) | v);
       }
       int total = kCoopFields * G;
-#ifdef PN2_EXP_CFG
-      if (dbg & 2) {
-        total = 0;
-        if (lane < kCoopFields) {
-          const unsigned v = lane == 0 ? (unsigned)(bmax >> 32) : lane == 1 ? (unsigned)bmax
-                           : lane == 2 ? __float_as_uint(bx) : lane == 3 ? __float_as_uint(by) : __float_as_uint(bz);
-          for (int gg = 0; gg < G; ++gg) lds_vals[c][lane][gg] = v;
-        }
-      }
-#endif
       bool failed = false;
       for (int qq = 0; qq < total; qq += 64) {
         const int l = qq + lane;
@@ -622,36 +596,57 @@ int round_ppt(int ppt) {
   return -1;
 }
 
-// PN2_FPS_MODE=resident|coop|stream and PN2_FPS_G=<power of two> override the
-// heuristic (tuning / tests only).
+// Test hook (pn2_fps_set_plan_override): force a kernel variant / cluster shape so that every variant can be checked
+// against the oracle on shapes the heuristic would route elsewhere.  Process-global, unset by default; never read from
+// the environment.
+struct FpsOverride {
+  int mode;      // -1 none | 0 resident | 1 cooperative | 2 streaming | 3 cooperative with a streamed tail
+  int G, NC, coop_bs, bs;   // 0 = heuristic
+};
+FpsOverride g_fps_override = {-1, 0, 0, 0, 0};
+
+// Number of CUs of the current device (a CPX/DPX partition reports its own count); every cluster workgroup must be
+// resident at once, so the cluster shapes are sized from this instead of a hard-coded 256.
+int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev] = v;
+  }
+  return cus[dev];
+}
+
 FpsPlan fps_plan(int B, int N, int m, bool few_cus = false) {
   FpsPlan p = {2, 1, 1024, 0, 1};
   if (m <= 1) { p.mode = 0; p.BS = 512; p.PPT = 1; return p; }
-  const char *mode_env = getenv("PN2_FPS_MODE");
-  const char *g_env = getenv("PN2_FPS_G");
-  const bool want_coop = mode_env && !strcmp(mode_env, "coop");
-  const bool want_resident = mode_env && !strcmp(mode_env, "resident");
-  const bool want_stream = mode_env && !strcmp(mode_env, "stream");
+  const FpsOverride ov = g_fps_override;
+  const int ncus = device_cus();
+  const long long max_coop_wgs = 2LL * ncus < kCoopMaxWorkgroups ? 2LL * ncus : kCoopMaxWorkgroups;
+  const bool want_coop = ov.mode == 1;
+  const bool want_resident = ov.mode == 0;
+  const bool want_stream = ov.mode == 2;
   if (want_stream) return p;
 
   // cooperative candidate: NC clouds per cluster (NC | B), G workgroups per cluster, NC*PPT <= 28
   // point slots per lane, (B/NC)*G <= 512 resident workgroups.
   FpsPlan c = {-1, 1, 512, 0, 1};
   {
-    const char *nc_env = getenv("PN2_FPS_NC");
     int best_nc = 1, best_g = 2;
     while (best_g < kCoopMaxG && (N + best_g * 512 - 1) / (best_g * 512) > 16) best_g *= 2;
     // Measured at 32 x 50k -> 2048 (profiles/r01_fps_variant_sweep.jsonl): (NC,G) = (1,8) 5.3 ms,
     // (2,8) 6.8, (2,16) 6.3, (4,16) 6.6, (4,32) 9.7: batching clouds per cluster does NOT pay (the
     // hand-off cost grows with the cluster size and the per-cloud serial work dominates), so the
-    // default stays one cloud per cluster; NC > 1 remains available through PN2_FPS_NC.
+    // default stays one cloud per cluster; NC > 1 remains available through the test hook.
     int G = best_g, NC = best_nc;
-    if (nc_env) {
-      const int want = atoi(nc_env);
+    if (ov.NC) {
+      const int want = ov.NC;
       if ((want == 1 || want == 2 || want == 4) && B % want == 0) { NC = want; G = (best_g / best_nc) * want; }
     }
-    if (g_env) {
-      const int want = atoi(g_env);
+    if (ov.G) {
+      const int want = ov.G;
       if (want >= 2 && want <= kCoopMaxG && (want & (want - 1)) == 0) G = want;
     }
     // few_cus (PN2_FPS_FEW_CUS: the sampling runs on a side stream next to the MFMA kernels of a training step):
@@ -659,18 +654,17 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false) {
     // 32 x 50k -> 2048), but a resident FPS workgroup pins 160 of the 512 VGPRs per lane on its CU for its whole
     // run and halves the occupancy of every co-running 8-wave GEMM workgroup there; on 128 CUs instead of 256 the
     // other half of the chip runs the step undisturbed and the step is 0.8 ms shorter (tools/corun_probe.py).
-    // PN2_FPS_COOP_BS=1024 forces the wide workgroups (tuning only).
     int cbs = 512;
-    if (NC == 1 && !g_env && few_cus && G >= 4) {
+    if (NC == 1 && !ov.G && few_cus && G >= 4) {
       const int wp = round_ppt((N + (G / 2) * 1024 - 1) / ((G / 2) * 1024));
       if (wp >= 8 && wp <= 16) { cbs = 1024; G /= 2; }
     }
-    if (const char *e = getenv("PN2_FPS_COOP_BS")) {
-      if (atoi(e) == 1024 && NC == 1) cbs = 1024;
-    }
+    if (ov.coop_bs == 1024 && NC == 1) cbs = 1024;
     const int ppt = round_ppt((N + G * cbs - 1) / (G * cbs));
     if (NC > 1 && NC * ppt > 28) NC = 1;                  // multi-cloud kernels are built for <= 28 slots
-    if (G <= kCoopMaxG && (long long)(B / NC) * G <= kCoopMaxWorkgroups && ppt > 0 && NC * ppt <= 28 &&
+    // residency: 512-thread cluster workgroups fit at least three to a CU (two are counted on), 1024-thread ones one
+    const long long cap = cbs == 1024 ? (long long)ncus : max_coop_wgs;
+    if (G <= kCoopMaxG && (long long)(B / NC) * G <= cap && ppt > 0 && NC * ppt <= 28 &&
         (cbs == 512 || (ppt >= 8 && ppt <= 16))) {
       c.mode = 1; c.G = G; c.PPT = ppt; c.NC = NC; c.BS = cbs;
     }
@@ -678,14 +672,10 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false) {
   // resident candidate
   // workgroup width: a round is one dependent chain per wave, so fewer, fatter waves win until the scan
   // itself dominates: 256 threads (one wave per SIMD) up to 2048 points, 512 up to 8192, then 1024.
-  // PN2_FPS_BS=256|512|1024 overrides (tuning only).
   FpsPlan r = {-1, 1, 512, 0, 1};
   {
     int bs = N <= 2048 ? 256 : (N <= 512 * 16 ? 512 : 1024);
-    if (const char *e = getenv("PN2_FPS_BS")) {
-      const int want = atoi(e);
-      if (want == 256 || want == 512 || want == 1024) bs = want;
-    }
+    if (ov.bs == 256 || ov.bs == 512 || ov.bs == 1024) bs = ov.bs;
     while (bs < 1024 && (N + bs - 1) / bs > (bs == 256 ? 16 : 16)) bs *= 2;
     if (N <= kFpsResidentMaxN && (N + bs - 1) / bs <= 24) { r.mode = 0; r.BS = bs; r.PPT = round_ppt((N + bs - 1) / bs); }
   }
@@ -695,32 +685,95 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false) {
   FpsPlan h = {-1, 1, 1024, 20, 1};
   {
     int G = 1;
-    while (G * 2 <= kCoopMaxG && (long long)B * (G * 2) <= 256) G *= 2;
-    if (g_env) {
-      const int want = atoi(g_env);
-      if (want >= 1 && want <= kCoopMaxG && (want & (want - 1)) == 0 && (long long)B * want <= kCoopMaxWorkgroups) G = want;
+    while (G * 2 <= kCoopMaxG && (long long)B * (G * 2) <= ncus) G *= 2;
+    if (ov.G) {
+      const int want = ov.G;
+      if (want >= 1 && want <= kCoopMaxG && (want & (want - 1)) == 0 && (long long)B * want <= ncus) G = want;
     }
-    if ((long long)B * G <= kCoopMaxWorkgroups) { h.mode = 3; h.G = G; }
+    if ((long long)B * G <= ncus) { h.mode = 3; h.G = G; }   // 1024 threads x 20 slots: one workgroup per CU
   }
-  const bool want_hybrid = mode_env && !strcmp(mode_env, "hybrid");
+  const bool want_hybrid = ov.mode == 3;
   if (want_hybrid && h.mode == 3) return h;
 
   if (want_coop && c.mode == 1) return c;
   if (want_resident && r.mode == 0) return r;
   if (r.mode == 0 && (N <= 16384 || c.mode != 1)) return r;
   if (c.mode == 1) return c;
-  if (h.mode == 3 && (long long)B * h.G <= 256) return h;
+  if (h.mode == 3) return h;
   return p;
 }
 
+// Every workgroup of a cluster kernel spins on its peers, so the whole grid must be resident at once.  The launch is
+// admitted only if the occupancy the runtime reports for THIS kernel on THIS device covers the grid (one workgroup per
+// CU of margin where more than two fit: the API can answer one high, MI355X_MICROARCH.md "Residency"); otherwise the
+// caller falls back to the streaming kernel.  A CPX/DPX partition reports its own CU count.  Not covered: CU masks
+// set on the stream and other processes sharing the GPU (the bounded spins then raise `status`, which the python
+// layer turns into a device-side assertion).
+bool coop_fits(const void *kernel, int block, unsigned grid) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, int> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  int nb = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({kernel, dev});
+    if (it != cache.end()) nb = it->second;
+    else {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess) nb = 0;
+      (void)hipGetLastError();
+      cache[{kernel, dev}] = nb;
+    }
+  }
+  const int allowed = nb >= 3 ? nb - 1 : nb;
+  return (long long)grid <= (long long)allowed * device_cus();
+}
+
+// Two cluster launches of this process must not overlap (main stream + geometry-prefetch stream): each would hold part
+// of the CUs while waiting for workgroups that cannot become resident.  They are chained through one event per device;
+// inside a stream capture the graph's own edges order them.
+struct CoopSerial {
+  hipStream_t s;
+  hipEvent_t ev = nullptr;
+  explicit CoopSerial(hipStream_t stream) : s(stream) {
+    static std::mutex mu;
+    static hipEvent_t events[64] = {nullptr};
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cs != hipStreamCaptureStatusNone) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!events[dev] && hipEventCreateWithFlags(&events[dev], hipEventDisableTiming) != hipSuccess) {
+        events[dev] = nullptr;
+        (void)hipGetLastError();
+        return;
+      }
+      ev = events[dev];
+    }
+    (void)hipStreamWaitEvent(s, ev, 0);
+  }
+  ~CoopSerial() {
+    if (ev) (void)hipEventRecord(ev, s);
+  }
+};
+
 }  // namespace
 
+extern "C" int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, int bs) {
+  if (mode < -1 || mode > 3 || G < 0 || NC < 0) return PN2_EINVAL;
+  g_fps_override = {mode, G, NC, coop_bs, bs};
+  return PN2_OK;
+}
+
+// cluster plans also reserve the streaming kernel's B x N floats behind the hand-off slots: the fallback when the
+// cluster would not be resident on this device
 extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int m) {
   if (B <= 0 || N <= 0 || m <= 1) return 0;
   const FpsPlan p = fps_plan(B, N, m);
   if (p.mode == 0) return 0;
-  if (p.mode == 1) return (size_t)B * kCoopCloudBytes + 256;
-  if (p.mode == 3) return (size_t)B * kCoopCloudBytes + 256 + (size_t)B * (size_t)N * sizeof(float);
+  if (p.mode == 1 || p.mode == 3) return (size_t)B * kCoopCloudBytes + 256 + (size_t)B * (size_t)N * sizeof(float);
   return (size_t)B * (size_t)N * sizeof(float);
 }
 
@@ -749,31 +802,34 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     if (workspace_bytes < need) return PN2_ENOSPC;
   }
 
+  const size_t head = (size_t)B * kCoopCloudBytes + 256;
+  float *tail = (plan.mode == 1 || plan.mode == 3) ? (float *)((char *)workspace + head) : (float *)workspace;
+  bool fits = true;
   if (plan.mode == 3) {
-    const size_t head = (size_t)B * kCoopCloudBytes + 256;
     u64 *slots = (u64 *)workspace;
     int *status = (int *)((char *)workspace + (size_t)B * kCoopCloudBytes);
-    float *tail = (float *)((char *)workspace + head);
     if (hipMemsetAsync(workspace, 0, head, s) != hipSuccess) return pn2_check_launch();
-    hipLaunchKernelGGL((fps_coop_kernel<1024, 20, 1, true>), dim3((unsigned)(B * plan.G)), dim3(1024), 0, s, B, N, m, L,
-                       plan.G, xyz, idxs, slots, status, tail);
-    return pn2_check_launch();
+    auto kfn = fps_coop_kernel<1024, 20, 1, true>;
+    const unsigned grid = (unsigned)(B * plan.G);
+    if ((fits = coop_fits((const void *)kfn, 1024, grid))) {
+      CoopSerial chain(s);
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(1024), 0, s, B, N, m, L, plan.G, xyz, idxs, slots, status, tail);
+      return pn2_check_launch();
+    }
   }
   if (plan.mode == 1) {
     u64 *slots = (u64 *)workspace;
     int *status = (int *)((char *)workspace + (size_t)B * kCoopCloudBytes);
-    if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return pn2_check_launch();
+    if (hipMemsetAsync(workspace, 0, head, s) != hipSuccess) return pn2_check_launch();
     const dim3 grid((unsigned)((B / plan.NC) * plan.G));
-#ifdef PN2_EXP_CFG
-    {
-      static int last = -1;
-      const int dbg = getenv("PN2_FPS_DBG") ? atoi(getenv("PN2_FPS_DBG")) : 0;
-      if (dbg != last) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fps_dbg), &dbg, sizeof(int)); last = dbg; }
-    }
-#endif
+    CoopSerial chain(s);
 #define PN2_FPS_COOP(PPT, NC)                                                                       \
-  hipLaunchKernelGGL((fps_coop_kernel<512, PPT, NC>), grid, dim3(512), 0, s, B, N, m, L, plan.G,    \
-                     xyz, idxs, slots, status)
+  {                                                                                                 \
+    auto kfn = fps_coop_kernel<512, PPT, NC>;                                                       \
+    if ((fits = coop_fits((const void *)kfn, 512, grid.x)))                                         \
+      hipLaunchKernelGGL(kfn, grid, dim3(512), 0, s, B, N, m, L, plan.G, xyz, idxs, slots, status,  \
+                         (float *)nullptr);                                                         \
+  }
 #define PN2_FPS_COOP_NC(NC)                                                                         \
   switch (plan.PPT) {                                                                               \
     case 1: PN2_FPS_COOP(1, NC); break;                                                             \
@@ -789,8 +845,12 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
   }
     if (plan.BS == 1024) {
 #define PN2_FPS_COOP_W(PPT)                                                                           \
-  hipLaunchKernelGGL((fps_coop_kernel<1024, PPT, 1>), grid, dim3(1024), 0, s, B, N, m, L, plan.G, xyz, idxs, \
-                     slots, status)
+  {                                                                                                   \
+    auto kfn = fps_coop_kernel<1024, PPT, 1>;                                                         \
+    if ((fits = coop_fits((const void *)kfn, 1024, grid.x)))                                          \
+      hipLaunchKernelGGL(kfn, grid, dim3(1024), 0, s, B, N, m, L, plan.G, xyz, idxs, slots, status,   \
+                         (float *)nullptr);                                                           \
+  }
       switch (plan.PPT) {
         case 8: PN2_FPS_COOP_W(8); break;
         case 10: PN2_FPS_COOP_W(10); break;
@@ -822,7 +882,7 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     }
 #undef PN2_FPS_COOP_NC
 #undef PN2_FPS_COOP
-    return pn2_check_launch();
+    if (fits) return pn2_check_launch();
   }
 
 #define PN2_FPS_RES(BS, PPT)                                                                   \
@@ -830,9 +890,8 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     hipLaunchKernelGGL((fps_resident_kernel<BS, PPT>), dim3(B), dim3(BS), 0, s, N, m, L, xyz,  \
                        idxs);                                                                  \
     break;
-  if (plan.mode == 2) {
-    hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(B), dim3(1024), 0, s, N, m, L, xyz,
-                       (float *)workspace, idxs);
+  if (plan.mode == 2 || !fits) {
+    hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(B), dim3(1024), 0, s, N, m, L, xyz, tail, idxs);
   } else if (plan.BS == 256) {
     switch (plan.PPT) {
       PN2_FPS_RES(256, 1) PN2_FPS_RES(256, 2) PN2_FPS_RES(256, 3) PN2_FPS_RES(256, 4)
@@ -860,6 +919,14 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
   return pn2_check_launch();
 }
 
+// Byte offset of the int32 status word inside the workspace of a (B, N, m) call, or -1 when the plan has no
+// inter-workgroup waits.  0 after a clean run, 1 when a bounded wait expired (the remaining indices are then 0).
+extern "C" long long pn2_fps_status_offset(int B, int N, int m) {
+  if (B <= 0 || N <= 0 || m <= 1) return -1;
+  const FpsPlan p = fps_plan(B, N, m);
+  return (p.mode == 1 || p.mode == 3) ? (long long)((size_t)B * kCoopCloudBytes) : -1;
+}
+
 // Test hook: status word of the last cooperative launch that used `workspace`
 // (0 = ok, 1 = a bounded spin expired).  Host-synchronous; not on the hot path.
 extern "C" int pn2_fps_coop_status(int B, const void *workspace, void *stream) {
@@ -872,8 +939,3 @@ extern "C" int pn2_fps_coop_status(int B, const void *workspace, void *stream) {
   return v;
 }
 
-#ifdef PN2_EXP_CFG
-extern "C" __attribute__((visibility("default"))) int pn2_dbg_fps_dump(unsigned *out /* [2*1024] host */) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fps_hw), sizeof(unsigned) * 2 * 1024);
-}
-#endif

@@ -644,9 +644,8 @@ int dispatch_fused(const BwdArgs &a, hipStream_t s) {
   const int ntn = a.N <= 64 ? 2 : 4, ktn = a.K <= 64 ? 2 : 4;
   if (a.X) return (ntn == 2 && ktn == 2) ? launch_fused2<GMODE, 2, true>(a, s) : PN2_EINVAL;
   // N, K <= 64: role-specialised version 2 (1.16 vs 1.31 ms at M = 4.2M); N = 128: version 1 (1.67 vs 2.44 ms —
-  // the two register sets of 64 x 128 gy tiles push version 2 past 256 VGPRs).  PN2_BWD_FUSED_V1=1 forces version 1.
-  if (ntn == 2 && ktn == 2 && !getenv("PN2_BWD_FUSED_V1")) return launch_fused2<GMODE, 2>(a, s);
-  if (ntn == 2 && ktn == 2) return launch_fused<GMODE, 2, 2, 128>(a, s);
+  // the two register sets of 64 x 128 gy tiles push version 2 past 256 VGPRs).
+  if (ntn == 2 && ktn == 2) return launch_fused2<GMODE, 2>(a, s);
   if (ntn == 4 && ktn == 2) return launch_fused<GMODE, 4, 2, 128>(a, s);
   if (ntn == 2 && ktn == 4) return launch_fused<GMODE, 2, 4, 128>(a, s);
   return PN2_EINVAL;
@@ -766,8 +765,7 @@ __global__ void first_layer_dw_kernel(int N, int K0, const float *__restrict__ c
 }  // namespace
 
 extern "C" int pn2_mlp_bwd_fused_fold_supported(int N, int K, int K0) {
-  return N > 32 && N <= 64 && K > 32 && K <= 64 && K0 >= 1 && K0 <= 8 && !getenv("PN2_BWD_FUSED_V1") &&
-         !getenv("PN2_BWD_NOFOLD");
+  return N > 32 && N <= 64 && K > 32 && K <= 64 && K0 >= 1 && K0 <= 8;
 }
 
 extern "C" int pn2_mlp_bwd_fused_fold(long long M, int N, int K, int gmode, const float *G, const float *Yl,

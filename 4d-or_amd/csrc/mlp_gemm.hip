@@ -69,15 +69,8 @@ constexpr int BM = 128;
 //
 // CW = wave columns: the workgroup is 4 x CW waves; wave (wr, wc) owns rows wr*32.. and the
 // NT column tiles wc*NT.. (CW = 2 keeps N = 256/288 at 64-80 accumulator registers per wave).
-#ifdef PN2_EXP_CFG
-// experiments only (tools/corun_probe.py): per-workgroup (start, end, HW_ID, XCC_ID) of the last launch
-__device__ unsigned long long g_gemm_dbg[4 * 4096];
-#endif
 template <int NT, int KC, int CW, int PRO, int EPI>
 __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a) {
-#ifdef PN2_EXP_CFG
-  const unsigned long long dbg_t0 = wall_clock64();
-#endif
   constexpr int THREADS = 256 * CW;
   constexpr int NTT = NT * CW;                 // column tiles per workgroup
   constexpr int LD = KC + 1;
@@ -367,17 +360,6 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   }
   if (total_steps & 1) iteration(0, ra0, rb0, rw0, pa0, pg0, ra1, rb1, rw1, pa1, pg1);
 
-#ifdef PN2_EXP_CFG
-  if (tid == 0) {
-    const unsigned w = blockIdx.x + gridDim.x * blockIdx.y;
-    if (w < 4096) {
-      g_gemm_dbg[4 * w + 0] = dbg_t0;
-      g_gemm_dbg[4 * w + 1] = wall_clock64();
-      g_gemm_dbg[4 * w + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-      g_gemm_dbg[4 * w + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    }
-  }
-#endif
   // ---- flush the column sums once per workgroup ----
   if (EPI != EPI_NONE) {
     for (int i = tid; i < 2 * NTT * 32; i += THREADS) (&red[0][0])[i] = 0.f;
@@ -864,9 +846,6 @@ void launch_one(const GemmArgs &a, hipStream_t s, int grid_override = 0) {
   // 8-wave workgroups: two per CU; 4-wave workgroups: three (their VGPR / LDS budgets admit it and the
   // third hides the barrier and LDS latencies of the other two: 455 -> 418 us on the 64 -> 64 layer of SA1)
   long long gx = (grid_override ? grid_override : (CW == 1 ? 768 : 512)) / ny;
-#ifdef PN2_EXP_CFG
-  if (const char *e = getenv("PN2_GEMM_GRID")) gx = atoi(e) / ny;
-#endif
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   dim3 grid((unsigned)gx, ny);
@@ -889,10 +868,8 @@ void launch_by_width(const GemmArgs &a, int tiles, hipStream_t s) {
     else if (tiles <= 4) {
       // 16-wide K chunks here: 71 instead of 87 VGPRs and 36 KB of LDS, so
       // THREE of these 8-wave workgroups fit a CU (grid 768), and two still fit next to a resident FPS workgroup of the
-      // geometry prefetch: 18.22 -> 18.08 ms/step (6-run means; PN2_GEMM_K32=1 restores the 32-wide variant, grid 512)
-      static const bool k32 = getenv("PN2_GEMM_K32") != nullptr;
-      if (k32) launch_one<2, 32, 2, PRO, EPI>(a, s);
-      else launch_one<2, 16, 2, PRO, EPI>(a, s, 768);
+      // geometry prefetch: 18.22 -> 18.08 ms/step (6-run means; the 32-wide variant ran with a grid of 512)
+      launch_one<2, 16, 2, PRO, EPI>(a, s, 768);
     }
     else if (tiles <= 6) launch_one<3, 16, 2, PRO, EPI>(a, s);
     else if (tiles <= 8 || tiles > 10) launch_one<4, 16, 2, PRO, EPI>(a, s);   // > 10: column blocks of 256
@@ -933,16 +910,6 @@ extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const f
   // served by the same kernels with the reductions compiled out via EPI_NONE on NONE/BNRELU);
   // backward = {GY, POOLG} x {MASK, NONE}
   if (pro == PRO_NONE && epi == EPI_STATS) launch_by_width<PRO_NONE, EPI_STATS>(a, tiles, s);
-#ifdef PN2_EXP_CFG
-  else if (pro == PRO_BNRELU && epi == EPI_STATS && getenv("PN2_GEMM_CFG") &&
-           (!getenv("PN2_GEMM_CFG_TILES") || atoi(getenv("PN2_GEMM_CFG_TILES")) == tiles)) {
-    int nt = 2, kc = 32, cw = 1;
-    sscanf(getenv("PN2_GEMM_CFG"), "%d,%d,%d", &nt, &kc, &cw);
-#define PN2_TRY(NT_, KC_, CW_) if (nt == NT_ && kc == KC_ && cw == CW_) launch_one<NT_, KC_, CW_, PRO_BNRELU, EPI_STATS>(a, s); else
-    PN2_TRY(1, 32, 1) PN2_TRY(2, 32, 1) PN2_TRY(2, 16, 1) PN2_TRY(4, 16, 1) PN2_TRY(4, 32, 1) PN2_TRY(1, 32, 2) PN2_TRY(2, 32, 2)
-    PN2_TRY(2, 16, 2) PN2_TRY(4, 16, 2) PN2_TRY(4, 8, 1) PN2_TRY(2, 8, 1) return PN2_EINVAL;
-  }
-#endif
   else if (pro == PRO_BNRELU && epi == EPI_STATS) launch_by_width<PRO_BNRELU, EPI_STATS>(a, tiles, s);
   else if (pro == PRO_NONE && epi == EPI_NONE) launch_by_width<PRO_NONE, EPI_NONE>(a, tiles, s);
   else if (pro == PRO_BNRELU && epi == EPI_NONE) launch_by_width<PRO_BNRELU, EPI_NONE>(a, tiles, s);
@@ -983,8 +950,7 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
   // K = 32j + (1..3) raw-input columns (relative xyz in front of the features): reduce the leading columns on the
   // VALU side and give the MFMA part the aligned rest, instead of a whole extra pass over g and y for 3 columns
   // (measured: K = 131, M = 1M 0.79 -> 0.55 ms; K = 259, M = 256k 0.31 -> 0.28; below that the extra pass is cheaper)
-  const int koff = (amode == PRO_NONE && kt == 4 && K > 32 && K % 32 >= 1 && K % 32 <= 3 && M >= (1 << 18) &&
-                    !getenv("PN2_WGRAD_NOLEAD")) ? K % 32 : 0;
+  const int koff = (amode == PRO_NONE && kt == 4 && K > 32 && K % 32 >= 1 && K % 32 <= 3 && M >= (1 << 18)) ? K % 32 : 0;
   a.koff = koff;
   const unsigned kblocks = (unsigned)((K - koff + 32 * kt - 1) / (32 * kt));
   long long wgs = 512 / kblocks;
@@ -1111,8 +1077,3 @@ extern "C" int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const fl
   return pn2_check_launch();
 }
 
-#ifdef PN2_EXP_CFG
-extern "C" __attribute__((visibility("default"))) int pn2_dbg_gemm_dump(unsigned long long *out /* [4*4096] host */) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_dbg), sizeof(unsigned long long) * 4 * 4096);
-}
-#endif

@@ -46,12 +46,24 @@ class PointnetSAModuleVotes(nn.Module):
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         new_xyz = pointnet2_utils.gather_operation(
             xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
-        return {"inds": inds, "new_xyz": new_xyz, "idx": self.grouper.query(xyz, new_xyz)}
+        return {"inds": inds, "new_xyz": new_xyz, "idx": self.grouper.query(xyz, new_xyz), "n_src": xyz.size(1)}
+
+    def _check_geometry(self, xyz, geometry):
+        """A prefetched sample_and_query() result must belong to a batch of this shape on this device."""
+        B, dev = xyz.size(0), xyz.device
+        nx, idx, inds = geometry["new_xyz"], geometry["idx"], geometry["inds"]
+        ok = (tuple(nx.shape) == (B, self.npoint, 3) and nx.device == dev
+              and idx.dtype == torch.int32 and tuple(idx.shape) == (B, self.npoint, self.nsample) and idx.device == dev
+              and tuple(inds.shape) == (B, self.npoint) and geometry.get("n_src", xyz.size(1)) == xyz.size(1))
+        if not ok:
+            raise RuntimeError(f"geometry does not match this batch: expected new_xyz ({B},{self.npoint},3), "
+                               f"idx int32 ({B},{self.npoint},{self.nsample}) for clouds of {xyz.size(1)} points on {dev}")
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None, geometry=None):
         """xyz (B,N,3), features (B,C,N) -> (new_xyz (B,npoint,3), new_features (B,C',npoint), inds (B,npoint)).
         `geometry` = result of sample_and_query(xyz) computed earlier (optional)."""
         if geometry is not None and self.pooling == "max" and _pm._rows_path_ok(xyz, features):
+            self._check_geometry(xyz, geometry)
             rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, geometry["new_xyz"],
                                      pointnet2_utils.as_rows(features), idx=geometry["idx"])
             return geometry["new_xyz"], pointnet2_utils.rows_to_channels(rows), geometry["inds"]
@@ -64,11 +76,21 @@ class PointnetSAModuleVotes(nn.Module):
             new_xyz = pointnet2_utils.gather_operation(
                 xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
 
-        if self.pooling == "max" and _pm._rows_path_ok(xyz, features):
-            rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, new_xyz, pointnet2_utils.as_rows(features))
-            return new_xyz, pointnet2_utils.rows_to_channels(rows), inds
+        if self.npoint is not None and _pm._rows_path_ok(xyz, features):
+            idx = self.grouper.query(xyz, new_xyz)
+            feats_rows = pointnet2_utils.as_rows(features)
+            if self.pooling == "max":
+                rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, new_xyz, feats_rows, idx=idx)
+            else:
+                rows = self._pool_rows(xyz, new_xyz, feats_rows, idx)
+            out = (new_xyz, pointnet2_utils.rows_to_channels(rows), inds)
+            return out + (self.grouper.last_unique_cnt,) if self.ret_unique_cnt else out
 
-        grouped, grouped_xyz = self.grouper(xyz, new_xyz, features)
+        unique_cnt = None
+        if self.ret_unique_cnt:
+            grouped, grouped_xyz, unique_cnt = self.grouper(xyz, new_xyz, features)
+        else:
+            grouped, grouped_xyz = self.grouper(xyz, new_xyz, features)
         h = self.mlp_module(grouped)                                   # (B, C', npoint, nsample)
         if self.pooling == "max":
             h = F.max_pool2d(h, kernel_size=[1, h.size(3)])
@@ -77,7 +99,23 @@ class PointnetSAModuleVotes(nn.Module):
         else:  # rbf-weighted mean over the neighbourhood (:244-248)
             rbf = torch.exp(-1 * grouped_xyz.pow(2).sum(1, keepdim=False) / (self.sigma ** 2) / 2)
             h = torch.sum(h * rbf.unsqueeze(1), -1, keepdim=True) / float(self.nsample)
+        if self.ret_unique_cnt:
+            return new_xyz, h.squeeze(-1), inds, unique_cnt
         return new_xyz, h.squeeze(-1), inds
+
+    def _pool_rows(self, xyz, new_xyz, feats_rows, idx):
+        """avg / rbf pooling (:241-248) on the rows path: fused gather kernel -> MFMA shared MLP on point-major rows ->
+        (weighted) mean over each neighbourhood; the rbf weights come from the same (optionally radius-normalised)
+        relative coordinates the grouper emits as `grouped_xyz`."""
+        g = pointnet2_utils.group_concat_rows(xyz, new_xyz, feats_rows, idx, self.use_xyz, self.normalize_xyz, self.radius)
+        B, m, ns, W = g.shape
+        h = _pm.mlp_rows(self.mlp_module, g.reshape(-1, W)).view(B, m, ns, -1)
+        if self.pooling == "avg":
+            return h.mean(dim=2)
+        rel = g[..., :3] if self.use_xyz else pointnet2_utils.group_concat_rows(
+            xyz, new_xyz, None, idx, True, self.normalize_xyz, self.radius)
+        rbf = torch.exp(-1 * rel.pow(2).sum(-1) / (self.sigma ** 2) / 2)          # (B, m, ns)
+        return torch.sum(h * rbf.unsqueeze(-1), dim=2) / float(self.nsample)
 
 
 class PointnetFPModule(_pm.PointnetFPModule):

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "pn2_gather_points": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_gather_points_grad": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_ball_query": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_ball_query_unique_resample": [ctypes.c_longlong, _c_int, ctypes.c_uint, _c_vp, _c_vp],
     "pn2_group_points": [_c_int] * 5 + [_c_vp] * 4,
     "pn2_group_points_grad": [_c_int] * 5 + [_c_vp] * 4,
     "pn2_three_nn": [_c_int] * 3 + [_c_vp] * 5,
@@ -61,6 +62,9 @@ _SIGNATURES = {
     "pn2_gather_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_scatter_add_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_segment_sum_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_segment_bn_rows": [_c_i64, _c_int, _c_int, _c_int, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_f32, _c_int, _c_vp, _c_vp,
+                            _c_vp],
+    "pn2_segment_bn_rows_grad": [_c_i64, _c_int, _c_int, _c_int, _c_i64] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 3,
     "pn2_mlp_gemm": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
     "pn2_mlp_wgrad": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_fused": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
@@ -84,6 +88,10 @@ _lib.pn2_fps_coop_status.argtypes = [_c_int, _c_vp, _c_vp]
 _lib.pn2_fps_coop_status.restype = _c_int
 _lib.pn2_fps_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_workspace_bytes.restype = _c_sz
+_lib.pn2_fps_status_offset.argtypes = [_c_int, _c_int, _c_int]
+_lib.pn2_fps_status_offset.restype = ctypes.c_longlong
+_lib.pn2_fps_set_plan_override.argtypes = [_c_int] * 5
+_lib.pn2_fps_set_plan_override.restype = _c_int
 _lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_supported.restype = _c_int
 _lib.pn2_mlp_bwd_fused_fold_supported.argtypes = [_c_int, _c_int, _c_int]
@@ -95,6 +103,7 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 
 ABI_VERSION = int(_lib.pn2_abi_version())
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
+                                               "pn2_fps_status_offset", "pn2_fps_set_plan_override",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
@@ -247,13 +256,27 @@ def furthest_point_sampling(points, nsamples):
     else:
         _call("pn2_furthest_point_sampling", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
               alg_bytes=B * (12 * N + 4 * nsamples))
-    if ws is not None and os.environ.get("PN2_FPS_CHECK") == "1":
-        # debug/test only (host sync): did a bounded inter-workgroup wait expire?
-        with torch.cuda.device(points.device):
-            st = _lib.pn2_fps_coop_status(B, _ptr(ws), torch.cuda.current_stream(points.device).cuda_stream)
-        if ws_bytes < B * N * 4 and st != 0:
-            _fail(f"pn2_furthest_point_sampling: cooperative kernel reported status {st}")
+    off = int(_lib.pn2_fps_status_offset(B, N, nsamples)) if ws is not None else -1
+    if off >= 0:
+        # a bounded inter-workgroup wait of the cluster kernels expired (CU-masked stream, another process on the GPU):
+        # the remaining indices are zeros.  Checked on the device, asynchronously, in stream order before any consumer.
+        torch._assert_async(ws[off // 4:off // 4 + 1].view(torch.int32) == 0)
     return out
+
+
+_FPS_MODES = {None: -1, "resident": 0, "coop": 1, "stream": 2, "hybrid": 3}
+
+
+@contextlib.contextmanager
+def fps_plan_override(mode=None, g=0, nc=0, coop_bs=0, bs=0):
+    """Test hook (pn2_fps_set_plan_override): force an FPS kernel variant / cluster shape.  Results never depend on it."""
+    rc = _lib.pn2_fps_set_plan_override(_FPS_MODES[mode], int(g), int(nc), int(coop_bs), int(bs))
+    if rc != 0:
+        _fail(f"pn2_fps_set_plan_override failed (rc={rc})")
+    try:
+        yield
+    finally:
+        _lib.pn2_fps_set_plan_override(-1, 0, 0, 0, 0)
 
 
 def gather_points(points, idx):
@@ -290,6 +313,18 @@ def ball_query(new_xyz, xyz, radius, nsample):
     _call("pn2_ball_query", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx),
           alg_bytes=B * (12 * N + 12 * m + 4 * m * nsample))
     return idx
+
+
+def ball_query_unique_resample(idx, seed, want_cnt=True):
+    """idx (B,m,nsample) i32 ball-query rows, IN PLACE: padded tails refilled with uniform draws from each row's unique
+    hits (GF3D sample_uniformly); -> unique_cnt (B,m) f32 or None."""
+    _i32(idx, "idx")
+    _same_device((idx, "idx"))
+    B, m, ns = idx.shape
+    cnt = torch.empty(B, m, dtype=torch.float32, device=idx.device) if want_cnt else None
+    _call("pn2_ball_query_unique_resample", idx, B * m, ns, int(seed) & 0xFFFFFFFF, _ptr(idx), _ptr(cnt),
+          alg_bytes=8 * B * m * ns + 4 * B * m)
+    return cnt
 
 
 def group_points(points, idx):
@@ -488,6 +523,37 @@ def segment_sum_rows(src, order, rowptr, dim_size, h=None, col0=0):
     _call("pn2_segment_sum_rows", src, E, h, int(dim_size), lds, int(col0),
           _ptr(src), _ptr(order), _ptr(rowptr), _ptr(out), alg_bytes=4 * E * h + 16 * E + 4 * int(dim_size) * h)
     return out
+
+
+def segment_bn_rows(x, ptr, gamma, beta, eps, relu, h=None, col0=0):
+    """x (R, ldx)[:, col0:col0+h], ptr (S+1) i64 -> (y (R,h), mean (S,h), rstd (S,h)): BatchNorm1d with the statistics of
+    each row segment (scan) + optional ReLU."""
+    _f32(x, "x"); _i64(ptr, "ptr"); _f32(gamma, "gamma"); _f32(beta, "beta")
+    _same_device((x, "x"), (ptr, "ptr"), (gamma, "gamma"), (beta, "beta"))
+    R, ldx = x.shape
+    C = ldx if h is None else int(h)
+    S = ptr.numel() - 1
+    y = torch.empty(R, C, dtype=torch.float32, device=x.device)
+    mean = torch.empty(S, C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(S, C, dtype=torch.float32, device=x.device)
+    _call("pn2_segment_bn_rows", x, R, C, ldx, int(col0), S, _ptr(x), _ptr(ptr), _ptr(gamma), _ptr(beta), float(eps),
+          int(bool(relu)), _ptr(y), _ptr(mean), _ptr(rstd), alg_bytes=8 * R * C + 8 * S * C)
+    return y, mean, rstd
+
+
+def segment_bn_rows_grad(grad_out, x, ptr, gamma, beta, mean, rstd, relu, col0=0, eps=None):
+    """-> (grad_x (R,C), dgamma (C), dbeta (C)); `eps` is implied by the saved rstd (accepted for interface symmetry)."""
+    _f32(grad_out, "grad_out"); _f32(x, "x"); _i64(ptr, "ptr")
+    _same_device((grad_out, "grad_out"), (x, "x"), (ptr, "ptr"))
+    R, C = grad_out.shape
+    S = ptr.numel() - 1
+    gx = torch.empty(R, C, dtype=torch.float32, device=x.device)
+    dg = torch.empty(S, C, dtype=torch.float32, device=x.device)
+    db = torch.empty(S, C, dtype=torch.float32, device=x.device)
+    _call("pn2_segment_bn_rows_grad", x, R, C, x.size(1), int(col0), S, _ptr(grad_out), _ptr(x), _ptr(ptr), _ptr(gamma),
+          _ptr(beta), _ptr(mean), _ptr(rstd), int(bool(relu)), _ptr(gx), _ptr(dg), _ptr(db),
+          alg_bytes=12 * R * C + 16 * S * C)
+    return gx, dg.sum(0), db.sum(0)
 
 
 # ---------------------------------------------- fused shared-MLP kernels (A10)

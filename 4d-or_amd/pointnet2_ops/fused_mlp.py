@@ -67,7 +67,8 @@ def supported(mlp: nn.Module, x: torch.Tensor, ns: int = 0) -> bool:
     layers = parse_stack(mlp)
     if layers is None:
         return False
-    return all(conv.out_channels <= 320 for conv, _ in layers)
+    # limits of pn2_mlp_gemm / pn2_mlp_wgrad (csrc/mlp_gemm.hip): N <= 320 output and K <= 2048 input channels
+    return all(conv.out_channels <= 320 and conv.in_channels <= 2048 for conv, _ in layers)
 
 
 class _FusedMLP(Function):

@@ -167,7 +167,7 @@ class _PointnetSAModuleBase(nn.Module):
         new_xyz = self._sample(xyz)
         idx = [g.query(xyz, new_xyz) if (new_xyz is not None and isinstance(g, pointnet2_utils.QueryAndGroup)) else None
                for g in self.groupers]
-        return {"new_xyz": new_xyz, "idx": idx}
+        return {"new_xyz": new_xyz, "idx": idx, "n_src": xyz.size(1)}
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor], geometry=None
                 ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
@@ -175,6 +175,7 @@ class _PointnetSAModuleBase(nn.Module):
         (new_xyz (B,npoint,3)|None, new_features (B, sum_k mlps[k][-1], npoint)).
         `geometry` = sample_and_query(xyz) computed earlier (optional; rows path only)."""
         if geometry is not None and _rows_path_ok(xyz, features):
+            self._check_geometry(xyz, geometry)
             return geometry["new_xyz"], self._forward_rows(xyz, geometry["new_xyz"], features, geometry["idx"])
         new_xyz = self._sample(xyz)
         if _rows_path_ok(xyz, features):
@@ -186,6 +187,25 @@ class _PointnetSAModuleBase(nn.Module):
             g = F.max_pool2d(g, kernel_size=[1, g.size(3)])     # (B, C_out, npoint, 1)
             pooled.append(g.squeeze(-1))
         return new_xyz, torch.cat(pooled, dim=1)
+
+    def _check_geometry(self, xyz, geometry):
+        """Cheap invariants of a prefetched `sample_and_query` result: it must belong to a batch of this shape on this
+        device (a stale or re-ordered geometry would otherwise gather out of range or silently mix clouds)."""
+        new_xyz, idx = geometry["new_xyz"], geometry["idx"]
+        B = xyz.size(0)
+        if len(idx) != len(self.groupers):
+            raise RuntimeError("geometry: one ball-query index tensor per scale expected")
+        if self.npoint is not None:
+            if new_xyz is None or tuple(new_xyz.shape) != (B, self.npoint, 3) or new_xyz.device != xyz.device:
+                raise RuntimeError(f"geometry: new_xyz must be ({B}, {self.npoint}, 3) on {xyz.device}")
+        if "n_src" in geometry and geometry["n_src"] != xyz.size(1):
+            raise RuntimeError(f"geometry was computed for clouds of {geometry['n_src']} points, got {xyz.size(1)}")
+        for g, i in zip(self.groupers, idx):
+            if i is None:
+                continue
+            if (i.dtype != torch.int32 or i.device != xyz.device or i.dim() != 3
+                    or tuple(i.shape[:2]) != (B, self.npoint) or i.size(2) != g.nsample):
+                raise RuntimeError(f"geometry: idx must be int32 ({B}, {self.npoint}, {g.nsample}) on {xyz.device}")
 
     def _forward_rows(self, xyz, new_xyz, features, idx=None):
         feats_rows = pointnet2_utils.as_rows(features)

@@ -8,7 +8,7 @@ autograd functions and their functional aliases (``furthest_point_sample``,
 modules keep their names, argument order, tensor layouts and differentiability
 (:36-280, :283-383).  ``QueryAndGroup`` additionally accepts the keyword
 arguments of the Group-Free-3D copy (GF3D/pointnet2/pointnet2_utils.py:301-371:
-``ret_grouped_xyz``, ``normalize_xyz``; ``sample_uniformly`` is rejected).
+``ret_grouped_xyz``, ``normalize_xyz``, ``sample_uniformly``, ``ret_unique_cnt``).
 
 Everything numeric happens in ``_ext`` (libpn2_hip.so).  On top of the literal
 API this file adds the *point-major* ("rows") operators the SA/FP modules use
@@ -31,6 +31,13 @@ __all__ = [
     "grouping_operation", "BallQuery", "ball_query", "QueryAndGroup", "GroupAll",
     "group_concat_rows", "rows_max", "three_interpolate_rows", "as_rows", "rows_to_channels",
 ]
+
+
+def _dense(features):
+    """Feature inputs of the literal ops may be the (B,C,N) *views* of point-major rows that the fast-path modules
+    return (pointnet2_modules._forward_rows); the native ops need dense channel-major memory like the reference's
+    CHECK_CONTIGUOUS (EXT/include/utils.h:5-10).  No copy when the tensor is already contiguous."""
+    return features if features.is_contiguous() else features.contiguous()
 
 
 def _fp32(t):
@@ -64,7 +71,7 @@ class GatherOperation(Function):
     def forward(ctx, features, idx):
         ctx.save_for_backward(idx)
         ctx.n_src = features.size(2)
-        return _ext.gather_points(features, idx)
+        return _ext.gather_points(_dense(features), idx)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -101,7 +108,7 @@ class ThreeInterpolate(Function):
     def forward(ctx, features, idx, weight):
         ctx.save_for_backward(idx, weight)
         ctx.m_src = features.size(2)
-        return _ext.three_interpolate(features, idx, weight)
+        return _ext.three_interpolate(_dense(features), idx, weight)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -119,7 +126,7 @@ class GroupingOperation(Function):
 
     @staticmethod
     def forward(ctx, features, idx):
-        features = _fp32(features)
+        features = _dense(_fp32(features))
         ctx.save_for_backward(idx)
         ctx.n_src = features.size(2)
         return _ext.group_points(features, idx)
@@ -242,16 +249,25 @@ class QueryAndGroup(nn.Module):
     def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False,
                  normalize_xyz=False, sample_uniformly=False, ret_unique_cnt=False):
         super().__init__()
-        if sample_uniformly or ret_unique_cnt:
-            raise NotImplementedError(
-                "sample_uniformly / ret_unique_cnt (host-side torch.unique resampling in "
-                "GF3D/pointnet2/pointnet2_utils.py:327-336) are not on the 4D-OR hot path")
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
         self.ret_grouped_xyz = ret_grouped_xyz
         self.normalize_xyz = normalize_xyz
+        self.sample_uniformly = sample_uniformly
+        self.ret_unique_cnt = ret_unique_cnt
+        if ret_unique_cnt:
+            assert sample_uniformly           # GF3D/pointnet2/pointnet2_utils.py:309-310
+        self.last_unique_cnt = None
 
     def query(self, xyz, new_xyz):
-        return ball_query(self.radius, self.nsample, xyz, new_xyz)
+        """Neighbourhood indices.  With `sample_uniformly` (GF3D :327-336, a host loop of torch.unique + torch.randint
+        per region in the reference) the padded tail of every row is redrawn uniformly from the row's unique hits by
+        one device kernel; the draws come from a counter-based generator seeded from torch's host generator (so
+        torch.manual_seed makes them reproducible) — same distribution as the reference, not the same stream."""
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        if self.sample_uniformly:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)))
+            self.last_unique_cnt = _ext.ball_query_unique_resample(idx, seed, want_cnt=True)
+        return idx
 
     def forward(self, xyz, new_xyz, features=None):
         idx = self.query(xyz, new_xyz)
@@ -266,7 +282,12 @@ class QueryAndGroup(nn.Module):
         else:
             picked = grouping_operation(features, idx)
             grouped = torch.cat([rel, picked], dim=1) if self.use_xyz else picked
-        return (grouped, rel) if self.ret_grouped_xyz else grouped
+        ret = [grouped]
+        if self.ret_grouped_xyz:
+            ret.append(rel)
+        if self.ret_unique_cnt:
+            ret.append(self.last_unique_cnt)          # (B, npoint) f32 on the device (the reference builds it on the host)
+        return ret[0] if len(ret) == 1 else tuple(ret)
 
     def forward_rows(self, xyz, new_xyz, feats_rows=None):
         """Fast path: (B,npoint,nsample,[3+]C) rows in one fused kernel."""

@@ -54,8 +54,27 @@ def _map_tensors(obj, fn):
     return obj
 
 
-def batch_signature(batch: Dict[str, Any]) -> Tuple:
-    return tuple((path, tuple(t.shape), str(t.dtype)) for path, t in _tensor_leaves(batch))
+def _scalar_leaves(obj, path=()):
+    """(path, value) for every int / float / bool below the top level of a nest (e.g. geometry["obj"][0]["n_src"])."""
+    if isinstance(obj, dict):
+        for k in sorted(obj, key=str):
+            yield from _scalar_leaves(obj[k], path + (k,))
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            yield from _scalar_leaves(v, path + (i,))
+    elif isinstance(obj, (bool, int, float)) and len(path) > 1:
+        yield path, obj
+
+
+def batch_signature(batch: Dict[str, Any], static_keys: Iterable[str] = ()) -> Tuple:
+    """What a captured graph is keyed on: shape and dtype of every tensor of the nest, every NESTED python scalar
+    (values a step_fn may branch on, e.g. the point count a prefetched geometry was computed for) and the top-level
+    entries named in `static_keys`.  Other top-level non-tensor entries (scan id, take index, ...) are per-sample
+    metadata: they ride along and must not influence the captured kernels."""
+    sig = [(path, tuple(t.shape), str(t.dtype)) for path, t in _tensor_leaves(batch)]
+    sig += [(path, type(v).__name__, v) for path, v in _scalar_leaves(batch)]
+    sig += [((k,), "static", batch.get(k)) for k in sorted(static_keys)]
+    return tuple(sig)
 
 
 class FlatGrads:
@@ -92,12 +111,21 @@ class GraphedTrainStep:
     """step_fn(batch) -> (loss, outputs) where outputs is a tensor / tuple of tensors / None.
 
     __call__(batch) performs one optimisation step and returns (loss, outputs); with capture
-    on, both are static tensors that the next call with the same signature overwrites."""
+    on, both are static tensors that the next call with the same signature overwrites.
+
+    What a replay freezes, and what is done about it: (1) python values step_fn branches on — nested scalars and the
+    `static_keys` entries are part of the signature (see batch_signature), so a different value captures a different
+    graph; (2) the optimizer's python-float hyper-parameters (lr under a scheduler, weight_decay, betas, eps) are baked
+    into the captured update — they are snapshotted at capture and every call compares them: a change drops the
+    captured graphs and re-captures (pass lr as a device tensor to change it without re-capturing, which a capturable
+    torch optimizer supports)."""
 
     def __init__(self, step_fn: Callable[[Dict[str, Any]], Tuple[torch.Tensor, Any]],
                  params: Iterable[torch.nn.Parameter], optimizer: torch.optim.Optimizer,
-                 capture: bool = True, process_group=None, max_graphs: int = 32):
+                 capture: bool = True, process_group=None, max_graphs: int = 32, static_keys: Iterable[str] = ()):
         self.step_fn, self.optimizer = step_fn, optimizer
+        self.static_keys = tuple(static_keys)
+        self._hyper = None
         self.grads = FlatGrads(params)
         self.group = process_group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
@@ -150,7 +178,10 @@ class GraphedTrainStep:
     def __call__(self, batch: Dict[str, Any]):
         if not self.capture:
             return self._eager(batch)
-        sig = batch_signature(batch)
+        hyper = self._hyper_params()
+        if self._graphs and hyper != self._hyper:
+            self._graphs.clear()                                  # a scheduler / the user changed a baked-in hyper-parameter
+        sig = batch_signature(batch, self.static_keys)
         c = self._graphs.get(sig)
         if c is None:
             n = self._seen.get(sig, 0)
@@ -163,6 +194,7 @@ class GraphedTrainStep:
                 torch.cuda.current_stream().wait_stream(self._stream)
                 return out
             c = self._graphs[sig] = self._capture(batch, sig)
+            self._hyper = hyper
         for (_, dst), (_, src) in zip(_tensor_leaves(c.static), _tensor_leaves(batch)):
             dst.copy_(src, non_blocking=True)
         for k, v in batch.items():
@@ -173,6 +205,18 @@ class GraphedTrainStep:
             self.grads.all_reduce_mean(self.group)
             c.opt.replay()
         return c.loss, c.outputs
+
+    def _hyper_params(self):
+        """Python-number hyper-parameters of every param group (device tensors are read by the graph at replay time)."""
+        out = []
+        for g in self.optimizer.param_groups:
+            for k in sorted(g):
+                v = g[k]
+                if k == "params" or torch.is_tensor(v):
+                    continue
+                if isinstance(v, (bool, int, float)) or (isinstance(v, tuple) and all(isinstance(x, (int, float)) for x in v)):
+                    out.append((k, v))
+        return tuple(out)
 
     @property
     def num_graphs(self) -> int:

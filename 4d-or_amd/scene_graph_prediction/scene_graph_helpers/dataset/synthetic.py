@@ -51,4 +51,27 @@ def synthetic_scan(n_obj=9, points_obj=4000, points_rel=8000, num_class=12, num_
 
 
 def to_device(batch, device):
-    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    return {k: (v.to(device) if (torch.is_tensor(v) or hasattr(v, "node_ptr")) else v) for k, v in batch.items()}
+
+
+def collate_scans(scans):
+    """Several scans -> ONE block-diagonal batch (MI355X-first: the reference's DataLoader has batch_size=1,
+    main.py:54-56, and leaves 90 % of the GPU idle on 9 + 72 small clouds).  Clouds are concatenated along the batch
+    axis, `edge_indices` are offset by each scan's first node row, and `scenes` (a SceneBatch) records the node / edge
+    row ranges so that the GCN's BatchNorm statistics and the loss average stay PER SCAN.  Per-scan metadata becomes
+    lists (`scan_ids`, `objs_jsons`, `take_idxs`)."""
+    from scene_graph_prediction.scene_graph_helpers.model.gcns.network_TripletGCN import SceneBatch
+    node_ptr, edge_ptr = [0], [0]
+    for s in scans:
+        node_ptr.append(node_ptr[-1] + s["obj_points"].size(0))
+        edge_ptr.append(edge_ptr[-1] + s["rel_points"].size(0))
+    batch = {k: torch.cat([s[k] for s in scans], dim=0) for k in
+             ("obj_points", "rel_points", "relation_objects_one_hot", "gt_class", "gt_rels")}
+    batch["edge_indices"] = torch.cat([s["edge_indices"] + off for s, off in zip(scans, node_ptr)], dim=1).contiguous()
+    batch["scenes"] = SceneBatch(torch.tensor(node_ptr), torch.tensor(edge_ptr))
+    batch["scan_ids"] = [s["scan_id"] for s in scans]
+    batch["objs_jsons"] = [s["objs_json"] for s in scans]
+    batch["take_idxs"] = [s.get("take_idx", 0) for s in scans]
+    if all("full_image_features" in s for s in scans):
+        batch["full_image_features"] = torch.stack([s["full_image_features"] for s in scans])     # (S, 6, F)
+    return batch

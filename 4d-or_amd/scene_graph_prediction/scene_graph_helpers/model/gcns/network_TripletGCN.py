@@ -22,6 +22,12 @@ the concatenation buffer; ``pn2_segment_sum_rows`` is a deterministic CSR sum th
 adds in edge order, i.e. bit-identical to a sequential CPU ``scatter_add_``).
 BatchNorm1d layers use batch statistics in train AND eval
 (``track_running_stats=False``, :20), like the reference.
+
+Batched scans (MI355X-first; the reference feeds one scan per step, main.py:54-56): several scans are concatenated
+block-diagonally — node rows, edge rows and ``edge_index`` offset per scan — and described by a ``SceneBatch``.  The
+edge gathers / scatters need nothing else (no edge crosses scans); the BatchNorm1d layers must keep normalising with
+the statistics of EACH scan's rows, which ``pn2_segment_bn_rows`` does in one launch (+ReLU), so a batch of S scans gives
+exactly the S single-scan results.
 """
 from typing import Optional, Tuple
 
@@ -86,6 +92,68 @@ class EdgeCSR:
         return self
 
 
+class SceneBatch:
+    """Row ranges of the scans of a block-diagonal batch: ``node_ptr`` / ``edge_ptr`` (S+1) int64 offsets into the node
+    and edge rows, plus the per-row scan ids the loss needs.  Built on the host by the collate step
+    (dataset/synthetic.py::collate_scans); moving it to the device is asynchronous."""
+
+    def __init__(self, node_ptr: torch.Tensor, edge_ptr: torch.Tensor):
+        self.node_ptr = node_ptr.to(torch.int64).contiguous()
+        self.edge_ptr = edge_ptr.to(torch.int64).contiguous()
+        if self.node_ptr.numel() != self.edge_ptr.numel() or self.node_ptr.numel() < 2:
+            raise RuntimeError("SceneBatch: node_ptr and edge_ptr must both have S + 1 entries")
+        self.num_scenes = self.node_ptr.numel() - 1
+        counts_n = self.node_ptr[1:] - self.node_ptr[:-1]
+        counts_e = self.edge_ptr[1:] - self.edge_ptr[:-1]
+        ids = torch.arange(self.num_scenes, device=self.node_ptr.device)
+        self.node_scene = torch.repeat_interleave(ids, counts_n)
+        self.edge_scene = torch.repeat_interleave(ids, counts_e)
+
+    def to(self, device):
+        other = object.__new__(SceneBatch)
+        other.num_scenes = self.num_scenes
+        for k in ("node_ptr", "edge_ptr", "node_scene", "edge_scene"):
+            setattr(other, k, getattr(self, k).to(device, non_blocking=True))
+        return other
+
+
+class _SegmentBNReLU(Function):
+    """BatchNorm1d(track_running_stats=False) [+ ReLU] with per-scan statistics (one launch for all scans)."""
+
+    @staticmethod
+    def forward(ctx, x, ptr, gamma, beta, eps, relu):
+        x = x.contiguous()
+        y, mean, rstd = _ext.segment_bn_rows(x, ptr, gamma, beta, eps, relu)
+        ctx.save_for_backward(x, ptr, gamma, beta, mean, rstd)
+        ctx.relu, ctx.eps = relu, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ptr, gamma, beta, mean, rstd = ctx.saved_tensors
+        gx, dgamma, dbeta = _ext.segment_bn_rows_grad(g.contiguous(), x, ptr, gamma, beta, mean, rstd, ctx.relu, eps=ctx.eps)
+        return gx, None, dgamma, dbeta, None, None
+
+
+def mlp_per_scene(mlp: torch.nn.Sequential, x: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+    """Run a `build_mlp` stack on block-diagonally batched rows: Linear layers see all rows at once (rocBLAS), every
+    BatchNorm1d (+ the ReLU behind it) normalises each scan's rows [ptr[s], ptr[s+1]) separately."""
+    layers = list(mlp)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
+        if isinstance(layer, torch.nn.BatchNorm1d):
+            if layer.track_running_stats or not layer.affine:
+                raise NotImplementedError("per-scene BatchNorm1d: build_mlp layers only (affine, no running statistics)")
+            relu = i + 1 < len(layers) and isinstance(layers[i + 1], torch.nn.ReLU)
+            x = _SegmentBNReLU.apply(x, ptr, layer.weight, layer.bias, layer.eps, relu)
+            i += 2 if relu else 1
+        else:
+            x = layer(x)
+            i += 1
+    return x
+
+
 class _TripletConcat(Function):
     """cat[x[dst], e, x[src]] -> (E, 2*dn + de), gathers written in place."""
 
@@ -132,17 +200,20 @@ class TripletGCN(torch.nn.Module):
                              do_bn=use_bn, on_last=True)
         self.nn2 = build_mlp([dim_hidden, dim_hidden, dim_node], do_bn=use_bn)
 
-    def forward(self, x, edge_feature, edge_index, csr: Optional[EdgeCSR] = None):
+    def forward(self, x, edge_feature, edge_index, csr: Optional[EdgeCSR] = None, scenes: Optional[SceneBatch] = None):
         csr = csr if csr is not None else EdgeCSR(edge_index, x.size(0))
-        gcn_x, gcn_e = self.propagate(csr, x=x, edge_feature=edge_feature)
+        gcn_x, gcn_e = self.propagate(csr, x=x, edge_feature=edge_feature, scenes=scenes)
+        if scenes is not None:
+            return mlp_per_scene(self.nn2, gcn_x, scenes.node_ptr), gcn_e
         return self.nn2(gcn_x), gcn_e
 
-    def propagate(self, csr, x, edge_feature):
-        node_msg, new_e = self.message(csr, x, edge_feature)
+    def propagate(self, csr, x, edge_feature, scenes=None):
+        node_msg, new_e = self.message(csr, x, edge_feature, scenes)
         return self.aggregate(node_msg, csr), new_e
 
-    def message(self, csr, x, edge_feature):
-        h = self.nn1(_TripletConcat.apply(x, edge_feature, csr))
+    def message(self, csr, x, edge_feature, scenes=None):
+        cat = _TripletConcat.apply(x, edge_feature, csr)
+        h = mlp_per_scene(self.nn1, cat, scenes.edge_ptr) if scenes is not None else self.nn1(cat)
         dh, de = self.dim_hidden, self.dim_edge
         return h[:, :dh] + h[:, dh + de:], h[:, dh:dh + de]
 
@@ -158,13 +229,15 @@ class TripletGCNModel(BaseNetwork):
         self.num_layers = num_layers
         self.gconvs = torch.nn.ModuleList(TripletGCN(**kwargs) for _ in range(num_layers))
 
-    def forward(self, node_feature, edge_feature, edges_indices, csr: Optional[EdgeCSR] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, node_feature, edge_feature, edges_indices, csr: Optional[EdgeCSR] = None,
+                scenes: Optional[SceneBatch] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """`csr` (optional) is an EdgeCSR of `edges_indices` prepared ahead of time (e.g. by the data
-        loader, on the host); without it the CSR is built here, sync-free, once per call."""
+        loader, on the host); without it the CSR is built here, sync-free, once per call.
+        `scenes` (optional): the rows are S scans batched block-diagonally; BatchNorm statistics stay per scan."""
         if csr is None:
             csr = EdgeCSR(edges_indices, node_feature.size(0))
         for i, gconv in enumerate(self.gconvs):
-            node_feature, edge_feature = gconv(node_feature, edge_feature, edges_indices, csr)
+            node_feature, edge_feature = gconv(node_feature, edge_feature, edges_indices, csr, scenes)
             if i < self.num_layers - 1:
                 node_feature = torch.nn.functional.relu(node_feature)
                 edge_feature = torch.nn.functional.relu(edge_feature)

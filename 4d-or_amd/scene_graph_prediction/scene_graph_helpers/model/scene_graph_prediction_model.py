@@ -10,8 +10,14 @@ constructor signature (:31), sub-module names / ``state_dict`` keys
 ``configure_optimizers`` (:240-242).  The reference derives from
 pytorch_lightning.LightningModule (harness; not installed and out of scope):
 this class is a plain ``nn.Module`` exposing the same step methods so any loop
-(ours: bench.py / the DDP runner) can drive it.  ``IMAGE_INPUT == 'full'``
-(timm EfficientNet-B5 late fusion) is rejected: stock-torch 2-D CNN, out of scope.
+(ours: bench.py / the DDP runner) can drive it.
+
+``IMAGE_INPUT == 'full'`` (:47-55, :96-100): the 2-D CNN itself (timm ``tf_efficientnet_b5_ns``, stock torch, absent
+offline) is out of scope, but everything after it is here — ``full_image_feature_reduction`` (Linear
+``num_features -> FULL_IMAGE_EMBEDDING_SIZE // 6``), the flatten over the six views and the late fusion in
+``PointNetRelCls`` — so the ``no_gt_image`` checkpoints load (``full_image_model.*`` entries are skipped unless a CNN
+was attached with ``attach_image_model``).  The batch then carries either ``full_image`` (6,3,H,W; needs an attached
+CNN) or ``full_image_features`` (6, num_features) computed by it ahead of time.
 """
 from collections import defaultdict
 
@@ -38,17 +44,63 @@ class SGPNModelWrapper(nn.Module):
         self.relationNames = relationNames
         self.lr = float(self.config["LR"])
         self.reset_metrics()
-        if self.config["IMAGE_INPUT"] == "full":
-            raise NotImplementedError("IMAGE_INPUT='full' needs timm's EfficientNet-B5 (out of scope, absent offline)")
-
         m = self.mconfig
+        self.with_images = self.config["IMAGE_INPUT"] == "full"
+        self.full_image_model = None
         self.obj_encoder = PointNetfeat2(input_dim=6, out_size=m["point_feature_size"], input_dropout=m["INPUT_DROPOUT"])
         self.rel_encoder = PointNetfeat2(input_dim=7, out_size=m["edge_feature_size"], input_dropout=m["INPUT_DROPOUT"])
         self.gcn = TripletGCNModel(num_layers=m["N_LAYERS"], dim_node=m["point_feature_size"],
                                    dim_edge=m["edge_feature_size"], dim_hidden=m["gcn_hidden_feature_size"])
         self.obj_predictor = PointNetCls(num_class, in_size=m["point_feature_size"], batch_norm=False, drop_out=True)
+        if self.with_images:
+            # EfficientNet-B5's `num_features` (2048) unless the config says otherwise (reference :57)
+            self.full_image_feature_reduction = nn.Linear(int(m.get("IMAGE_MODEL_NUM_FEATURES", 2048)),
+                                                          m["FULL_IMAGE_EMBEDDING_SIZE"] // 6)
         self.rel_predictor = PointNetRelCls(num_rel, in_size=m["edge_feature_size"], batch_norm=False, drop_out=True,
-                                            image_embedding_size=None, n_object_types=self.n_object_types)
+                                            image_embedding_size=m["FULL_IMAGE_EMBEDDING_SIZE"] if self.with_images else None,
+                                            n_object_types=self.n_object_types)
+
+    # ------------------------------------------------------------------ image branch (late fusion only)
+    def attach_image_model(self, cnn: nn.Module):
+        """Plug in the 2-D backbone (any module mapping (6,3,H,W) -> (6, num_features)); frozen except `conv_head`
+        and with its BatchNorms in eval mode, like the reference (:51-55, :74-85)."""
+        self.full_image_model = cnn
+        for p in cnn.parameters():
+            p.requires_grad = False
+        head = getattr(cnn, "conv_head", None)
+        if head is not None:
+            for p in head.parameters():
+                p.requires_grad = True
+        return self
+
+    def freeze_image_model_batchnorm(self):
+        if self.full_image_model is None:
+            return
+        for module in self.full_image_model.modules():
+            if isinstance(module, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                if getattr(module, "weight", None) is not None:
+                    module.weight.requires_grad_(False)
+                if getattr(module, "bias", None) is not None:
+                    module.bias.requires_grad_(False)
+                module.eval()
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        if self.with_images and self.full_image_model is None:
+            state_dict = {k: v for k, v in state_dict.items() if not k.startswith("full_image_model.")}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _image_embedding(self, batch):
+        if "full_image_features" in batch:
+            feats = batch["full_image_features"]
+        elif self.full_image_model is not None:
+            self.freeze_image_model_batchnorm()
+            feats = self.full_image_model(batch["full_image"])
+        else:
+            raise RuntimeError("IMAGE_INPUT='full': the batch needs 'full_image_features' (6, num_features), or attach the "
+                               "2-D CNN with attach_image_model() and pass 'full_image'")
+        if feats.dim() == 3:                                        # (S, 6, F): one embedding per scan of a batch
+            return self.full_image_feature_reduction(feats).flatten(1)
+        return self.full_image_feature_reduction(feats).flatten()
 
     # ------------------------------------------------------------------ forward
     def precompute_geometry(self, batch):
@@ -61,17 +113,46 @@ class SGPNModelWrapper(nn.Module):
         geo = batch.get("geometry")
         obj_feature = self.obj_encoder(batch["obj_points"], geometry=None if geo is None else geo["obj"])
         rel_feature = self.rel_encoder(batch["rel_points"], geometry=None if geo is None else geo["rel"])
-        gcn_obj_feature, gcn_rel_feature = self.gcn(obj_feature, rel_feature, batch["edge_indices"], batch.get("edge_csr"))
+        scenes = batch.get("scenes")          # block-diagonal batch of several scans (dataset/synthetic.py::collate_scans)
+        gcn_obj_feature, gcn_rel_feature = self.gcn(obj_feature, rel_feature, batch["edge_indices"], batch.get("edge_csr"),
+                                                    scenes=scenes)
         obj_cls = self.obj_predictor(gcn_obj_feature if self.mconfig["OBJ_PRED_FROM_GCN"] else obj_feature)
-        rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=batch["relation_objects_one_hot"])
+        if self.with_images:
+            emb = self._image_embedding(batch)
+            if emb.dim() == 2:                                      # batched scans: every edge gets its own scan's embedding
+                emb = emb[scenes.edge_scene]
+                rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=torch.cat(
+                    [emb, batch["relation_objects_one_hot"]], dim=1))
+            else:
+                rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=batch["relation_objects_one_hot"],
+                                             image_embeddings=emb)
+        else:
+            rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=batch["relation_objects_one_hot"])
         if return_meta_data:
             return obj_cls, rel_cls, obj_feature, rel_feature, gcn_obj_feature, gcn_rel_feature, None
         return obj_cls, rel_cls
 
     # ------------------------------------------------------------------ steps
+    @staticmethod
+    def _nll_per_scene(logp, target, weight, scene, num_scenes):
+        """Weighted NLL averaged PER SCAN, then over the scans: what the reference's one-scan steps optimise on
+        average (F.nll_loss(weight=...) divides by the sum of the target weights of that scan)."""
+        w = weight[target]
+        picked = -logp.gather(1, target.unsqueeze(1)).squeeze(1) * w
+        num = torch.zeros(num_scenes, dtype=logp.dtype, device=logp.device).index_add_(0, scene, picked)
+        den = torch.zeros(num_scenes, dtype=logp.dtype, device=logp.device).index_add_(0, scene, w)
+        return (num / den).mean()
+
     def loss(self, obj_pred, rel_pred, batch):
-        loss_obj = F.nll_loss(obj_pred, batch["gt_class"], weight=self.weights_obj.to(batch["gt_class"].device, non_blocking=True))
-        loss_rel = F.nll_loss(rel_pred, batch["gt_rels"], weight=self.weights_rel.to(batch["gt_rels"].device, non_blocking=True))
+        w_obj = self.weights_obj.to(batch["gt_class"].device, non_blocking=True)
+        w_rel = self.weights_rel.to(batch["gt_rels"].device, non_blocking=True)
+        scenes = batch.get("scenes")
+        if scenes is not None:
+            loss_obj = self._nll_per_scene(obj_pred, batch["gt_class"], w_obj, scenes.node_scene, scenes.num_scenes)
+            loss_rel = self._nll_per_scene(rel_pred, batch["gt_rels"], w_rel, scenes.edge_scene, scenes.num_scenes)
+        else:
+            loss_obj = F.nll_loss(obj_pred, batch["gt_class"], weight=w_obj)
+            loss_rel = F.nll_loss(rel_pred, batch["gt_rels"], weight=w_rel)
         return self.mconfig["lambda_o"] * loss_obj + loss_rel
 
     def _step(self, batch, split):
@@ -92,12 +173,27 @@ class SGPNModelWrapper(nn.Module):
         predicted = torch.max(rel_pred.detach(), 1)[1].cpu().tolist()
         none_id = self.relationNames.index("none")
         edges = batch["edge_indices"].transpose(0, 1).cpu().tolist()
-        triples = []
-        for (start, end), rel in zip(edges, predicted):
-            if rel == none_id:
-                continue
-            triples.append((batch["objs_json"][start + 1], self.relationNames[rel], batch["objs_json"][end + 1]))
-        return batch["scan_id"], triples
+        scenes = batch.get("scenes")
+        if scenes is None:
+            triples = []
+            for (start, end), rel in zip(edges, predicted):
+                if rel == none_id:
+                    continue
+                triples.append((batch["objs_json"][start + 1], self.relationNames[rel], batch["objs_json"][end + 1]))
+            return batch["scan_id"], triples
+        # block-diagonal batch: one (scan_id, triples) per scan, node ids local to the scan again
+        node_ptr, edge_ptr = scenes.node_ptr.cpu().tolist(), scenes.edge_ptr.cpu().tolist()
+        out = []
+        for s in range(scenes.num_scenes):
+            objs, off, triples = batch["objs_jsons"][s], node_ptr[s], []
+            for e in range(edge_ptr[s], edge_ptr[s + 1]):
+                rel = predicted[e]
+                if rel == none_id:
+                    continue
+                start, end = edges[e]
+                triples.append((objs[start - off + 1], self.relationNames[rel], objs[end - off + 1]))
+            out.append((batch["scan_ids"][s], triples))
+        return out
 
     def configure_optimizers(self, capturable=False):
         """AdamW(lr=LR, weight_decay=W_DECAY) (reference :240-242); `capturable` keeps the step counters on
@@ -122,9 +218,17 @@ class SGPNModelWrapper(nn.Module):
             raise NotImplementedError()
         preds = getattr(self, f"{split}_take_rel_preds")
         gts = getattr(self, f"{split}_take_rel_gts")
-        take = batch.get("take_idx", 0)
-        preds[take].extend(rel_pred.detach().cpu().numpy().argmax(1))
-        gts[take].extend(batch["gt_rels"].detach().cpu().numpy())
+        p, g = rel_pred.detach().cpu().numpy().argmax(1), batch["gt_rels"].detach().cpu().numpy()
+        scenes = batch.get("scenes")
+        if scenes is None:
+            take = batch.get("take_idx", 0)
+            preds[take].extend(p)
+            gts[take].extend(g)
+            return
+        edge_ptr = scenes.edge_ptr.cpu().tolist()
+        for s, take in enumerate(batch.get("take_idxs", [0] * scenes.num_scenes)):
+            preds[take].extend(p[edge_ptr[s]:edge_ptr[s + 1]])
+            gts[take].extend(g[edge_ptr[s]:edge_ptr[s + 1]])
 
     def evaluate_predictions(self, epoch_loss, split):
         """Per-take and overall precision / recall / F1 (sklearn classification_report, like the

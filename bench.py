@@ -236,11 +236,23 @@ def roofline_of(top, pmc_applies=True):
     return roof
 
 
-def cpu_baseline(points, sample_scenes, threads, workload="backbone"):
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(points, sample_scenes, threads, workload="backbone", repeats=5):
     """Same stack, same step, on the host: oracle port (C/OpenMP restatement of the nine
-    native ops) + stock-torch CPU MLPs.  Bounded sample; reported, never optimised."""
+    native ops) + stock-torch CPU MLPs.  Protocol of SURVEY.md 8d: one warm-up, then the MEDIAN of `repeats` runs,
+    forward-only and forward + backward + AdamW, all host cores.  Bounded sample; reported, never optimised."""
     from pointnet2_ops import pointnet2_utils as pu
     import oracle_ext
+    import statistics
     torch.set_num_threads(threads)
     saved = pu._ext
     pu._ext = oracle_ext.OracleRowsExt
@@ -248,21 +260,36 @@ def cpu_baseline(points, sample_scenes, threads, workload="backbone"):
         model = build_model("cpu", workload)
         opt = torch.optim.AdamW(model.parameters(), lr=3e-5, weight_decay=1e-3)
         pc = synthetic_scenes(sample_scenes, points, seed=1234, device="cpu")
-        t0 = time.perf_counter()
-        train_step(model, opt, pc)
-        dt = time.perf_counter() - t0
+        t_all = time.perf_counter()
+        train_step(model, opt, pc)                                   # warm-up (allocator, OpenMP pool, oneDNN primitives)
+        step_s, fwd_s = [], []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            train_step(model, opt, pc)
+            step_s.append(time.perf_counter() - t0)
+        with torch.no_grad():
+            for _ in range(repeats):
+                t0 = time.perf_counter()
+                model(pc)
+                fwd_s.append(time.perf_counter() - t0)
+        wall = time.perf_counter() - t_all
     finally:
         pu._ext = saved
+    dt, df = statistics.median(step_s), statistics.median(fwd_s)
     return {"value": round(sample_scenes / dt, 4), "unit": "scenes/s", "cores": threads, "kind": "port",
-            "sample": f"{sample_scenes} scenes x {points} pts, 1 fwd+bwd+AdamW step, {dt:.1f} s wall "
-                      f"(oracle ops are OpenMP-parallel over scenes; MLPs torch CPU with {threads} threads)"}
+            "forward_only_value": round(sample_scenes / df, 4), "cpu_model": cpu_model_name(),
+            "median_step_s": round(dt, 3), "median_forward_s": round(df, 3), "repeats": repeats,
+            "sample": f"{sample_scenes} scenes x {points} pts; 1 warm-up + median of {repeats} fwd+bwd+AdamW steps and of "
+                      f"{repeats} train-mode forwards, {wall:.1f} s of CPU work in total (oracle ops are OpenMP-parallel "
+                      f"over scenes; MLPs torch CPU with {threads} threads)"}
 
 
 def bench_sgp(args, device, rank, world, distributed, _ext):
     """BASELINE configs[2] shape on one or more GPUs: SGPNModelWrapper (2 MSG encoders + 2-layer
-    TripletGCN + heads), one synthetic scan per step and rank, fwd + loss + bwd + AdamW, fp32."""
+    TripletGCN + heads), `--scans-per-step` synthetic scans per step and rank (block-diagonal batch, per-scan GCN
+    BatchNorm statistics and loss average; 1 = the reference's DataLoader(batch_size=1)), fwd + loss + bwd + AdamW."""
     from scene_graph_prediction.main import RELATION_NAMES, config_loader
-    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import synthetic_scan, to_device
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan, to_device
     from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
     cfg = config_loader("no_gt.json")
     torch.manual_seed(0)
@@ -274,7 +301,12 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
             p.requires_grad_(False)
     trainable = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(trainable, lr=float(cfg["LR"]), weight_decay=float(cfg["W_DECAY"]), capturable=args.graphs)
-    scan = to_device(synthetic_scan(9, 4000, 8000, seed=100 + rank), device)
+    S = max(1, int(args.scans_per_step))
+    if S == 1:
+        scan = to_device(synthetic_scan(9, 4000, 8000, seed=100 + rank), device)
+    else:
+        scan = to_device(collate_scans([synthetic_scan(9, 4000, 8000, seed=100 + rank * S + i, scan_id=f"synthetic_{i:06d}")
+                                        for i in range(S)]), device)
     # geometry of the NEXT scan (FPS chains + ball queries of both encoders) on a side stream during this step,
     # like the backbone workload; the scan-at-a-time loop of the reference knows its next scan from the data loader
     side = torch.cuda.Stream(device=device) if args.geometry_pipeline else None
@@ -346,11 +378,13 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     elapsed = float(t.item())
     if rank == 0:
         out = {"metric": "OR scans/sec fwd+bwd (9 objects x 4000 pts + 72 pairs x 8000 pts per scan)",
-               "value": round(world * args.steps / elapsed, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
+               "value": round(world * S * args.steps / elapsed, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[2] shape: SGPNModelWrapper(no_gt.json), 1 synthetic scan per step "
-                                      "and rank, train mode, fwd + weighted NLL + bwd + AdamW",
+               "config": {"workload": f"BASELINE configs[2] shape: SGPNModelWrapper(no_gt.json), {S} synthetic scan(s) per step "
+                                      "and rank (block-diagonal batch: per-scan GCN BatchNorm statistics and loss average; "
+                                      "SA BatchNorm2d statistics over the step's clouds), train mode, fwd + weighted NLL + bwd + AdamW",
+                          "scans_per_step": S,
                           "parallelism": f"dp{world}", "hip_graphs": bool(args.graphs),
                           "host_enqueue_ms_per_step": round(enqueue_ms, 3),
                           "geometry_pipeline": bool(args.geometry_pipeline and not args.graphs)}}
@@ -374,7 +408,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-scenes", type=int, default=4)
+    ap.add_argument("--cpu-sample-scenes", type=int, default=2)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the forward-only figure reported beside the headline")
     ap.add_argument("--no-serial-reference", action="store_true",
@@ -384,6 +418,8 @@ def main():
                          "scene-graph model's MSG object encoder (SURVEY 8d stack 2a); sgp = BASELINE configs[2] shape: the full "
                          "scene-graph model on synthetic scans (9 objects x 4000 pts + 72 pairs x 8000 pts, one scan per "
                          "step like the reference's DataLoader(batch_size=1)), fp32")
+    ap.add_argument("--scans-per-step", type=int, default=1,
+                    help="sgp workload: scans per step and rank, collated block-diagonally (BASELINE configs[2] names 32)")
     ap.add_argument("--graphs", action="store_true",
                     help="sgp workload: replay the whole step as one hipGraph (runtime.GraphedTrainStep); gradients are "
                          "averaged with one flat all-reduce between the backward and the optimizer graph when N > 1")
@@ -520,6 +556,10 @@ def main():
         }
         if serial_ms is not None:
             out["ms_per_step_without_geometry_pipeline"] = round(serial_ms, 3)
+            out["config"]["ms_per_step_without_geometry_pipeline"] = round(serial_ms, 3)   # = the step LATENCY
+        if fwd_ms is not None:
+            out["config"]["forward_only_ms_per_step"] = round(fwd_ms, 3)
+            out["config"]["forward_only_scenes_per_s"] = round(args.batch / fwd_ms * 1e3, 1)
         if timer is not None:
             rows = kernel_table(timer.summary(), sampled_steps)
             out["kernels"] = rows

@@ -69,6 +69,16 @@ int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *xyz,
                                    void *workspace, size_t workspace_bytes,
                                    int *idxs, int flags, void *stream);
 
+/* Multi-workgroup ("cluster") FPS variants spin on their peers with BOUNDED waits.  A launch is only admitted when
+ * the occupancy the runtime reports for the kernel covers the whole grid on the current device (otherwise the
+ * streaming kernel runs), and cluster launches of one process are chained so that two never overlap.  Should a wait
+ * still expire (CU-masked stream, another process on the GPU) the kernel stops, leaves the remaining indices 0 and
+ * sets the int32 at pn2_fps_status_offset() bytes into `workspace` to 1 (-1: this shape has no such word); callers
+ * must check it (the python binding asserts on the device, asynchronously). */
+long long pn2_fps_status_offset(int B, int N, int m);
+/* Test hook: force a kernel variant (mode: -1 heuristic | 0 resident | 1 cluster | 2 streaming | 3 cluster with a
+ * streamed tail) and cluster shape (0 = heuristic).  Process-global; results never depend on it. */
+int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, int bs);
 /* Test hook for the multi-workgroup FPS variant: returns the status word a
  * launch left in `workspace` (0 ok, 1 a bounded inter-workgroup wait expired,
  * <0 query failed).  Synchronises `stream`; never used on the hot path. */
@@ -95,6 +105,16 @@ int pn2_gather_points_grad(int B, int C, int N, int m, const float *grad_out,
 int pn2_ball_query(int B, int N, int m, float radius, int nsample,
                    const float *new_xyz, const float *xyz, int *idx,
                    void *stream);
+
+/* sample_uniformly / ret_unique_cnt of the Group-Free-3D QueryAndGroup
+ *   (GF3D/pointnet2/pointnet2_utils.py:327-336: a host loop of torch.unique + torch.randint per region).
+ * idx (rows, nsample) ball-query rows, IN PLACE: the padded tail of every row (everything behind its strictly
+ * ascending prefix = the unique hits) is refilled with members of that prefix drawn uniformly by a counter-based
+ * generator keyed on (seed, row, slot); unique_cnt (rows) f32 (may be NULL) receives the prefix length.
+ * Same distribution as the reference, not the same random stream (the reference consumes torch's host generator).
+ */
+int pn2_ball_query_unique_resample(long long rows, int nsample, unsigned seed, int *idx, float *unique_cnt,
+                                   void *stream);
 
 /* ------------------------------------------------------------------ A8 ---
  * group_points / group_points_grad  (EXT/include/group_points.h:4-5,
@@ -278,6 +298,23 @@ int pn2_scatter_add_rows(int64_t E, int H, int64_t N, int lds, int col0,
 int pn2_segment_sum_rows(int64_t E, int H, int64_t N, int lds, int col0,
                          const float *src, const int64_t *order,
                          const int64_t *rowptr, float *out, void *stream);
+
+/* Per-segment BatchNorm1d (+ optional ReLU) for block-diagonally batched scans.  The reference trains and evaluates
+ * one scan per step, and its GCN BatchNorm1d layers are built with track_running_stats=False
+ * (network_TripletGCN.py:20), i.e. they ALWAYS normalise with the statistics of the current scan's rows.  When S scans
+ * are batched, rows [ptr[s], ptr[s+1]) of x belong to scan s and get their own mean / biased variance:
+ *   y[r][c] = [relu]((x[r][col0+c] - mean[s][c]) * rstd[s][c] * gamma[c] + beta[c]),  rstd = 1/sqrt(var + eps).
+ * x (R, ldx) columns [col0, col0+C); ptr (S+1) i64; y (R, C); mean / rstd (S, C) are outputs kept for the backward.
+ * _grad: grad_out (R, C) w.r.t. y -> grad_x (R, C) and the per-segment partial sums dgamma_part / dbeta_part (S, C)
+ * (the caller sums them over S: deterministic).  Replaces S calls of torch's batch_norm on S tiny tensors.
+ */
+int pn2_segment_bn_rows(int64_t R, int C, int ldx, int col0, int64_t S, const float *x, const int64_t *ptr,
+                        const float *gamma, const float *beta, float eps, int relu, float *y, float *mean,
+                        float *rstd, void *stream);
+int pn2_segment_bn_rows_grad(int64_t R, int C, int ldx, int col0, int64_t S, const float *grad_out,
+                             const float *x, const int64_t *ptr, const float *gamma, const float *beta,
+                             const float *mean, const float *rstd, int relu, float *grad_x,
+                             float *dgamma_part, float *dbeta_part, void *stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -64,6 +64,13 @@ def pack_sd(sd, prefix):
     return {prefix + k: v.detach().numpy() for k, v in sd.items()}
 
 
+def sd_manifest(sd, prefix):
+    """keys / shapes / per-tensor sums: the consumer rebuilds the module under the same seed (same initialisation
+    order => same weights) instead of shipping megabytes of random numbers."""
+    return {prefix + "keys": np.array(list(sd.keys())), prefix + "shapes": np.array([str(tuple(v.shape)) for v in sd.values()]),
+            prefix + "sums": np.array([float(v.double().sum()) for v in sd.values()])}
+
+
 def save(name, **arrays):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **arrays)
@@ -170,8 +177,95 @@ def fixture_gf3d_backbone():
          grad_sa1_conv0=gw.numpy(), grad_fp2_conv1=gw2.numpy()[::4])
 
 
+def fixture_votes_pooling():
+    """GF3D PointnetSAModuleVotes with the three pooling modes (GF3D/pointnet2/pointnet2_modules.py:236-248), the
+    normalize_xyz flag and a caller-supplied `inds`; train-mode forward + backward."""
+    from external_src.group_free_3D.pointnet2 import pointnet2_modules as ref_gf
+    assert ref_gf.__file__.startswith(REF)
+    out = {}
+    pc = cloud(2, 700, 5, 41)
+    xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+    out["pc"] = pc.numpy()
+    for pooling, norm, sigma in (("max", True, None), ("avg", False, None), ("rbf", True, None), ("rbf", False, 0.11)):
+        tag = f"{pooling}_{int(norm)}_{'d' if sigma is None else 's'}"
+        torch.manual_seed(42)
+        sa = ref_gf.PointnetSAModuleVotes(mlp=[5, 16, 24], npoint=48, radius=0.35, nsample=12, use_xyz=True,
+                                          pooling=pooling, sigma=sigma, normalize_xyz=norm)
+        sd0 = {k: v.clone() for k, v in sa.state_dict().items()}
+        sa.train()
+        f = feats.clone().requires_grad_(True)
+        nx, nf, inds = sa(xyz, f)
+        (nf * torch.linspace(0.5, 1.5, nf.numel()).view_as(nf)).sum().backward()
+        out[f"{tag}/new_xyz"], out[f"{tag}/new_features"] = nx.detach().numpy(), nf.detach().numpy()
+        out[f"{tag}/inds"], out[f"{tag}/grad_features"] = inds.numpy(), f.grad.numpy()
+        out[f"{tag}/grad_w0"] = sa.mlp_module.layer0.conv.weight.grad.numpy()
+        out.update(pack_sd(sd0, f"{tag}/sd0/"))
+    save("votes_pooling.npz", **out)
+
+
+def fixture_heads():
+    """PointNetCls / PointNetRelCls (SGH/model/pointnets/network_PointNet.py:188-271): initialisation (xavier_normal
+    under a fixed seed), eval-mode outputs, and a train-mode forward/backward of the BatchNorm variant without dropout;
+    the relation head with the subject/object one-hot and with the image late fusion."""
+    from scene_graph_prediction.scene_graph_helpers.model.pointnets import network_PointNet as ref_pn
+    assert ref_pn.__file__.startswith(REF)
+    out = {}
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(11, 256, generator=g)
+    onehot = torch.zeros(11, 12)
+    onehot[torch.arange(11), torch.randint(0, 6, (11,), generator=g)] = 1
+    onehot[torch.arange(11), 6 + torch.randint(0, 6, (11,), generator=g)] = 1
+    img = torch.randn(768, generator=g)
+    out["x"], out["onehot"], out["img"] = x.numpy(), onehot.numpy(), img.numpy()
+
+    torch.manual_seed(52)
+    cls = ref_pn.PointNetCls(12, in_size=256, batch_norm=False, drop_out=True).eval()
+    out.update(sd_manifest(cls.state_dict(), "cls/"))
+    out["cls/y_eval"] = cls(x).detach().numpy()
+
+    torch.manual_seed(53)
+    rel = ref_pn.PointNetRelCls(15, in_size=256, batch_norm=False, drop_out=True, image_embedding_size=None,
+                                n_object_types=6).eval()
+    out.update(sd_manifest(rel.state_dict(), "rel/"))
+    out["rel/y_eval"] = rel(x, relation_objects_one_hot=onehot).detach().numpy()
+
+    torch.manual_seed(54)
+    reli = ref_pn.PointNetRelCls(15, in_size=256, batch_norm=False, drop_out=True, image_embedding_size=768,
+                                 n_object_types=6).eval()
+    out.update(sd_manifest(reli.state_dict(), "reli/"))
+    out["reli/y_eval"] = reli(x, relation_objects_one_hot=onehot, image_embeddings=img).detach().numpy()
+
+    torch.manual_seed(55)
+    bn = ref_pn.PointNetRelCls(15, in_size=256, batch_norm=True, drop_out=False, image_embedding_size=None,
+                               n_object_types=6).train()
+    out.update(sd_manifest(bn.state_dict(), "relbn/"))
+    xx = x.clone().requires_grad_(True)
+    y = bn(xx, relation_objects_one_hot=onehot)
+    (y * torch.linspace(0.5, 1.5, y.numel()).view_as(y)).sum().backward()
+    out["relbn/y_train"], out["relbn/grad_x"] = y.detach().numpy(), xx.grad.numpy()
+    out["relbn/grad_fc1"] = bn.fc1.weight.grad.numpy()[::8, ::8]
+    save("heads.npz", **out)
+
+
+def fixture_sample_uniformly():
+    """GF3D QueryAndGroup(sample_uniformly=True, ret_unique_cnt=True) (GF3D/pointnet2/pointnet2_utils.py:327-339): the
+    reference's host loop under torch.manual_seed.  The product resamples on the device with its own counter-based
+    generator, so only the deterministic parts are compared exactly (leading unique indices, unique_cnt); the fixture
+    also keeps the reference's full index tensor for the distribution check."""
+    from external_src.group_free_3D.pointnet2 import pointnet2_utils as ref_gu
+    assert ref_gu.__file__.startswith(REF)
+    pc = cloud(2, 900, 2, 61)
+    xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+    new_xyz = xyz[:, :40].contiguous()
+    qg = ref_gu.QueryAndGroup(0.3, 16, use_xyz=True, ret_grouped_xyz=True, sample_uniformly=True, ret_unique_cnt=True)
+    torch.manual_seed(62)
+    grouped, grouped_xyz, cnt = qg(xyz, new_xyz, feats)
+    plain = ref_gu.ball_query(0.3, 16, xyz, new_xyz)
+    save("sample_uniformly.npz", pc=pc.numpy(), unique_cnt=cnt.numpy(), ball_idx=plain.numpy(),
+         grouped=grouped.numpy(), grouped_xyz=grouped_xyz.numpy())
+
+
 if __name__ == "__main__":
-    fixture_sa_msg()
-    fixture_fp()
-    fixture_msg_encoder()
-    fixture_gf3d_backbone()
+    which = sys.argv[1:] or ["sa_msg", "fp", "msg_encoder", "gf3d_backbone", "votes_pooling", "heads", "sample_uniformly"]
+    for name in which:
+        globals()["fixture_" + name]()

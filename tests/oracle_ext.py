@@ -89,3 +89,67 @@ class OracleRowsExt(OracleExt):
             for p in range(int(rowptr[n]), int(rowptr[n + 1])):
                 out[n] += s[int(order[p])]
         return out
+
+    @staticmethod
+    def ball_query_unique_resample(idx, seed, want_cnt=True):
+        """GF3D/pointnet2/pointnet2_utils.py:327-336 restated on CPU: torch.unique per region for the leading part and
+        the count (the reference's own ops), the tail drawn with the product's counter-based generator
+        (csrc/ball_query.hip pn2_mix32) instead of torch.randint so that the result is comparable bit for bit."""
+        B, m, ns = idx.shape
+        cnt = torch.zeros(B, m)
+        M = 0xFFFFFFFF
+        for b in range(B):
+            for r in range(m):
+                uniq = torch.unique(idx[b, r, :])
+                n = uniq.shape[0]
+                cnt[b, r] = n
+                row = b * m + r
+                tail = []
+                for s_ in range(n, ns):
+                    h = (seed ^ ((row * 0x9E3779B9) & M) ^ ((s_ * 0x85EBCA6B) & M)) & M
+                    h ^= h >> 16; h = (h * 0x7FEB352D) & M
+                    h ^= h >> 15; h = (h * 0x846CA68B) & M
+                    h ^= h >> 16
+                    tail.append(int(uniq[h % n]))
+                idx[b, r, :] = torch.cat([uniq, torch.tensor(tail, dtype=idx.dtype)])
+        return cnt if want_cnt else None
+
+    @staticmethod
+    def segment_bn_rows(x, ptr, gamma, beta, eps, relu, h=None, col0=0):
+        """What the reference's one-scan-per-step loop computes: torch's own batch_norm (batch statistics) on the rows of
+        each scan separately (network_TripletGCN.py:20 — track_running_stats=False), then the optional ReLU."""
+        import torch.nn.functional as F
+        C = x.size(1) if h is None else h
+        xs = x[:, col0:col0 + C]
+        S = ptr.numel() - 1
+        y = torch.empty(x.size(0), C)
+        mean, rstd = torch.empty(S, C), torch.empty(S, C)
+        for s_ in range(S):
+            a, b = int(ptr[s_]), int(ptr[s_ + 1])
+            seg = xs[a:b]
+            out = F.batch_norm(seg, None, None, gamma, beta, True, 0.0, eps)
+            y[a:b] = F.relu(out) if relu else out
+            mean[s_] = seg.mean(0)
+            rstd[s_] = 1.0 / torch.sqrt(seg.var(0, unbiased=False) + eps)
+        return y, mean, rstd
+
+    @staticmethod
+    def segment_bn_rows_grad(grad_out, x, ptr, gamma, beta, mean, rstd, relu, col0=0, eps=1e-5):
+        """Backward of the above through torch autograd, scan by scan."""
+        import torch.nn.functional as F
+        C = grad_out.size(1)
+        S = ptr.numel() - 1
+        gx = torch.empty(x.size(0), C)
+        dg, db = torch.zeros(C), torch.zeros(C)
+        for s_ in range(S):
+            a, b = int(ptr[s_]), int(ptr[s_ + 1])
+            with torch.enable_grad():                   # called from inside an autograd Function's backward
+                seg = x[a:b, col0:col0 + C].detach().clone().requires_grad_(True)
+                ga, be = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+                out = F.batch_norm(seg, None, None, ga, be, True, 0.0, eps)
+                out = F.relu(out) if relu else out
+                out.backward(grad_out[a:b])
+            gx[a:b] = seg.grad
+            dg += ga.grad
+            db += be.grad
+        return gx, dg, db

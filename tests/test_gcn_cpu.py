@@ -73,3 +73,38 @@ def test_build_mlp_layout():
     m = build_mlp([4, 8, 6], do_bn=True, on_last=True)
     assert [type(l).__name__ for l in m] == ["Linear", "BatchNorm1d", "ReLU", "Linear", "BatchNorm1d", "ReLU"]
     assert [type(l).__name__ for l in build_mlp([4, 8, 6], do_bn=True)] == ["Linear", "BatchNorm1d", "ReLU", "Linear"]
+
+
+def test_batched_scans_equal_single_scan_steps(oracle_backend):
+    """S scans collated block-diagonally (per-scan GCN BatchNorm statistics, per-scan loss average) give the S
+    single-scan results: forward, the mean of the per-scan losses, and the gradients of their mean (eval-mode encoders:
+    SA BatchNorm on running statistics, as at inference; heads without dropout)."""
+    from scene_graph_prediction.main import RELATION_NAMES, config_loader
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan
+    from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+    torch.manual_seed(0)
+    m = SGPNModelWrapper(config_loader("no_gt.json"), 12, 15, torch.rand(12) + 0.5, torch.rand(15) + 0.5, RELATION_NAMES).eval()
+    scans = [synthetic_scan(n, 300, 400, seed=i, scan_id=f"s{i}", ) for i, n in enumerate([5, 4, 6])]
+    batch = collate_scans(scans)
+    assert batch["edge_indices"].max() == 14 and batch["scenes"].num_scenes == 3
+    obj, rel = m(batch)
+    loss = m.loss(obj, rel, batch)
+    loss.backward()
+    got = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    outs, total = [], 0.0
+    for s in scans:
+        o, r = m(s)
+        l = m.loss(o, r, s) / len(scans)
+        l.backward()
+        outs.append((o.detach(), r.detach()))
+        total += float(l.detach())
+    assert abs(float(loss.detach()) - total) < 1e-5
+    torch.testing.assert_close(obj.detach(), torch.cat([o for o, _ in outs]), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(rel.detach(), torch.cat([r for _, r in outs]), atol=1e-4, rtol=1e-4)
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            assert float((got[n] - p.grad).abs().max()) <= 1e-4 * max(1.0, float(p.grad.abs().max())), n
+    # triples: one (scan_id, triples) per scan, with scan-local object ids
+    per_scan = [m.predict_step(s) for s in scans]
+    assert m.predict_step(batch) == per_scan

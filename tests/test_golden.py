@@ -139,3 +139,115 @@ def test_gf3d_backbone_matches_reference_layer(oracle_backend, fast):
             np.testing.assert_allclose(g1, z["grad_fp2_conv1"], atol=1e-5, rtol=2e-2)
     finally:
         pm.set_fast_path(prev)
+
+
+VOTES_CASES = [("max", True, None), ("avg", False, None), ("rbf", True, None), ("rbf", False, 0.11)]
+
+
+def _votes_case(z, pooling, norm, sigma, device="cpu"):
+    from external_src.group_free_3D.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    tag = f"{pooling}_{int(norm)}_{'d' if sigma is None else 's'}"
+    pc = torch.from_numpy(z["pc"]).to(device)
+    xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+    sa = PointnetSAModuleVotes(mlp=[5, 16, 24], npoint=48, radius=0.35, nsample=12, use_xyz=True, pooling=pooling,
+                               sigma=sigma, normalize_xyz=norm)
+    sa.load_state_dict(sd_from(z, f"{tag}/sd0/"), strict=True)        # same keys / shapes as the reference module
+    sa = sa.to(device).train()
+    f = feats.clone().requires_grad_(True)
+    nx, nf, inds = sa(xyz, f)
+    (nf * torch.linspace(0.5, 1.5, nf.numel(), device=device).view_as(nf)).sum().backward()
+    return tag, nx, nf, inds, f.grad, sa.mlp_module.layer0.conv.weight.grad
+
+
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("pooling,norm,sigma", VOTES_CASES)
+def test_votes_pooling_modes_match_reference_layer(oracle_backend, fast, pooling, norm, sigma):
+    """max / avg / rbf pooling of PointnetSAModuleVotes (GF3D/pointnet2/pointnet2_modules.py:236-248) incl. the default
+    sigma = radius / 2 and normalize_xyz, literal and rows path, against the imported reference module."""
+    z = load("votes_pooling.npz")
+    prev = pm.set_fast_path(fast)
+    try:
+        tag, nx, nf, inds, gf, gw = _votes_case(z, pooling, norm, sigma)
+    finally:
+        pm.set_fast_path(prev)
+    assert np.array_equal(inds.numpy(), z[f"{tag}/inds"])
+    assert np.array_equal(nx.detach().numpy(), z[f"{tag}/new_xyz"])
+    np.testing.assert_allclose(nf.detach().numpy(), z[f"{tag}/new_features"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(gf.numpy(), z[f"{tag}/grad_features"], atol=2e-5, rtol=1e-3)
+    np.testing.assert_allclose(gw.numpy(), z[f"{tag}/grad_w0"], atol=2e-4, rtol=1e-3)
+
+
+def _heads(z):
+    from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet import PointNetCls, PointNetRelCls
+    torch.manual_seed(52)
+    cls = PointNetCls(12, in_size=256, batch_norm=False, drop_out=True).eval()
+    torch.manual_seed(53)
+    rel = PointNetRelCls(15, in_size=256, batch_norm=False, drop_out=True, image_embedding_size=None, n_object_types=6).eval()
+    torch.manual_seed(54)
+    reli = PointNetRelCls(15, in_size=256, batch_norm=False, drop_out=True, image_embedding_size=768, n_object_types=6).eval()
+    torch.manual_seed(55)
+    bn = PointNetRelCls(15, in_size=256, batch_norm=True, drop_out=False, image_embedding_size=None, n_object_types=6).train()
+    return {"cls": cls, "rel": rel, "reli": reli, "relbn": bn}
+
+
+def test_heads_match_reference(device="cpu"):
+    """PointNetCls / PointNetRelCls against the imported reference classes
+    (SGH/model/pointnets/network_PointNet.py:188-271): state_dict keys / shapes, the seeded xavier initialisation,
+    eval outputs (one-hot and image late fusion) and a train-mode forward / backward of the BatchNorm variant."""
+    z = load("heads.npz")
+    heads = _heads(z)
+    for name, mod in heads.items():
+        sd = mod.state_dict()
+        assert list(sd.keys()) == list(z[f"{name}/keys"]), name
+        assert [str(tuple(v.shape)) for v in sd.values()] == list(z[f"{name}/shapes"]), name
+        np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], z[f"{name}/sums"], rtol=1e-12, atol=1e-12)
+        mod.to(device)
+    x, onehot, img = (torch.from_numpy(z[k]).to(device) for k in ("x", "onehot", "img"))
+    tol = dict(atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(heads["cls"](x).detach().cpu().numpy(), z["cls/y_eval"], **tol)
+    np.testing.assert_allclose(heads["rel"](x, relation_objects_one_hot=onehot).detach().cpu().numpy(), z["rel/y_eval"], **tol)
+    np.testing.assert_allclose(heads["reli"](x, relation_objects_one_hot=onehot, image_embeddings=img).detach().cpu().numpy(),
+                               z["reli/y_eval"], **tol)
+    xx = x.clone().requires_grad_(True)
+    y = heads["relbn"](xx, relation_objects_one_hot=onehot)
+    (y * torch.linspace(0.5, 1.5, y.numel(), device=device).view_as(y)).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), z["relbn/y_train"], **tol)
+    np.testing.assert_allclose(xx.grad.cpu().numpy(), z["relbn/grad_x"], atol=1e-5, rtol=1e-3)
+    np.testing.assert_allclose(heads["relbn"].fc1.weight.grad.cpu().numpy()[::8, ::8], z["relbn/grad_fc1"], atol=1e-5, rtol=1e-3)
+
+
+def test_sample_uniformly_matches_reference_where_deterministic(oracle_backend):
+    """QueryAndGroup(sample_uniformly=True, ret_unique_cnt=True) vs the imported GF3D module
+    (GF3D/pointnet2/pointnet2_utils.py:327-339): unique_cnt and the leading unique entries are exact; the redrawn tail
+    (torch.randint on the host in the reference, a counter-based device generator here) must come from the row's
+    unique set and use it about uniformly."""
+    from pointnet2_ops import pointnet2_utils as pu
+    z = load("sample_uniformly.npz")
+    pc = torch.from_numpy(z["pc"])
+    xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+    new_xyz = xyz[:, :40].contiguous()
+    qg = pu.QueryAndGroup(0.3, 16, use_xyz=True, ret_grouped_xyz=True, sample_uniformly=True, ret_unique_cnt=True)
+    torch.manual_seed(62)
+    grouped, grouped_xyz, cnt = qg(xyz, new_xyz, feats)
+    assert np.array_equal(cnt.numpy(), z["unique_cnt"])
+    ref_idx = torch.from_numpy(z["ball_idx"]).long()
+    idx = pu.ball_query(0.3, 16, xyz, new_xyz)
+    assert np.array_equal(idx.numpy(), z["ball_idx"])
+    # leading unique part of the grouped tensor equals the reference's; tail members come from the unique set
+    want, got = z["grouped"], grouped.numpy()
+    B, m = cnt.shape
+    counts = np.zeros(16)
+    for b in range(B):
+        for r in range(m):
+            n = int(cnt[b, r])
+            assert np.array_equal(got[b, :, r, :n], want[b, :, r, :n])
+            uniq_cols = {tuple(want[b, :, r, s]) for s in range(n)}
+            for s in range(n, 16):
+                assert tuple(got[b, :, r, s]) in uniq_cols
+            if n == 4:                                              # pooled histogram of the draws of all 4-hit rows
+                cols = [tuple(want[b, :, r, s]) for s in range(n)]
+                for s in range(n, 16):
+                    counts[cols.index(tuple(got[b, :, r, s]))] += 1
+    if counts.sum() >= 100:
+        frac = counts[:4] / counts.sum()
+        assert frac.min() > 0.15 and frac.max() < 0.35, frac

@@ -15,9 +15,8 @@ def unit_ball(B, N, seed):
 
 
 @pytest.mark.parametrize("B,N,m", [(32, 50000, 2048), (2, 200000, 512)])
-def test_fps_properties(monkeypatch, B, N, m):
+def test_fps_properties(B, N, m):
     from pointnet2_ops import _ext
-    monkeypatch.setenv("PN2_FPS_CHECK", "1")
     xyz = unit_ball(B, N, 7)
     idx = _ext.furthest_point_sampling(xyz, m).long()
     assert int(idx.min()) >= 0 and int(idx.max()) < N and bool((idx[:, 0] == 0).all())
@@ -29,8 +28,8 @@ def test_fps_properties(monkeypatch, B, N, m):
     run = torch.stack([d[:, j, :j].min(dim=1).values for j in range(1, 300)], dim=1)
     assert bool((run[:, 1:] <= run[:, :-1] + 1e-6).all())
     # same answer from the kernel variant that shares no code path for the reduction
-    monkeypatch.setenv("PN2_FPS_MODE", "stream")
-    assert torch.equal(_ext.furthest_point_sampling(xyz[:2], 200).long(), idx[:2, :200])
+    with _ext.fps_plan_override(mode="stream"):
+        assert torch.equal(_ext.furthest_point_sampling(xyz[:2], 200).long(), idx[:2, :200])
 
 
 def test_ball_query_and_group_properties():

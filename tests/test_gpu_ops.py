@@ -66,14 +66,10 @@ def test_fps_every_kernel_variant_agrees_with_oracle(ext, monkeypatch, mode, g, 
         pytest.skip("does not fit the register file of one workgroup")
     if mode == "coop" and (B * g > 256 or (N + g - 1) // g > 512 * 24):
         pytest.skip("cluster does not fit")
-    monkeypatch.setenv("PN2_FPS_CHECK", "1")
-    if mode:
-        monkeypatch.setenv("PN2_FPS_MODE", mode)
-    if g:
-        monkeypatch.setenv("PN2_FPS_G", str(g))
     xyz = clouds(B, N, kind, seed=N + B)
     want = O.furthest_point_sampling(xyz, m)
-    got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    with ext.fps_plan_override(mode=mode, g=g or 0):
+        got = ext.furthest_point_sampling(dev(xyz), m).cpu()      # (a failed cluster hand-off asserts on the device)
     assert torch.equal(got, want)
 
 
@@ -86,11 +82,10 @@ def test_fps_cluster_with_streamed_tail_agrees_with_oracle(ext, monkeypatch, g, 
     with a cloud that fits entirely (empty tail)."""
     if B * g > 256:
         pytest.skip("cluster does not fit")
-    monkeypatch.setenv("PN2_FPS_MODE", "hybrid")
-    monkeypatch.setenv("PN2_FPS_G", str(g))
     xyz = clouds(B, N, kind, seed=N + B + g)
     want = O.furthest_point_sampling(xyz, m)
-    got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    with ext.fps_plan_override(mode="hybrid", g=g):
+        got = ext.furthest_point_sampling(dev(xyz), m).cpu()
     assert torch.equal(got, want)
 
 
@@ -119,13 +114,10 @@ def test_fps_multi_cloud_clusters_agree_with_oracle(ext, monkeypatch, nc, g, B, 
     """NC clouds per cluster / G workgroups per cluster: same indices as the lane-accurate oracle."""
     if B % nc or (B // nc) * g > 512 or nc * ((N + g * 512 - 1) // (g * 512)) > 16:
         pytest.skip("configuration does not fit")
-    monkeypatch.setenv("PN2_FPS_CHECK", "1")
-    monkeypatch.setenv("PN2_FPS_MODE", "coop")
-    monkeypatch.setenv("PN2_FPS_NC", str(nc))
-    monkeypatch.setenv("PN2_FPS_G", str(g))
     xyz = clouds(B, N, kind, seed=N + B + nc)
     want = O.furthest_point_sampling(xyz, m)
-    got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    with ext.fps_plan_override(mode="coop", g=g, nc=nc):
+        got = ext.furthest_point_sampling(dev(xyz), m).cpu()
     assert torch.equal(got, want)
 
 

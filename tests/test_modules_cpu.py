@@ -120,6 +120,9 @@ def test_literal_path_serves_coordinate_gradients(oracle_backend):
     assert xyz.grad is not None and xyz.grad.abs().sum() > 0
 
 
-def test_query_and_group_rejects_host_side_resampling():
-    with pytest.raises(NotImplementedError):
-        pu.QueryAndGroup(0.2, 8, sample_uniformly=True)
+def test_query_and_group_unique_cnt_needs_sample_uniformly():
+    """ret_unique_cnt without sample_uniformly is the reference's assertion (GF3D/pointnet2/pointnet2_utils.py:309-310)."""
+    with pytest.raises(AssertionError):
+        pu.QueryAndGroup(0.2, 8, ret_unique_cnt=True)
+    q = pu.QueryAndGroup(0.2, 8, sample_uniformly=True, ret_unique_cnt=True)
+    assert q.sample_uniformly and q.ret_unique_cnt
