@@ -295,6 +295,85 @@ extern "C" int pn2_group_points_grad(int B, int C, int N, int npoints, int nsamp
   return pn2_check_launch();
 }
 
+// bf16 rows for the mixed-precision shared MLP (csrc/mlp_bf16.hip): same gather as the wide kernel, the row written as
+// bf16 with a pitch `ldo` that is a multiple of 8 elements (16-byte row groups for the GEMM loader); the pad columns
+// W..ldo-1 are written as zeros.  Lane l produces the column pair (2l, 2l+1) [+128 per pass] and stores one dword.
+__global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_kernel(
+    int N, int m, int ns, int C, int Cx, int normalize, float radius, int ldo,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats, const int *__restrict__ idx, unsigned *__restrict__ out /* bf16 pairs */,
+    unsigned rows, unsigned rows_per_wave) {
+  const int lane = pn2_lane();
+  const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+  const int W = Cx + C;
+  unsigned r0 = wave * rows_per_wave;
+  if (r0 >= rows) return;
+  unsigned r1 = r0 + rows_per_wave;
+  if (r1 > rows) r1 = rows;
+  unsigned bj = r0 / (unsigned)ns;
+  unsigned s = r0 - bj * (unsigned)ns;
+  unsigned b = bj / (unsigned)m;
+  unsigned j = bj - b * (unsigned)m;
+  for (unsigned base = r0; base < r1; base += 8) {
+    const unsigned nrow = (r1 - base) < 8u ? (r1 - base) : 8u;
+    const int myi = lane < (int)nrow ? idx[base + lane] : 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if ((unsigned)q >= nrow) break;            // wave-uniform
+      const int ii = __builtin_amdgcn_readlane(myi, q);
+      const size_t src = (size_t)b * N + (size_t)ii;
+      unsigned *o = out + (size_t)(base + q) * (ldo / 2);
+      const float *f = feats + src * C - Cx;     // f[c] = feature column c - Cx
+      for (int c = 2 * lane; c < ldo; c += 128) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int cc = c + h;
+          float t = 0.f;
+          if (cc < Cx) {
+            t = xyz[src * 3 + cc] - new_xyz[(size_t)bj * 3 + cc];
+            if (normalize) t = __fdiv_rn(t, radius);
+          } else if (cc < W) {
+            t = f[cc];
+          }
+          v[h] = t;
+        }
+        const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)v[0]);
+        const unsigned hi = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
+        o[c >> 1] = lo | (hi << 16);
+      }
+      if (++s == (unsigned)ns) {
+        s = 0; ++bj;
+        if (++j == (unsigned)m) { j = 0; ++b; }
+      }
+    }
+  }
+}
+
+extern "C" int pn2_group_concat_rows_bf16(int B, int N, int m, int ns, int C, int use_xyz, int normalize, float radius,
+                                          int ldo, const float *xyz, const float *new_xyz, const float *feats,
+                                          const int *idx, void *out, void *stream) {
+  if (B < 0 || N < 0 || m < 0 || ns < 0 || C < 0) return PN2_EINVAL;
+  const int Cx = use_xyz ? 3 : 0;
+  if (ldo < Cx + C || ldo % 8 != 0) return PN2_EINVAL;
+  const size_t rows_sz = (size_t)B * m * ns;
+  if (rows_sz == 0 || Cx + C == 0) return PN2_OK;
+  if (!idx || !out) return PN2_ENULL;
+  if (Cx && (!xyz || !new_xyz)) return PN2_ENULL;
+  if (C && !feats) return PN2_ENULL;
+  if (normalize && !(radius > 0.f)) return PN2_EINVAL;
+  if (rows_sz >= 0x7fffffffull) return PN2_EINVAL;
+  const unsigned rows = (unsigned)rows_sz;
+  const unsigned want_waves = 256u * 16u;
+  unsigned rpw = (rows + want_waves - 1) / want_waves;
+  rpw = (rpw + 7u) & ~7u;
+  const unsigned waves = (rows + rpw - 1) / rpw;
+  const unsigned grid = (waves + kBlock / 64 - 1) / (kBlock / 64);
+  hipLaunchKernelGGL(group_concat_rows_bf16_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C, Cx,
+                     normalize, radius, ldo, xyz, new_xyz, feats, idx, (unsigned *)out, rows, rpw);
+  return pn2_check_launch();
+}
+
 extern "C" int pn2_group_concat_rows(int B, int N, int m, int ns, int C, int use_xyz,
                                      int normalize, float radius, const float *xyz,
                                      const float *new_xyz, const float *feats,

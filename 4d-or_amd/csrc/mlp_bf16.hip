@@ -1,0 +1,722 @@
+// mlp_bf16.hip — bf16-MFMA variants of the shared per-point MLP kernels (mixed precision).
+//
+// The reference trains under 16-bit AMP (scene_graph_prediction/main.py:64 `precision=16`): the 1x1 convolutions of
+// the SA/FP shared MLPs (OPS/pointnet2_modules.py:9-19) run in half precision with fp32 master weights, BatchNorm
+// keeps fp32 statistics, and the grouping ops stay fp32 (`custom_fwd(cast_inputs=torch.float32)`,
+// OPS/pointnet2_utils.py:198).  The MI355X counterpart: activations between the layers of a stack are STORED as bf16
+// (the raw pre-BatchNorm outputs y_l and the gradients dL/dz_l — the only large tensors of the step), the matrix
+// products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, BatchNorm statistics / constants stay fp32 / fp64,
+// weights and weight gradients stay fp32, and the geometry kernels are untouched.
+//
+// With bf16 operands the arithmetic intensity of these tall-skinny GEMMs (K, N <= 320) is ~50 FLOP/B against a ridge
+// of ~310 FLOP/B (2.5 PFLOP/s / 8 TB/s): every kernel here is HBM-bound, the MFMA pipe is ~15 % busy.  They are
+// therefore built for bytes in flight, not for MFMA issue: 16-byte loads of bf16 rows, the weight matrix resident in
+// LDS for the lifetime of a persistent workgroup, the next A chunk prefetched into registers behind the current
+// chunk's MFMAs, two workgroups per CU.
+//
+//   pn2_mlp_gemm_bf16  : Y[M][N] = pro(X)[M][K] * W[N][K]^T   (same prologue / epilogue algebra as csrc/mlp_gemm.hip)
+//   pn2_mlp_wgrad_bf16 : dW[N][K] += gy^T * act                (operands transposed into LDS as packed row pairs)
+//   pn2_*_bf16 helpers : BN+ReLU(+max) and their backward preparations on bf16 y
+#include "pn2_common.h"
+#include "mlp_common.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned short bf_bits(float f) { return __builtin_bit_cast(unsigned short, (bf16)f); }
+__device__ __forceinline__ unsigned bf_pack(float lo, float hi) {
+  return (unsigned)bf_bits(lo) | ((unsigned)bf_bits(hi) << 16);
+}
+__device__ __forceinline__ float bf_round(float f) { return (float)(bf16)f; }
+
+__device__ __forceinline__ u32x4 bload128(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ unsigned short bload16(rsrc_t r, int voff, int soff) {
+  return (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+__device__ __forceinline__ void bstore16(unsigned short v, rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b16(v, r, voff, soff, 0);
+}
+
+constexpr int TM = 128;        // rows per tile: 4 waves x 32
+constexpr int KC = 64;         // K chunk (4 MFMA k-steps of 16)
+constexpr int AP = KC + 8;     // LDS pitch of the A chunk in bf16 elements (16-byte rows, conflict-free b128 reads)
+
+struct GemmBf16Args {
+  const void *X;      // [M][ldx]  bf16 (or fp32 when XF32); PRO_GY: g
+  const bf16 *X2;     // PRO_GY / PRO_POOLG: y_l [M][ldx]
+  const float *p0, *p1, *p2;   // per-K prologue vectors
+  const int *arg;     // PRO_POOLG [M/ns][K]
+  const float *gP;    // PRO_POOLG [M/ns][K]
+  const float *W;     // [N][K] fp32 master weights
+  void *Y;            // [M][ldy] bf16 (fp32 when YF32)
+  double *stats;      // [2][N]
+  const bf16 *Yprev;  // EPI_MASK [M][ldy]
+  const float *e_fin; // EPI_MASK: [mean | rstd | scale | shift] x N
+  long long M;
+  int K, N, ldx, ldy, ns;
+  int Kp;             // K rounded up to KC
+  int wres;           // weights resident in LDS
+};
+
+// ---------------------------------------------------------------------------------------------- forward / dgrad
+// Workgroup = 4 x CW waves: wave (wr, wc) owns rows wr*32.. of the 128-row tile and the NT 32-column tiles wc*NT.. .
+// CW = 2 keeps the accumulators of N > 128 within 128 VGPRs per lane (two workgroups of 8 waves per CU).
+template <int NT, int CW, int PRO, int EPI, bool XF32, bool YF32>
+__global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf16Args a) {
+  constexpr int NTH = 256 * CW;                     // threads
+  constexpr int NTT = NT * CW;                      // column tiles of the workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16 *sA = (bf16 *)smem;                          // [TM][AP]
+  float *sP = (float *)(smem + TM * AP * 2);        // [3][Kp] prologue parameters, zero padded
+  const int Kp = a.Kp;
+  bf16 *sW = (bf16 *)(smem + TM * AP * 2 + (PRO != PRO_NONE ? 3 * Kp * 4 : 0));   // [NTT*32][WP]
+  const int WP = a.wres ? Kp + 8 : AP;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) & 3, wc = tid >> 8;
+  const int K = a.K, N = a.N;
+
+  if constexpr (PRO != PRO_NONE) {
+    for (int k = tid; k < Kp; k += NTH) {
+      sP[k] = k < K ? a.p0[k] : 0.f;
+      sP[Kp + k] = k < K ? a.p1[k] : 0.f;
+      sP[2 * Kp + k] = (PRO != PRO_BNRELU && k < K) ? a.p2[k] : 0.f;
+    }
+  }
+  auto stage_w = [&](int k0, int kw) {              // sW[n][0..kw) = bf16(W[n][k0..k0+kw)), zero outside N x K
+    const int total = NTT * 32 * kw;
+    for (int e = tid; e < total; e += NTH) {
+      const int n = e / kw, k = e - n * kw;
+      const float v = (n < N && k0 + k < K) ? a.W[(size_t)n * K + k0 + k] : 0.f;
+      sW[n * WP + k] = (bf16)v;
+    }
+  };
+  if (a.wres) stage_w(0, Kp);
+
+  // per-column epilogue constants and running column sums (this lane's column of each 32-wide tile)
+  float s1[NT], s2[NT], e_mean[NT], e_rstd[NT], e_sc[NT], e_sh[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    s1[nt] = s2[nt] = 0.f;
+    const int c = (wc * NT + nt) * 32 + (lane & 31);
+    if constexpr (EPI == EPI_MASK) {
+      const bool ok = c < N;
+      e_mean[nt] = ok ? a.e_fin[c] : 0.f;
+      e_rstd[nt] = ok ? a.e_fin[N + c] : 0.f;
+      e_sc[nt] = ok ? a.e_fin[2 * N + c] : 0.f;
+      e_sh[nt] = ok ? a.e_fin[3 * N + c] : 0.f;
+    }
+  }
+
+  const long long ntiles = (a.M + TM - 1) / TM;
+  const int nchunks = Kp / KC;
+  // A loader, bf16 input: thread -> (row = tid / (2 CW), 32 / CW consecutive k = J x 16 bytes)
+  constexpr int J = 4 / CW;
+  const int lr = tid / (2 * CW), lk = (tid % (2 * CW)) * (8 * J);
+  const int xs = XF32 ? 4 : 2;
+
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long row0 = tile * TM;
+    const long long rows_left = a.M - row0;
+    const rsrc_t rX = make_rsrc((const char *)a.X + (size_t)row0 * a.ldx * xs, rows_left * a.ldx * xs);
+    rsrc_t rX2 = rX;
+    if constexpr (PRO == PRO_GY || PRO == PRO_POOLG)
+      rX2 = make_rsrc((const char *)a.X2 + (size_t)row0 * a.ldx * 2, rows_left * a.ldx * 2);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+
+    u32x4 ra[J], rb[J];                              // prefetched raw 16-byte groups (g / x and y)
+    auto issue = [&](int kc) {
+      if constexpr (!XF32) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int k = kc * KC + lk + 8 * j;
+          const int off = k < a.ldx ? (lr * a.ldx + k) * 2 : kOobOffset;
+          if constexpr (PRO != PRO_POOLG) ra[j] = bload128(rX, off, 0);
+          if constexpr (PRO == PRO_GY || PRO == PRO_POOLG) rb[j] = bload128(rX2, off, 0);
+        }
+      }
+    };
+    auto commit = [&](int kc) {                      // prologue + write the chunk into sA
+      if constexpr (XF32) {
+        // fp32 rows (first layer of an un-grouped stack, FP modules): flat, coalesced scalar loads; PRO_NONE only
+        const int k = tid & 63, kk = kc * KC + k;
+        const int off0 = ((tid >> 6) * a.ldx + kk) * 4;
+#pragma unroll 8
+        for (int i = 0; i < 32 / CW; ++i) {
+          const float v = bload(rX, kk < K ? off0 + i * (4 * CW) * a.ldx * 4 : kOobOffset, 0);
+          sA[((tid >> 6) + 4 * CW * i) * AP + k] = (bf16)v;
+        }
+      } else {
+        const long long grow = row0 + lr;
+        int sample = 0;
+        long long grp = 0;
+        if constexpr (PRO == PRO_POOLG) { grp = grow / a.ns; sample = (int)(grow - grp * a.ns); }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int k = kc * KC + lk + 8 * j;
+          float v[8];
+          if constexpr (PRO == PRO_NONE) {
+            *(u32x4 *)&sA[lr * AP + lk + 8 * j] = ra[j];
+            continue;
+          }
+          const float *q0 = sP + k, *q1 = sP + Kp + k, *q2 = sP + 2 * Kp + k;
+          if constexpr (PRO == PRO_BNRELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              v[2 * i] = fmaxf(fmaf(bf_lo(ra[j][i]), q0[2 * i], q1[2 * i]), 0.f);
+              v[2 * i + 1] = fmaxf(fmaf(bf_hi(ra[j][i]), q0[2 * i + 1], q1[2 * i + 1]), 0.f);
+            }
+          } else if constexpr (PRO == PRO_GY) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              v[2 * i] = fmaf(q0[2 * i], bf_lo(ra[j][i]), fmaf(q1[2 * i], bf_lo(rb[j][i]), q2[2 * i]));
+              v[2 * i + 1] = fmaf(q0[2 * i + 1], bf_hi(ra[j][i]), fmaf(q1[2 * i + 1], bf_hi(rb[j][i]), q2[2 * i + 1]));
+            }
+          } else {   // PRO_POOLG: the pooled gradient reaches only the arg-max row of each (group, channel)
+            const bool live = grow < a.M && k < K;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float y = (i & 1) ? bf_hi(rb[j][i >> 1]) : bf_lo(rb[j][i >> 1]);
+              float g = 0.f;
+              if (live && k + i < K) {
+                const size_t o = (size_t)grp * K + k + i;
+                g = a.arg[o] == sample ? a.gP[o] : 0.f;
+              }
+              v[i] = fmaf(q0[i], g, fmaf(q1[i], y, q2[i]));
+            }
+          }
+          u32x4 w;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[i] = bf_pack(v[2 * i], v[2 * i + 1]);
+          *(u32x4 *)&sA[lr * AP + lk + 8 * j] = w;
+        }
+      }
+    };
+
+    issue(0);
+    for (int kc = 0; kc < nchunks; ++kc) {
+      __syncthreads();                               // the previous chunk's fragment reads are done
+      commit(kc);
+      if (!a.wres) stage_w(kc * KC, KC);
+      if (kc + 1 < nchunks) issue(kc + 1);
+      __syncthreads();
+      const int kb = a.wres ? kc * KC : 0;
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        const bf16x8 af = *(const bf16x8 *)&sA[(wave * 32 + (lane & 31)) * AP + ks * 16 + (lane >> 5) * 8];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const bf16x8 bfr = *(const bf16x8 *)&sW[((wc * NT + nt) * 32 + (lane & 31)) * WP + kb + ks * 16 + (lane >> 5) * 8];
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue: C layout — lane holds column nt*32 + (lane & 31), rows (i&3) + 8*(i>>2) + 4*(lane>>5) of its wave
+    const int ys = YF32 ? 4 : 2;
+    const rsrc_t rY = make_rsrc((char *)a.Y + (size_t)row0 * a.ldy * ys, rows_left * a.ldy * ys);
+    rsrc_t rYp = rY;
+    if constexpr (EPI == EPI_MASK) rYp = make_rsrc((const char *)a.Yprev + (size_t)row0 * a.ldy * 2, rows_left * a.ldy * 2);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = (wc * NT + nt) * 32 + (lane & 31);
+      const bool cok = c < N;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const int eoff = cok ? r * a.ldy + c : -1;
+        float v = acc[nt][i];
+        if constexpr (EPI == EPI_MASK) {
+          const float yp = bf_lo((unsigned)bload16(rYp, eoff < 0 ? kOobOffset : eoff * 2, 0));
+          v = fmaf(yp, e_sc[nt], e_sh[nt]) > 0.f ? v : 0.f;
+          const float vr = YF32 ? v : bf_round(v);
+          s1[nt] += vr;
+          s2[nt] = fmaf(vr, (yp - e_mean[nt]) * e_rstd[nt], s2[nt]);
+        } else if constexpr (EPI == EPI_STATS) {
+          const float vr = YF32 ? v : bf_round(v);
+          s1[nt] += vr;
+          s2[nt] = fmaf(vr, vr, s2[nt]);
+        }
+        if constexpr (YF32) bstore(v, rY, eoff < 0 ? kOobOffset : eoff * 4, 0);
+        else bstore16(bf_bits(v), rY, eoff < 0 ? kOobOffset : eoff * 2, 0);
+      }
+    }
+  }
+
+  if constexpr (EPI != EPI_NONE) {
+    // lanes l and l+32 hold the same column; 4 waves hold different rows: reduce through LDS, one fp64 atomic per column
+    __syncthreads();
+    float *red = (float *)smem;                      // [2][4][NTT*32]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float t1 = s1[nt] + __shfl_xor(s1[nt], 32);
+      const float t2 = s2[nt] + __shfl_xor(s2[nt], 32);
+      if (lane < 32) {
+        red[(0 * 4 + wave) * NTT * 32 + (wc * NT + nt) * 32 + lane] = t1;
+        red[(1 * 4 + wave) * NTT * 32 + (wc * NT + nt) * 32 + lane] = t2;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * NTT * 32; e += NTH) {
+      const int which = e / (NTT * 32), c = e - which * NTT * 32;
+      if (c < N) {
+        const float *p = red + which * 4 * NTT * 32 + c;
+        atomicAdd(a.stats + (size_t)which * N + c, (double)p[0] + (double)p[NTT * 32] + (double)p[2 * NTT * 32] + (double)p[3 * NTT * 32]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+// dW[n][k] += sum_m gy[m][n] * act[m][k].  Both MFMA operands are indexed [feature][row]: A = gy^T, B = act^T, the
+// contraction runs over rows.  A thread loads TWO consecutive rows x 8 consecutive features (16-byte pieces of the
+// row-major tensors, coalesced across the features), applies the prologue and writes the 8 (row, row+1) pairs as
+// packed dwords into the transposed LDS image T[feature][row]; row groups of 8 are XOR-swizzled with the feature
+// group so that the 16 column groups of a wave store into different banks, and fragment reads stay 16-byte aligned.
+struct WgradBf16Args {
+  const bf16 *G;      // gmode GY: dL/dz_l [M][N]
+  const bf16 *Yl;     // y_l [M][N]
+  const float *consts;  // [3][N] c1 | c2 | c3
+  const int *arg;     // gmode POOLG [M/ns][N]
+  const float *gP;    // gmode POOLG [M/ns][N]
+  const void *X;      // act source [M][ldx]: bf16 y_{l-1} (amode BNRELU) or the stack's input rows (amode NONE; fp32 when XF32)
+  const float *a_fin; // amode BNRELU: [mean | rstd | scale | shift] x K
+  float *dW;          // [N][K] ACCUMULATES
+  long long M;
+  int N, K, ldx, ns;
+};
+
+template <int MT>
+__device__ __forceinline__ int swz(int feature, int m) { return m ^ (((feature >> 3) & (MT / 8 - 1)) << 3); }
+
+template <int NTW, int KTB, int MT, int GMODE, int AMODE, bool XF32>
+__global__ __launch_bounds__(256, 2) void mlp_wgrad_bf16_kernel(const WgradBf16Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MP = MT + 8;                          // pitch in bf16 elements
+  constexpr int NB = 4 * NTW * 32;                    // gy features held (>= N)
+  constexpr int KB = KTB * 32;                        // act features per block
+  bf16 *sG = (bf16 *)smem;                            // [NB][MP]
+  bf16 *sX = sG + NB * MP;                            // [KB][MP]
+  float *sC = (float *)(sX + KB * MP);                // [3][NB] gy constants, then [2][KB] act scale / shift
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, K = a.K;
+  const int k0 = blockIdx.y * KB;
+
+  for (int n = tid; n < NB; n += 256) {
+    sC[n] = n < N ? a.consts[n] : 0.f;
+    sC[NB + n] = n < N ? a.consts[N + n] : 0.f;
+    sC[2 * NB + n] = n < N ? a.consts[2 * N + n] : 0.f;
+  }
+  float *sS = sC + 3 * NB;
+  for (int k = tid; k < KB; k += 256) {
+    const bool ok = AMODE == PRO_BNRELU && k0 + k < K;
+    sS[k] = ok ? a.a_fin[2 * K + k0 + k] : 0.f;
+    sS[KB + k] = ok ? a.a_fin[3 * K + k0 + k] : 0.f;
+  }
+  __syncthreads();
+
+  f32x16 acc[NTW][KTB];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < KTB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int CG = (N + 7) / 8;                         // 8-feature column groups of gy
+  const int XG = XF32 ? 0 : (min(K - k0, KB) + 7) / 8;
+  const long long ntiles = (a.M + MT - 1) / MT;
+
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long row0 = tile * MT;
+    const long long rows_left = a.M - row0;
+    __syncthreads();                                  // previous tile's fragment reads are done
+
+    // ---- gy tile -> sG (transposed, packed row pairs)
+    {
+      const rsrc_t rG = make_rsrc((const char *)(GMODE == PRO_GY ? a.G : a.Yl) + (size_t)row0 * N * 2, rows_left * N * 2);
+      const rsrc_t rY = make_rsrc((const char *)a.Yl + (size_t)row0 * N * 2, rows_left * N * 2);
+      const int tasks = (MT / 2) * CG;
+      for (int t = tid; t < tasks; t += 256) {
+        const int rp = t / CG, cg = t - rp * CG;
+        const int m = 2 * rp, n = cg * 8;
+        const int off0 = (m * N + n) * 2, off1 = off0 + N * 2;
+        u32x4 g0, g1;
+        const u32x4 y0 = bload128(rY, off0, 0), y1 = bload128(rY, off1, 0);
+        if constexpr (GMODE == PRO_GY) { g0 = bload128(rG, off0, 0); g1 = bload128(rG, off1, 0); }
+        float v0[8], v1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float c1 = sC[n + i], c2 = sC[NB + n + i], c3 = sC[2 * NB + n + i];
+          float ga, gb;
+          if constexpr (GMODE == PRO_GY) {
+            ga = (i & 1) ? bf_hi(g0[i >> 1]) : bf_lo(g0[i >> 1]);
+            gb = (i & 1) ? bf_hi(g1[i >> 1]) : bf_lo(g1[i >> 1]);
+          } else {
+            ga = gb = 0.f;
+            if (n + i < N) {
+              const long long ra_ = row0 + m, rb_ = ra_ + 1;
+              if (ra_ < a.M) { const long long q = ra_ / a.ns; const size_t o = (size_t)q * N + n + i; ga = a.arg[o] == (int)(ra_ - q * a.ns) ? a.gP[o] : 0.f; }
+              if (rb_ < a.M) { const long long q = rb_ / a.ns; const size_t o = (size_t)q * N + n + i; gb = a.arg[o] == (int)(rb_ - q * a.ns) ? a.gP[o] : 0.f; }
+            }
+          }
+          const float ya = (i & 1) ? bf_hi(y0[i >> 1]) : bf_lo(y0[i >> 1]);
+          const float yb = (i & 1) ? bf_hi(y1[i >> 1]) : bf_lo(y1[i >> 1]);
+          // rows past M must contribute nothing (their y reads are out of range = 0, but c3 is not)
+          v0[i] = row0 + m < a.M ? fmaf(c1, ga, fmaf(c2, ya, c3)) : 0.f;
+          v1[i] = row0 + m + 1 < a.M ? fmaf(c1, gb, fmaf(c2, yb, c3)) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          *(unsigned *)&sG[(n + i) * MP + swz<MT>(n + i, m)] = bf_pack(v0[i], v1[i]);
+      }
+      // features N .. NB-1 of the last partly used tile row block must read as zero
+      for (int t = tid; t < (NB - CG * 8) * (MT / 2); t += 256) {
+        const int f = CG * 8 + t / (MT / 2), mp = t % (MT / 2);
+        *(unsigned *)&sG[f * MP + 2 * mp] = 0u;
+      }
+    }
+    // ---- activation tile -> sX (transposed, packed row pairs)
+    if constexpr (!XF32) {
+      const rsrc_t rX = make_rsrc((const char *)a.X + (size_t)row0 * a.ldx * 2, rows_left * a.ldx * 2);
+      const int tasks = (MT / 2) * XG;
+      for (int t = tid; t < tasks; t += 256) {
+        const int rp = t / XG, cg = t - rp * XG;
+        const int m = 2 * rp, k = cg * 8;
+        const int off0 = (m * a.ldx + k0 + k) * 2, off1 = off0 + a.ldx * 2;
+        const u32x4 x0 = bload128(rX, off0, 0), x1 = bload128(rX, off1, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float xa = (i & 1) ? bf_hi(x0[i >> 1]) : bf_lo(x0[i >> 1]);
+          float xb = (i & 1) ? bf_hi(x1[i >> 1]) : bf_lo(x1[i >> 1]);
+          if constexpr (AMODE == PRO_BNRELU) {
+            const float sc = sS[k + i], sh = sS[KB + k + i];
+            xa = row0 + m < a.M ? fmaxf(fmaf(xa, sc, sh), 0.f) : 0.f;
+            xb = row0 + m + 1 < a.M ? fmaxf(fmaf(xb, sc, sh), 0.f) : 0.f;
+          }
+          if (k0 + k + i >= K) xa = xb = 0.f;
+          *(unsigned *)&sX[(k + i) * MP + swz<MT>(k + i, m)] = bf_pack(xa, xb);
+        }
+      }
+      for (int t = tid; t < (KB - XG * 8) * (MT / 2); t += 256) {
+        const int f = XG * 8 + t / (MT / 2), mp = t % (MT / 2);
+        *(unsigned *)&sX[f * MP + 2 * mp] = 0u;
+      }
+    } else {
+      // fp32 input rows of arbitrary width (amode NONE): one (row pair, feature) per task, coalesced over features
+      const rsrc_t rX = make_rsrc((const char *)a.X + (size_t)row0 * a.ldx * 4, rows_left * a.ldx * 4);
+      const int tasks = (MT / 2) * KB;
+      for (int t = tid; t < tasks; t += 256) {
+        const int rp = t / KB, k = t - rp * KB;
+        const int m = 2 * rp;
+        const bool ok = k0 + k < K;
+        const float xa = bload(rX, ok ? (m * a.ldx + k0 + k) * 4 : kOobOffset, 0);
+        const float xb = bload(rX, ok ? ((m + 1) * a.ldx + k0 + k) * 4 : kOobOffset, 0);
+        *(unsigned *)&sX[k * MP + swz<MT>(k, m)] = bf_pack(xa, xb);
+      }
+    }
+    __syncthreads();
+
+    // ---- dW tile block += gy^T act over the MT rows
+#pragma unroll
+    for (int ms = 0; ms < MT / 16; ++ms) {
+      const int m = ms * 16 + (lane >> 5) * 8;
+      bf16x8 af[NTW], bfr[KTB];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int f = (wave * NTW + i) * 32 + (lane & 31);
+        af[i] = *(const bf16x8 *)&sG[f * MP + swz<MT>(f, m)];
+      }
+#pragma unroll
+      for (int j = 0; j < KTB; ++j) {
+        const int f = j * 32 + (lane & 31);
+        bfr[j] = *(const bf16x8 *)&sX[f * MP + swz<MT>(f, m)];
+      }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int j = 0; j < KTB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- flush: C layout — column (lane & 31) = k, rows = n
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < KTB; ++j) {
+      const int k = k0 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = (wave * NTW + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (n < N && k < K) atomicAdd(a.dW + (size_t)n * K + k, acc[i][j][e]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- element-wise helpers
+// ReLU(BN(y)) for a stack that returns activations (FP modules): y bf16 -> out fp32
+__global__ __launch_bounds__(256) void bn_relu_apply_bf16_kernel(size_t total, int N, const bf16 *__restrict__ y,
+                                                                const float *__restrict__ fin, float *__restrict__ out) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % N);
+    out[e] = fmaxf(fmaf((float)y[e], fin[2 * N + c], fin[3 * N + c]), 0.f);
+  }
+}
+
+constexpr int kPrepRowsBf = 16;
+
+// gpre = gout * [BN(y) > 0] (bf16), sums += (sum gpre, sum gpre * yhat) — backward entry of an un-pooled stack
+__global__ __launch_bounds__(256) void bn_relu_bwd_prep_bf16_kernel(long long M, int N, const bf16 *__restrict__ y,
+                                                                   const float *__restrict__ gout,
+                                                                   const float *__restrict__ fin,
+                                                                   bf16 *__restrict__ gpre, double *__restrict__ sums) {
+  __shared__ float part[2][256];
+  const long long r0 = (long long)blockIdx.x * kPrepRowsBf;
+  const int cw = N < 256 ? N : 256;
+  const int groups = 256 / cw;
+  const int grp = threadIdx.x / cw;
+  const bool active = grp < groups;
+  for (int c0 = 0; c0 < N; c0 += cw) {
+    const int c = c0 + threadIdx.x - grp * cw;
+    float s1 = 0.f, s2 = 0.f;
+    if (active && c < N) {
+      const float mean = fin[c], rstd = fin[N + c], sc = fin[2 * N + c], sh = fin[3 * N + c];
+      for (int r = grp; r < kPrepRowsBf; r += groups) {
+        const long long row = r0 + r;
+        if (row >= M) break;
+        const size_t off = (size_t)row * N + c;
+        const float yy = (float)y[off];
+        const float g = bf_round(fmaf(yy, sc, sh) > 0.f ? gout[off] : 0.f);
+        gpre[off] = (bf16)g;
+        s1 += g;
+        s2 = fmaf(g, (yy - mean) * rstd, s2);
+      }
+    }
+    part[0][threadIdx.x] = s1;
+    part[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (grp == 0 && c < N) {
+      for (int q = 1; q < groups; ++q) { s1 += part[0][threadIdx.x + q * cw]; s2 += part[1][threadIdx.x + q * cw]; }
+      atomicAdd(sums + c, (double)s1);
+      atomicAdd(sums + N + c, (double)s2);
+    }
+    __syncthreads();
+  }
+}
+
+// ReLU(BN(y)) + max over groups of ns rows (+ first arg-max, + raw value there): y bf16 -> fp32 / int32 (R, C)
+__global__ __launch_bounds__(256) void bn_relu_rows_max_bf16_kernel(size_t total /* R*C/2 */, int ns, int C,
+                                                                   const bf16 *__restrict__ y,
+                                                                   const float *__restrict__ fin, float *__restrict__ out,
+                                                                   int *__restrict__ arg, float *__restrict__ yraw) {
+  const int CV = C / 2;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t r = e / CV;
+    const int c = (int)(e - r * CV) * 2;
+    const float sc0 = fin[2 * C + c], sc1 = fin[2 * C + c + 1], sh0 = fin[3 * C + c], sh1 = fin[3 * C + c + 1];
+    const unsigned *p = (const unsigned *)(y + r * ns * C + c);
+    unsigned w = p[0];
+    float r0 = bf_lo(w), r1 = bf_hi(w);
+    float b0 = fmaxf(fmaf(r0, sc0, sh0), 0.f), b1 = fmaxf(fmaf(r1, sc1, sh1), 0.f);
+    int i0 = 0, i1 = 0;
+    for (int s = 1; s < ns; ++s) {
+      w = p[(size_t)s * CV];
+      const float q0 = bf_lo(w), q1 = bf_hi(w);
+      const float z0 = fmaxf(fmaf(q0, sc0, sh0), 0.f), z1 = fmaxf(fmaf(q1, sc1, sh1), 0.f);
+      if (z0 > b0) { b0 = z0; i0 = s; r0 = q0; }
+      if (z1 > b1) { b1 = z1; i1 = s; r1 = q1; }
+    }
+    out[r * C + c] = b0; out[r * C + c + 1] = b1;
+    arg[r * C + c] = i0; arg[r * C + c + 1] = i1;
+    yraw[r * C + c] = r0; yraw[r * C + c + 1] = r1;
+  }
+}
+
+inline unsigned capped_grid(size_t work, unsigned cap = 16384) {
+  size_t g = (work + 255) / 256;
+  if (g > cap) g = cap;
+  return (unsigned)(g ? g : 1);
+}
+
+constexpr int kMaxResidentWBytes = 72 * 1024;
+
+template <int NT, int CW, int PRO, int EPI, bool XF32, bool YF32>
+int launch_gemm(GemmBf16Args a, hipStream_t s) {
+  constexpr int NTT = NT * CW;
+  const size_t wbytes_res = (size_t)NTT * 32 * (a.Kp + 8) * 2;
+  a.wres = wbytes_res <= (size_t)kMaxResidentWBytes;
+  const size_t wbytes = a.wres ? wbytes_res : (size_t)NTT * 32 * AP * 2;
+  size_t lds = (size_t)TM * AP * 2 + (PRO != PRO_NONE ? 3 * (size_t)a.Kp * 4 : 0) + wbytes;
+  const size_t red = (size_t)2 * 4 * NTT * 32 * 4;
+  if (lds < red) lds = red;
+  auto kfn = mlp_gemm_bf16_kernel<NT, CW, PRO, EPI, XF32, YF32>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return pn2_check_launch();
+  const long long ntiles = (a.M + TM - 1) / TM;
+  long long grid = 512;                                     // persistent: two workgroups per CU
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256 * CW), lds, s, a);
+  return pn2_check_launch();
+}
+
+template <int PRO, int EPI, bool XF32, bool YF32>
+int dispatch_nt(const GemmBf16Args &a, hipStream_t s) {
+  const int nt = (a.N + 31) / 32;
+  switch (nt) {
+    case 1: return launch_gemm<1, 1, PRO, EPI, XF32, YF32>(a, s);
+    case 2: return launch_gemm<2, 1, PRO, EPI, XF32, YF32>(a, s);
+    case 3: return launch_gemm<3, 1, PRO, EPI, XF32, YF32>(a, s);
+    case 4: return launch_gemm<4, 1, PRO, EPI, XF32, YF32>(a, s);
+    case 5: case 6: return launch_gemm<3, 2, PRO, EPI, XF32, YF32>(a, s);
+    case 7: case 8: return launch_gemm<4, 2, PRO, EPI, XF32, YF32>(a, s);
+    case 9: case 10: return launch_gemm<5, 2, PRO, EPI, XF32, YF32>(a, s);
+    default: return PN2_EINVAL;
+  }
+}
+
+template <int NTW, int KTB, int MT, int GMODE, int AMODE, bool XF32>
+int launch_wgrad(const WgradBf16Args &a, hipStream_t s) {
+  constexpr int MP = MT + 8, NB = 4 * NTW * 32, KB = KTB * 32;
+  const size_t lds = (size_t)(NB + KB) * MP * 2 + (size_t)(3 * NB + 2 * KB) * 4;
+  auto kfn = mlp_wgrad_bf16_kernel<NTW, KTB, MT, GMODE, AMODE, XF32>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return pn2_check_launch();
+  const unsigned kblocks = (unsigned)((a.K + KB - 1) / KB);
+  const long long ntiles = (a.M + MT - 1) / MT;
+  long long gx = 512 / kblocks;
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)gx, kblocks), dim3(256), lds, s, a);
+  return pn2_check_launch();
+}
+
+template <int GMODE, int AMODE, bool XF32>
+int dispatch_wgrad(const WgradBf16Args &a, hipStream_t s) {
+  if (a.N <= 128) {
+    if (a.K <= 32) return launch_wgrad<1, 1, 128, GMODE, AMODE, XF32>(a, s);
+    if (a.K <= 64) return launch_wgrad<1, 2, 128, GMODE, AMODE, XF32>(a, s);
+    return launch_wgrad<1, 4, 128, GMODE, AMODE, XF32>(a, s);
+  }
+  if (a.N <= 256) {
+    if (a.K <= 32) return launch_wgrad<2, 1, 64, GMODE, AMODE, XF32>(a, s);
+    return launch_wgrad<2, 2, 64, GMODE, AMODE, XF32>(a, s);
+  }
+  if (a.N <= 384) {
+    if (a.K <= 32) return launch_wgrad<3, 1, 64, GMODE, AMODE, XF32>(a, s);
+    return launch_wgrad<3, 2, 64, GMODE, AMODE, XF32>(a, s);
+  }
+  return PN2_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
+                                 const void *X, const void *X2, const float *p0, const float *p1, const float *p2,
+                                 const int *arg, const float *gP, int ns, const float *W, void *Y, double *stats,
+                                 const void *Yprev, const float *e_fin, void *stream) {
+  if (M < 0 || K <= 0 || N <= 0 || N > 320 || K > 4096 || ldx < K || ldy < N) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!W || !Y) return PN2_ENULL;
+  if (!x_f32 && (ldx % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)X2 & 15))) return PN2_EINVAL;   // 16-byte row groups
+  if (x_f32 && pro != PRO_NONE) return PN2_EINVAL;
+  if (pro != PRO_POOLG && !X) return PN2_ENULL;
+  if (pro != PRO_NONE && (!p0 || !p1)) return PN2_ENULL;
+  if ((pro == PRO_GY || pro == PRO_POOLG) && (!X2 || !p2)) return PN2_ENULL;
+  if (pro == PRO_POOLG && (!arg || !gP || ns <= 0)) return PN2_ENULL;
+  if (epi != EPI_NONE && !stats) return PN2_ENULL;
+  if (epi == EPI_MASK && (!Yprev || !e_fin)) return PN2_ENULL;
+  if (y_f32 && epi != EPI_NONE) return PN2_EINVAL;
+  GemmBf16Args a;
+  a.X = X; a.X2 = (const bf16 *)X2; a.p0 = p0; a.p1 = p1; a.p2 = p2; a.arg = arg; a.gP = gP; a.W = W; a.Y = Y;
+  a.stats = stats; a.Yprev = (const bf16 *)Yprev; a.e_fin = e_fin; a.M = M; a.K = K; a.N = N; a.ldx = ldx; a.ldy = ldy;
+  a.ns = ns; a.Kp = (K + KC - 1) / KC * KC; a.wres = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (x_f32) {
+    if (epi == EPI_STATS) return dispatch_nt<PRO_NONE, EPI_STATS, true, false>(a, s);
+    if (epi == EPI_NONE && !y_f32) return dispatch_nt<PRO_NONE, EPI_NONE, true, false>(a, s);
+    return PN2_EINVAL;
+  }
+  switch (pro * 8 + epi * 2 + (y_f32 ? 1 : 0)) {
+    case PRO_NONE * 8 + EPI_NONE * 2: return dispatch_nt<PRO_NONE, EPI_NONE, false, false>(a, s);
+    case PRO_NONE * 8 + EPI_STATS * 2: return dispatch_nt<PRO_NONE, EPI_STATS, false, false>(a, s);
+    case PRO_BNRELU * 8 + EPI_NONE * 2: return dispatch_nt<PRO_BNRELU, EPI_NONE, false, false>(a, s);
+    case PRO_BNRELU * 8 + EPI_STATS * 2: return dispatch_nt<PRO_BNRELU, EPI_STATS, false, false>(a, s);
+    case PRO_GY * 8 + EPI_MASK * 2: return dispatch_nt<PRO_GY, EPI_MASK, false, false>(a, s);
+    case PRO_POOLG * 8 + EPI_MASK * 2: return dispatch_nt<PRO_POOLG, EPI_MASK, false, false>(a, s);
+    case PRO_GY * 8 + EPI_NONE * 2 + 1: return dispatch_nt<PRO_GY, EPI_NONE, false, true>(a, s);
+    case PRO_POOLG * 8 + EPI_NONE * 2 + 1: return dispatch_nt<PRO_POOLG, EPI_NONE, false, true>(a, s);
+    default: return PN2_EINVAL;
+  }
+}
+
+extern "C" int pn2_mlp_wgrad_bf16(long long M, int N, int K, int gmode, int amode, int x_f32, int ldx, const void *G,
+                                  const void *Yl, const float *consts, const int *arg, const float *gP, int ns,
+                                  const void *X, const float *a_fin, float *dW, void *stream) {
+  if (M < 0 || N <= 0 || K <= 0 || N > 384 || N % 8 != 0 || ldx < K) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Yl || !consts || !X || !dW) return PN2_ENULL;
+  if (gmode == PRO_GY && !G) return PN2_ENULL;
+  if (gmode == PRO_POOLG && (!arg || !gP || ns <= 0)) return PN2_ENULL;
+  if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
+  if (amode == PRO_BNRELU && (!a_fin || x_f32)) return PN2_EINVAL;
+  if (!x_f32 && (ldx % 8 != 0 || ((uintptr_t)X & 15))) return PN2_EINVAL;
+  if (((uintptr_t)Yl & 15) || ((uintptr_t)G & 15)) return PN2_EINVAL;
+  WgradBf16Args a;
+  a.G = (const bf16 *)G; a.Yl = (const bf16 *)Yl; a.consts = consts; a.arg = arg; a.gP = gP; a.X = X; a.a_fin = a_fin;
+  a.dW = dW; a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ns = ns;
+  hipStream_t s = (hipStream_t)stream;
+  if (gmode == PRO_GY) {
+    if (amode == PRO_BNRELU) return dispatch_wgrad<PRO_GY, PRO_BNRELU, false>(a, s);
+    return x_f32 ? dispatch_wgrad<PRO_GY, PRO_NONE, true>(a, s) : dispatch_wgrad<PRO_GY, PRO_NONE, false>(a, s);
+  }
+  if (amode == PRO_BNRELU) return dispatch_wgrad<PRO_POOLG, PRO_BNRELU, false>(a, s);
+  return x_f32 ? dispatch_wgrad<PRO_POOLG, PRO_NONE, true>(a, s) : dispatch_wgrad<PRO_POOLG, PRO_NONE, false>(a, s);
+}
+
+extern "C" int pn2_bn_relu_apply_bf16(long long M, int N, const void *y, const float *fin, float *out, void *stream) {
+  if (M < 0 || N <= 0) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!y || !fin || !out) return PN2_ENULL;
+  const size_t total = (size_t)M * N;
+  hipLaunchKernelGGL(bn_relu_apply_bf16_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream, total, N,
+                     (const bf16 *)y, fin, out);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_bn_relu_bwd_prep_bf16(long long M, int N, const void *y, const float *gout, const float *fin,
+                                         void *gpre, double *sums, void *stream) {
+  if (M < 0 || N <= 0) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!y || !gout || !fin || !gpre || !sums) return PN2_ENULL;
+  const long long blocks = (M + kPrepRowsBf - 1) / kPrepRowsBf;
+  if (blocks > 0x7fffffffLL) return PN2_EINVAL;
+  hipLaunchKernelGGL(bn_relu_bwd_prep_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, N,
+                     (const bf16 *)y, gout, fin, (bf16 *)gpre, sums);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_bn_relu_rows_max_bf16(long long R, int ns, int C, const void *y, const float *fin, float *out,
+                                         int *arg, float *yraw, void *stream) {
+  if (R < 0 || ns <= 0 || C <= 0 || C % 2 != 0) return PN2_EINVAL;
+  if (R == 0) return PN2_OK;
+  if (!y || !fin || !out || !arg || !yraw) return PN2_ENULL;
+  const size_t total = (size_t)R * C / 2;
+  hipLaunchKernelGGL(bn_relu_rows_max_bf16_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream, total, ns,
+                     C, (const bf16 *)y, fin, out, arg, yraw);
+  return pn2_check_launch();
+}

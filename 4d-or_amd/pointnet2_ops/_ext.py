@@ -47,7 +47,7 @@ _SIGNATURES = {
     "pn2_gather_points": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_gather_points_grad": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_ball_query": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
-    "pn2_ball_query_unique_resample": [ctypes.c_longlong, _c_int, ctypes.c_uint, _c_vp, _c_vp],
+    "pn2_ball_query_unique_resample": [ctypes.c_longlong, _c_int, ctypes.c_uint, _c_vp, _c_vp, _c_vp],
     "pn2_group_points": [_c_int] * 5 + [_c_vp] * 4,
     "pn2_group_points_grad": [_c_int] * 5 + [_c_vp] * 4,
     "pn2_three_nn": [_c_int] * 3 + [_c_vp] * 5,
@@ -63,14 +63,20 @@ _SIGNATURES = {
     "pn2_scatter_add_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_segment_sum_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_segment_bn_rows": [_c_i64, _c_int, _c_int, _c_int, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_f32, _c_int, _c_vp, _c_vp,
-                            _c_vp],
-    "pn2_segment_bn_rows_grad": [_c_i64, _c_int, _c_int, _c_int, _c_i64] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 3,
+                            _c_vp, _c_vp],
+    "pn2_segment_bn_rows_grad": [_c_i64, _c_int, _c_int, _c_int, _c_i64] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_gemm": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
     "pn2_mlp_wgrad": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_fused": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
     "pn2_mlp_bwd_fused_fold": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 +
                               [_c_int] + [_c_vp] * 4,
     "pn2_rows_gram": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp],
+    "pn2_mlp_gemm_bf16": [ctypes.c_longlong] + [_c_int] * 8 + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
+    "pn2_mlp_wgrad_bf16": [ctypes.c_longlong] + [_c_int] * 6 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
+    "pn2_bn_relu_apply_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_bn_relu_bwd_prep_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_bn_relu_rows_max_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_group_concat_rows_bf16": [_c_int] * 7 + [_c_f32, _c_int] + [_c_vp] * 6,
     "pn2_first_layer_dw": [_c_int, _c_int] + [_c_vp] * 6,
     "pn2_bn_finalize": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_bwd_consts": [_c_int, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int,
@@ -757,3 +763,107 @@ def pool_bwd_prep(yraw, pooled, gP, fin, sums=None):
     _call("pn2_pool_bwd_prep", pooled, R, C, _ptr(yraw), _ptr(pooled), _ptr(gP), _ptr(fin), _ptr(gPm),
           _ptr(sums), alg_bytes=16 * R * C)
     return gPm, sums
+
+
+# ------------------------------------------- mixed precision: bf16 activations, fp32 weights / statistics (A10)
+HAS_BF16_MLP = True
+BF16 = torch.bfloat16
+
+
+def _bf16(t, name):
+    _check_cuda(t, name)
+    if t.dtype != torch.bfloat16 or not t.is_contiguous():
+        _fail(f"{name} must be a contiguous bfloat16 tensor")
+
+
+def pad8(k):
+    return (int(k) + 7) // 8 * 8
+
+
+def group_concat_rows_bf16(xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius):
+    """As group_concat_rows, rows written as bf16 with a pitch rounded up to 8 columns (zero pad): (B,m,ns,pad8(Cx+C))."""
+    _i32(idx, "idx")
+    B, m, ns = idx.shape
+    N = xyz.size(1)
+    C = 0
+    if use_xyz:
+        _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
+    if feats_rows is not None:
+        _f32(feats_rows, "features")
+        C = feats_rows.size(2)
+    _same_device((xyz, "xyz"), (idx, "idx"), (new_xyz, "new_xyz"), (feats_rows, "features"))
+    W = (3 if use_xyz else 0) + C
+    ldo = pad8(W)
+    out = torch.empty(B, m, ns, ldo, dtype=torch.bfloat16, device=xyz.device)
+    _call("pn2_group_concat_rows_bf16", xyz, B, N, m, ns, C, int(bool(use_xyz)), int(bool(normalize)),
+          float(radius if radius is not None else 1.0), ldo, _ptr(xyz), _ptr(new_xyz), _ptr(feats_rows), _ptr(idx), _ptr(out),
+          alg_bytes=B * (4 * m * ns + (12 * N + 12 * m if use_xyz else 0) + 4 * C * N + 2 * ldo * m * ns))
+    return out
+
+
+def mlp_gemm_bf16(X, W, pro=PRO_NONE, epi=EPI_NONE, X2=None, p=None, arg=None, gP=None, ns=0, stats=None, Yprev=None,
+                  e_fin=None, M=None, out_f32=False):
+    """Y (M, N) = pro(X) (M, K) @ W (N, K)^T on the bf16 MFMA path.  X: bf16 rows (pitch = X.size(1), a multiple of 8, may
+    exceed K with zero pad columns) or fp32 rows (pro 0 only); W fp32; Y bf16 (fp32 when out_f32)."""
+    _f32(W, "W")
+    N, K = W.shape
+    ref = X if X is not None else X2
+    M = int(M if M is not None else ref.size(0))
+    x_f32 = ref.dtype == torch.float32
+    ldx = ref.size(1)
+    Y = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=W.device)
+    p0 = p1 = p2 = None
+    if p is not None:
+        p0, p1 = p[0], p[1]
+        p2 = p[2] if len(p) > 2 else None
+    eb = 4 if x_f32 else 2
+    nbytes = (M * ldx * eb * (2 if pro == PRO_GY else 1) + M * N * (4 if out_f32 else 2) * (2 if epi == EPI_MASK else 1)
+              + 4 * N * K)
+    _call("pn2_mlp_gemm_bf16", W, M, K, N, int(pro), int(epi), int(x_f32), int(bool(out_f32)), ldx, N, _ptr(X), _ptr(X2),
+          _ptr(p0), _ptr(p1), _ptr(p2), _ptr(arg), _ptr(gP), int(ns), _ptr(W), _ptr(Y), _ptr(stats), _ptr(Yprev), _ptr(e_fin),
+          alg_bytes=nbytes, alg_flops=2 * M * N * K,
+          tag=(f"M{M},K{K},N{N},pro{int(pro)},epi{int(epi)}" if DETAIL_TAGS else None))
+    return Y
+
+
+def mlp_wgrad_bf16(Yl, consts, X, gmode, amode, K, G=None, arg=None, gP=None, ns=0, a_fin=None, dW=None):
+    """dW (N, K) fp32 += gy^T @ act; Yl / G bf16 (M, N); X bf16 (M, ldx >= K) or fp32 rows (amode 0)."""
+    M, N = Yl.shape
+    x_f32 = X.dtype == torch.float32
+    if dW is None:
+        dW = torch.zeros(N, int(K), dtype=torch.float32, device=Yl.device)
+    _call("pn2_mlp_wgrad_bf16", Yl, M, N, int(K), int(gmode), int(amode), int(x_f32), X.size(1), _ptr(G), _ptr(Yl),
+          _ptr(consts), _ptr(arg), _ptr(gP), int(ns), _ptr(X), _ptr(a_fin), _ptr(dW),
+          alg_bytes=2 * M * N * (2 if gmode == PRO_GY else 1) + M * X.size(1) * (4 if x_f32 else 2) + 4 * N * int(K),
+          alg_flops=2 * M * N * int(K), tag=(f"M{M},N{N},K{K},g{int(gmode)},a{int(amode)}" if DETAIL_TAGS else None))
+    return dW
+
+
+def bn_relu_apply_bf16(y, fin):
+    _bf16(y, "y")
+    M, N = y.shape
+    out = torch.empty(M, N, dtype=torch.float32, device=y.device)
+    _call("pn2_bn_relu_apply_bf16", y, M, N, _ptr(y), _ptr(fin), _ptr(out), alg_bytes=6 * M * N)
+    return out
+
+
+def bn_relu_bwd_prep_bf16(y, gout, fin, sums=None):
+    _bf16(y, "y"); _f32(gout, "gout")
+    M, N = y.shape
+    gpre = torch.empty_like(y)
+    if sums is None:
+        sums = torch.zeros(2, N, dtype=torch.float64, device=y.device)
+    _call("pn2_bn_relu_bwd_prep_bf16", y, M, N, _ptr(y), _ptr(gout), _ptr(fin), _ptr(gpre), _ptr(sums), alg_bytes=8 * M * N)
+    return gpre, sums
+
+
+def bn_relu_rows_max_bf16(y, fin, ns):
+    _bf16(y, "y")
+    M, C = y.shape
+    R = M // int(ns)
+    out = torch.empty(R, C, dtype=torch.float32, device=y.device)
+    arg = torch.empty(R, C, dtype=torch.int32, device=y.device)
+    yraw = torch.empty(R, C, dtype=torch.float32, device=y.device)
+    _call("pn2_bn_relu_rows_max_bf16", y, R, int(ns), C, _ptr(y), _ptr(fin), _ptr(out), _ptr(arg), _ptr(yraw),
+          alg_bytes=2 * M * C + 12 * R * C)
+    return out, arg, yraw

@@ -30,6 +30,34 @@ def _ext():
 #: hidden layers with 32 < N, K <= 128 run dgrad and wgrad as one kernel (csrc/mlp_bwd_fused.hip)
 FUSED_BACKWARD = True
 
+#: arithmetic of the shared-MLP stacks.  float32 = exact fp32 MFMA (the parity path, default).  bfloat16 = the MI355X
+#: counterpart of the reference's 16-bit AMP training (scene_graph_prediction/main.py:64 `precision=16`): activations
+#: between the layers stored as bf16, bf16 MFMA with fp32 accumulation, fp32 weights / BatchNorm statistics / weight
+#: gradients; the geometry and grouping kernels stay fp32 like the reference's `custom_fwd(cast_inputs=float32)`
+#: (OPS/pointnet2_utils.py:198).
+_MLP_DTYPE = torch.float32
+
+
+def set_mlp_dtype(dtype) -> torch.dtype:
+    """torch.float32 | torch.bfloat16 (or "f32" / "bf16"); returns the previous setting."""
+    global _MLP_DTYPE
+    dtype = {"f32": torch.float32, "fp32": torch.float32, "bf16": torch.bfloat16}.get(dtype, dtype)
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("shared-MLP dtype must be torch.float32 or torch.bfloat16")
+    prev, _MLP_DTYPE = _MLP_DTYPE, dtype
+    return prev
+
+
+def mlp_dtype() -> torch.dtype:
+    return _MLP_DTYPE
+
+
+def _bf16_ok(layers, ns) -> bool:
+    """Shapes the bf16 kernels cover (csrc/mlp_bf16.hip): output widths that are multiples of 8 (16-byte bf16 row
+    groups) up to 320, any input width."""
+    return (all(conv.out_channels % 8 == 0 and conv.out_channels <= 320 and conv.in_channels <= 4096 for conv, _ in layers)
+            and (not ns or layers[-1][0].out_channels % 2 == 0))
+
 
 def parse_stack(mlp: nn.Module) -> Optional[List[Tuple[nn.Conv2d, nn.modules.batchnorm._BatchNorm]]]:
     """Flatten `mlp` into [(conv1x1, bn), ...] if it is exactly (conv, bn, relu)*; else None."""
@@ -225,6 +253,136 @@ class _FusedMLP(Function):
         return (gx, None, None, None, *grads)
 
 
+class _FusedMLPBf16(Function):
+    """The same stack on the bf16 MFMA kernels: y_l and the activation gradients are bf16 tensors, everything that is
+    reduced (BatchNorm sums, weight gradients) or small (pooled outputs, per-channel constants) stays fp32 / fp64."""
+
+    @staticmethod
+    def forward(ctx, x, ns, layers, group, *params):
+        e = _ext()
+        ctx.group = group
+        if group is not None:
+            xyz, new_xyz, idx, use_xyz, normalize, radius = group
+            ctx.feat_shape = None if x is None else tuple(x.shape)
+            k_in = (3 if use_xyz else 0) + (0 if x is None else x.size(2))
+            x = e.group_concat_rows_bf16(xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize, radius)
+            x = x.view(-1, x.size(-1))                                      # (M, pad8(k_in)) bf16, zero pad columns
+        else:
+            x = x.contiguous()                                              # fp32 rows of any width
+            k_in = x.size(1)
+        M = x.size(0)
+        L = len(layers)
+        ys, fins, batch_flags = [], [], []
+        stat_bufs = e.zero_arena(x.device, [((2, conv.out_channels), torch.float64) for conv, _ in layers])
+        cur = x
+        for l, (conv, bn) in enumerate(layers):
+            W = params[3 * l].view(conv.out_channels, conv.in_channels)
+            gamma, beta = params[3 * l + 1], params[3 * l + 2]
+            use_batch = bn.training or bn.running_mean is None
+            pro = e.PRO_NONE if l == 0 else e.PRO_BNRELU
+            p = None if l == 0 else (fins[-1][2], fins[-1][3])
+            if use_batch:
+                stats = stat_bufs[l]
+                y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
+                momentum = 0.0
+                rm = rv = nbt = None
+                if bn.training and bn.track_running_stats and bn.running_mean is not None:
+                    rm, rv = bn.running_mean, bn.running_var
+                    if bn.momentum is not None:
+                        momentum, nbt = bn.momentum, bn.num_batches_tracked
+                    else:
+                        if bn.num_batches_tracked is not None:
+                            bn.num_batches_tracked.add_(1)
+                        momentum = 1.0 / float(bn.num_batches_tracked)
+                fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt)
+            else:
+                y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
+                rstd = torch.rsqrt(bn.running_var + bn.eps)
+                scale = gamma * rstd
+                fin = torch.stack([bn.running_mean, rstd, scale, beta - bn.running_mean * scale]).contiguous()
+            ys.append(y)
+            fins.append(fin)
+            batch_flags.append(use_batch)
+            cur = y
+        yraw = None
+        if ns:
+            out, arg, yraw = e.bn_relu_rows_max_bf16(ys[-1], fins[-1], ns)
+        else:
+            out, arg = e.bn_relu_apply_bf16(ys[-1], fins[-1]), None
+        ctx.ns, ctx.L, ctx.batch_flags, ctx.k_in = ns, L, batch_flags, k_in
+        ctx.shapes = [params[3 * l].shape for l in range(L)]
+        saved = [x] + ys + fins + [params[3 * l] for l in range(L)] + [params[3 * l + 1] for l in range(L)]
+        if ns:
+            saved += [out, arg, yraw]
+            ctx.mark_non_differentiable(arg)
+        ctx.save_for_backward(*saved)
+        return (out, arg) if ns else out
+
+    @staticmethod
+    def backward(ctx, g_out, *unused):
+        e = _ext()
+        L, ns = ctx.L, ctx.ns
+        saved = ctx.saved_tensors
+        x = saved[0]
+        ys = saved[1:1 + L]
+        fins = saved[1 + L:1 + 2 * L]
+        Ws = [w.view(w.size(0), w.size(1)) for w in saved[1 + 2 * L:1 + 3 * L]]
+        gammas = saved[1 + 3 * L:1 + 4 * L]
+        M = x.size(0)
+        g_out = g_out.contiguous()
+        f64, f32 = torch.float64, torch.float32
+        need_dgrad0 = ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None)
+        arena = e.zero_arena(x.device, [((2, Ws[-1].size(0)), f64)] + [((2, Ws[l].size(1)), f64) for l in range(L)] +
+                             [(tuple(Ws[l].shape), f32) for l in range(L)])
+        sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:1 + 2 * L]
+        if ns:
+            pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
+            gPm, sums = e.pool_bwd_prep(yraw, pooled, g_out, fins[-1], sums=sums0)
+            gmode, G = e.PRO_POOLG, None
+        else:
+            G, sums = e.bn_relu_bwd_prep_bf16(ys[-1], g_out, fins[-1], sums=sums0)
+            gmode, arg, gPm = e.PRO_GY, None, None
+
+        grads = [None] * (3 * L)
+        gx = None
+        for l in range(L - 1, -1, -1):
+            need_dgrad = l > 0 or need_dgrad0
+            if need_dgrad:
+                k0 = 3 if (l == 0 and ctx.group is not None and ctx.group[3]) else 0
+                consts, dgamma, dbeta, Wt = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l],
+                                                            W=Ws[l].contiguous(), k0=k0)
+            else:
+                consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
+            grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            act = x if l == 0 else ys[l - 1]
+            dW = e.mlp_wgrad_bf16(ys[l], consts, act, gmode, e.PRO_NONE if l == 0 else e.PRO_BNRELU, Ws[l].size(1),
+                                  G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1], dW=dWs[l])
+            grads[3 * l] = dW.view(ctx.shapes[l])
+            if need_dgrad:
+                p = (consts[0], consts[1], consts[2])
+                if l > 0:
+                    sums = sums_in[l]
+                    G = e.mlp_gemm_bf16(G, Wt, pro=gmode, epi=e.EPI_MASK, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns,
+                                        stats=sums, Yprev=ys[l - 1], e_fin=fins[l - 1], M=M)
+                    gmode, arg, gPm = e.PRO_GY, None, None
+                else:
+                    gx = e.mlp_gemm_bf16(G, Wt, pro=gmode, epi=e.EPI_NONE, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns, M=M,
+                                         out_f32=True)
+        if gx is not None and ctx.group is not None:
+            idx = ctx.group[2]
+            Bq, npoint, nsample = idx.shape
+            Bf, Nf, Cf = ctx.feat_shape
+            gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0)
+        return (gx, None, None, None, *grads)
+
+
+def _node(layers, ns):
+    """The autograd node for the current arithmetic (set_mlp_dtype) that covers this stack."""
+    if _MLP_DTYPE == torch.bfloat16 and getattr(_ext(), "HAS_BF16_MLP", False) and _bf16_ok(layers, ns):
+        return _FusedMLPBf16
+    return _FusedMLP
+
+
 def _params(layers):
     params = []
     for conv, bn in layers:
@@ -236,7 +394,7 @@ def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0) -> torch.Tens
     """x (M, C_in) rows -> (M, C_out) [ns == 0] or (M // ns, C_out) max-pooled over groups of ns rows."""
     layers = parse_stack(mlp)
     assert layers is not None, "fused_shared_mlp: unsupported stack (call supported() first)"
-    res = _FusedMLP.apply(x, int(ns), layers, None, *_params(layers))
+    res = _node(layers, ns).apply(x, int(ns), layers, None, *_params(layers))
     return res[0] if ns else res
 
 
@@ -247,5 +405,5 @@ def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz,
     assert layers is not None
     B, m, ns = idx.shape
     group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius)
-    res = _FusedMLP.apply(feats_rows, int(ns), layers, group, *_params(layers))
+    res = _node(layers, ns).apply(feats_rows, int(ns), layers, group, *_params(layers))
     return res[0].view(B, m, -1)

@@ -42,6 +42,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md chip table (spec; ~6300 achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA (= fp32 vector peak), same table
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (32x32x16), same table (the 5 PF headline figure is 2:1 sparse)
 
 
 def synthetic_scenes(batch, points, seed, device):
@@ -181,8 +182,9 @@ def forward_only(net, backbone, pc, steps, prefetcher):
 def kernel_table(table, steps):
     """Per-entry-point rows from a KernelTimer summary, sorted by time."""
     rows = []
-    ridge = F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)     # flop/byte where the rooflines cross
     for name, d in table.items():
+        peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS
+        ridge = peak * 1e12 / (HBM_PEAK_GBPS * 1e9)                   # flop/byte where the rooflines cross
         per_launch_ms = d["ms"] / d["calls"]
         per_launch_bytes = d["alg_bytes"] / d["calls"]
         per_launch_flops = d["alg_flops"] / d["calls"]
@@ -195,8 +197,8 @@ def kernel_table(table, steps):
                      "alg_MB_per_launch": round(per_launch_bytes / 1e6, 3),
                      "alg_GFLOP_per_launch": round(per_launch_flops / 1e9, 3),
                      "GBps": round(gbps, 1), "TFLOPps": round(tfps, 2),
-                     "bound": "mfma" if mfma_bound else "hbm",
-                     "frac": round(tfps / F32_MFMA_PEAK_TFLOPS if mfma_bound else gbps / HBM_PEAK_GBPS, 5)})
+                     "bound": "mfma" if mfma_bound else "hbm", "mfma_peak_TFLOPps": peak,
+                     "frac": round(tfps / peak if mfma_bound else gbps / HBM_PEAK_GBPS, 5)})
     rows.sort(key=lambda r: -r["ms_per_step"])
     return rows
 
@@ -206,7 +208,7 @@ def roofline_of(top, pmc_applies=True):
     collected on the default command — backbone workload, 32 x 50k — and is quoted for that command only)."""
     if top["bound"] == "mfma":
         roof = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["TFLOPps"],
-                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac"]}
+                "peak": top.get("mfma_peak_TFLOPps", F32_MFMA_PEAK_TFLOPS), "unit": "TFLOP/s", "frac": top["frac"]}
     else:
         roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"]}
@@ -355,15 +357,21 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    timer = None
+    # per-kernel HIP events on ONE sampled step only: two event records per launch double the host cost of a step that
+    # is host-bound at one scan per step (~400 launches)
+    timer, sampled = None, -1
     if not args.no_kernel_timing:
-        timer = _ext.KernelTimer()
+        timer = _ext.KernelTimer(torch.cuda.current_stream(device).cuda_stream)
+        timer.enabled = False
         _ext.TIMER = timer
+        sampled = args.steps // 2
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if timer is not None:
+            timer.enabled = i == sampled
         step()
     enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to enqueue a step (no GPU wait)
     torch.cuda.synchronize()
@@ -380,7 +388,7 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
         out = {"metric": "OR scans/sec fwd+bwd (9 objects x 4000 pts + 72 pairs x 8000 pts per scan)",
                "value": round(world * S * args.steps / elapsed, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2] shape: SGPNModelWrapper(no_gt.json), {S} synthetic scan(s) per step "
                                       "and rank (block-diagonal batch: per-scan GCN BatchNorm statistics and loss average; "
                                       "SA BatchNorm2d statistics over the step's clouds), train mode, fwd + weighted NLL + bwd + AdamW",
@@ -389,11 +397,14 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
                           "host_enqueue_ms_per_step": round(enqueue_ms, 3),
                           "geometry_pipeline": bool(args.geometry_pipeline and not args.graphs)}}
         if timer is not None:
-            rows = [{"kernel": k, "calls_per_step": d["calls"] / args.steps, "ms_per_step": round(d["ms"] / args.steps, 4)}
-                    for k, d in timer.summary().items()]
-            rows.sort(key=lambda r: -r["ms_per_step"])
+            rows = kernel_table(timer.summary(), 1)
             out["kernels"] = rows
-            out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in rows), 3)
+            out["kernel_timing"] = {"method": "HIP events on the launch stream around every C-ABI call", "sampled_steps": 1,
+                                    "of_steps": args.steps}
+            main_rows = [r for r in rows if not r["kernel"].endswith("@side")]
+            out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
+            if main_rows:
+                out["roofline"] = roofline_of(main_rows[0], False)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
@@ -418,6 +429,9 @@ def main():
                          "scene-graph model's MSG object encoder (SURVEY 8d stack 2a); sgp = BASELINE configs[2] shape: the full "
                          "scene-graph model on synthetic scans (9 objects x 4000 pts + 72 pairs x 8000 pts, one scan per "
                          "step like the reference's DataLoader(batch_size=1)), fp32")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="arithmetic of the shared-MLP stacks: f32 = exact fp32 MFMA (the headline / parity path); bf16 = the "
+                         "counterpart of the reference's 16-bit AMP (bf16 activations and MFMA, fp32 weights and statistics)")
     ap.add_argument("--scans-per-step", type=int, default=1,
                     help="sgp workload: scans per step and rank, collated block-diagonally (BASELINE configs[2] names 32)")
     ap.add_argument("--graphs", action="store_true",
@@ -444,7 +458,8 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
-    from pointnet2_ops import _ext
+    from pointnet2_ops import _ext, fused_mlp
+    fused_mlp.set_mlp_dtype(args.dtype)
 
     if args.workload == "sgp":
         return bench_sgp(args, device, rank, world, distributed, _ext)
@@ -538,7 +553,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: {args.batch} scenes/GPU x {args.points} pts x (3 xyz + 3 rgb) fp32, " + (

@@ -272,6 +272,39 @@ int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const float *pooled
                       const float *gP, const float *fin, float *gPm, double *sums,
                       void *stream);
 
+/* ----------------------------------------------------- A10, mixed precision ---
+ * bf16 variants of the shared-MLP kernels.  The reference trains under 16-bit AMP (scene_graph_prediction/main.py:64
+ * `precision=16`; GroupingOperation forces fp32, OPS/pointnet2_utils.py:198): 1x1 convolutions in half precision,
+ * fp32 master weights, fp32 BatchNorm statistics.  Here the activations BETWEEN the layers of a stack (raw pre-BN
+ * outputs y_l, gradients dL/dz_l) are stored as bf16, the products run on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation, statistics / constants / weights / weight gradients stay fp32 (fp64 sums).  bf16 tensors are passed as
+ * `void *`, row pitches (ldx / ldy, in elements) must be multiples of 8 and the base pointers 16-byte aligned.
+ *
+ *   pn2_mlp_gemm_bf16: Y[M][N] (pitch ldy) = pro(X)[M][K] (pitch ldx) * W[N][K]^T, pro / epi as pn2_mlp_gemm.
+ *     x_f32: X is fp32 rows of any pitch (pro must be 0);  y_f32: Y is fp32 (epi must be 0: the input gradient that
+ *     leaves the stack).  Columns K..ldx-1 of a bf16 X must be finite (they meet zero weights).  N <= 320.
+ *   pn2_mlp_wgrad_bf16: dW[N][K] fp32 += gy^T * act, gy / act formed on the fly as in pn2_mlp_wgrad; G, Yl bf16 [M][N]
+ *     (N % 8 == 0), X = bf16 y_{l-1} (amode 1) or the stack's input rows (amode 0; fp32 of any pitch when x_f32).
+ *   pn2_bn_relu_apply_bf16 / pn2_bn_relu_bwd_prep_bf16 / pn2_bn_relu_rows_max_bf16: as the fp32 helpers with y bf16
+ *     (gpre bf16); pooled outputs, arg-max and raw arg-max values stay fp32 / int32 (C % 2 == 0).
+ *   pn2_group_concat_rows_bf16: pn2_group_concat_rows writing bf16 rows of pitch ldo (% 8 == 0), pad columns zeroed.
+ */
+int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
+                      const void *X, const void *X2, const float *p0, const float *p1, const float *p2,
+                      const int *arg, const float *gP, int ns, const float *W, void *Y, double *stats,
+                      const void *Yprev, const float *e_fin, void *stream);
+int pn2_mlp_wgrad_bf16(long long M, int N, int K, int gmode, int amode, int x_f32, int ldx, const void *G,
+                       const void *Yl, const float *consts, const int *arg, const float *gP, int ns,
+                       const void *X, const float *a_fin, float *dW, void *stream);
+int pn2_bn_relu_apply_bf16(long long M, int N, const void *y, const float *fin, float *out, void *stream);
+int pn2_bn_relu_bwd_prep_bf16(long long M, int N, const void *y, const float *gout, const float *fin,
+                              void *gpre, double *sums, void *stream);
+int pn2_bn_relu_rows_max_bf16(long long R, int ns, int C, const void *y, const float *fin, float *out,
+                              int *arg, float *yraw, void *stream);
+int pn2_group_concat_rows_bf16(int B, int N, int m, int ns, int C, int use_xyz, int normalize, float radius,
+                               int ldo, const float *xyz, const float *new_xyz, const float *feats,
+                               const int *idx, void *out, void *stream);
+
 /* ------------------------------------------------------------------ A12 ---
  * TripletGCN edge primitives.  Replace torch_geometric 2.0.2
  * MessagePassing.__lift__ (x.index_select(-2, edge_index[i])) and

@@ -48,3 +48,18 @@ def test_python_binding_covers_every_symbol_and_refuses_cpu_tensors():
         _ext.ball_query(torch.zeros(1, 3, 2).transpose(1, 2), torch.zeros(1, 4, 3), 0.1, 2)
     with pytest.raises(RuntimeError, match="int tensor"):
         _ext.gather_points(torch.zeros(1, 3, 4), torch.zeros(1, 2, dtype=torch.int64))
+
+
+def test_ctypes_signatures_have_the_header_arity():
+    """Every ctypes argtypes list (incl. the trailing stream) has as many entries as the C prototype has parameters: a
+    missing entry makes ctypes pass the 64-bit stream handle as a 32-bit int (hipErrorInvalidValue at launch)."""
+    from pointnet2_ops import _ext
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    seen = 0
+    for m in re.finditer(r"\b(pn2_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        name, params = m.group(1), m.group(2)
+        n = 0 if params.strip() in ("", "void") else params.count(",") + 1
+        if name in _ext._SIGNATURES:
+            assert len(_ext._SIGNATURES[name]) == n, name
+            seen += 1
+    assert seen == len(_ext._SIGNATURES)
