@@ -61,6 +61,7 @@ struct GemmBf16Args {
   const float *e_fin; // EPI_MASK: [mean | rstd | scale | shift] x N
   long long M;
   int K, N, ldx, ldy, ns;
+  int Nfull;          // stride of the per-column vectors (stats, e_fin): the full output width when N is a column block
   int Kp;             // K rounded up to KC
   int wres;           // weights resident in LDS
 };
@@ -109,9 +110,9 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
     if constexpr (EPI == EPI_MASK) {
       const bool ok = c < N;
       e_mean[nt] = ok ? a.e_fin[c] : 0.f;
-      e_rstd[nt] = ok ? a.e_fin[N + c] : 0.f;
-      e_sc[nt] = ok ? a.e_fin[2 * N + c] : 0.f;
-      e_sh[nt] = ok ? a.e_fin[3 * N + c] : 0.f;
+      e_rstd[nt] = ok ? a.e_fin[a.Nfull + c] : 0.f;
+      e_sc[nt] = ok ? a.e_fin[2 * a.Nfull + c] : 0.f;
+      e_sh[nt] = ok ? a.e_fin[3 * a.Nfull + c] : 0.f;
     }
   }
 
@@ -197,9 +198,11 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
               v[i] = fmaf(q0[i], g, fmaf(q1[i], y, q2[i]));
             }
           }
+          // rows past M read as zeros, but their prologue value (relu(shift), c3) is not zero: they must not reach the
+          // column sums of the epilogue
           u32x4 w;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) w[i] = bf_pack(v[2 * i], v[2 * i + 1]);
+          for (int i = 0; i < 4; ++i) w[i] = grow < a.M ? bf_pack(v[2 * i], v[2 * i + 1]) : 0u;
           *(u32x4 *)&sA[lr * AP + lk + 8 * j] = w;
         }
       }
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
       const int which = e / (NTT * 32), c = e - which * NTT * 32;
       if (c < N) {
         const float *p = red + which * 4 * NTT * 32 + c;
-        atomicAdd(a.stats + (size_t)which * N + c, (double)p[0] + (double)p[NTT * 32] + (double)p[2 * NTT * 32] + (double)p[3 * NTT * 32]);
+        atomicAdd(a.stats + (size_t)which * a.Nfull + c, (double)p[0] + (double)p[NTT * 32] + (double)p[2 * NTT * 32] + (double)p[3 * NTT * 32]);
       }
     }
   }
@@ -623,13 +626,15 @@ int dispatch_wgrad(const WgradBf16Args &a, hipStream_t s) {
   return PN2_EINVAL;
 }
 
+int pn2_mlp_gemm_bf16_block(GemmBf16Args a, int n0, int nb, int ys, int pro, int epi, int x_f32, int y_f32, hipStream_t s);
+
 }  // namespace
 
 extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
                                  const void *X, const void *X2, const float *p0, const float *p1, const float *p2,
                                  const int *arg, const float *gP, int ns, const float *W, void *Y, double *stats,
                                  const void *Yprev, const float *e_fin, void *stream) {
-  if (M < 0 || K <= 0 || N <= 0 || N > 320 || K > 4096 || ldx < K || ldy < N) return PN2_EINVAL;
+  if (M < 0 || K <= 0 || N <= 0 || K > 4096 || ldx < K || ldy < N) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!W || !Y) return PN2_ENULL;
   if (!x_f32 && (ldx % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)X2 & 15))) return PN2_EINVAL;   // 16-byte row groups
@@ -644,8 +649,29 @@ extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, in
   GemmBf16Args a;
   a.X = X; a.X2 = (const bf16 *)X2; a.p0 = p0; a.p1 = p1; a.p2 = p2; a.arg = arg; a.gP = gP; a.W = W; a.Y = Y;
   a.stats = stats; a.Yprev = (const bf16 *)Yprev; a.e_fin = e_fin; a.M = M; a.K = K; a.N = N; a.ldx = ldx; a.ldy = ldy;
-  a.ns = ns; a.Kp = (K + KC - 1) / KC * KC; a.wres = 0;
+  a.ns = ns; a.Kp = (K + KC - 1) / KC * KC; a.wres = 0; a.Nfull = N;
   hipStream_t s = (hipStream_t)stream;
+  if (N > 320) {
+    // wide outputs (the input gradient of a 512-column FP stack): column blocks of 256, A re-read per block
+    const int ys = y_f32 ? 4 : 2;
+    for (int n0 = 0; n0 < N; n0 += 256) {
+      const int nb = N - n0 < 256 ? N - n0 : 256;
+      const int rc = pn2_mlp_gemm_bf16_block(a, n0, nb, ys, pro, epi, x_f32, y_f32, s);
+      if (rc != PN2_OK) return rc;
+    }
+    return PN2_OK;
+  }
+  return pn2_mlp_gemm_bf16_block(a, 0, N, y_f32 ? 4 : 2, pro, epi, x_f32, y_f32, s);
+}
+
+namespace {
+int pn2_mlp_gemm_bf16_block(GemmBf16Args a, int n0, int nb, int ys, int pro, int epi, int x_f32, int y_f32, hipStream_t s) {
+  a.W += (size_t)n0 * a.K;
+  a.Y = (char *)a.Y + (size_t)n0 * ys;
+  if (a.Yprev) a.Yprev += n0;
+  if (a.e_fin) a.e_fin += n0;
+  if (a.stats) a.stats += n0;
+  a.N = nb;
   if (x_f32) {
     if (epi == EPI_STATS) return dispatch_nt<PRO_NONE, EPI_STATS, true, false>(a, s);
     if (epi == EPI_NONE && !y_f32) return dispatch_nt<PRO_NONE, EPI_NONE, true, false>(a, s);
@@ -663,6 +689,7 @@ extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, in
     default: return PN2_EINVAL;
   }
 }
+}  // namespace
 
 extern "C" int pn2_mlp_wgrad_bf16(long long M, int N, int K, int gmode, int amode, int x_f32, int ldx, const void *G,
                                   const void *Yl, const float *consts, const int *arg, const float *gP, int ns,
