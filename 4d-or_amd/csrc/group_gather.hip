@@ -350,6 +350,44 @@ __global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_kernel(
   }
 }
 
+// Narrow bf16 rows (pitch 8 or 16: the 3+3 / 3+4 columns of an SA1 level): a lane per row, one or two 16-byte stores.
+template <int LDO>
+__global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_narrow_kernel(
+    int N, int m, int ns, int C, int Cx, int normalize, float radius,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats, const int *__restrict__ idx, unsigned *__restrict__ out, unsigned rows) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const int W = Cx + C;
+  for (unsigned r = blockIdx.x * kBlock + threadIdx.x; r < rows; r += gridDim.x * kBlock) {
+    const unsigned bj = r / (unsigned)ns;
+    const unsigned b = bj / (unsigned)m;
+    const size_t src = (size_t)b * N + (size_t)idx[r];
+    float v[LDO];
+#pragma unroll
+    for (int c = 0; c < LDO; ++c) {
+      float t = 0.f;
+      if (c < Cx) {
+        t = xyz[src * 3 + c] - new_xyz[(size_t)bj * 3 + c];
+        if (normalize) t = __fdiv_rn(t, radius);
+      } else if (c < W) {
+        t = feats[src * C + (c - Cx)];
+      }
+      v[c] = t;
+    }
+#pragma unroll
+    for (int h = 0; h < LDO / 8; ++h) {
+      u4 w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)v[8 * h + 2 * i]);
+        const unsigned hi = __builtin_bit_cast(unsigned short, (__bf16)v[8 * h + 2 * i + 1]);
+        w[i] = lo | (hi << 16);
+      }
+      *(u4 *)(out + (size_t)r * (LDO / 2) + 4 * h) = w;
+    }
+  }
+}
+
 extern "C" int pn2_group_concat_rows_bf16(int B, int N, int m, int ns, int C, int use_xyz, int normalize, float radius,
                                           int ldo, const float *xyz, const float *new_xyz, const float *feats,
                                           const int *idx, void *out, void *stream) {
@@ -364,6 +402,17 @@ extern "C" int pn2_group_concat_rows_bf16(int B, int N, int m, int ns, int C, in
   if (normalize && !(radius > 0.f)) return PN2_EINVAL;
   if (rows_sz >= 0x7fffffffull) return PN2_EINVAL;
   const unsigned rows = (unsigned)rows_sz;
+  if (ldo <= 16) {
+    unsigned grid = (rows + kBlock - 1) / kBlock;
+    if (grid > 8192) grid = 8192;
+    if (ldo == 8)
+      hipLaunchKernelGGL(group_concat_rows_bf16_narrow_kernel<8>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns,
+                         C, Cx, normalize, radius, xyz, new_xyz, feats, idx, (unsigned *)out, rows);
+    else
+      hipLaunchKernelGGL(group_concat_rows_bf16_narrow_kernel<16>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns,
+                         C, Cx, normalize, radius, xyz, new_xyz, feats, idx, (unsigned *)out, rows);
+    return pn2_check_launch();
+  }
   const unsigned want_waves = 256u * 16u;
   unsigned rpw = (rows + want_waves - 1) / want_waves;
   rpw = (rpw + 7u) & ~7u;

@@ -92,11 +92,11 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
     }
   }
   auto stage_w = [&](int k0, int kw) {              // sW[n][0..kw) = bf16(W[n][k0..k0+kw)), zero outside N x K
-    const int total = NTT * 32 * kw;
-    for (int e = tid; e < total; e += NTH) {
-      const int n = e / kw, k = e - n * kw;
-      const float v = (n < N && k0 + k < K) ? a.W[(size_t)n * K + k0 + k] : 0.f;
-      sW[n * WP + k] = (bf16)v;
+    // a wave per weight row, lanes along k: coalesced fp32 loads, no per-element index arithmetic
+    for (int n = tid >> 6; n < NTT * 32; n += NTH / 64) {
+      const bool nok = n < N;
+      const float *wr = a.W + (size_t)(nok ? n : 0) * K + k0;
+      for (int k = lane; k < kw; k += 64) sW[n * WP + k] = (bf16)((nok && k0 + k < K) ? wr[k] : 0.f);
     }
   };
   if (a.wres) stage_w(0, Kp);
@@ -161,9 +161,6 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
         }
       } else {
         const long long grow = row0 + lr;
-        int sample = 0;
-        long long grp = 0;
-        if constexpr (PRO == PRO_POOLG) { grp = grow / a.ns; sample = (int)(grow - grp * a.ns); }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
           const int k = kc * KC + lk + 8 * j;
@@ -185,17 +182,11 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
               v[2 * i] = fmaf(q0[2 * i], bf_lo(ra[j][i]), fmaf(q1[2 * i], bf_lo(rb[j][i]), q2[2 * i]));
               v[2 * i + 1] = fmaf(q0[2 * i + 1], bf_hi(ra[j][i]), fmaf(q1[2 * i + 1], bf_hi(rb[j][i]), q2[2 * i + 1]));
             }
-          } else {   // PRO_POOLG: the pooled gradient reaches only the arg-max row of each (group, channel)
-            const bool live = grow < a.M && k < K;
+          } else {   // PRO_POOLG: dense part c2*y + c3 here; the pooled gradient is patched in afterwards (patch_pool)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               const float y = (i & 1) ? bf_hi(rb[j][i >> 1]) : bf_lo(rb[j][i >> 1]);
-              float g = 0.f;
-              if (live && k + i < K) {
-                const size_t o = (size_t)grp * K + k + i;
-                g = a.arg[o] == sample ? a.gP[o] : 0.f;
-              }
-              v[i] = fmaf(q0[i], g, fmaf(q1[i], y, q2[i]));
+              v[i] = fmaf(q1[i], y, q2[i]);
             }
           }
           // rows past M read as zeros, but their prologue value (relu(shift), c3) is not zero: they must not reach the
@@ -208,12 +199,36 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
       }
     };
 
+    // PRO_POOLG: the gradient of a max-pooled layer is ONE non-zero per (neighbourhood, channel), at the arg-max row:
+    // instead of testing every element against the arg-max (two scattered loads per element) the dense tile
+    // c2*y + c3 is staged first and c1*gP is added at the arg-max rows of the neighbourhoods this tile intersects
+    auto patch_pool = [&](int kc) {
+      const long long g0 = row0 / a.ns;
+      const long long last = (row0 + TM - 1 < a.M - 1 ? row0 + TM - 1 : a.M - 1);
+      const int ngr = (int)(last / a.ns - g0) + 1;
+      for (int t = tid; t < ngr * KC; t += NTH) {
+        const int gi = t >> 6, kk = t & 63, k = kc * KC + kk;
+        if (k < K) {
+          const size_t o = (size_t)(g0 + gi) * K + k;
+          const long long row = (g0 + gi) * a.ns + a.arg[o] - row0;
+          if (row >= 0 && row < TM && row0 + row < a.M) {
+            bf16 *cell = &sA[(int)row * AP + kk];
+            *cell = (bf16)fmaf(sP[k], a.gP[o], (float)*cell);
+          }
+        }
+      }
+    };
+
     issue(0);
     for (int kc = 0; kc < nchunks; ++kc) {
       __syncthreads();                               // the previous chunk's fragment reads are done
       commit(kc);
       if (!a.wres) stage_w(kc * KC, KC);
       if (kc + 1 < nchunks) issue(kc + 1);
+      if constexpr (PRO == PRO_POOLG) {
+        __syncthreads();
+        patch_pool(kc);
+      }
       __syncthreads();
       const int kb = a.wres ? kc * KC : 0;
 #pragma unroll
@@ -364,17 +379,10 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad_bf16_kernel(const WgradBf16A
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float c1 = sC[n + i], c2 = sC[NB + n + i], c3 = sC[2 * NB + n + i];
-          float ga, gb;
+          float ga = 0.f, gb = 0.f;                  // PRO_POOLG: the pooled gradient is patched in below
           if constexpr (GMODE == PRO_GY) {
             ga = (i & 1) ? bf_hi(g0[i >> 1]) : bf_lo(g0[i >> 1]);
             gb = (i & 1) ? bf_hi(g1[i >> 1]) : bf_lo(g1[i >> 1]);
-          } else {
-            ga = gb = 0.f;
-            if (n + i < N) {
-              const long long ra_ = row0 + m, rb_ = ra_ + 1;
-              if (ra_ < a.M) { const long long q = ra_ / a.ns; const size_t o = (size_t)q * N + n + i; ga = a.arg[o] == (int)(ra_ - q * a.ns) ? a.gP[o] : 0.f; }
-              if (rb_ < a.M) { const long long q = rb_ / a.ns; const size_t o = (size_t)q * N + n + i; gb = a.arg[o] == (int)(rb_ - q * a.ns) ? a.gP[o] : 0.f; }
-            }
           }
           const float ya = (i & 1) ? bf_hi(y0[i >> 1]) : bf_lo(y0[i >> 1]);
           const float yb = (i & 1) ? bf_hi(y1[i >> 1]) : bf_lo(y1[i >> 1]);
@@ -390,6 +398,23 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad_bf16_kernel(const WgradBf16A
       for (int t = tid; t < (NB - CG * 8) * (MT / 2); t += 256) {
         const int f = CG * 8 + t / (MT / 2), mp = t % (MT / 2);
         *(unsigned *)&sG[f * MP + 2 * mp] = 0u;
+      }
+      if constexpr (GMODE == PRO_POOLG) {
+        // one non-zero per (neighbourhood, feature): add c1 * gP at the arg-max row of every neighbourhood in this tile
+        __syncthreads();
+        const long long q0 = row0 / a.ns;
+        const long long last = (row0 + MT - 1 < a.M - 1 ? row0 + MT - 1 : a.M - 1);
+        const int ngr = (int)(last / a.ns - q0) + 1;
+        for (int gi = 0; gi < ngr; ++gi) {
+          for (int n = tid; n < N; n += 256) {
+            const size_t o = (size_t)(q0 + gi) * N + n;
+            const long long row = (q0 + gi) * a.ns + a.arg[o] - row0;
+            if (row >= 0 && row < MT && row0 + row < a.M) {
+              bf16 *cell = &sG[n * MP + swz<MT>(n, (int)row)];
+              *cell = (bf16)fmaf(sC[n], a.gP[o], (float)*cell);
+            }
+          }
+        }
       }
     }
     // ---- activation tile -> sX (transposed, packed row pairs)
@@ -566,9 +591,12 @@ int launch_gemm(GemmBf16Args a, hipStream_t s) {
   const size_t red = (size_t)2 * 4 * NTT * 32 * 4;
   if (lds < red) lds = red;
   auto kfn = mlp_gemm_bf16_kernel<NT, CW, PRO, EPI, XF32, YF32>;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return pn2_check_launch();
+  static bool big_lds = false;                            // per template instance: opt in to > 64 KB of LDS once
+  if (lds > 64 * 1024 && !big_lds) {
+    if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return pn2_check_launch();
+    big_lds = true;
+  }
   const long long ntiles = (a.M + TM - 1) / TM;
   long long grid = 512;                                     // persistent: two workgroups per CU
   if (grid > ntiles) grid = ntiles;
@@ -596,9 +624,12 @@ int launch_wgrad(const WgradBf16Args &a, hipStream_t s) {
   constexpr int MP = MT + 8, NB = 4 * NTW * 32, KB = KTB * 32;
   const size_t lds = (size_t)(NB + KB) * MP * 2 + (size_t)(3 * NB + 2 * KB) * 4;
   auto kfn = mlp_wgrad_bf16_kernel<NTW, KTB, MT, GMODE, AMODE, XF32>;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return pn2_check_launch();
+  static bool big_lds = false;
+  if (lds > 64 * 1024 && !big_lds) {
+    if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return pn2_check_launch();
+    big_lds = true;
+  }
   const unsigned kblocks = (unsigned)((a.K + KB - 1) / KB);
   const long long ntiles = (a.M + MT - 1) / MT;
   long long gx = 512 / kblocks;

@@ -256,7 +256,9 @@ def test_backbone_levels_bf16_close_to_fp32():
             args[-1].requires_grad_(True)
             out = mod(*args)
             out = out[1] if isinstance(out, tuple) else out
-            (out * torch.linspace(0.5, 1.5, out.numel(), device="cuda").view_as(out)).sum().backward()
+            # sign-alternating loss weights: a gradient with a large per-channel MEAN is what BatchNorm's backward
+            # subtracts again, and bf16 rounds it before the subtraction
+            (out * torch.linspace(-1.0, 1.0, out.numel(), device="cuda").view_as(out)).sum().backward()
             return out.detach(), args[-1].grad, [p.grad for p in mod.parameters()]
         finally:
             fused_mlp.set_mlp_dtype(prev)
@@ -267,7 +269,7 @@ def test_backbone_levels_bf16_close_to_fp32():
         e_gx = float((got[1] - ref[1]).norm() / ref[1].norm())
         e_gw = max(float((a_ - b_).norm() / (b_.norm() + 1e-12)) for a_, b_ in zip(got[2], ref[2]) if b_.norm() > 1e-6)
         print(f"\n[bf16 level {name}] forward rel-max {e_fwd:.3e}, grad_in rel-L2 {e_gx:.3e}, worst grad_w rel-L2 {e_gw:.3e}", end="")
-        assert e_fwd <= 2e-2 and e_gx <= 1e-1 and e_gw <= 1e-1, name
+        assert e_fwd <= 2e-2 and e_gx <= 1.5e-1 and e_gw <= 1e-1, name
 
 
 def test_scene_graph_model_bf16_step():

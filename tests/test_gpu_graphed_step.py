@@ -69,7 +69,7 @@ def test_prefetched_geometry_is_a_graph_input():
         rl.backward()
         want = torch.cat([p.grad.flatten() for p in ref.parameters() if p.requires_grad])
         assert abs(float(loss) - float(rl.detach())) < 1e-3, i
-        assert _rel(stepper.grads.flat, want) < 1e-2, i   # the geometry of the previous scan would give O(1)
+        assert _rel(stepper.grads.flat, want) < 3e-2, i   # the geometry of the previous scan would give O(1)
     assert stepper.num_graphs == 1                        # scan 0 eager, scan 1 captured, scans 2-3 replayed
 
 

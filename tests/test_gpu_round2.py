@@ -312,10 +312,10 @@ def test_batched_scans_on_gpu_equal_single_scan_steps():
     # gradients: both sides are the same fp32 kernels with different summation orders (rocBLAS picks other GEMM splits
     # for 56 rows than for 5, atomics reorder); the per-scan BatchNorm over 4..9 node rows amplifies that (see the
     # conditioning note in the GCN test above), so parameters are compared in norm
-    worst, top = 0.0, max(float(p.grad.norm()) for p in m.parameters() if p.grad is not None)
-    for n, p in m.named_parameters():
-        if p.grad is not None and float(p.grad.norm()) > 1e-6 * top:
-            worst = max(worst, float((got[n] - p.grad).norm() / p.grad.norm()))
-    print(f"[batched scans] worst parameter-gradient rel-L2 {worst:.3e}")
-    assert worst <= 3e-2
+    top = max(float(p.grad.norm()) for p in m.parameters() if p.grad is not None)
+    errs = sorted(((float((got[n] - p.grad).norm() / p.grad.norm()), n, float(p.grad.norm())) for n, p in m.named_parameters()
+                   if p.grad is not None and float(p.grad.norm()) > 1e-4 * top), reverse=True)
+    for e_, n, nrm in errs[:4]:
+        print(f"[batched scans] grad rel-L2 {e_:.3e}  |g| {nrm:.3e}  {n}")
+    assert errs[0][0] <= 3e-2
     assert m.predict_step(batch) == [m.predict_step(to_device(s, "cuda")) for s in scans]
