@@ -178,29 +178,42 @@ __global__ __launch_bounds__(kBlock) void group_concat_rows_narrow_kernel(
 }
 
 // grad_feats[b, idx[row], :] += grad_out[row, col0 : col0 + C]   (hardware fp32 atomics), a wave per row group
+// A wave walks whole neighbourhoods.  A ball-query row is "hits in ascending index, then padding with the FIRST hit"
+// (EXT/src/ball_query_gpu.cu:34-38): with a small radius most of the ns slots of a neighbourhood are that padding, i.e.
+// the SAME destination row.  Their gradients are summed in registers and leave as ONE atomic per channel; only the
+// genuine other hits pay an atomic each (measured on the scene-graph encoders: 16-32 slots, 4-10 distinct hits).
+// Any index row is handled correctly (slots equal to slot 0 are pre-reduced, the rest go out individually).
 __global__ __launch_bounds__(kBlock) void group_rows_grad_kernel(
     int N, int m, int ns, int C, int ldg, int col0, const float *__restrict__ grad_out,
-    const int *__restrict__ idx, float *__restrict__ grad_feats, unsigned rows, unsigned rows_per_wave) {
+    const int *__restrict__ idx, float *__restrict__ grad_feats, unsigned groups, unsigned groups_per_wave) {
   const int lane = pn2_lane();
   const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-  unsigned r0 = wave * rows_per_wave;
-  if (r0 >= rows) return;
-  unsigned r1 = r0 + rows_per_wave;
-  if (r1 > rows) r1 = rows;
-  const unsigned mns = (unsigned)m * (unsigned)ns;
-  unsigned b = r0 / mns;
-  unsigned inb = r0 - b * mns;                   // row index inside the cloud
-  for (unsigned base = r0; base < r1; base += 8) {
-    const unsigned nrow = (r1 - base) < 8u ? (r1 - base) : 8u;
-    const int myi = lane < (int)nrow ? idx[base + lane] : 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if ((unsigned)q >= nrow) break;
-      const int ii = __builtin_amdgcn_readlane(myi, q);
-      float *dst = grad_feats + ((size_t)b * N + (size_t)ii) * C;
-      const float *g = grad_out + (size_t)(base + q) * ldg + col0;
-      for (int c = lane; c < C; c += 64) atomicAdd(dst + c, g[c]);
-      if (++inb == mns) { inb = 0; ++b; }
+  unsigned g0 = wave * groups_per_wave;
+  if (g0 >= groups) return;
+  unsigned g1 = g0 + groups_per_wave;
+  if (g1 > groups) g1 = groups;
+  for (unsigned gq = g0; gq < g1; ++gq) {
+    const unsigned b = gq / (unsigned)m;
+    const int *irow = idx + (size_t)gq * ns;
+    const float *grow = grad_out + (size_t)gq * ns * ldg + col0;
+    float *base = grad_feats + (size_t)b * N * C;
+    const int first = irow[0];
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + lane;
+      const bool ok = c < C;
+      float acc = 0.f;
+      for (int s0 = 0; s0 < ns; s0 += 64) {
+        const int cnt = ns - s0 < 64 ? ns - s0 : 64;
+        const int myi = lane < cnt ? irow[s0 + lane] : first;
+#pragma unroll 4
+        for (int q = 0; q < cnt; ++q) {
+          const int ii = __builtin_amdgcn_readlane(myi, q);
+          const float g = ok ? grow[(size_t)(s0 + q) * ldg + c] : 0.f;
+          if (ii == first) acc += g;                        // wave-uniform branch
+          else if (ok) atomicAdd(base + (size_t)ii * C + c, g);
+        }
+      }
+      if (ok) atomicAdd(base + (size_t)first * C + c, acc);
     }
   }
 }
@@ -464,16 +477,15 @@ extern "C" int pn2_group_rows_grad(int B, int N, int m, int ns, int C, int ldg, 
   const size_t total = (size_t)B * m * ns * (size_t)C;
   if (total == 0) return PN2_OK;
   if (!grad_out || !idx || !grad_feats) return PN2_ENULL;
-  const size_t rows_sz = (size_t)B * m * ns;
-  if (rows_sz >= 0x7fffffffull) return PN2_EINVAL;
-  const unsigned rows = (unsigned)rows_sz;
-  const unsigned want_waves = 256u * 16u;
-  unsigned rpw = (rows + want_waves - 1) / want_waves;
-  rpw = (rpw + 7u) & ~7u;
-  const unsigned waves = (rows + rpw - 1) / rpw;
+  const size_t groups_sz = (size_t)B * m;
+  if (groups_sz >= 0x7fffffffull) return PN2_EINVAL;
+  const unsigned groups = (unsigned)groups_sz;
+  const unsigned want_waves = 256u * 32u;
+  const unsigned gpw = (groups + want_waves - 1) / want_waves;
+  const unsigned waves = (groups + gpw - 1) / gpw;
   const unsigned grid = (waves + kBlock / 64 - 1) / (kBlock / 64);
   hipLaunchKernelGGL(group_rows_grad_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C, ldg,
-                     col0, grad_out, idx, grad_feats, rows, rpw);
+                     col0, grad_out, idx, grad_feats, groups, gpw);
   return pn2_check_launch();
 }
 

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "pn2_gather_points": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_gather_points_grad": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_ball_query": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_ball_query_ws": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp],
     "pn2_ball_query_unique_resample": [ctypes.c_longlong, _c_int, ctypes.c_uint, _c_vp, _c_vp, _c_vp],
     "pn2_group_points": [_c_int] * 5 + [_c_vp] * 4,
     "pn2_group_points_grad": [_c_int] * 5 + [_c_vp] * 4,
@@ -94,6 +95,8 @@ _lib.pn2_fps_coop_status.argtypes = [_c_int, _c_vp, _c_vp]
 _lib.pn2_fps_coop_status.restype = _c_int
 _lib.pn2_fps_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_workspace_bytes.restype = _c_sz
+_lib.pn2_ball_query_workspace_bytes.argtypes = [_c_int, _c_int, _c_int, _c_int]
+_lib.pn2_ball_query_workspace_bytes.restype = _c_sz
 _lib.pn2_fps_status_offset.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_status_offset.restype = ctypes.c_longlong
 _lib.pn2_fps_set_plan_override.argtypes = [_c_int] * 5
@@ -110,6 +113,7 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override",
+                                               "pn2_ball_query_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
@@ -230,6 +234,9 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None, label=None):
         _fail(f"{name} failed: {detail} (rc={rc}, hipError={_lib.pn2_last_hip_error()})")
 
 
+#: route ball queries of clouds >= 2048 points through the cell-list kernels (identical results; tests flip it to
+#: compare both implementations)
+BALL_QUERY_GRID = True
 PN2_FPS_FEW_CUS = 1
 _sched = threading.local()
 
@@ -316,8 +323,15 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.size(1)
     nsample = int(nsample)
     idx = torch.empty(B, m, nsample, dtype=torch.int32, device=new_xyz.device)  # kernel writes every slot
-    _call("pn2_ball_query", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx),
-          alg_bytes=B * (12 * N + 12 * m + 4 * m * nsample))
+    ws_bytes = int(_lib.pn2_ball_query_workspace_bytes(B, N, m, nsample)) if BALL_QUERY_GRID else 0
+    if ws_bytes:
+        # cell-list path (sparse balls): scratch for the binned cloud, no initialisation needed
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=new_xyz.device)
+        _call("pn2_ball_query_ws", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx), _ptr(ws),
+              ws_bytes, alg_bytes=B * (12 * N + 12 * m + 4 * m * nsample), label="pn2_ball_query")
+    else:
+        _call("pn2_ball_query", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx),
+              alg_bytes=B * (12 * N + 12 * m + 4 * m * nsample))
     return idx
 
 

@@ -106,6 +106,17 @@ int pn2_ball_query(int B, int N, int m, float radius, int nsample,
                    const float *new_xyz, const float *xyz, int *idx,
                    void *stream);
 
+/* Cell-list variant of the same operator (identical results): the cloud is binned once into cells of edge >= radius and
+ * a centre only tests the points of its 27 neighbouring cells; the hits are rank-sorted by index, which reproduces the
+ * reference's "first nsample in ascending index + first-hit padding" exactly.  Pays when balls are sparse (the
+ * scene-graph encoders: radius 0.1 / 0.2 in 4000 / 8000-point clouds, where the index-order scan never exits early).
+ * pn2_ball_query_workspace_bytes() == 0 means the shape is served by the plain scan (pn2_ball_query_ws then ignores the
+ * workspace); otherwise `workspace` (16-byte aligned, no initialisation needed) must hold that many bytes.
+ */
+size_t pn2_ball_query_workspace_bytes(int B, int N, int m, int nsample);
+int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                      int *idx, void *workspace, size_t workspace_bytes, void *stream);
+
 /* sample_uniformly / ret_unique_cnt of the Group-Free-3D QueryAndGroup
  *   (GF3D/pointnet2/pointnet2_utils.py:327-336: a host loop of torch.unique + torch.randint per region).
  * idx (rows, nsample) ball-query rows, IN PLACE: the padded tail of every row (everything behind its strictly

