@@ -378,16 +378,31 @@ extern "C" int pn2_ball_query(int B, int N, int m, float radius, int nsample,
 }
 
 // Workspace of the cell-list path: 0 = this shape runs the plain index-order scan (small clouds, huge nsample).
-extern "C" size_t pn2_ball_query_workspace_bytes(int B, int N, int m, int nsample) {
-  if (B <= 0 || m <= 0 || N < 2048 || nsample <= 0 || nsample > kGridCap) return 0;
+// Which algorithm: the cell list pays when balls are SPARSE.  The host cannot see the coordinates, so it estimates the
+// hits per ball for a cloud that fills the unit ball (the 4D-OR clouds are normalised that way, zero_mean of
+// data_preparation_utils.py:12-18): E = N r^3.  Measured (tools/microbench.py): E = 8 and 64 with nsample 16 / 32 —
+// cell list 1.5-4x faster; E = 130 / nsample 32 and E = 400 / nsample 64 — the early-exit scan is faster.  Results are
+// identical either way.
+extern "C" size_t pn2_ball_query_workspace_bytes(int B, int N, int m, float radius, int nsample) {
+  if (B <= 0 || m <= 0 || N < 2048 || nsample <= 0 || nsample > kGridCap || !(radius > 0.f)) return 0;
+  if ((double)N * radius * radius * radius > 4.0 * nsample) return 0;
+  return pn2_ball_query_grid_bytes(B, N, nsample);
+}
+
+// Raw requirement of the cell-list kernels (0: shape not covered — nsample beyond the collection cap); a caller that
+// passes this much workspace to pn2_ball_query_ws gets the cell list whatever the density estimate says.
+extern "C" size_t pn2_ball_query_grid_bytes(int B, int N, int nsample) {
+  if (B <= 0 || N <= 0 || nsample <= 0 || nsample > kGridCap) return 0;
   const size_t per_cloud = (size_t)kGridHdr * 4 + (size_t)(kGridMaxG * kGridMaxG * kGridMaxG + 1) * 4 + (size_t)N * 16;
   return (size_t)B * per_cloud + 256;
 }
 
 extern "C" int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                                  int *idx, void *workspace, size_t workspace_bytes, void *stream) {
-  const size_t need = pn2_ball_query_workspace_bytes(B, N, m, nsample);
-  if (need == 0 || !workspace) return pn2_ball_query(B, N, m, radius, nsample, new_xyz, xyz, idx, stream);
+  if (B < 0 || N < 0 || m < 0 || nsample < 0) return PN2_EINVAL;
+  const size_t need = pn2_ball_query_grid_bytes(B, N, nsample);
+  if (need == 0 || !workspace || workspace_bytes == 0 || m == 0)
+    return pn2_ball_query(B, N, m, radius, nsample, new_xyz, xyz, idx, stream);
   if (workspace_bytes < need) return PN2_ENOSPC;
   if (!new_xyz || !idx || !xyz) return PN2_ENULL;
   if (((uintptr_t)workspace & 15) != 0) return PN2_EINVAL;

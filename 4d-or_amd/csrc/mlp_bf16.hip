@@ -43,6 +43,9 @@ __device__ __forceinline__ unsigned short bload16(rsrc_t r, int voff, int soff) 
 __device__ __forceinline__ void bstore16(unsigned short v, rsrc_t r, int voff, int soff) {
   __builtin_amdgcn_raw_buffer_store_b16(v, r, voff, soff, 0);
 }
+__device__ __forceinline__ void bstore128(u32x4 v, rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
 
 constexpr int TM = 128;        // rows per tile: 4 waves x 32
 constexpr int KC = 64;         // K chunk (4 MFMA k-steps of 16)
@@ -247,6 +250,40 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
     const rsrc_t rY = make_rsrc((char *)a.Y + (size_t)row0 * a.ldy * ys, rows_left * a.ldy * ys);
     rsrc_t rYp = rY;
     if constexpr (EPI == EPI_MASK) rYp = make_rsrc((const char *)a.Yprev + (size_t)row0 * a.ldy * 2, rows_left * a.ldy * 2);
+    if constexpr (EPI == EPI_MASK) {
+      // ReLU-backward epilogue through LDS: the y_{l-1} tile comes in with coalesced 16-byte loads, every lane masks its
+      // accumulator elements against it IN PLACE (C layout, 2-byte LDS accesses), and the tile leaves with coalesced
+      // 16-byte stores — instead of 16 x NT two-byte global loads and stores per lane.
+      bf16 *sY = sW + NTT * 32 * WP;                 // [TM][YP]
+      constexpr int YP = NTT * 32 + 8;
+      const int CGn = N >> 3;                        // N % 8 == 0 (bf16 rows)
+      for (int t = tid; t < TM * CGn; t += NTH) {
+        const int r = t / CGn, cg = t - r * CGn;
+        *(u32x4 *)&sY[r * YP + cg * 8] = bload128(rYp, (r * a.ldy + cg * 8) * 2, 0);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = (wc * NT + nt) * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          bf16 *cell = &sY[r * YP + c];
+          const float yp = (float)*cell;
+          const float v = fmaf(yp, e_sc[nt], e_sh[nt]) > 0.f ? acc[nt][i] : 0.f;
+          const bf16 vb = (bf16)v;
+          const float vr = (float)vb;
+          s1[nt] += vr;
+          s2[nt] = fmaf(vr, (yp - e_mean[nt]) * e_rstd[nt], s2[nt]);
+          *cell = vb;
+        }
+      }
+      __syncthreads();
+      for (int t = tid; t < TM * CGn; t += NTH) {
+        const int r = t / CGn, cg = t - r * CGn;
+        bstore128(*(const u32x4 *)&sY[r * YP + cg * 8], rY, (r * a.ldy + cg * 8) * 2, 0);
+      }
+    } else {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int c = (wc * NT + nt) * 32 + (lane & 31);
@@ -270,6 +307,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
         if constexpr (YF32) bstore(v, rY, eoff < 0 ? kOobOffset : eoff * 4, 0);
         else bstore16(bf_bits(v), rY, eoff < 0 ? kOobOffset : eoff * 2, 0);
       }
+    }
     }
   }
 
@@ -586,8 +624,13 @@ int launch_gemm(GemmBf16Args a, hipStream_t s) {
   constexpr int NTT = NT * CW;
   const size_t wbytes_res = (size_t)NTT * 32 * (a.Kp + 8) * 2;
   a.wres = wbytes_res <= (size_t)kMaxResidentWBytes;
+  if (EPI == EPI_MASK && a.N % 8 != 0) return PN2_EINVAL;
+  const size_t fixed = (size_t)TM * AP * 2 + (PRO != PRO_NONE ? 3 * (size_t)a.Kp * 4 : 0) +
+                       (EPI == EPI_MASK ? (size_t)TM * (NTT * 32 + 8) * 2 : 0);
+  if (a.wres && fixed + wbytes_res > 160 * 1024) a.wres = 0;
   const size_t wbytes = a.wres ? wbytes_res : (size_t)NTT * 32 * AP * 2;
-  size_t lds = (size_t)TM * AP * 2 + (PRO != PRO_NONE ? 3 * (size_t)a.Kp * 4 : 0) + wbytes;
+  size_t lds = fixed + wbytes;
+  if (lds > 160 * 1024) return PN2_EINVAL;
   const size_t red = (size_t)2 * 4 * NTT * 32 * 4;
   if (lds < red) lds = red;
   auto kfn = mlp_gemm_bf16_kernel<NT, CW, PRO, EPI, XF32, YF32>;

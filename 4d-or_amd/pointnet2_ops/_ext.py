@@ -95,8 +95,10 @@ _lib.pn2_fps_coop_status.argtypes = [_c_int, _c_vp, _c_vp]
 _lib.pn2_fps_coop_status.restype = _c_int
 _lib.pn2_fps_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_workspace_bytes.restype = _c_sz
-_lib.pn2_ball_query_workspace_bytes.argtypes = [_c_int, _c_int, _c_int, _c_int]
+_lib.pn2_ball_query_workspace_bytes.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int]
 _lib.pn2_ball_query_workspace_bytes.restype = _c_sz
+_lib.pn2_ball_query_grid_bytes.argtypes = [_c_int, _c_int, _c_int]
+_lib.pn2_ball_query_grid_bytes.restype = _c_sz
 _lib.pn2_fps_status_offset.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_status_offset.restype = ctypes.c_longlong
 _lib.pn2_fps_set_plan_override.argtypes = [_c_int] * 5
@@ -113,7 +115,7 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override",
-                                               "pn2_ball_query_workspace_bytes",
+                                               "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
@@ -234,8 +236,8 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None, label=None):
         _fail(f"{name} failed: {detail} (rc={rc}, hipError={_lib.pn2_last_hip_error()})")
 
 
-#: route ball queries of clouds >= 2048 points through the cell-list kernels (identical results; tests flip it to
-#: compare both implementations)
+#: let the library route sparse-ball queries (clouds >= 2048 points, estimated N r^3 <= 4 nsample) through the cell-list
+#: kernels (identical results; tests flip it to compare both implementations, or force the cell list with "force")
 BALL_QUERY_GRID = True
 PN2_FPS_FEW_CUS = 1
 _sched = threading.local()
@@ -323,7 +325,10 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.size(1)
     nsample = int(nsample)
     idx = torch.empty(B, m, nsample, dtype=torch.int32, device=new_xyz.device)  # kernel writes every slot
-    ws_bytes = int(_lib.pn2_ball_query_workspace_bytes(B, N, m, nsample)) if BALL_QUERY_GRID else 0
+    if BALL_QUERY_GRID == "force":
+        ws_bytes = int(_lib.pn2_ball_query_grid_bytes(B, N, nsample))
+    else:
+        ws_bytes = int(_lib.pn2_ball_query_workspace_bytes(B, N, m, float(radius), nsample)) if BALL_QUERY_GRID else 0
     if ws_bytes:
         # cell-list path (sparse balls): scratch for the binned cloud, no initialisation needed
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=new_xyz.device)

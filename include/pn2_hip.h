@@ -110,10 +110,12 @@ int pn2_ball_query(int B, int N, int m, float radius, int nsample,
  * a centre only tests the points of its 27 neighbouring cells; the hits are rank-sorted by index, which reproduces the
  * reference's "first nsample in ascending index + first-hit padding" exactly.  Pays when balls are sparse (the
  * scene-graph encoders: radius 0.1 / 0.2 in 4000 / 8000-point clouds, where the index-order scan never exits early).
+ * Crowded balls (estimated N r^3 > 4 nsample, or N < 2048) are better served by the early-exit scan:
  * pn2_ball_query_workspace_bytes() == 0 means the shape is served by the plain scan (pn2_ball_query_ws then ignores the
  * workspace); otherwise `workspace` (16-byte aligned, no initialisation needed) must hold that many bytes.
  */
-size_t pn2_ball_query_workspace_bytes(int B, int N, int m, int nsample);
+size_t pn2_ball_query_workspace_bytes(int B, int N, int m, float radius, int nsample);
+size_t pn2_ball_query_grid_bytes(int B, int N, int nsample);   /* raw requirement: forces the cell list */
 int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                       int *idx, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -358,12 +358,12 @@ def test_cell_list_ball_query_is_bit_exact(B, N, m, ns, r, kind):
     new_xyz[:, -1] = 40.0                                                         # far outside the bounding box
     new_xyz = new_xyz.contiguous()
     want = oracle_ext.OracleRowsExt.ball_query(new_xyz, xyz, r, ns)
-    assert _ext.BALL_QUERY_GRID
-    got = _ext.ball_query(new_xyz.cuda(), xyz.cuda(), r, ns).cpu()
-    assert torch.equal(got, want)
-    _ext.BALL_QUERY_GRID = False
-    try:
-        scan = _ext.ball_query(new_xyz.cuda(), xyz.cuda(), r, ns).cpu()
-    finally:
-        _ext.BALL_QUERY_GRID = True
-    assert torch.equal(scan, want)
+    results = {}
+    for mode in ("force", False, True):                 # cell list forced, index-order scan, the library's own choice
+        _ext.BALL_QUERY_GRID = mode
+        try:
+            results[mode] = _ext.ball_query(new_xyz.cuda(), xyz.cuda(), r, ns).cpu()
+        finally:
+            _ext.BALL_QUERY_GRID = True
+    for mode, got in results.items():
+        assert torch.equal(got, want), mode
