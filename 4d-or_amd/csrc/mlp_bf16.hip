@@ -76,12 +76,13 @@ template <int NT, int CW, int PRO, int EPI, bool XF32, bool YF32>
 __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf16Args a) {
   constexpr int NTH = 256 * CW;                     // threads
   constexpr int NTT = NT * CW;                      // column tiles of the workgroup
+  // LDS: [ W tile | prologue parameters | A chunk, re-used by the ReLU-backward epilogue as the y_{l-1} / output tile ]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16 *sA = (bf16 *)smem;                          // [TM][AP]
-  float *sP = (float *)(smem + TM * AP * 2);        // [3][Kp] prologue parameters, zero padded
   const int Kp = a.Kp;
-  bf16 *sW = (bf16 *)(smem + TM * AP * 2 + (PRO != PRO_NONE ? 3 * Kp * 4 : 0));   // [NTT*32][WP]
   const int WP = a.wres ? Kp + 8 : AP;
+  bf16 *sW = (bf16 *)smem;                          // [NTT*32][WP]
+  float *sP = (float *)(smem + NTT * 32 * WP * 2);  // [3][Kp] prologue parameters, zero padded
+  bf16 *sA = (bf16 *)((unsigned char *)sP + (PRO != PRO_NONE ? 3 * Kp * 4 : 0));   // [TM][AP]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) & 3, wc = tid >> 8;
@@ -254,9 +255,10 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
       // ReLU-backward epilogue through LDS: the y_{l-1} tile comes in with coalesced 16-byte loads, every lane masks its
       // accumulator elements against it IN PLACE (C layout, 2-byte LDS accesses), and the tile leaves with coalesced
       // 16-byte stores — instead of 16 x NT two-byte global loads and stores per lane.
-      bf16 *sY = sW + NTT * 32 * WP;                 // [TM][YP]
+      bf16 *sY = sA;                                 // [TM][YP]: the A chunk is dead after the last MFMA
       constexpr int YP = NTT * 32 + 8;
       const int CGn = N >> 3;                        // N % 8 == 0 (bf16 rows)
+      __syncthreads();                               // every wave is done with the A chunk
       for (int t = tid; t < TM * CGn; t += NTH) {
         const int r = t / CGn, cg = t - r * CGn;
         *(u32x4 *)&sY[r * YP + cg * 8] = bload128(rYp, (r * a.ldy + cg * 8) * 2, 0);
@@ -625,8 +627,9 @@ int launch_gemm(GemmBf16Args a, hipStream_t s) {
   const size_t wbytes_res = (size_t)NTT * 32 * (a.Kp + 8) * 2;
   a.wres = wbytes_res <= (size_t)kMaxResidentWBytes;
   if (EPI == EPI_MASK && a.N % 8 != 0) return PN2_EINVAL;
-  const size_t fixed = (size_t)TM * AP * 2 + (PRO != PRO_NONE ? 3 * (size_t)a.Kp * 4 : 0) +
-                       (EPI == EPI_MASK ? (size_t)TM * (NTT * 32 + 8) * 2 : 0);
+  size_t tile = (size_t)TM * AP * 2;                        // A chunk, aliased by the epilogue tile of EPI_MASK
+  if (EPI == EPI_MASK && (size_t)TM * (NTT * 32 + 8) * 2 > tile) tile = (size_t)TM * (NTT * 32 + 8) * 2;
+  const size_t fixed = tile + (PRO != PRO_NONE ? 3 * (size_t)a.Kp * 4 : 0);
   if (a.wres && fixed + wbytes_res > 160 * 1024) a.wres = 0;
   const size_t wbytes = a.wres ? wbytes_res : (size_t)NTT * 32 * AP * 2;
   size_t lds = fixed + wbytes;

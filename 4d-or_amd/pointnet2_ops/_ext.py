@@ -66,6 +66,10 @@ _SIGNATURES = {
     "pn2_segment_bn_rows": [_c_i64, _c_int, _c_int, _c_int, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_f32, _c_int, _c_vp, _c_vp,
                             _c_vp, _c_vp],
     "pn2_segment_bn_rows_grad": [_c_i64, _c_int, _c_int, _c_int, _c_i64] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 4,
+    "pn2_prep_object_boxes": [_c_int, _c_int, _c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_prep_chunk_counts": [_c_int] * 4 + [_c_vp] * 6,
+    "pn2_prep_select": [_c_int] * 6 + [ctypes.c_uint] + [_c_vp] * 7,
+    "pn2_prep_gather_normalise": [_c_int] * 5 + [_c_vp] * 7,
     "pn2_mlp_gemm": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
     "pn2_mlp_wgrad": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_fused": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
@@ -97,6 +101,8 @@ _lib.pn2_fps_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_workspace_bytes.restype = _c_sz
 _lib.pn2_ball_query_workspace_bytes.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int]
 _lib.pn2_ball_query_workspace_bytes.restype = _c_sz
+_lib.pn2_prep_num_chunks.argtypes = [_c_int]
+_lib.pn2_prep_num_chunks.restype = _c_int
 _lib.pn2_ball_query_grid_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_ball_query_grid_bytes.restype = _c_sz
 _lib.pn2_fps_status_offset.argtypes = [_c_int, _c_int, _c_int]
@@ -116,6 +122,7 @@ ABI_VERSION = int(_lib.pn2_abi_version())
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
+                                               "pn2_prep_num_chunks",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
@@ -886,3 +893,34 @@ def bn_relu_rows_max_bf16(y, fin, ns):
     _call("pn2_bn_relu_rows_max_bf16", y, R, int(ns), C, _ptr(y), _ptr(fin), _ptr(out), _ptr(arg), _ptr(yraw),
           alg_bytes=2 * M * C + 12 * R * C)
     return out, arg, yraw
+
+
+# ------------------------------------------------- (f)3: crops of a fused scan (dataset/gpu_preparation.py drives these)
+def prepare_scan_crops(points, masks, edges, n_obj, t_obj, t_rel, padding, seed):
+    """points (P, ld) f32, masks (P) i32, edges (2, E) i32 -> (obj (n_obj, t_obj, ld), rel (E, t_rel, ld+1), boxes, sel)
+    through the four pn2_prep_* kernels + one torch.cumsum (see include/pn2_hip.h)."""
+    _f32(points, "points"); _i32(masks, "masks"); _i32(edges, "edges")
+    _same_device((points, "points"), (masks, "masks"), (edges, "edges"))
+    P, ld = points.shape
+    E = edges.size(1)
+    dev = points.device
+    keys = torch.empty(max(n_obj, 1) * 6, dtype=torch.int32, device=dev)
+    boxes = torch.empty(n_obj, 6, dtype=torch.float32, device=dev)
+    _call("pn2_prep_object_boxes", points, P, ld, n_obj, float(padding), _ptr(points), _ptr(masks), _ptr(keys), _ptr(boxes),
+          alg_bytes=P * (12 + 4))
+    nch = int(_lib.pn2_prep_num_chunks(P))
+    crops = n_obj + E
+    counts = torch.empty(crops, nch, dtype=torch.int32, device=dev)
+    _call("pn2_prep_chunk_counts", points, P, ld, n_obj, E, _ptr(points), _ptr(masks), _ptr(boxes), _ptr(edges), _ptr(counts),
+          alg_bytes=crops * P * 16)
+    prefix = torch.zeros(crops, nch + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, dim=1, out=prefix[:, 1:])
+    slots = n_obj * t_obj + E * t_rel
+    sel = torch.empty(slots, dtype=torch.int32, device=dev)
+    _call("pn2_prep_select", points, P, ld, n_obj, E, int(t_obj), int(t_rel), int(seed) & 0xFFFFFFFF, _ptr(points), _ptr(masks),
+          _ptr(boxes), _ptr(edges), _ptr(prefix), _ptr(sel), alg_bytes=slots * 4)
+    obj = torch.empty(n_obj, t_obj, ld, dtype=torch.float32, device=dev)
+    rel = torch.empty(E, t_rel, ld + 1, dtype=torch.float32, device=dev)
+    _call("pn2_prep_gather_normalise", points, ld, n_obj, E, int(t_obj), int(t_rel), _ptr(points), _ptr(masks), _ptr(edges),
+          _ptr(sel), _ptr(obj), _ptr(rel), alg_bytes=slots * (4 + 8 * ld))
+    return obj, rel, boxes, sel, prefix[:, -1]

@@ -318,6 +318,37 @@ int pn2_group_concat_rows_bf16(int B, int N, int m, int ns, int C, int use_xyz, 
                                int ldo, const float *xyz, const float *new_xyz, const float *feats,
                                const int *idx, void *out, void *stream);
 
+/* ----------------------------------------------------------------- (f)3 ---
+ * Per-object / per-pair crops of a fused scan on the GPU: the step in front of the hot path
+ *   (SGH/dataset/data_preparation_utils.py:110-125 object crops, :173-224 pair crops, :37-49 re-sampling, :12-18
+ *   zero_mean; 81 crops per scan on the host with open3d in the reference).
+ * points (P, ld) fp32 rows (xyz first, ld >= 3), masks (P) i32 object id 1..n_obj (0 = context),
+ * edges (2, E) i32 ordered pairs of object indices (0-based).  Crops 0..n_obj-1 are the objects, then the E pairs.
+ *   pn2_prep_object_boxes     : boxes (n_obj, 6) = [min xyz - padding | max xyz + padding]; keys = n_obj*6 u32 scratch.
+ *   pn2_prep_chunk_counts     : counts (crops, pn2_prep_num_chunks(P)) i32 members per 1024-point chunk
+ *                               (object: masks == id; pair: strictly inside the union of the two boxes, all points).
+ *   [caller: prefix (crops, chunks+1) i64 = exclusive prefix sums of counts along the chunks]
+ *   pn2_prep_select           : sel (n_obj*t_obj + E*t_rel) i32 scan indices: members >= target -> one distinct member
+ *                               per stratum of the member order; fewer -> draws with replacement; counter-based
+ *                               generator keyed on (seed, crop, slot); -1 for an empty crop.
+ *   pn2_prep_gather_normalise : obj_out (n_obj, t_obj, ld), rel_out (E, t_rel, ld + 1) with the mask channel
+ *                               1 = subject / 2 = object / 0 = context last, xyz centred on the mean of the crop and
+ *                               divided by its largest norm (zero_mean).
+ * Deterministic parts restate the reference exactly; the sampler replaces open3d's voxel trace + numpy's global
+ * generator (not reproducible) by a seeded one with the same two regimes.
+ */
+int pn2_prep_num_chunks(int P);
+int pn2_prep_object_boxes(int P, int ld, int n_obj, float padding, const float *points, const int *masks,
+                          unsigned *keys, float *boxes, void *stream);
+int pn2_prep_chunk_counts(int P, int ld, int n_obj, int E, const float *points, const int *masks,
+                          const float *boxes, const int *edges, int *counts, void *stream);
+int pn2_prep_select(int P, int ld, int n_obj, int E, int t_obj, int t_rel, unsigned seed, const float *points,
+                    const int *masks, const float *boxes, const int *edges, const long long *prefix,
+                    int *sel, void *stream);
+int pn2_prep_gather_normalise(int ld, int n_obj, int E, int t_obj, int t_rel, const float *points,
+                              const int *masks, const int *edges, const int *sel, float *obj_out,
+                              float *rel_out, void *stream);
+
 /* ------------------------------------------------------------------ A12 ---
  * TripletGCN edge primitives.  Replace torch_geometric 2.0.2
  * MessagePassing.__lift__ (x.index_select(-2, edge_index[i])) and

@@ -367,3 +367,47 @@ def test_cell_list_ball_query_is_bit_exact(B, N, m, ns, r, kind):
             _ext.BALL_QUERY_GRID = True
     for mode, got in results.items():
         assert torch.equal(got, want), mode
+
+
+# ------------------------------------------------------------------------------------------------- GPU data preparation
+@pytest.mark.parametrize("n_obj,P,t_obj,t_rel", [(4, 60000, 1000, 2000), (3, 20000, 4000, 8000), (2, 5000, 300, 700)])
+def test_gpu_scan_preparation_matches_the_numpy_restatement(n_obj, P, t_obj, t_rel):
+    """crops / boxes / filters / mask channel / zero_mean of data_preparation_utils.py on the GPU vs
+    the numpy restatement (tests/prep_oracle.py): boxes and member counts exact, selected indices bit-exact, the
+    normalised clouds within 1e-5, the batch layout of collate_fn."""
+    import prep_oracle
+    from scene_graph_prediction.scene_graph_helpers.dataset import gpu_preparation as gp
+    pts, masks = gp.synthetic_fused_scan(n_obj, P, seed=n_obj, device="cuda")
+    names = ["Patient", "instrument_table", "human_1", "anesthesia_equipment"][:n_obj]
+    batch = gp.prepare_scan(pts, masks, n_obj, t_obj, t_rel, padding=0.2, seed=77, object_names=names)
+    obj, rel, boxes, sel, counts, edges = prep_oracle.prepare(pts.cpu().numpy(), masks.cpu().numpy(), n_obj, t_obj, t_rel, 0.2, 77)
+    assert np.array_equal(batch["edge_indices"].cpu().numpy(), edges)
+    np.testing.assert_array_equal(batch["prep"]["boxes"].cpu().numpy(), boxes)
+    np.testing.assert_array_equal(batch["prep"]["members"].cpu().numpy(), counts)
+    np.testing.assert_array_equal(batch["prep"]["selection"].cpu().numpy(), sel)
+    assert batch["obj_points"].shape == (n_obj, 6, t_obj) and batch["rel_points"].shape == (n_obj * (n_obj - 1), 7, t_rel)
+    np.testing.assert_allclose(batch["obj_points"].permute(0, 2, 1).cpu().numpy(), obj, atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(batch["rel_points"].permute(0, 2, 1).cpu().numpy(), rel, atol=1e-5, rtol=1e-5)
+    # zero_mean: centred, unit sphere; mask channel in {0, 1, 2}; one-hot = two ones per edge
+    xyz = batch["rel_points"][:, :3]
+    assert float(xyz.mean(dim=2).abs().max()) < 1e-4 and abs(float(xyz.norm(dim=1).max()) - 1.0) < 1e-5
+    assert set(batch["rel_points"][:, 6].unique().tolist()) <= {0.0, 1.0, 2.0}
+    assert bool((batch["relation_objects_one_hot"].sum(1) == 2).all())
+    # the under-populated object (2500 points < target in the first two cases) was up-sampled with replacement
+    if t_obj > 2500:
+        first = batch["prep"]["selection"][:t_obj]
+        assert len(torch.unique(first)) < t_obj
+
+
+def test_prepared_scan_runs_through_the_model():
+    from scene_graph_prediction.main import RELATION_NAMES, config_loader
+    from scene_graph_prediction.scene_graph_helpers.dataset import gpu_preparation as gp
+    from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+    torch.manual_seed(0)
+    model = SGPNModelWrapper(config_loader("no_gt.json"), 12, len(RELATION_NAMES), torch.ones(12), torch.ones(len(RELATION_NAMES)),
+                             RELATION_NAMES).cuda().eval()
+    pts, masks = gp.synthetic_fused_scan(5, 120000, seed=1, device="cuda")
+    names = ["Patient", "operating_table", "human_0", "instrument", "secondary_table"]
+    batch = gp.prepare_scan(pts, masks, 5, 4000, 8000, seed=3, object_names=names, scan_id="prep_000001")
+    scan_id, triples = model.predict_step(batch)
+    assert scan_id == "prep_000001" and all(len(t) == 3 for t in triples)
