@@ -70,6 +70,8 @@ _SIGNATURES = {
     "pn2_prep_chunk_counts": [_c_int] * 4 + [_c_vp] * 6,
     "pn2_prep_select": [_c_int] * 6 + [ctypes.c_uint] + [_c_vp] * 7,
     "pn2_prep_gather_normalise": [_c_int] * 5 + [_c_vp] * 7,
+    "pn2_floyd_warshall": [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_gen_edge_input": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_mlp_gemm": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
     "pn2_mlp_wgrad": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_fused": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
@@ -924,3 +926,26 @@ def prepare_scan_crops(points, masks, edges, n_obj, t_obj, t_rel, padding, seed)
     _call("pn2_prep_gather_normalise", points, ld, n_obj, E, int(t_obj), int(t_rel), _ptr(points), _ptr(masks), _ptr(edges),
           _ptr(sel), _ptr(obj), _ptr(rel), alg_bytes=slots * (4 + 8 * ld))
     return obj, rel, boxes, sel, prefix[:, -1]
+
+
+# ------------------------------------------- (f)4: Graphormer pre-processing (role_prediction/graphormer/algos.pyx)
+def floyd_warshall(adjacency):
+    """adjacency (B, n, n) int64 -> (dist (B,n,n), path (B,n,n)) int64; algos.pyx:11-54."""
+    _i64(adjacency, "adjacency")
+    _same_device((adjacency, "adjacency"))
+    B, n, _ = adjacency.shape
+    dist, path = torch.empty_like(adjacency), torch.empty_like(adjacency)
+    _call("pn2_floyd_warshall", adjacency, B, n, _ptr(adjacency), _ptr(dist), _ptr(path), alg_bytes=24 * B * n * n)
+    return dist, path
+
+
+def gen_edge_input(max_dist, path, edge_feat):
+    """path (B,n,n), edge_feat (B,n,n,F) int64 -> (B,n,n,max_dist,F) int64, -1 where there is no edge; algos.pyx:62-89."""
+    _i64(path, "path"); _i64(edge_feat, "edge_feat")
+    _same_device((path, "path"), (edge_feat, "edge_feat"))
+    B, n, _ = path.shape
+    F = edge_feat.size(-1)
+    out = torch.full((B, n, n, int(max_dist), F), -1, dtype=torch.int64, device=path.device)
+    _call("pn2_gen_edge_input", path, B, n, int(max_dist), F, _ptr(path), _ptr(edge_feat), _ptr(out),
+          alg_bytes=8 * B * n * n * (1 + F + int(max_dist) * F))
+    return out

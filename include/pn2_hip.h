@@ -393,6 +393,20 @@ int pn2_segment_bn_rows_grad(int64_t R, int C, int ldx, int col0, int64_t S, con
                              const float *mean, const float *rstd, int relu, float *grad_x,
                              float *dgamma_part, float *dbeta_part, void *stream);
 
+/* ----------------------------------------------------------------- (f)4 ---
+ * Graphormer pre-processing of the role-prediction task (role_prediction/graphormer/algos.pyx:11-89, called from
+ * wrapper.py:39-41), batched over B graphs of n <= 128 nodes, int64 like the reference's numpy arrays:
+ *   pn2_floyd_warshall: adjacency (B,n,n) -> dist (B,n,n) hop counts (unreachable = 12) and path (B,n,n) intermediate
+ *     vertices (12 where unreachable);
+ *   pn2_gen_edge_input: path (B,n,n), edge_feat (B,n,n,F) -> out (B,n,n,max_dist,F), which the CALLER pre-fills with
+ *     -1: edge features along [i] + get_all_edges(path, i, j) + [j].
+ * Bit-for-bit the reference, quirks included (see csrc/graph_algos.hip); parity is checked against the reference's
+ * own Cython module compiled into oracle/_ref.
+ */
+int pn2_floyd_warshall(int B, int n, const long long *adjacency, long long *dist, long long *path, void *stream);
+int pn2_gen_edge_input(int B, int n, int max_dist, int F, const long long *path, const long long *edge_feat,
+                       long long *out, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

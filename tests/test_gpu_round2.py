@@ -411,3 +411,58 @@ def test_prepared_scan_runs_through_the_model():
     batch = gp.prepare_scan(pts, masks, 5, 4000, 8000, seed=3, object_names=names, scan_id="prep_000001")
     scan_id, triples = model.predict_step(batch)
     assert scan_id == "prep_000001" and all(len(t) == 3 for t in triples)
+
+
+# ------------------------------------------------------------------------------------------------- (f)4
+def _ref_algos():
+    """The reference's own Cython module, compiled from role_prediction/graphormer/algos.pyx into oracle/_ref by
+    `make -C oracle ref` (__graft_entry__.build() does it whenever /root/reference is present; the .so travels)."""
+    import importlib
+    import sys
+    d = os.path.join(os.path.dirname(G.rstrip("/")), "..", "oracle", "_ref")
+    d = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref"))
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    try:
+        return importlib.import_module("algos")
+    except ImportError:
+        pytest.skip("oracle/_ref/algos*.so not built (needs /root/reference + cython: make -C oracle ref)")
+
+
+@pytest.mark.parametrize("n,density,seed", [(1, 0.5, 0), (2, 1.0, 1), (5, 0.3, 2), (13, 0.15, 3), (14, 0.12, 4), (20, 0.1, 5),
+                                            (31, 0.05, 6), (40, 0.04, 7), (9, 0.0, 8)])
+def test_graphormer_algos_match_the_compiled_reference(n, density, seed):
+    """floyd_warshall / gen_edge_input (role_prediction/graphormer/algos.pyx:11-89) on the GPU == the reference's own
+    module: hop distances, intermediate vertices (incl. vertex 12 colliding with the MAX_DIST marker for n > 12 and
+    vertex 0 never expanded) and the edge features along every path, all int64, bit for bit; also batched."""
+    ref = _ref_algos()
+    from role_prediction.graphormer import algos
+    rng = np.random.default_rng(seed)
+    adj = rng.random((n, n)) < density
+    np.fill_diagonal(adj, False)
+    Mr, Pr = ref.floyd_warshall(adj)
+    M, P = algos.floyd_warshall(adj)
+    assert M.dtype == np.int64 and np.array_equal(M, Mr) and np.array_equal(P, Pr)
+    feat = rng.integers(1, 50, size=(n, n, 3))
+    md = int(np.amax(Mr)) if n else 0
+    if md > 0:
+        Er = ref.gen_edge_input(md, Pr, feat)
+        E = algos.gen_edge_input(md, P, feat)
+        assert E.shape == Er.shape and np.array_equal(E, Er)
+    # a batch of graphs in one launch
+    adjs = torch.from_numpy(np.stack([adj, adj.T, np.zeros_like(adj)])).cuda()
+    Mb, Pb = algos.floyd_warshall(adjs)
+    for b, a in enumerate((adj, adj.T, np.zeros_like(adj))):
+        mr, pr = ref.floyd_warshall(a)
+        assert np.array_equal(Mb[b].cpu().numpy(), mr) and np.array_equal(Pb[b].cpu().numpy(), pr)
+
+
+def test_instance_label_fps_call_shape():
+    """compute_instance_labels.py:95,195: furthest_point_sample on ONE whole-object cloud (1, n, 3) -> 200 samples
+    (NPOINTS), n = a few 1e5 points in metric units: bit-exact against the oracle."""
+    from pointnet2_ops import pointnet2_utils as pu2
+    g = torch.Generator().manual_seed(12)
+    pts = torch.rand(1, 180000, 3, generator=g) * torch.tensor([2000.0, 900.0, 600.0])       # millimetres, like the scans
+    want = oracle_ext.OracleRowsExt.furthest_point_sampling(pts, 200)
+    got = pu2.furthest_point_sample(pts.cuda(), 200)[0].cpu()
+    assert torch.equal(got, want[0])
