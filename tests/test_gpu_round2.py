@@ -416,17 +416,22 @@ def test_prepared_scan_runs_through_the_model():
 # ------------------------------------------------------------------------------------------------- (f)4
 def _ref_algos():
     """The reference's own Cython module, compiled from role_prediction/graphormer/algos.pyx into oracle/_ref by
-    `make -C oracle ref` (__graft_entry__.build() does it whenever /root/reference is present; the .so travels)."""
+    `make -C oracle ref` (__graft_entry__.build() does it whenever /root/reference is present; the .so travels).
+    Cython registers the module under its source-tree name `role_prediction.graphormer.algos` as well — exactly the
+    name of the product's mirror — so the product module is imported first and its sys.modules entry restored."""
     import importlib
     import sys
-    d = os.path.join(os.path.dirname(G.rstrip("/")), "..", "oracle", "_ref")
+    import role_prediction.graphormer.algos as product
     d = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref"))
     if d not in sys.path:
         sys.path.insert(0, d)
     try:
-        return importlib.import_module("algos")
+        ref = importlib.import_module("algos")
     except ImportError:
         pytest.skip("oracle/_ref/algos*.so not built (needs /root/reference + cython: make -C oracle ref)")
+    sys.modules["role_prediction.graphormer.algos"] = product
+    assert ref is not product and ref.__file__.endswith(".so") and product.__file__.endswith("algos.py")
+    return ref, product
 
 
 @pytest.mark.parametrize("n,density,seed", [(1, 0.5, 0), (2, 1.0, 1), (5, 0.3, 2), (13, 0.15, 3), (14, 0.12, 4), (20, 0.1, 5),
@@ -435,8 +440,7 @@ def test_graphormer_algos_match_the_compiled_reference(n, density, seed):
     """floyd_warshall / gen_edge_input (role_prediction/graphormer/algos.pyx:11-89) on the GPU == the reference's own
     module: hop distances, intermediate vertices (incl. vertex 12 colliding with the MAX_DIST marker for n > 12 and
     vertex 0 never expanded) and the edge features along every path, all int64, bit for bit; also batched."""
-    ref = _ref_algos()
-    from role_prediction.graphormer import algos
+    ref, algos = _ref_algos()
     rng = np.random.default_rng(seed)
     adj = rng.random((n, n)) < density
     np.fill_diagonal(adj, False)
