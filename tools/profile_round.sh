@@ -2,15 +2,21 @@
 # Round profile of `python bench.py` on the GPU box: kernel-trace statistics + HBM traffic counters
 # (separate rocprofv3 passes, as MI355X_MICROARCH.md prescribes).  Usage: bash tools/profile_round.sh <tag>
 # Outputs land in gpurun_out/prof_<tag>/; copy the summaries you keep into profiles/.
-TAG=${1:-r01}
+# Optional further arguments are appended to the bench command (e.g. `--workload sgp --scans-per-step 8 --dtype bf16`).
+TAG=${1:-r02}
+shift
+EXTRA="$@"
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-serial-reference --no-forward-only"
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-serial-reference --no-forward-only $EXTRA"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- $CMD > $O/stats.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- $CMD > $O/fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- $CMD > $O/write.log 2>&1
+# matrix-core utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD with the MFMA pipe busy, GRBM_GUI_ACTIVE the
+# kernel's cycles (MI355X_MICROARCH.md, rocprofv3 PMC slots): busy fraction = MFMA_BUSY / (GUI_ACTIVE x 1024 SIMDs)
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $O/mfma --output-format csv -- $CMD > $O/mfma.log 2>&1
 python - <<PY
 import csv, glob, json, re, collections
 O = "$O"
@@ -25,7 +31,7 @@ def agg(sub, counter):
             k = short(r["Kernel_Name"]); tot[k] += float(r["Counter_Value"]); cnt[k] += 1
     return tot, cnt
 fe, fc = agg("fetch", "FETCH_SIZE"); wr, wc = agg("write", "WRITE_SIZE")
-out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-serial-reference --no-forward-only (separate passes)",
+out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- " + "$CMD".replace("$R/", "") + " (separate passes)",
        "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); counters in KiB", "kernels": {}}
 for k in sorted(set(fe) | set(wr)):
     n = max(fc[k], wc[k], 1)
@@ -33,6 +39,18 @@ for k in sorted(set(fe) | set(wr)):
     out["kernels"][k] = {"launches_traced": n, "fetch_bytes_per_launch_raw": f, "fetch_bytes_per_launch_corrected_x2": 2 * f,
                          "write_bytes_per_launch": w, "hbm_bytes_per_launch": 2 * f + w}
 json.dump(out, open(f"{O}/hbm_traffic_per_kernel.json", "w"), indent=1)
+# MFMA pass
+mf = {}
+for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"):
+    tot, cnt = agg("mfma", name)
+    for k in tot:
+        mf.setdefault(k, {})[name] = tot[k] / max(cnt[k], 1)
+for k, d in mf.items():
+    if d.get("GRBM_GUI_ACTIVE"):
+        d["mfma_busy_frac_of_1024_simds"] = round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["GRBM_GUI_ACTIVE"] * 1024.0), 4)
+json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -- " + "$CMD".replace("$R/", ""),
+           "note": "per-launch averages; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)", "kernels": mf},
+          open(f"{O}/mfma_util_per_kernel.json", "w"), indent=1)
 # kernel stats: name, calls, total ns, avg ns, pct
 for f in glob.glob(f"{O}/stats/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
