@@ -304,7 +304,26 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     trainable = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(trainable, lr=float(cfg["LR"]), weight_decay=float(cfg["W_DECAY"]), capturable=args.graphs)
     S = max(1, int(args.scans_per_step))
-    if S == 1:
+    fused = None
+    if args.with_prep:
+        # end to end: every step first cuts this step's scans out of resident fused room clouds (300k points, 9
+        # instances each) with the GPU preparation kernels (dataset/gpu_preparation.py), then trains on them
+        from scene_graph_prediction.scene_graph_helpers.dataset import gpu_preparation as gp
+        fused = [gp.synthetic_fused_scan(9, 300000, seed=100 + rank * S + i, device=device) for i in range(S)]
+        names = ["Patient", "operating_table", "human_0", "human_1", "instrument", "secondary_table", "instrument_table",
+                 "anesthesia_equipment", "human_2"]
+        g = torch.Generator().manual_seed(7)
+        labels = [(torch.randint(0, 12, (9,), generator=g).to(device), torch.randint(0, 15, (72,), generator=g).to(device))
+                  for _ in range(S)]
+
+        def prepare(step_idx):
+            scans = [gp.prepare_scan(p, m, 9, 4000, 8000, seed=step_idx * S + i, object_names=names, gt_class=labels[i][0],
+                                     gt_rels=labels[i][1], scan_id=f"prep_{i:06d}") for i, (p, m) in enumerate(fused)]
+            for sc in scans:
+                sc.pop("prep")
+            return scans[0] if S == 1 else to_device(collate_scans(scans), device)
+        scan = prepare(0)
+    elif S == 1:
         scan = to_device(synthetic_scan(9, 4000, 8000, seed=100 + rank), device)
     else:
         scan = to_device(collate_scans([synthetic_scan(9, 4000, 8000, seed=100 + rank * S + i, scan_id=f"synthetic_{i:06d}")
@@ -315,6 +334,8 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     main = torch.cuda.current_stream(device)
     state = {"geo": None}
 
+    counter = {"step": 0}
+
     def launch_geometry():
         side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -322,6 +343,9 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
 
     def with_prefetched_geometry():
         """This step's batch (geometry enqueued during the previous step) + enqueue the next scan's geometry."""
+        if fused is not None:
+            counter["step"] += 1
+            return prepare(counter["step"])                  # crops change every step: preparation + geometry in the step
         if side is None:
             return scan
         if state["geo"] is None:
@@ -393,6 +417,7 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
                                       "and rank (block-diagonal batch: per-scan GCN BatchNorm statistics and loss average; "
                                       "SA BatchNorm2d statistics over the step's clouds), train mode, fwd + weighted NLL + bwd + AdamW",
                           "scans_per_step": S,
+                          "with_gpu_preparation": bool(args.with_prep),
                           "parallelism": f"dp{world}", "hip_graphs": bool(args.graphs),
                           "host_enqueue_ms_per_step": round(enqueue_ms, 3),
                           "geometry_pipeline": bool(args.geometry_pipeline and not args.graphs)}}
@@ -429,6 +454,9 @@ def main():
                          "scene-graph model's MSG object encoder (SURVEY 8d stack 2a); sgp = BASELINE configs[2] shape: the full "
                          "scene-graph model on synthetic scans (9 objects x 4000 pts + 72 pairs x 8000 pts, one scan per "
                          "step like the reference's DataLoader(batch_size=1)), fp32")
+    ap.add_argument("--with-prep", action="store_true",
+                    help="sgp workload: include the GPU data preparation (object / pair crops of 300k-point fused scans, "
+                         "re-sampling, zero_mean) of every step's scans in the timed region")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="arithmetic of the shared-MLP stacks: f32 = exact fp32 MFMA (the headline / parity path); bf16 = the "
                          "counterpart of the reference's 16-bit AMP (bf16 activations and MFMA, fp32 weights and statistics)")
