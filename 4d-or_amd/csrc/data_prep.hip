@@ -39,17 +39,33 @@ __device__ __forceinline__ unsigned prep_mix(unsigned seed, unsigned a, unsigned
   return h;
 }
 
-// keys[obj][0..2] = min xyz, [3..5] = max xyz as order-preserving uints (caller presets 0xFF.. / 0)
+// keys[obj][0..2] = min xyz, [3..5] = max xyz as order-preserving uints (caller presets 0xFF.. / 0).  A handful of
+// objects share 6 words each: reduce in LDS per workgroup, one global atomic per (workgroup, object, word).
+constexpr int kMaxBoxObjs = 64;
 __global__ __launch_bounds__(256) void prep_bbox_kernel(int P, int ld, int n_obj, const float *__restrict__ pts,
                                                        const int *__restrict__ masks, unsigned *__restrict__ keys) {
+  __shared__ unsigned sk[kMaxBoxObjs * 6];
+  const bool lds_ok = n_obj <= kMaxBoxObjs;
+  if (lds_ok) {
+    for (int i = threadIdx.x; i < n_obj * 6; i += 256) sk[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+  }
+  unsigned *dst = lds_ok ? sk : keys;
   for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
     const int o = masks[p] - 1;
     if (o < 0 || o >= n_obj) continue;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const unsigned k = f2key(pts[(size_t)p * ld + d]);
-      atomicMin(keys + o * 6 + d, k);
-      atomicMax(keys + o * 6 + 3 + d, k);
+      atomicMin(dst + o * 6 + d, k);
+      atomicMax(dst + o * 6 + 3 + d, k);
+    }
+  }
+  if (lds_ok) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_obj * 6; i += 256) {
+      if ((i % 6) < 3) { if (sk[i] != 0xFFFFFFFFu) atomicMin(keys + i, sk[i]); }
+      else if (sk[i] != 0u) atomicMax(keys + i, sk[i]);
     }
   }
 }
@@ -109,51 +125,81 @@ __global__ __launch_bounds__(256) void prep_count_kernel(int P, int ld, int n_ob
   if (lane == 0) counts[(size_t)c * nchunks + chunk] = n;
 }
 
-// sel[slot]: scan index of the member drawn for (crop, slot); -1 for an empty crop.  One wave per slot.
+// sel[slot]: scan index of the member drawn for (crop, slot); -1 for an empty crop.  A wave owns a run of kRun
+// consecutive slots of ONE crop: their strata are consecutive ranges of the member order, so neighbouring slots mostly
+// land in the same 1024-point chunk and the 16 ballot masks of that chunk are computed once and re-used.
+constexpr int kRun = 32;
 __global__ __launch_bounds__(256) void prep_select_kernel(int P, int ld, int n_obj, int E, int nchunks, int t_obj, int t_rel,
                                                          unsigned seed, const float *__restrict__ pts,
                                                          const int *__restrict__ masks, const float *__restrict__ boxes,
                                                          const int *__restrict__ edges,
                                                          const long long *__restrict__ prefix /* (crops, nchunks+1) */,
-                                                         int *__restrict__ sel, long long slots) {
+                                                         int *__restrict__ sel, long long runs, int runs_obj_per_crop,
+                                                         int runs_rel_per_crop) {
   const int lane = pn2_lane();
-  const long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (slot >= slots) return;
-  const long long obj_slots = (long long)n_obj * t_obj;
-  int c, t, target;
-  if (slot < obj_slots) { c = (int)(slot / t_obj); t = (int)(slot - (long long)c * t_obj); target = t_obj; }
-  else { const long long s = slot - obj_slots; c = n_obj + (int)(s / t_rel); t = (int)(s - (long long)(c - n_obj) * t_rel); target = t_rel; }
+  const long long run = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (run >= runs) return;
+  const long long obj_runs = (long long)n_obj * runs_obj_per_crop;
+  int c, t0, target;
+  long long slot0;
+  if (run < obj_runs) {
+    c = (int)(run / runs_obj_per_crop); t0 = (int)(run - (long long)c * runs_obj_per_crop) * kRun; target = t_obj;
+    slot0 = (long long)c * t_obj;
+  } else {
+    const long long r = run - obj_runs;
+    const int e = (int)(r / runs_rel_per_crop);
+    c = n_obj + e; t0 = (int)(r - (long long)e * runs_rel_per_crop) * kRun; target = t_rel;
+    slot0 = (long long)n_obj * t_obj + (long long)e * t_rel;
+  }
   const long long *pre = prefix + (size_t)c * (nchunks + 1);
   const long long count = pre[nchunks];
-  if (count == 0) { if (lane == 0) sel[slot] = -1; return; }
-  const unsigned h = prep_mix(seed, (unsigned)c, (unsigned)t);
-  long long q;
-  if (count < target) {
-    q = (long long)(h % (unsigned long long)count);                         // with replacement (:38-39)
-  } else {
-    const long long s0 = (long long)t * count / target, s1 = (long long)(t + 1) * count / target;   // stratum of slot t
-    q = s0 + (long long)(h % (unsigned long long)(s1 - s0));
+  const int t1 = t0 + kRun < target ? t0 + kRun : target;
+  if (count == 0) {
+    for (int t = t0 + lane; t < t1; t += 64) sel[slot0 + t] = -1;
+    return;
   }
-  int lo = 0, hi = nchunks;                                                 // largest chunk with pre[chunk] <= q
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (pre[mid] <= q) lo = mid; else hi = mid;
-  }
-  int need = (int)(q - pre[lo]);                                            // rank inside the chunk
   const Crop k = load_crop(c, n_obj, boxes, edges, E);
-  for (int i = 0; i < kChunk; i += 64) {
-    const int p = lo * kChunk + i + lane;
-    const u64 m = __ballot(p < P && member(k, pts, masks, ld, p));
-    const int n = __popcll(m);
-    if (need < n) {
-      u64 mm = m;
-      for (int j = 0; j < need; ++j) mm &= mm - 1;                          // drop the `need` lowest set bits
-      if (lane == 0) sel[slot] = lo * kChunk + i + (__ffsll((long long)mm) - 1);
-      return;
+  int cached = -1;
+  u64 cm[kChunk / 64];
+  for (int t = t0; t < t1; ++t) {
+    const unsigned h = prep_mix(seed, (unsigned)c, (unsigned)t);
+    long long q;
+    if (count < target) {
+      q = (long long)(h % (unsigned long long)count);                       // with replacement (:38-39)
+    } else {
+      const long long s0 = (long long)t * count / target, s1 = (long long)(t + 1) * count / target;   // stratum of slot t
+      q = s0 + (long long)(h % (unsigned long long)(s1 - s0));
     }
-    need -= n;
+    int lo = 0, hi = nchunks;                                               // largest chunk with pre[chunk] <= q
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre[mid] <= q) lo = mid; else hi = mid;
+    }
+    if (lo != cached) {
+#pragma unroll
+      for (int i = 0; i < kChunk / 64; ++i) {
+        const int p = lo * kChunk + i * 64 + lane;
+        cm[i] = __ballot(p < P && member(k, pts, masks, ld, p));
+      }
+      cached = lo;
+    }
+    int need = (int)(q - pre[lo]);                                          // rank inside the chunk
+    int found = -1;
+#pragma unroll
+    for (int i = 0; i < kChunk / 64; ++i) {
+      const int n = __popcll(cm[i]);
+      if (found < 0) {
+        if (need < n) {
+          u64 mm = cm[i];
+          for (int j = 0; j < need; ++j) mm &= mm - 1;                      // drop the `need` lowest set bits
+          found = lo * kChunk + i * 64 + (__ffsll((long long)mm) - 1);
+        } else {
+          need -= n;
+        }
+      }
+    }
+    if (lane == 0) sel[slot0 + t] = found;
   }
-  if (lane == 0) sel[slot] = -1;                                            // unreachable when prefix matches the counts
 }
 
 // one workgroup per crop: gather rows -> out (T, W), W = ld (+1 mask channel for pairs), then zero_mean (:12-18)
@@ -229,7 +275,7 @@ extern "C" int pn2_prep_object_boxes(int P, int ld, int n_obj, float padding, co
   }
   if (P > 0) {
     unsigned grid = (unsigned)((P + 255) / 256);
-    if (grid > 4096) grid = 4096;
+    if (grid > 512) grid = 512;
     hipLaunchKernelGGL(prep_bbox_kernel, dim3(grid), dim3(256), 0, s, P, ld, n_obj, points, masks, keys);
   }
   hipLaunchKernelGGL(prep_bbox_finish_kernel, dim3((unsigned)((n_obj * 6 + 63) / 64)), dim3(64), 0, s, n_obj, padding, keys,
@@ -256,10 +302,12 @@ extern "C" int pn2_prep_select(int P, int ld, int n_obj, int E, int t_obj, int t
   const long long slots = (long long)n_obj * t_obj + (long long)E * t_rel;
   if (slots == 0) return PN2_OK;
   if (!points || !masks || !boxes || !prefix || !sel || (E > 0 && !edges)) return PN2_ENULL;
-  const long long blocks = (slots + 3) / 4;
+  const int ro = (t_obj + kRun - 1) / kRun, rr = (t_rel + kRun - 1) / kRun;
+  const long long runs = (long long)n_obj * ro + (long long)E * rr;
+  const long long blocks = (runs + 3) / 4;
   if (blocks > 0x7fffffffLL) return PN2_EINVAL;
   hipLaunchKernelGGL(prep_select_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, ld, n_obj, E,
-                     pn2_prep_num_chunks(P), t_obj, t_rel, seed, points, masks, boxes, edges, prefix, sel, slots);
+                     pn2_prep_num_chunks(P), t_obj, t_rel, seed, points, masks, boxes, edges, prefix, sel, runs, ro, rr);
   return pn2_check_launch();
 }
 

@@ -95,12 +95,41 @@ def record_stream_tree(obj, stream):
             record_stream_tree(v, stream)
 
 
-def train_step(model, opt, pc, geometry=None, between=None):
-    opt.zero_grad(set_to_none=True)
+class FlatGradSync:
+    """Data parallelism without DistributedDataParallel: every parameter's .grad is a view of ONE flat fp32 buffer
+    (runtime.FlatGrads), zeroed once per step and averaged with ONE RCCL all-reduce between backward and the optimizer.
+    The models on this path have 0.65 M (backbone) / 3.9 M (scene-graph model) live parameters: a single 2.6 / 15.6 MB
+    collective is latency-bound over xGMI and there is nothing to overlap, while DDP's per-step bookkeeping (bucket
+    rebuild, autograd hooks on ~100 parameters, reducer traversal) costs the host thread that is this step's bottleneck
+    (measured at world size 1 under torchrun: 22.1 ms/step with DDP vs 17.9 without)."""
+
+    def __init__(self, params, world):
+        from runtime.graphed_step import FlatGrads
+        self.world = world
+        self.flat = FlatGrads(params)
+        if world > 1:                                     # same initial weights everywhere (all ranks seed alike; belt and braces)
+            for p in self.flat.params:
+                dist.broadcast(p.data, src=0)
+
+    def zero(self):
+        self.flat.zero_()
+
+    def sync(self):
+        if self.world > 1:
+            self.flat.all_reduce_mean()
+
+
+def train_step(model, opt, pc, geometry=None, between=None, sync=None):
+    if sync is not None:
+        sync.zero()
+    else:
+        opt.zero_grad(set_to_none=True)
     feats = model(pc, geometry=geometry)["fp2_features"]
     loss = feats.square().mean()
     nxt = between() if between is not None else None     # hook between forward and backward
     loss.backward()
+    if sync is not None:
+        sync.sync()
     opt.step()
     return nxt
 
@@ -130,14 +159,14 @@ class GeometryPrefetcher:
         return geo
 
 
-def run_steps(net, backbone, opt, pc, steps, prefetcher, on_step=None):
+def run_steps(net, backbone, opt, pc, steps, prefetcher, on_step=None, sync=None):
     """`steps` training steps on the resident batch; with a prefetcher, step i consumes the geometry
     enqueued during step i-1 and enqueues the one for step i+1."""
     if prefetcher is None:
         for i in range(steps):
             if on_step is not None:
                 on_step(i)
-            train_step(net, opt, pc)
+            train_step(net, opt, pc, sync=sync)
         return
     # steady state across calls: the geometry enqueued by the last step of the previous call (warm-up) feeds the first
     # step of this one, exactly as it does between two steps
@@ -151,7 +180,7 @@ def run_steps(net, backbone, opt, pc, steps, prefetcher, on_step=None):
         # (measured launch positions with 512-thread FPS clusters: start of the step 20.2 ms, behind sa1's forward 20.7,
         # behind sa2 21.5, behind the whole forward 22.2-23.3; with PN2_FPS_FEW_CUS: 18.2 at the start, 18.2 behind the forward)
         nxt = prefetcher.launch(pc)
-        train_step(net, opt, pc, cur)
+        train_step(net, opt, pc, cur, sync=sync)
         geo = nxt
     prefetcher.pending = geo
 
@@ -286,6 +315,13 @@ def cpu_baseline(points, sample_scenes, threads, workload="backbone", repeats=5)
                       f"over scenes; MLPs torch CPU with {threads} threads)"}
 
 
+def emit_json(out, args):
+    sys.stdout.flush()
+    os.dup2(args._real_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
+
+
 def bench_sgp(args, device, rank, world, distributed, _ext):
     """BASELINE configs[2] shape on one or more GPUs: SGPNModelWrapper (2 MSG encoders + 2-layer
     TripletGCN + heads), `--scans-per-step` synthetic scans per step and rank (block-diagonal batch, per-scan GCN
@@ -366,16 +402,23 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
         def step():
             graphed(with_prefetched_geometry())
     else:
-        net = model
-        if distributed:
+        net, sync = model, None
+        if distributed and args.grad_sync == "ddp":
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=64,
                                                             gradient_as_bucket_view=True, broadcast_buffers=False)
+        elif distributed:
+            sync = FlatGradSync(trainable, world)
 
         def step():
             batch = with_prefetched_geometry()
-            opt.zero_grad(set_to_none=True)
+            if sync is not None:
+                sync.zero()
+            else:
+                opt.zero_grad(set_to_none=True)
             obj, rel = net(batch)
             model.loss(obj, rel, batch).backward()
+            if sync is not None:
+                sync.sync()
             opt.step()
 
     for _ in range(args.warmup):
@@ -430,7 +473,7 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
             out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
             if main_rows:
                 out["roofline"] = roofline_of(main_rows[0], False)
-        print(json.dumps(out), flush=True)
+        emit_json(out, args)
     if distributed:
         dist.destroy_process_group()
 
@@ -454,6 +497,9 @@ def main():
                          "scene-graph model's MSG object encoder (SURVEY 8d stack 2a); sgp = BASELINE configs[2] shape: the full "
                          "scene-graph model on synthetic scans (9 objects x 4000 pts + 72 pairs x 8000 pts, one scan per "
                          "step like the reference's DataLoader(batch_size=1)), fp32")
+    ap.add_argument("--grad-sync", choices=["flat", "ddp"], default="flat",
+                    help="multi-GPU gradient exchange: flat = one RCCL all-reduce of a flat gradient buffer per step (default); "
+                         "ddp = torch DistributedDataParallel")
     ap.add_argument("--with-prep", action="store_true",
                     help="sgp workload: include the GPU data preparation (object / pair crops of 300k-point fused scans, "
                          "re-sampling, zero_mean) of every step's scans in the timed region")
@@ -471,6 +517,13 @@ def main():
     ap.add_argument("--geometry-pipeline", dest="geometry_pipeline", action="store_true", help=argparse.SUPPRESS)
     ap.set_defaults(geometry_pipeline=True)
     args = ap.parse_args()
+
+    # stdout carries exactly ONE JSON line: anything a library prints there (RCCL's version banner at communicator
+    # creation) is routed to stderr; the real stdout is restored for the final print
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    args._real_stdout = real_stdout
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -493,18 +546,20 @@ def main():
         return bench_sgp(args, device, rank, world, distributed, _ext)
 
     model = build_model(device, args.workload)
-    net = model
-    if distributed:
+    net, sync = model, None
+    if distributed and args.grad_sync == "ddp":
         # gradients only: one flat bucket (650k params = 2.6 MB, latency-bound over xGMI)
         # BatchNorm statistics stay per rank (no SyncBN: the reference is single-GPU), so the running
         # buffers are not re-broadcast from rank 0 before every forward either
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=64,
                                                         gradient_as_bucket_view=True, broadcast_buffers=False)
+    elif distributed:
+        sync = FlatGradSync(model.parameters(), world)
     opt = torch.optim.AdamW(model.parameters(), lr=3e-5, weight_decay=1e-3)
     pc = synthetic_scenes(args.batch, args.points, seed=1000 + rank, device=device)   # resident in HBM
 
     prefetcher = GeometryPrefetcher(model, device) if args.geometry_pipeline else None
-    run_steps(net, model, opt, pc, args.warmup, prefetcher)
+    run_steps(net, model, opt, pc, args.warmup, prefetcher, sync=sync)
     torch.cuda.synchronize()
 
     main_stream = torch.cuda.current_stream(device).cuda_stream
@@ -513,19 +568,19 @@ def main():
     serial_ms, serial_rows = None, None
     if prefetcher is not None and rank == 0 and world == 1 and not args.no_serial_reference:
         ks = max(2, min(args.steps, 5))
-        run_steps(net, model, opt, pc, 1, None)
+        run_steps(net, model, opt, pc, 1, None, sync=sync)
         torch.cuda.synchronize()
         ts = time.perf_counter()
-        run_steps(net, model, opt, pc, ks, None)
+        run_steps(net, model, opt, pc, ks, None, sync=sync)
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - ts) / ks * 1e3
         if not args.no_kernel_timing:
             st = _ext.KernelTimer(main_stream)
             _ext.TIMER = st
-            run_steps(net, model, opt, pc, 2, None)
+            run_steps(net, model, opt, pc, 2, None, sync=sync)
             _ext.TIMER = None
             serial_rows = kernel_table(st.summary(), 2)
-        run_steps(net, model, opt, pc, 2, prefetcher)       # back to the pipelined steady state
+        run_steps(net, model, opt, pc, 2, prefetcher, sync=sync)       # back to the pipelined steady state
         torch.cuda.synchronize()
 
     # per-kernel HIP events are sampled on a few of the timed steps; the table is normalised by the number of sampled steps
@@ -549,7 +604,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(net, model, opt, pc, args.steps, prefetcher, on_step)
+    run_steps(net, model, opt, pc, args.steps, prefetcher, on_step, sync=sync)
     enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to enqueue a step (no GPU wait)
     torch.cuda.synchronize()
     if distributed:
@@ -636,7 +691,7 @@ def main():
             except Exception as e:  # the baseline is informational; never lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "scenes/s", "cores": threads, "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
-        print(json.dumps(out), flush=True)
+        emit_json(out, args)
 
     if distributed:
         dist.destroy_process_group()

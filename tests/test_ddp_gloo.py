@@ -72,3 +72,59 @@ def test_two_rank_gloo_gradient_allreduce(tmp_path):
     assert torch.equal(res["params"][0], res["params"][1])                    # ranks stay in sync
     mean_local = (res["local_grads"][0] + res["local_grads"][1]) / 2          # DDP averages gradients
     torch.testing.assert_close(res["ddp_grad"], mean_local, atol=1e-6, rtol=1e-5)
+
+
+def _flat_worker(rank, world, port, out):
+    """bench.py's default gradient exchange (FlatGradSync: one all-reduce of a flat buffer, no DDP) on 2 gloo ranks."""
+    sys.path[:0] = [os.path.join(REPO, "4d-or_amd"), REPO, os.path.join(REPO, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import oracle_ext
+    from pointnet2_ops import pointnet2_modules as pm, pointnet2_utils as pu
+    pu._ext = oracle_ext.OracleRowsExt
+    torch.manual_seed(rank)                    # DIFFERENT initial weights: the constructor must broadcast rank 0's
+    sa = pm.PointnetSAModuleMSG(npoint=32, radii=[0.3, 0.6], nsamples=[4, 8], mlps=[[3, 8, 8], [3, 8, 16]])
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.sa = sa
+
+        def forward(self, pc, geometry=None):
+            xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+            return {"fp2_features": self.sa(xyz, feats)[1]}
+
+    model = Net()
+    sync = bench.FlatGradSync(model.parameters(), world)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(100 + rank)
+    pc = torch.rand(2, 200, 6, generator=g) * 2 - 1
+    local = Net()
+    local.sa = __import__("copy").deepcopy(model.sa)
+    local(pc)["fp2_features"].square().mean().backward()
+    lg = torch.cat([p.grad.flatten() for p in local.parameters()])
+    for i in range(2):
+        bench.train_step(model, opt, pc, sync=sync)
+        if i == 0:
+            first = sync.flat.flat.clone()
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    lgs = [torch.zeros_like(lg) for _ in range(world)]
+    dist.all_gather(lgs, lg)
+    if rank == 0:
+        torch.save({"params": gathered, "sync_grad": first, "local_grads": lgs}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_flat_gradient_allreduce(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_flat_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["params"][0], res["params"][1])                    # broadcast at start + identical updates
+    mean_local = (res["local_grads"][0] + res["local_grads"][1]) / 2
+    torch.testing.assert_close(res["sync_grad"], mean_local, atol=1e-6, rtol=1e-5)
