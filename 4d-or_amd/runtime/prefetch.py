@@ -36,7 +36,9 @@ class GeometryPrefetcher:
         self.precompute = precompute
         self.batches = batches
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.side = torch.cuda.Stream(device=self.device)
+        # high priority = a hardware queue of its own: two default-priority streams can be mapped onto ONE queue (HIP
+        # assigns queues round-robin) and then never overlap (profiles/r02_stream_queue_aliasing.md)
+        self.side = torch.cuda.Stream(device=self.device, priority=-1)
 
     def _launch(self, batch):
         main = torch.cuda.current_stream(self.device)

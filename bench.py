@@ -134,6 +134,14 @@ def train_step(model, opt, pc, geometry=None, between=None, sync=None):
     return nxt
 
 
+def side_stream(device):
+    """The geometry-prefetch stream.  HIP maps streams onto a few hardware queues round-robin, and two streams on one
+    queue run strictly one after the other: under torchrun (RCCL's own streams shift the mapping) a default-priority
+    side stream landed on the main stream's queue and the whole overlap was gone (23.8 instead of 18.2 ms/step,
+    profiles/r02_stream_queue_aliasing.md).  A high-priority stream gets a queue of its own."""
+    return torch.cuda.Stream(device=device, priority=-1)
+
+
 class GeometryPrefetcher:
     """Data-loader-style pipelining of the coordinate-only work (FPS chain, ball queries, 3-NN
     weights: no parameters involved).  The geometry of the NEXT batch is enqueued on a side HIP
@@ -143,7 +151,7 @@ class GeometryPrefetcher:
 
     def __init__(self, backbone, device):
         self.backbone = backbone
-        self.side = torch.cuda.Stream(device=device)
+        self.side = side_stream(device)
         self.main = torch.cuda.current_stream(device)
         self.pending = None           # geometry enqueued for the NEXT step (of the same resident batch)
 
@@ -366,7 +374,7 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
                                         for i in range(S)]), device)
     # geometry of the NEXT scan (FPS chains + ball queries of both encoders) on a side stream during this step,
     # like the backbone workload; the scan-at-a-time loop of the reference knows its next scan from the data loader
-    side = torch.cuda.Stream(device=device) if args.geometry_pipeline else None
+    side = side_stream(device) if args.geometry_pipeline else None
     main = torch.cuda.current_stream(device)
     state = {"geo": None}
 
