@@ -169,12 +169,16 @@ def test_wgrad_bf16(M, N, K, kind, pooled):
 def test_group_concat_rows_bf16_matches_fp32_kernel():
     from pointnet2_ops import _ext as e
     g = torch.Generator().manual_seed(3)
-    B, N, m, ns, C = 3, 700, 40, 16, 5
+    B, N, m, ns = 3, 700, 40, 16
     xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1).cuda()
-    feats = torch.randn(B, N, C, generator=g).cuda()
     idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32).cuda()
     new_xyz = xyz[:, :m].contiguous()
-    for use_xyz, norm, f in ((True, True, feats), (True, False, None), (False, False, feats)):
+    cases = []
+    for C in (5, 13, 37, 128, 192, 256):            # pitch 8 / 16 (lane per row) and wide rows (wave per row group)
+        feats = torch.randn(B, N, C, generator=g).cuda()
+        cases += [(True, True, feats), (False, False, feats)]
+    cases.append((True, False, None))
+    for use_xyz, norm, f in cases:
         want = e.group_concat_rows(xyz, new_xyz, f, idx, use_xyz, norm, 0.4)
         got = e.group_concat_rows_bf16(xyz, new_xyz, f, idx, use_xyz, norm, 0.4)
         W = want.size(-1)
