@@ -337,33 +337,23 @@ __global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_kernel(
       const size_t src = (size_t)b * N + (size_t)ii;
       unsigned *o = out + (size_t)(base + q) * (ldo / 2);
       const float *f = feats + src * C - Cx;     // f[c] = feature column c - Cx
-      // a lane produces FOUR columns (one 8-byte store): a 200-column row is one pass of 50 lanes; columns inside the
-      // feature range come in as two dword-aligned 8-byte loads
-      for (int c = 4 * lane; c < ldo; c += 256) {
-        float v[4];
-        if (c >= Cx && c + 3 < W) {
-          const float2 a = *(const float2 *)(f + c), d = *(const float2 *)(f + c + 2);
-          v[0] = a.x; v[1] = a.y; v[2] = d.x; v[3] = d.y;
-        } else {
+      for (int c = 2 * lane; c < ldo; c += 128) {
+        float v[2];
 #pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            const int cc = c + h;
-            float t = 0.f;
-            if (cc < Cx) {
-              t = xyz[src * 3 + cc] - new_xyz[(size_t)bj * 3 + cc];
-              if (normalize) t = __fdiv_rn(t, radius);
-            } else if (cc < W) {
-              t = f[cc];
-            }
-            v[h] = t;
+        for (int h = 0; h < 2; ++h) {
+          const int cc = c + h;
+          float t = 0.f;
+          if (cc < Cx) {
+            t = xyz[src * 3 + cc] - new_xyz[(size_t)bj * 3 + cc];
+            if (normalize) t = __fdiv_rn(t, radius);
+          } else if (cc < W) {
+            t = f[cc];
           }
+          v[h] = t;
         }
-        uint2 w;
-        w.x = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) |
-              ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
-        w.y = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) |
-              ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
-        *(uint2 *)(o + (c >> 1)) = w;
+        const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)v[0]);
+        const unsigned hi = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
+        o[c >> 1] = lo | (hi << 16);
       }
       if (++s == (unsigned)ns) {
         s = 0; ++bj;
