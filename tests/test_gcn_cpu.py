@@ -2,6 +2,7 @@
 README.md:87 — "parity unpinned" against them): checked against a plain-torch
 index_select / index_add_ restatement of MessagePassing(source_to_target) and
 against the hand example of network_util.py:86-94."""
+import pytest
 import torch
 
 from scene_graph_prediction.scene_graph_helpers.model.gcns.network_TripletGCN import (
@@ -108,3 +109,58 @@ def test_batched_scans_equal_single_scan_steps(oracle_backend):
     # triples: one (scan_id, triples) per scan, with scan-local object ids
     per_scan = [m.predict_step(s) for s in scans]
     assert m.predict_step(batch) == per_scan
+
+
+def test_with_images_config_late_fusion(oracle_backend):
+    """BASELINE configs[3] plumbing (scene_graph_prediction_model.py:47-55, 96-100): with IMAGE_INPUT='full' the model
+    owns `full_image_feature_reduction` (num_features -> 768 // 6), flattens the six views into one 768-vector and
+    late-fuses it in the relation head; the 2-D CNN itself is external (precomputed features or an attached module);
+    reference checkpoints with `full_image_model.*` entries load."""
+    from scene_graph_prediction.main import RELATION_NAMES, config_loader
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan
+    from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+    cfg = config_loader("no_gt_image.json")
+    assert cfg["IMAGE_INPUT"] == "full" and cfg["MODEL"]["IMAGE_MODEL"] == "tf_efficientnet_b5_ns"
+    torch.manual_seed(0)
+    m = SGPNModelWrapper(cfg, 12, 15, torch.ones(12), torch.ones(15), RELATION_NAMES).eval()
+    sd = m.state_dict()
+    assert sd["full_image_feature_reduction.weight"].shape == (128, 2048)
+    assert sd["rel_predictor.fc3.weight"].shape == (15, 256 + 768 + 12)
+    scan = synthetic_scan(4, 300, 400, seed=1)
+    with pytest.raises(RuntimeError, match="full_image_features"):
+        m(scan)
+    g = torch.Generator().manual_seed(2)
+    scan["full_image_features"] = torch.randn(6, 2048, generator=g)
+    obj, rel = m(scan)
+    assert obj.shape == (4, 12) and rel.shape == (12, 15)
+    # the embedding really reaches the relation logits, and only them
+    other = dict(scan, full_image_features=scan["full_image_features"] + 1.0)
+    obj2, rel2 = m(other)
+    assert torch.equal(obj, obj2) and not torch.allclose(rel, rel2)
+    # an attached CNN (any module mapping (6,3,H,W) -> (6, num_features)) is frozen except `conv_head`
+    class TinyCNN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = torch.nn.Conv2d(3, 4, 3)
+            self.bn = torch.nn.BatchNorm2d(4)
+            self.conv_head = torch.nn.Conv2d(4, 2048, 1)
+
+        def forward(self, x):
+            return self.conv_head(self.bn(self.stem(x))).mean(dim=(2, 3))
+    m.attach_image_model(TinyCNN())
+    img = dict(scan, full_image=torch.randn(6, 3, 16, 16, generator=g))
+    img.pop("full_image_features")
+    _, rel3 = m(img)
+    assert rel3.shape == (12, 15) and not m.full_image_model.bn.training
+    assert not m.full_image_model.stem.weight.requires_grad and m.full_image_model.conv_head.weight.requires_grad
+    # a reference checkpoint carries the CNN's weights under full_image_model.*: skipped when no CNN is attached
+    m2 = SGPNModelWrapper(cfg, 12, 15, torch.ones(12), torch.ones(15), RELATION_NAMES)
+    ref_sd = dict(sd)
+    ref_sd["full_image_model.conv_stem.weight"] = torch.zeros(1)
+    m2.load_state_dict(ref_sd, strict=True)
+    # batched scans: one embedding per scan
+    scans = [dict(synthetic_scan(n, 300, 400, seed=10 + n), full_image_features=torch.randn(6, 2048, generator=g)) for n in (4, 5)]
+    m.full_image_model = None
+    ob, rb = m(collate_scans(scans))
+    singles = [m(s) for s in scans]
+    torch.testing.assert_close(rb, torch.cat([r for _, r in singles]), atol=1e-4, rtol=1e-4)
