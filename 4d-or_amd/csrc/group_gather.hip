@@ -319,6 +319,9 @@ __global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_kernel(
   const int lane = pn2_lane();
   const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
   const int W = Cx + C;
+  // 16-byte feature loads: xyz in front, feature width a multiple of 4 (<= 248 so that 62 lanes cover a row), 16-byte
+  // aligned feature rows
+  const bool fast = Cx == 3 && C >= 4 && (C & 3) == 0 && C <= 248 && (((size_t)feats) & 15) == 0;
   unsigned r0 = wave * rows_per_wave;
   if (r0 >= rows) return;
   unsigned r1 = r0 + rows_per_wave;
@@ -336,6 +339,36 @@ __global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_kernel(
       const int ii = __builtin_amdgcn_readlane(myi, q);
       const size_t src = (size_t)b * N + (size_t)ii;
       unsigned *o = out + (size_t)(base + q) * (ldo / 2);
+      if (fast) {
+        // [x y z | f0 f1 ...]: lane j loads features 4j..4j+3 with ONE 16-byte load; the row's dword d holds columns
+        // (2d, 2d+1), i.e. dword 2j+1 = (previous lane's 4th value | f[4j]) and dword 2j+2 = (f[4j+1] | f[4j+2]):
+        // one shuffle, one 8-byte store per lane.  Lane 63 writes (x, y); the lane behind the last feature lane
+        // closes the row (last feature | zero pad).
+        const float *fr = feats + src * C;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int nl = C >> 2;                                   // feature lanes
+        if (lane < nl) v = *(const float4 *)(fr + 4 * lane);
+        float rx = 0.f, ry = 0.f, rz = 0.f;
+        if (lane == 0 || lane == 63) {
+          rx = xyz[src * 3 + 0] - new_xyz[(size_t)bj * 3 + 0];
+          ry = xyz[src * 3 + 1] - new_xyz[(size_t)bj * 3 + 1];
+          rz = xyz[src * 3 + 2] - new_xyz[(size_t)bj * 3 + 2];
+          if (normalize) { rx = __fdiv_rn(rx, radius); ry = __fdiv_rn(ry, radius); rz = __fdiv_rn(rz, radius); }
+        }
+        float prev = __shfl_up(v.w, 1);
+        if (lane == 0) prev = rz;
+        auto pk = [](float lo, float hi) {
+          return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) |
+                 ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+        };
+        if (lane < nl) {
+          o[2 * lane + 1] = pk(prev, v.x);
+          o[2 * lane + 2] = pk(v.y, v.z);
+        } else if (lane == nl) {
+          for (int d = 2 * nl + 1; d < ldo / 2; ++d) o[d] = d == 2 * nl + 1 ? pk(prev, 0.f) : 0u;
+        }
+        if (lane == 63) o[0] = pk(rx, ry);
+      } else {
       const float *f = feats + src * C - Cx;     // f[c] = feature column c - Cx
       for (int c = 2 * lane; c < ldo; c += 128) {
         float v[2];
@@ -354,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_kernel(
         const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)v[0]);
         const unsigned hi = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
         o[c >> 1] = lo | (hi << 16);
+      }
       }
       if (++s == (unsigned)ns) {
         s = 0; ++bj;
