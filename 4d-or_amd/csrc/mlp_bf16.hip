@@ -534,6 +534,291 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad_bf16_kernel(const WgradBf16A
     }
 }
 
+// ---------------------------------------------------------------------------------------------- one-pass backward
+// dgrad AND wgrad of a hidden layer from ONE read of (g, y_l, y_{l-1}) — what pn2_mlp_gemm_bf16(pro 2|3, epi 2) and
+// pn2_mlp_wgrad_bf16(amode 1) compute for the same operands:
+//   Gout[M][K] = [BN(y_{l-1}) > 0] * (gy * W),  sums += (sum Gout, sum Gout * yhat_{l-1}),  dW[N][K] += gy^T relu(BN(y_{l-1}))
+// Both kernels are HBM-bound and between them read g and y_l twice and y_{l-1} twice; here a 64-row tile of gy is staged
+// row-major (dgrad A operand) AND transposed (wgrad A operand), the activation tile transposed (wgrad B operand) and
+// raw row-major (ReLU mask / yhat of the dgrad epilogue, overwritten in place by the masked result and stored with
+// 16-byte rows), the transposed weights stay resident.  8 waves: the 2 x K/32 dgrad tiles and the N/32 x K/32 wgrad
+// tiles are dealt round-robin; wgrad accumulators persist across the workgroup's tiles.  N, K in {32, 64, 96, 128}.
+struct BwdBf16Args {
+  const bf16 *G, *Yl;
+  const float *consts;      // [3][N]
+  const int *arg;
+  const float *gP;
+  const float *Wt;          // [K][N] fp32 (transposed weights, as the dgrad call takes them)
+  const bf16 *Yprev;        // [M][K]
+  const float *a_fin;       // [mean | rstd | scale | shift] x K
+  bf16 *Gout;               // [M][K]
+  double *sums;             // [2][K]
+  float *dW;                // [N][K] ACCUMULATES
+  long long M;
+  int N, K, ns;
+};
+
+template <int NTN, int KTK, int GMODE>
+__global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args a) {
+  constexpr int MT = 64, MP = MT + 8;
+  constexpr int NB = NTN * 32, KB = KTK * 32, NP = NB + 8, KP = KB + 8;
+  constexpr int DT = (2 * KTK + 7) / 8;              // dgrad tiles per wave
+  constexpr int WT = (NTN * KTK + 7) / 8;            // wgrad tiles per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16 *sWt = (bf16 *)smem;                          // [KB][NP]
+  bf16 *sGY = sWt + KB * NP;                         // [MT][NP]
+  bf16 *sGT = sGY + MT * NP;                         // [NB][MP]
+  bf16 *sXT = sGT + NB * MP;                         // [KB][MP]
+  bf16 *sO = sXT + KB * MP;                          // [MT][KP]
+  float *sC = (float *)(sO + MT * KP);               // c1 | c2 | c3 [NB], then mean | rstd | scale | shift [KB]
+  float *sF = sC + 3 * NB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, K = a.K;                        // == NB, KB (checked by the host wrapper)
+  for (int n = tid; n < NB; n += 512) { sC[n] = a.consts[n]; sC[NB + n] = a.consts[N + n]; sC[2 * NB + n] = a.consts[2 * N + n]; }
+  for (int k = tid; k < KB; k += 512) {
+    sF[k] = a.a_fin[k]; sF[KB + k] = a.a_fin[K + k]; sF[2 * KB + k] = a.a_fin[2 * K + k]; sF[3 * KB + k] = a.a_fin[3 * K + k];
+  }
+  for (int k = wave; k < KB; k += 8)
+    for (int n = lane; n < NB; n += 64) sWt[k * NP + n] = (bf16)a.Wt[(size_t)k * N + n];
+
+  f32x16 accw[WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accw[i][e] = 0.f;
+  float s1[DT], s2[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) s1[i] = s2[i] = 0.f;
+
+  constexpr int CGn = NB / 8, CGk = KB / 8;
+  constexpr int GT = (32 * CGn + 511) / 512;         // gy tasks per thread (row pair x 8 columns)
+  constexpr int XT = (32 * CGk + 511) / 512;
+  const long long ntiles = (a.M + MT - 1) / MT;
+
+  u32x4 rg0[GT], rg1[GT], ry0[GT], ry1[GT], rx0[XT], rx1[XT];
+  auto issue = [&](long long tile) {
+    const long long row0 = tile * MT, left = a.M - row0;
+    const rsrc_t rG = make_rsrc((const char *)(GMODE == PRO_GY ? a.G : a.Yl) + (size_t)row0 * N * 2, left * N * 2);
+    const rsrc_t rY = make_rsrc((const char *)a.Yl + (size_t)row0 * N * 2, left * N * 2);
+    const rsrc_t rX = make_rsrc((const char *)a.Yprev + (size_t)row0 * K * 2, left * K * 2);
+#pragma unroll
+    for (int i = 0; i < GT; ++i) {
+      const int t = tid + 512 * i;
+      const int rp = t / CGn, cg = t - rp * CGn;
+      const int off = t < 32 * CGn ? (2 * rp * N + cg * 8) * 2 : kOobOffset;
+      ry0[i] = bload128(rY, off, 0);
+      ry1[i] = bload128(rY, off, N * 2);
+      if constexpr (GMODE == PRO_GY) { rg0[i] = bload128(rG, off, 0); rg1[i] = bload128(rG, off, N * 2); }
+    }
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+      const int t = tid + 512 * i;
+      const int rp = t / CGk, cg = t - rp * CGk;
+      const int off = t < 32 * CGk ? (2 * rp * K + cg * 8) * 2 : kOobOffset;
+      rx0[i] = bload128(rX, off, 0);
+      rx1[i] = bload128(rX, off, K * 2);
+    }
+  };
+
+  long long tile = blockIdx.x;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long long row0 = tile * MT;
+    __syncthreads();                                 // previous tile: MFMA reads and the output store are done
+    // ---- commit: gy tile (row-major + transposed), activation tile (raw row-major + activated transposed)
+#pragma unroll
+    for (int i = 0; i < GT; ++i) {
+      const int t = tid + 512 * i;
+      if (t < 32 * CGn) {
+        const int rp = t / CGn, cg = t - rp * CGn, m = 2 * rp, n = cg * 8;
+        const bool ok0 = row0 + m < a.M, ok1 = row0 + m + 1 < a.M;
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float c1 = sC[n + e], c2 = sC[NB + n + e], c3 = sC[2 * NB + n + e];
+          float ga = 0.f, gb = 0.f;
+          if constexpr (GMODE == PRO_GY) {
+            ga = (e & 1) ? bf_hi(rg0[i][e >> 1]) : bf_lo(rg0[i][e >> 1]);
+            gb = (e & 1) ? bf_hi(rg1[i][e >> 1]) : bf_lo(rg1[i][e >> 1]);
+          }
+          const float ya = (e & 1) ? bf_hi(ry0[i][e >> 1]) : bf_lo(ry0[i][e >> 1]);
+          const float yb = (e & 1) ? bf_hi(ry1[i][e >> 1]) : bf_lo(ry1[i][e >> 1]);
+          v0[e] = ok0 ? fmaf(c1, ga, fmaf(c2, ya, c3)) : 0.f;
+          v1[e] = ok1 ? fmaf(c1, gb, fmaf(c2, yb, c3)) : 0.f;
+        }
+        u32x4 w0, w1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { w0[e] = bf_pack(v0[2 * e], v0[2 * e + 1]); w1[e] = bf_pack(v1[2 * e], v1[2 * e + 1]); }
+        *(u32x4 *)&sGY[m * NP + n] = w0;
+        *(u32x4 *)&sGY[(m + 1) * NP + n] = w1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *(unsigned *)&sGT[(n + e) * MP + swz<MT>(n + e, m)] = bf_pack(v0[e], v1[e]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+      const int t = tid + 512 * i;
+      if (t < 32 * CGk) {
+        const int rp = t / CGk, cg = t - rp * CGk, m = 2 * rp, k = cg * 8;
+        const bool ok0 = row0 + m < a.M, ok1 = row0 + m + 1 < a.M;
+        *(u32x4 *)&sO[m * KP + k] = rx0[i];
+        *(u32x4 *)&sO[(m + 1) * KP + k] = rx1[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sc = sF[2 * KB + k + e], sh = sF[3 * KB + k + e];
+          const float xa = (e & 1) ? bf_hi(rx0[i][e >> 1]) : bf_lo(rx0[i][e >> 1]);
+          const float xb = (e & 1) ? bf_hi(rx1[i][e >> 1]) : bf_lo(rx1[i][e >> 1]);
+          const float aa = ok0 ? fmaxf(fmaf(xa, sc, sh), 0.f) : 0.f;
+          const float ab = ok1 ? fmaxf(fmaf(xb, sc, sh), 0.f) : 0.f;
+          *(unsigned *)&sXT[(k + e) * MP + swz<MT>(k + e, m)] = bf_pack(aa, ab);
+        }
+      }
+    }
+    if constexpr (GMODE == PRO_POOLG) {
+      __syncthreads();
+      const long long q0 = row0 / a.ns;
+      const long long last = (row0 + MT - 1 < a.M - 1 ? row0 + MT - 1 : a.M - 1);
+      const int ngr = (int)(last / a.ns - q0) + 1;
+      for (int t = tid; t < ngr * NB; t += 512) {
+        const int gi = t / NB, n = t - gi * NB;
+        const size_t o = (size_t)(q0 + gi) * N + n;
+        const long long row = (q0 + gi) * a.ns + a.arg[o] - row0;
+        if (row >= 0 && row < MT && row0 + row < a.M) {
+          bf16 *c0 = &sGY[(int)row * NP + n];
+          const bf16 nv = (bf16)fmaf(sC[n], a.gP[o], (float)*c0);
+          *c0 = nv;
+          sGT[n * MP + swz<MT>(n, (int)row)] = nv;
+        }
+      }
+    }
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);   // next tile's loads fly behind this tile's MFMAs
+
+    // ---- dgrad tiles of this wave
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const int t = wave + 8 * d;
+      if (t < 2 * KTK) {                                       // wave-uniform
+        const int rt = t / KTK, ct = t - rt * KTK;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NB / 16; ++ks) {
+          const bf16x8 af = *(const bf16x8 *)&sGY[(rt * 32 + (lane & 31)) * NP + ks * 16 + (lane >> 5) * 8];
+          const bf16x8 bfr = *(const bf16x8 *)&sWt[(ct * 32 + (lane & 31)) * NP + ks * 16 + (lane >> 5) * 8];
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc, 0, 0, 0);
+        }
+        const int k = ct * 32 + (lane & 31);
+        const float mean = sF[k], rstd = sF[KB + k], sc = sF[2 * KB + k], sh = sF[3 * KB + k];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          bf16 *cell = &sO[m * KP + k];
+          const float yp = (float)*cell;
+          const float v = fmaf(yp, sc, sh) > 0.f ? acc[e] : 0.f;
+          const bf16 vb = (bf16)v;
+          const float vr = (float)vb;
+          s1[d] += vr;
+          s2[d] = fmaf(vr, (yp - mean) * rstd, s2[d]);
+          *cell = vb;
+        }
+      }
+    }
+    // ---- wgrad tiles of this wave
+#pragma unroll
+    for (int ms = 0; ms < MT / 16; ++ms) {
+      const int m = ms * 16 + (lane >> 5) * 8;
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        const int t = wave + 8 * i;
+        if (t < NTN * KTK) {
+          const int nt = t / KTK, kt = t - nt * KTK;
+          const int fn = nt * 32 + (lane & 31), fk = kt * 32 + (lane & 31);
+          const bf16x8 af = *(const bf16x8 *)&sGT[fn * MP + swz<MT>(fn, m)];
+          const bf16x8 bfr = *(const bf16x8 *)&sXT[fk * MP + swz<MT>(fk, m)];
+          accw[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, accw[i], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                           // masked tile complete in sO
+    {
+      const long long left = a.M - row0;
+      const rsrc_t rO = make_rsrc((char *)a.Gout + (size_t)row0 * K * 2, left * K * 2);
+      for (int t = tid; t < MT * CGk; t += 512) {
+        const int r = t / CGk, cg = t - r * CGk;
+        bstore128(*(const u32x4 *)&sO[r * KP + cg * 8], rO, (r * K + cg * 8) * 2, 0);
+      }
+    }
+  }
+
+  // ---- flush: column sums (LDS reduction over the waves that share a column tile) and dW
+  __syncthreads();
+  float *red = (float *)smem;                                  // [2][KB], zeroed
+  for (int i = tid; i < 2 * KB; i += 512) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    const int t = wave + 8 * d;
+    if (t < 2 * KTK) {
+      const int ct = t % KTK;
+      const float t1 = s1[d] + __shfl_xor(s1[d], 32), t2 = s2[d] + __shfl_xor(s2[d], 32);
+      if (lane < 32) { atomicAdd(&red[ct * 32 + lane], t1); atomicAdd(&red[KB + ct * 32 + lane], t2); }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * KB; i += 512) atomicAdd(a.sums + (size_t)(i / KB) * K + (i % KB), (double)red[i]);
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+    const int t = wave + 8 * i;
+    if (t < NTN * KTK) {
+      const int nt = t / KTK, kt = t - nt * KTK;
+      const int k = kt * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        atomicAdd(a.dW + (size_t)n * K + k, accw[i][e]);
+      }
+    }
+  }
+}
+
+template <int NTN, int KTK, int GMODE>
+int launch_bwd(const BwdBf16Args &a, hipStream_t s) {
+  constexpr int MT = 64, MP = MT + 8, NB = NTN * 32, KB = KTK * 32, NP = NB + 8, KP = KB + 8;
+  const size_t lds = (size_t)(KB * NP + MT * NP + NB * MP + KB * MP + MT * KP) * 2 + (size_t)(3 * NB + 4 * KB) * 4;
+  auto kfn = mlp_bwd_bf16_kernel<NTN, KTK, GMODE>;
+  static bool big_lds = false;
+  if (lds > 64 * 1024 && !big_lds) {
+    if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return pn2_check_launch();
+    big_lds = true;
+  }
+  const long long ntiles = (a.M + MT - 1) / MT;
+  long long grid = lds > 80 * 1024 ? 256 : 512;
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), lds, s, a);
+  return pn2_check_launch();
+}
+
+template <int GMODE>
+int dispatch_bwd(const BwdBf16Args &a, hipStream_t s) {
+  switch ((a.N / 32) * 8 + a.K / 32) {
+    case 1 * 8 + 1: return launch_bwd<1, 1, GMODE>(a, s);
+    case 1 * 8 + 2: return launch_bwd<1, 2, GMODE>(a, s);
+    case 2 * 8 + 1: return launch_bwd<2, 1, GMODE>(a, s);
+    case 2 * 8 + 2: return launch_bwd<2, 2, GMODE>(a, s);
+    case 2 * 8 + 4: return launch_bwd<2, 4, GMODE>(a, s);
+    case 4 * 8 + 2: return launch_bwd<4, 2, GMODE>(a, s);
+    case 4 * 8 + 4: return launch_bwd<4, 4, GMODE>(a, s);
+    case 3 * 8 + 3: return launch_bwd<3, 3, GMODE>(a, s);
+    case 4 * 8 + 3: return launch_bwd<4, 3, GMODE>(a, s);
+    case 3 * 8 + 4: return launch_bwd<3, 4, GMODE>(a, s);
+    default: return PN2_EINVAL;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- element-wise helpers
 // ReLU(BN(y)) for a stack that returns activations (FP modules): y bf16 -> out fp32
 __global__ __launch_bounds__(256) void bn_relu_apply_bf16_kernel(size_t total, int N, const bf16 *__restrict__ y,
@@ -790,6 +1075,29 @@ extern "C" int pn2_mlp_wgrad_bf16(long long M, int N, int K, int gmode, int amod
   }
   if (amode == PRO_BNRELU) return dispatch_wgrad<PRO_POOLG, PRO_BNRELU, false>(a, s);
   return x_f32 ? dispatch_wgrad<PRO_POOLG, PRO_NONE, true>(a, s) : dispatch_wgrad<PRO_POOLG, PRO_NONE, false>(a, s);
+}
+
+extern "C" int pn2_mlp_bwd_bf16_supported(int N, int K) {
+  if (N % 32 || K % 32 || N < 32 || K < 32 || N > 128 || K > 128) return 0;
+  const int c = (N / 32) * 8 + K / 32;
+  return c == 9 || c == 10 || c == 17 || c == 18 || c == 20 || c == 34 || c == 36 || c == 27 || c == 35 || c == 28;
+}
+
+extern "C" int pn2_mlp_bwd_bf16(long long M, int N, int K, int gmode, const void *G, const void *Yl, const float *consts,
+                                const int *arg, const float *gP, int ns, const float *Wt, const void *Yprev,
+                                const float *a_fin, void *Gout, double *sums, float *dW, void *stream) {
+  if (M < 0 || !pn2_mlp_bwd_bf16_supported(N, K)) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Yl || !consts || !Wt || !Yprev || !a_fin || !Gout || !sums || !dW) return PN2_ENULL;
+  if (gmode == PRO_GY && !G) return PN2_ENULL;
+  if (gmode == PRO_POOLG && (!arg || !gP || ns <= 0)) return PN2_ENULL;
+  if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
+  if (((uintptr_t)Yl & 15) || ((uintptr_t)G & 15) || ((uintptr_t)Yprev & 15) || ((uintptr_t)Gout & 15)) return PN2_EINVAL;
+  BwdBf16Args a;
+  a.G = (const bf16 *)G; a.Yl = (const bf16 *)Yl; a.consts = consts; a.arg = arg; a.gP = gP; a.Wt = Wt;
+  a.Yprev = (const bf16 *)Yprev; a.a_fin = a_fin; a.Gout = (bf16 *)Gout; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K;
+  a.ns = ns;
+  return gmode == PRO_GY ? dispatch_bwd<PRO_GY>(a, (hipStream_t)stream) : dispatch_bwd<PRO_POOLG>(a, (hipStream_t)stream);
 }
 
 extern "C" int pn2_bn_relu_apply_bf16(long long M, int N, const void *y, const float *fin, float *out, void *stream) {

@@ -80,6 +80,7 @@ _SIGNATURES = {
     "pn2_rows_gram": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp],
     "pn2_mlp_gemm_bf16": [ctypes.c_longlong] + [_c_int] * 8 + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
     "pn2_mlp_wgrad_bf16": [ctypes.c_longlong] + [_c_int] * 6 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
+    "pn2_mlp_bwd_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
     "pn2_bn_relu_apply_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_bwd_prep_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_rows_max_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -113,6 +114,8 @@ _lib.pn2_fps_set_plan_override.argtypes = [_c_int] * 5
 _lib.pn2_fps_set_plan_override.restype = _c_int
 _lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_supported.restype = _c_int
+_lib.pn2_mlp_bwd_bf16_supported.argtypes = [_c_int, _c_int]
+_lib.pn2_mlp_bwd_bf16_supported.restype = _c_int
 _lib.pn2_mlp_bwd_fused_fold_supported.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_fold_supported.restype = _c_int
 _lib.pn2_abi_version.restype = _c_int
@@ -126,6 +129,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_prep_num_chunks",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
+                                               "pn2_mlp_bwd_bf16_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
 HAS_ROWS = True
@@ -865,6 +869,27 @@ def mlp_wgrad_bf16(Yl, consts, X, gmode, amode, K, G=None, arg=None, gP=None, ns
           alg_bytes=2 * M * N * (2 if gmode == PRO_GY else 1) + M * X.size(1) * (4 if x_f32 else 2) + 4 * N * int(K),
           alg_flops=2 * M * N * int(K), tag=(f"M{M},N{N},K{K},g{int(gmode)},a{int(amode)}" if DETAIL_TAGS else None))
     return dW
+
+
+def mlp_bwd_bf16_supported(N, K):
+    return bool(_lib.pn2_mlp_bwd_bf16_supported(int(N), int(K)))
+
+
+def mlp_bwd_bf16(Yl, consts, Wt, Yprev, a_fin, gmode, G=None, arg=None, gP=None, ns=0, sums=None, dW=None):
+    """One-pass backward of a hidden layer on bf16 tensors -> (Gout (M,K) bf16, sums (2,K) f64, dW (N,K) f32).
+    Wt = the layer's weights transposed (K, N) fp32; `sums` / `dW`: pre-zeroed accumulators (optional)."""
+    M, N = Yl.shape
+    K = Yprev.size(1)
+    Gout = torch.empty(M, K, dtype=torch.bfloat16, device=Yl.device)
+    if sums is None:
+        sums = torch.zeros(2, K, dtype=torch.float64, device=Yl.device)
+    if dW is None:
+        dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
+    _call("pn2_mlp_bwd_bf16", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP), int(ns),
+          _ptr(Wt), _ptr(Yprev), _ptr(a_fin), _ptr(Gout), _ptr(sums), _ptr(dW),
+          alg_bytes=2 * (M * N * (2 if gmode == PRO_GY else 1) + 2 * M * K) + 4 * N * K, alg_flops=4 * M * N * K,
+          tag=(f"M{M},N{N},K{K},g{int(gmode)}" if DETAIL_TAGS else None))
+    return Gout, sums, dW
 
 
 def bn_relu_apply_bf16(y, fin):

@@ -354,6 +354,13 @@ class _FusedMLPBf16(Function):
             else:
                 consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            if l > 0 and FUSED_BACKWARD and e.mlp_bwd_bf16_supported(Ws[l].size(0), Ws[l].size(1)):
+                # hidden layer: dgrad + wgrad from one read of (g, y_l, y_{l-1})
+                G, sums, dW = e.mlp_bwd_bf16(ys[l], consts, Wt, ys[l - 1], fins[l - 1], gmode, G=G, arg=arg, gP=gPm, ns=ns,
+                                             sums=sums_in[l], dW=dWs[l])
+                grads[3 * l] = dW.view(ctx.shapes[l])
+                gmode, arg, gPm = e.PRO_GY, None, None
+                continue
             act = x if l == 0 else ys[l - 1]
             dW = e.mlp_wgrad_bf16(ys[l], consts, act, gmode, e.PRO_NONE if l == 0 else e.PRO_BNRELU, Ws[l].size(1),
                                   G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1], dW=dWs[l])

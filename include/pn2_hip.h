@@ -309,6 +309,13 @@ int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, int x_f32, in
 int pn2_mlp_wgrad_bf16(long long M, int N, int K, int gmode, int amode, int x_f32, int ldx, const void *G,
                        const void *Yl, const float *consts, const int *arg, const float *gP, int ns,
                        const void *X, const float *a_fin, float *dW, void *stream);
+/* One-pass backward of a hidden layer in bf16 (N, K multiples of 32 up to 128; pn2_mlp_bwd_bf16_supported): what
+ * pn2_mlp_gemm_bf16(pro 2|3, epi 2) + pn2_mlp_wgrad_bf16(amode 1) compute, from ONE read of g / y_l / y_{l-1}.
+ * Wt = the layer's weights transposed, fp32 [K][N] (as pn2_bn_bwd_consts emits them); dW and sums ACCUMULATE. */
+int pn2_mlp_bwd_bf16_supported(int N, int K);
+int pn2_mlp_bwd_bf16(long long M, int N, int K, int gmode, const void *G, const void *Yl, const float *consts,
+                     const int *arg, const float *gP, int ns, const float *Wt, const void *Yprev,
+                     const float *a_fin, void *Gout, double *sums, float *dW, void *stream);
 int pn2_bn_relu_apply_bf16(long long M, int N, const void *y, const float *fin, float *out, void *stream);
 int pn2_bn_relu_bwd_prep_bf16(long long M, int N, const void *y, const float *gout, const float *fin,
                               void *gpre, double *sums, void *stream);

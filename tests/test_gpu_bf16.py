@@ -166,6 +166,54 @@ def test_wgrad_bf16(M, N, K, kind, pooled):
     _close(dW, want, rel=2e-3, what="dW")            # fp32 accumulation of exact bf16 products: order-of-summation noise only
 
 
+@pytest.mark.parametrize("M,N,K,ns", [(4096, 128, 128, 16), (3000, 64, 64, 16), (2500, 128, 64, 32), (1999, 64, 128, 64),
+                                      (777, 32, 32, 16), (1200, 96, 96, 16), (640, 128, 96, 32), (64, 64, 32, 16)])
+@pytest.mark.parametrize("pooled", [False, True])
+def test_one_pass_backward_bf16_equals_the_two_kernels(M, N, K, ns, pooled):
+    """pn2_mlp_bwd_bf16 against the dgrad + wgrad pair it replaces (same operands): masked input gradient bit-identical
+    up to the double rounding of the sparse patch, column sums and weight gradient within summation-order noise; and
+    against the torch formulas."""
+    from pointnet2_ops import _ext as e
+    assert e.mlp_bwd_bf16_supported(N, K)
+    g = torch.Generator().manual_seed(M + N + K)
+    M = M // ns * ns if pooled else M
+    y = torch.randn(M, N, generator=g).to(BF).cuda()
+    yprev = torch.randn(M, K, generator=g).to(BF).cuda()
+    W = (torch.randn(N, K, generator=g) / N ** 0.5).cuda()
+    Wt = W.t().contiguous()
+    c = torch.stack([torch.randn(N, generator=g), torch.randn(N, generator=g) * 0.1, torch.randn(N, generator=g) * 0.05]).cuda()
+    fin = torch.stack([torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5, torch.rand(K, generator=g) + 0.5,
+                       torch.randn(K, generator=g) * 0.3]).cuda().contiguous()
+    if pooled:
+        R = M // ns
+        arg = torch.randint(0, ns, (R, N), generator=g, dtype=torch.int32).cuda()
+        gP = torch.randn(R, N, generator=g).cuda()
+        dense = torch.zeros(R, ns, N, device="cuda")
+        dense.scatter_(1, arg.long().unsqueeze(1), gP.unsqueeze(1))
+        gfull, G, gmode = dense.view(M, N), None, e.PRO_POOLG
+    else:
+        G = torch.randn(M, N, generator=g).to(BF).cuda()
+        gfull, arg, gP, gmode = G.float(), None, None, e.PRO_GY
+    Gout, sums, dW = e.mlp_bwd_bf16(y, c, Wt, yprev, fin, gmode, G=G, arg=arg, gP=gP, ns=ns if pooled else 0)
+    # the pair of kernels
+    st = torch.zeros(2, K, dtype=torch.float64, device="cuda")
+    G2 = e.mlp_gemm_bf16(G, Wt, pro=gmode, epi=e.EPI_MASK, X2=y, p=(c[0], c[1], c[2]), arg=arg, gP=gP, ns=ns if pooled else 0,
+                         stats=st, Yprev=yprev, e_fin=fin, M=M)
+    dW2 = e.mlp_wgrad_bf16(y, c, yprev, gmode, e.PRO_BNRELU, K, G=G, arg=arg, gP=gP, ns=ns if pooled else 0, a_fin=fin)
+    _close(Gout, G2.float(), rel=1.0 / 128, what="Gout vs dgrad kernel")
+    _close(dW, dW2, rel=2e-3, what="dW vs wgrad kernel")
+    torch.testing.assert_close(sums, st, rtol=2e-3, atol=2e-3 * M ** 0.5)
+    # torch formulas on the same rounded operands
+    gy = _r(c[0] * gfull + c[1] * y.float() + c[2])
+    act = _r(torch.relu(yprev.float() * fin[2] + fin[3]))
+    mask = (yprev.float() * fin[2] + fin[3]) > 0
+    _close(Gout, (gy @ _r(Wt).t()) * mask, what="Gout")
+    _close(dW, gy.t() @ act, rel=2e-3, what="dW")
+    o = Gout.float().double()
+    torch.testing.assert_close(sums[0], o.sum(0), rtol=1e-4, atol=1e-5 * M)
+    torch.testing.assert_close(sums[1], (o * ((yprev.float() - fin[0]) * fin[1]).double()).sum(0), rtol=1e-4, atol=1e-5 * M)
+
+
 def test_group_concat_rows_bf16_matches_fp32_kernel():
     from pointnet2_ops import _ext as e
     g = torch.Generator().manual_seed(3)
