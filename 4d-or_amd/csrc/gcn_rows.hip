@@ -44,6 +44,26 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(long long E, int H,
   }
 }
 
+// ---- q[e, :] += pa[ia[e], cola : cola+H] + pb[ib[e], colb : colb+H]  (first Linear of the triplet MLP applied to the
+//      NODES before the lift: W [x_i | e | x_j] = Wa x_i + Wb e + Wc x_j, network_TripletGCN.py:46-47)
+__global__ __launch_bounds__(kBlock) void gather2_add_rows_kernel(long long E, int H, int ldp, int cola, int colb,
+                                                                 const float *__restrict__ p,
+                                                                 const int64_t *__restrict__ ia,
+                                                                 const int64_t *__restrict__ ib, float *__restrict__ q) {
+  const int lane = pn2_lane();
+  for (long long r = wave_row(); r < E; r += (long long)gridDim.x * kWavesPerBlock) {
+    const float *a = p + (size_t)ia[r] * ldp + cola, *b = p + (size_t)ib[r] * ldp + colb;
+    float *d = q + (size_t)r * H;
+    for (int h = lane * 4; h < H; h += 256) {
+      const f4 va = *(const f4 *)(a + h), vb = *(const f4 *)(b + h);
+      f4 v = *(const f4 *)(d + h);
+      v.x = __fadd_rn(v.x, __fadd_rn(va.x, vb.x)); v.y = __fadd_rn(v.y, __fadd_rn(va.y, vb.y));
+      v.z = __fadd_rn(v.z, __fadd_rn(va.z, vb.z)); v.w = __fadd_rn(v.w, __fadd_rn(va.w, vb.w));
+      *(f4 *)(d + h) = v;
+    }
+  }
+}
+
 // ---- atomic scatter-add: out[index[r]] += src[r, col0 : col0+H] --------------------------------
 __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(long long E, int H, int lds, int col0,
                                                                  const float *__restrict__ src,
@@ -59,8 +79,10 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(long long E, i
 
 // ---- deterministic CSR segment sum -----------------------------------------------------------
 // out[n] = sum over p in [rowptr[n], rowptr[n+1]) of src[order[p], col0 : col0+H], added in that order.
+// col1 >= 0: the row contribution is src[e, col0 : col0+H] + src[e, col1 : col1+H] (the TripletGCN node message is the
+// sum of the first and the last block of nn1's output, network_TripletGCN.py:50), added as ONE value per element
 template <bool VEC>
-__global__ __launch_bounds__(kBlock) void segment_sum_rows_kernel(long long N, int H, int lds, int col0,
+__global__ __launch_bounds__(kBlock) void segment_sum_rows_kernel(long long N, int H, int lds, int col0, int col1,
                                                                  const float *__restrict__ src,
                                                                  const int64_t *__restrict__ order,
                                                                  const int64_t *__restrict__ rowptr,
@@ -79,7 +101,11 @@ __global__ __launch_bounds__(kBlock) void segment_sum_rows_kernel(long long N, i
         for (int i = 0; i < kMaxPasses; ++i) {
           const int h = lane * 4 + i * 256;
           if (h < H) {
-            const f4 v = *(const f4 *)(s + h);
+            f4 v = *(const f4 *)(s + h);
+            if (col1 >= 0) {
+              const f4 w = *(const f4 *)(s + (col1 - col0) + h);
+              v.x = __fadd_rn(v.x, w.x); v.y = __fadd_rn(v.y, w.y); v.z = __fadd_rn(v.z, w.z); v.w = __fadd_rn(v.w, w.w);
+            }
             acc[i].x = __fadd_rn(acc[i].x, v.x); acc[i].y = __fadd_rn(acc[i].y, v.y);
             acc[i].z = __fadd_rn(acc[i].z, v.z); acc[i].w = __fadd_rn(acc[i].w, v.w);
           }
@@ -93,7 +119,10 @@ __global__ __launch_bounds__(kBlock) void segment_sum_rows_kernel(long long N, i
     } else {
       for (int h = lane; h < H; h += 64) {
         float acc = 0.f;
-        for (int64_t p = p0; p < p1; ++p) acc = __fadd_rn(acc, src[(size_t)order[p] * lds + col0 + h]);
+        for (int64_t p = p0; p < p1; ++p) {
+          const float *r = src + (size_t)order[p] * lds;
+          acc = __fadd_rn(acc, col1 >= 0 ? __fadd_rn(r[col0 + h], r[col1 + h]) : r[col0 + h]);
+        }
         dst[h] = acc;
       }
     }
@@ -216,13 +245,34 @@ extern "C" int pn2_segment_sum_rows(int64_t E, int H, int64_t N, int lds, int co
   if (E < 0 || H < 0 || N < 0 || col0 < 0 || lds < col0 + H) return PN2_EINVAL;
   if (N == 0 || H == 0) return PN2_OK;
   if (!rowptr || !out || (E > 0 && (!src || !order))) return PN2_ENULL;
-  const bool vec = H % 4 == 0 && H <= 256 * kMaxPasses && lds % 4 == 0 && col0 % 4 == 0 && aligned16(src) && aligned16(out);
+  return pn2_segment_sum2_rows(E, H, N, lds, col0, -1, src, order, rowptr, out, stream);
+}
+
+extern "C" int pn2_segment_sum2_rows(int64_t E, int H, int64_t N, int lds, int col0, int col1, const float *src,
+                                     const int64_t *order, const int64_t *rowptr, float *out, void *stream) {
+  if (E < 0 || H < 0 || N < 0 || col0 < 0 || lds < col0 + H || (col1 >= 0 && lds < col1 + H)) return PN2_EINVAL;
+  if (N == 0 || H == 0) return PN2_OK;
+  if (!rowptr || !out || (E > 0 && (!src || !order))) return PN2_ENULL;
+  const bool vec = H % 4 == 0 && H <= 256 * kMaxPasses && lds % 4 == 0 && col0 % 4 == 0 && (col1 < 0 || col1 % 4 == 0) &&
+                   aligned16(src) && aligned16(out);
   if (vec)
     hipLaunchKernelGGL(segment_sum_rows_kernel<true>, dim3(row_grid(N)), dim3(kBlock), 0, (hipStream_t)stream,
-                       (long long)N, H, lds, col0, src, order, rowptr, out);
+                       (long long)N, H, lds, col0, col1, src, order, rowptr, out);
   else
     hipLaunchKernelGGL(segment_sum_rows_kernel<false>, dim3(row_grid(N)), dim3(kBlock), 0, (hipStream_t)stream,
-                       (long long)N, H, lds, col0, src, order, rowptr, out);
+                       (long long)N, H, lds, col0, col1, src, order, rowptr, out);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_gather2_add_rows(int64_t E, int H, int64_t N, int ldp, int cola, int colb, const float *p,
+                                    const int64_t *ia, const int64_t *ib, float *q, void *stream) {
+  if (E < 0 || H < 0 || N < 0 || cola < 0 || colb < 0 || ldp < cola + H || ldp < colb + H) return PN2_EINVAL;
+  if (H % 4 != 0 || ldp % 4 != 0 || cola % 4 != 0 || colb % 4 != 0) return PN2_EINVAL;
+  if (E == 0 || H == 0) return PN2_OK;
+  if (!p || !ia || !ib || !q) return PN2_ENULL;
+  if (!aligned16(p) || !aligned16(q)) return PN2_EINVAL;
+  hipLaunchKernelGGL(gather2_add_rows_kernel, dim3(row_grid(E)), dim3(kBlock), 0, (hipStream_t)stream, (long long)E, H, ldp,
+                     cola, colb, p, ia, ib, q);
   return pn2_check_launch();
 }
 

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "pn2_gather_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_scatter_add_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_segment_sum_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_gather2_add_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_segment_sum2_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_segment_bn_rows": [_c_i64, _c_int, _c_int, _c_int, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_f32, _c_int, _c_vp, _c_vp,
                             _c_vp, _c_vp],
     "pn2_segment_bn_rows_grad": [_c_i64, _c_int, _c_int, _c_int, _c_i64] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 4,
@@ -560,6 +562,27 @@ def segment_sum_rows(src, order, rowptr, dim_size, h=None, col0=0):
     out = torch.empty(int(dim_size), h, dtype=torch.float32, device=src.device)
     _call("pn2_segment_sum_rows", src, E, h, int(dim_size), lds, int(col0),
           _ptr(src), _ptr(order), _ptr(rowptr), _ptr(out), alg_bytes=4 * E * h + 16 * E + 4 * int(dim_size) * h)
+    return out
+
+
+def gather2_add_rows(q, p, ia, ib, cola, colb):
+    """q (E,H) += p[ia, cola:cola+H] + p[ib, colb:colb+H]  (in place; returns q)."""
+    _f32(q, "q"); _f32(p, "p"); _i64(ia, "ia"); _i64(ib, "ib")
+    _same_device((q, "q"), (p, "p"), (ia, "ia"), (ib, "ib"))
+    E, H = q.shape
+    _call("pn2_gather2_add_rows", q, E, H, p.size(0), p.size(1), int(cola), int(colb), _ptr(p), _ptr(ia), _ptr(ib), _ptr(q),
+          alg_bytes=16 * E + 16 * E * H)
+    return q
+
+
+def segment_sum2_rows(src, order, rowptr, dim_size, h, col0, col1):
+    """out (dim_size,h) = CSR segment sum of src[:, col0:col0+h] + src[:, col1:col1+h] (deterministic, edge order)."""
+    _f32(src, "src"); _i64(order, "order"); _i64(rowptr, "rowptr")
+    _same_device((src, "src"), (order, "order"), (rowptr, "rowptr"))
+    E, lds = src.shape
+    out = torch.empty(int(dim_size), int(h), dtype=torch.float32, device=src.device)
+    _call("pn2_segment_sum2_rows", src, E, int(h), int(dim_size), lds, int(col0), int(col1), _ptr(src), _ptr(order),
+          _ptr(rowptr), _ptr(out), alg_bytes=8 * E * int(h) + 16 * E + 4 * int(dim_size) * int(h))
     return out
 
 

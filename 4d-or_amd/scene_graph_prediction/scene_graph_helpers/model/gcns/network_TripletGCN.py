@@ -17,9 +17,14 @@ Their semantics on this call path are restated here without either package:
 * ``aggregate`` (:54-58): sum of node messages over ``edge_index[1]`` into ``N`` rows;
 * ``update``: identity; then ``nn2`` on the aggregated rows (:42-43).
 
-Gather and scatter run in libpn2_hip.so (``pn2_gather_rows`` writes straight into
-the concatenation buffer; ``pn2_segment_sum_rows`` is a deterministic CSR sum that
-adds in edge order, i.e. bit-identical to a sequential CPU ``scatter_add_``).
+Gather and scatter run in libpn2_hip.so.  The first Linear of ``nn1`` is applied BEFORE the lift:
+``W [x_i | e | x_j] = Wa x_i + Wb e + Wc x_j``, so the node part is one (N, dn) x (dn, 2H) GEMM instead of an
+(E, 2 dn) one (E/N ~ 8 times fewer FLOPs) and ``pn2_gather2_add_rows`` lifts the PRODUCTS onto the edges — the
+(E, 2 dn + de) concatenation is never built.  That form is taken from ``LIFT_MIN_EDGES`` edges on (below, the step is launch-bound and the
+literal concat form has fewer launches).  In the lifted form the split + aggregate (:50-58) is one ``pn2_segment_sum2_rows`` (first +
+last block of nn1's output summed while aggregating); the CSR sums add in edge order, i.e. like a sequential CPU
+``scatter_add_``.  The literal concat path (``pn2_gather_rows`` into the concatenation buffer) also serves dimensions
+that are not multiples of 4.
 BatchNorm1d layers use batch statistics in train AND eval
 (``track_running_stats=False``, :20), like the reference.
 
@@ -53,6 +58,13 @@ def build_mlp(dim_list, activation="relu", do_bn=False, dropout=0, on_last=False
         if dropout > 0:
             layers.append(torch.nn.Dropout(p=dropout))
     return torch.nn.Sequential(*layers)
+
+
+# Edge count from which nn1's first Linear is applied to the nodes and the products lifted (see the module docstring).
+# Measured on MI355X, 2 layers 256/256/512, forward+backward (tools/gcn_time.py): the step is launch-bound (~2 ms) up to
+# 64 scans (4 608 edges), where the lifted form's extra small launches cost +0.3 ms; from 256 scans (18 432 edges) it is
+# 11-17 % faster (4.35 -> 3.87 ms; 1 024 scans 14.0 -> 11.9 ms; 4 096 scans 50.6 -> 42.1 ms).
+LIFT_MIN_EDGES = 8192
 
 
 class EdgeCSR:
@@ -176,6 +188,57 @@ class _TripletConcat(Function):
         return gx, g[:, dn:dn + de], None
 
 
+class _TripletLinear(Function):
+    """``Linear(cat[x[dst], e, x[src]])`` (nn1[0], :46-47) with the node part of the product computed per NODE."""
+
+    @staticmethod
+    def forward(ctx, x, e, weight, bias, csr):
+        dn, de, H = x.size(1), e.size(1), weight.size(0)
+        wn = torch.cat([weight[:, :dn], weight[:, dn + de:]], 0)          # (2H, dn): [Wa ; Wc]
+        p = x @ wn.t()                                                     # (N, 2H) = [x Wa^T | x Wc^T]
+        q = torch.addmm(bias, e, weight[:, dn:dn + de].t())                # (E, H)
+        _ext.gather2_add_rows(q, p, csr.dst, csr.src, 0, H)
+        ctx.save_for_backward(x, e, weight)
+        ctx.csr = csr
+        return q
+
+    @staticmethod
+    def backward(ctx, g):
+        x, e, weight = ctx.saved_tensors
+        csr = ctx.csr
+        dn, de, H = x.size(1), e.size(1), weight.size(0)
+        g = g.contiguous()
+        gp = torch.cat([_ext.segment_sum_rows(g, csr.order, csr.rowptr, csr.num_nodes),
+                        _ext.segment_sum_rows(g, csr.order_src, csr.rowptr_src, csr.num_nodes)], 1)   # (N, 2H)
+        wn = torch.cat([weight[:, :dn], weight[:, dn + de:]], 0)
+        gx = gp @ wn
+        ge = g @ weight[:, dn:dn + de]
+        gwn = gp.t() @ x                                                   # (2H, dn)
+        gw = torch.cat([gwn[:H], g.t() @ e, gwn[H:]], 1)
+        return gx, ge, gw, g.sum(0), None
+
+
+class _SplitAggregate(Function):
+    """h (E, 2 dh + de) -> (sum over edge_index[1] of h[:, :dh] + h[:, dh+de:], h[:, dh:dh+de])  (:50-58)."""
+
+    @staticmethod
+    def forward(ctx, h, csr, dh, de):
+        h = h.contiguous()
+        ctx.csr, ctx.dh, ctx.de = csr, dh, de
+        node = _ext.segment_sum2_rows(h, csr.order, csr.rowptr, csr.num_nodes, dh, 0, dh + de)
+        return node, h[:, dh:dh + de].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_node, g_edge):
+        csr, dh, de = ctx.csr, ctx.dh, ctx.de
+        gh = torch.empty(csr.dst.numel(), 2 * dh + de, dtype=torch.float32, device=g_node.device)
+        g_node = g_node.contiguous()
+        _ext.gather_rows(g_node, csr.dst, out=gh, col0=0, check=False)
+        gh[:, dh:dh + de] = g_edge
+        _ext.gather_rows(g_node, csr.dst, out=gh, col0=dh + de, check=False)
+        return gh, None, None, None
+
+
 class _AggregateAdd(Function):
     """scatter(msg, index=edge_index[1], dim=-2, dim_size=N, reduce='add')."""
 
@@ -207,7 +270,18 @@ class TripletGCN(torch.nn.Module):
             return mlp_per_scene(self.nn2, gcn_x, scenes.node_ptr), gcn_e
         return self.nn2(gcn_x), gcn_e
 
+    def _lift_after_linear(self, n_edges):
+        first = self.nn1[0]
+        return (n_edges >= LIFT_MIN_EDGES and self.dim_node % 4 == 0 and self.dim_edge % 4 == 0 and self.dim_hidden % 4 == 0
+                and isinstance(first, torch.nn.Linear) and first.bias is not None)
+
     def propagate(self, csr, x, edge_feature, scenes=None):
+        if self._lift_after_linear(edge_feature.size(0)):
+            # Linear on the nodes, lift the products, rest of nn1 on the edges, split + aggregate in one CSR sum
+            h = _TripletLinear.apply(x.contiguous(), edge_feature.contiguous(), self.nn1[0].weight, self.nn1[0].bias, csr)
+            rest = self.nn1[1:]
+            h = mlp_per_scene(rest, h, scenes.edge_ptr) if scenes is not None else rest(h)
+            return _SplitAggregate.apply(h, csr, self.dim_hidden, self.dim_edge)
         node_msg, new_e = self.message(csr, x, edge_feature, scenes)
         return self.aggregate(node_msg, csr), new_e
 

@@ -383,6 +383,19 @@ int pn2_segment_sum_rows(int64_t E, int H, int64_t N, int lds, int col0,
                          const float *src, const int64_t *order,
                          const int64_t *rowptr, float *out, void *stream);
 
+/* Triplet message without the (E, 2*dn+de) concatenation (network_TripletGCN.py:45-52):
+ *   pn2_gather2_add_rows : q (E,H) += p[ia[e], cola:cola+H] + p[ib[e], colb:colb+H].  nn1's first Linear is applied to the
+ *     NODES once (p = x [Wa | Wc]^T, (N, 2H)) and to the edge features (q = e Wb^T + b) and only the products are lifted:
+ *     W [x_i | e | x_j] = Wa x_i + Wb e + Wc x_j — E/N times fewer FLOPs in the node part, no concat buffer.
+ *   pn2_segment_sum2_rows: pn2_segment_sum_rows over src[e, col0:col0+H] + src[e, col1:col1+H] (node message = first +
+ *     last block of nn1's output, :50) without materialising the sum; col1 < 0 = plain segment sum.
+ * H and the column offsets must be multiples of 4 for pn2_gather2_add_rows (16-byte lanes).
+ */
+int pn2_gather2_add_rows(int64_t E, int H, int64_t N, int ldp, int cola, int colb, const float *p,
+                         const int64_t *ia, const int64_t *ib, float *q, void *stream);
+int pn2_segment_sum2_rows(int64_t E, int H, int64_t N, int lds, int col0, int col1, const float *src,
+                          const int64_t *order, const int64_t *rowptr, float *out, void *stream);
+
 /* Per-segment BatchNorm1d (+ optional ReLU) for block-diagonally batched scans.  The reference trains and evaluates
  * one scan per step, and its GCN BatchNorm1d layers are built with track_running_stats=False
  * (network_TripletGCN.py:20), i.e. they ALWAYS normalise with the statistics of the current scan's rows.  When S scans

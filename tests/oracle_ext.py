@@ -153,3 +153,14 @@ class OracleRowsExt(OracleExt):
             dg += ga.grad
             db += be.grad
         return gx, dg, db
+
+    @staticmethod
+    def gather2_add_rows(q, p, ia, ib, cola, colb):
+        H = q.size(1)
+        q += p[ia, cola:cola + H] + p[ib, colb:colb + H]
+        return q
+
+    @staticmethod
+    def segment_sum2_rows(src, order, rowptr, dim_size, h, col0, col1):
+        s = (src[:, col0:col0 + h] + src[:, col1:col1 + h]).contiguous()
+        return OracleRowsExt.segment_sum_rows(s, order, rowptr, dim_size)

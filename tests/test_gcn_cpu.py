@@ -76,10 +76,21 @@ def test_build_mlp_layout():
     assert [type(l).__name__ for l in build_mlp([4, 8, 6], do_bn=True)] == ["Linear", "BatchNorm1d", "ReLU", "Linear"]
 
 
-def test_batched_scans_equal_single_scan_steps(oracle_backend):
+@pytest.mark.parametrize("lifted", [False, True])
+def test_batched_scans_equal_single_scan_steps(oracle_backend, monkeypatch, lifted):
     """S scans collated block-diagonally (per-scan GCN BatchNorm statistics, per-scan loss average) give the S
     single-scan results: forward, the mean of the per-scan losses, and the gradients of their mean (eval-mode encoders:
-    SA BatchNorm on running statistics, as at inference; heads without dropout)."""
+    SA BatchNorm on running statistics, as at inference; heads without dropout).
+
+    lifted=False runs the literal concat form of the triplet message, whose CPU arithmetic is row-for-row the same in
+    a 5-row and a 15-row call, so the comparison is tight.  lifted=True (first Linear applied to the nodes, products
+    lifted) has one GEMM over the N node rows whose blocking depends on N; at random init the encoders emit nearly
+    identical rows (spread 1e-3), the per-scan BatchNorm1d amplifies the round-off ~100x and the parameter gradients are
+    what is left after |dL/dx| ~ 20 cancels — both forms are equally far from an fp64 run there (see
+    test_lifted_first_linear_equals_concat for the well-conditioned, tight comparison), so the gradient tolerance of
+    this case is tied to |dL/dx| at the GCN inputs."""
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as g
+    monkeypatch.setattr(g, "LIFT_MIN_EDGES", 0 if lifted else 1 << 60)
     from scene_graph_prediction.main import RELATION_NAMES, config_loader
     from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan
     from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
@@ -88,10 +99,21 @@ def test_batched_scans_equal_single_scan_steps(oracle_backend):
     scans = [synthetic_scan(n, 300, 400, seed=i, scan_id=f"s{i}", ) for i, n in enumerate([5, 4, 6])]
     batch = collate_scans(scans)
     assert batch["edge_indices"].max() == 14 and batch["scenes"].num_scenes == 3
+    seen = {}
+    gcn_forward = m.gcn.forward
+
+    def watched(x, e, *a, **k):
+        x.retain_grad(); e.retain_grad()
+        seen["x"], seen["e"] = x, e
+        return gcn_forward(x, e, *a, **k)
+
+    m.gcn.forward = watched
     obj, rel = m(batch)
     loss = m.loss(obj, rel, batch)
     loss.backward()
     got = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    upstream = max(float(seen["x"].grad.abs().max()), float(seen["e"].grad.abs().max()), 1.0)
+    m.gcn.forward = gcn_forward
     m.zero_grad()
     outs, total = [], 0.0
     for s in scans:
@@ -105,7 +127,8 @@ def test_batched_scans_equal_single_scan_steps(oracle_backend):
     torch.testing.assert_close(rel.detach(), torch.cat([r for _, r in outs]), atol=1e-4, rtol=1e-4)
     for n, p in m.named_parameters():
         if p.grad is not None:
-            assert float((got[n] - p.grad).abs().max()) <= 1e-4 * max(1.0, float(p.grad.abs().max())), n
+            tol = 1e-3 * upstream if lifted else 1e-4 * max(1.0, float(p.grad.abs().max()))
+            assert float((got[n] - p.grad).abs().max()) <= tol, n
     # triples: one (scan_id, triples) per scan, with scan-local object ids
     per_scan = [m.predict_step(s) for s in scans]
     assert m.predict_step(batch) == per_scan
@@ -164,3 +187,41 @@ def test_with_images_config_late_fusion(oracle_backend):
     ob, rb = m(collate_scans(scans))
     singles = [m(s) for s in scans]
     torch.testing.assert_close(rb, torch.cat([r for _, r in singles]), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n_nodes", [4, 6, 9])   # (BatchNorm1d over 2-3 rows is ill-conditioned in either form)
+def test_lifted_first_linear_equals_concat(oracle_backend, monkeypatch, n_nodes):
+    """W [x_i | e | x_j] = Wa x_i + Wb e + Wc x_j: the lifted form of nn1[0] (+ split/aggregate in one CSR sum) against
+    the literal concat form (network_TripletGCN.py:45-58) and against an fp64 run of the literal form."""
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as g
+
+    def literal64(net, x, e, ei):
+        for i, c in enumerate(net.gconvs):
+            h = c.nn1(torch.cat([x[ei[1]], e, x[ei[0]]], 1))
+            dh, de = c.dim_hidden, c.dim_edge
+            agg = torch.zeros(x.size(0), dh, dtype=x.dtype).index_add_(0, ei[1], h[:, :dh] + h[:, dh + de:])
+            x, e = c.nn2(agg), h[:, dh:dh + de]
+            if i < net.num_layers - 1:
+                x, e = torch.relu(x), torch.relu(e)
+        return x, e
+
+    def run(mode):
+        torch.manual_seed(3)
+        net = g.TripletGCNModel(2, dim_node=64, dim_edge=32, dim_hidden=128)
+        x = torch.randn(n_nodes, 64)
+        ei = torch.tensor([(i, j) for i in range(n_nodes) for j in range(n_nodes) if i != j]).t().contiguous()
+        e = torch.randn(ei.size(1), 32)
+        w1, w2 = torch.randn(n_nodes, 64), torch.randn(ei.size(1), 32)
+        if mode == "f64":
+            net, x, e, w1, w2 = net.double(), x.double(), e.double(), w1.double(), w2.double()
+        x.requires_grad_(True); e.requires_grad_(True)
+        monkeypatch.setattr(g, "LIFT_MIN_EDGES", 0 if mode == "lifted" else 1 << 60)
+        a, b = literal64(net, x, e, ei) if mode == "f64" else net(x, e, ei)
+        ((a * w1).sum() + (b * w2).sum()).backward()
+        return [a.detach(), b.detach(), x.grad, e.grad] + [p.grad for p in net.parameters()]
+
+    ref, concat, lifted = run("f64"), run("concat"), run("lifted")
+    for r, c, l in zip(ref, concat, lifted):
+        scale = max(1.0, float(r.abs().max()))
+        err_c, err_l = float((c.double() - r).abs().max()) / scale, float((l.double() - r).abs().max()) / scale
+        assert err_l <= max(2e-5, 4 * err_c), (err_l, err_c)

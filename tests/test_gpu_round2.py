@@ -204,11 +204,36 @@ def test_stress_shape_full_stack_64x200k():
         assert torch.equal(ep["sa1_inds"][b:b + 1, :96].cpu(), want)
 
 
-def test_three_layer_gcn_on_64_block_diagonal_scenes_matches_oracle():
+@pytest.mark.parametrize("E,N,H,ldp,cola,colb", [(72, 9, 512, 1024, 0, 512), (4608, 576, 512, 1024, 0, 512), (7, 3, 4, 16, 8, 4),
+                                                 (300, 40, 1280, 2560, 1280, 0)])
+def test_lifted_product_gather_and_two_window_segment_sum_are_bit_exact(E, N, H, ldp, cola, colb):
+    from pointnet2_ops import _ext
+    g = torch.Generator().manual_seed(E + H)
+    p = torch.randn(N, ldp, generator=g)
+    q = torch.randn(E, H, generator=g)
+    ia, ib = torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)
+    want = oracle_ext.OracleRowsExt.gather2_add_rows(q.clone(), p, ia, ib, cola, colb)
+    got = _ext.gather2_add_rows(q.cuda(), p.cuda(), ia.cuda(), ib.cuda(), cola, colb)
+    assert torch.equal(got.cpu(), want)
+    src = torch.randn(E, ldp + 8, generator=g)
+    order = torch.sort(ia, stable=True).indices
+    rowptr = torch.zeros(N + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(ia, minlength=N), 0)
+    want = oracle_ext.OracleRowsExt.segment_sum2_rows(src, order, rowptr, N, H, cola, colb + 8)
+    got = _ext.segment_sum2_rows(src.cuda(), order.cuda(), rowptr.cuda(), N, H, cola, colb + 8)
+    assert torch.equal(got.cpu(), want)
+    with pytest.raises(RuntimeError):
+        _ext.gather2_add_rows(q.cuda(), p.cuda(), ia.cuda(), ib.cuda(), cola, ldp)      # window past the row
+
+
+@pytest.mark.parametrize("lifted", [True, False])
+def test_three_layer_gcn_on_64_block_diagonal_scenes_matches_oracle(lifted, monkeypatch):
     """configs[4]'s "3-hop GNN" over 64 scenes batched block-diagonally (per-scene BatchNorm statistics,
-    network_TripletGCN.py:20): HIP kernels vs the oracle backend, forward and gradients."""
+    network_TripletGCN.py:20): HIP kernels vs the oracle backend, forward and gradients, with the first Linear of the
+    triplet MLP lifted after the product (default) and in the literal concat form."""
     from pointnet2_ops import _ext
     from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    monkeypatch.setattr(gcn, "LIFT_MIN_EDGES", 0 if lifted else 1 << 60)
     torch.manual_seed(5)
     model = gcn.TripletGCNModel(num_layers=3, dim_node=256, dim_edge=256, dim_hidden=512).train()
     g = torch.Generator().manual_seed(6)
