@@ -19,9 +19,24 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// 16 bytes at a dword-aligned address (rows of 3 + C floats): hipcc emits global_load/store_dwordx4 for it
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) F4Dw { f4v v; };
+
 inline unsigned grid1d(size_t work, int block = kBlock) {
   size_t g = (work + block - 1) / block;
   return (unsigned)(g ? g : 1);
+}
+
+// XCD-aware workgroup order for the row-slab kernels: consecutive workgroup ids are dispatched round-robin over the 8 XCDs
+// (each with its own 4 MB L2), so with slabs handed out in id order every cloud's rows are spread over all eight L2s and
+// every L2 sees every cloud's feature table (33 MB at SA2: each row is fetched ~16 times from the memory side).  Here
+// XCD x takes the x-th eighth of the slabs: the workgroups resident on one XCD work on 2-3 neighbouring clouds, whose
+// tables (1 MB each) stay in that L2.  The launchers pad the grid to a multiple of 8.
+__device__ __forceinline__ unsigned xcd_slab_wave() {
+  const unsigned per = gridDim.x >> 3;
+  const unsigned wg = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  return __builtin_amdgcn_readfirstlane(wg * (kBlock / 64) + (threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------- gather ----
@@ -135,6 +150,107 @@ __global__ __launch_bounds__(kBlock) void group_concat_rows_wide_kernel(
         s = 0; ++bj;
         if (++j == (unsigned)m) { j = 0; ++b; }
       }
+    }
+  }
+}
+
+// Wide rows whose feature width is a multiple of 4: the same walk, EIGHT ROWS IN FLIGHT.  The first version above moves
+// one row at a time (index -> address -> dword loads -> dword stores), so a wave has one row's worth of loads outstanding
+// and the kernel ran at 0.2-0.3 of the HBM rate with 1.7x the algorithmic traffic (dword stores into 524-byte rows).  Here
+// a batch of eight rows issues ALL its 16-byte feature loads (R rows per wave instruction: 64 / R lanes per row, R = 4, 2, 1
+// for C <= 64, 128, 256) and the six xyz loads of each row's first lane before the first store; the stores are 16-byte
+// (dword-aligned: the row pitch 3 + C is odd) plus three dwords per row for the relative xyz.
+template <int R>
+__global__ __launch_bounds__(kBlock) void group_concat_rows_wide4_kernel(
+    int N, int m, int ns, int C, int normalize, float radius,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats, const int *__restrict__ idx, float *__restrict__ out,
+    unsigned rows, unsigned rows_per_wave) {
+  constexpr int LPR = 64 / R;                    // lanes per row
+  constexpr int P = 8 / R;                       // wave instructions per batch of 8 rows
+  constexpr int Cx = 3;
+  const int lane = pn2_lane();
+  const unsigned wave = xcd_slab_wave();
+  const int W = Cx + C;
+  const int sub = lane / LPR, l = lane % LPR;
+  const bool fl = 4 * l < C;                     // this lane carries features
+  unsigned r0 = wave * rows_per_wave;
+  if (r0 >= rows) return;
+  unsigned r1 = r0 + rows_per_wave;
+  if (r1 > rows) r1 = rows;
+  unsigned bj = r0 / (unsigned)ns;               // b*m + j of row `base` (scalar)
+  unsigned s = r0 - bj * (unsigned)ns;
+  unsigned b = bj / (unsigned)m;
+  unsigned j = bj - b * (unsigned)m;
+  for (unsigned base = r0; base < r1; base += 8) {
+    const unsigned nrow = (r1 - base) < 8u ? (r1 - base) : 8u;
+    const int myi = lane < (int)nrow ? idx[base + lane] : 0;
+    // A batch that lies inside one neighbourhood and repeats one index (ball-query padding = the first hit again,
+    // EXT/src/ball_query_gpu.cu:34-38: 60 of 64 slots on the scene-graph encoders) is eight copies of ONE output row:
+    // it is gathered once and stored eight times.
+    const bool same = nrow == 8u && s + 8u <= (unsigned)ns &&
+                      __all(lane >= 8 || myi == __builtin_amdgcn_readlane(myi, 0));
+    if (same) {                                   // wave-uniform
+      const size_t src = (size_t)b * N + (size_t)__builtin_amdgcn_readlane(myi, 0);
+      f4v v0 = f4v{0.f, 0.f, 0.f, 0.f};
+      float rel0[3] = {0.f, 0.f, 0.f};
+      if (fl) v0 = *(const f4v *)(feats + src * C + 4 * l);
+      if (l == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          rel0[d] = xyz[src * 3 + d] - new_xyz[(size_t)bj * 3 + d];
+          if (normalize) rel0[d] = __fdiv_rn(rel0[d], radius);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        float *o = out + (size_t)(base + p * R + sub) * W;
+        if (fl) ((F4Dw *)(o + Cx + 4 * l))->v = v0;
+        if (l == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) o[d] = rel0[d];
+        }
+      }
+      s += 8u;
+      if (s >= (unsigned)ns) {
+        s -= (unsigned)ns; ++bj;
+        if (++j == (unsigned)m) { j = 0; ++b; }
+      }
+      continue;
+    }
+    float4 v[P];
+    float rel[P][3];
+    unsigned q_of[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const unsigned q = p * R + sub;            // row of the batch this lane works on (ns >= 8: at most one wrap)
+      q_of[p] = q;
+      const unsigned wrap = (s + q) >= (unsigned)ns ? 1u : 0u;
+      const unsigned bjq = bj + wrap;
+      const unsigned bq = b + ((wrap && j + 1 == (unsigned)m) ? 1u : 0u);
+      const int ii = __shfl(myi, (int)q);
+      const size_t src = (size_t)bq * N + (size_t)ii;
+      v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < nrow && fl) v[p] = *(const float4 *)(feats + src * C + 4 * l);
+      if (q < nrow && l == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) rel[p][d] = xyz[src * 3 + d] - new_xyz[(size_t)bjq * 3 + d];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const unsigned q = q_of[p];
+      float *o = out + (size_t)(base + q) * W;
+      if (q < nrow && fl) ((F4Dw *)(o + Cx + 4 * l))->v = f4v{v[p].x, v[p].y, v[p].z, v[p].w};
+      if (q < nrow && l == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[d] = normalize ? __fdiv_rn(rel[p][d], radius) : rel[p][d];
+      }
+    }
+    s += nrow;
+    if (s >= (unsigned)ns) {
+      s -= (unsigned)ns; ++bj;
+      if (++j == (unsigned)m) { j = 0; ++b; }
     }
   }
 }
@@ -397,6 +513,140 @@ __global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_kernel(
   }
 }
 
+// bf16 rows, 16-byte stores: lane g of a row produces the output columns 8g .. 8g+7 = features 8g-3 .. 8g+4 with two
+// dword-aligned 16-byte loads (lane 0: x y z f0 | f1..f4) and writes ONE aligned 16-byte group; R rows per wave
+// instruction (64 / R lanes per row, pitch <= 8 * 64 / R), eight rows in flight.  (The dword-store version above moves
+// 2 x 4 bytes per lane and row and ran at 1.1-1.9 TB/s, slower than the fp32 kernel moving twice the bytes.)
+template <int R>
+__global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_wide8_kernel(
+    int N, int m, int ns, int C, int normalize, float radius, int ldo,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats, const int *__restrict__ idx, unsigned *__restrict__ out,
+    unsigned rows, unsigned rows_per_wave) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  constexpr int LPR = 64 / R;
+  constexpr int P = 8 / R;
+  const int lane = pn2_lane();
+  const unsigned wave = xcd_slab_wave();
+  const int sub = lane / LPR, g = lane % LPR;
+  const bool active = g < ldo / 8;
+  const int c0 = 8 * g - 3;                        // feature column of output column 8g
+  const bool whole = g > 0 && c0 + 8 <= C;         // both 16-byte loads lie inside the feature row
+  // one output row group (8 columns of this lane) gathered and packed
+  auto load_pack = [&](size_t src, unsigned bjq) {
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = 0.f;
+    const float *fr = feats + src * C;
+    if (active) {
+      if (whole) {
+        const f4v a = ((const F4Dw *)(fr + c0))->v, c = ((const F4Dw *)(fr + c0 + 4))->v;
+        t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; t[4] = c.x; t[5] = c.y; t[6] = c.z; t[7] = c.w;
+      } else if (g == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          t[d] = xyz[src * 3 + d] - new_xyz[(size_t)bjq * 3 + d];
+          if (normalize) t[d] = __fdiv_rn(t[d], radius);
+        }
+        t[3] = fr[0];
+        const f4v c = ((const F4Dw *)(fr + 1))->v;
+        t[4] = c.x; t[5] = c.y; t[6] = c.z; t[7] = c.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (c0 + i < C) t[i] = fr[c0 + i];
+      }
+    }
+    u4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)t[2 * i]);
+      const unsigned hi = __builtin_bit_cast(unsigned short, (__bf16)t[2 * i + 1]);
+      w[i] = lo | (hi << 16);
+    }
+    return w;
+  };
+  unsigned r0 = wave * rows_per_wave;
+  if (r0 >= rows) return;
+  unsigned r1 = r0 + rows_per_wave;
+  if (r1 > rows) r1 = rows;
+  unsigned bj = r0 / (unsigned)ns;
+  unsigned s = r0 - bj * (unsigned)ns;
+  unsigned b = bj / (unsigned)m;
+  unsigned j = bj - b * (unsigned)m;
+  for (unsigned base = r0; base < r1; base += 8) {
+    const unsigned nrow = (r1 - base) < 8u ? (r1 - base) : 8u;
+    const int myi = lane < (int)nrow ? idx[base + lane] : 0;
+    // one neighbourhood, one repeated index (ball-query padding): eight copies of one row — gather once, store eight times
+    const bool same = nrow == 8u && s + 8u <= (unsigned)ns &&
+                      __all(lane >= 8 || myi == __builtin_amdgcn_readlane(myi, 0));
+    if (same) {                                   // wave-uniform
+      const size_t src = (size_t)b * N + (size_t)__builtin_amdgcn_readlane(myi, 0);
+      u4 w = load_pack(src, bj);
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (active) *(u4 *)(out + (size_t)(base + p * R + sub) * (ldo / 2) + 4 * g) = w;
+      s += 8u;
+      if (s >= (unsigned)ns) {
+        s -= (unsigned)ns; ++bj;
+        if (++j == (unsigned)m) { j = 0; ++b; }
+      }
+      continue;
+    }
+    float f[P][8];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const unsigned q = p * R + sub;
+      const unsigned wrap = (s + q) >= (unsigned)ns ? 1u : 0u;
+      const unsigned bjq = bj + wrap;
+      const unsigned bq = b + ((wrap && j + 1 == (unsigned)m) ? 1u : 0u);
+      const int ii = __shfl(myi, (int)q);
+      const size_t src = (size_t)bq * N + (size_t)ii;
+      const float *fr = feats + src * C;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[p][i] = 0.f;
+      if (q < nrow && active) {
+        if (whole) {
+          const f4v a = ((const F4Dw *)(fr + c0))->v, c = ((const F4Dw *)(fr + c0 + 4))->v;
+          f[p][0] = a.x; f[p][1] = a.y; f[p][2] = a.z; f[p][3] = a.w;
+          f[p][4] = c.x; f[p][5] = c.y; f[p][6] = c.z; f[p][7] = c.w;
+        } else if (g == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) f[p][d] = xyz[src * 3 + d] - new_xyz[(size_t)bjq * 3 + d];
+          f[p][3] = fr[0];
+          const f4v c = ((const F4Dw *)(fr + 1))->v;      // C >= 5 (the launcher only takes pitches > 16)
+          f[p][4] = c.x; f[p][5] = c.y; f[p][6] = c.z; f[p][7] = c.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (c0 + i < C) f[p][i] = fr[c0 + i];
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const unsigned q = p * R + sub;
+      if (normalize && g == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) f[p][d] = __fdiv_rn(f[p][d], radius);
+      }
+      u4 w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)f[p][2 * i]);
+        const unsigned hi = __builtin_bit_cast(unsigned short, (__bf16)f[p][2 * i + 1]);
+        w[i] = lo | (hi << 16);
+      }
+      if (q < nrow && active) *(u4 *)(out + (size_t)(base + q) * (ldo / 2) + 4 * g) = w;
+    }
+    s += nrow;
+    if (s >= (unsigned)ns) {
+      s -= (unsigned)ns; ++bj;
+      if (++j == (unsigned)m) { j = 0; ++b; }
+    }
+  }
+}
+
 // Narrow bf16 rows (pitch 8 or 16: the 3+3 / 3+4 columns of an SA1 level): a lane per row, one or two 16-byte stores.
 template <int LDO>
 __global__ __launch_bounds__(kBlock) void group_concat_rows_bf16_narrow_kernel(
@@ -464,9 +714,21 @@ extern "C" int pn2_group_concat_rows_bf16(int B, int N, int m, int ns, int C, in
   unsigned rpw = (rows + want_waves - 1) / want_waves;
   rpw = (rpw + 7u) & ~7u;
   const unsigned waves = (rows + rpw - 1) / rpw;
-  const unsigned grid = (waves + kBlock / 64 - 1) / (kBlock / 64);
-  hipLaunchKernelGGL(group_concat_rows_bf16_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C, Cx,
-                     normalize, radius, ldo, xyz, new_xyz, feats, idx, (unsigned *)out, rows, rpw);
+  const unsigned grid = ((waves + kBlock / 64 - 1) / (kBlock / 64) + 7u) & ~7u;        // multiple of 8: xcd_slab_wave()
+  // 16-byte variant: xyz in front, neighbourhoods of at least 8, pitch <= 512 columns
+  const bool wide8 = Cx == 3 && C >= 5 && ns >= 8 && ldo <= 512;
+  if (wide8 && ldo <= 128)
+    hipLaunchKernelGGL(group_concat_rows_bf16_wide8_kernel<4>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C,
+                       normalize, radius, ldo, xyz, new_xyz, feats, idx, (unsigned *)out, rows, rpw);
+  else if (wide8 && ldo <= 256)
+    hipLaunchKernelGGL(group_concat_rows_bf16_wide8_kernel<2>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C,
+                       normalize, radius, ldo, xyz, new_xyz, feats, idx, (unsigned *)out, rows, rpw);
+  else if (wide8)
+    hipLaunchKernelGGL(group_concat_rows_bf16_wide8_kernel<1>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C,
+                       normalize, radius, ldo, xyz, new_xyz, feats, idx, (unsigned *)out, rows, rpw);
+  else
+    hipLaunchKernelGGL(group_concat_rows_bf16_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C, Cx,
+                       normalize, radius, ldo, xyz, new_xyz, feats, idx, (unsigned *)out, rows, rpw);
   return pn2_check_launch();
 }
 
@@ -497,9 +759,22 @@ extern "C" int pn2_group_concat_rows(int B, int N, int m, int ns, int C, int use
     unsigned rpw = (rows + want_waves - 1) / want_waves;
     rpw = (rpw + 7u) & ~7u;
     const unsigned waves = (rows + rpw - 1) / rpw;
-    const unsigned grid = (waves + kBlock / 64 - 1) / (kBlock / 64);
-    hipLaunchKernelGGL(group_concat_rows_wide_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C,
-                       Cx, normalize, radius, xyz, new_xyz, feats, idx, out, rows, rpw);
+    const unsigned grid = ((waves + kBlock / 64 - 1) / (kBlock / 64) + 7u) & ~7u;      // multiple of 8: xcd_slab_wave()
+    // 16-byte variant: xyz in front, feature width a multiple of 4 up to 256, neighbourhoods of at least 8 (a batch of
+    // eight rows then crosses at most one centre), 16-byte aligned feature rows
+    const bool wide4 = Cx == 3 && C >= 4 && (C & 3) == 0 && C <= 256 && ns >= 8 && (((size_t)feats) & 15) == 0;
+    if (wide4 && C <= 64)
+      hipLaunchKernelGGL(group_concat_rows_wide4_kernel<4>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C,
+                         normalize, radius, xyz, new_xyz, feats, idx, out, rows, rpw);
+    else if (wide4 && C <= 128)
+      hipLaunchKernelGGL(group_concat_rows_wide4_kernel<2>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C,
+                         normalize, radius, xyz, new_xyz, feats, idx, out, rows, rpw);
+    else if (wide4)
+      hipLaunchKernelGGL(group_concat_rows_wide4_kernel<1>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C,
+                         normalize, radius, xyz, new_xyz, feats, idx, out, rows, rpw);
+    else
+      hipLaunchKernelGGL(group_concat_rows_wide_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C,
+                         Cx, normalize, radius, xyz, new_xyz, feats, idx, out, rows, rpw);
   }
   return pn2_check_launch();
 }

@@ -49,7 +49,8 @@ class Pointnet2Backbone(nn.Module):
         # FPS shape that leaves half of the CUs to the co-running step (include/pn2_hip.h: PN2_FPS_FEW_CUS)
         with getattr(pointnet2_utils._ext, "background_geometry", contextlib.nullcontext)():
             for i in (1, 2, 3, 4):
-                g = getattr(self, f"sa{i}").sample_and_query(levels[-1])
+                # levels 2-4 gather features that carry a gradient (level 1 reads the input colours)
+                g = getattr(self, f"sa{i}").sample_and_query(levels[-1], inverse_index=i > 1)
                 geo["sa"].append(g)
                 levels.append(g["new_xyz"])
             geo["fp"].append(self.fp1.interpolation(levels[3], levels[4]))

@@ -38,15 +38,20 @@ class PointnetSAModuleVotes(nn.Module):
             mlp[0] += 3                      # in place like the reference (:205-207)
         self.mlp_module = pt_utils.SharedMLP(mlp, bn=bn)
 
-    def sample_and_query(self, xyz: torch.Tensor, inds: torch.Tensor = None):
+    def sample_and_query(self, xyz: torch.Tensor, inds: torch.Tensor = None, inverse_index: bool = False):
         """The data-only part of the module (no parameters, no features): FPS indices, sampled centres
         and ball-query neighbourhoods.  Lets a pipeline compute the geometry of the NEXT batch on a side
-        stream while the current batch trains (see Pointnet2Backbone.precompute_geometry)."""
+        stream while the current batch trains (see Pointnet2Backbone.precompute_geometry).
+        `inverse_index`: this level's features will need a gradient — also build the inverse of a crowded
+        neighbourhood index (per-point sum instead of atomics in the backward, csrc/group_csr.hip)."""
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         new_xyz = pointnet2_utils.gather_operation(
             xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
-        return {"inds": inds, "new_xyz": new_xyz, "idx": self.grouper.query(xyz, new_xyz), "n_src": xyz.size(1)}
+        idx = self.grouper.query(xyz, new_xyz)
+        if inverse_index:
+            _pm.attach_inverse_indices([self.grouper], [idx], xyz.size(1))
+        return {"inds": inds, "new_xyz": new_xyz, "idx": idx, "n_src": xyz.size(1)}
 
     def _check_geometry(self, xyz, geometry):
         """A prefetched sample_and_query() result must belong to a batch of this shape on this device."""

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "pn2_three_interpolate_grad": [_c_int] * 4 + [_c_vp] * 5,
     "pn2_group_concat_rows": [_c_int] * 7 + [_c_f32] + [_c_vp] * 6,
     "pn2_group_rows_grad": [_c_int] * 7 + [_c_vp] * 4,
+    "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
+    "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_rows_max": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_rows_max_grad": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_three_interpolate_rows": [_c_int] * 6 + [_c_vp] * 5,
@@ -106,6 +108,8 @@ _lib.pn2_fps_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_workspace_bytes.restype = _c_sz
 _lib.pn2_ball_query_workspace_bytes.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int]
 _lib.pn2_ball_query_workspace_bytes.restype = _c_sz
+_lib.pn2_group_inverse_index_workspace_bytes.argtypes = [_c_int] * 4
+_lib.pn2_group_inverse_index_workspace_bytes.restype = _c_sz
 _lib.pn2_prep_num_chunks.argtypes = [_c_int]
 _lib.pn2_prep_num_chunks.restype = _c_int
 _lib.pn2_ball_query_grid_bytes.argtypes = [_c_int, _c_int, _c_int]
@@ -129,7 +133,7 @@ ABI_VERSION = int(_lib.pn2_abi_version())
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
-                                               "pn2_prep_num_chunks",
+                                               "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_bwd_bf16_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
@@ -463,6 +467,51 @@ def group_rows_grad(grad_out, idx, n, c, col0):
     _call("pn2_group_rows_grad", grad_out, B, int(n), m, ns, int(c), W, int(col0),
           _ptr(grad_out), _ptr(idx), _ptr(out),
           alg_bytes=B * (4 * m * ns + 4 * int(c) * m * ns + 4 * int(c) * int(n)))
+    return out
+
+
+def group_inverse_index(idx, n):
+    """idx (B,m,ns) i32 neighbourhood indices into clouds of n points -> (ptr (B*n+1) i32, refs (B*m*ns) i32): the rows
+    (b*m + j)*ns + s that gathered each point, sorted by (point, row).  Data only (no features): build it next to the ball
+    query, e.g. on the geometry prefetch stream."""
+    _i32(idx, "idx")
+    _same_device((idx, "idx"))
+    B, m, ns = idx.shape
+    n = int(n)
+    ptr = torch.empty(B * n + 1, dtype=torch.int32, device=idx.device)
+    refs = torch.empty(B * m * ns, dtype=torch.int32, device=idx.device)
+    ws_bytes = int(_lib.pn2_group_inverse_index_workspace_bytes(B, n, m, ns))
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=idx.device)     # torch allocations are 512-byte aligned
+    _call("pn2_group_inverse_index", idx, B, n, m, ns, _ptr(idx), _ptr(ptr), _ptr(refs), _ptr(ws), ws_bytes,
+          alg_bytes=B * m * ns * 8 + B * n * 4)
+    return ptr, refs
+
+
+def attach_inverse_index(idx, n):
+    """Build the inverse of `idx` and hang it on the tensor (`idx.pn2_inverse`): the backward of the fused grouping nodes
+    then sums the feature gradient per point (pn2_group_rows_grad_csr, bit-reproducible) instead of scattering atomics."""
+    idx.pn2_inverse = (int(n),) + group_inverse_index(idx, n)
+    return idx
+
+
+def inverse_index_of(idx, n):
+    inv = getattr(idx, "pn2_inverse", None)
+    return inv[1:] if inv is not None and inv[0] == int(n) else None
+
+
+def group_rows_grad_csr(grad_out, inv, n, c, col0):
+    """grad_out (B,m,ns,W) + inv = (ptr, refs) of its index -> (B,n,c); every output row written, fixed summation order."""
+    _f32(grad_out, "grad_out")
+    ptr, refs = inv
+    _i32(ptr, "ptr"); _i32(refs, "refs")
+    _same_device((grad_out, "grad_out"), (ptr, "ptr"), (refs, "refs"))
+    B, m, ns, W = grad_out.shape
+    n, c = int(n), int(c)
+    if ptr.numel() != B * n + 1 or refs.numel() != B * m * ns:
+        raise RuntimeError("group_rows_grad_csr: inverse index does not belong to this gradient's neighbourhoods")
+    out = torch.empty(B, n, c, dtype=torch.float32, device=grad_out.device)
+    _call("pn2_group_rows_grad_csr", grad_out, B, n, c, W, int(col0), B * m * ns, _ptr(grad_out), _ptr(ptr), _ptr(refs),
+          _ptr(out), alg_bytes=B * (8 * m * ns + 4 * c * m * ns + 4 * c * n + 4 * n), label="pn2_group_rows_grad")
     return out
 
 

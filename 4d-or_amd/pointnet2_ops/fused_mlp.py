@@ -249,7 +249,11 @@ class _FusedMLP(Function):
             idx = ctx.group[2]
             Bq, npoint, nsample = idx.shape
             Bf, Nf, Cf = ctx.feat_shape
-            gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0)
+            inv = e.inverse_index_of(idx, Nf)
+            if inv is not None:          # prefetched inverse index: per-point sum, no atomics (csrc/group_csr.hip)
+                gx = e.group_rows_grad_csr(gx.view(Bq, npoint, nsample, Cf), inv, Nf, Cf, 0)
+            else:
+                gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0)
         return (gx, None, None, None, *grads)
 
 
@@ -379,7 +383,11 @@ class _FusedMLPBf16(Function):
             idx = ctx.group[2]
             Bq, npoint, nsample = idx.shape
             Bf, Nf, Cf = ctx.feat_shape
-            gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0)
+            inv = e.inverse_index_of(idx, Nf)
+            if inv is not None:          # prefetched inverse index: per-point sum, no atomics (csrc/group_csr.hip)
+                gx = e.group_rows_grad_csr(gx.view(Bq, npoint, nsample, Cf), inv, Nf, Cf, 0)
+            else:
+                gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0)
         return (gx, None, None, None, *grads)
 
 

