@@ -45,13 +45,20 @@ __global__ __launch_bounds__(kBlock) void inv_ptr_kernel(unsigned rows, unsigned
 
 // A wave per point; R sub-waves of 64 / R lanes walk the point's rows R at a time (C <= 4 * 64 / R), four 16-byte loads in
 // flight per lane; the sub-wave sums are combined in a fixed order.
-template <int R>
+// BF: grad_out holds bf16 (the mixed-precision stack's activation gradients): 8-byte loads of four values.
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+template <int R, bool BF>
 __global__ __launch_bounds__(kBlock) void group_rows_grad_csr_kernel(int C, int ldg, int col0, unsigned npoints,
-                                                                    const float *__restrict__ g,
+                                                                    const void *__restrict__ gv,
                                                                     const int *__restrict__ ptr,
                                                                     const int *__restrict__ refs,
                                                                     float *__restrict__ out) {
   constexpr int LPR = 64 / R;
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const float *g = (const float *)gv;
+  const unsigned short *gb = (const unsigned short *)gv;
   const int lane = pn2_lane();
   const int sub = lane / LPR, l = lane % LPR;
   const bool fl = 4 * l < C;
@@ -69,7 +76,14 @@ __global__ __launch_bounds__(kBlock) void group_rows_grad_csr_kernel(int C, int 
           const int i = (t + u) * R + sub;
           const int r = __shfl(myref, i & 63);
           v[u] = f4v{0.f, 0.f, 0.f, 0.f};
-          if (i < cnt && fl) v[u] = ((const F4Dw *)(g + (size_t)r * ldg + col0 + 4 * l))->v;
+          if (i < cnt && fl) {
+            if constexpr (BF) {
+              const u2v w = *(const u2v *)(gb + (size_t)r * ldg + col0 + 4 * l);
+              v[u] = f4v{bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y)};
+            } else {
+              v[u] = ((const F4Dw *)(g + (size_t)r * ldg + col0 + 4 * l))->v;
+            }
+          }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -87,9 +101,10 @@ __global__ __launch_bounds__(kBlock) void group_rows_grad_csr_kernel(int C, int 
   }
 }
 
-// any C: lane c, c + 64, ... (dword loads)
+// any C: lane c, c + 64, ... (element loads)
+template <bool BF>
 __global__ __launch_bounds__(kBlock) void group_rows_grad_csr_any_kernel(int C, int ldg, int col0, unsigned npoints,
-                                                                        const float *__restrict__ g,
+                                                                        const void *__restrict__ gv,
                                                                         const int *__restrict__ ptr,
                                                                         const int *__restrict__ refs,
                                                                         float *__restrict__ out) {
@@ -99,7 +114,10 @@ __global__ __launch_bounds__(kBlock) void group_rows_grad_csr_any_kernel(int C, 
     const int p0 = ptr[n], p1 = ptr[n + 1];
     for (int c = lane; c < C; c += 64) {
       float acc = 0.f;
-      for (int p = p0; p < p1; ++p) acc = __fadd_rn(acc, g[(size_t)refs[p] * ldg + col0 + c]);
+      for (int p = p0; p < p1; ++p) {
+        const size_t e = (size_t)refs[p] * ldg + col0 + c;
+        acc = __fadd_rn(acc, BF ? bf16_lo(((const unsigned short *)gv)[e]) : ((const float *)gv)[e]);
+      }
       out[(size_t)n * C + c] = acc;
     }
   }
@@ -161,8 +179,10 @@ extern "C" int pn2_group_inverse_index(int B, int N, int m, int ns, const int *i
   return pn2_check_launch();
 }
 
-extern "C" int pn2_group_rows_grad_csr(int B, int N, int C, int ldg, int col0, int64_t rows, const float *grad_out,
-                                       const int *ptr, const int *refs, float *grad_feats, void *stream) {
+namespace {
+template <bool BF>
+int launch_rows_grad_csr(int B, int N, int C, int ldg, int col0, int64_t rows, const void *grad_out, const int *ptr,
+                         const int *refs, float *grad_feats, void *stream) {
   if (B < 0 || N < 0 || C < 0 || col0 < 0 || ldg < col0 + C || rows < 0 || rows >= 0x7fffffffll) return PN2_EINVAL;
   const size_t npoints = (size_t)B * N;
   if (npoints == 0 || C == 0) return PN2_OK;
@@ -171,15 +191,28 @@ extern "C" int pn2_group_rows_grad_csr(int B, int N, int C, int ldg, int col0, i
   const unsigned waves_wanted = 256u * 32u;
   unsigned grid = (unsigned)((npoints < waves_wanted ? npoints : waves_wanted) + 3) / 4;
   if (grid == 0) grid = 1;
-  const bool v4 = (C & 3) == 0 && C <= 256 && (((size_t)grad_feats) & 15) == 0 && (((size_t)grad_out) & 3) == 0;
-#define PN2_CSR(R) hipLaunchKernelGGL(group_rows_grad_csr_kernel<R>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, C, ldg, \
-                                      col0, (unsigned)npoints, grad_out, ptr, refs, grad_feats)
+  // 4 values per lane: fp32 rows at dword alignment (16-byte loads), bf16 rows at 8-byte alignment
+  const bool v4 = (C & 3) == 0 && C <= 256 && (((size_t)grad_feats) & 15) == 0 &&
+                  (BF ? ((ldg & 3) == 0 && (col0 & 3) == 0 && (((size_t)grad_out) & 7) == 0) : (((size_t)grad_out) & 3) == 0);
+#define PN2_CSR(R) hipLaunchKernelGGL((group_rows_grad_csr_kernel<R, BF>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, C, \
+                                      ldg, col0, (unsigned)npoints, grad_out, ptr, refs, grad_feats)
   if (v4 && C <= 64) PN2_CSR(4);
   else if (v4 && C <= 128) PN2_CSR(2);
   else if (v4) PN2_CSR(1);
   else
-    hipLaunchKernelGGL(group_rows_grad_csr_any_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, C, ldg, col0,
+    hipLaunchKernelGGL(group_rows_grad_csr_any_kernel<BF>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, C, ldg, col0,
                        (unsigned)npoints, grad_out, ptr, refs, grad_feats);
 #undef PN2_CSR
   return pn2_check_launch();
+}
+}  // namespace
+
+extern "C" int pn2_group_rows_grad_csr(int B, int N, int C, int ldg, int col0, int64_t rows, const float *grad_out,
+                                       const int *ptr, const int *refs, float *grad_feats, void *stream) {
+  return launch_rows_grad_csr<false>(B, N, C, ldg, col0, rows, grad_out, ptr, refs, grad_feats, stream);
+}
+
+extern "C" int pn2_group_rows_grad_csr_bf16(int B, int N, int C, int ldg, int col0, int64_t rows, const void *grad_out,
+                                            const int *ptr, const int *refs, float *grad_feats, void *stream) {
+  return launch_rows_grad_csr<true>(B, N, C, ldg, col0, rows, grad_out, ptr, refs, grad_feats, stream);
 }

@@ -334,6 +334,154 @@ __global__ __launch_bounds__(kBlock) void group_rows_grad_kernel(
   }
 }
 
+// The same walk over bf16 gradient rows (mixed-precision stack): lane l owns the channel pair (2l, 2l+1) [+128 per pass],
+// one dword load per slot.  C, ldg and col0 even.
+__global__ __launch_bounds__(kBlock) void group_rows_grad_bf16_kernel(
+    int N, int m, int ns, int C, int ldg, int col0, const unsigned short *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_feats, unsigned groups, unsigned groups_per_wave) {
+  const int lane = pn2_lane();
+  const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+  unsigned g0 = wave * groups_per_wave;
+  if (g0 >= groups) return;
+  unsigned g1 = g0 + groups_per_wave;
+  if (g1 > groups) g1 = groups;
+  for (unsigned gq = g0; gq < g1; ++gq) {
+    const unsigned b = gq / (unsigned)m;
+    const int *irow = idx + (size_t)gq * ns;
+    const unsigned short *grow = grad_out + (size_t)gq * ns * ldg + col0;
+    float *base = grad_feats + (size_t)b * N * C;
+    const int first = irow[0];
+    for (int c0 = 0; c0 < C; c0 += 128) {
+      const int c = c0 + 2 * lane;
+      const bool ok = c < C;
+      float acc0 = 0.f, acc1 = 0.f;
+      for (int s0 = 0; s0 < ns; s0 += 64) {
+        const int cnt = ns - s0 < 64 ? ns - s0 : 64;
+        const int myi = lane < cnt ? irow[s0 + lane] : first;
+#pragma unroll 4
+        for (int q = 0; q < cnt; ++q) {
+          const int ii = __builtin_amdgcn_readlane(myi, q);
+          const unsigned w = ok ? *(const unsigned *)(grow + (size_t)(s0 + q) * ldg + c) : 0u;
+          const float ga = __builtin_bit_cast(float, w << 16), gb = __builtin_bit_cast(float, w & 0xffff0000u);
+          if (ii == first) { acc0 += ga; acc1 += gb; }         // wave-uniform branch
+          else if (ok) {
+            atomicAdd(base + (size_t)ii * C + c, ga);
+            atomicAdd(base + (size_t)ii * C + c + 1, gb);
+          }
+        }
+      }
+      if (ok) {
+        atomicAdd(base + (size_t)first * C + c, acc0);
+        atomicAdd(base + (size_t)first * C + c + 1, acc1);
+      }
+    }
+  }
+}
+
+// Vector form of the two kernels above for the padded part: R sub-waves of 64 / R lanes take R slots of the neighbourhood per
+// wave instruction, a lane owns CH = 4 (fp32 rows) or 8 (bf16 rows) adjacent channels = one 16-byte load, four passes in
+// flight; slots that repeat the first hit are summed in registers and the sub-waves' sums combined at the end.  (The
+// dword-per-lane walk needs ns * C / 64 wave loads per neighbourhood — 192 at C = 192, ns = 64; this one 64 resp. 32.)  The
+// genuine other hits keep the lane-per-channel form: their atomics must stay one contiguous 256-byte request per wave
+// instruction — issued from the 16-byte layout (lane stride CH) the same atomics ran 4x slower on crowded balls.
+template <int R, bool BF>
+__global__ __launch_bounds__(kBlock) void group_rows_grad_vec_kernel(
+    int N, int m, int ns, int C, int ldg, int col0, const void *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_feats, unsigned groups, unsigned groups_per_wave) {
+  constexpr int LPR = 64 / R;
+  constexpr int CH = BF ? 8 : 4;
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const int lane = pn2_lane();
+  const int sub = lane / LPR, l = lane % LPR;
+  const bool fl = CH * l < C;
+  const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+  unsigned g0 = wave * groups_per_wave;
+  if (g0 >= groups) return;
+  unsigned g1 = g0 + groups_per_wave;
+  if (g1 > groups) g1 = groups;
+  for (unsigned gq = g0; gq < g1; ++gq) {
+    const unsigned b = gq / (unsigned)m;
+    const int *irow = idx + (size_t)gq * ns;
+    float *base = grad_feats + (size_t)b * N * C;
+    const size_t row0 = (size_t)gq * ns;
+    const int first = irow[0];
+    float acc[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) acc[i] = 0.f;
+    for (int s0 = 0; s0 < ns; s0 += 64) {
+      const int cnt = ns - s0 < 64 ? ns - s0 : 64;
+      const int myi = lane < cnt ? irow[s0 + lane] : first;
+      unsigned long long others = __ballot(myi != first);          // slots of this block that are genuine other hits
+      if (others != ~0ull >> (64 - cnt)) {                           // some slot repeats the first hit (wave-uniform)
+        for (int t = 0; t * R < cnt; t += 4) {
+          float v[4][CH];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int q = (t + u) * R + sub;
+            const int iq = __shfl(myi, q & 63);                    // every lane takes part (a lane that is masked off
+            const bool on = q < cnt && fl && iq == first;           // would read as 0 for the others)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[u][i] = 0.f;
+            if (on) {
+              const size_t e = (row0 + s0 + q) * (size_t)ldg + col0 + CH * l;
+              if constexpr (BF) {
+                const u4v w = *(const u4v *)((const unsigned short *)grad_out + e);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  v[u][2 * i] = __builtin_bit_cast(float, w[i] << 16);
+                  v[u][2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+                }
+              } else {
+                const f4v w = ((const F4Dw *)((const float *)grad_out + e))->v;
+                v[u][0] = w.x; v[u][1] = w.y; v[u][2] = w.z; v[u][3] = w.w;
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[i] += v[u][i];
+        }
+      }
+      while (others) {                                               // wave-uniform walk over the other hits
+        const int q = __builtin_ctzll(others);
+        others &= others - 1;
+        const int ii = __builtin_amdgcn_readlane(myi, q);
+        const size_t e = (row0 + s0 + q) * (size_t)ldg + col0;
+        float *dst = base + (size_t)ii * C;
+        for (int c = lane; c < C; c += 64) {
+          const float gv = BF ? __builtin_bit_cast(float, (unsigned)((const unsigned short *)grad_out)[e + c] << 16)
+                              : ((const float *)grad_out)[e + c];
+          atomicAdd(dst + c, gv);
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= LPR; d >>= 1)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) acc[i] += __shfl_xor(acc[i], d);
+    if (sub == 0 && fl)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) atomicAdd(base + (size_t)first * C + CH * l + i, acc[i]);
+  }
+}
+
+template <bool BF>
+bool launch_rows_grad_vec(int N, int m, int ns, int C, int ldg, int col0, const void *grad_out, const int *idx,
+                          float *grad_feats, unsigned groups, unsigned gpw, unsigned grid, hipStream_t stream) {
+  constexpr int CH = BF ? 8 : 4;
+  // 16-byte loads: bf16 rows need 16-byte alignment of every (row, column group), fp32 rows dword alignment
+  if (C % CH != 0 || C > 64 * CH) return false;
+  if (BF && ((ldg & 7) || (col0 & 7) || (((size_t)grad_out) & 15))) return false;
+#define PN2_VEC(R) hipLaunchKernelGGL((group_rows_grad_vec_kernel<R, BF>), dim3(grid), dim3(kBlock), 0, stream, N, m, ns, C, \
+                                      ldg, col0, grad_out, idx, grad_feats, groups, gpw)
+  if (C <= 16 * CH) PN2_VEC(4);
+  else if (C <= 32 * CH) PN2_VEC(2);
+  else PN2_VEC(1);
+#undef PN2_VEC
+  return true;
+}
+
 // max over the ns axis of x (R, ns, C); first maximal s wins (torch max_pool2d).
 __global__ __launch_bounds__(kBlock) void rows_max_kernel(int ns, int C, const float *__restrict__ x,
                                                          float *__restrict__ out, int *__restrict__ arg,
@@ -793,8 +941,29 @@ extern "C" int pn2_group_rows_grad(int B, int N, int m, int ns, int C, int ldg, 
   const unsigned gpw = (groups + want_waves - 1) / want_waves;
   const unsigned waves = (groups + gpw - 1) / gpw;
   const unsigned grid = (waves + kBlock / 64 - 1) / (kBlock / 64);
-  hipLaunchKernelGGL(group_rows_grad_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C, ldg,
-                     col0, grad_out, idx, grad_feats, groups, gpw);
+  if (!launch_rows_grad_vec<false>(N, m, ns, C, ldg, col0, grad_out, idx, grad_feats, groups, gpw, grid, (hipStream_t)stream))
+    hipLaunchKernelGGL(group_rows_grad_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C, ldg,
+                       col0, grad_out, idx, grad_feats, groups, gpw);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_group_rows_grad_bf16(int B, int N, int m, int ns, int C, int ldg, int col0, const void *grad_out,
+                                        const int *idx, float *grad_feats, void *stream) {
+  if (B < 0 || N < 0 || m < 0 || ns < 0 || C < 0 || col0 < 0 || ldg < col0 + C) return PN2_EINVAL;
+  if ((C & 1) || (ldg & 1) || (col0 & 1) || (((size_t)grad_out) & 3)) return PN2_EINVAL;
+  const size_t total = (size_t)B * m * ns * (size_t)C;
+  if (total == 0) return PN2_OK;
+  if (!grad_out || !idx || !grad_feats) return PN2_ENULL;
+  const size_t groups_sz = (size_t)B * m;
+  if (groups_sz >= 0x7fffffffull) return PN2_EINVAL;
+  const unsigned groups = (unsigned)groups_sz;
+  const unsigned want_waves = 256u * 32u;
+  const unsigned gpw = (groups + want_waves - 1) / want_waves;
+  const unsigned waves = (groups + gpw - 1) / gpw;
+  const unsigned grid = (waves + kBlock / 64 - 1) / (kBlock / 64);
+  if (!launch_rows_grad_vec<true>(N, m, ns, C, ldg, col0, grad_out, idx, grad_feats, groups, gpw, grid, (hipStream_t)stream))
+    hipLaunchKernelGGL(group_rows_grad_bf16_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, m, ns, C, ldg, col0,
+                       (const unsigned short *)grad_out, idx, grad_feats, groups, gpw);
   return pn2_check_launch();
 }
 

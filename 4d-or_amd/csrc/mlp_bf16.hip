@@ -1046,6 +1046,8 @@ int pn2_mlp_gemm_bf16_block(GemmBf16Args a, int n0, int nb, int ys, int pro, int
     case PRO_BNRELU * 8 + EPI_STATS * 2: return dispatch_nt<PRO_BNRELU, EPI_STATS, false, false>(a, s);
     case PRO_GY * 8 + EPI_MASK * 2: return dispatch_nt<PRO_GY, EPI_MASK, false, false>(a, s);
     case PRO_POOLG * 8 + EPI_MASK * 2: return dispatch_nt<PRO_POOLG, EPI_MASK, false, false>(a, s);
+    case PRO_GY * 8 + EPI_NONE * 2: return dispatch_nt<PRO_GY, EPI_NONE, false, false>(a, s);        // bf16 gradient rows of a
+    case PRO_POOLG * 8 + EPI_NONE * 2: return dispatch_nt<PRO_POOLG, EPI_NONE, false, false>(a, s);  // grouped first layer
     case PRO_GY * 8 + EPI_NONE * 2 + 1: return dispatch_nt<PRO_GY, EPI_NONE, false, true>(a, s);
     case PRO_POOLG * 8 + EPI_NONE * 2 + 1: return dispatch_nt<PRO_POOLG, EPI_NONE, false, true>(a, s);
     default: return PN2_EINVAL;

@@ -58,6 +58,8 @@ _SIGNATURES = {
     "pn2_group_rows_grad": [_c_int] * 7 + [_c_vp] * 4,
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
     "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
+    "pn2_group_rows_grad_csr_bf16": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
+    "pn2_group_rows_grad_bf16": [_c_int] * 7 + [_c_vp] * 4,
     "pn2_rows_max": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_rows_max_grad": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_three_interpolate_rows": [_c_int] * 6 + [_c_vp] * 5,
@@ -458,15 +460,26 @@ def group_concat_rows(xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius)
     return out
 
 
+def _grad_rows(grad_out):
+    """fp32 or bf16 gradient rows -> (entry point suffix, element bytes)."""
+    if grad_out.dtype == torch.bfloat16:
+        if not grad_out.is_contiguous():
+            raise RuntimeError("grad_out must be contiguous")
+        return "_bf16", 2
+    _f32(grad_out, "grad_out")
+    return "", 4
+
+
 def group_rows_grad(grad_out, idx, n, c, col0):
-    """grad_out (B,m,ns,W) -> (B,n,c) gradient of the gathered feature columns."""
-    _f32(grad_out, "grad_out"); _i32(idx, "idx")
+    """grad_out (B,m,ns,W) fp32 or bf16 -> (B,n,c) fp32 gradient of the gathered feature columns."""
+    sfx, eb = _grad_rows(grad_out)
+    _i32(idx, "idx")
     _same_device((grad_out, "grad_out"), (idx, "idx"))
     B, m, ns, W = grad_out.shape
     out = torch.zeros(B, int(n), int(c), dtype=torch.float32, device=grad_out.device)
-    _call("pn2_group_rows_grad", grad_out, B, int(n), m, ns, int(c), W, int(col0),
+    _call("pn2_group_rows_grad" + sfx, grad_out, B, int(n), m, ns, int(c), W, int(col0),
           _ptr(grad_out), _ptr(idx), _ptr(out),
-          alg_bytes=B * (4 * m * ns + 4 * int(c) * m * ns + 4 * int(c) * int(n)))
+          alg_bytes=B * (4 * m * ns + eb * int(c) * m * ns + 4 * int(c) * int(n)), label="pn2_group_rows_grad")
     return out
 
 
@@ -501,7 +514,7 @@ def inverse_index_of(idx, n):
 
 def group_rows_grad_csr(grad_out, inv, n, c, col0):
     """grad_out (B,m,ns,W) + inv = (ptr, refs) of its index -> (B,n,c); every output row written, fixed summation order."""
-    _f32(grad_out, "grad_out")
+    sfx, eb = _grad_rows(grad_out)
     ptr, refs = inv
     _i32(ptr, "ptr"); _i32(refs, "refs")
     _same_device((grad_out, "grad_out"), (ptr, "ptr"), (refs, "refs"))
@@ -510,8 +523,8 @@ def group_rows_grad_csr(grad_out, inv, n, c, col0):
     if ptr.numel() != B * n + 1 or refs.numel() != B * m * ns:
         raise RuntimeError("group_rows_grad_csr: inverse index does not belong to this gradient's neighbourhoods")
     out = torch.empty(B, n, c, dtype=torch.float32, device=grad_out.device)
-    _call("pn2_group_rows_grad_csr", grad_out, B, n, c, W, int(col0), B * m * ns, _ptr(grad_out), _ptr(ptr), _ptr(refs),
-          _ptr(out), alg_bytes=B * (8 * m * ns + 4 * c * m * ns + 4 * c * n + 4 * n), label="pn2_group_rows_grad")
+    _call("pn2_group_rows_grad_csr" + sfx, grad_out, B, n, c, W, int(col0), B * m * ns, _ptr(grad_out), _ptr(ptr), _ptr(refs),
+          _ptr(out), alg_bytes=B * (8 * m * ns + eb * c * m * ns + 4 * c * n + 4 * n), label="pn2_group_rows_grad")
     return out
 
 

@@ -377,8 +377,11 @@ class _FusedMLPBf16(Function):
                                         stats=sums, Yprev=ys[l - 1], e_fin=fins[l - 1], M=M)
                     gmode, arg, gPm = e.PRO_GY, None, None
                 else:
+                    # gradient rows of a grouped first layer stay bf16 (the scatter / per-point sum accumulates in fp32);
+                    # a plain row input gets its fp32 gradient directly
+                    rows_bf16 = ctx.group is not None and Wt.size(0) % 4 == 0
                     gx = e.mlp_gemm_bf16(G, Wt, pro=gmode, epi=e.EPI_NONE, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns, M=M,
-                                         out_f32=True)
+                                         out_f32=not rows_bf16)
         if gx is not None and ctx.group is not None:
             idx = ctx.group[2]
             Bq, npoint, nsample = idx.shape

@@ -393,6 +393,13 @@ int pn2_segment_sum_rows(int64_t E, int H, int64_t N, int lds, int col0,
  *       fp32); every output row is WRITTEN (zeros for unreferenced points), the summation order is fixed by the sort, so
  *       the result is bit-reproducible.
  */
+/* bf16 gradient rows (mixed-precision stack): pn2_group_rows_grad_bf16 is pn2_group_rows_grad over bf16 `grad_out`
+ * (C, ldg, col0 even, 4-byte aligned base), pn2_group_rows_grad_csr_bf16 the per-point sum; the accumulation and
+ * grad_feats stay fp32. */
+int pn2_group_rows_grad_bf16(int B, int N, int m, int ns, int C, int ldg, int col0, const void *grad_out,
+                             const int *idx, float *grad_feats, void *stream);
+int pn2_group_rows_grad_csr_bf16(int B, int N, int C, int ldg, int col0, int64_t rows, const void *grad_out,
+                                 const int *ptr, const int *refs, float *grad_feats, void *stream);
 size_t pn2_group_inverse_index_workspace_bytes(int B, int N, int m, int ns);
 int pn2_group_inverse_index(int B, int N, int m, int ns, const int *idx, int *ptr, int *refs, void *workspace,
                             size_t workspace_bytes, void *stream);

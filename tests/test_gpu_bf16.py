@@ -352,3 +352,23 @@ def test_scene_graph_model_bf16_step():
     e_r = float((rf16 - rf32).norm() / rf32.norm())
     print(f"\n[bf16 sgp] loss fp32 {l32:.5f} bf16 {l16:.5f}; encoder features rel-L2: objects {e_o:.3e}, relations {e_r:.3e}")
     assert abs(l16 - l32) <= 2e-2 * abs(l32) and e_o <= 2e-2 and e_r <= 2e-2
+
+
+@pytest.mark.parametrize("B,N,m,ns,C", [(4, 512, 64, 16, 192), (3, 300, 37, 9, 64), (2, 1000, 50, 32, 130), (5, 128, 16, 64, 256),
+                                        (2, 90, 7, 8, 36)])
+def test_feature_gradient_from_bf16_rows(B, N, m, ns, C):
+    """pn2_group_rows_grad_bf16 / pn2_group_rows_grad_csr_bf16 == the fp32 kernels on the same (bf16-representable) rows."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(C + ns)
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    idx[:, ::2, ns // 2:] = idx[:, ::2, :1]
+    idx = idx.cuda()
+    go = torch.randn(B, m, ns, C, generator=g).to(BF).cuda()
+    want = e.group_rows_grad(go.float(), idx, N, C, 0)
+    got = e.group_rows_grad(go, idx, N, C, 0)
+    torch.testing.assert_close(got, want, atol=2e-4, rtol=1e-4)            # atomics: order noise only
+    inv = e.group_inverse_index(idx, N)
+    want_csr = e.group_rows_grad_csr(go.float(), inv, N, C, 0)
+    got_csr = e.group_rows_grad_csr(go, inv, N, C, 0)
+    assert torch.equal(got_csr, want_csr)                                   # same values, same fixed order
+    torch.testing.assert_close(got_csr, want, atol=2e-4, rtol=1e-4)

@@ -60,6 +60,12 @@ def main():
         t = timeit(lambda: _ext.group_rows_grad(go, idx, N, C, 3))
         print(json.dumps(dict(kernel="group_rows_grad", shape=name, ms=round(t * 1e3, 4), alg_MB=round(sbytes / 1e6, 1),
                               GBps=round(sbytes / t / 1e9, 1))), flush=True)
+        if _ext.HAS_BF16_MLP and C % 8 == 0:
+            gob = torch.randn(B, m, ns, C, generator=g).to(torch.bfloat16).to(dev)
+            bb = rows * (4 + 2 * C) + 2 * B * N * 4 * C
+            t = timeit(lambda: _ext.group_rows_grad(gob, idx, N, C, 0))
+            print(json.dumps(dict(kernel="group_rows_grad_bf16", shape=name, ms=round(t * 1e3, 4), alg_MB=round(bb / 1e6, 1),
+                                  GBps=round(bb / t / 1e9, 1))), flush=True)
         t = timeit(lambda: _ext.group_inverse_index(idx, N))
         print(json.dumps(dict(kernel="group_inverse_index", shape=name, ms=round(t * 1e3, 4), rows=rows)), flush=True)
         inv = _ext.group_inverse_index(idx, N)
