@@ -832,12 +832,12 @@ __global__ __launch_bounds__(256) void bn_relu_apply_bf16_kernel(size_t total, i
 constexpr int kPrepRowsBf = 16;
 
 // gpre = gout * [BN(y) > 0] (bf16), sums += (sum gpre, sum gpre * yhat) — backward entry of an un-pooled stack
-__global__ __launch_bounds__(256) void bn_relu_bwd_prep_bf16_kernel(long long M, int N, const bf16 *__restrict__ y,
+__global__ __launch_bounds__(256) void bn_relu_bwd_prep_bf16_kernel(long long M, int N, int rpb, const bf16 *__restrict__ y,
                                                                    const float *__restrict__ gout,
                                                                    const float *__restrict__ fin,
                                                                    bf16 *__restrict__ gpre, double *__restrict__ sums) {
   __shared__ float part[2][256];
-  const long long r0 = (long long)blockIdx.x * kPrepRowsBf;
+  const long long r0 = (long long)blockIdx.x * rpb;
   const int cw = N < 256 ? N : 256;
   const int groups = 256 / cw;
   const int grp = threadIdx.x / cw;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_prep_bf16_kernel(long long M,
     float s1 = 0.f, s2 = 0.f;
     if (active && c < N) {
       const float mean = fin[c], rstd = fin[N + c], sc = fin[2 * N + c], sh = fin[3 * N + c];
-      for (int r = grp; r < kPrepRowsBf; r += groups) {
+      for (int r = grp; r < rpb; r += groups) {
         const long long row = r0 + r;
         if (row >= M) break;
         const size_t off = (size_t)row * N + c;
@@ -1117,18 +1117,72 @@ extern "C" int pn2_bn_relu_bwd_prep_bf16(long long M, int N, const void *y, cons
   if (M < 0 || N <= 0) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!y || !gout || !fin || !gpre || !sums) return PN2_ENULL;
-  const long long blocks = (M + kPrepRowsBf - 1) / kPrepRowsBf;
-  if (blocks > 0x7fffffffLL) return PN2_EINVAL;
-  hipLaunchKernelGGL(bn_relu_bwd_prep_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, N,
+  // rows per block as in pn2_bn_relu_bwd_prep (csrc/mlp_gemm.hip): 16 up to 64k rows, then ~4096 blocks
+  int rpb = kPrepRowsBf;
+  if (M > 65536) rpb = (int)(((M + 4095) / 4096 + kPrepRowsBf - 1) / kPrepRowsBf * kPrepRowsBf);
+  const long long blocks = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL(bn_relu_bwd_prep_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, N, rpb,
                      (const bf16 *)y, gout, fin, (bf16 *)gpre, sums);
   return pn2_check_launch();
 }
+
+namespace {
+// Eight channels per thread (one 16-byte load per row, two rows in flight): the pair-per-thread kernel above keeps 4 bytes
+// per lane outstanding and ran at 3.1 TB/s on the scene-graph encoders' last layers.
+__global__ __launch_bounds__(256) void bn_relu_rows_max_bf16_v8_kernel(size_t total /* R*C/8 */, int ns, int C,
+                                                                      const bf16 *__restrict__ y,
+                                                                      const float *__restrict__ fin, float *__restrict__ out,
+                                                                      int *__restrict__ arg, float *__restrict__ yraw) {
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef int i4v __attribute__((ext_vector_type(4)));
+  const int CV = C / 8;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t r = e / CV;
+    const int c = (int)(e - r * CV) * 8;
+    float sc[8], sh[8], best[8], raw[8];
+    int bi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = fin[2 * C + c + i]; sh[i] = fin[3 * C + c + i]; best[i] = -1.f; raw[i] = 0.f; bi[i] = 0; }
+    const u4v *p = (const u4v *)(y + r * ns * C + c);
+    auto take = [&](const u4v w, int s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float q0 = bf_lo(w[i]), q1 = bf_hi(w[i]);
+        const float z0 = fmaxf(fmaf(q0, sc[2 * i], sh[2 * i]), 0.f), z1 = fmaxf(fmaf(q1, sc[2 * i + 1], sh[2 * i + 1]), 0.f);
+        if (z0 > best[2 * i]) { best[2 * i] = z0; bi[2 * i] = s; raw[2 * i] = q0; }           // first maximum wins (z >= 0 > -1)
+        if (z1 > best[2 * i + 1]) { best[2 * i + 1] = z1; bi[2 * i + 1] = s; raw[2 * i + 1] = q1; }
+      }
+    };
+    int s = 0;
+    for (; s + 2 <= ns; s += 2) {
+      const u4v w0 = p[(size_t)s * CV], w1 = p[(size_t)(s + 1) * CV];
+      take(w0, s);
+      take(w1, s + 1);
+    }
+    if (s < ns) take(p[(size_t)s * CV], s);
+    const size_t o = r * C + c;
+    *(f4v *)(out + o) = f4v{best[0], best[1], best[2], best[3]};
+    *(f4v *)(out + o + 4) = f4v{best[4], best[5], best[6], best[7]};
+    *(i4v *)(arg + o) = i4v{bi[0], bi[1], bi[2], bi[3]};
+    *(i4v *)(arg + o + 4) = i4v{bi[4], bi[5], bi[6], bi[7]};
+    *(f4v *)(yraw + o) = f4v{raw[0], raw[1], raw[2], raw[3]};
+    *(f4v *)(yraw + o + 4) = f4v{raw[4], raw[5], raw[6], raw[7]};
+  }
+}
+}  // namespace
 
 extern "C" int pn2_bn_relu_rows_max_bf16(long long R, int ns, int C, const void *y, const float *fin, float *out,
                                          int *arg, float *yraw, void *stream) {
   if (R < 0 || ns <= 0 || C <= 0 || C % 2 != 0) return PN2_EINVAL;
   if (R == 0) return PN2_OK;
   if (!y || !fin || !out || !arg || !yraw) return PN2_ENULL;
+  if (C % 8 == 0 && !(((uintptr_t)y | (uintptr_t)out | (uintptr_t)arg | (uintptr_t)yraw) & 15)) {
+    const size_t total8 = (size_t)R * C / 8;
+    hipLaunchKernelGGL(bn_relu_rows_max_bf16_v8_kernel, dim3(capped_grid(total8)), dim3(256), 0, (hipStream_t)stream, total8,
+                       ns, C, (const bf16 *)y, fin, out, arg, yraw);
+    return pn2_check_launch();
+  }
   const size_t total = (size_t)R * C / 2;
   hipLaunchKernelGGL(bn_relu_rows_max_bf16_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream, total, ns,
                      C, (const bf16 *)y, fin, out, arg, yraw);

@@ -697,10 +697,19 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(size_t total, int N,
   }
 }
 
-constexpr int kPrepRows = 16;   // rows per block of the two backward-prep kernels
+constexpr int kPrepRows = 16;   // minimum rows per block of the two backward-prep kernels
+
+// Rows per block: 16 up to 64k rows (the measured optimum at the headline shapes, see bn_relu_bwd_prep_kernel), then as many
+// as keep the grid near 4096 blocks — every block ends with 2 N fp64 atomics onto the SAME 2 N addresses, and with 18 000
+// blocks (scene-graph encoders, 295k pooled rows) those serialised atomics, not the rows, were the kernel's time.
+inline int prep_rows_per_block(long long rows) {
+  if (rows <= 65536) return kPrepRows;
+  const long long r = (rows + 4095) / 4096;
+  return (int)((r + kPrepRows - 1) / kPrepRows * kPrepRows);
+}
 
 // g_pre = g_out * [relu(bn(y)) > 0];  sums: dbeta += g_pre, dgamma += g_pre * yhat
-__global__ __launch_bounds__(256) void bn_relu_bwd_prep_kernel(long long M, int N, const float *__restrict__ y,
+__global__ __launch_bounds__(256) void bn_relu_bwd_prep_kernel(long long M, int N, int rpb, const float *__restrict__ y,
                                                               const float *__restrict__ gout,
                                                               const float *__restrict__ fin,
                                                               float *__restrict__ gpre, double *__restrict__ sums) {
@@ -708,7 +717,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_prep_kernel(long long M, int 
   // pre-reduced through LDS.  The kernel is latency bound (a thread's rows are a serial chain): measured
   // 64 rows/block 0.28 ms/step, 256 rows 0.79, 16 rows 0.25 — more, smaller blocks win despite 4x the fp64 atomics.
   __shared__ float part[2][256];
-  const long long r0 = (long long)blockIdx.x * kPrepRows;
+  const long long r0 = (long long)blockIdx.x * rpb;
   const int cw = N < 256 ? N : 256;              // columns per pass
   const int groups = 256 / cw;                   // >= 1
   const int grp = threadIdx.x / cw;
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_prep_kernel(long long M, int 
     if (active && c < N) {
       const float mean = fin[c], rstd = fin[N + c], sc = fin[2 * N + c], sh = fin[3 * N + c];
 #pragma unroll 4
-      for (int r = grp; r < kPrepRows; r += groups) {
+      for (int r = grp; r < rpb; r += groups) {
         const long long row = r0 + r;
         if (row >= M) break;
         const size_t off = (size_t)row * N + c;
@@ -792,13 +801,13 @@ __global__ __launch_bounds__(256) void bn_relu_rows_max_kernel(size_t total /* R
 
 // Pool backward reductions: gPm = gP * [pooled > 0]; dbeta += gPm; dgamma += gPm * yhat[arg-max row]
 // (yraw = the pre-BN value at the arg-max, saved by the forward kernel).
-__global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int C, const float *__restrict__ yraw,
+__global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int C, int rpb, const float *__restrict__ yraw,
                                                            const float *__restrict__ pooled,
                                                            const float *__restrict__ gP,
                                                            const float *__restrict__ fin,
                                                            float *__restrict__ gPm, double *__restrict__ sums) {
   __shared__ float part[2][256];                 // see bn_relu_bwd_prep_kernel
-  const long long r0 = (long long)blockIdx.x * kPrepRows;
+  const long long r0 = (long long)blockIdx.x * rpb;
   const int cw = C < 256 ? C : 256;
   const int groups = 256 / cw;
   const int grp = threadIdx.x / cw;
@@ -809,7 +818,7 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int C, 
     if (active && c < C) {
       const float mean = fin[c], rstd = fin[C + c];
 #pragma unroll 4
-      for (int i = grp; i < kPrepRows; i += groups) {
+      for (int i = grp; i < rpb; i += groups) {
         const long long r = r0 + i;
         if (r >= R) break;
         const size_t off = (size_t)r * C + c;
@@ -1044,8 +1053,9 @@ extern "C" int pn2_bn_relu_bwd_prep(long long M, int N, const float *y, const fl
   if (M < 0 || N <= 0) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!y || !gout || !fin || !gpre || !sums) return PN2_ENULL;
-  hipLaunchKernelGGL(bn_relu_bwd_prep_kernel, dim3((unsigned)((M + kPrepRows - 1) / kPrepRows)), dim3(256), 0,
-                     (hipStream_t)stream, M, N, y, gout, fin, gpre, sums);
+  const int rpb = prep_rows_per_block(M);
+  hipLaunchKernelGGL(bn_relu_bwd_prep_kernel, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0,
+                     (hipStream_t)stream, M, N, rpb, y, gout, fin, gpre, sums);
   return pn2_check_launch();
 }
 
@@ -1072,8 +1082,9 @@ extern "C" int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const fl
   if (R < 0 || C <= 0) return PN2_EINVAL;
   if (R == 0) return PN2_OK;
   if (!yraw || !pooled || !gP || !fin || !gPm || !sums) return PN2_ENULL;
-  hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3((unsigned)((R + kPrepRows - 1) / kPrepRows)), dim3(256), 0,
-                     (hipStream_t)stream, R, C, yraw, pooled, gP, fin, gPm, sums);
+  const int rpb = prep_rows_per_block(R);
+  hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0,
+                     (hipStream_t)stream, R, C, rpb, yraw, pooled, gP, fin, gPm, sums);
   return pn2_check_launch();
 }
 
