@@ -372,3 +372,68 @@ def test_feature_gradient_from_bf16_rows(B, N, m, ns, C):
     got_csr = e.group_rows_grad_csr(go, inv, N, C, 0)
     assert torch.equal(got_csr, want_csr)                                   # same values, same fixed order
     torch.testing.assert_close(got_csr, want, atol=2e-4, rtol=1e-4)
+
+
+def _fin(C, g):
+    """(mean, rstd, scale, shift) rows as the BatchNorm finalize kernel lays them out; some negative scales."""
+    mean, rstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.2
+    return torch.stack([mean, rstd, gamma * rstd, beta - mean * gamma * rstd]).contiguous()
+
+
+@pytest.mark.parametrize("R,ns,C", [(300, 16, 128), (77, 9, 64), (50, 64, 256), (33, 7, 40), (120, 32, 6), (1000, 1, 8)])
+def test_bn_relu_rows_max_kernels(R, ns, C):
+    """ReLU(BN(y)) + max over ns rows with the FIRST arg-max and the raw value there: fp32 kernel, bf16 pair kernel
+    (C % 8 != 0) and the 16-byte bf16 kernel (C % 8 == 0) against torch."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(R + C)
+    y = (torch.randn(R * ns, C, generator=g) * 2).round(decimals=1)            # ties
+    fin = _fin(C, g)
+    for dt, fn in ((torch.float32, e.bn_relu_rows_max), (BF, e.bn_relu_rows_max_bf16)):
+        yy = y.to(dt)
+        z = torch.relu(torch.addcmul(fin[3], yy.float(), fin[2])).view(R, ns, C)       # same fma as the kernels
+        want_arg = torch.zeros(R, C, dtype=torch.long)
+        want = z[:, 0].clone()
+        for s in range(1, ns):                                                          # strict >: first maximum wins
+            take = z[:, s] > want
+            want = torch.where(take, z[:, s], want)
+            want_arg = torch.where(take, torch.full_like(want_arg, s), want_arg)
+        out, arg, raw = fn(yy.cuda(), fin.cuda(), ns)
+        # fma vs mul+add: compare values with a tolerance, the arg-max exactly wherever the top-2 gap exceeds it
+        torch.testing.assert_close(out.cpu(), want, atol=1e-5, rtol=1e-5)
+        top2 = z.topk(min(2, ns), dim=1).values
+        safe = (top2[:, 0] - top2[:, -1] > 1e-4) if ns > 1 else torch.ones(R, C, dtype=torch.bool)
+        tied_first = (z == z.max(1, keepdim=True).values).float().argmax(1)
+        assert torch.equal(arg.cpu().long()[safe], want_arg[safe])
+        # exact ties away from the ReLU boundary come from equal inputs: the first of them must win
+        exact_ties = ((top2[:, 0] == top2[:, -1]) & (top2[:, 0] > 1e-3)) if ns > 1 else torch.zeros(R, C, dtype=torch.bool)
+        assert torch.equal(arg.cpu().long()[exact_ties], tied_first[exact_ties])
+        picked = yy.float().view(R, ns, C).gather(1, arg.cpu().long().unsqueeze(1)).squeeze(1)
+        assert torch.equal(raw.cpu(), picked)
+
+
+@pytest.mark.parametrize("R,C", [(70000, 128), (300000, 64), (1000, 256), (66000, 40)])
+def test_backward_prep_kernels_at_large_row_counts(R, C):
+    """pool_bwd_prep / bn_relu_bwd_prep (fp32, bf16): more rows per block above 64k rows — same sums, same masked rows."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(R % 1000 + C)
+    fin = _fin(C, g).cuda()
+    yraw = torch.randn(R, C, generator=g).cuda()
+    pooled = torch.relu(torch.randn(R, C, generator=g)).cuda()
+    gP = torch.randn(R, C, generator=g).cuda()
+    gPm, sums = e.pool_bwd_prep(yraw, pooled, gP, fin)
+    want = gP * (pooled > 0)
+    assert torch.equal(gPm, want)
+    yhat = (yraw - fin[0]) * fin[1]
+    torch.testing.assert_close(sums[0], want.double().sum(0), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(sums[1], (want * yhat).double().sum(0), rtol=1e-4, atol=1e-2)
+    for dt in (torch.float32, BF):
+        y = torch.randn(R, C, generator=g).to(dt).cuda()
+        gout = torch.randn(R, C, generator=g).cuda()
+        fn = e.bn_relu_bwd_prep if dt == torch.float32 else e.bn_relu_bwd_prep_bf16
+        gpre, s2 = fn(y, gout, fin)
+        mask = torch.addcmul(fin[3], y.float(), fin[2]) > 0
+        w = (gout * mask).to(dt)
+        same = (gpre == w).float().mean()
+        assert float(same) > 0.9999                                                 # fma vs mul+add at the ReLU boundary
+        torch.testing.assert_close(s2[0], w.double().sum(0), rtol=1e-3, atol=0.5)
