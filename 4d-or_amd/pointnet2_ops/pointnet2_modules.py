@@ -24,6 +24,8 @@ Two execution paths produce the same numbers (tests compare them):
 """
 from typing import List, Optional, Tuple
 
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -107,11 +109,52 @@ def mlp_rows(mlp: nn.Module, rows: torch.Tensor) -> torch.Tensor:
     return shared_mlp_rows(mlp, rows)
 
 
-def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None) -> torch.Tensor:
+# ---------------------------------------------------------------------------------- batched scans, per-scan statistics
+# The reference trains on ONE scan per step (SGP/main.py:54-56), so every training-mode BatchNorm of the encoders sees the
+# clouds of one scan (9 objects resp. 72 pairs).  A block-diagonal batch of S scans (dataset/synthetic.py::collate_scans)
+# keeps that arithmetic when the shared MLPs are run per scan: inside `per_scan_statistics`, a stack whose BatchNorms are in
+# training mode processes each scan's clouds [c_s, c_{s+1}) as its own call (own batch statistics, running statistics
+# updated scan after scan, in order) — everything without statistics (sampling, ball query, grouping geometry) stays batched.
+# The row counts per call stay large (>= 10^5), so the kernels keep their efficiency; the price is S times the launches.
+_SCAN_SEGMENTS = {}          # clouds in the batch -> clouds per scan
+
+
+@contextlib.contextmanager
+def per_scan_statistics(*clouds_per_scan):
+    """`clouds_per_scan`: one sequence per encoder input of the step, e.g. ([9] * S, [72] * S) for the object and the
+    relation encoder of the scene-graph model.  Batches of one scan need no entry."""
+    saved = dict(_SCAN_SEGMENTS)
+    try:
+        for sizes in clouds_per_scan:
+            sizes = tuple(int(v) for v in sizes)
+            if len(sizes) < 2:
+                continue
+            total = sum(sizes)
+            if _SCAN_SEGMENTS.get(total, sizes) != sizes:
+                raise RuntimeError("per_scan_statistics: two inputs with the same number of clouds but different scans")
+            _SCAN_SEGMENTS[total] = sizes
+        yield
+    finally:
+        _SCAN_SEGMENTS.clear()
+        _SCAN_SEGMENTS.update(saved)
+
+
+def _trains_batchnorm(mlp: nn.Module) -> bool:
+    return any(isinstance(m, nn.modules.batchnorm._BatchNorm) and (m.training or m.running_mean is None)
+               for m in mlp.modules())
+
+
+def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _whole_batch=False) -> torch.Tensor:
     """One SA scale on the rows path: group -> shared MLP -> max -> (B, npoint, C_out).
     Ball-query groupers with a fusable MLP run as a single autograd node (gather, MLP, pool and
     the scatter of the feature gradient); anything else goes through forward_rows + mlp_pool_rows."""
     from pointnet2_ops import fused_mlp
+    sizes = None if _whole_batch else _SCAN_SEGMENTS.get(xyz.size(0))
+    if sizes is not None and _trains_batchnorm(mlp):
+        split = lambda t: [None] * len(sizes) if t is None else t.split_with_sizes(sizes)
+        parts = [sa_scale_rows(grouper, mlp, x, nx, f, i, _whole_batch=True)
+                 for x, nx, f, i in zip(split(xyz), split(new_xyz), split(feats_rows), split(idx))]
+        return torch.cat(parts, dim=0)
     if (_FUSED_MLP and isinstance(grouper, pointnet2_utils.QueryAndGroup) and new_xyz is not None
             and (grouper.use_xyz or feats_rows is not None)
             and fused_mlp.supported(mlp, xyz if feats_rows is None else feats_rows, grouper.nsample)):

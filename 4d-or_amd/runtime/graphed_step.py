@@ -31,10 +31,22 @@ import torch
 import torch.distributed as dist
 
 
+# Objects in a batch may carry device tensors too (e.g. the SceneBatch of a block-diagonal batch of scans).  A graph can only
+# take them as inputs if it can see and re-point those tensors, so such a class declares them:
+#     graph_tensor_fields : names of its tensor attributes (copied into the graph's static buffers on every call)
+#     graph_static()      : hashable python state a step_fn may branch on (part of the graph's signature)
+#     map_tensors(fn)     : a new object with every declared tensor replaced by fn(tensor)
+def _is_graph_object(obj) -> bool:
+    return hasattr(obj, "graph_tensor_fields") and hasattr(obj, "map_tensors") and hasattr(obj, "graph_static")
+
+
 def _tensor_leaves(obj, path=()):
     """(path, tensor) for every tensor in a nest of dict / list / tuple (e.g. batch["geometry"]), in a fixed order."""
     if torch.is_tensor(obj):
         yield path, obj
+    elif _is_graph_object(obj):
+        for name in obj.graph_tensor_fields:
+            yield path + (name,), getattr(obj, name)
     elif isinstance(obj, dict):
         for k in sorted(obj, key=str):
             yield from _tensor_leaves(obj[k], path + (k,))
@@ -51,6 +63,8 @@ def _map_tensors(obj, fn):
         return {k: _map_tensors(v, fn) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
         return type(obj)(_map_tensors(v, fn) for v in obj)
+    if _is_graph_object(obj):
+        return obj.map_tensors(fn)
     return obj
 
 
@@ -64,6 +78,8 @@ def _scalar_leaves(obj, path=()):
             yield from _scalar_leaves(v, path + (i,))
     elif isinstance(obj, (bool, int, float)) and len(path) > 1:
         yield path, obj
+    elif _is_graph_object(obj):
+        yield path + ("graph_static",), obj.graph_static()
 
 
 def batch_signature(batch: Dict[str, Any], static_keys: Iterable[str] = ()) -> Tuple:
@@ -154,7 +170,8 @@ class GraphedTrainStep:
     # ------------------------------------------------------------------ capture
     def _capture(self, batch, sig) -> _Captured:
         for k, v in batch.items():
-            if not (torch.is_tensor(v) or v is None or isinstance(v, (str, int, float, bool, dict, list, tuple))):
+            if not (torch.is_tensor(v) or v is None or isinstance(v, (str, int, float, bool, dict, list, tuple))
+                    or _is_graph_object(v)):
                 raise ValueError(f"batch[{k!r}] ({type(v).__name__}) may hold device tensors whose addresses a graph "
                                  "would freeze; pass plain tensors (or dicts / lists of them) and let step_fn derive such objects")
         c = _Captured()
@@ -198,7 +215,7 @@ class GraphedTrainStep:
         for (_, dst), (_, src) in zip(_tensor_leaves(c.static), _tensor_leaves(batch)):
             dst.copy_(src, non_blocking=True)
         for k, v in batch.items():
-            if not isinstance(v, (torch.Tensor, dict, list, tuple)):
+            if not isinstance(v, (torch.Tensor, dict, list, tuple)) and not _is_graph_object(v):
                 c.static[k] = v                                   # plain metadata (scan id, ...) just rides along
         c.fwd_bwd.replay()
         if c.opt is not None:

@@ -117,16 +117,28 @@ class SceneBatch:
         self.num_scenes = self.node_ptr.numel() - 1
         counts_n = self.node_ptr[1:] - self.node_ptr[:-1]
         counts_e = self.edge_ptr[1:] - self.edge_ptr[:-1]
+        # host copies (the collate step builds the batch on the CPU: no device read-back later)
+        self.nodes_per_scene, self.edges_per_scene = counts_n.tolist(), counts_e.tolist()
         ids = torch.arange(self.num_scenes, device=self.node_ptr.device)
         self.node_scene = torch.repeat_interleave(ids, counts_n)
         self.edge_scene = torch.repeat_interleave(ids, counts_e)
 
-    def to(self, device):
+    # graph-input protocol of runtime.GraphedTrainStep: the tensors a captured step reads, the python state it branches on
+    graph_tensor_fields = ("node_ptr", "edge_ptr", "node_scene", "edge_scene")
+
+    def graph_static(self):
+        return (tuple(self.nodes_per_scene), tuple(self.edges_per_scene))
+
+    def map_tensors(self, fn):
         other = object.__new__(SceneBatch)
         other.num_scenes = self.num_scenes
-        for k in ("node_ptr", "edge_ptr", "node_scene", "edge_scene"):
-            setattr(other, k, getattr(self, k).to(device, non_blocking=True))
+        other.nodes_per_scene, other.edges_per_scene = self.nodes_per_scene, self.edges_per_scene
+        for k in self.graph_tensor_fields:
+            setattr(other, k, fn(getattr(self, k)))
         return other
+
+    def to(self, device):
+        return self.map_tensors(lambda t: t.to(device, non_blocking=True))
 
 
 class _SegmentBNReLU(Function):
@@ -145,6 +157,26 @@ class _SegmentBNReLU(Function):
         x, ptr, gamma, beta, mean, rstd = ctx.saved_tensors
         gx, dgamma, dbeta = _ext.segment_bn_rows_grad(g.contiguous(), x, ptr, gamma, beta, mean, rstd, ctx.relu, eps=ctx.eps)
         return gx, None, dgamma, dbeta, None, None
+
+
+class SegmentBatchNorm(Function):
+    """Per-scan BatchNorm1d returning the per-scan (mean, rstd) as well — for layers that keep running statistics (the
+    classification heads, pointnets/network_PointNet.py::scan_batch_norm)."""
+
+    @staticmethod
+    def forward(ctx, x, ptr, gamma, beta, eps):
+        x = x.contiguous()
+        y, mean, rstd = _ext.segment_bn_rows(x, ptr, gamma, beta, eps, False)
+        ctx.save_for_backward(x, ptr, gamma, beta, mean, rstd)
+        ctx.eps = eps
+        ctx.mark_non_differentiable(mean, rstd)
+        return y, mean, rstd
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gr):
+        x, ptr, gamma, beta, mean, rstd = ctx.saved_tensors
+        gx, dgamma, dbeta = _ext.segment_bn_rows_grad(g.contiguous(), x, ptr, gamma, beta, mean, rstd, False, eps=ctx.eps)
+        return gx, None, dgamma, dbeta, None
 
 
 def mlp_per_scene(mlp: torch.nn.Sequential, x: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:

@@ -8,7 +8,35 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from scene_graph_prediction.scene_graph_helpers.model.gcns.network_TripletGCN import SegmentBatchNorm
 from scene_graph_prediction.scene_graph_helpers.model.pointnets.networks_base import BaseNetwork
+
+
+def scan_batch_norm(bn: nn.BatchNorm1d, x, ptr):
+    """`bn(x)` for rows of S scans [ptr[s], ptr[s+1]): in training mode the batch statistics are per scan and the running
+    statistics receive the S updates of S single-scan steps, in scan order (momentum EMA, unbiased variance —
+    torch.nn.functional.batch_norm); in eval mode (running statistics) it is plain `bn(x)`."""
+    if ptr is None or not (bn.training or bn.running_mean is None):
+        return bn(x)
+    y, mean, rstd = SegmentBatchNorm.apply(x, ptr, bn.weight, bn.bias, bn.eps)
+    if bn.running_mean is not None:
+        with torch.no_grad():
+            n = (ptr[1:] - ptr[:-1]).to(x.dtype).unsqueeze(1)                      # rows per scan
+            var = (1.0 / (rstd * rstd) - bn.eps).clamp_min(0) * n / (n - 1).clamp_min(1)
+            S = mean.size(0)
+            if bn.momentum is None:                                                # cumulative average
+                for s in range(S):
+                    bn.num_batches_tracked += 1
+                    f = 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.lerp_(mean[s], f)
+                    bn.running_var.lerp_(var[s], f)
+            else:
+                m = float(bn.momentum)
+                w = m * (1.0 - m) ** torch.arange(S - 1, -1, -1, device=x.device, dtype=x.dtype)   # weight of scan s
+                bn.running_mean.mul_((1.0 - m) ** S).add_((w.unsqueeze(1) * mean).sum(0))
+                bn.running_var.mul_((1.0 - m) ** S).add_((w.unsqueeze(1) * var).sum(0))
+                bn.num_batches_tracked += S
+    return y
 
 
 class _Head(BaseNetwork):
@@ -16,16 +44,16 @@ class _Head(BaseNetwork):
         self.fc1 = nn.Linear(in_size, 512)
         self.fc2 = nn.Linear(512, 256)
 
-    def _trunk(self, x, use_bn):
+    def _trunk(self, x, use_bn, scan_ptr=None):
         x = self.fc1(x)
         if use_bn:
-            x = self.bn1(x)
+            x = scan_batch_norm(self.bn1, x, scan_ptr)
         x = self.relu(x)
         x = self.fc2(x)
         if self.use_drop_out:
             x = self.dropout(x)
         if use_bn:
-            x = self.bn2(x)
+            x = scan_batch_norm(self.bn2, x, scan_ptr)
         return self.relu(x)
 
 
@@ -47,8 +75,9 @@ class PointNetCls(_Head):
             self.init_weights("constant", 1, target_op="BatchNorm")
             self.init_weights("xavier_normal", 1)
 
-    def forward(self, x):
-        return F.log_softmax(self.fc3(self._trunk(x, self.use_batch_norm)), dim=1)
+    def forward(self, x, scan_ptr=None):
+        """`scan_ptr` (S+1 row offsets, optional): the rows are S scans and training-mode BatchNorm statistics are per scan."""
+        return F.log_softmax(self.fc3(self._trunk(x, self.use_batch_norm, scan_ptr)), dim=1)
 
 
 class PointNetRelCls(_Head):
@@ -70,8 +99,8 @@ class PointNetRelCls(_Head):
             self.init_weights("constant", 1, target_op="BatchNorm")
             self.init_weights("xavier_normal", 1)
 
-    def forward(self, x, relation_objects_one_hot=None, image_embeddings=None):
-        x = self._trunk(x, self.use_bn)
+    def forward(self, x, relation_objects_one_hot=None, image_embeddings=None, scan_ptr=None):
+        x = self._trunk(x, self.use_bn, scan_ptr)
         if image_embeddings is not None:            # late fusion of the scene-level image embedding
             x = torch.cat([x, image_embeddings.unsqueeze(0).repeat(len(x), 1)], dim=1)
         if relation_objects_one_hot is not None:    # late fusion of subject/object classes

@@ -19,6 +19,7 @@ offline) is out of scope, but everything after it is here — ``full_image_featu
 was attached with ``attach_image_model``).  The batch then carries either ``full_image`` (6,3,H,W; needs an attached
 CNN) or ``full_image_features`` (6, num_features) computed by it ahead of time.
 """
+import contextlib
 from collections import defaultdict
 
 import torch
@@ -26,6 +27,7 @@ import torch.nn.functional as F
 import torch.optim as optim
 from torch import nn
 
+from pointnet2_ops.pointnet2_modules import per_scan_statistics
 from scene_graph_prediction.scene_graph_helpers.model.gcns.network_TripletGCN import TripletGCNModel
 from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet import PointNetCls, PointNetRelCls
 from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet2 import PointNetfeat as PointNetfeat2
@@ -109,25 +111,36 @@ class SGPNModelWrapper(nn.Module):
         return {"obj": self.obj_encoder.precompute_geometry(batch["obj_points"]),
                 "rel": self.rel_encoder.precompute_geometry(batch["rel_points"])}
 
+    #: Batched scans in TRAINING mode: BatchNorm batch statistics per scan everywhere (encoders, GCN, heads), i.e. the
+    #: arithmetic of S single-scan steps of the reference (main.py:54-56) with their gradients averaged.  False: the encoders
+    #: and heads normalise over the whole batch (fewer launches, a different — larger-batch — BatchNorm).
+    per_scan_statistics = True
+
     def forward(self, batch, return_meta_data=False):
         geo = batch.get("geometry")
-        obj_feature = self.obj_encoder(batch["obj_points"], geometry=None if geo is None else geo["obj"])
-        rel_feature = self.rel_encoder(batch["rel_points"], geometry=None if geo is None else geo["rel"])
         scenes = batch.get("scenes")          # block-diagonal batch of several scans (dataset/synthetic.py::collate_scans)
+        per_scan = scenes is not None and scenes.num_scenes > 1 and self.training and self.per_scan_statistics
+        node_ptr = scenes.node_ptr if per_scan else None
+        edge_ptr = scenes.edge_ptr if per_scan else None
+        with (per_scan_statistics(scenes.nodes_per_scene, scenes.edges_per_scene) if per_scan else contextlib.nullcontext()):
+            obj_feature = self.obj_encoder(batch["obj_points"], geometry=None if geo is None else geo["obj"])
+            rel_feature = self.rel_encoder(batch["rel_points"], geometry=None if geo is None else geo["rel"])
         gcn_obj_feature, gcn_rel_feature = self.gcn(obj_feature, rel_feature, batch["edge_indices"], batch.get("edge_csr"),
                                                     scenes=scenes)
-        obj_cls = self.obj_predictor(gcn_obj_feature if self.mconfig["OBJ_PRED_FROM_GCN"] else obj_feature)
+        obj_cls = self.obj_predictor(gcn_obj_feature if self.mconfig["OBJ_PRED_FROM_GCN"] else obj_feature,
+                                     scan_ptr=node_ptr)
         if self.with_images:
             emb = self._image_embedding(batch)
             if emb.dim() == 2:                                      # batched scans: every edge gets its own scan's embedding
                 emb = emb[scenes.edge_scene]
                 rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=torch.cat(
-                    [emb, batch["relation_objects_one_hot"]], dim=1))
+                    [emb, batch["relation_objects_one_hot"]], dim=1), scan_ptr=edge_ptr)
             else:
                 rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=batch["relation_objects_one_hot"],
-                                             image_embeddings=emb)
+                                             image_embeddings=emb, scan_ptr=edge_ptr)
         else:
-            rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=batch["relation_objects_one_hot"])
+            rel_cls = self.rel_predictor(gcn_rel_feature, relation_objects_one_hot=batch["relation_objects_one_hot"],
+                                         scan_ptr=edge_ptr)
         if return_meta_data:
             return obj_cls, rel_cls, obj_feature, rel_feature, gcn_obj_feature, gcn_rel_feature, None
         return obj_cls, rel_cls

@@ -348,6 +348,7 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     trainable = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(trainable, lr=float(cfg["LR"]), weight_decay=float(cfg["W_DECAY"]), capturable=args.graphs)
     S = max(1, int(args.scans_per_step))
+    model.per_scan_statistics = not args.whole_batch_statistics
     fused = None
     if args.with_prep:
         # end to end: every step first cuts this step's scans out of resident fused room clouds (300k points, 9
@@ -465,9 +466,12 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2] shape: SGPNModelWrapper(no_gt.json), {S} synthetic scan(s) per step "
-                                      "and rank (block-diagonal batch: per-scan GCN BatchNorm statistics and loss average; "
-                                      "SA BatchNorm2d statistics over the step's clouds), train mode, fwd + weighted NLL + bwd + AdamW",
-                          "scans_per_step": S,
+                                      "and rank (block-diagonal batch, loss = mean of the per-scan losses; BatchNorm batch "
+                                      "statistics " + ("per scan in encoders, GCN and heads = the arithmetic of single-scan steps"
+                                                       if model.per_scan_statistics or S == 1 else
+                                                       "per scan in the GCN, over the whole step's clouds in encoders and heads") +
+                                      "), train mode, fwd + weighted NLL + bwd + AdamW",
+                          "scans_per_step": S, "per_scan_statistics": bool(model.per_scan_statistics or S == 1),
                           "with_gpu_preparation": bool(args.with_prep),
                           "parallelism": f"dp{world}", "hip_graphs": bool(args.graphs),
                           "host_enqueue_ms_per_step": round(enqueue_ms, 3),
@@ -516,6 +520,10 @@ def main():
                          "counterpart of the reference's 16-bit AMP (bf16 activations and MFMA, fp32 weights and statistics)")
     ap.add_argument("--scans-per-step", type=int, default=1,
                     help="sgp workload: scans per step and rank, collated block-diagonally (BASELINE configs[2] names 32)")
+    ap.add_argument("--whole-batch-statistics", action="store_true",
+                    help="sgp workload with several scans per step: encoders and heads normalise over all the step's clouds "
+                         "(a larger BatchNorm batch, fewer launches) instead of per scan (default: per scan = the arithmetic "
+                         "of single-scan steps of the reference with their gradients averaged)")
     ap.add_argument("--graphs", action="store_true",
                     help="sgp workload: replay the whole step as one hipGraph (runtime.GraphedTrainStep); gradients are "
                          "averaged with one flat all-reduce between the backward and the optimizer graph when N > 1")

@@ -225,3 +225,58 @@ def test_lifted_first_linear_equals_concat(oracle_backend, monkeypatch, n_nodes)
         scale = max(1.0, float(r.abs().max()))
         err_c, err_l = float((c.double() - r).abs().max()) / scale, float((l.double() - r).abs().max()) / scale
         assert err_l <= max(2e-5, 4 * err_c), (err_l, err_c)
+
+
+def test_batched_training_with_per_scan_statistics_equals_single_scan_steps(oracle_backend, monkeypatch):
+    """TRAINING mode: a block-diagonal batch of S scans with `per_scan_statistics` (default) is the arithmetic of S
+    single-scan steps of the reference (main.py:54-56) — every BatchNorm (SA shared MLPs, GCN, heads) normalises with the
+    statistics of ONE scan; loss = mean of the per-scan losses, gradients = mean of the per-scan gradients, running
+    statistics = the S momentum updates in scan order.  Dropout is switched off (its random stream differs)."""
+    import copy
+    from scene_graph_prediction.main import RELATION_NAMES, config_loader
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as g
+    from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+    monkeypatch.setattr(g, "LIFT_MIN_EDGES", 1 << 60)             # literal concat form: row-for-row the same CPU arithmetic
+    torch.manual_seed(0)
+    m = SGPNModelWrapper(config_loader("no_gt.json"), 12, 15, torch.rand(12) + 0.5, torch.rand(15) + 0.5, RELATION_NAMES).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    single = copy.deepcopy(m)
+    scans = [synthetic_scan(n, 300, 400, seed=i, scan_id=f"s{i}") for i, n in enumerate([5, 4, 6])]
+    batch = collate_scans(scans)
+    obj, rel = m(batch)
+    loss = m.loss(obj, rel, batch)
+    loss.backward()
+    outs, total = [], 0.0
+    for s in scans:
+        o, r = single(s)
+        l = single.loss(o, r, s) / len(scans)
+        l.backward()
+        outs.append((o.detach(), r.detach()))
+        total += float(l.detach())
+    assert abs(float(loss.detach()) - total) < 1e-5
+    torch.testing.assert_close(obj.detach(), torch.cat([o for o, _ in outs]), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(rel.detach(), torch.cat([r for _, r in outs]), atol=1e-4, rtol=1e-4)
+    grads = dict(single.named_parameters())
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            want = grads[n].grad
+            assert float((p.grad - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), n
+    # running statistics after the step: S sequential momentum updates == the batched closed form
+    stats = dict(single.named_buffers())
+    checked = stepped = 0
+    for n, b in m.named_buffers():
+        if n.endswith("running_mean") or n.endswith("running_var"):
+            torch.testing.assert_close(b, stats[n], atol=1e-5, rtol=1e-4)
+            checked += 1
+        elif n.endswith("num_batches_tracked"):
+            assert int(b) == int(stats[n])                          # (layers outside the feature path never run: 0)
+            stepped += int(b) == len(scans)
+    assert checked >= 10 and stepped >= 10
+    # and the whole-batch mode is a DIFFERENT BatchNorm (sanity: the switch does something)
+    m2 = copy.deepcopy(single)
+    m2.per_scan_statistics = False
+    o2, _ = m2(batch)
+    assert float((o2.detach() - obj.detach()).abs().max()) > 1e-3

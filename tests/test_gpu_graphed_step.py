@@ -109,3 +109,29 @@ def test_geometry_prefetcher_yields_identical_steps():
             assert torch.equal(a_obj, b_obj) and torch.equal(a_rel, b_rel)
             seen += 1
     assert seen == len(scans)
+
+
+def test_block_diagonal_batches_are_graph_inputs():
+    """A collated batch of scans carries a SceneBatch object (row offsets on the device + per-scan counts on the host): its
+    tensors are copied into the graph's static buffers like any other input, its counts are part of the signature.  Replays
+    with DIFFERENT scans of the same shape reproduce each batch's own eager gradient (per-scan statistics in training)."""
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans
+    model = _model()
+    ref = copy.deepcopy(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    stepper = GraphedTrainStep(model.pure_training_step, params, torch.optim.SGD(params, lr=0.0))
+    batches = [to_device(collate_scans([synthetic_scan(9, 512, 1024, seed=3 * k + i) for i in range(2)]), "cuda") for k in range(4)]
+    other = to_device(collate_scans([synthetic_scan(n, 512, 1024, seed=40 + n) for n in (8, 10)]), "cuda")   # same totals? no: 18 nodes
+    for i, batch in enumerate(batches):
+        loss, _ = stepper(batch)
+        ref.zero_grad(set_to_none=True)
+        rl, _ = ref.pure_training_step(batch)
+        rl.backward()
+        want = torch.cat([p.grad.flatten() for p in ref.parameters() if p.requires_grad])
+        assert abs(float(loss) - float(rl.detach())) < 1e-3, i
+        assert _rel(stepper.grads.flat, want) < 3e-2, i
+    assert stepper.num_graphs == 1
+    # 8 + 10 objects: the same 18 node rows but other per-scan counts (and 56 + 90 edges): a different signature
+    stepper(other)
+    stepper(other)
+    assert stepper.num_graphs == 2

@@ -346,6 +346,55 @@ def test_batched_scans_on_gpu_equal_single_scan_steps():
     assert m.predict_step(batch) == [m.predict_step(to_device(s, "cuda")) for s in scans]
 
 
+def test_batched_training_on_gpu_with_per_scan_statistics_equals_single_scan_steps():
+    """TRAINING mode on the HIP path: S scans per step with `per_scan_statistics` (default) == S single-scan steps of the
+    reference's loop (main.py:54-56): log-probabilities, mean loss, averaged gradients, running statistics after the S
+    momentum updates.  Dropout off (its random stream differs between one call and S calls)."""
+    from scene_graph_prediction.main import RELATION_NAMES, config_loader
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan, to_device
+    from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+    torch.manual_seed(0)
+    m = SGPNModelWrapper(config_loader("no_gt.json"), 12, 15, torch.rand(12) + 0.5, torch.rand(15) + 0.5,
+                         RELATION_NAMES).cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    single = copy.deepcopy(m)
+    scans = [synthetic_scan(n, 1024, 2048, seed=i, scan_id=f"s{i}") for i, n in enumerate([5, 9, 4, 7, 6, 9, 8, 5])]
+    batch = to_device(collate_scans(scans), "cuda")
+    obj, rel = m(batch)
+    loss = m.loss(obj, rel, batch)
+    loss.backward()
+    outs, total = [], 0.0
+    for s in scans:
+        sd = to_device(s, "cuda")
+        o, r = single(sd)
+        l = single.loss(o, r, sd) / len(scans)
+        l.backward()
+        outs.append((o.detach(), r.detach()))
+        total += float(l.detach())
+    e_obj = float((obj.detach() - torch.cat([o for o, _ in outs])).abs().max())
+    e_rel = float((rel.detach() - torch.cat([r for _, r in outs])).abs().max())
+    print(f"\n[batched training] log-prob max abs err: objects {e_obj:.3e}, relations {e_rel:.3e}; loss {float(loss):.6f} vs {total:.6f}")
+    assert e_obj <= 2e-4 and e_rel <= 2e-4            # train-mode BatchNorm over 4-9 rows on top of the eval-mode 1e-4
+    assert abs(float(loss.detach()) - total) < 1e-5
+    want = dict(single.named_parameters())
+    top = max(float(p.grad.norm()) for p in single.parameters() if p.grad is not None)
+    errs = sorted(((float((p.grad - want[n].grad).norm() / want[n].grad.norm()), n) for n, p in m.named_parameters()
+                   if p.grad is not None and float(want[n].grad.norm()) > 1e-4 * top), reverse=True)
+    print(f"[batched training] worst gradient rel-L2 {errs[0][0]:.3e} ({errs[0][1]})")
+    assert errs[0][0] <= 6e-2                         # same conditioning-aware bound as the eval-mode test above
+    stats = dict(single.named_buffers())
+    for n, b in m.named_buffers():
+        if n.endswith("running_mean") or n.endswith("running_var"):
+            torch.testing.assert_close(b, stats[n], atol=1e-4, rtol=1e-3)
+        elif n.endswith("num_batches_tracked"):
+            assert int(b) == int(stats[n])
+    m.per_scan_statistics = False                      # the whole-batch mode is a different BatchNorm
+    o2, _ = m(batch)
+    assert float((o2.detach() - obj.detach()).abs().max()) > 1e-3
+
+
 # ------------------------------------------------------------------------------------------------- cell-list ball query
 def _bq_cloud(B, N, kind, seed):
     g = torch.Generator().manual_seed(seed)
