@@ -881,7 +881,11 @@ void launch_by_width(const GemmArgs &a, int tiles, hipStream_t s) {
       launch_one<2, 16, 2, PRO, EPI>(a, s, 768);
     }
     else if (tiles <= 6) launch_one<3, 16, 2, PRO, EPI>(a, s);
-    else if (tiles <= 8 || tiles > 10) launch_one<4, 16, 2, PRO, EPI>(a, s);   // > 10: column blocks of 256
+    // 7-8 tiles (N = 256): TWO column blocks of the 128-column variant above instead of one 256-column workgroup (4 tiles
+    // per wave, 87+ VGPRs, grid 512) — A is read twice (the second time from L2), but three workgroups per CU stay
+    // resident: 17.37 -> 17.14 ms/step, the 256-wide layers of SA3 / SA4 / FP 0.317 -> 0.206, 0.140 -> 0.111, 0.119 -> 0.087 ms
+    else if (tiles <= 8) launch_one<2, 16, 2, PRO, EPI>(a, s, 768);
+    else if (tiles > 10) launch_one<4, 16, 2, PRO, EPI>(a, s);   // > 10: column blocks of 256
     else launch_one<5, 16, 2, PRO, EPI>(a, s);
   }
 }
