@@ -250,19 +250,23 @@ def roofline_of(top, pmc_applies=True):
         roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"]}
     traffic, traffic_src = None, None
-    tf = os.path.join(REPO, "profiles", "r01_hbm_traffic_per_kernel.json")
     kname = {"pn2_mlp_gemm": "mlp_gemm_kernel", "pn2_mlp_wgrad": "mlp_wgrad_kernel",
              "pn2_mlp_bwd_fused": "mlp_bwd_fused_kernel", "pn2_mlp_bwd_fused_fold": "mlp_bwd_fused2_kernel",
              "pn2_bn_relu_rows_max": "bn_relu_rows_max_kernel",
-             "pn2_group_concat_rows": "group_concat_rows_kernel",
-             "pn2_group_rows_grad": "group_rows_grad_kernel"}.get(top["kernel"])
-    if pmc_applies and kname and os.path.exists(tf):
+             "pn2_group_concat_rows": "group_concat_rows_wide4_kernel",
+             "pn2_group_rows_grad": "group_rows_grad_csr_kernel"}.get(top["kernel"])
+    # newest committed counter summary of the default command first (tools/profile_round.sh + tools/summarise_profile.py)
+    for fname, key, scale in (("r02_backbone_counters.json", "hbm_MB_per_launch", 1e6),
+                              ("r01_hbm_traffic_per_kernel.json", "hbm_bytes_per_launch", 1.0)):
+        tf = os.path.join(REPO, "profiles", fname)
+        if not (pmc_applies and kname and os.path.exists(tf)) or traffic is not None:
+            continue
         try:
             rec = json.load(open(tf))["kernels"].get(kname)
-            if rec:
-                traffic = int(rec["hbm_bytes_per_launch"])
+            if rec and rec.get(key):
+                traffic = int(rec[key] * scale)
                 traffic_src = ("PMC FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE per launch, separate rocprofv3 "
-                               "passes over this command: profiles/r01_hbm_traffic_per_kernel.json")
+                               f"passes over this command: profiles/{fname}")
         except Exception:
             pass
     roof.update({"traffic": traffic, "traffic_source": traffic_src,
