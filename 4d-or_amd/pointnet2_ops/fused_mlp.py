@@ -134,7 +134,8 @@ class _FusedMLP(Function):
                 y = e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
                 momentum = 0.0
                 rm = rv = nbt = None
-                if bn.training and bn.track_running_stats and bn.running_mean is not None:
+                if (bn.training and bn.track_running_stats and bn.running_mean is not None
+                        and not getattr(ctx, "defer_running", False)):     # (a segmented call updates them itself, in scan order)
                     rm, rv = bn.running_mean, bn.running_var
                     if bn.momentum is not None:
                         momentum, nbt = bn.momentum, bn.num_batches_tracked       # counter bumped by the finalize kernel
@@ -290,7 +291,8 @@ class _FusedMLPBf16(Function):
                 y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
                 momentum = 0.0
                 rm = rv = nbt = None
-                if bn.training and bn.track_running_stats and bn.running_mean is not None:
+                if (bn.training and bn.track_running_stats and bn.running_mean is not None
+                        and not getattr(ctx, "defer_running", False)):     # (a segmented call updates them itself, in scan order)
                     rm, rv = bn.running_mean, bn.running_var
                     if bn.momentum is not None:
                         momentum, nbt = bn.momentum, bn.num_batches_tracked
@@ -394,6 +396,161 @@ class _FusedMLPBf16(Function):
         return (gx, None, None, None, *grads)
 
 
+class _SegCtx:
+    """What _FusedMLP / _FusedMLPBf16 need from an autograd ctx, for one scan of a segmented call."""
+    defer_running = True        # the scans may run concurrently: running statistics are updated after all of them
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+_EMA_WEIGHTS = {}
+
+
+def _ema_weights(device, dtype, momentum, rows_per_scan):
+    """(w (S,1): weight of scan s's statistic after S momentum updates, u (S,1): biased -> unbiased variance factor).
+    Cached per configuration: built from host numbers (a copy), which a stream capture does not allow — the first,
+    eager call of a step signature creates them, replays find them."""
+    key = (device, dtype, momentum, tuple(rows_per_scan))
+    hit = _EMA_WEIGHTS.get(key)
+    if hit is None:
+        S = len(rows_per_scan)
+        w = [0.0 if momentum is None else momentum * (1.0 - momentum) ** (S - 1 - s) for s in range(S)]
+        u = [n / max(n - 1, 1) for n in rows_per_scan]
+        hit = _EMA_WEIGHTS[key] = (torch.tensor(w, dtype=dtype, device=device).unsqueeze(1),
+                                   torch.tensor(u, dtype=dtype, device=device).unsqueeze(1))
+    return hit
+
+
+def _update_running_stats(layers, subs, rows_per_scan):
+    """The running statistics after S single-scan training steps, in scan order, from the scans' batch statistics
+    (`fin` rows 0 / 1 = mean / rstd of the finalize kernel): running <- (1 - m) running + m stat, S times, closed form
+    (momentum None = cumulative average: a loop); unbiased variance like torch.nn.functional.batch_norm."""
+    L, S = len(layers), len(subs)
+    with torch.no_grad():
+        for l, (_, bn) in enumerate(layers):
+            if not (bn.training and bn.track_running_stats and bn.running_mean is not None):
+                continue
+            fins = [sub.saved_tensors[1 + L + l] for sub in subs]
+            mean = torch.stack([f[0] for f in fins])                                     # (S, C)
+            rstd = torch.stack([f[1] for f in fins])
+            w, unbias = _ema_weights(mean.device, mean.dtype, None if bn.momentum is None else float(bn.momentum),
+                                     rows_per_scan)
+            var = (1.0 / (rstd * rstd) - bn.eps).clamp_min(0) * unbias
+            if bn.momentum is None:
+                for s in range(S):
+                    bn.num_batches_tracked += 1
+                    f = 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.lerp_(mean[s], f)
+                    bn.running_var.lerp_(var[s], f)
+            else:
+                mom = float(bn.momentum)
+                bn.running_mean.mul_((1.0 - mom) ** S).add_((w * mean).sum(0))
+                bn.running_var.mul_((1.0 - mom) ** S).add_((w * var).sum(0))
+                bn.num_batches_tracked += S
+
+
+#: streams the scans of a segmented call are spread over (1 = all on the calling stream).  One scan's layer chain is
+#: ~20 dependent kernels of 10-90 us each — most of them too small to fill 256 CUs and all of them paying their launch
+#: latency in series; the scans are independent, so chains on different streams overlap on the chip.
+SEGMENT_STREAMS = 2
+_WORKERS = {}
+
+
+def _worker_streams(device, n):
+    """n - 1 side streams per device (created once, high priority like the geometry prefetch stream: default-priority
+    streams can share a hardware queue with the calling stream, profiles/r02_stream_queue_aliasing.md)."""
+    pool = _WORKERS.setdefault(device, [])
+    while len(pool) < n - 1:
+        pool.append(torch.cuda.Stream(device=device, priority=-1))
+    return pool[:n - 1]
+
+
+class _Fork:
+    """Round-robin scans over the calling stream and the worker streams; `join()` makes the calling stream wait for all
+    of them.  Tensors a worker allocated and the calling stream reads afterwards are registered with the allocator
+    (record_stream), or their blocks could be handed out again on the worker while the calling stream still reads them."""
+
+    def __init__(self, device, n_scans):
+        self.main = torch.cuda.current_stream(device)
+        n = max(1, min(int(SEGMENT_STREAMS), n_scans)) if device.type == "cuda" else 1
+        self.streams = [self.main] + (_worker_streams(device, n) if n > 1 else [])
+        if len(self.streams) > 1:
+            start = torch.cuda.Event()
+            start.record(self.main)
+            for st in self.streams[1:]:
+                st.wait_event(start)
+
+    def stream(self, s):
+        return self.streams[s % len(self.streams)]
+
+    def join(self, *tensor_lists):
+        for st in self.streams[1:]:
+            self.main.wait_stream(st)
+        if len(self.streams) > 1:
+            for tensors in tensor_lists:
+                for t in tensors:
+                    if t is not None:
+                        t.record_stream(self.main)
+
+
+class _SegmentedGroupMLP(Function):
+    """fused_group_mlp_pool over a batch of S scans with PER-SCAN BatchNorm statistics, as ONE autograd node: the clouds
+    [c_s, c_{s+1}) of every scan run through the inner node (own batch statistics) and the S results are concatenated; the
+    running statistics then receive the S momentum updates in scan order (_update_running_stats).  Equivalent to S
+    separate nodes + split/cat (pointnet2_modules.sa_scale_rows without the fused kernels does exactly that) — but the
+    scans' kernel chains are issued on SEGMENT_STREAMS streams so that they overlap on the GPU."""
+
+    @staticmethod
+    def forward(ctx, x, ns, layers, group, sizes, inner, *params):
+        xyz, new_xyz, idx, use_xyz, normalize, radius = group
+        m = idx.size(1)
+        fork = _Fork(idx.device, len(sizes))
+        subs, outs, args, c0 = [], [], [], 0
+        for s, n_clouds in enumerate(sizes):
+            c1 = c0 + n_clouds
+            sub = _SegCtx((ctx.needs_input_grad[0],))
+            g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius)
+            with torch.cuda.stream(fork.stream(s)):
+                out, arg = inner.forward(sub, None if x is None else x[c0:c1], ns, layers, g, *params)
+            subs.append(sub)
+            outs.append(out)
+            args.append(arg)
+            c0 = c1
+        fork.join(outs, args)
+        ctx.subs, ctx.inner, ctx.rows = subs, inner, [n * m for n in sizes]
+        _update_running_stats(layers, subs, [n * m * ns for n in sizes])
+        out, arg = torch.cat(outs, 0), torch.cat(args, 0)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, g_out, *unused):
+        g_out = g_out.contiguous()
+        fork = _Fork(g_out.device, len(ctx.subs))
+        gxs, pgs, r0 = [], [], 0
+        for s, (sub, rows) in enumerate(zip(ctx.subs, ctx.rows)):
+            with torch.cuda.stream(fork.stream(s)):      # the stream this scan's forward ran on (same round-robin)
+                res = ctx.inner.backward(sub, g_out[r0:r0 + rows])
+            r0 += rows
+            gxs.append(res[0])
+            pgs.append(list(res[4:]))
+        fork.join(gxs, *pgs)
+        acc = pgs[0]
+        for pg in pgs[1:]:                                          # one multi-tensor add per scan
+            torch._foreach_add_(acc, pg)
+        ctx.subs = None
+        gx = None if gxs[0] is None else torch.cat(gxs, 0)
+        return (gx, None, None, None, None, None, *acc)
+
+
 def _node(layers, ns):
     """The autograd node for the current arithmetic (set_mlp_dtype) that covers this stack."""
     if _MLP_DTYPE == torch.bfloat16 and getattr(_ext(), "HAS_BF16_MLP", False) and _bf16_ok(layers, ns):
@@ -416,12 +573,20 @@ def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0) -> torch.Tens
     return res[0] if ns else res
 
 
-def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius) -> torch.Tensor:
+def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius,
+                         clouds_per_scan: Optional[Sequence[int]] = None) -> torch.Tensor:
     """Ball-query neighbourhoods -> shared MLP -> max, one autograd node:
-    xyz (B,N,3), new_xyz (B,m,3), feats_rows (B,N,C)|None, idx (B,m,ns) -> (B, m, C_out)."""
+    xyz (B,N,3), new_xyz (B,m,3), feats_rows (B,N,C)|None, idx (B,m,ns) -> (B, m, C_out).
+    `clouds_per_scan` (sums to B): BatchNorm batch statistics per scan (see _SegmentedGroupMLP)."""
     layers = parse_stack(mlp)
     assert layers is not None
     B, m, ns = idx.shape
     group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius)
-    res = _node(layers, ns).apply(feats_rows, int(ns), layers, group, *_params(layers))
+    if clouds_per_scan is not None and len(clouds_per_scan) > 1:
+        if sum(clouds_per_scan) != B:
+            raise RuntimeError("fused_group_mlp_pool: clouds_per_scan must sum to the number of clouds")
+        res = _SegmentedGroupMLP.apply(None if feats_rows is None else feats_rows.contiguous(), int(ns), layers, group,
+                                       tuple(int(v) for v in clouds_per_scan), _node(layers, ns), *_params(layers))
+    else:
+        res = _node(layers, ns).apply(feats_rows, int(ns), layers, group, *_params(layers))
     return res[0].view(B, m, -1)

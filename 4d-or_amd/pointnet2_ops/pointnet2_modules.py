@@ -151,6 +151,13 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
     from pointnet2_ops import fused_mlp
     sizes = None if _whole_batch else _SCAN_SEGMENTS.get(xyz.size(0))
     if sizes is not None and _trains_batchnorm(mlp):
+        if (_FUSED_MLP and isinstance(grouper, pointnet2_utils.QueryAndGroup) and new_xyz is not None
+                and (grouper.use_xyz or feats_rows is not None)
+                and fused_mlp.supported(mlp, xyz if feats_rows is None else feats_rows, grouper.nsample)):
+            if idx is None:
+                idx = grouper.query(xyz, new_xyz)
+            return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
+                                                  grouper.normalize_xyz, grouper.radius, clouds_per_scan=sizes)
         split = lambda t: [None] * len(sizes) if t is None else t.split_with_sizes(sizes)
         parts = [sa_scale_rows(grouper, mlp, x, nx, f, i, _whole_batch=True)
                  for x, nx, f, i in zip(split(xyz), split(new_xyz), split(feats_rows), split(idx))]

@@ -353,6 +353,9 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     opt = torch.optim.AdamW(trainable, lr=float(cfg["LR"]), weight_decay=float(cfg["W_DECAY"]), capturable=args.graphs)
     S = max(1, int(args.scans_per_step))
     model.per_scan_statistics = not args.whole_batch_statistics
+    if args.segment_streams is not None:
+        from pointnet2_ops import fused_mlp
+        fused_mlp.SEGMENT_STREAMS = max(1, int(args.segment_streams))
     fused = None
     if args.with_prep:
         # end to end: every step first cuts this step's scans out of resident fused room clouds (300k points, 9
@@ -528,6 +531,9 @@ def main():
                     help="sgp workload with several scans per step: encoders and heads normalise over all the step's clouds "
                          "(a larger BatchNorm batch, fewer launches) instead of per scan (default: per scan = the arithmetic "
                          "of single-scan steps of the reference with their gradients averaged)")
+    ap.add_argument("--segment-streams", type=int, default=None,
+                    help="sgp workload with per-scan statistics: streams the scans' shared-MLP chains are spread over "
+                         "(pointnet2_ops.fused_mlp.SEGMENT_STREAMS; default: the library's setting)")
     ap.add_argument("--graphs", action="store_true",
                     help="sgp workload: replay the whole step as one hipGraph (runtime.GraphedTrainStep); gradients are "
                          "averaged with one flat all-reduce between the backward and the optimizer graph when N > 1")

@@ -14,15 +14,17 @@ import bench  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "backbone"
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-if which == "sgp":
+if which.startswith("sgp"):
     from scene_graph_prediction.main import RELATION_NAMES, config_loader
-    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import synthetic_scan, to_device
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan, to_device
     from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
     cfg = config_loader("no_gt.json")
     model = SGPNModelWrapper(cfg, 12, len(RELATION_NAMES), torch.ones(12), torch.ones(len(RELATION_NAMES)),
                              RELATION_NAMES).to(dev).train()
     opt = torch.optim.AdamW([p for p in model.parameters()], lr=1e-4)
-    scan = to_device(synthetic_scan(9, 4000, 8000, seed=1), dev)
+    S = int(which[3:] or 1)                      # "sgp8": eight scans per step, per-scan statistics
+    scan = to_device(synthetic_scan(9, 4000, 8000, seed=1), dev) if S == 1 else to_device(
+        collate_scans([synthetic_scan(9, 4000, 8000, seed=i) for i in range(S)]), dev)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -47,4 +49,4 @@ for _ in range(10):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+st.sort_stats("tottime").print_stats(28)
