@@ -303,3 +303,30 @@ def test_group_rows_grad_csr_empty_and_unreferenced_points(ext):
     ptr, refs = ext.group_inverse_index(dev(idx), 10)
     got = ext.group_rows_grad_csr(dev(go), (ptr, refs), 10, 8, 0).cpu()
     assert torch.equal(got[:, 0], torch.full((2, 8), 12.0)) and float(got[:, 1:].abs().max()) == 0.0
+
+
+def test_new_entry_points_reject_bad_arguments(ext):
+    """C-ABI argument checks of the round-2 entry points: negative codes, no launch, no exit."""
+    lib = ext._lib
+    idx = torch.zeros(2, 3, 4, dtype=torch.int32).cuda()
+    ptr = torch.empty(2 * 10 + 1, dtype=torch.int32).cuda()
+    refs = torch.empty(24, dtype=torch.int32).cuda()
+    need = int(lib.pn2_group_inverse_index_workspace_bytes(2, 10, 3, 4))
+    assert need > 0
+    ws = torch.empty(need + 512, dtype=torch.uint8).cuda()
+    p = lambda t: t.data_ptr()
+    assert lib.pn2_group_inverse_index(2, 10, 3, 4, p(idx), p(ptr), p(refs), p(ws), need - 1, None) == -4      # PN2_ENOSPC
+    assert lib.pn2_group_inverse_index(2, 10, 3, 4, p(idx), p(ptr), p(refs), p(ws) + 4, need, None) == -1      # alignment
+    assert lib.pn2_group_inverse_index(2, 10, 3, 4, p(idx), None, p(refs), p(ws), need, None) == -2            # PN2_ENULL
+    assert lib.pn2_group_inverse_index(-1, 10, 3, 4, p(idx), p(ptr), p(refs), p(ws), need, None) == -1
+    go = torch.zeros(2, 3, 4, 8).cuda()
+    out = torch.empty(2, 10, 8).cuda()
+    assert lib.pn2_group_rows_grad_csr(2, 10, 8, 4, 0, 24, p(go), p(ptr), p(refs), p(out), None) == -1         # ldg < col0 + C
+    assert lib.pn2_group_rows_grad_csr(2, 10, 8, 8, 0, 24, p(go), None, p(refs), p(out), None) == -2
+    gb = torch.zeros(2, 3, 4, 7, dtype=torch.bfloat16).cuda()
+    assert lib.pn2_group_rows_grad_bf16(2, 10, 3, 4, 7, 7, 0, p(gb), p(idx), p(out), None) == -1                # odd C
+    q, pp = torch.zeros(5, 6).cuda(), torch.zeros(3, 12).cuda()
+    ia = torch.zeros(5, dtype=torch.int64).cuda()
+    assert lib.pn2_gather2_add_rows(5, 6, 3, 12, 0, 6, p(pp), p(ia), p(ia), p(q), None) == -1                   # H % 4 != 0
+    with pytest.raises(RuntimeError):
+        ext.group_rows_grad_csr(go, (ptr, refs[:-1].contiguous()), 10, 8, 0)
