@@ -2,6 +2,8 @@
 README.md:87 — "parity unpinned" against them): checked against a plain-torch
 index_select / index_add_ restatement of MessagePassing(source_to_target) and
 against the hand example of network_util.py:86-94."""
+import copy
+
 import pytest
 import torch
 
@@ -280,3 +282,27 @@ def test_batched_training_with_per_scan_statistics_equals_single_scan_steps(orac
     m2.per_scan_statistics = False
     o2, _ = m2(batch)
     assert float((o2.detach() - obj.detach()).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("momentum", [0.1, 0.37, None])
+def test_running_statistics_closed_form_equals_sequential_updates(momentum):
+    """fused_mlp._update_running_stats (the S momentum updates of a segmented call, from the scans' batch statistics) ==
+    S calls of torch's batch_norm in training mode, in scan order; same for the heads' scan_batch_norm."""
+    from types import SimpleNamespace
+    from pointnet2_ops import fused_mlp
+    from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet import scan_batch_norm
+    g = torch.Generator().manual_seed(7)
+    C, rows = 24, [40, 7, 130, 2, 65]
+    xs = [torch.randn(n, C, generator=g) * (1 + i) + i for i, n in enumerate(rows)]
+    ref = torch.nn.BatchNorm2d(C, momentum=momentum).train()
+    ref.running_mean.normal_(generator=g); ref.running_var.uniform_(0.5, 2.0, generator=g)
+    bn = copy.deepcopy(ref)
+    for x in xs:                                                        # the reference sequence: one scan per call
+        ref(x.t().reshape(1, C, -1, 1))
+    # what the finalize kernel leaves per scan: fin rows 0 / 1 = batch mean / rstd (biased variance)
+    fins = [torch.stack([x.mean(0), torch.rsqrt(x.var(0, unbiased=False) + bn.eps), torch.zeros(C), torch.zeros(C)]) for x in xs]
+    subs = [SimpleNamespace(saved_tensors=(None, None, f)) for f in fins]            # [x] + ys (L) + fins (L)
+    fused_mlp._update_running_stats([(None, bn)], subs, rows)
+    torch.testing.assert_close(bn.running_mean, ref.running_mean, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(bn.running_var, ref.running_var, atol=1e-4, rtol=1e-4)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == len(rows)
