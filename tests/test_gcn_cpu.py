@@ -287,10 +287,10 @@ def test_batched_training_with_per_scan_statistics_equals_single_scan_steps(orac
 @pytest.mark.parametrize("momentum", [0.1, 0.37, None])
 def test_running_statistics_closed_form_equals_sequential_updates(momentum):
     """fused_mlp._update_running_stats (the S momentum updates of a segmented call, from the scans' batch statistics) ==
-    S calls of torch's batch_norm in training mode, in scan order; same for the heads' scan_batch_norm."""
+    S calls of torch's batch_norm in training mode, in scan order (the heads' scan_batch_norm uses the same closed form and is
+    covered by the full-model test above)."""
     from types import SimpleNamespace
     from pointnet2_ops import fused_mlp
-    from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet import scan_batch_norm
     g = torch.Generator().manual_seed(7)
     C, rows = 24, [40, 7, 130, 2, 65]
     xs = [torch.randn(n, C, generator=g) * (1 + i) + i for i, n in enumerate(rows)]
