@@ -36,6 +36,9 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(REPO, "4d-or_amd"), REPO, os.path.join(REPO, "tests")]
+# multi-process GPU jobs on this pool: the host driver only supports dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise);
+# normally exported already, set here too so that a bare torchrun environment works
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
