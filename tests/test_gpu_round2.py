@@ -346,10 +346,21 @@ def test_batched_scans_on_gpu_equal_single_scan_steps():
     assert m.predict_step(batch) == [m.predict_step(to_device(s, "cuda")) for s in scans]
 
 
-def test_batched_training_on_gpu_with_per_scan_statistics_equals_single_scan_steps():
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_batched_training_on_gpu_with_per_scan_statistics_equals_single_scan_steps(dtype):
     """TRAINING mode on the HIP path: S scans per step with `per_scan_statistics` (default) == S single-scan steps of the
     reference's loop (main.py:54-56): log-probabilities, mean loss, averaged gradients, running statistics after the S
-    momentum updates.  Dropout off (its random stream differs between one call and S calls)."""
+    momentum updates.  Dropout off (its random stream differs between one call and S calls).  bf16: the same comparison
+    with the mixed-precision stacks on BOTH sides (identical per-scan arithmetic, so the bounds stay the fp32 ones)."""
+    from pointnet2_ops import fused_mlp
+    prev = fused_mlp.set_mlp_dtype(dtype)
+    try:
+        _batched_training_equals_single_scan_steps()
+    finally:
+        fused_mlp.set_mlp_dtype(prev)
+
+
+def _batched_training_equals_single_scan_steps():
     from scene_graph_prediction.main import RELATION_NAMES, config_loader
     from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan, to_device
     from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
