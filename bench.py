@@ -617,12 +617,14 @@ def main():
     if not args.no_kernel_timing:
         timer = _ext.KernelTimer(main_stream)
         _ext.TIMER = timer
-        # K < 4: every step; otherwise ONE step in the middle of the timed region (two event records per launch serialise
-        # consecutive kernels: a sampled step is ~3 ms longer, and it is part of the timed region)
+        # K < 4: every step; K < 24: one step in the middle of the timed region (two event records per launch serialise
+        # consecutive kernels: a sampled step is ~3 ms longer); longer runs: two steps
         if args.steps < 4:
             sampled = set(range(args.steps))
-        else:
+        elif args.steps < 24:
             sampled = {args.steps // 2}
+        else:
+            sampled = {args.steps // 3, 2 * args.steps // 3}
         sampled_steps = len(sampled)
 
         def on_step(i):
