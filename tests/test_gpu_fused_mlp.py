@@ -61,15 +61,20 @@ def test_fused_matches_torch(spec, M, ns, train):
     o0, gx0, gp0, sd0 = _run(mlp, x, ns, fused=False, train=train)
     o1, gx1, gp1, sd1 = _run(mlp, x, ns, fused=True, train=train)
     torch.testing.assert_close(o1, o0, atol=1e-4, rtol=1e-4)
-    if M >= (1 << 17):
-        # tens of millions of pre-activations: a handful sit within rounding of the ReLU threshold and flip their
-        # mask between two implementations (O(1) differences in single elements) — compare in norm
+    # A pre-activation within rounding of the ReLU threshold flips its mask between two implementations — and, in training
+    # mode, between two RUNS of this one (the fp64 statistics atomics commit in another order: last-bit differences in
+    # mean / rstd).  A flipped unit changes one whole row of the input gradient by O(1) and moves the weight-gradient sums
+    # by one row's share.  Large M (tens of millions of pre-activations) always has a handful, small M has one in about
+    # 1 of 100 runs (seen once in 25 full-suite runs: spec3-1000-0-True): up to two such rows are tolerated, with the
+    # bounds in norm that the large cases use.
+    bad_rows = int(((gx1 - gx0).abs() > 1e-4 + 1e-3 * gx0.abs()).any(dim=1).sum())
+    flips = M >= (1 << 17) or bad_rows > 0
+    if flips:
+        assert M >= (1 << 17) or bad_rows <= 2, bad_rows
         assert float((gx1 - gx0).norm() / gx0.norm()) < 2e-3
-    else:
-        torch.testing.assert_close(gx1, gx0, atol=1e-4, rtol=1e-3)
     for a, b in zip(gp1, gp0):
         scale = float(b.abs().max()) + 1e-6
-        tol = 5e-3 if M >= (1 << 17) else 2e-4           # large M: the mask flips above also move the sums
+        tol = 5e-3 if flips else 2e-4                     # the mask flips above also move the sums
         assert float((a - b).abs().max()) <= tol * scale + 1e-5, (a - b).abs().max()
     for k in sd0:
         torch.testing.assert_close(sd1[k].float(), sd0[k].float(), atol=1e-5, rtol=1e-4)
