@@ -14,6 +14,7 @@ batch statistics (biased variance) and updates ``running_mean`` / ``running_var`
 running statistics.  Gradients are produced for the input rows, the conv weights and
 the BatchNorm affine parameters.
 """
+import collections
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -411,7 +412,8 @@ class _SegCtx:
         pass
 
 
-_EMA_WEIGHTS = {}
+_EMA_WEIGHTS = collections.OrderedDict()       # bounded (LRU): scans of varying size give ever new row-count tuples
+_EMA_WEIGHTS_MAX = 4096
 
 
 def _ema_weights(device, dtype, momentum, rows_per_scan):
@@ -420,7 +422,11 @@ def _ema_weights(device, dtype, momentum, rows_per_scan):
     eager call of a step signature creates them, replays find them."""
     key = (device, dtype, momentum, tuple(rows_per_scan))
     hit = _EMA_WEIGHTS.get(key)
-    if hit is None:
+    if hit is not None:
+        _EMA_WEIGHTS.move_to_end(key)
+    else:
+        if len(_EMA_WEIGHTS) >= _EMA_WEIGHTS_MAX:
+            _EMA_WEIGHTS.popitem(last=False)
         S = len(rows_per_scan)
         w = [0.0 if momentum is None else momentum * (1.0 - momentum) ** (S - 1 - s) for s in range(S)]
         u = [n / max(n - 1, 1) for n in rows_per_scan]
