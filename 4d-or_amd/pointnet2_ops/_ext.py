@@ -470,13 +470,19 @@ def _grad_rows(grad_out):
     return "", 4
 
 
-def group_rows_grad(grad_out, idx, n, c, col0):
-    """grad_out (B,m,ns,W) fp32 or bf16 -> (B,n,c) fp32 gradient of the gathered feature columns."""
+def group_rows_grad(grad_out, idx, n, c, col0, out=None):
+    """grad_out (B,m,ns,W) fp32 or bf16 -> (B,n,c) fp32 gradient of the gathered feature columns.
+    `out`: a ZERO-FILLED contiguous (B,n,c) fp32 tensor to accumulate into (e.g. a slice of a larger batch)."""
     sfx, eb = _grad_rows(grad_out)
     _i32(idx, "idx")
     _same_device((grad_out, "grad_out"), (idx, "idx"))
     B, m, ns, W = grad_out.shape
-    out = torch.zeros(B, int(n), int(c), dtype=torch.float32, device=grad_out.device)
+    if out is None:
+        out = torch.zeros(B, int(n), int(c), dtype=torch.float32, device=grad_out.device)
+    else:
+        _f32(out, "out")
+        if tuple(out.shape) != (B, int(n), int(c)) or out.device != grad_out.device:
+            raise RuntimeError("group_rows_grad: out must be a contiguous float (B, n, c) tensor on the gradient's device")
     _call("pn2_group_rows_grad" + sfx, grad_out, B, int(n), m, ns, int(c), W, int(col0),
           _ptr(grad_out), _ptr(idx), _ptr(out),
           alg_bytes=B * (4 * m * ns + eb * int(c) * m * ns + 4 * int(c) * int(n)), label="pn2_group_rows_grad")
@@ -512,8 +518,9 @@ def inverse_index_of(idx, n):
     return inv[1:] if inv is not None and inv[0] == int(n) else None
 
 
-def group_rows_grad_csr(grad_out, inv, n, c, col0):
-    """grad_out (B,m,ns,W) + inv = (ptr, refs) of its index -> (B,n,c); every output row written, fixed summation order."""
+def group_rows_grad_csr(grad_out, inv, n, c, col0, out=None):
+    """grad_out (B,m,ns,W) + inv = (ptr, refs) of its index -> (B,n,c); every output row written, fixed summation order.
+    `out`: contiguous (B,n,c) fp32 destination (overwritten)."""
     sfx, eb = _grad_rows(grad_out)
     ptr, refs = inv
     _i32(ptr, "ptr"); _i32(refs, "refs")
@@ -522,7 +529,12 @@ def group_rows_grad_csr(grad_out, inv, n, c, col0):
     n, c = int(n), int(c)
     if ptr.numel() != B * n + 1 or refs.numel() != B * m * ns:
         raise RuntimeError("group_rows_grad_csr: inverse index does not belong to this gradient's neighbourhoods")
-    out = torch.empty(B, n, c, dtype=torch.float32, device=grad_out.device)
+    if out is None:
+        out = torch.empty(B, n, c, dtype=torch.float32, device=grad_out.device)
+    else:
+        _f32(out, "out")
+        if tuple(out.shape) != (B, n, c) or out.device != grad_out.device:
+            raise RuntimeError("group_rows_grad_csr: out must be a contiguous float (B, n, c) tensor on the gradient's device")
     _call("pn2_group_rows_grad_csr" + sfx, grad_out, B, n, c, W, int(col0), B * m * ns, _ptr(grad_out), _ptr(ptr), _ptr(refs),
           _ptr(out), alg_bytes=B * (8 * m * ns + eb * c * m * ns + 4 * c * n + 4 * n), label="pn2_group_rows_grad")
     return out

@@ -253,9 +253,9 @@ class _FusedMLP(Function):
             Bf, Nf, Cf = ctx.feat_shape
             inv = e.inverse_index_of(idx, Nf)
             if inv is not None:          # prefetched inverse index: per-point sum, no atomics (csrc/group_csr.hip)
-                gx = e.group_rows_grad_csr(gx.view(Bq, npoint, nsample, Cf), inv, Nf, Cf, 0)
-            else:
-                gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0)
+                gx = e.group_rows_grad_csr(gx.view(Bq, npoint, nsample, Cf), inv, Nf, Cf, 0, out=getattr(ctx, "gx_out", None))
+            else:                        # (a segmented call hands in its zero-filled slice of the batch's gradient)
+                gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0, out=getattr(ctx, "gx_out", None))
         return (gx, None, None, None, *grads)
 
 
@@ -391,9 +391,9 @@ class _FusedMLPBf16(Function):
             Bf, Nf, Cf = ctx.feat_shape
             inv = e.inverse_index_of(idx, Nf)
             if inv is not None:          # prefetched inverse index: per-point sum, no atomics (csrc/group_csr.hip)
-                gx = e.group_rows_grad_csr(gx.view(Bq, npoint, nsample, Cf), inv, Nf, Cf, 0)
-            else:
-                gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0)
+                gx = e.group_rows_grad_csr(gx.view(Bq, npoint, nsample, Cf), inv, Nf, Cf, 0, out=getattr(ctx, "gx_out", None))
+            else:                        # (a segmented call hands in its zero-filled slice of the batch's gradient)
+                gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0, out=getattr(ctx, "gx_out", None))
         return (gx, None, None, None, *grads)
 
 
@@ -531,7 +531,8 @@ class _SegmentedGroupMLP(Function):
             args.append(arg)
             c0 = c1
         fork.join(outs, args)
-        ctx.subs, ctx.inner, ctx.rows = subs, inner, [n * m for n in sizes]
+        ctx.subs, ctx.inner, ctx.rows, ctx.sizes = subs, inner, [n * m for n in sizes], sizes
+        ctx.feat_shape = None if x is None else tuple(x.shape)
         _update_running_stats(layers, subs, [n * m * ns for n in sizes])
         out, arg = torch.cat(outs, 0), torch.cat(args, 0)
         ctx.mark_non_differentiable(arg)
@@ -540,20 +541,27 @@ class _SegmentedGroupMLP(Function):
     @staticmethod
     def backward(ctx, g_out, *unused):
         g_out = g_out.contiguous()
+        # the scans scatter their feature gradient straight into their slice of ONE zero-filled (B, N, C) tensor (allocated
+        # and cleared on the calling stream before the fork) instead of S tensors + a concatenating copy
+        gx_all = None
+        if ctx.needs_input_grad[0] and ctx.feat_shape is not None:
+            gx_all = torch.zeros(ctx.feat_shape, dtype=torch.float32, device=g_out.device)
         fork = _Fork(g_out.device, len(ctx.subs))
-        gxs, pgs, r0 = [], [], 0
-        for s, (sub, rows) in enumerate(zip(ctx.subs, ctx.rows)):
+        gxs, pgs, r0, c0 = [], [], 0, 0
+        for s, (sub, rows, n_clouds) in enumerate(zip(ctx.subs, ctx.rows, ctx.sizes)):
+            sub.gx_out = None if gx_all is None else gx_all[c0:c0 + n_clouds]
             with torch.cuda.stream(fork.stream(s)):      # the stream this scan's forward ran on (same round-robin)
                 res = ctx.inner.backward(sub, g_out[r0:r0 + rows])
             r0 += rows
+            c0 += n_clouds
             gxs.append(res[0])
             pgs.append(list(res[4:]))
-        fork.join(gxs, *pgs)
+        fork.join(*pgs)
         acc = pgs[0]
         for pg in pgs[1:]:                                          # one multi-tensor add per scan
             torch._foreach_add_(acc, pg)
         ctx.subs = None
-        gx = None if gxs[0] is None else torch.cat(gxs, 0)
+        gx = gx_all if (gx_all is not None and gxs[0] is not None) else None
         return (gx, None, None, None, None, None, *acc)
 
 
