@@ -116,8 +116,10 @@ class _FusedMLP(Function):
         if group is not None:
             xyz, new_xyz, idx, use_xyz, normalize, radius = group
             ctx.feat_shape = None if x is None else tuple(x.shape)
-            x = e.group_concat_rows(xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize,
-                                    radius).view(-1, (3 if use_xyz else 0) + (0 if x is None else x.size(2)))
+            pre = getattr(ctx, "x_rows", None)          # a segmented call groups the whole batch once and hands in the rows
+            x = pre if pre is not None else e.group_concat_rows(
+                xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize,
+                radius).view(-1, (3 if use_xyz else 0) + (0 if x is None else x.size(2)))
         x = x.contiguous()
         M = x.size(0)
         L = len(layers)
@@ -271,8 +273,11 @@ class _FusedMLPBf16(Function):
             xyz, new_xyz, idx, use_xyz, normalize, radius = group
             ctx.feat_shape = None if x is None else tuple(x.shape)
             k_in = (3 if use_xyz else 0) + (0 if x is None else x.size(2))
-            x = e.group_concat_rows_bf16(xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize, radius)
-            x = x.view(-1, x.size(-1))                                      # (M, pad8(k_in)) bf16, zero pad columns
+            pre = getattr(ctx, "x_rows", None)          # a segmented call groups the whole batch once and hands in the rows
+            if pre is None:
+                pre = e.group_concat_rows_bf16(xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize,
+                                               radius)
+            x = pre.view(-1, pre.size(-1))                                  # (M, pad8(k_in)) bf16, zero pad columns
         else:
             x = x.contiguous()                                              # fp32 rows of any width
             k_in = x.size(1)
@@ -518,11 +523,20 @@ class _SegmentedGroupMLP(Function):
     def forward(ctx, x, ns, layers, group, sizes, inner, *params):
         xyz, new_xyz, idx, use_xyz, normalize, radius = group
         m = idx.size(1)
+        # the grouping has no statistics: ONE gather for the whole batch (before the fork), the scans take row slices
+        # (same-box A/B at 8 scans, bf16: 195.4 -> 202.4 scans/s)
+        e = _ext()
+        feats = None if x is None else x.contiguous()
+        if inner is _FusedMLPBf16:
+            rows_all = e.group_concat_rows_bf16(xyz, new_xyz, feats, idx, use_xyz, normalize, radius)
+        else:
+            rows_all = e.group_concat_rows(xyz, new_xyz, feats, idx, use_xyz, normalize, radius)
         fork = _Fork(idx.device, len(sizes))
         subs, outs, args, c0 = [], [], [], 0
         for s, n_clouds in enumerate(sizes):
             c1 = c0 + n_clouds
             sub = _SegCtx((ctx.needs_input_grad[0],))
+            sub.x_rows = rows_all[c0:c1].view(-1, rows_all.size(-1))
             g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius)
             with torch.cuda.stream(fork.stream(s)):
                 out, arg = inner.forward(sub, None if x is None else x[c0:c1], ns, layers, g, *params)
