@@ -1023,6 +1023,41 @@ extern "C" int pn2_bn_finalize(int N, double count, const double *stats, const f
   return pn2_check_launch();
 }
 
+namespace {
+// Running statistics after S single-scan training steps (block-diagonal batch with per-scan statistics), in scan order:
+// running <- (1 - m) running + m stat_s, s = 0..S-1, closed form with the host-computed weights w[s] = m (1 - m)^(S-1-s),
+// wu[s] = w[s] n_s / (n_s - 1) (unbiased variance like torch.nn.functional.batch_norm) and decay = (1 - m)^S.
+// fins (S, 4, C): rows 0 / 1 of every scan = batch mean / rstd as bn_finalize_kernel leaves them.
+__global__ __launch_bounds__(128) void bn_running_update_kernel(int S, int C, const float *__restrict__ fins, float eps,
+                                                               float decay, const float *__restrict__ w,
+                                                               const float *__restrict__ wu, float *__restrict__ rm,
+                                                               float *__restrict__ rv, long long *__restrict__ nbt) {
+  const int c = blockIdx.x * 128 + threadIdx.x;
+  if (c < C) {
+    float m = 0.f, v = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float *f = fins + (size_t)s * 4 * C;
+      const float r = f[C + c];
+      m = fmaf(w[s], f[c], m);
+      v = fmaf(wu[s], fmaxf(1.0f / (r * r) - eps, 0.f), v);
+    }
+    rm[c] = fmaf(decay, rm[c], m);
+    rv[c] = fmaf(decay, rv[c], v);
+  }
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += S;
+}
+}  // namespace
+
+extern "C" int pn2_bn_running_update(int S, int C, const float *fins, float eps, float decay, const float *w,
+                                     const float *wu, float *running_mean, float *running_var,
+                                     long long *num_batches_tracked, void *stream) {
+  if (S <= 0 || C <= 0) return PN2_EINVAL;
+  if (!fins || !w || !wu || !running_mean || !running_var) return PN2_ENULL;
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, S, C, fins, eps,
+                     decay, w, wu, running_mean, running_var, num_batches_tracked);
+  return pn2_check_launch();
+}
+
 extern "C" int pn2_bn_bwd_consts(int N, double count, const double *sums, const float *gamma,
                                  const float *fin, int use_batch_stats, float *consts, float *dgamma,
                                  float *dbeta, const float *W, int K, int k0, float *Wt, void *stream) {

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "pn2_three_interpolate_grad": [_c_int] * 4 + [_c_vp] * 5,
     "pn2_group_concat_rows": [_c_int] * 7 + [_c_f32] + [_c_vp] * 6,
     "pn2_group_rows_grad": [_c_int] * 7 + [_c_vp] * 4,
+    "pn2_bn_running_update": [_c_int, _c_int, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
     "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_rows_grad_csr_bf16": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
@@ -829,11 +830,30 @@ def first_layer_dw(consts, P1, W0, gram):
     return dW0
 
 
-def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None):
+def bn_running_update(fins, eps, decay, w, wu, running_mean, running_var, num_batches_tracked=None):
+    """fins (S,4,C) of S scans -> running statistics after the S momentum updates (see include/pn2_hip.h)."""
+    _f32(fins, "fins"); _f32(w, "w"); _f32(wu, "wu"); _f32(running_mean, "running_mean"); _f32(running_var, "running_var")
+    S, four, C = fins.shape
+    if four != 4 or w.numel() != S or wu.numel() != S or running_mean.numel() != C or running_var.numel() != C:
+        raise RuntimeError("bn_running_update: fins (S,4,C), w / wu (S), running statistics (C) expected")
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        _fail("bn_running_update: num_batches_tracked must be int64")
+    _call("pn2_bn_running_update", fins, S, C, _ptr(fins), float(eps), float(decay), _ptr(w), _ptr(wu), _ptr(running_mean),
+          _ptr(running_var), _ptr(num_batches_tracked))
+
+
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None, out=None):
     """fin (4,N) = [mean | rstd | scale | shift]; updates the running statistics in place and, if given, bumps the int64
-    scalar `num_batches_tracked` (what _BatchNorm.forward does with a separate add_ kernel per layer)."""
+    scalar `num_batches_tracked` (what _BatchNorm.forward does with a separate add_ kernel per layer).
+    `out`: a contiguous (4,N) fp32 destination (e.g. one scan's block of an (S,4,N) buffer)."""
     N = stats.size(1)
-    fin = torch.empty(4, N, dtype=torch.float32, device=stats.device)
+    if out is None:
+        fin = torch.empty(4, N, dtype=torch.float32, device=stats.device)
+    else:
+        _f32(out, "out")
+        if tuple(out.shape) != (4, N):
+            raise RuntimeError("bn_finalize: out must be a contiguous float (4, N) tensor")
+        fin = out
     if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
         _fail("bn_finalize: num_batches_tracked must be int64")
     _call("pn2_bn_finalize", stats, N, float(count), _ptr(stats), _ptr(gamma), _ptr(beta), float(eps),

@@ -146,7 +146,8 @@ class _FusedMLP(Function):
                         if bn.num_batches_tracked is not None:
                             bn.num_batches_tracked.add_(1)
                         momentum = 1.0 / float(bn.num_batches_tracked)
-                fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt)
+                fo = getattr(ctx, "fin_out", None)          # segmented call: this scan's block of the layer's (S,4,C) buffer
+                fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt, out=None if fo is None else fo[l])
             else:
                 y = e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
                 rstd = torch.rsqrt(bn.running_var + bn.eps)
@@ -306,7 +307,8 @@ class _FusedMLPBf16(Function):
                         if bn.num_batches_tracked is not None:
                             bn.num_batches_tracked.add_(1)
                         momentum = 1.0 / float(bn.num_batches_tracked)
-                fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt)
+                fo = getattr(ctx, "fin_out", None)          # segmented call: this scan's block of the layer's (S,4,C) buffer
+                fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt, out=None if fo is None else fo[l])
             else:
                 y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
                 rstd = torch.rsqrt(bn.running_var + bn.eps)
@@ -422,9 +424,9 @@ _EMA_WEIGHTS_MAX = 4096
 
 
 def _ema_weights(device, dtype, momentum, rows_per_scan):
-    """(w (S,1): weight of scan s's statistic after S momentum updates, u (S,1): biased -> unbiased variance factor).
-    Cached per configuration: built from host numbers (a copy), which a stream capture does not allow — the first,
-    eager call of a step signature creates them, replays find them."""
+    """(w (S): weight of scan s's statistic after S momentum updates, wu (S): w times the biased -> unbiased variance
+    factor n / (n - 1)).  Cached per configuration: built from host numbers (a copy), which a stream capture does not
+    allow — the first, eager call of a step signature creates them, replays find them."""
     key = (device, dtype, momentum, tuple(rows_per_scan))
     hit = _EMA_WEIGHTS.get(key)
     if hit is not None:
@@ -433,28 +435,32 @@ def _ema_weights(device, dtype, momentum, rows_per_scan):
         if len(_EMA_WEIGHTS) >= _EMA_WEIGHTS_MAX:
             _EMA_WEIGHTS.popitem(last=False)
         S = len(rows_per_scan)
-        w = [0.0 if momentum is None else momentum * (1.0 - momentum) ** (S - 1 - s) for s in range(S)]
-        u = [n / max(n - 1, 1) for n in rows_per_scan]
-        hit = _EMA_WEIGHTS[key] = (torch.tensor(w, dtype=dtype, device=device).unsqueeze(1),
-                                   torch.tensor(u, dtype=dtype, device=device).unsqueeze(1))
+        w = [momentum * (1.0 - momentum) ** (S - 1 - s) for s in range(S)]
+        wu = [ws * n / max(n - 1, 1) for ws, n in zip(w, rows_per_scan)]
+        hit = _EMA_WEIGHTS[key] = (torch.tensor(w, dtype=dtype, device=device), torch.tensor(wu, dtype=dtype, device=device))
     return hit
 
 
-def _update_running_stats(layers, subs, rows_per_scan):
-    """The running statistics after S single-scan training steps, in scan order, from the scans' batch statistics
-    (`fin` rows 0 / 1 = mean / rstd of the finalize kernel): running <- (1 - m) running + m stat, S times, closed form
-    (momentum None = cumulative average: a loop); unbiased variance like torch.nn.functional.batch_norm."""
-    L, S = len(layers), len(subs)
+def _update_running_stats(layers, fins, rows_per_scan):
+    """The running statistics after S single-scan training steps, in scan order, from the scans' batch statistics.
+    `fins[l]` (S,4,C_l): rows 0 / 1 of every scan = mean / rstd as the finalize kernel leaves them.  running <- (1 - m)
+    running + m stat, S times, in closed form — ONE launch per layer (pn2_bn_running_update; as torch ops the same update
+    was ~16 tiny kernels per layer, 670 per 8-scan step of the scene-graph model); unbiased variance like
+    torch.nn.functional.batch_norm.  momentum None (cumulative average) and CPU tensors (unit test) take the torch form."""
+    S = len(rows_per_scan)
     with torch.no_grad():
-        for l, (_, bn) in enumerate(layers):
-            if not (bn.training and bn.track_running_stats and bn.running_mean is not None):
+        for (_, bn), F in zip(layers, fins):
+            if F is None or not (bn.training and bn.track_running_stats and bn.running_mean is not None):
                 continue
-            fins = [sub.saved_tensors[1 + L + l] for sub in subs]
-            mean = torch.stack([f[0] for f in fins])                                     # (S, C)
-            rstd = torch.stack([f[1] for f in fins])
-            w, unbias = _ema_weights(mean.device, mean.dtype, None if bn.momentum is None else float(bn.momentum),
-                                     rows_per_scan)
-            var = (1.0 / (rstd * rstd) - bn.eps).clamp_min(0) * unbias
+            if bn.momentum is not None and F.is_cuda:
+                mom = float(bn.momentum)
+                w, wu = _ema_weights(F.device, F.dtype, mom, rows_per_scan)
+                _ext().bn_running_update(F, bn.eps, (1.0 - mom) ** S, w, wu, bn.running_mean, bn.running_var,
+                                         bn.num_batches_tracked)
+                continue
+            mean, rstd = F[:, 0], F[:, 1]
+            n = torch.tensor(rows_per_scan, dtype=F.dtype, device=F.device).unsqueeze(1)
+            var = (1.0 / (rstd * rstd) - bn.eps).clamp_min(0) * n / (n - 1).clamp_min(1)
             if bn.momentum is None:
                 for s in range(S):
                     bn.num_batches_tracked += 1
@@ -463,6 +469,7 @@ def _update_running_stats(layers, subs, rows_per_scan):
                     bn.running_var.lerp_(var[s], f)
             else:
                 mom = float(bn.momentum)
+                w = (mom * (1.0 - mom) ** torch.arange(S - 1, -1, -1, device=F.device, dtype=F.dtype)).unsqueeze(1)
                 bn.running_mean.mul_((1.0 - mom) ** S).add_((w * mean).sum(0))
                 bn.running_var.mul_((1.0 - mom) ** S).add_((w * var).sum(0))
                 bn.num_batches_tracked += S
@@ -531,12 +538,17 @@ class _SegmentedGroupMLP(Function):
             rows_all = e.group_concat_rows_bf16(xyz, new_xyz, feats, idx, use_xyz, normalize, radius)
         else:
             rows_all = e.group_concat_rows(xyz, new_xyz, feats, idx, use_xyz, normalize, radius)
+        # per layer ONE (S,4,C) buffer for the scans' (mean | rstd | scale | shift) blocks: the running-statistics update
+        # reads it as it lies
+        fin_bufs = [torch.empty(len(sizes), 4, conv.out_channels, dtype=torch.float32, device=idx.device)
+                    if (bn.training or bn.running_mean is None) else None for conv, bn in layers]
         fork = _Fork(idx.device, len(sizes))
         subs, outs, args, c0 = [], [], [], 0
         for s, n_clouds in enumerate(sizes):
             c1 = c0 + n_clouds
             sub = _SegCtx((ctx.needs_input_grad[0],))
             sub.x_rows = rows_all[c0:c1].view(-1, rows_all.size(-1))
+            sub.fin_out = [None if F is None else F[s] for F in fin_bufs]
             g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius)
             with torch.cuda.stream(fork.stream(s)):
                 out, arg = inner.forward(sub, None if x is None else x[c0:c1], ns, layers, g, *params)
@@ -547,7 +559,7 @@ class _SegmentedGroupMLP(Function):
         fork.join(outs, args)
         ctx.subs, ctx.inner, ctx.rows, ctx.sizes = subs, inner, [n * m for n in sizes], sizes
         ctx.feat_shape = None if x is None else tuple(x.shape)
-        _update_running_stats(layers, subs, [n * m * ns for n in sizes])
+        _update_running_stats(layers, fin_bufs, [n * m * ns for n in sizes])
         out, arg = torch.cat(outs, 0), torch.cat(args, 0)
         ctx.mark_non_differentiable(arg)
         return out, arg

@@ -271,6 +271,13 @@ int pn2_bn_finalize(int N, double count, const double *stats, const float *gamma
                     const float *beta, float eps, float momentum, float *running_mean,
                     float *running_var, long long *num_batches_tracked /* += 1 if not NULL */, float *fin,
                     void *stream);
+/* Running statistics of a block-diagonal batch of S scans trained with per-scan BatchNorm statistics: the S momentum
+ * updates of S single-scan steps of the reference (main.py:54-56), in scan order, in one launch.  fins (S,4,C): the
+ * (mean | rstd | scale | shift) blocks pn2_bn_finalize wrote for the scans (called with running_mean = NULL);
+ * w[s] = m (1-m)^(S-1-s), wu[s] = w[s] n_s / (n_s - 1), decay = (1-m)^S; num_batches_tracked (optional) += S. */
+int pn2_bn_running_update(int S, int C, const float *fins, float eps, float decay, const float *w, const float *wu,
+                          float *running_mean, float *running_var, long long *num_batches_tracked, void *stream);
+
 /* W != NULL: additionally Wt[K - k0][N] = W[N][K0 + ..]^T (the row-major weight the dgrad call of this layer takes) */
 int pn2_bn_bwd_consts(int N, double count, const double *sums, const float *gamma,
                       const float *fin, int use_batch_stats, float *consts, float *dgamma,

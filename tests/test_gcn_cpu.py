@@ -289,7 +289,6 @@ def test_running_statistics_closed_form_equals_sequential_updates(momentum):
     """fused_mlp._update_running_stats (the S momentum updates of a segmented call, from the scans' batch statistics) ==
     S calls of torch's batch_norm in training mode, in scan order (the heads' scan_batch_norm uses the same closed form and is
     covered by the full-model test above)."""
-    from types import SimpleNamespace
     from pointnet2_ops import fused_mlp
     g = torch.Generator().manual_seed(7)
     C, rows = 24, [40, 7, 130, 2, 65]
@@ -301,8 +300,7 @@ def test_running_statistics_closed_form_equals_sequential_updates(momentum):
         ref(x.t().reshape(1, C, -1, 1))
     # what the finalize kernel leaves per scan: fin rows 0 / 1 = batch mean / rstd (biased variance)
     fins = [torch.stack([x.mean(0), torch.rsqrt(x.var(0, unbiased=False) + bn.eps), torch.zeros(C), torch.zeros(C)]) for x in xs]
-    subs = [SimpleNamespace(saved_tensors=(None, None, f)) for f in fins]            # [x] + ys (L) + fins (L)
-    fused_mlp._update_running_stats([(None, bn)], subs, rows)
+    fused_mlp._update_running_stats([(None, bn)], [torch.stack(fins)], rows)             # one (S,4,C) buffer per layer
     torch.testing.assert_close(bn.running_mean, ref.running_mean, atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(bn.running_var, ref.running_var, atol=1e-4, rtol=1e-4)
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == len(rows)

@@ -555,3 +555,24 @@ def test_instance_label_fps_call_shape():
     want = oracle_ext.OracleRowsExt.furthest_point_sampling(pts, 200)
     got = pu2.furthest_point_sample(pts.cuda(), 200)[0].cpu()
     assert torch.equal(got, want[0])
+
+
+@pytest.mark.parametrize("momentum", [0.1, 0.5])
+def test_running_statistics_kernel_equals_sequential_batch_norm_calls(momentum):
+    """pn2_bn_running_update: the S momentum updates of S single-scan steps in one launch == S training-mode calls of
+    torch's BatchNorm on the scans, in order (running_mean, running_var with the unbiased variance, num_batches_tracked)."""
+    from pointnet2_ops import fused_mlp
+    g = torch.Generator().manual_seed(11)
+    C, rows = 200, [40, 7, 130, 2, 65, 1000]
+    xs = [torch.randn(n, C, generator=g) * (1 + i) + i for i, n in enumerate(rows)]
+    ref = torch.nn.BatchNorm2d(C, momentum=momentum).train()
+    ref.running_mean.normal_(generator=g); ref.running_var.uniform_(0.5, 2.0, generator=g)
+    bn = copy.deepcopy(ref).cuda()
+    for x in xs:
+        ref(x.t().reshape(1, C, -1, 1))
+    F = torch.stack([torch.stack([x.mean(0), torch.rsqrt(x.var(0, unbiased=False) + bn.eps), torch.zeros(C), torch.zeros(C)])
+                     for x in xs]).cuda()
+    fused_mlp._update_running_stats([(None, bn)], [F], rows)
+    torch.testing.assert_close(bn.running_mean.cpu(), ref.running_mean, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(bn.running_var.cpu(), ref.running_var, atol=1e-4, rtol=1e-4)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == len(rows)
