@@ -96,11 +96,37 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
     }
   }
   auto stage_w = [&](int k0, int kw) {              // sW[n][0..kw) = bf16(W[n][k0..k0+kw)), zero outside N x K
-    // a wave per weight row, lanes along k: coalesced fp32 loads, no per-element index arithmetic
-    for (int n = tid >> 6; n < NTT * 32; n += NTH / 64) {
-      const bool nok = n < N;
-      const float *wr = a.W + (size_t)(nok ? n : 0) * K + k0;
-      for (int k = lane; k < kw; k += 64) sW[n * WP + k] = (bf16)((nok && k0 + k < K) ? wr[k] : 0.f);
+    // a wave per weight row, a lane per FOUR consecutive k (one dword-aligned 16-byte load, one 8-byte LDS store), four rows
+    // in flight.  (First version: one float per lane and row, one row at a time — every workgroup spent ~30 us staging a
+    // resident 128 x 128 weight, which is most of a launch when M is small.)
+    typedef float w4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(4))) W4 { w4 v; };
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    constexpr int WAVES = NTH / 64;
+    for (int kb = 0; kb < kw; kb += 256) {
+      const int k = kb + 4 * lane;                    // column of this lane inside the staged range
+      const bool kin = k < kw;
+      for (int n0 = tid >> 6; n0 < NTT * 32; n0 += 4 * WAVES) {
+        w4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int n = n0 + u * WAVES;
+          v[u] = w4{0.f, 0.f, 0.f, 0.f};
+          if (kin && n < NTT * 32 && n < N) {
+            const float *wr = a.W + (size_t)n * K + k0 + k;
+            if (k0 + k + 3 < K) v[u] = ((const W4 *)wr)->v;
+            else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[u][i] = k0 + k + i < K ? wr[i] : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int n = n0 + u * WAVES;
+          if (kin && n < NTT * 32) *(u2 *)&sW[n * WP + k] = u2{bf_pack(v[u][0], v[u][1]), bf_pack(v[u][2], v[u][3])};
+        }
+      }
     }
   };
   if (a.wres) stage_w(0, Kp);
@@ -1013,11 +1039,18 @@ extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, in
   a.stats = stats; a.Yprev = (const bf16 *)Yprev; a.e_fin = e_fin; a.M = M; a.K = K; a.N = N; a.ldx = ldx; a.ldy = ldy;
   a.ns = ns; a.Kp = (K + KC - 1) / KC * KC; a.wres = 0; a.Nfull = N;
   hipStream_t s = (hipStream_t)stream;
-  if (N > 320) {
-    // wide outputs (the input gradient of a 512-column FP stack): column blocks of 256, A re-read per block
+  // Column blocks (A re-read per block, the second time from L2) in two cases: outputs wider than the 320 columns a
+  // workgroup covers (the input gradient of a 512-column FP stack), and weights that do not fit LDS at full width — a
+  // non-resident weight tile is re-staged per 64-column K chunk of EVERY row tile with scalar loads, which ran the
+  // 256 x 256 layers at the fp32 kernel's speed (M = 524k: 632 us, 90 us of HBM time); blocks of the widest multiple of 32
+  // columns whose bf16 weights (K + 8 pitch) stay resident put them back on the streaming path.
+  int block = N > 320 ? 256 : N;
+  const int fit = (int)((size_t)kMaxResidentWBytes / ((size_t)(a.Kp + 8) * 2) / 32) * 32;      // resident columns
+  if (fit >= 32 && fit < block) block = fit;
+  if (block < N) {
     const int ys = y_f32 ? 4 : 2;
-    for (int n0 = 0; n0 < N; n0 += 256) {
-      const int nb = N - n0 < 256 ? N - n0 : 256;
+    for (int n0 = 0; n0 < N; n0 += block) {
+      const int nb = N - n0 < block ? N - n0 : block;
       const int rc = pn2_mlp_gemm_bf16_block(a, n0, nb, ys, pro, epi, x_f32, y_f32, s);
       if (rc != PN2_OK) return rc;
     }
