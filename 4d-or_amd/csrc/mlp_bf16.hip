@@ -605,8 +605,28 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
   for (int k = tid; k < KB; k += 512) {
     sF[k] = a.a_fin[k]; sF[KB + k] = a.a_fin[K + k]; sF[2 * KB + k] = a.a_fin[2 * K + k]; sF[3 * KB + k] = a.a_fin[3 * K + k];
   }
-  for (int k = wave; k < KB; k += 8)
-    for (int n = lane; n < NB; n += 64) sWt[k * NP + n] = (bf16)a.Wt[(size_t)k * N + n];
+  {
+    // transposed weights -> LDS: a thread per four consecutive n (16-byte load, 8-byte store), four rows in flight
+    // (N = NB is a multiple of 32: aligned).  One float per lane and row at a time cost every workgroup ~30 us.
+    typedef float w4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    constexpr int LPRW = NB / 4;                       // lanes per weight row (8 .. 32)
+    constexpr int RPI = 512 / LPRW;                    // rows per pass of the workgroup
+    const int wn = (tid % LPRW) * 4, wk0 = tid / LPRW;
+    for (int k0 = wk0; k0 < KB; k0 += 4 * RPI) {
+      w4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * RPI;
+        v[u] = k < KB ? *(const w4 *)(a.Wt + (size_t)k * N + wn) : w4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * RPI;
+        if (k < KB) *(u2 *)&sWt[k * NP + wn] = u2{bf_pack(v[u][0], v[u][1]), bf_pack(v[u][2], v[u][3])};
+      }
+    }
+  }
 
   f32x16 accw[WT];
 #pragma unroll
