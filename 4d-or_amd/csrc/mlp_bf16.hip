@@ -950,18 +950,34 @@ inline unsigned capped_grid(size_t work, unsigned cap = 16384) {
   return (unsigned)(g ? g : 1);
 }
 
-constexpr int kMaxResidentWBytes = 72 * 1024;
+// LDS of one workgroup: 160 KB per CU.  Weights are kept resident whenever the whole footprint (weights + prologue table +
+// A chunk / epilogue tile) fits — also when that leaves room for only ONE workgroup per CU: at K = N = 256 (135 KB of
+// weights) the resident single launch takes 669 us for 2M rows, two resident 128-column blocks 1221 us, the streamed
+// form (weights re-staged per K chunk of every row tile) 2394 us.
+constexpr size_t kLdsBudget = 158 * 1024;
+
+inline int gemm_tile_columns(int n) {                // columns a workgroup covers for an n-column (block of the) output
+  const int nt = (n + 31) / 32;
+  return 32 * (nt <= 4 ? nt : (nt + 1) / 2 * 2);
+}
+
+inline size_t gemm_lds_need(int n, int Kp, int pro, int epi) {      // with resident weights
+  const int cols = gemm_tile_columns(n);
+  size_t tile = (size_t)TM * AP * 2;
+  if (epi == EPI_MASK && (size_t)TM * (cols + 8) * 2 > tile) tile = (size_t)TM * (cols + 8) * 2;
+  return (size_t)cols * (Kp + 8) * 2 + tile + (pro != PRO_NONE ? 3 * (size_t)Kp * 4 : 0);
+}
 
 template <int NT, int CW, int PRO, int EPI, bool XF32, bool YF32>
 int launch_gemm(GemmBf16Args a, hipStream_t s) {
   constexpr int NTT = NT * CW;
   const size_t wbytes_res = (size_t)NTT * 32 * (a.Kp + 8) * 2;
-  a.wres = wbytes_res <= (size_t)kMaxResidentWBytes;
+  a.wres = 1;
   if (EPI == EPI_MASK && a.N % 8 != 0) return PN2_EINVAL;
   size_t tile = (size_t)TM * AP * 2;                        // A chunk, aliased by the epilogue tile of EPI_MASK
   if (EPI == EPI_MASK && (size_t)TM * (NTT * 32 + 8) * 2 > tile) tile = (size_t)TM * (NTT * 32 + 8) * 2;
   const size_t fixed = tile + (PRO != PRO_NONE ? 3 * (size_t)a.Kp * 4 : 0);
-  if (a.wres && fixed + wbytes_res > 160 * 1024) a.wres = 0;
+  if (fixed + wbytes_res > kLdsBudget) a.wres = 0;          // (the host wrapper picks column blocks that fit)
   const size_t wbytes = a.wres ? wbytes_res : (size_t)NTT * 32 * AP * 2;
   size_t lds = fixed + wbytes;
   if (lds > 160 * 1024) return PN2_EINVAL;
@@ -975,7 +991,7 @@ int launch_gemm(GemmBf16Args a, hipStream_t s) {
     big_lds = true;
   }
   const long long ntiles = (a.M + TM - 1) / TM;
-  long long grid = 512;                                     // persistent: two workgroups per CU
+  long long grid = lds > 80 * 1024 ? 256 : 512;             // persistent: as many workgroups per CU as the LDS admits
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256 * CW), lds, s, a);
   return pn2_check_launch();
@@ -1061,12 +1077,11 @@ extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, in
   hipStream_t s = (hipStream_t)stream;
   // Column blocks (A re-read per block, the second time from L2) in two cases: outputs wider than the 320 columns a
   // workgroup covers (the input gradient of a 512-column FP stack), and weights that do not fit LDS at full width — a
-  // non-resident weight tile is re-staged per 64-column K chunk of EVERY row tile with scalar loads, which ran the
-  // 256 x 256 layers at the fp32 kernel's speed (M = 524k: 632 us, 90 us of HBM time); blocks of the widest multiple of 32
-  // columns whose bf16 weights (K + 8 pitch) stay resident put them back on the streaming path.
+  // non-resident weight tile is re-staged per 64-column K chunk of EVERY row tile, which ran the 256 x 256 layers at the
+  // fp32 kernel's speed (M = 524k: 632 us, 90 us of HBM time); the widest multiple of 32 columns whose footprint (resident
+  // bf16 weights at pitch K + 8, A chunk / epilogue tile, prologue table) fits the LDS budget is taken.
   int block = N > 320 ? 256 : N;
-  const int fit = (int)((size_t)kMaxResidentWBytes / ((size_t)(a.Kp + 8) * 2) / 32) * 32;      // resident columns
-  if (fit >= 32 && fit < block) block = fit;
+  while (block > 32 && gemm_lds_need(block, a.Kp, pro, epi) > kLdsBudget) block = (block - 1) / 32 * 32;
   if (block < N) {
     const int ys = y_f32 ? 4 : 2;
     for (int n0 = 0; n0 < N; n0 += block) {
