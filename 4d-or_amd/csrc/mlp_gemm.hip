@@ -21,6 +21,10 @@
 //     EPI_STATS   column sums of out and out^2 (fp64 atomics)  -> BatchNorm batch statistics
 //     EPI_MASK    out *= [BN(yprev) > 0]; column sums of out and out * yhat_prev
 //                                                             -> ReLU backward + BN-backward reductions
+//     EPI_POOL    column sums as EPI_STATS, and per group of `ns` consecutive rows the maximum of every column
+//                 with its row index; `out` is NOT stored (the max-pooled last layer of an SA stack: BatchNorm with
+//                 a positive scale and ReLU are monotone, so max(relu(bn(y))) = relu(bn(max y)); columns with a
+//                 negative gamma arrive with their weight row negated, `sgn` restores the column sums)
 //
 // BatchNorm backward in this formulation: with yhat = (y-mean)*rstd, z = gamma*yhat+beta,
 // g = dL/dz, dbeta = sum g, dgamma = sum g*yhat (both produced by the previous kernel's
@@ -52,6 +56,10 @@ struct GemmArgs {
   const float *e_scale, *e_shift, *e_mean, *e_rstd;  // EPI_MASK: per output column
   long long M;
   int K, N, ns, pro, epi;
+  // EPI_POOL
+  float *pmax;       // [M/psz][N], psz = min(ns, 32): maximum of the (sign-adjusted) raw output over each partial row group
+  int *parg;         // [M/psz][N] row of that maximum inside the partial group (first one among equals)
+  const float *sgn;  // [N] +-1: sign the weight rows were multiplied with
 };
 
 constexpr int BM = 128;
@@ -83,6 +91,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   __shared__ float As[2][BM * LD];
   __shared__ float Ws[2][NTT * 32 * LD];
   __shared__ float red[2][NTT * 32];
+  constexpr bool POOLE = EPI == EPI_POOL;
   // per-input-column prologue parameters (p0, p1, p2), staged once and ZERO beyond K: a padded
   // column then evaluates to relu(0*x + 0) = 0 (v_max_f32 drops a NaN operand) resp. 0*g + 0*y + 0,
   // so ragged K needs no masks.  (A global load inside the step loop would be the youngest entry of
@@ -247,6 +256,19 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
     yoff[t] = col < N ? (rbase * N + col) * 4 : kOobOffset;
   }
   const int rowpitch = N * 4;
+  // EPI_POOL: partial groups of psz = min(ns, 32) rows; kernel-constant per-lane offsets of the lane's partial result
+  const bool psz16 = POOLE && a.ns == 16;
+  const int psh = psz16 ? 4 : 5;
+  const long long npart = POOLE ? (M >> psh) : 0;
+  int poff[POOLE ? NT : 1];
+  if (POOLE) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = n0 + (wcol * NT + t) * 32 + cl;
+      const int pl = psz16 ? wave * 2 + (lane >> 5) : wave;
+      poff[POOLE ? t : 0] = (col < N && (psz16 || lane < 32)) ? (pl * N + col) * 4 : kOobOffset;
+    }
+  }
   float yp[MASKE ? NT : 1][16];
   // EPI_MASK constants of this lane's output columns (fixed for the whole kernel)
   float e_s[MASKE ? NT : 1], e_h[MASKE ? NT : 1], e_m[MASKE ? NT : 1], e_r[MASKE ? NT : 1];
@@ -305,9 +327,66 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
           for (int r = 0; r < 16; ++r)
             acc[t][r] = (m0 + rbase + (r & 3) + 8 * (r >> 2)) < M ? acc[t][r] : 0.f;
       }
-      const rsrc_t rsy = make_rsrc(a.Y + (size_t)m0 * N, (M - m0) * N * 4);
+      if (POOLE) {
+        // ---- statistics + group maxima; nothing is stored to Y ----
+        const long long pfirst = m0 >> psh;                       // first partial group of this tile
+        const rsrc_t rspv = make_rsrc(a.pmax + (size_t)pfirst * N, (npart - pfirst) * N * 4);
+        const rsrc_t rspr = make_rsrc(a.parg + (size_t)pfirst * N, (npart - pfirst) * N * 4);
+        // lane (cl, h = lane >> 5) holds rows 4h + (r & 3) + 8 (r >> 2), r < 16, of the wave's 32-row block:
+        // registers 0-7 lie in the first 16-row sub-group (rows ascending in r), registers 8-15 in the second
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NT; ++t) {
+          float s1 = 0.f, s2 = 0.f;
+          float bst[2];
+          int bi[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            bst[q] = acc[t][8 * q];
+            bi[q] = 0;
+            s1 += bst[q];
+            s2 = __fmaf_rn(bst[q], bst[q], s2);
+            acc[t][8 * q] = 0.f;
+#pragma unroll
+            for (int r = 1; r < 8; ++r) {
+              const float v = acc[t][8 * q + r];
+              const bool gt = v > bst[q];
+              bst[q] = gt ? v : bst[q];
+              bi[q] = gt ? r : bi[q];
+              s1 += v;
+              s2 = __fmaf_rn(v, v, s2);
+              acc[t][8 * q + r] = 0.f;
+            }
+          }
+          cs1[t] += s1;
+          cs2[t] += s2;
+          // combine the two half-waves (rows interleave in blocks of four): larger value, then smaller row
+          float b[2];
+          int rw[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int row = (bi[q] & 3) + 8 * (bi[q] >> 2) + 4 * (lane >> 5);
+            const float ob = __shfl_xor(bst[q], 32);
+            const int orow = __shfl_xor(row, 32);
+            const bool take = ob > bst[q] || (ob == bst[q] && orow < row);
+            b[q] = take ? ob : bst[q];
+            rw[q] = take ? orow : row;
+          }
+          // partial groups of psz = min(ns, 32) rows: ns = 16 publishes both sub-groups (lanes 0-31 the first, lanes
+          // 32-63 the second), otherwise the 32 rows of the wave are one partial (first maximum wins) published by lanes 0-31
+          const bool second = b[1] > b[0];
+          const float b32 = second ? b[1] : b[0];
+          const int r32 = second ? 16 + rw[1] : rw[0];
+          const bool hi = (lane >> 5) != 0;
+          const float vout = psz16 ? (hi ? b[1] : b[0]) : b32;
+          const int rout = psz16 ? (hi ? rw[1] : rw[0]) : r32;
+          bstore(vout, rspv, poff[POOLE ? t : 0], 0);
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned)rout, rspr, poff[POOLE ? t : 0], 0, 0);
+          __builtin_amdgcn_sched_barrier(0);      // one column tile at a time
+        }
+      }
+      const rsrc_t rsy = make_rsrc(POOLE ? (float *)a.pmax : a.Y + (size_t)m0 * N, POOLE ? 4 : (M - m0) * N * 4);
+#pragma unroll
+      for (int t = 0; t < (POOLE ? 0 : NT); ++t) {
         float es = 0.f, eh = 0.f, em = 0.f, er = 0.f;
         if (MASKE) { es = e_s[MASKE ? t : 0]; eh = e_h[MASKE ? t : 0]; em = e_m[MASKE ? t : 0]; er = e_r[MASKE ? t : 0]; }
         float s1 = 0.f, s2 = 0.f;
@@ -373,7 +452,8 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
     for (int i = tid; i < NTT * 32; i += THREADS) {
       const int col = n0 + i;
       if (col < N) {
-        atomicAdd(a.stats + col, (double)red[0][i]);
+        const float sg = (POOLE && a.sgn) ? a.sgn[col] : 1.f;
+        atomicAdd(a.stats + col, (double)(red[0][i] * sg));
         atomicAdd(a.stats + N + col, (double)red[1][i]);
       }
     }
@@ -931,6 +1011,90 @@ extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const f
   else if (pro == PRO_GY && epi == EPI_NONE) launch_by_width<PRO_GY, EPI_NONE>(a, tiles, s);
   else if (pro == PRO_POOLG && epi == EPI_NONE) launch_by_width<PRO_POOLG, EPI_NONE>(a, tiles, s);
   else return PN2_EINVAL;
+  return pn2_check_launch();
+}
+
+namespace {
+// W' = diag(sgn) W, sgn = -1 where gamma < 0 (rows of the pooled layer's weight), and the sign vector itself
+__global__ __launch_bounds__(256) void pool_flip_rows_kernel(int N, int K, const float *__restrict__ W,
+                                                            const float *__restrict__ gamma, float *__restrict__ Wf,
+                                                            float *__restrict__ sgn) {
+  const int total = N * K;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int n = e / K;
+    const bool neg = gamma && gamma[n] < 0.f;
+    Wf[e] = neg ? -W[e] : W[e];
+    if (e - n * K == 0) sgn[n] = neg ? -1.f : 1.f;
+  }
+}
+
+// pooled = relu(bn(max)) from the sign-adjusted raw partial maxima (ns/psz partial groups of psz = min(ns, 32) rows per
+// group, first maximum wins): |scale| * pmax + shift == scale * y + shift bit for bit
+__global__ __launch_bounds__(256) void pool_finalize_kernel(size_t total, int C, int nsub, int psz,
+                                                           const float *__restrict__ pmax, const int *__restrict__ parg,
+                                                           const float *__restrict__ fin, const float *__restrict__ sgn,
+                                                           float *__restrict__ out, int *__restrict__ arg,
+                                                           float *__restrict__ yraw) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t g = e / C;
+    const int c = (int)(e - g * C);
+    const size_t p0 = g * nsub * C + c;
+    float best = pmax[p0];
+    int row = parg[p0];
+    for (int j = 1; j < nsub; ++j) {
+      const float v = pmax[p0 + (size_t)j * C];
+      if (v > best) { best = v; row = j * psz + parg[p0 + (size_t)j * C]; }
+    }
+    const float raw = best * sgn[c];
+    yraw[e] = raw;
+    arg[e] = row;
+    out[e] = fmaxf(__fmaf_rn(raw, fin[2 * C + c], fin[3 * C + c]), 0.f);
+  }
+}
+}  // namespace
+
+// Last layer of a max-pooled stack without materialising its output: column sums for the batch statistics and, per
+// group of `ns` rows, the column maxima of pro(X) * Wf^T with their rows (see EPI_POOL above).  Replaces
+// Conv2d + BatchNorm2d + ReLU + F.max_pool2d of OPS/pointnet2_modules.py:58-70 together with pn2_pool_finalize.
+extern "C" int pn2_mlp_gemm_pool(long long M, int K, int N, int pro, const float *X, const float *p0, const float *p1,
+                                 const float *Wf, const float *sgn, int ns, double *stats, float *pmax, int *parg,
+                                 void *stream) {
+  if (M < 0 || K <= 0 || N <= 0 || K > 2048) return PN2_EINVAL;
+  if (pro != PRO_NONE && pro != PRO_BNRELU) return PN2_EINVAL;
+  if (ns != 16 && ns != 32 && ns != 64 && ns != 128) return PN2_EINVAL;
+  if (M % ns) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!X || !Wf || !sgn || !stats || !pmax || !parg) return PN2_ENULL;
+  if (pro == PRO_BNRELU && (!p0 || !p1)) return PN2_ENULL;
+  if ((M + BM - 1) / BM > 0x7fffffffLL) return PN2_EINVAL;
+  GemmArgs a = {};
+  a.X = X; a.p0 = p0; a.p1 = p1; a.W = Wf; a.stats = stats; a.pmax = pmax; a.parg = parg; a.sgn = sgn;
+  a.M = M; a.K = K; a.N = N; a.ns = ns; a.pro = pro; a.epi = EPI_POOL;
+  const int tiles = (N + 31) / 32;
+  if (pro == PRO_NONE) launch_by_width<PRO_NONE, EPI_POOL>(a, tiles, (hipStream_t)stream);
+  else launch_by_width<PRO_BNRELU, EPI_POOL>(a, tiles, (hipStream_t)stream);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_pool_flip_rows(int N, int K, const float *W, const float *gamma, float *Wf, float *sgn,
+                                  void *stream) {
+  if (N <= 0 || K <= 0) return PN2_EINVAL;
+  if (!W || !Wf || !sgn) return PN2_ENULL;
+  hipLaunchKernelGGL(pool_flip_rows_kernel, dim3(capped_grid((size_t)N * K, 256, 256)), dim3(256), 0,
+                     (hipStream_t)stream, N, K, W, gamma, Wf, sgn);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_pool_finalize(long long R, int C, int ns, const float *pmax, const int *parg, const float *fin,
+                                 const float *sgn, float *out, int *arg, float *yraw, void *stream) {
+  if (R < 0 || C <= 0) return PN2_EINVAL;
+  if (ns != 16 && ns != 32 && ns != 64 && ns != 128) return PN2_EINVAL;
+  if (R == 0) return PN2_OK;
+  if (!pmax || !parg || !fin || !sgn || !out || !arg || !yraw) return PN2_ENULL;
+  const size_t total = (size_t)R * C;
+  const int psz = ns < 32 ? ns : 32;
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream, total, C,
+                     ns / psz, psz, pmax, parg, fin, sgn, out, arg, yraw);
   return pn2_check_launch();
 }
 

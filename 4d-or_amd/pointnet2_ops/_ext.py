@@ -100,6 +100,9 @@ _SIGNATURES = {
     "pn2_bn_relu_bwd_prep": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_rows_max": [ctypes.c_longlong, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_pool_bwd_prep": [ctypes.c_longlong, _c_int] + [_c_vp] * 7,
+    "pn2_pool_flip_rows": [_c_int, _c_int] + [_c_vp] * 5,
+    "pn2_mlp_gemm_pool": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
+    "pn2_pool_finalize": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 8,
 }
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here == ABI mismatch: fail loudly
@@ -901,6 +904,51 @@ def bn_relu_rows_max(y, fin, ns):
     yraw = torch.empty(R, C, dtype=torch.float32, device=y.device)
     _call("pn2_bn_relu_rows_max", y, R, int(ns), C, _ptr(y), _ptr(fin), _ptr(out), _ptr(arg), _ptr(yraw),
           alg_bytes=4 * M * C + 12 * R * C)
+    return out, arg, yraw
+
+
+def pool_flip_rows(W, gamma):
+    """(Wf, sgn): Wf = diag(sgn) W with sgn = -1 where gamma < 0 (pn2_pool_flip_rows)."""
+    _f32(W, "W")
+    N, K = W.shape
+    Wf = torch.empty_like(W)
+    sgn = torch.empty(N, dtype=torch.float32, device=W.device)
+    _call("pn2_pool_flip_rows", W, N, K, _ptr(W), _ptr(gamma), _ptr(Wf), _ptr(sgn))
+    return Wf, sgn
+
+
+def pool_layer_supported(K, N, ns):
+    """Shapes pn2_mlp_gemm_pool covers."""
+    return ns in (16, 32, 64, 128) and N <= 320 and K <= 2048
+
+
+def mlp_gemm_pool(X, Wf, sgn, ns, p=None, stats=None):
+    """Pooled last layer without its (M, N) output: -> (pmax, parg) partial maxima (M / min(ns, 32), N) of
+    pro(X) @ Wf^T; `stats` (2, N) float64 accumulates the column sums (include/pn2_hip.h)."""
+    _f32(X, "X"); _f32(Wf, "Wf")
+    N, K = Wf.shape
+    M = X.size(0)
+    psz = min(int(ns), 32)
+    pmax = torch.empty(M // psz, N, dtype=torch.float32, device=X.device)
+    parg = torch.empty(M // psz, N, dtype=torch.int32, device=X.device)
+    p0, p1 = (None, None) if p is None else (p[0], p[1])
+    _call("pn2_mlp_gemm_pool", X, M, K, N, PRO_NONE if p is None else PRO_BNRELU, _ptr(X), _ptr(p0), _ptr(p1), _ptr(Wf),
+          _ptr(sgn), int(ns), _ptr(stats), _ptr(pmax), _ptr(parg),
+          alg_bytes=4 * (M * K + N * K + 2 * (M // psz) * N), alg_flops=2 * M * N * K,
+          tag=(f"M{M},K{K},N{N},ns{int(ns)}" if DETAIL_TAGS else None))
+    return pmax, parg
+
+
+def pool_finalize(pmax, parg, fin, sgn, ns):
+    """-> (out (R,C), arg (R,C) int32, yraw (R,C)) like bn_relu_rows_max, from the partial maxima of mlp_gemm_pool."""
+    P, C = pmax.shape
+    psz = min(int(ns), 32)
+    R = P * psz // int(ns)
+    out = torch.empty(R, C, dtype=torch.float32, device=pmax.device)
+    arg = torch.empty(R, C, dtype=torch.int32, device=pmax.device)
+    yraw = torch.empty(R, C, dtype=torch.float32, device=pmax.device)
+    _call("pn2_pool_finalize", pmax, R, C, int(ns), _ptr(pmax), _ptr(parg), _ptr(fin), _ptr(sgn), _ptr(out), _ptr(arg),
+          _ptr(yraw), alg_bytes=8 * P * C + 12 * R * C)
     return out, arg, yraw
 
 

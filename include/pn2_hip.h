@@ -292,6 +292,24 @@ int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const float *pooled
                       const float *gP, const float *fin, float *gPm, double *sums,
                       void *stream);
 
+/* Max-pooled LAST layer of an SA stack without materialising its (B*npoint*nsample, C_out) output — the grouped
+ * per-neighbourhood MLP + max of OPS/pointnet2_modules.py:58-70 (Conv2d 1x1 + BatchNorm2d + ReLU, F.max_pool2d) fused:
+ * BatchNorm with a positive scale and ReLU are monotone, so max_s relu(bn(y_s)) = relu(bn(max_s y_s)).
+ *   pn2_pool_flip_rows: Wf = diag(sgn) W, sgn[n] = -1 where gamma[n] < 0 (then the MINIMUM of y is wanted) else +1.
+ *   pn2_mlp_gemm_pool:  y' = pro(X) Wf^T (pro 0 | 1 as pn2_mlp_gemm), never stored; stats[0][n] += sgn[n] sum y',
+ *     stats[1][n] += sum y'^2 (fp64, ACCUMULATES); per partial group of psz = min(ns, 32) consecutive rows and column:
+ *     pmax[M/psz][N] = max y', parg[M/psz][N] = row of the first maximum.  ns in {16, 32, 64, 128}, M % ns == 0.
+ *   pn2_pool_finalize:  combines the ns/psz partial groups (first maximum wins) -> arg[R][C]; yraw = sgn * max
+ *     (= the raw pre-BN value at the arg-max), out = relu(yraw * scale + shift) with fin = [mean|rstd|scale|shift].
+ *   Outputs are what pn2_bn_relu_rows_max produces from a materialised y (equal values; among rows that tie AFTER
+ *   BatchNorm's rounding the arg-max is the row of the largest raw value instead of the first of them). */
+int pn2_pool_flip_rows(int N, int K, const float *W, const float *gamma, float *Wf, float *sgn, void *stream);
+int pn2_mlp_gemm_pool(long long M, int K, int N, int pro, const float *X, const float *p0, const float *p1,
+                      const float *Wf, const float *sgn, int ns, double *stats, float *pmax, int *parg,
+                      void *stream);
+int pn2_pool_finalize(long long R, int C, int ns, const float *pmax, const int *parg, const float *fin,
+                      const float *sgn, float *out, int *arg, float *yraw, void *stream);
+
 /* ----------------------------------------------------- A10, mixed precision ---
  * bf16 variants of the shared-MLP kernels.  The reference trains under 16-bit AMP (scene_graph_prediction/main.py:64
  * `precision=16`; GroupingOperation forces fp32, OPS/pointnet2_utils.py:198): 1x1 convolutions in half precision,
