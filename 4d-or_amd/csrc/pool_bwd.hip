@@ -1,0 +1,422 @@
+// pool_bwd.hip — backward of the max-pooled LAST layer of an SA stack without its (M, N) output.
+//
+// Forward (mlp_gemm.hip, EPI_POOL): y_L = a W^T is never stored, a = relu(bn(y_{L-1})) the activation of the layer
+// below, only pooled = relu(bn(max_s y_L)) and the arg-max rows are kept (OPS/pointnet2_modules.py:58-70).
+// Backward of BatchNorm (batch statistics) + max pool: dL/dy_L = c1 gS + c2 y_L + c3 with per-column constants, gS the
+// pooled gradient scattered to the arg-max rows (ONE non-zero per group and column).  With y_L = a W^T both products of
+// the layer's backward collapse onto K x K matrices (K = width of the layer below, N = width of this one):
+//
+//   dL/da = dL/dy_L W      = a (W^T diag(c2) W)  +  1 (c3^T W)  +  gS (diag(c1) W)
+//                          = a G + 1 v^T + S            G: K x K,  S: row r gets sum_{n: arg[g][n] = r} gPm[g][n] W'[n][:]
+//   dW    = dL/dy_L^T a    = diag(c1) T  +  diag(c2) W (a^T a)  +  c3 (1^T a)
+//                                                       T[n][:] = sum_g gPm[g][n] a[row arg[g][n] of group g][:]
+//
+// so one pass over y_{L-1} computes   g = [a > 0] (a G + v + S)   (stored: the gradient the layer below continues from),
+// its BatchNorm-backward column sums, the Gram matrix a^T a, the column sums of a and T — 2 K^2 MACs per row on the
+// matrix pipe instead of 4 N K, and no read of y_L: the tensor does not exist.  The sparse parts S and T are N K MACs per
+// GROUP and run on the vector unit next to the MFMAs: S as an owner-computes scatter through an LDS tile (LDS float
+// atomics retire at 0.3 lane-operations per clock: tools/ubench/lds_atomic.hip), T as a gather from the activation tile.
+//
+// Tiling: 64-row tiles, 2 K/32 waves.  z-tile (activation) in LDS with pitch K+1: the a G product reads A fragments from
+// it (B = G lives in registers: K/2 per lane, loaded once), the Gram product reads both fragments from it.  Results go
+// through an LDS staging tile so that mask, statistics and the 16-byte stores run in the row-major layout the raw
+// y_{L-1} registers already have.
+#include "pn2_common.h"
+#include "mlp_common.h"
+
+namespace {
+
+struct PoolBwdArgs {
+  const float *Yp;    // [M][K]  raw pre-BN output of the layer below
+  const float *finp;  // [4][K]  mean | rstd | scale | shift of the layer below
+  const float *G;     // [K][K]  W^T diag(c2) W
+  const float *v;     // [K]     W^T c3
+  const float *Wp;    // [N][K]  diag(c1) W
+  const int *arg;     // [R][N]  arg-max row per (group, column)
+  const float *gPm;   // [R][N]  pooled gradient, zero where pooled <= 0
+  float *Gout;        // [M][K]  dL/dz of the layer below (ReLU mask applied)
+  double *sums;       // [2][K]  += sum g, sum g * yhat
+  float *pZ;          // [grid][K][K]  partial a^T a
+  float *pS;          // [grid][K]     partial column sums of a
+  float *pT;          // [grid][N][K]  partial T
+  long long M;
+  int N, ns;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 64;
+
+template <int KT, int TNW>
+__global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs a) {
+  constexpr int K = 32 * KT, NW = 2 * KT, THREADS = 64 * NW;
+  constexpr int LDZ = K + 1;          // activation tile: conflict-free ds_read_b32 for both fragment patterns
+  constexpr int LDT = K + 4;          // staging tile: 16-byte aligned rows
+  constexpr int CG = K / 4;           // threads per row in the row-major phases
+  constexpr int RP = THREADS / CG;    // rows per pass (16)
+  constexpr int NPASS = TM / RP;      // 4
+  constexpr int RPW = TM / NW;        // staging rows a wave owns in the scatter phase
+  constexpr int KH = KT / 2;          // 64-column halves of a row a lane covers
+  constexpr int GB = KT / 2;          // Gram blocks per wave
+  static_assert(RP == 16 && NPASS == 4, "row-major mapping");
+  __shared__ float zt[TM * LDZ];                                    // activation a = relu(bn(y))
+  __shared__ __attribute__((aligned(16))) float st[TM * LDT];       // S, then a G + v + S
+  __shared__ __attribute__((aligned(16))) float ht[TM * LDT];       // yhat = (y - mean) * rstd for the statistics
+  __shared__ __attribute__((aligned(16))) float prm[4 * K];         // mean | rstd | scale | shift of the layer below
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long M = a.M;
+  const int N = a.N, ns = a.ns;
+  const long long R = M / ns;
+  const long long ntiles = (M + TM - 1) / TM;
+
+  // ---- kernel constants ----
+  const int c4 = tid % CG, r0 = tid / CG;
+  for (int i = tid; i < 4 * K; i += THREADS) prm[i] = a.finp[i];
+  const int rb = wave / KT, cb = wave % KT;             // a G output block of this wave
+  float Greg[K / 2];
+#pragma unroll
+  for (int s = 0; s < K / 2; ++s) Greg[s] = a.G[(2 * s + (lane >> 5)) * K + cb * 32 + (lane & 31)];
+  const float vreg = a.v[cb * 32 + (lane & 31)];
+  const int ib = wave >> 1, jb0 = (wave & 1) * GB;      // Gram blocks (ib, jb0 .. jb0 + GB - 1)
+
+  f32x16 accG[GB];
+#pragma unroll
+  for (int b = 0; b < GB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accG[b][r] = 0.f;
+  float tacc[TNW][KH];
+#pragma unroll
+  for (int j = 0; j < TNW; ++j)
+#pragma unroll
+    for (int h = 0; h < KH; ++h) tacc[j][h] = 0.f;
+  float zsum[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int yoff = (r0 * K + 4 * c4) * 4;               // lane part of a row-major address (bytes), pass i adds RP*K*4*i
+  f32x4 ycur[NPASS];
+  auto load_tile = [&](long long tile, f32x4 (&y)[NPASS]) {
+    const long long m0 = tile * TM;
+    const rsrc_t rs_ = make_rsrc(a.Yp + (size_t)m0 * K, (M - m0) * K * 4);
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i)
+      y[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, yoff, i * RP * K * 4, 0));
+  };
+
+  long long tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile, ycur);
+  __syncthreads();                                       // parameter table
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long long m0 = tile * TM;
+    const int mrem = (int)((M - m0) < (long long)TM ? (M - m0) : (long long)TM);
+    // ---- (A) activation tile, normalised rows ----
+    {
+      const f32x4 mu = *reinterpret_cast<const f32x4 *>(&prm[4 * c4]);
+      const f32x4 rs = *reinterpret_cast<const f32x4 *>(&prm[K + 4 * c4]);
+      const f32x4 sc = *reinterpret_cast<const f32x4 *>(&prm[2 * K + 4 * c4]);
+      const f32x4 sh = *reinterpret_cast<const f32x4 *>(&prm[3 * K + 4 * c4]);
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        const int row = r0 + RP * i;
+        const bool valid = row < mrem;
+        f32x4 yh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float y = ycur[i][j];
+          float z = fmaxf(__fmaf_rn(y, sc[j], sh[j]), 0.f);
+          z = valid ? z : 0.f;
+          zsum[j] += z;
+          zt[row * LDZ + 4 * c4 + j] = z;
+          yh[j] = (y - mu[j]) * rs[j];
+        }
+        *reinterpret_cast<f32x4 *>(&ht[row * LDT + 4 * c4]) = yh;
+      }
+    }
+    __syncthreads();                                     // activation tile visible; the previous tile's staging reads are done
+    // the staging rows this wave owns start from zero
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+      for (int h = 0; h < KH; ++h) st[(wave * RPW + rr) * LDT + lane + 64 * h] = 0.f;
+    // next tile's rows in flight behind everything below (the registers are free: (E) works from the LDS tiles)
+    {
+      const long long nt = tile + gridDim.x;
+      load_tile(nt < ntiles ? nt : tile, ycur);
+    }
+
+    // ---- (B) sparse parts: groups that overlap this tile ----
+    const long long g_first = m0 / ns;
+    const int ngt = ns >= TM ? 1 : TM / ns;
+    for (int gi = 0; gi < ngt; ++gi) {
+      const long long g = g_first + gi;
+      if (g >= R) break;
+      const int base = (int)(g * ns - m0);               // tile row of the group's first row (-64 for the second half of ns = 128)
+      const int *argg = a.arg + (size_t)g * N;
+      const float *gpg = a.gPm + (size_t)g * N;
+      // S: every wave scans all N entries and keeps those whose row it owns
+      for (int nb = 0; nb < N; nb += 64) {
+        const int n = nb + lane;
+        int rt = -1;
+        float cf = 0.f;
+        if (n < N) {
+          rt = base + argg[n];
+          cf = gpg[n];
+        }
+        const bool mine = (unsigned)(rt - wave * RPW) < (unsigned)RPW && cf != 0.f;
+        u64 mask = __ballot(mine);
+        while (mask) {
+          int er[4], en[4];
+          float ec[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (mask) {
+              const int e = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              er[u] = __builtin_amdgcn_readlane(rt, e);
+              ec[u] = pn2_readlane_f32(cf, e);
+              en[u] = nb + e;
+            } else {
+              er[u] = wave * RPW;
+              ec[u] = 0.f;
+              en[u] = 0;
+            }
+          }
+          float w[4][KH];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < KH; ++h) w[u][h] = a.Wp[(size_t)en[u] * K + lane + 64 * h];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < KH; ++h) {
+              float *p = &st[er[u] * LDT + lane + 64 * h];
+              *p = __fmaf_rn(ec[u], w[u][h], *p);
+            }
+        }
+      }
+      // T: this wave's columns n = wave * TNW + j gather their arg-max activation row
+      {
+        const int n = wave * TNW + lane;
+        int rt = 0;
+        float cf = 0.f;
+        if (lane < TNW && n < N) {
+          rt = base + argg[n];
+          cf = gpg[n];
+        }
+        const bool ok = (unsigned)rt < (unsigned)TM;
+        cf = ok ? cf : 0.f;
+        rt = ok ? rt : 0;
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          const int r = __builtin_amdgcn_readlane(rt, j);
+          const float c = pn2_readlane_f32(cf, j);
+#pragma unroll
+          for (int h = 0; h < KH; ++h) tacc[j][h] = __fmaf_rn(c, zt[r * LDZ + lane + 64 * h], tacc[j][h]);
+          if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+
+    // ---- (C) matrix products ----
+    f32x16 accZ;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accZ[r] = 0.f;
+    {
+      const float *za = &zt[(rb * 32 + (lane & 31)) * LDZ + (lane >> 5)];
+#pragma unroll
+      for (int s = 0; s < K / 2; ++s) {
+        accZ = __builtin_amdgcn_mfma_f32_32x32x2f32(za[2 * s], Greg[s], accZ, 0, 0, 0);
+        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);     // bounds how many fragment reads are hoisted (registers)
+      }
+      const float *ga = &zt[(lane >> 5) * LDZ + ib * 32 + (lane & 31)];
+      const float *gb = &zt[(lane >> 5) * LDZ + jb0 * 32 + (lane & 31)];
+#pragma unroll
+      for (int s = 0; s < TM / 2; ++s) {
+        const float av = ga[2 * s * LDZ];
+#pragma unroll
+        for (int b = 0; b < GB; ++b)
+          accG[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gb[2 * s * LDZ + b * 32], accG[b], 0, 0, 0);
+        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                                     // S complete, activation tile free
+    // ---- (D) a G + v + S into the staging tile ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      float *p = &st[row * LDT + cb * 32 + (lane & 31)];
+      *p = (accZ[r] + vreg) + *p;
+    }
+    __syncthreads();
+    // ---- (E) mask, statistics, store (row-major) ----
+    {
+      const rsrc_t rso = make_rsrc(a.Gout + (size_t)m0 * K, (M - m0) * K * 4);
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        const int row = r0 + RP * i;
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(&st[row * LDT + 4 * c4]);
+        const f32x4 yh = *reinterpret_cast<const f32x4 *>(&ht[row * LDT + 4 * c4]);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // the activation tile is the forward's own ReLU decision (rows past M hold zeros)
+          const float g = zt[row * LDZ + 4 * c4 + j] > 0.f ? q[j] : 0.f;
+          o[j] = g;
+          cs1[j] += g;
+          cs2[j] = __fmaf_rn(g, yh[j], cs2[j]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), rso,
+                                               yoff, i * RP * K * 4, 0);
+      }
+    }
+  }
+
+  // ---- flush ----
+  __syncthreads();
+  float *rbuf = zt;                                      // [3][THREADS][4]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    rbuf[(0 * THREADS + tid) * 4 + j] = zsum[j];
+    rbuf[(1 * THREADS + tid) * 4 + j] = cs1[j];
+    rbuf[(2 * THREADS + tid) * 4 + j] = cs2[j];
+  }
+  __syncthreads();
+  if (tid < K) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int q = 0; q < RP; ++q) {
+      const int src = ((q * CG + (tid >> 2)) * 4) + (tid & 3);
+      t0 += rbuf[0 * THREADS * 4 + src];
+      t1 += rbuf[1 * THREADS * 4 + src];
+      t2 += rbuf[2 * THREADS * 4 + src];
+    }
+    a.pS[(size_t)blockIdx.x * K + tid] = t0;
+    atomicAdd(a.sums + tid, (double)t1);
+    atomicAdd(a.sums + K + tid, (double)t2);
+  }
+  float *pz = a.pZ + (size_t)blockIdx.x * K * K;
+#pragma unroll
+  for (int b = 0; b < GB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      pz[i * K + (jb0 + b) * 32 + (lane & 31)] = accG[b][r];
+    }
+  float *pt = a.pT + (size_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int j = 0; j < TNW; ++j) {
+    const int n = wave * TNW + j;
+    if (n < N) {
+#pragma unroll
+      for (int h = 0; h < KH; ++h) pt[(size_t)n * K + lane + 64 * h] = tacc[j][h];
+    }
+  }
+}
+
+// G = W^T diag(c2) W, v = W^T c3, W' = diag(c1) W  (consts = [c1 | c2 | c3] x N from pn2_bn_bwd_consts)
+__global__ __launch_bounds__(128) void pool_bwd_setup_kernel(int N, int K, const float *__restrict__ W,
+                                                            const float *__restrict__ consts, float *__restrict__ G,
+                                                            float *__restrict__ v, float *__restrict__ Wp) {
+  const int j = blockIdx.x, k = threadIdx.x;             // grid K + 1 + N blocks, K threads
+  if (k >= K) return;
+  if (j < K) {
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += (double)consts[N + n] * (double)W[(size_t)n * K + j] * (double)W[(size_t)n * K + k];
+    G[j * K + k] = (float)s;
+  } else if (j == K) {
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += (double)consts[2 * N + n] * (double)W[(size_t)n * K + k];
+    v[k] = (float)s;
+  } else {
+    const int n = j - K - 1;
+    Wp[(size_t)n * K + k] = consts[n] * W[(size_t)n * K + k];
+  }
+}
+
+// fp64 sums of the per-workgroup partials: out[e] = sum_b part[b][e]
+__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(int nblk, int count, const float *__restrict__ part,
+                                                             double *__restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * count + e];
+  out[e] = s;
+}
+
+// dW[n][k] = c1[n] T[n][k] + c2[n] sum_j W[n][j] Z[j][k] + c3[n] s[k]
+__global__ __launch_bounds__(128) void pool_bwd_assemble_kernel(int N, int K, int nblk, const float *__restrict__ W,
+                                                               const float *__restrict__ consts,
+                                                               const double *__restrict__ Z, const double *__restrict__ S,
+                                                               const float *__restrict__ pT, float *__restrict__ dW) {
+  const int n = blockIdx.x, k = threadIdx.x;
+  if (k >= K) return;
+  double t = 0.0;
+  for (int b = 0; b < nblk; ++b) t += (double)pT[((size_t)b * N + n) * K + k];
+  double wz = 0.0;
+  for (int j = 0; j < K; ++j) wz += (double)W[(size_t)n * K + j] * Z[j * K + k];
+  dW[(size_t)n * K + k] = (float)((double)consts[n] * t + (double)consts[N + n] * wz + (double)consts[2 * N + n] * S[k]);
+}
+
+int pool_bwd_grid(int K, long long ntiles) {
+  const long long g = K == 64 ? 512 : 256;               // 2 resp. 1 workgroup(s) per CU
+  return (int)(ntiles < g ? ntiles : g);
+}
+
+}  // namespace
+
+extern "C" int pn2_pool_bwd_supported(int N, int K, int ns) {
+  return (K == 64 || K == 128) && N >= 1 && N <= 256 && (ns == 16 || ns == 32 || ns == 64 || ns == 128);
+}
+
+extern "C" size_t pn2_pool_bwd_workspace_bytes(long long M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const long long ntiles = (M + TM - 1) / TM;
+  const size_t g = (size_t)pool_bwd_grid(K, ntiles);
+  // G | v | W' | partial Z, S, T | reduced Z, S (fp64)
+  size_t b = (size_t)(K * K + K + N * K) * 4;
+  b = (b + 255) / 256 * 256;
+  b += g * ((size_t)K * K + K + (size_t)N * K) * 4;
+  b = (b + 255) / 256 * 256;
+  b += (size_t)(K * K + K) * 8;
+  return b;
+}
+
+// Backward of the pooled last layer in Gram form (see the head of this file): replaces group_points_grad-free parts of
+// F.max_pool2d + BatchNorm2d + Conv2d backward (autograd of OPS/pointnet2_modules.py:58-70) for that layer.
+//   consts [3][N] from pn2_bn_bwd_consts of this layer; arg / gPm [M/ns][N] from pn2_pool_finalize / pn2_pool_bwd_prep;
+//   Yp [M][K], fin_p [4][K] of the layer below; Gout [M][K]; sums [2][K] fp64 ACCUMULATES; dW [N][K] is written.
+extern "C" int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, const float *fin_p, const float *W,
+                            const float *consts, const int *arg, const float *gPm, float *Gout, double *sums,
+                            float *dW, void *workspace, size_t workspace_bytes, void *stream) {
+  if (M < 0 || !pn2_pool_bwd_supported(N, K, ns) || M % ns) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Yp || !fin_p || !W || !consts || !arg || !gPm || !Gout || !sums || !dW || !workspace) return PN2_ENULL;
+  if (workspace_bytes < pn2_pool_bwd_workspace_bytes(M, N, K)) return PN2_ENOSPC;
+  hipStream_t s = (hipStream_t)stream;
+  const long long ntiles = (M + TM - 1) / TM;
+  const int grid = pool_bwd_grid(K, ntiles);
+  char *ws = (char *)workspace;
+  float *G = (float *)ws, *v = G + K * K, *Wp = v + K;
+  size_t off = ((size_t)(K * K + K + N * K) * 4 + 255) / 256 * 256;
+  float *pZ = (float *)(ws + off), *pS = pZ + (size_t)grid * K * K, *pT = pS + (size_t)grid * K;
+  off += (size_t)grid * ((size_t)K * K + K + (size_t)N * K) * 4;
+  off = (off + 255) / 256 * 256;
+  double *Zr = (double *)(ws + off), *Sr = Zr + K * K;
+
+  hipLaunchKernelGGL(pool_bwd_setup_kernel, dim3(K + 1 + N), dim3(128), 0, s, N, K, W, consts, G, v, Wp);
+  PoolBwdArgs a;
+  a.Yp = Yp; a.finp = fin_p; a.G = G; a.v = v; a.Wp = Wp; a.arg = arg; a.gPm = gPm; a.Gout = Gout; a.sums = sums;
+  a.pZ = pZ; a.pS = pS; a.pT = pT; a.M = M; a.N = N; a.ns = ns;
+  if (K == 64) {
+    if (N <= 64) hipLaunchKernelGGL((pool_bwd_kernel<2, 16>), dim3(grid), dim3(256), 0, s, a);
+    else if (N <= 128) hipLaunchKernelGGL((pool_bwd_kernel<2, 32>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pool_bwd_kernel<2, 64>), dim3(grid), dim3(256), 0, s, a);
+  } else {
+    if (N <= 128) hipLaunchKernelGGL((pool_bwd_kernel<4, 16>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((pool_bwd_kernel<4, 32>), dim3(grid), dim3(512), 0, s, a);
+  }
+  // pZ and pS are contiguous: one reduction over K*K + K values... they are laid out [grid][K*K] then [grid][K]
+  hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((K * K + 255) / 256), dim3(256), 0, s, grid, K * K, pZ, Zr);
+  hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, grid, K, pS, Sr);
+  hipLaunchKernelGGL(pool_bwd_assemble_kernel, dim3(N), dim3(128), 0, s, N, K, grid, W, consts, Zr, Sr, pT, dW);
+  return pn2_check_launch();
+}

@@ -103,6 +103,7 @@ _SIGNATURES = {
     "pn2_pool_flip_rows": [_c_int, _c_int] + [_c_vp] * 5,
     "pn2_mlp_gemm_pool": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_pool_finalize": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 8,
+    "pn2_pool_bwd": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 10 + [_c_sz, _c_vp],
 }
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here == ABI mismatch: fail loudly
@@ -130,6 +131,10 @@ _lib.pn2_mlp_bwd_bf16_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_bf16_supported.restype = _c_int
 _lib.pn2_mlp_bwd_fused_fold_supported.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_fold_supported.restype = _c_int
+_lib.pn2_pool_bwd_supported.argtypes = [_c_int, _c_int, _c_int]
+_lib.pn2_pool_bwd_supported.restype = _c_int
+_lib.pn2_pool_bwd_workspace_bytes.argtypes = [ctypes.c_longlong, _c_int, _c_int]
+_lib.pn2_pool_bwd_workspace_bytes.restype = _c_sz
 _lib.pn2_abi_version.restype = _c_int
 _lib.pn2_last_hip_error.restype = _c_int
 _lib.pn2_strerror.argtypes = [_c_int]
@@ -141,7 +146,8 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
-                                               "pn2_mlp_bwd_bf16_supported",
+                                               "pn2_mlp_bwd_bf16_supported", "pn2_pool_bwd_supported",
+                                               "pn2_pool_bwd_workspace_bytes",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
 HAS_ROWS = True
@@ -950,6 +956,26 @@ def pool_finalize(pmax, parg, fin, sgn, ns):
     _call("pn2_pool_finalize", pmax, R, C, int(ns), _ptr(pmax), _ptr(parg), _ptr(fin), _ptr(sgn), _ptr(out), _ptr(arg),
           _ptr(yraw), alg_bytes=8 * P * C + 12 * R * C)
     return out, arg, yraw
+
+
+def pool_bwd_supported(N, K, ns):
+    return bool(_lib.pn2_pool_bwd_supported(int(N), int(K), int(ns)))
+
+
+def pool_bwd(Yp, fin_p, W, consts, arg, gPm, ns, sums):
+    """Gram-form backward of the pooled last layer (pn2_pool_bwd): -> (Gout (M,K), dW (N,K)); `sums` (2,K) fp64
+    accumulates the BatchNorm-backward column sums of the layer below."""
+    _f32(Yp, "Yp"); _f32(W, "W")
+    M, K = Yp.shape
+    N = W.size(0)
+    Gout = torch.empty(M, K, dtype=torch.float32, device=Yp.device)
+    dW = torch.empty(N, K, dtype=torch.float32, device=Yp.device)
+    nb = int(_lib.pn2_pool_bwd_workspace_bytes(M, N, K))
+    ws = torch.empty(nb, dtype=torch.uint8, device=Yp.device)
+    _call("pn2_pool_bwd", Yp, M, N, K, int(ns), _ptr(Yp), _ptr(fin_p), _ptr(W), _ptr(consts), _ptr(arg), _ptr(gPm),
+          _ptr(Gout), _ptr(sums), _ptr(dW), _ptr(ws), nb, alg_bytes=4 * (2 * M * K + 2 * (M // int(ns)) * N + N * K),
+          alg_flops=4 * M * K * K, tag=(f"M{M},N{N},K{K},ns{int(ns)}" if DETAIL_TAGS else None))
+    return Gout, dW
 
 
 def pool_bwd_prep(yraw, pooled, gP, fin, sums=None):

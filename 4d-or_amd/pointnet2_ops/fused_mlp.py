@@ -31,6 +31,10 @@ def _ext():
 #: hidden layers with 32 < N, K <= 128 run dgrad and wgrad as one kernel (csrc/mlp_bwd_fused.hip)
 FUSED_BACKWARD = True
 
+#: the max-pooled last layer of a stack never materialises its (M, C_out) output: the forward GEMM reduces the group
+#: maxima in its epilogue (pn2_mlp_gemm_pool), the backward runs in Gram form from y_{L-1} alone (pn2_pool_bwd)
+POOL_FUSED = True
+
 #: arithmetic of the shared-MLP stacks.  float32 = exact fp32 MFMA (the parity path, default).  bfloat16 = the MI355X
 #: counterpart of the reference's 16-bit AMP training (scene_graph_prediction/main.py:64 `precision=16`): activations
 #: between the layers stored as bf16, bf16 MFMA with fp32 accumulation, fp32 weights / BatchNorm statistics / weight
@@ -126,15 +130,24 @@ class _FusedMLP(Function):
         ys, fins, batch_flags = [], [], []
         stat_bufs = e.zero_arena(x.device, [((2, conv.out_channels), torch.float64) for conv, _ in layers])
         cur = x
+        # pooled last layer without its output tensor: needs the Gram-form backward whenever anything needs a gradient
+        Kl, Nl = layers[-1][0].in_channels, layers[-1][0].out_channels
+        needs_grad = any(ctx.needs_input_grad)
+        pool_fused = bool(POOL_FUSED and ns and L >= 2 and M % ns == 0 and getattr(e, "pool_layer_supported", None)
+                          and e.pool_layer_supported(Kl, Nl, ns) and (not needs_grad or e.pool_bwd_supported(Nl, Kl, ns)))
+        pooled_parts = None
         for l, (conv, bn) in enumerate(layers):
             W = params[3 * l].view(conv.out_channels, conv.in_channels)
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
             use_batch = bn.training or bn.running_mean is None
             pro = e.PRO_NONE if l == 0 else e.PRO_BNRELU
             p = None if l == 0 else (fins[-1][2], fins[-1][3])
+            if pool_fused and l == L - 1:
+                Wf, sgn = e.pool_flip_rows(W.contiguous(), gamma)
+                pooled_parts = e.mlp_gemm_pool(cur, Wf, sgn, ns, p=p, stats=stat_bufs[l]) + (sgn,)
             if use_batch:
                 stats = stat_bufs[l]
-                y = e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
+                y = None if pooled_parts is not None else e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
                 momentum = 0.0
                 rm = rv = nbt = None
                 if (bn.training and bn.track_running_stats and bn.running_mean is not None
@@ -149,7 +162,7 @@ class _FusedMLP(Function):
                 fo = getattr(ctx, "fin_out", None)          # segmented call: this scan's block of the layer's (S,4,C) buffer
                 fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt, out=None if fo is None else fo[l])
             else:
-                y = e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
+                y = None if pooled_parts is not None else e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
                 rstd = torch.rsqrt(bn.running_var + bn.eps)
                 scale = gamma * rstd
                 fin = torch.stack([bn.running_mean, rstd, scale, beta - bn.running_mean * scale]).contiguous()
@@ -158,11 +171,14 @@ class _FusedMLP(Function):
             batch_flags.append(use_batch)
             cur = y
         yraw = None
-        if ns:
+        if pooled_parts is not None:
+            out, arg, yraw = e.pool_finalize(pooled_parts[0], pooled_parts[1], fins[-1], pooled_parts[2], ns)
+        elif ns:
             out, arg, yraw = e.bn_relu_rows_max(ys[-1], fins[-1], ns)
         else:
             out, arg = e.bn_relu_apply(ys[-1], fins[-1]), None
         ctx.ns, ctx.L, ctx.batch_flags = ns, L, batch_flags
+        ctx.pool_fused = pooled_parts is not None
         ctx.shapes = [params[3 * l].shape for l in range(L)]
         saved = [x] + ys + fins + [params[3 * l] for l in range(L)] + [params[3 * l + 1] for l in range(L)]
         if ns:
@@ -191,6 +207,7 @@ class _FusedMLP(Function):
         need_dgrad0 = ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None)
         K0 = x.size(1)
         fold = (L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0]
+                and not (ctx.pool_fused and L == 2)          # (layer 1 is then the pooled layer: Gram-form kernel)
                 and e.mlp_bwd_fused_fold_supported(Ws[1].size(0), Ws[1].size(1), K0))
         arena = e.zero_arena(x.device, [((2, Ws[-1].size(0)), f64)] + [((2, Ws[l].size(1)), f64) for l in range(L)] +
                              [(tuple(Ws[l].shape), f32) for l in range(L)] +
@@ -207,6 +224,15 @@ class _FusedMLP(Function):
         grads = [None] * (3 * L)
         gx = None
         for l in range(L - 1, -1, -1):
+            if l == L - 1 and ctx.pool_fused:
+                # pooled layer in Gram form: y_l was never stored (csrc/pool_bwd.hip)
+                consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
+                grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+                G, dW = e.pool_bwd(ys[l - 1], fins[l - 1], Ws[l].contiguous(), consts, arg, gPm, ns, sums_in[l])
+                grads[3 * l] = dW.view(ctx.shapes[l])
+                sums = sums_in[l]
+                gmode, arg, gPm = e.PRO_GY, None, None
+                continue
             one_pass = (l <= 1 and fold) or (l > 0 and FUSED_BACKWARD and
                                              e.mlp_bwd_fused_supported(Ws[l].size(0), Ws[l].size(1)))
             Wt = None

@@ -310,6 +310,22 @@ int pn2_mlp_gemm_pool(long long M, int K, int N, int pro, const float *X, const 
 int pn2_pool_finalize(long long R, int C, int ns, const float *pmax, const int *parg, const float *fin,
                       const float *sgn, float *out, int *arg, float *yraw, void *stream);
 
+/* Backward of that layer in Gram form (csrc/pool_bwd.hip): with y_L = a W^T never stored, a = relu(bn(y_{L-1})),
+ *   dL/da = a (W^T diag(c2) W) + 1 (W^T c3)^T + S,   S[row] = sum over the columns n whose arg-max is `row` of
+ *           gPm[g][n] c1[n] W[n][:]
+ *   dW    = diag(c1) T + diag(c2) W (a^T a) + c3 (1^T a),   T[n][:] = sum_g gPm[g][n] a[arg-max row of (g, n)][:]
+ * — the autograd of Conv2d 1x1 + BatchNorm2d (batch statistics) + ReLU + F.max_pool2d (OPS/pointnet2_modules.py:58-70)
+ * for the pooled layer from ONE pass over y_{L-1}: 2 K^2 MACs per row instead of 4 N K, no (M, N) tensor.
+ *   consts = [c1|c2|c3] x N of this layer (pn2_bn_bwd_consts on the sums of pn2_pool_bwd_prep); arg, gPm [M/ns][N];
+ *   Yp [M][K] and fin_p = [mean|rstd|scale|shift] x K of the layer below.  Writes Gout [M][K] = dL/dz_{L-1} (ReLU
+ *   mask applied) and dW [N][K]; sums [2][K] += (sum Gout, sum Gout * yhat_{L-1}) (fp64, ACCUMULATES).
+ *   K in {64, 128}, N <= 256, ns in {16, 32, 64, 128} (pn2_pool_bwd_supported); workspace >= pn2_pool_bwd_workspace_bytes. */
+int pn2_pool_bwd_supported(int N, int K, int ns);
+size_t pn2_pool_bwd_workspace_bytes(long long M, int N, int K);
+int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, const float *fin_p, const float *W,
+                 const float *consts, const int *arg, const float *gPm, float *Gout, double *sums, float *dW,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
 /* ----------------------------------------------------- A10, mixed precision ---
  * bf16 variants of the shared-MLP kernels.  The reference trains under 16-bit AMP (scene_graph_prediction/main.py:64
  * `precision=16`; GroupingOperation forces fp32, OPS/pointnet2_utils.py:198): 1x1 convolutions in half precision,
