@@ -36,9 +36,7 @@ struct PoolBwdArgs {
   const float *gPm;   // [R][N]  pooled gradient, zero where pooled <= 0
   float *Gout;        // [M][K]  dL/dz of the layer below (ReLU mask applied)
   double *sums;       // [2][K]  += sum g, sum g * yhat
-  float *pZ;          // [grid][K][K]  partial a^T a
-  float *pS;          // [grid][K]     partial column sums of a
-  float *pT;          // [grid][N][K]  partial T
+  float *part;        // [grid][K*K + K + N*K]  per-workgroup partials: a^T a | column sums of a | T
   long long M;
   int N, ns;
 };
@@ -47,7 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 64;
 
-template <int KT, int TNW>
+template <int KT, int TNW, bool WLDS>
 __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs a) {
   constexpr int K = 32 * KT, NW = 2 * KT, THREADS = 64 * NW;
   constexpr int LDZ = K + 1;          // activation tile: conflict-free ds_read_b32 for both fragment patterns
@@ -58,21 +56,27 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
   constexpr int RPW = TM / NW;        // staging rows a wave owns in the scatter phase
   constexpr int KH = KT / 2;          // 64-column halves of a row a lane covers
   constexpr int GB = KT / 2;          // Gram blocks per wave
-  static_assert(RP == 16 && NPASS == 4, "row-major mapping");
+  constexpr int NBC = NW * TNW / 64;  // 64-column batches of a group's N entries
+  constexpr int GMAX = (8 / NBC) < 4 ? (8 / NBC) : 4;   // groups per tile this instantiation holds index registers for
+  static_assert(RP == 16 && NPASS == 4 && NBC >= 1, "row-major mapping");
   __shared__ float zt[TM * LDZ];                                    // activation a = relu(bn(y))
   __shared__ __attribute__((aligned(16))) float st[TM * LDT];       // S, then a G + v + S
-  __shared__ __attribute__((aligned(16))) float ht[TM * LDT];       // yhat = (y - mean) * rstd for the statistics
   __shared__ __attribute__((aligned(16))) float prm[4 * K];         // mean | rstd | scale | shift of the layer below
+  __shared__ float wl[WLDS ? NW * TNW * K : 1];                     // W' = diag(c1) W, resident (lane = column: conflict-free)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long M = a.M;
   const int N = a.N, ns = a.ns;
   const long long R = M / ns;
   const long long ntiles = (M + TM - 1) / TM;
+  const int ngt = ns >= TM ? 1 : TM / ns;               // groups that overlap a tile (<= GMAX by the host's choice)
 
   // ---- kernel constants ----
   const int c4 = tid % CG, r0 = tid / CG;
   for (int i = tid; i < 4 * K; i += THREADS) prm[i] = a.finp[i];
+  if (WLDS)
+    for (int i = tid; i < N * K; i += THREADS) wl[WLDS ? i : 0] = a.Wp[i];
   const int rb = wave / KT, cb = wave % KT;             // a G output block of this wave
   float Greg[K / 2];
 #pragma unroll
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
   float zsum[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
 
   const int yoff = (r0 * K + 4 * c4) * 4;               // lane part of a row-major address (bytes), pass i adds RP*K*4*i
-  f32x4 ycur[NPASS];
+  f32x4 ycur[NPASS], ynxt[NPASS];
   auto load_tile = [&](long long tile, f32x4 (&y)[NPASS]) {
     const long long m0 = tile * TM;
     const rsrc_t rs_ = make_rsrc(a.Yp + (size_t)m0 * K, (M - m0) * K * 4);
@@ -101,34 +105,56 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
     for (int i = 0; i < NPASS; ++i)
       y[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, yoff, i * RP * K * 4, 0));
   };
+  // index registers of a tile: S scans all N entries of each group (lane = entry), T takes this wave's TNW columns.
+  // Loaded one phase ahead (behind the matrix products of the previous tile).
+  int sa[GMAX][NBC], ta[GMAX];
+  float sg[GMAX][NBC], tg[GMAX];
+  auto load_idx = [&](long long tile) {
+    const long long g_first = tile * TM / ns;
+#pragma unroll
+    for (int gi = 0; gi < GMAX; ++gi) {
+      const long long g = g_first + gi;
+      const bool gok = gi < ngt && g < R;
+      const int *argg = a.arg + (size_t)(gok ? g : 0) * N;
+      const float *gpg = a.gPm + (size_t)(gok ? g : 0) * N;
+#pragma unroll
+      for (int q = 0; q < NBC; ++q) {
+        const int n = q * 64 + lane;
+        const bool ok = gok && n < N;
+        sa[gi][q] = ok ? argg[ok ? n : 0] : -(1 << 20);
+        sg[gi][q] = ok ? gpg[ok ? n : 0] : 0.f;
+      }
+      const int n = wave * TNW + lane;
+      const bool ok = gok && lane < TNW && n < N;
+      ta[gi] = ok ? argg[ok ? n : 0] : -(1 << 20);
+      tg[gi] = ok ? gpg[ok ? n : 0] : 0.f;
+    }
+  };
 
   long long tile = blockIdx.x;
-  if (tile < ntiles) load_tile(tile, ycur);
-  __syncthreads();                                       // parameter table
+  if (tile < ntiles) {
+    load_tile(tile, ycur);
+    load_idx(tile);
+  }
+  __syncthreads();                                       // parameter table, resident W'
   for (; tile < ntiles; tile += gridDim.x) {
     const long long m0 = tile * TM;
     const int mrem = (int)((M - m0) < (long long)TM ? (M - m0) : (long long)TM);
-    // ---- (A) activation tile, normalised rows ----
+    // ---- (A) activation tile ----
     {
-      const f32x4 mu = *reinterpret_cast<const f32x4 *>(&prm[4 * c4]);
-      const f32x4 rs = *reinterpret_cast<const f32x4 *>(&prm[K + 4 * c4]);
       const f32x4 sc = *reinterpret_cast<const f32x4 *>(&prm[2 * K + 4 * c4]);
       const f32x4 sh = *reinterpret_cast<const f32x4 *>(&prm[3 * K + 4 * c4]);
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
         const int row = r0 + RP * i;
         const bool valid = row < mrem;
-        f32x4 yh;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float y = ycur[i][j];
-          float z = fmaxf(__fmaf_rn(y, sc[j], sh[j]), 0.f);
+          float z = fmaxf(__fmaf_rn(ycur[i][j], sc[j], sh[j]), 0.f);
           z = valid ? z : 0.f;
           zsum[j] += z;
           zt[row * LDZ + 4 * c4 + j] = z;
-          yh[j] = (y - mu[j]) * rs[j];
         }
-        *reinterpret_cast<f32x4 *>(&ht[row * LDT + 4 * c4]) = yh;
       }
     }
     __syncthreads();                                     // activation tile visible; the previous tile's staging reads are done
@@ -137,74 +163,74 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
     for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
       for (int h = 0; h < KH; ++h) st[(wave * RPW + rr) * LDT + lane + 64 * h] = 0.f;
-    // next tile's rows in flight behind everything below (the registers are free: (E) works from the LDS tiles)
-    {
-      const long long nt = tile + gridDim.x;
-      load_tile(nt < ntiles ? nt : tile, ycur);
-    }
+    // next tile's rows in flight behind everything below
+    const long long nt = (tile + gridDim.x) < ntiles ? tile + gridDim.x : tile;
+    load_tile(nt, ynxt);
 
-    // ---- (B) sparse parts: groups that overlap this tile ----
+    // ---- (B) sparse parts ----
     const long long g_first = m0 / ns;
-    const int ngt = ns >= TM ? 1 : TM / ns;
-    for (int gi = 0; gi < ngt; ++gi) {
-      const long long g = g_first + gi;
-      if (g >= R) break;
-      const int base = (int)(g * ns - m0);               // tile row of the group's first row (-64 for the second half of ns = 128)
-      const int *argg = a.arg + (size_t)g * N;
-      const float *gpg = a.gPm + (size_t)g * N;
-      // S: every wave scans all N entries and keeps those whose row it owns
-      for (int nb = 0; nb < N; nb += 64) {
-        const int n = nb + lane;
-        int rt = -1;
-        float cf = 0.f;
-        if (n < N) {
-          rt = base + argg[n];
-          cf = gpg[n];
-        }
-        const bool mine = (unsigned)(rt - wave * RPW) < (unsigned)RPW && cf != 0.f;
-        u64 mask = __ballot(mine);
-        while (mask) {
-          int er[4], en[4];
-          float ec[4];
+    // S: the RPW staging rows this wave owns lie in ONE group (RPW divides ns): of that group's N entries (lane = entry)
+    // the wave keeps those whose arg-max row it owns and adds coef * W'[n][:] to the row (lanes = columns; LDS
+    // read-modify-write, exclusive rows — LDS float atomics are 20x slower, tools/ubench/lds_atomic.hip)
+    {
+      const int gw = ns >= TM ? 0 : (wave * RPW) / ns;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (mask) {
-              const int e = __builtin_ctzll(mask);
-              mask &= mask - 1;
-              er[u] = __builtin_amdgcn_readlane(rt, e);
-              ec[u] = pn2_readlane_f32(cf, e);
-              en[u] = nb + e;
-            } else {
-              er[u] = wave * RPW;
-              ec[u] = 0.f;
-              en[u] = 0;
+      for (int gi = 0; gi < GMAX; ++gi) {
+        if (gi == gw) {
+          const int base = (int)((g_first + gi) * ns - m0);
+#pragma unroll
+          for (int q = 0; q < NBC; ++q) {
+            const int rt = base + sa[gi][q];
+            const float cf = sg[gi][q];
+            const bool mine = (unsigned)(rt - wave * RPW) < (unsigned)RPW && cf != 0.f;
+            u64 mask = __ballot(mine);
+#ifdef PB_NO_S
+            mask = 0;
+#endif
+            while (mask) {
+              int er[4], en[4];
+              float ec[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                if (mask) {
+                  const int e = __builtin_ctzll(mask);
+                  mask &= mask - 1;
+                  er[u] = __builtin_amdgcn_readlane(rt, e);
+                  ec[u] = pn2_readlane_f32(cf, e);
+                  en[u] = q * 64 + e;
+                } else {
+                  er[u] = wave * RPW;
+                  ec[u] = 0.f;
+                  en[u] = 0;
+                }
+              }
+              float w[4][KH];
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int h = 0; h < KH; ++h)
+                  w[u][h] = WLDS ? wl[WLDS ? en[u] * K + lane + 64 * h : 0] : a.Wp[(size_t)en[u] * K + lane + 64 * h];
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int h = 0; h < KH; ++h) {
+                  float *p = &st[er[u] * LDT + lane + 64 * h];
+                  *p = __fmaf_rn(ec[u], w[u][h], *p);
+                }
             }
           }
-          float w[4][KH];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int h = 0; h < KH; ++h) w[u][h] = a.Wp[(size_t)en[u] * K + lane + 64 * h];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int h = 0; h < KH; ++h) {
-              float *p = &st[er[u] * LDT + lane + 64 * h];
-              *p = __fmaf_rn(ec[u], w[u][h], *p);
-            }
         }
       }
-      // T: this wave's columns n = wave * TNW + j gather their arg-max activation row
-      {
-        const int n = wave * TNW + lane;
-        int rt = 0;
-        float cf = 0.f;
-        if (lane < TNW && n < N) {
-          rt = base + argg[n];
-          cf = gpg[n];
-        }
+    }
+    // T: this wave's columns n = wave * TNW + j gather their arg-max activation row of every group in the tile
+#ifndef PB_NO_T
+#pragma unroll
+    for (int gi = 0; gi < GMAX; ++gi) {
+      if (gi < ngt) {
+        const int base = (int)((g_first + gi) * ns - m0);  // tile row of the group's first row (-64: second half of ns = 128)
+        int rt = base + ta[gi];
         const bool ok = (unsigned)rt < (unsigned)TM;
-        cf = ok ? cf : 0.f;
+        const float cf = ok ? tg[gi] : 0.f;
         rt = ok ? rt : 0;
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
@@ -216,6 +242,8 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
         }
       }
     }
+#endif
+    load_idx(nt);                                        // (the index registers are free now)
 
     // ---- (C) matrix products ----
     f32x16 accZ;
@@ -239,7 +267,7 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
         if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();                                     // S complete, activation tile free
+    __syncthreads();                                     // S complete, matrix products done with the activation tile
     // ---- (D) a G + v + S into the staging tile ----
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -251,11 +279,12 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
     // ---- (E) mask, statistics, store (row-major) ----
     {
       const rsrc_t rso = make_rsrc(a.Gout + (size_t)m0 * K, (M - m0) * K * 4);
+      const f32x4 mu = *reinterpret_cast<const f32x4 *>(&prm[4 * c4]);
+      const f32x4 rs = *reinterpret_cast<const f32x4 *>(&prm[K + 4 * c4]);
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
         const int row = r0 + RP * i;
         const f32x4 q = *reinterpret_cast<const f32x4 *>(&st[row * LDT + 4 * c4]);
-        const f32x4 yh = *reinterpret_cast<const f32x4 *>(&ht[row * LDT + 4 * c4]);
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -263,15 +292,18 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
           const float g = zt[row * LDZ + 4 * c4 + j] > 0.f ? q[j] : 0.f;
           o[j] = g;
           cs1[j] += g;
-          cs2[j] = __fmaf_rn(g, yh[j], cs2[j]);
+          cs2[j] = __fmaf_rn(g, (ycur[i][j] - mu[j]) * rs[j], cs2[j]);
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), rso,
                                                yoff, i * RP * K * 4, 0);
       }
     }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) ycur[i] = ynxt[i];
   }
 
   // ---- flush ----
+  float *prec = a.part + (size_t)blockIdx.x * (K * K + K + (size_t)N * K);
   __syncthreads();
   float *rbuf = zt;                                      // [3][THREADS][4]
 #pragma unroll
@@ -289,11 +321,11 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
       t1 += rbuf[1 * THREADS * 4 + src];
       t2 += rbuf[2 * THREADS * 4 + src];
     }
-    a.pS[(size_t)blockIdx.x * K + tid] = t0;
+    prec[K * K + tid] = t0;
     atomicAdd(a.sums + tid, (double)t1);
     atomicAdd(a.sums + K + tid, (double)t2);
   }
-  float *pz = a.pZ + (size_t)blockIdx.x * K * K;
+  float *pz = prec;
 #pragma unroll
   for (int b = 0; b < GB; ++b)
 #pragma unroll
@@ -301,7 +333,7 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
       const int i = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       pz[i * K + (jb0 + b) * 32 + (lane & 31)] = accG[b][r];
     }
-  float *pt = a.pT + (size_t)blockIdx.x * N * K;
+  float *pt = prec + K * K + K;
 #pragma unroll
   for (int j = 0; j < TNW; ++j) {
     const int n = wave * TNW + j;
@@ -332,28 +364,37 @@ __global__ __launch_bounds__(128) void pool_bwd_setup_kernel(int N, int K, const
   }
 }
 
-// fp64 sums of the per-workgroup partials: out[e] = sum_b part[b][e]
+// fp64 sums of the per-workgroup partial records: out[e] += sum over this block's slice of the records (out zeroed by
+// the caller; grid.y slices of the records so that the sum is not one thread's serial chain of nblk dependent adds)
 __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(int nblk, int count, const float *__restrict__ part,
                                                              double *__restrict__ out) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= count) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * count + e];
-  out[e] = s;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+    s0 += (double)part[(size_t)b * count + e];
+    s1 += (double)part[(size_t)(b + 1) * count + e];
+    s2 += (double)part[(size_t)(b + 2) * count + e];
+    s3 += (double)part[(size_t)(b + 3) * count + e];
+  }
+  for (; b < b1; ++b) s0 += (double)part[(size_t)b * count + e];
+  atomicAdd(out + e, (s0 + s1) + (s2 + s3));
 }
 
-// dW[n][k] = c1[n] T[n][k] + c2[n] sum_j W[n][j] Z[j][k] + c3[n] s[k]
-__global__ __launch_bounds__(128) void pool_bwd_assemble_kernel(int N, int K, int nblk, const float *__restrict__ W,
+// dW[n][k] = c1[n] T[n][k] + c2[n] sum_j W[n][j] Z[j][k] + c3[n] s[k]   (red = reduced record: Z | s | T)
+__global__ __launch_bounds__(128) void pool_bwd_assemble_kernel(int N, int K, const float *__restrict__ W,
                                                                const float *__restrict__ consts,
-                                                               const double *__restrict__ Z, const double *__restrict__ S,
-                                                               const float *__restrict__ pT, float *__restrict__ dW) {
+                                                               const double *__restrict__ red, float *__restrict__ dW) {
   const int n = blockIdx.x, k = threadIdx.x;
   if (k >= K) return;
-  double t = 0.0;
-  for (int b = 0; b < nblk; ++b) t += (double)pT[((size_t)b * N + n) * K + k];
+  const double *Z = red, *S = red + K * K, *T = red + K * K + K;
   double wz = 0.0;
   for (int j = 0; j < K; ++j) wz += (double)W[(size_t)n * K + j] * Z[j * K + k];
-  dW[(size_t)n * K + k] = (float)((double)consts[n] * t + (double)consts[N + n] * wz + (double)consts[2 * N + n] * S[k]);
+  dW[(size_t)n * K + k] =
+      (float)((double)consts[n] * T[(size_t)n * K + k] + (double)consts[N + n] * wz + (double)consts[2 * N + n] * S[k]);
 }
 
 int pool_bwd_grid(int K, long long ntiles) {
@@ -364,19 +405,22 @@ int pool_bwd_grid(int K, long long ntiles) {
 }  // namespace
 
 extern "C" int pn2_pool_bwd_supported(int N, int K, int ns) {
-  return (K == 64 || K == 128) && N >= 1 && N <= 256 && (ns == 16 || ns == 32 || ns == 64 || ns == 128);
+  if (!((K == 64 || K == 128) && N >= 1 && N <= 256 && (ns == 16 || ns == 32 || ns == 64 || ns == 128))) return 0;
+  // index registers: (64 / ns) groups x ceil(N / 64) entry batches per tile must fit eight batches
+  const int nbc = K == 64 ? (N <= 64 ? 1 : N <= 128 ? 2 : 4) : (N <= 128 ? 2 : 4);
+  const int ngt = ns >= 64 ? 1 : 64 / ns;
+  return ngt * nbc <= 8;
 }
 
 extern "C" size_t pn2_pool_bwd_workspace_bytes(long long M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const long long ntiles = (M + TM - 1) / TM;
   const size_t g = (size_t)pool_bwd_grid(K, ntiles);
-  // G | v | W' | partial Z, S, T | reduced Z, S (fp64)
-  size_t b = (size_t)(K * K + K + N * K) * 4;
-  b = (b + 255) / 256 * 256;
-  b += g * ((size_t)K * K + K + (size_t)N * K) * 4;
-  b = (b + 255) / 256 * 256;
-  b += (size_t)(K * K + K) * 8;
+  const size_t rec = (size_t)K * K + K + (size_t)N * K;
+  // G | v | W' | per-workgroup partial records | reduced record (fp64)
+  size_t b = ((size_t)(K * K + K + N * K) * 4 + 255) / 256 * 256;
+  b += (g * rec * 4 + 255) / 256 * 256;
+  b += rec * 8;
   return b;
 }
 
@@ -397,26 +441,27 @@ extern "C" int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, 
   char *ws = (char *)workspace;
   float *G = (float *)ws, *v = G + K * K, *Wp = v + K;
   size_t off = ((size_t)(K * K + K + N * K) * 4 + 255) / 256 * 256;
-  float *pZ = (float *)(ws + off), *pS = pZ + (size_t)grid * K * K, *pT = pS + (size_t)grid * K;
-  off += (size_t)grid * ((size_t)K * K + K + (size_t)N * K) * 4;
-  off = (off + 255) / 256 * 256;
-  double *Zr = (double *)(ws + off), *Sr = Zr + K * K;
+  const size_t rec = (size_t)K * K + K + (size_t)N * K;
+  float *part = (float *)(ws + off);
+  off += ((size_t)grid * rec * 4 + 255) / 256 * 256;
+  double *red = (double *)(ws + off);
+  if (hipMemsetAsync(red, 0, rec * 8, s) != hipSuccess) return PN2_ELAUNCH;
 
   hipLaunchKernelGGL(pool_bwd_setup_kernel, dim3(K + 1 + N), dim3(128), 0, s, N, K, W, consts, G, v, Wp);
   PoolBwdArgs a;
   a.Yp = Yp; a.finp = fin_p; a.G = G; a.v = v; a.Wp = Wp; a.arg = arg; a.gPm = gPm; a.Gout = Gout; a.sums = sums;
-  a.pZ = pZ; a.pS = pS; a.pT = pT; a.M = M; a.N = N; a.ns = ns;
+  a.part = part; a.M = M; a.N = N; a.ns = ns;
   if (K == 64) {
-    if (N <= 64) hipLaunchKernelGGL((pool_bwd_kernel<2, 16>), dim3(grid), dim3(256), 0, s, a);
-    else if (N <= 128) hipLaunchKernelGGL((pool_bwd_kernel<2, 32>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((pool_bwd_kernel<2, 64>), dim3(grid), dim3(256), 0, s, a);
+    if (N <= 64) hipLaunchKernelGGL((pool_bwd_kernel<2, 16, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (N <= 128) hipLaunchKernelGGL((pool_bwd_kernel<2, 32, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pool_bwd_kernel<2, 64, false>), dim3(grid), dim3(256), 0, s, a);
   } else {
-    if (N <= 128) hipLaunchKernelGGL((pool_bwd_kernel<4, 16>), dim3(grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((pool_bwd_kernel<4, 32>), dim3(grid), dim3(512), 0, s, a);
+    if (N <= 128) hipLaunchKernelGGL((pool_bwd_kernel<4, 16, false>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((pool_bwd_kernel<4, 32, false>), dim3(grid), dim3(512), 0, s, a);
   }
-  // pZ and pS are contiguous: one reduction over K*K + K values... they are laid out [grid][K*K] then [grid][K]
-  hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((K * K + 255) / 256), dim3(256), 0, s, grid, K * K, pZ, Zr);
-  hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, grid, K, pS, Sr);
-  hipLaunchKernelGGL(pool_bwd_assemble_kernel, dim3(N), dim3(128), 0, s, N, K, grid, W, consts, Zr, Sr, pT, dW);
+  const int slices = grid >= 64 ? 16 : 1;
+  hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((unsigned)((rec + 255) / 256), slices), dim3(256), 0, s, grid, (int)rec,
+                     part, red);
+  hipLaunchKernelGGL(pool_bwd_assemble_kernel, dim3(N), dim3(128), 0, s, N, K, W, consts, red, dW);
   return pn2_check_launch();
 }
