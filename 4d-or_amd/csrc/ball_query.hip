@@ -127,8 +127,9 @@ struct GridHdr {
 static_assert(sizeof(GridHdr) == kGridHdr * 4, "header layout");
 
 __device__ __forceinline__ int grid_coord(float v, float mn, float inv, int dim) {
-  int c = (int)floorf((v - mn) * inv);
-  return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+  // comparisons first: a NaN / infinite coordinate lands in cell 0 resp. the last one without an undefined float -> int cast
+  const float f = floorf((v - mn) * inv);
+  return f >= 0.f ? (f < (float)dim ? (int)f : dim - 1) : 0;
 }
 
 // workspace per cloud: GridHdr | cell_start[kGridMaxG^3 + 1] | records[N] (float4: x, y, z, bits(index))
@@ -166,13 +167,14 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int N, int G, float
       float mn = red[d][0], mx = red[3 + d][0];
       for (int w = 1; w < 16; ++w) { mn = fminf(mn, red[d][w]); mx = fmaxf(mx, red[3 + d][w]); }
       if (!(mx >= mn)) { mn = 0.f; mx = 0.f; }               // N == 0 / NaN coordinates: one cell
-      const float ext = mx - mn;
+      float ext = mx - mn;
+      if (!(ext < 3.0e38f)) { mn = 0.f; ext = 0.f; }          // infinite extent: one cell along this axis (inv = 0 below)
       const float cs = fmaxf(r * 1.0001f, ext / (float)G);      // cell edge >= r (strictly, against rounding)
       int dim = cs > 0.f ? (int)floorf(ext / cs) + 1 : 1;
       if (dim > G) dim = G;
       if (dim < 1) dim = 1;
       h.mn[d] = mn;
-      h.inv[d] = cs > 0.f ? 1.0f / cs : 0.f;
+      h.inv[d] = (cs > 0.f && dim > 1) ? 1.0f / cs : 0.f;
       h.dim[d] = dim;
       cells *= dim;
     }
@@ -401,7 +403,9 @@ extern "C" int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample,
                                  int *idx, void *workspace, size_t workspace_bytes, void *stream) {
   if (B < 0 || N < 0 || m < 0 || nsample < 0) return PN2_EINVAL;
   const size_t need = pn2_ball_query_grid_bytes(B, N, nsample);
-  if (need == 0 || !workspace || workspace_bytes == 0 || m == 0)
+  // the cell edge is sized from the radius: a negative / non-finite radius (r*r is still a valid threshold for the
+  // scan) would make cells smaller than the ball and the 27-cell search miss hits — such calls take the scan
+  if (need == 0 || !workspace || workspace_bytes == 0 || m == 0 || !(radius > 0.f) || !(radius < 3.0e38f))
     return pn2_ball_query(B, N, m, radius, nsample, new_xyz, xyz, idx, stream);
   if (workspace_bytes < need) return PN2_ENOSPC;
   if (!new_xyz || !idx || !xyz) return PN2_ENULL;

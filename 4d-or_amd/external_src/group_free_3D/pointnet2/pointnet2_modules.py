@@ -49,9 +49,11 @@ class PointnetSAModuleVotes(nn.Module):
         new_xyz = pointnet2_utils.gather_operation(
             xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
         idx = self.grouper.query(xyz, new_xyz)
-        if inverse_index:
-            _pm.attach_inverse_indices([self.grouper], [idx], xyz.size(1))
-        return {"inds": inds, "new_xyz": new_xyz, "idx": idx, "n_src": xyz.size(1)}
+        inv = _pm.build_inverse_indices([self.grouper], [idx], xyz.size(1))[0] if inverse_index else None
+        # sample_uniformly / ret_unique_cnt: the count belongs to THIS query (the grouper's last_unique_cnt is overwritten
+        # by the next call — a geometry computed ahead of time must carry its own)
+        return {"inds": inds, "new_xyz": new_xyz, "idx": idx, "inv": inv, "n_src": xyz.size(1),
+                "unique_cnt": getattr(self.grouper, "last_unique_cnt", None) if self.ret_unique_cnt else None}
 
     def _check_geometry(self, xyz, geometry):
         """A prefetched sample_and_query() result must belong to a batch of this shape on this device."""
@@ -70,8 +72,9 @@ class PointnetSAModuleVotes(nn.Module):
         if geometry is not None and self.pooling == "max" and _pm._rows_path_ok(xyz, features):
             self._check_geometry(xyz, geometry)
             rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, geometry["new_xyz"],
-                                     pointnet2_utils.as_rows(features), idx=geometry["idx"])
-            return geometry["new_xyz"], pointnet2_utils.rows_to_channels(rows), geometry["inds"]
+                                     pointnet2_utils.as_rows(features), idx=geometry["idx"], inv=geometry.get("inv"))
+            out = (geometry["new_xyz"], pointnet2_utils.rows_to_channels(rows), geometry["inds"])
+            return out + (geometry.get("unique_cnt"),) if self.ret_unique_cnt else out
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:

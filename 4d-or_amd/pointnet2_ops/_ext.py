@@ -36,6 +36,10 @@ if not os.path.exists(LIB_PATH):
     )
 
 _lib = ctypes.CDLL(LIB_PATH)
+_lib.pn2_abi_version.restype = ctypes.c_int
+if int(_lib.pn2_abi_version()) != 3:
+    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 3: "
+                      f"rebuild it (`make -C {os.path.join(_PKG_DIR, 'csrc')}`)")
 
 _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                         ctypes.c_void_p, ctypes.c_size_t)
@@ -141,6 +145,9 @@ _lib.pn2_strerror.argtypes = [_c_int]
 _lib.pn2_strerror.restype = ctypes.c_char_p
 
 ABI_VERSION = int(_lib.pn2_abi_version())
+#: the header revision this binding was written against: a stale prebuilt libpn2_hip.so fails here with a version
+#: error instead of an AttributeError on the first missing symbol
+EXPECTED_ABI_VERSION = 3
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
@@ -517,15 +524,10 @@ def group_inverse_index(idx, n):
 
 
 def attach_inverse_index(idx, n):
-    """Build the inverse of `idx` and hang it on the tensor (`idx.pn2_inverse`): the backward of the fused grouping nodes
-    then sums the feature gradient per point (pn2_group_rows_grad_csr, bit-reproducible) instead of scattering atomics."""
-    idx.pn2_inverse = (int(n),) + group_inverse_index(idx, n)
-    return idx
-
-
-def inverse_index_of(idx, n):
-    inv = getattr(idx, "pn2_inverse", None)
-    return inv[1:] if inv is not None and inv[0] == int(n) else None
+    """Deprecated spelling of group_inverse_index (round 2 hung the result on the idx tensor as a Python attribute, which
+    neither record_stream nor a graph capture's clones can see): returns (ptr, refs) — carry it next to `idx`, e.g. as
+    geometry["inv"]."""
+    return group_inverse_index(idx, n)
 
 
 def group_rows_grad_csr(grad_out, inv, n, c, col0, out=None):

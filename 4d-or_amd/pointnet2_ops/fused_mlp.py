@@ -118,7 +118,7 @@ class _FusedMLP(Function):
         e = _ext()
         ctx.group = group
         if group is not None:
-            xyz, new_xyz, idx, use_xyz, normalize, radius = group
+            xyz, new_xyz, idx, use_xyz, normalize, radius = group[:6]
             ctx.feat_shape = None if x is None else tuple(x.shape)
             pre = getattr(ctx, "x_rows", None)          # a segmented call groups the whole batch once and hands in the rows
             x = pre if pre is not None else e.group_concat_rows(
@@ -280,7 +280,7 @@ class _FusedMLP(Function):
             idx = ctx.group[2]
             Bq, npoint, nsample = idx.shape
             Bf, Nf, Cf = ctx.feat_shape
-            inv = e.inverse_index_of(idx, Nf)
+            inv = ctx.group[6] if len(ctx.group) > 6 else None          # (ptr, refs) carried next to idx
             if inv is not None:          # prefetched inverse index: per-point sum, no atomics (csrc/group_csr.hip)
                 gx = e.group_rows_grad_csr(gx.view(Bq, npoint, nsample, Cf), inv, Nf, Cf, 0, out=getattr(ctx, "gx_out", None))
             else:                        # (a segmented call hands in its zero-filled slice of the batch's gradient)
@@ -297,7 +297,7 @@ class _FusedMLPBf16(Function):
         e = _ext()
         ctx.group = group
         if group is not None:
-            xyz, new_xyz, idx, use_xyz, normalize, radius = group
+            xyz, new_xyz, idx, use_xyz, normalize, radius = group[:6]
             ctx.feat_shape = None if x is None else tuple(x.shape)
             k_in = (3 if use_xyz else 0) + (0 if x is None else x.size(2))
             pre = getattr(ctx, "x_rows", None)          # a segmented call groups the whole batch once and hands in the rows
@@ -422,7 +422,7 @@ class _FusedMLPBf16(Function):
             idx = ctx.group[2]
             Bq, npoint, nsample = idx.shape
             Bf, Nf, Cf = ctx.feat_shape
-            inv = e.inverse_index_of(idx, Nf)
+            inv = ctx.group[6] if len(ctx.group) > 6 else None          # (ptr, refs) carried next to idx
             if inv is not None:          # prefetched inverse index: per-point sum, no atomics (csrc/group_csr.hip)
                 gx = e.group_rows_grad_csr(gx.view(Bq, npoint, nsample, Cf), inv, Nf, Cf, 0, out=getattr(ctx, "gx_out", None))
             else:                        # (a segmented call hands in its zero-filled slice of the batch's gradient)
@@ -554,7 +554,7 @@ class _SegmentedGroupMLP(Function):
 
     @staticmethod
     def forward(ctx, x, ns, layers, group, sizes, inner, *params):
-        xyz, new_xyz, idx, use_xyz, normalize, radius = group
+        xyz, new_xyz, idx, use_xyz, normalize, radius = group[:6]
         m = idx.size(1)
         # the grouping has no statistics: ONE gather for the whole batch (before the fork), the scans take row slices
         # (same-box A/B at 8 scans, bf16: 195.4 -> 202.4 scans/s)
@@ -640,14 +640,14 @@ def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0) -> torch.Tens
 
 
 def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius,
-                         clouds_per_scan: Optional[Sequence[int]] = None) -> torch.Tensor:
+                         clouds_per_scan: Optional[Sequence[int]] = None, inv=None) -> torch.Tensor:
     """Ball-query neighbourhoods -> shared MLP -> max, one autograd node:
     xyz (B,N,3), new_xyz (B,m,3), feats_rows (B,N,C)|None, idx (B,m,ns) -> (B, m, C_out).
     `clouds_per_scan` (sums to B): BatchNorm batch statistics per scan (see _SegmentedGroupMLP)."""
     layers = parse_stack(mlp)
     assert layers is not None
     B, m, ns = idx.shape
-    group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius)
+    group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius, inv)    # inv: (ptr, refs) of the whole batch's idx
     if clouds_per_scan is not None and len(clouds_per_scan) > 1:
         if sum(clouds_per_scan) != B:
             raise RuntimeError("fused_group_mlp_pool: clouds_per_scan must sum to the number of clouds")

@@ -25,6 +25,7 @@ Two execution paths produce the same numbers (tests compare them):
 from typing import List, Optional, Tuple
 
 import contextlib
+import threading
 
 import torch
 import torch.nn as nn
@@ -116,27 +117,36 @@ def mlp_rows(mlp: nn.Module, rows: torch.Tensor) -> torch.Tensor:
 # training mode processes each scan's clouds [c_s, c_{s+1}) as its own call (own batch statistics, running statistics
 # updated scan after scan, in order) — everything without statistics (sampling, ball query, grouping geometry) stays batched.
 # The row counts per call stay large (>= 10^5), so the kernels keep their efficiency; the price is S times the launches.
-_SCAN_SEGMENTS = {}          # clouds in the batch -> clouds per scan
+class _ScanSegments(threading.local):
+    """clouds in the batch -> clouds per scan, PER THREAD (a DataParallel replica or a threaded loader must not see
+    another thread's segmentation); only SA stacks whose input has exactly that many clouds are split."""
+
+    def __init__(self):
+        self.table = {}
+
+
+_SEG = _ScanSegments()
 
 
 @contextlib.contextmanager
 def per_scan_statistics(*clouds_per_scan):
     """`clouds_per_scan`: one sequence per encoder input of the step, e.g. ([9] * S, [72] * S) for the object and the
     relation encoder of the scene-graph model.  Batches of one scan need no entry."""
-    saved = dict(_SCAN_SEGMENTS)
+    table = _SEG.table
+    saved = dict(table)
     try:
         for sizes in clouds_per_scan:
             sizes = tuple(int(v) for v in sizes)
             if len(sizes) < 2:
                 continue
             total = sum(sizes)
-            if _SCAN_SEGMENTS.get(total, sizes) != sizes:
+            if table.get(total, sizes) != sizes:
                 raise RuntimeError("per_scan_statistics: two inputs with the same number of clouds but different scans")
-            _SCAN_SEGMENTS[total] = sizes
+            table[total] = sizes
         yield
     finally:
-        _SCAN_SEGMENTS.clear()
-        _SCAN_SEGMENTS.update(saved)
+        table.clear()
+        table.update(saved)
 
 
 def _trains_batchnorm(mlp: nn.Module) -> bool:
@@ -144,12 +154,12 @@ def _trains_batchnorm(mlp: nn.Module) -> bool:
                for m in mlp.modules())
 
 
-def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _whole_batch=False) -> torch.Tensor:
+def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _whole_batch=False, inv=None) -> torch.Tensor:
     """One SA scale on the rows path: group -> shared MLP -> max -> (B, npoint, C_out).
     Ball-query groupers with a fusable MLP run as a single autograd node (gather, MLP, pool and
     the scatter of the feature gradient); anything else goes through forward_rows + mlp_pool_rows."""
     from pointnet2_ops import fused_mlp
-    sizes = None if _whole_batch else _SCAN_SEGMENTS.get(xyz.size(0))
+    sizes = None if _whole_batch else _SEG.table.get(xyz.size(0))
     if sizes is not None and _trains_batchnorm(mlp):
         if (_FUSED_MLP and isinstance(grouper, pointnet2_utils.QueryAndGroup) and new_xyz is not None
                 and (grouper.use_xyz or feats_rows is not None)
@@ -168,10 +178,10 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
         if idx is None:
             idx = grouper.query(xyz, new_xyz)
         return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
-                                              grouper.normalize_xyz, grouper.radius)
+                                              grouper.normalize_xyz, grouper.radius, inv=inv)
     if idx is not None:
         g = pointnet2_utils.group_concat_rows(xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
-                                              grouper.normalize_xyz, grouper.radius)
+                                              grouper.normalize_xyz, grouper.radius, inv=inv)
         return mlp_pool_rows(mlp, g)
     return mlp_pool_rows(mlp, grouper.forward_rows(xyz, new_xyz, feats_rows))
 
@@ -184,14 +194,17 @@ def crowded_balls(grouper, n_src: int) -> bool:
     return n_src * float(grouper.radius) ** 3 > 4.0 * grouper.nsample
 
 
-def attach_inverse_indices(groupers, idx_list, n_src: int):
-    """Inverse neighbourhood index for every crowded ball-query scale (hung on the idx tensor, see _ext.attach_inverse_index)."""
-    attach = getattr(pointnet2_utils._ext, "attach_inverse_index", None)
-    if attach is None:
-        return
+def build_inverse_indices(groupers, idx_list, n_src: int):
+    """Inverse neighbourhood index (ptr, refs) for every crowded ball-query scale, None for the others.  The result
+    travels NEXT to the indices (geometry["inv"]): explicit tensors are seen by record_stream, by a graph capture's static
+    copies and by _check_geometry, which a Python attribute on the idx tensor was not."""
+    build = getattr(pointnet2_utils._ext, "group_inverse_index", None)
+    out = []
     for g, idx in zip(groupers, idx_list):
-        if idx is not None and isinstance(g, pointnet2_utils.QueryAndGroup) and crowded_balls(g, n_src):
-            attach(idx, n_src)
+        ok = (build is not None and idx is not None and isinstance(g, pointnet2_utils.QueryAndGroup)
+              and crowded_balls(g, n_src))
+        out.append(tuple(build(idx, n_src)) if ok else None)
+    return out
 
 
 def mlp_pool_rows(mlp: nn.Module, grouped: torch.Tensor) -> torch.Tensor:
@@ -237,9 +250,8 @@ class _PointnetSAModuleBase(nn.Module):
         new_xyz = self._sample(xyz)
         idx = [g.query(xyz, new_xyz) if (new_xyz is not None and isinstance(g, pointnet2_utils.QueryAndGroup)) else None
                for g in self.groupers]
-        if inverse_index:
-            attach_inverse_indices(self.groupers, idx, xyz.size(1))
-        return {"new_xyz": new_xyz, "idx": idx, "n_src": xyz.size(1)}
+        inv = build_inverse_indices(self.groupers, idx, xyz.size(1)) if inverse_index else [None] * len(idx)
+        return {"new_xyz": new_xyz, "idx": idx, "inv": inv, "n_src": xyz.size(1)}
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor], geometry=None
                 ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
@@ -248,7 +260,8 @@ class _PointnetSAModuleBase(nn.Module):
         `geometry` = sample_and_query(xyz) computed earlier (optional; rows path only)."""
         if geometry is not None and _rows_path_ok(xyz, features):
             self._check_geometry(xyz, geometry)
-            return geometry["new_xyz"], self._forward_rows(xyz, geometry["new_xyz"], features, geometry["idx"])
+            return geometry["new_xyz"], self._forward_rows(xyz, geometry["new_xyz"], features, geometry["idx"],
+                                                           geometry.get("inv"))
         new_xyz = self._sample(xyz)
         if _rows_path_ok(xyz, features):
             return new_xyz, self._forward_rows(xyz, new_xyz, features)
@@ -272,6 +285,14 @@ class _PointnetSAModuleBase(nn.Module):
                 raise RuntimeError(f"geometry: new_xyz must be ({B}, {self.npoint}, 3) on {xyz.device}")
         if "n_src" in geometry and geometry["n_src"] != xyz.size(1):
             raise RuntimeError(f"geometry was computed for clouds of {geometry['n_src']} points, got {xyz.size(1)}")
+        inv = geometry.get("inv")
+        if inv is not None:
+            if len(inv) != len(idx):
+                raise RuntimeError("geometry: one inverse index (or None) per scale expected")
+            for i, v in zip(idx, inv):
+                if v is not None and (i is None or v[0].numel() != B * xyz.size(1) + 1 or v[1].numel() != i.numel()
+                                      or v[0].device != xyz.device):
+                    raise RuntimeError("geometry: inverse index does not belong to these neighbourhoods")
         for g, i in zip(self.groupers, idx):
             if i is None:
                 continue
@@ -279,13 +300,14 @@ class _PointnetSAModuleBase(nn.Module):
                     or tuple(i.shape[:2]) != (B, self.npoint) or i.size(2) != g.nsample):
                 raise RuntimeError(f"geometry: idx must be int32 ({B}, {self.npoint}, {g.nsample}) on {xyz.device}")
 
-    def _forward_rows(self, xyz, new_xyz, features, idx=None):
+    def _forward_rows(self, xyz, new_xyz, features, idx=None, inv=None):
         feats_rows = pointnet2_utils.as_rows(features)
         B = xyz.size(0)
         pooled = []
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             pooled.append(sa_scale_rows(grouper, mlp, xyz, new_xyz, feats_rows,
-                                        idx=None if idx is None else idx[k]))        # (B, npoint, C_out)
+                                        idx=None if idx is None else idx[k],
+                                        inv=None if inv is None else inv[k]))        # (B, npoint, C_out)
         rows = pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=2)
         return pointnet2_utils.rows_to_channels(rows)           # (B, sum C_out, npoint) view
 

@@ -176,12 +176,12 @@ def rows_to_channels(rows: torch.Tensor) -> torch.Tensor:
 
 class _GroupConcatRows(Function):
     @staticmethod
-    def forward(ctx, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius):
+    def forward(ctx, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius, inv=None):
         ctx.save_for_backward(idx)
         ctx.n_src = xyz.size(1)
         ctx.c = 0 if feats_rows is None else feats_rows.size(2)
         ctx.col0 = 3 if use_xyz else 0
-        ctx.inv = getattr(_ext, "inverse_index_of", lambda *_: None)(idx, ctx.n_src)
+        ctx.inv = inv                     # (ptr, refs) of _ext.group_inverse_index, or None
         return _ext.group_concat_rows(xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius)
 
     @staticmethod
@@ -193,13 +193,14 @@ class _GroupConcatRows(Function):
                 g = _ext.group_rows_grad_csr(grad_out.contiguous(), ctx.inv, ctx.n_src, ctx.c, ctx.col0)
             else:
                 g = _ext.group_rows_grad(grad_out.contiguous(), idx, ctx.n_src, ctx.c, ctx.col0)
-        return None, None, g, None, None, None, None
+        return None, None, g, None, None, None, None, None
 
 
-def group_concat_rows(xyz, new_xyz, feats_rows, idx, use_xyz=True, normalize=False, radius=None):
+def group_concat_rows(xyz, new_xyz, feats_rows, idx, use_xyz=True, normalize=False, radius=None, inv=None):
     """Fused QueryAndGroup tail: -> (B,npoint,nsample,[3+]C) rows.  Gradients flow
-    to `feats_rows` only (callers route coordinates that need grad to the literal path)."""
-    return _GroupConcatRows.apply(xyz, new_xyz, feats_rows, idx, bool(use_xyz), bool(normalize), radius)
+    to `feats_rows` only (callers route coordinates that need grad to the literal path).
+    `inv`: inverse of `idx` (_ext.group_inverse_index) -> atomic-free feature gradient."""
+    return _GroupConcatRows.apply(xyz, new_xyz, feats_rows, idx, bool(use_xyz), bool(normalize), radius, inv)
 
 
 class _RowsMax(Function):

@@ -119,6 +119,11 @@ class SceneBatch:
         counts_e = self.edge_ptr[1:] - self.edge_ptr[:-1]
         # host copies (the collate step builds the batch on the CPU: no device read-back later)
         self.nodes_per_scene, self.edges_per_scene = counts_n.tolist(), counts_e.tolist()
+        # every BatchNorm of the model normalises over ONE scan's rows: torch's batch_norm refuses a single row in
+        # training mode ("Expected more than 1 value per channel"), and a scan needs >= 2 objects to have an edge at all
+        # (EXT or_dataset.py:130-133 builds all ordered pairs) — refuse here instead of normalising with var = 0
+        if min(self.nodes_per_scene) < 2 or min(self.edges_per_scene) < 2:
+            raise RuntimeError("SceneBatch: every scan needs at least 2 nodes and 2 edges (per-scan BatchNorm statistics)")
         ids = torch.arange(self.num_scenes, device=self.node_ptr.device)
         self.node_scene = torch.repeat_interleave(ids, counts_n)
         self.edge_scene = torch.repeat_interleave(ids, counts_e)

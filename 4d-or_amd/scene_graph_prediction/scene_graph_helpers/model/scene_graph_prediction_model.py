@@ -154,7 +154,11 @@ class SGPNModelWrapper(nn.Module):
         picked = -logp.gather(1, target.unsqueeze(1)).squeeze(1) * w
         num = torch.zeros(num_scenes, dtype=logp.dtype, device=logp.device).index_add_(0, scene, picked)
         den = torch.zeros(num_scenes, dtype=logp.dtype, device=logp.device).index_add_(0, scene, w)
-        return (num / den).mean()
+        # a scan whose targets all carry zero class weight has no loss (F.nll_loss of that scan alone is 0/0): it is left
+        # out of the mean instead of poisoning the other scans' loss and gradients with NaN
+        valid = den > 0
+        per = torch.where(valid, num / torch.where(valid, den, torch.ones_like(den)), torch.zeros_like(num))
+        return per.sum() / valid.sum().clamp_min(1).to(per.dtype)
 
     def loss(self, obj_pred, rel_pred, batch):
         w_obj = self.weights_obj.to(batch["gt_class"].device, non_blocking=True)

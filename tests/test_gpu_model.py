@@ -86,11 +86,14 @@ def test_gf3d_backbone_gpu_matches_golden_fixture():
     assert np.array_equal(ep["sa1_inds"][:, :256].cpu().numpy(), z["sa1_inds"])      # FPS indices bit-exact
     assert np.array_equal(ep["sa2_inds"][:, :64].cpu().numpy(), z["sa2_inds"])
     assert np.array_equal(ep["sa4_xyz"].detach().cpu().numpy(), z["sa4_xyz"])
-    np.testing.assert_allclose(ep["sa4_features"].detach().cpu().numpy()[:, ::4], z["sa4_features"], atol=1e-3, rtol=1e-3)
-    np.testing.assert_allclose(feats.detach().cpu().numpy()[:, ::8, ::4], z["fp2_features"], atol=1e-3, rtol=1e-3)
-    assert abs(float(loss.detach()) - float(z["loss"][0])) < 1e-5
+    # END-TO-END train mode: six batch-statistics BatchNorm levels re-normalise upstream reassociation noise, so this is
+    # looser than the per-level 1e-4 checks of tests/test_gpu_round2.py (measured round 3: features 6.4e-5 absolute on
+    # magnitude 4.2, first-layer weight gradient 3.6e-3 in norm — an arg-max tie re-routes a gradient)
+    np.testing.assert_allclose(ep["sa4_features"].detach().cpu().numpy()[:, ::4], z["sa4_features"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(feats.detach().cpu().numpy()[:, ::8, ::4], z["fp2_features"], atol=2e-4, rtol=1e-4)
+    assert abs(float(loss.detach()) - float(z["loss"][0])) < 1e-6
     g0 = net.sa1.mlp_module.layer0.conv.weight.grad.cpu().numpy()
-    assert np.linalg.norm(g0 - z["grad_sa1_conv0"]) / np.linalg.norm(z["grad_sa1_conv0"]) < 8e-2
+    assert np.linalg.norm(g0 - z["grad_sa1_conv0"]) / np.linalg.norm(z["grad_sa1_conv0"]) < 2e-2
 
 
 def test_msg_encoder_gpu_matches_golden_fixture():
@@ -126,7 +129,7 @@ def test_precomputed_geometry_on_a_side_stream_gives_identical_results(monkeypat
         geo = net.precompute_geometry(pc)
     torch.cuda.current_stream().wait_stream(side)
     # level 1 gathers the input colours (no gradient): no inverse index; levels 2-4 are crowded (N r^3 > 4 nsample)
-    assert [hasattr(lvl["idx"], "pn2_inverse") for lvl in geo["sa"]] == [False, True, True, True]
+    assert [lvl["inv"] is not None for lvl in geo["sa"]] == [False, True, True, True]      # explicit tensors next to idx
     with torch.no_grad():
         got = net(pc, geometry=geo)
     for k in ref:

@@ -499,51 +499,31 @@ def test_prepared_scan_runs_through_the_model():
 
 
 # ------------------------------------------------------------------------------------------------- (f)4
-def _ref_algos():
-    """The reference's own Cython module, compiled from role_prediction/graphormer/algos.pyx into oracle/_ref by
-    `make -C oracle ref` (__graft_entry__.build() does it whenever /root/reference is present; the .so travels).
-    Cython registers the module under its source-tree name `role_prediction.graphormer.algos` as well — exactly the
-    name of the product's mirror — so the product module is imported first and its sys.modules entry restored."""
-    import importlib
-    import sys
-    import role_prediction.graphormer.algos as product
-    d = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref"))
-    if d not in sys.path:
-        sys.path.insert(0, d)
-    try:
-        ref = importlib.import_module("algos")
-    except ImportError:
-        pytest.skip("oracle/_ref/algos*.so not built (needs /root/reference + cython: make -C oracle ref)")
-    sys.modules["role_prediction.graphormer.algos"] = product
-    assert ref is not product and ref.__file__.endswith(".so") and product.__file__.endswith("algos.py")
-    return ref, product
-
-
 @pytest.mark.parametrize("n,density,seed", [(1, 0.5, 0), (2, 1.0, 1), (5, 0.3, 2), (13, 0.15, 3), (14, 0.12, 4), (20, 0.1, 5),
                                             (31, 0.05, 6), (40, 0.04, 7), (9, 0.0, 8)])
 def test_graphormer_algos_match_the_compiled_reference(n, density, seed):
     """floyd_warshall / gen_edge_input (role_prediction/graphormer/algos.pyx:11-89) on the GPU == the reference's own
     module: hop distances, intermediate vertices (incl. vertex 12 colliding with the MAX_DIST marker for n > 12 and
-    vertex 0 never expanded) and the edge features along every path, all int64, bit for bit; also batched."""
-    ref, algos = _ref_algos()
-    rng = np.random.default_rng(seed)
-    adj = rng.random((n, n)) < density
-    np.fill_diagonal(adj, False)
-    Mr, Pr = ref.floyd_warshall(adj)
+    vertex 0 never expanded) and the edge features along every path, all int64, bit for bit; also batched.  The expected
+    values are a fixture generated in the build container from the reference's compiled Cython module
+    (tests/golden/make_algos_golden.py -> tests/golden/algos.npz); nothing built from the reference is imported here."""
+    import role_prediction.graphormer.algos as algos
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "algos.npz"))
+    key = f"n{n}_s{seed}"
+    adj, feat = fx[key + "_adj"], fx[key + "_feat"]
+    Mr, Pr = fx[key + "_M"], fx[key + "_P"]
     M, P = algos.floyd_warshall(adj)
     assert M.dtype == np.int64 and np.array_equal(M, Mr) and np.array_equal(P, Pr)
-    feat = rng.integers(1, 50, size=(n, n, 3))
     md = int(np.amax(Mr)) if n else 0
     if md > 0:
-        Er = ref.gen_edge_input(md, Pr, feat)
+        Er = fx[key + "_E"]
         E = algos.gen_edge_input(md, P, feat)
         assert E.shape == Er.shape and np.array_equal(E, Er)
     # a batch of graphs in one launch
     adjs = torch.from_numpy(np.stack([adj, adj.T, np.zeros_like(adj)])).cuda()
     Mb, Pb = algos.floyd_warshall(adjs)
-    for b, a in enumerate((adj, adj.T, np.zeros_like(adj))):
-        mr, pr = ref.floyd_warshall(a)
-        assert np.array_equal(Mb[b].cpu().numpy(), mr) and np.array_equal(Pb[b].cpu().numpy(), pr)
+    for b, tag in enumerate(("", "_T", "_Z")):
+        assert np.array_equal(Mb[b].cpu().numpy(), fx[key + tag + "_M"]) and np.array_equal(Pb[b].cpu().numpy(), fx[key + tag + "_P"])
 
 
 def test_instance_label_fps_call_shape():
