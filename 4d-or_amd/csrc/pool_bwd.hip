@@ -344,6 +344,333 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
   }
 }
 
+// K = 64: eight waves per 64-row tile, one workgroup per CU.  Matrix roles: waves 0-3 own the four 32 x 32 blocks of
+// a G (+ v + S), waves 4-7 the four blocks of the Gram matrix a^T a.  The sparse parts are laid out so that the inner loops
+// have no scalar bookkeeping at all (per-entry readlane / find-first-bit chains cost 180 cycles per entry):
+//   T (waves 4-7): lanes = columns n, registers = a slab of columns k; every lane walks along ITS arg-max row of the
+//     activation tile with immediate offsets;
+//   S (waves 0-3): lanes = the 64 rows of the tile, registers = a 16-column slab of k.  While the tile is staged, every
+//     thread files ONE (group, column) entry under its arg-max row — rank from an LDS integer atomic, up to CAP entries per
+//     row, the rest in an overflow list — and in the scatter phase lane r walks the list of row r, reading W'[n][slab]
+//     (pitch K + 1: the rows n differ per lane).  The order inside a row's list is the arrival order of the atomics: the
+//     fp32 sum of a row is not bit-reproducible from run to run (like the atomic weight gradients of mlp_wgrad).
+#ifdef PB_PROF
+#define PB_T(i) { const long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; }
+#else
+#define PB_T(i)
+#endif
+template <int NH>
+__global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a) {
+#ifdef PB_PROF
+  long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = __builtin_readcyclecounter();
+#endif
+  constexpr int K = 64, NW = 8, THREADS = 512;
+  constexpr int LDZ = K + 1, LDT = K + 4, LDW = K + 1;
+  constexpr int CG = K / 4;           // 16 threads per row
+  constexpr int RP = THREADS / CG;    // 32 rows per pass
+  constexpr int NPASS = TM / RP;      // 2
+  constexpr int NPAD = 64 * NH;       // entries per group, padded (N <= NPAD)
+  constexpr int GMAX = THREADS / NPAD < 4 ? THREADS / NPAD : 4;   // groups per tile: one entry per thread
+  constexpr int KQ = 16 * NH;         // T: waves 4-7 = (64-column half of N) x (KQ-column slab of K)
+  constexpr int KS = K / 4;           // S: 16-column slab of K per wave (waves 0-3; waves 4-7 run T meanwhile)
+  constexpr int CAP = 8;              // listed entries per row
+  constexpr int OVC = GMAX * NPAD;    // overflow capacity: every entry of the tile
+  __shared__ float zt[TM * LDZ];
+  __shared__ __attribute__((aligned(16))) float st[TM * LDT];
+  __shared__ __attribute__((aligned(16))) float prm[4 * K];
+  __shared__ float wl[NPAD * LDW];
+  __shared__ int cnt[TM + 1];         // entries filed per row; [TM] = overflow count
+  __shared__ int lst_n[TM * CAP];
+  __shared__ float lst_c[TM * CAP];
+  __shared__ int ovf_rn[OVC];         // row << 16 | n
+  __shared__ float ovf_c[OVC];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool zrole = wave < 4;
+  const long long M = a.M;
+  const int N = a.N, ns = a.ns;
+  const long long R = M / ns;
+  const long long ntiles = (M + TM - 1) / TM;
+  const int ngt = ns >= TM ? 1 : TM / ns;
+
+  const int c4 = tid % CG, r0 = tid / CG;
+  for (int i = tid; i < 4 * K; i += THREADS) prm[i] = a.finp[i];
+  for (int i = tid; i < N * K; i += THREADS) wl[(i / K) * LDW + (i % K)] = a.Wp[i];
+  if (tid <= TM) cnt[tid] = 0;
+  const int blk = wave & 3;
+  const int rb = blk >> 1, cb = blk & 1;                 // output block of a G (waves 0-3) / Gram block (waves 4-7)
+  // B fragments of a G (waves 0-3 only)
+  float Greg[K / 2];
+#pragma unroll
+  for (int s = 0; s < K / 2; ++s) Greg[s] = zrole ? a.G[(2 * s + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
+  const float vreg = a.v[cb * 32 + (lane & 31)];
+  const int tn0 = ((wave & 3) % NH) * 64, tk0 = ((wave & 3) / NH) * KQ;     // T (waves 4-7): first column n, first column k
+  float tacc[KQ];
+#pragma unroll
+  for (int kk = 0; kk < KQ; ++kk) tacc[kk] = 0.f;
+
+  f32x16 acc;                                            // role 1: per-tile a G block; role 2: running Gram block
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float zsum[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int yoff = (r0 * K + 4 * c4) * 4;
+  f32x4 ycur[NPASS], ynxt[NPASS];
+  auto load_tile = [&](long long tile, f32x4 (&y)[NPASS]) {
+    const long long m0 = tile * TM;
+    const rsrc_t rs_ = make_rsrc(a.Yp + (size_t)m0 * K, (M - m0) * K * 4);
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i)
+      y[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, yoff, i * RP * K * 4, 0));
+  };
+  // index registers, loaded one phase ahead: the thread's own entry (group tid / NPAD, column tid % NPAD) for the row
+  // lists, and for waves 4-7 the column tn0 + lane of every group for T
+  const int egi = tid / NPAD, en = tid % NPAD;
+  int ea, ta[GMAX];
+  float ec, tg[GMAX];
+  auto load_idx = [&](long long tile) {
+    const long long g_first = tile * TM / ns;
+    {
+      const long long g = g_first + egi;
+      const bool ok = egi < ngt && g < R && en < N;
+      ea = ok ? a.arg[(size_t)(ok ? g : 0) * N + (ok ? en : 0)] : -(1 << 20);
+      ec = ok ? a.gPm[(size_t)(ok ? g : 0) * N + (ok ? en : 0)] : 0.f;
+    }
+#pragma unroll
+    for (int gi = 0; gi < GMAX; ++gi) {
+      const long long g = g_first + gi;
+      const int n = tn0 + lane;
+      const bool ok = !zrole && gi < ngt && g < R && n < N;
+      ta[gi] = ok ? a.arg[(size_t)(ok ? g : 0) * N + (ok ? n : 0)] : -(1 << 20);
+      tg[gi] = ok ? a.gPm[(size_t)(ok ? g : 0) * N + (ok ? n : 0)] : 0.f;
+    }
+  };
+
+  long long tile = blockIdx.x;
+  if (tile < ntiles) {
+    load_tile(tile, ycur);
+    load_idx(tile);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long long m0 = tile * TM;
+    const int mrem = (int)((M - m0) < (long long)TM ? (M - m0) : (long long)TM);
+    const long long g_first = m0 / ns;
+    PB_T(9)
+    // ---- (A) activation tile; this thread's entry filed under its arg-max row ----
+    {
+      const f32x4 sc = *reinterpret_cast<const f32x4 *>(&prm[2 * K + 4 * c4]);
+      const f32x4 sh = *reinterpret_cast<const f32x4 *>(&prm[3 * K + 4 * c4]);
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        const int row = r0 + RP * i;
+        const bool valid = row < mrem;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float z = fmaxf(__fmaf_rn(ycur[i][j], sc[j], sh[j]), 0.f);
+          z = valid ? z : 0.f;
+          zsum[j] += z;
+          zt[row * LDZ + 4 * c4 + j] = z;
+        }
+      }
+      const int row = (int)((g_first + egi) * ns - m0) + ea;     // tile row of the entry's arg-max (ns = 128: may lie outside)
+      if ((unsigned)row < (unsigned)TM && ec != 0.f) {
+        const int rank = atomicAdd(&cnt[row], 1);
+        if (rank < CAP) {
+          lst_n[row * CAP + rank] = en;
+          lst_c[row * CAP + rank] = ec;
+        } else {
+          const int o = atomicAdd(&cnt[TM], 1);
+          ovf_rn[o] = (row << 16) | en;
+          ovf_c[o] = ec;
+        }
+      }
+    }
+    PB_T(0)
+    __syncthreads();
+    PB_T(1)
+    const long long nt = (tile + gridDim.x) < ntiles ? tile + gridDim.x : tile;
+    load_tile(nt, ynxt);
+
+    // ---- (B) sparse parts ----
+    if (zrole) {
+      // S: lane = tile row, registers = this wave's KS columns.  The first CAP list slots of the row are read up front
+      // (empty slots: coefficient 0), so the W' reads of all slots are independent and in flight together.
+      float sreg[KS];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) sreg[kk] = 0.f;
+      const int filed = cnt[lane];
+      const int mine = filed < CAP ? filed : CAP;
+      // two list slots per step: their W' reads are independent and in flight together
+      for (int c = 0; __ballot(c < mine) != 0ull; c += 2) {
+        int n2[2];
+        float c2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bool act = c + u < mine;
+          n2[u] = act ? lst_n[lane * CAP + c + u] : 0;
+          c2[u] = act ? lst_c[lane * CAP + c + u] : 0.f;
+        }
+        float w[2][KS];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk) w[u][kk] = wl[n2[u] * LDW + wave * KS + kk];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk) sreg[kk] = __fmaf_rn(c2[u], w[u][kk], sreg[kk]);
+      }
+      const int nov = __builtin_amdgcn_readfirstlane(cnt[TM]);
+      for (int o = 0; o < nov; ++o) {                      // rows with more than CAP entries: one lane at a time
+        const int rn = __builtin_amdgcn_readfirstlane(ovf_rn[o]);
+        const float cf = (rn >> 16) == lane ? ovf_c[o] : 0.f;
+        const float *wr = &wl[(rn & 0xffff) * LDW + wave * KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) sreg[kk] = __fmaf_rn(cf, wr[kk], sreg[kk]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; kk += 4) {
+        f32x4 o4 = {sreg[kk], sreg[kk + 1], sreg[kk + 2], sreg[kk + 3]};
+        *reinterpret_cast<f32x4 *>(&st[lane * LDT + wave * KS + kk]) = o4;
+      }
+    }
+    // T: lanes = columns n of this wave's half, registers = its KQ columns k; every lane walks along ITS arg-max row of
+    // the activation tile (immediate offsets, independent loads)
+#pragma unroll
+    for (int gi = 0; gi < GMAX; ++gi) {
+      if (!zrole && gi < ngt) {
+        const int base = (int)((g_first + gi) * ns - m0);
+        int rt = base + ta[gi];
+        const bool ok = (unsigned)rt < (unsigned)TM;
+        const float cf = ok ? tg[gi] : 0.f;
+        rt = ok ? rt : 0;
+        const float *zr = &zt[rt * LDZ + tk0];
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) tacc[kk] = __fmaf_rn(cf, zr[kk], tacc[kk]);
+      }
+    }
+    PB_T(2)
+    load_idx(nt);
+
+    // ---- (C) matrix products: one 32 x 32 block per wave ----
+    if (zrole) {
+      const float *za = &zt[(rb * 32 + (lane & 31)) * LDZ + (lane >> 5)];
+#pragma unroll
+      for (int s = 0; s < K / 2; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[2 * s], Greg[s], acc, 0, 0, 0);
+        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // Gram block: both fragments come from LDS — operands of the next eight steps are read while eight MFMAs issue
+      const float *ga = &zt[(lane >> 5) * LDZ + rb * 32 + (lane & 31)];
+      const float *gb = &zt[(lane >> 5) * LDZ + cb * 32 + (lane & 31)];
+      float pa[2][8], pb[2][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { pa[0][u] = ga[2 * u * LDZ]; pb[0][u] = gb[2 * u * LDZ]; }
+#pragma unroll
+      for (int g8 = 0; g8 < TM / 16; ++g8) {
+        if (g8 + 1 < TM / 16) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            pa[(g8 + 1) & 1][u] = ga[2 * (8 * (g8 + 1) + u) * LDZ];
+            pb[(g8 + 1) & 1][u] = gb[2 * (8 * (g8 + 1) + u) * LDZ];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[g8 & 1][u], pb[g8 & 1][u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    PB_T(3)
+    __syncthreads();
+    PB_T(4)
+    // ---- (D) a G + v + S into the staging tile; the row lists are free again ----
+    if (zrole) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = st[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + cb * 32 + (lane & 31)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + cb * 32 + (lane & 31)] = (acc[r] + vreg) + t[r];
+        acc[r] = 0.f;
+      }
+    } else if (tid - 256 <= TM) {
+      cnt[tid - 256] = 0;
+    }
+    PB_T(5)
+    __syncthreads();
+    PB_T(6)
+    // ---- (E) mask, statistics, store ----
+    {
+      const rsrc_t rso = make_rsrc(a.Gout + (size_t)m0 * K, (M - m0) * K * 4);
+      const f32x4 mu = *reinterpret_cast<const f32x4 *>(&prm[4 * c4]);
+      const f32x4 rs = *reinterpret_cast<const f32x4 *>(&prm[K + 4 * c4]);
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        const int row = r0 + RP * i;
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(&st[row * LDT + 4 * c4]);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g = zt[row * LDZ + 4 * c4 + j] > 0.f ? q[j] : 0.f;
+          o[j] = g;
+          cs1[j] += g;
+          cs2[j] = __fmaf_rn(g, (ycur[i][j] - mu[j]) * rs[j], cs2[j]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), rso,
+                                               yoff, i * RP * K * 4, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) ycur[i] = ynxt[i];
+    PB_T(7)
+  }
+#ifdef PB_PROF
+  if (lane == 0 && blockIdx.x < 64) {
+    long long *dst = (long long *)a.Gout + (blockIdx.x * 8 + wave) * 10;      // (experiment build only: clobbers the first rows of the output)
+    for (int i = 0; i < 10; ++i) dst[i] = prof[i];
+  }
+#endif
+
+  // ---- flush ----
+  float *prec = a.part + (size_t)blockIdx.x * (K * K + K + (size_t)N * K);
+  __syncthreads();
+  float *rbuf = st;                                      // [THREADS][4], three rounds (st holds 64 x 68 floats)
+  float t3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int round = 0; round < 3; ++round) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rbuf[tid * 4 + j] = round == 0 ? zsum[j] : (round == 1 ? cs1[j] : cs2[j]);
+    __syncthreads();
+    if (tid < K) {
+      float t = 0.f;
+      for (int q = 0; q < RP; ++q) t += rbuf[((q * CG + (tid >> 2)) * 4) + (tid & 3)];
+      t3[round] = t;
+    }
+    __syncthreads();
+  }
+  if (tid < K) {
+    prec[K * K + tid] = t3[0];
+    atomicAdd(a.sums + tid, (double)t3[1]);
+    atomicAdd(a.sums + K + tid, (double)t3[2]);
+  }
+  if (!zrole) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      prec[i * K + cb * 32 + (lane & 31)] = acc[r];
+    }
+  }
+  float *pt = prec + K * K + K;
+  if (!zrole && tn0 + lane < N) {
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) pt[(size_t)(tn0 + lane) * K + tk0 + kk] = tacc[kk];
+  }
+}
+
 // G = W^T diag(c2) W, v = W^T c3, W' = diag(c1) W  (consts = [c1 | c2 | c3] x N from pn2_bn_bwd_consts)
 __global__ __launch_bounds__(128) void pool_bwd_setup_kernel(int N, int K, const float *__restrict__ W,
                                                             const float *__restrict__ consts, float *__restrict__ G,
@@ -398,7 +725,7 @@ __global__ __launch_bounds__(128) void pool_bwd_assemble_kernel(int N, int K, co
 }
 
 int pool_bwd_grid(int K, long long ntiles) {
-  const long long g = K == 64 ? 512 : 256;               // 2 resp. 1 workgroup(s) per CU
+  const long long g = 256;                               // one workgroup per CU
   return (int)(ntiles < g ? ntiles : g);
 }
 
@@ -406,9 +733,10 @@ int pool_bwd_grid(int K, long long ntiles) {
 
 extern "C" int pn2_pool_bwd_supported(int N, int K, int ns) {
   if (!((K == 64 || K == 128) && N >= 1 && N <= 256 && (ns == 16 || ns == 32 || ns == 64 || ns == 128))) return 0;
-  // index registers: (64 / ns) groups x ceil(N / 64) entry batches per tile must fit eight batches
-  const int nbc = K == 64 ? (N <= 64 ? 1 : N <= 128 ? 2 : 4) : (N <= 128 ? 2 : 4);
   const int ngt = ns >= 64 ? 1 : 64 / ns;
+  if (K == 64 && N <= 128) return ngt * (N <= 64 ? 64 : 128) <= 512;      // one (group, column) entry per thread
+  // index registers: (64 / ns) groups x ceil(N / 64) entry batches per tile must fit eight batches
+  const int nbc = K == 64 ? 4 : (N <= 128 ? 2 : 4);
   return ngt * nbc <= 8;
 }
 
@@ -452,8 +780,8 @@ extern "C" int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, 
   a.Yp = Yp; a.finp = fin_p; a.G = G; a.v = v; a.Wp = Wp; a.arg = arg; a.gPm = gPm; a.Gout = Gout; a.sums = sums;
   a.part = part; a.M = M; a.N = N; a.ns = ns;
   if (K == 64) {
-    if (N <= 64) hipLaunchKernelGGL((pool_bwd_kernel<2, 16, true>), dim3(grid), dim3(256), 0, s, a);
-    else if (N <= 128) hipLaunchKernelGGL((pool_bwd_kernel<2, 32, true>), dim3(grid), dim3(256), 0, s, a);
+    if (N <= 64) hipLaunchKernelGGL((pool_bwd64_kernel<1>), dim3(grid), dim3(512), 0, s, a);
+    else if (N <= 128) hipLaunchKernelGGL((pool_bwd64_kernel<2>), dim3(grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((pool_bwd_kernel<2, 64, false>), dim3(grid), dim3(256), 0, s, a);
   } else {
     if (N <= 128) hipLaunchKernelGGL((pool_bwd_kernel<4, 16, false>), dim3(grid), dim3(512), 0, s, a);
