@@ -57,3 +57,92 @@ def test_pooled_layer_without_materialised_output_equals_gemm_plus_rows_max(ns, 
     assert torch.equal(yr, yraw)
     # first maximum among exact ties (padding rows repeat row 0): never an index in the padded half unless row 0 lost
     assert int((arg[live] >= ns // 2).sum()) == 0
+
+
+# ---------------------------------------------------------------------------------- BASELINE configs[3]: with_images
+def _image_scan(seed):
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import synthetic_scan
+    scan = synthetic_scan(4, 1500, 2000, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    scan["full_image_features"] = torch.randn(6, 2048, generator=g)      # what the (external) 2-D CNN emits per view
+    return scan
+
+
+def _to(batch, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def test_with_images_config_on_the_hip_path_matches_the_oracle_backend():
+    """BASELINE configs[3] (`no_gt_image.json`: IMAGE_INPUT = 'full'): precomputed `full_image_features` (6 views x
+    num_features) -> full_image_feature_reduction -> 768-vector late-fused into the relation head
+    (scene_graph_prediction_model.py:47-55, 96-100).  The point-cloud encoders and the GCN run on the HIP kernels; the
+    whole forward / loss / backward is compared with the same model on the CPU oracle backend, fp32."""
+    import copy
+    import oracle_ext
+    from pointnet2_ops import _ext, pointnet2_utils as pu
+    from scene_graph_prediction.main import RELATION_NAMES, config_loader
+    from scene_graph_prediction.scene_graph_helpers.model import scene_graph_prediction_model as sgm
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    cfg = config_loader("no_gt_image.json")
+    torch.manual_seed(0)
+    model = sgm.SGPNModelWrapper(cfg, 12, 15, torch.ones(12), torch.ones(15), RELATION_NAMES).eval()
+    scan = _image_scan(3)
+
+    def run(dev, backend):
+        saved = pu._ext, gcn._ext
+        pu._ext = gcn._ext = backend
+        try:
+            m = copy.deepcopy(model).to(dev)
+            b = _to(scan, dev)
+            obj, rel = m(b)
+            loss = m.loss(obj, rel, b)
+            loss.backward()
+            grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
+            return obj.detach().cpu(), rel.detach().cpu(), float(loss.detach()), grads
+        finally:
+            pu._ext, gcn._ext = saved
+
+    obj_r, rel_r, loss_r, g_r = run("cpu", oracle_ext.OracleRowsExt)
+    obj_g, rel_g, loss_g, g_g = run("cuda", _ext)
+    torch.testing.assert_close(obj_g, obj_r, atol=2e-4, rtol=1e-3)
+    torch.testing.assert_close(rel_g, rel_r, atol=2e-4, rtol=1e-3)
+    assert abs(loss_g - loss_r) < 1e-4
+    assert set(g_g) == set(g_r) and "full_image_feature_reduction.weight" in g_g
+    for k in g_r:
+        # the GCN's BatchNorm1d over the 4 nodes / 12 edges of ONE scan is ill-conditioned (fp32 vs fp64 of the same GCN
+        # on the CPU differ by 4.5e-4 per parameter, tools/gcn_conditioning.py; DESIGN.md 4d) and everything upstream
+        # inherits it: 5e-2 in norm (single entries of a GCN weight move by up to 8e-2 of the largest one, identical with
+        # and without the pooled-layer kernels);
+        # biases in front of a BatchNorm have an exactly-zero true gradient, hence the absolute floor
+        assert float((g_g[k] - g_r[k]).norm()) <= 5e-2 * float(g_r[k].norm()) + 1e-4, k      # in norm: single entries move more
+
+
+def test_with_images_config_in_mixed_precision():
+    """configs[3] under the bf16 shared-MLP arithmetic (the reference's precision=16, main.py:64): same model, same scan,
+    log-probabilities close to the fp32 HIP path and finite gradients everywhere incl. the image reduction layer."""
+    import copy
+    from pointnet2_ops import fused_mlp
+    from scene_graph_prediction.main import RELATION_NAMES, config_loader
+    from scene_graph_prediction.scene_graph_helpers.model import scene_graph_prediction_model as sgm
+    cfg = config_loader("no_gt_image.json")
+    torch.manual_seed(0)
+    model = sgm.SGPNModelWrapper(cfg, 12, 15, torch.ones(12), torch.ones(15), RELATION_NAMES).eval().cuda()
+    scan = _to(_image_scan(4), "cuda")
+
+    def run():
+        m = copy.deepcopy(model)
+        obj, rel = m(scan)
+        m.loss(obj, rel, scan).backward()
+        return obj.detach(), rel.detach(), {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+
+    obj32, rel32, g32 = run()
+    prev = fused_mlp.set_mlp_dtype(torch.bfloat16)
+    try:
+        obj16, rel16, g16 = run()
+    finally:
+        fused_mlp.set_mlp_dtype(prev)
+    # log-probabilities of magnitude 2-3; the 4-node / 12-edge BatchNorms of the GCN amplify the bf16 rounding (measured 0.10)
+    assert float((obj16 - obj32).abs().max()) < 0.25 and float((rel16 - rel32).abs().max()) < 0.25
+    assert set(g16) == set(g32) and all(bool(torch.isfinite(v).all()) for v in g16.values())
+    gi = "full_image_feature_reduction.weight"
+    assert float((g16[gi] - g32[gi]).norm() / g32[gi].norm()) < 0.5
