@@ -29,6 +29,71 @@ def config_loader(path):
         return json.load(f)
 
 
+def setup_distributed(device: torch.device):
+    """(rank, world).  Under torchrun (WORLD_SIZE > 1) one process per GPU: RCCL (`nccl` backend on ROCm) over xGMI for
+    cuda devices, gloo for the CPU tests.  The reference trains on ONE GPU (main.py:62 `gpus=1`); scans are independent,
+    so the data-parallel run shards them by rank and averages the gradients — nothing else is exchanged."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what the host driver supports
+    if not dist.is_initialized():
+        dist.init_process_group("nccl" if device.type == "cuda" else "gloo")
+    return dist.get_rank(), world
+
+
+def train(model, config, scans, device, epochs=1, graphs=False, rank=0, world=1, log=print):
+    """The train mode of the runner: one scan per step like main.py:54-56.  world > 1: rank r takes scans r, r + world, ...;
+    every parameter's .grad is a view of one flat buffer (runtime.FlatGrads) that is averaged with ONE all-reduce between
+    backward and optimizer step; the classification heads the encoders inherit but never call are frozen —
+    they would otherwise sit in the buffer as zeros and take AdamW's weight decay; rank 0's initial weights are broadcast.
+    Returns the list of (step, loss) of this rank."""
+    import torch.distributed as dist
+    from runtime import FlatGrads, GeometryPrefetcher, GraphedTrainStep
+    model.train()
+    flat = None
+    if graphs or world > 1:
+        for n, p in model.named_parameters():
+            if ".backbone.fc_layer." in n:
+                p.requires_grad_(False)
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=model.lr,
+                                weight_decay=float(config["W_DECAY"]), capturable=bool(graphs))
+    else:
+        opt = model.configure_optimizers(capturable=False)
+    if world > 1:
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+    graphed = None
+    if graphs:
+        graphed = GraphedTrainStep(model.pure_training_step, model.parameters(), opt)
+    elif world > 1:
+        flat = FlatGrads(model.parameters())
+    mine = scans[rank::world]
+    history = []
+    for epoch in range(epochs):
+        device_scans = (to_device(scan, device) for scan in mine)
+        # the next scan's sampling geometry is prefetched on a side stream (GPU only)
+        it = GeometryPrefetcher(model.precompute_geometry, device_scans) if device.type == "cuda" else device_scans
+        for i, batch in enumerate(it):
+            if graphed is not None:
+                loss, rel_pred = graphed(batch)
+                model.update_metrics(batch, rel_pred, split="train")
+            else:
+                if flat is not None:
+                    flat.zero_()
+                else:
+                    opt.zero_grad(set_to_none=True)
+                loss = model.training_step(batch, i)
+                loss.backward()
+                if flat is not None:
+                    flat.all_reduce_mean()
+                opt.step()
+            history.append((epoch * len(mine) + i, float(loss.detach())))
+            log(f"[rank {rank}] epoch {epoch} step {i}: loss {history[-1][1]:.4f}")
+    return history
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=str, default="no_gt.json")
@@ -40,57 +105,43 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--graphs", action="store_true",
                     help="train mode: replay each scan shape's whole step (fwd + loss + bwd + AdamW) as one hipGraph")
+    ap.add_argument("--device", type=str, default="cuda",
+                    help="cuda (default; under torchrun: cuda:LOCAL_RANK) | cpu (tests: needs a CPU backend in pointnet2_utils._ext)")
     args = ap.parse_args(argv)
 
     torch.manual_seed(42)                                     # main.py:40 seeds everything with 42
     config = config_loader(args.config)
     dcfg = config["dataset"]
+    if args.device == "cuda" and "LOCAL_RANK" in os.environ:
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    device = torch.device(args.device if args.device != "cuda" else f"cuda:{torch.cuda.current_device()}")
+    rank, world = setup_distributed(device) if args.mode == "train" else (0, 1)
     model = SGPNModelWrapper(config, 12, len(RELATION_NAMES), torch.ones(12), torch.ones(len(RELATION_NAMES)),
-                             RELATION_NAMES).cuda()
+                             RELATION_NAMES).to(device)
     if args.weights:
-        model.load_state_dict(torch.load(args.weights, map_location="cuda"))
+        model.load_state_dict(torch.load(args.weights, map_location=device))
     scans = [synthetic_scan(args.objects, dcfg["num_points_objects"], dcfg["num_points_relation"], seed=i,
                             scan_id=f"synthetic_{i:06d}") for i in range(args.scans)]
 
     if args.mode == "train":
-        model.train()
-        opt = model.configure_optimizers(capturable=args.graphs)
-        if args.graphs:
-            from runtime import GraphedTrainStep
-            # flat gradients are dense zeros where eager autograd leaves None: keep AdamW's weight decay off the
-            # classifier heads the encoders inherit but never call by freezing them
-            for n, p in model.named_parameters():
-                if ".backbone.fc_layer." in n:
-                    p.requires_grad_(False)
-            opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=model.lr,
-                                    weight_decay=float(config["W_DECAY"]), capturable=True)
-            graphed = GraphedTrainStep(model.pure_training_step, model.parameters(), opt)
-        from runtime import GeometryPrefetcher
-        for epoch in range(args.epochs):
-            # batch = one scan per step, like main.py:54-56; the next scan's sampling geometry is prefetched on a side stream
-            device_scans = (to_device(scan, "cuda") for scan in scans)
-            for i, batch in enumerate(GeometryPrefetcher(model.precompute_geometry, device_scans)):
-                if args.graphs:
-                    loss, rel_pred = graphed(batch)
-                    model.update_metrics(batch, rel_pred, split="train")
-                else:
-                    opt.zero_grad(set_to_none=True)
-                    loss = model.training_step(batch, i)
-                    loss.backward()
-                    opt.step()
-                print(f"epoch {epoch} step {i}: loss {float(loss.detach()):.4f}")
-        print(json.dumps({k: v for k, v in model.evaluate_predictions(0.0, "train").items() if k != "per_take"}))
+        train(model, config, scans, device, epochs=args.epochs, graphs=args.graphs, rank=rank, world=world)
+        if rank == 0:
+            print(json.dumps({k: v for k, v in model.evaluate_predictions(0.0, "train").items() if k != "per_take"}))
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
         return
     model.eval()
     if args.mode == "evaluate":
         with torch.no_grad():
-            total = sum(float(model.validation_step(to_device(s, "cuda"), i)) for i, s in enumerate(scans))
+            total = sum(float(model.validation_step(to_device(s, device), i)) for i, s in enumerate(scans))
         print(json.dumps({k: v for k, v in model.evaluate_predictions(total, "val").items() if k != "per_take"}))
         return
     results = {}
     with torch.no_grad():
         for i, scan in enumerate(scans):
-            scan_id, rels = model.predict_step(to_device(scan, "cuda"), i)
+            scan_id, rels = model.predict_step(to_device(scan, device), i)
             results[scan_id] = rels
     with open(args.out, "w") as f:                            # same wire format as main.py:111-115
         json.dump(results, f)

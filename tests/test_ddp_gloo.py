@@ -128,3 +128,81 @@ def test_two_rank_flat_gradient_allreduce(tmp_path):
     assert torch.equal(res["params"][0], res["params"][1])                    # broadcast at start + identical updates
     mean_local = (res["local_grads"][0] + res["local_grads"][1]) / 2
     torch.testing.assert_close(res["sync_grad"], mean_local, atol=1e-6, rtol=1e-5)
+
+
+def _runner_worker(rank, world, port, out):
+    """scene_graph_prediction.main.train on 2 gloo ranks: the full SGPN model (two MSG encoders + TripletGCN + heads) on the
+    CPU oracle backend, scans sharded by rank, ONE flat gradient all-reduce per step."""
+    sys.path[:0] = [os.path.join(REPO, "4d-or_amd"), REPO, os.path.join(REPO, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    import copy
+    import oracle_ext
+    from pointnet2_ops import pointnet2_utils as pu
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    pu._ext = gcn._ext = oracle_ext.OracleRowsExt
+    from scene_graph_prediction import main as runner
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import synthetic_scan, to_device
+    from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+    device = torch.device("cpu")
+    r, w = runner.setup_distributed(device)
+    assert (r, w) == (rank, world)
+    cfg = runner.config_loader("no_gt.json")
+    torch.manual_seed(7 + rank)                  # DIFFERENT initial weights per rank: train() must broadcast rank 0's
+    model = SGPNModelWrapper(cfg, 12, 15, torch.ones(12), torch.ones(15), runner.RELATION_NAMES)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0                            # deterministic steps (the local reference below re-runs them)
+    scans = [synthetic_scan(3, 300, 400, seed=i, scan_id=f"s{i}") for i in range(4)]
+
+    # reference: what this rank's first step computes locally, from rank 0's weights
+    torch.manual_seed(7)
+    ref = SGPNModelWrapper(cfg, 12, 15, torch.ones(12), torch.ones(15), runner.RELATION_NAMES)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    ref.train()
+    loss = ref.training_step(to_device(scans[rank], device), 0)
+    loss.backward()
+    names = [n for n, p in ref.named_parameters() if p.grad is not None and ".backbone.fc_layer." not in n]
+    local = torch.cat([dict(ref.named_parameters())[n].grad.flatten() for n in names])
+
+    seen = {}
+    orig_step = torch.optim.AdamW.step
+
+    def spy(self, *a, **k):                      # gradients as the optimizer sees them at the first step
+        if "g" not in seen:
+            byname = {n: p for n, p in model.named_parameters()}
+            seen["g"] = torch.cat([byname[n].grad.flatten() for n in names]).clone()
+        return orig_step(self, *a, **k)
+
+    torch.optim.AdamW.step = spy
+    try:
+        hist = runner.train(model, cfg, scans, device, epochs=1, rank=rank, world=world, log=lambda *_: None)
+    finally:
+        torch.optim.AdamW.step = orig_step
+    assert len(hist) == 2                        # 4 scans over 2 ranks
+    frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+    assert frozen and all(".backbone.fc_layer." in n for n in frozen)
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    locals_ = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(locals_, local)
+    if rank == 0:
+        torch.save({"params": gathered, "seen": seen["g"], "locals": locals_}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_runner_train_mode_on_two_gloo_ranks(tmp_path):
+    """4d-or_amd/scene_graph_prediction/main.py --mode train under torchrun (here: 2 gloo ranks on the CPU oracle
+    backend): rank 0's weights everywhere, scans sharded by rank, the gradient the optimizer sees = the mean of the ranks'
+    local gradients, the inherited dead classification heads frozen, parameters in sync after the epoch."""
+    out = str(tmp_path / "runner.pt")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_runner_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["params"][0], res["params"][1])
+    mean_local = (res["locals"][0] + res["locals"][1]) / 2
+    torch.testing.assert_close(res["seen"], mean_local, atol=1e-6, rtol=1e-4)
