@@ -259,7 +259,40 @@ __global__ __launch_bounds__(1024) void prep_gather_kernel(int ld, int n_obj, in
       o[0] = o[0] / dist; o[1] = o[1] / dist; o[2] = o[2] / dist;
     }
 }
+// Cell key of every point for ONE rung of the voxel ladder (data_preparation_utils.py:42-44:
+// pc.voxel_down_sample_and_trace(size, min_bound, max_bound)).  open3d works in double precision on the float32
+// coordinates: voxel origin = min_bound - size / 2, ref = (p - origin) / size, voxel = floor(ref), and the trace matrix has
+// one column per OCTANT of a voxel — bit c of the column is set when ref_c - voxel_c >= 0.5 — holding the LAST point index
+// that fell into it.  key = (vx << 29 | vy << 16 | vz << 3 | octant): equal keys <=> same slot of the trace matrix.
+__global__ __launch_bounds__(256) void prep_voxel_keys_kernel(int n, int ld, const float *__restrict__ pts,
+                                                             const float *__restrict__ min_bound, double size,
+                                                             long long *__restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  long long key = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double origin = (double)min_bound[c] - size * 0.5;
+    const double ref = ((double)pts[(size_t)i * ld + c] - origin) / size;
+    const double fl = floor(ref);
+    long long v = (long long)fl;
+    v = v < 0 ? 0 : (v > 8191 ? 8191 : v);               // 13 bits per axis (a NaN coordinate lands in voxel 0)
+    key |= v << (29 - 13 * c);
+    if (ref - fl >= 0.5) key |= 1ll << c;
+  }
+  keys[i] = key;
+}
 }  // namespace
+
+extern "C" int pn2_prep_voxel_keys(int n, int ld, const float *pts, const float *min_bound, double size,
+                                   long long *keys, void *stream) {
+  if (n < 0 || ld < 3 || !(size > 0.0)) return PN2_EINVAL;
+  if (n == 0) return PN2_OK;
+  if (!pts || !min_bound || !keys) return PN2_ENULL;
+  hipLaunchKernelGGL(prep_voxel_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, ld,
+                     pts, min_bound, size, keys);
+  return pn2_check_launch();
+}
 
 extern "C" int pn2_prep_num_chunks(int P) { return P <= 0 ? 0 : (P + kChunk - 1) / kChunk; }
 

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "pn2_prep_chunk_counts": [_c_int] * 4 + [_c_vp] * 6,
     "pn2_prep_select": [_c_int] * 6 + [ctypes.c_uint] + [_c_vp] * 7,
     "pn2_prep_gather_normalise": [_c_int] * 5 + [_c_vp] * 7,
+    "pn2_prep_voxel_keys": [_c_int, _c_int, _c_vp, _c_vp, ctypes.c_double, _c_vp, _c_vp],
     "pn2_floyd_warshall": [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_gen_edge_input": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_mlp_gemm": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
@@ -1144,6 +1145,43 @@ def prepare_scan_crops(points, masks, edges, n_obj, t_obj, t_rel, padding, seed)
     _call("pn2_prep_gather_normalise", points, ld, n_obj, E, int(t_obj), int(t_rel), _ptr(points), _ptr(masks), _ptr(edges),
           _ptr(sel), _ptr(obj), _ptr(rel), alg_bytes=slots * (4 + 8 * ld))
     return obj, rel, boxes, sel, prefix[:, -1]
+
+
+def prep_voxel_keys(pts, min_bound, size):
+    """pts (n, ld >= 3) f32 rows, min_bound (3) f32 -> (n) int64 trace-slot keys of one voxel-ladder rung (pn2_prep_voxel_keys)."""
+    _f32(pts, "pts"); _f32(min_bound, "min_bound")
+    _same_device((pts, "pts"), (min_bound, "min_bound"))
+    n, ld = pts.shape
+    keys = torch.empty(n, dtype=torch.int64, device=pts.device)
+    _call("pn2_prep_voxel_keys", pts, n, ld, _ptr(pts), _ptr(min_bound), float(size), _ptr(keys), alg_bytes=n * 20)
+    return keys
+
+
+def prep_object_boxes(points, masks, n_obj, padding):
+    """(n_obj, 6) padded boxes [min | max] of the object members (pn2_prep_object_boxes)."""
+    _f32(points, "points"); _i32(masks, "masks")
+    P, ld = points.shape
+    keys = torch.empty(max(n_obj, 1) * 6, dtype=torch.int32, device=points.device)
+    boxes = torch.empty(n_obj, 6, dtype=torch.float32, device=points.device)
+    _call("pn2_prep_object_boxes", points, P, ld, n_obj, float(padding), _ptr(points), _ptr(masks), _ptr(keys), _ptr(boxes),
+          alg_bytes=P * (12 + 4))
+    return boxes
+
+
+def prep_gather_normalise(points, masks, edges, sel, n_obj, t_obj, t_rel):
+    """Selected scan indices `sel` (n_obj*t_obj + E*t_rel) i32 -> (obj (n_obj, t_obj, ld), rel (E, t_rel, ld+1)): gather,
+    mask channel, zero_mean (pn2_prep_gather_normalise)."""
+    _f32(points, "points"); _i32(masks, "masks"); _i32(edges, "edges"); _i32(sel, "sel")
+    _same_device((points, "points"), (masks, "masks"), (edges, "edges"), (sel, "sel"))
+    P, ld = points.shape
+    E = edges.size(1)
+    if sel.numel() != n_obj * int(t_obj) + E * int(t_rel):
+        raise RuntimeError("prep_gather_normalise: sel must hold n_obj * t_obj + E * t_rel indices")
+    obj = torch.empty(n_obj, t_obj, ld, dtype=torch.float32, device=points.device)
+    rel = torch.empty(E, t_rel, ld + 1, dtype=torch.float32, device=points.device)
+    _call("pn2_prep_gather_normalise", points, ld, n_obj, E, int(t_obj), int(t_rel), _ptr(points), _ptr(masks), _ptr(edges),
+          _ptr(sel), _ptr(obj), _ptr(rel), alg_bytes=sel.numel() * (4 + 8 * ld))
+    return obj, rel
 
 
 # ------------------------------------------- (f)4: Graphormer pre-processing (role_prediction/graphormer/algos.pyx)

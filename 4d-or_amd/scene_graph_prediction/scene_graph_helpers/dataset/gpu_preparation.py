@@ -8,10 +8,14 @@ as four HIP kernels (csrc/data_prep.hip) on the scan already resident in HBM.  E
 n-major (:127-133); the subject / object one-hot follows ``objname_to_onehot`` (:21-34).
 
 What is and is not identical to the reference: boxes, filters, mask channel, edge order, one-hot and zero_mean are
-restated exactly (tests compare against a numpy restatement of those lines).  The sub-sampling cannot be: the
-reference draws from numpy's global generator on top of an open3d voxel trace.  Here it is a seeded counter-based
-sampler with the same two regimes (fewer members than the target: draws with replacement; more: distinct members, one
-per stratum of the member order) — statistical, not bitwise, parity.
+restated exactly (tests compare against a numpy restatement of those lines).  The sub-sampling has two modes:
+``downsample="voxel"`` restates ``calculate_downsample_indices`` (:37-49) — the voxel ladder 15, 20, ... 95 with open3d's
+voxel_down_sample_and_trace semantics (slot keys by pn2_prep_voxel_keys, last point per trace slot, the coarsest rung
+that keeps more than the target, then a seeded draw without replacement; fewer members than the target: draws with
+replacement) — identical CANDIDATE SETS, while the final draw comes from a seeded torch generator instead of numpy's
+global one (statistical parity; open3d itself is absent, so the trace is pinned by hand-derived known answers only:
+"parity unpinned" for it).  ``downsample="strata"`` (default, fastest: no member lists, no sorts) is a seeded
+counter-based sampler with the same two regimes, one distinct member per stratum of the member order.
 """
 from typing import Dict, List, Optional, Sequence
 
@@ -36,10 +40,66 @@ def fully_connected_edges(n_obj: int) -> torch.Tensor:
     return torch.tensor(pairs, dtype=torch.int64).t().contiguous() if pairs else torch.zeros(2, 0, dtype=torch.int64)
 
 
+VOXEL_LADDER = tuple(range(15, 100, 5))                      # data_preparation_utils.py:42 (scan units: millimetres)
+
+
+def calculate_downsample_indices(pointset: torch.Tensor, target_N: int, generator: Optional[torch.Generator] = None,
+                                 return_candidates: bool = False):
+    """data_preparation_utils.py:37-49 on the GPU.  pointset (n, >= 3) fp32 cuda rows -> (target_N) int64 indices into it.
+
+    n < target_N: draws with replacement (:38-39).  Otherwise the voxel ladder: for size 15, 20, ... the candidate set is
+    np.unique(trace)[1:] of open3d's voxel_down_sample_and_trace(size, min_bound, max_bound) — the last point of every
+    occupied (voxel, octant) slot, ascending, minus the FIRST entry (the reference drops element 0 assuming it is the -1 of
+    an empty slot; when every slot of every voxel is occupied that drops a real point — kept, it is what the reference
+    computes); the last rung with more than target_N candidates wins, the ladder stops at the first that has not (:43-47);
+    then target_N of them without replacement (:48).  `return_candidates`: also (best_choice, rung index or -1)."""
+    from pointnet2_ops import _ext as e
+    n = pointset.size(0)
+    dev = pointset.device
+    if n < target_N:
+        pick = torch.randint(n, (target_N,), generator=generator, device=dev)
+        return (pick, None, -2) if return_candidates else pick
+    rows = pointset.contiguous().float()
+    min_bound = rows[:, :3].amin(dim=0).contiguous()
+    best, rung = torch.arange(n, device=dev), -1
+    for r, size in enumerate(VOXEL_LADDER):
+        keys = e.prep_voxel_keys(rows, min_bound, float(size))
+        skeys, order = torch.sort(keys, stable=True)             # equal keys keep the point order: the run's last = the slot's entry
+        last = torch.ones(n, dtype=torch.bool, device=dev)
+        last[:-1] = skeys[1:] != skeys[:-1]
+        choice = torch.sort(order[last]).values                  # np.unique: ascending point indices
+        vox = skeys[last] >> 3
+        nvox = 1 + int((vox[1:] != vox[:-1]).sum()) if vox.numel() else 0
+        if choice.numel() < 8 * nvox:
+            pass                                                 # some slot is empty: np.unique's first element is the -1
+        else:
+            choice = choice[1:]                                  # no -1 in the trace: the reference still drops element 0
+        if choice.numel() > target_N:
+            best, rung = choice, r
+        else:
+            break
+    pick = best[torch.randperm(best.numel(), generator=generator, device=dev)[:target_N]]
+    return (pick, best, rung) if return_candidates else pick
+
+
+def crop_members(points: torch.Tensor, masks: torch.Tensor, boxes: torch.Tensor, edges: torch.Tensor, n_obj: int):
+    """Member point indices of every crop, ascending: objects = masks == id (:118), pairs = strictly inside the union of
+    the two padded boxes (:203-208)."""
+    out = [torch.nonzero(masks == i + 1).squeeze(1) for i in range(n_obj)]
+    xyz = points[:, :3]
+    for a, b in edges.t().tolist():
+        lo = torch.minimum(boxes[a, :3], boxes[b, :3])
+        hi = torch.maximum(boxes[a, 3:], boxes[b, 3:])
+        inside = ((xyz > lo) & (xyz < hi)).all(dim=1)
+        out.append(torch.nonzero(inside).squeeze(1))
+    return out
+
+
 def prepare_scan(points: torch.Tensor, masks: torch.Tensor, n_obj: int, num_points_objects: int = 4000,
                  num_points_relation: int = 8000, padding: float = 0.2, seed: int = 0,
                  object_names: Optional[Sequence[str]] = None, gt_class: Optional[torch.Tensor] = None,
-                 gt_rels: Optional[torch.Tensor] = None, scan_id: str = "scan", take_idx: int = 0) -> Dict:
+                 gt_rels: Optional[torch.Tensor] = None, scan_id: str = "scan", take_idx: int = 0,
+                 downsample: str = "strata") -> Dict:
     """points (P, 6) fp32 on the GPU (xyz + rgb in [0,1]), masks (P,) int32 with object ids 1..n_obj (0 = context)
     -> the A0 batch: obj_points (n_obj, 6, T_o), rel_points (E, 7, T_r), edge_indices (2, E) int64,
     relation_objects_one_hot (E, 12) [needs object_names], plus the optional labels passed through."""
@@ -49,8 +109,26 @@ def prepare_scan(points: torch.Tensor, masks: torch.Tensor, n_obj: int, num_poin
     masks = masks.contiguous().to(torch.int32)
     edges64 = fully_connected_edges(n_obj).to(points.device)
     edges = edges64.to(torch.int32).contiguous()
-    obj, rel, boxes, sel, counts = _ext.prepare_scan_crops(points, masks, edges, n_obj, num_points_objects,
-                                                          num_points_relation, padding, seed)
+    if downsample == "voxel":
+        # the reference's voxel ladder per crop (81 crops per scan), then the same gather / mask channel / zero_mean kernel
+        boxes = _ext.prep_object_boxes(points, masks, n_obj, padding)
+        members = crop_members(points, masks, boxes, edges64, n_obj)
+        gen = torch.Generator(device=points.device).manual_seed(int(seed))
+        sel_parts = []
+        for c, mem in enumerate(members):
+            target = num_points_objects if c < n_obj else num_points_relation
+            if mem.numel() == 0:
+                sel_parts.append(torch.full((target,), -1, dtype=torch.int64, device=points.device))
+                continue
+            sel_parts.append(mem[calculate_downsample_indices(points[mem], target, gen)])
+        sel = torch.cat(sel_parts).to(torch.int32)
+        counts = torch.tensor([m.numel() for m in members], dtype=torch.int64, device=points.device)
+        obj, rel = _ext.prep_gather_normalise(points, masks, edges, sel, n_obj, num_points_objects, num_points_relation)
+    elif downsample == "strata":
+        obj, rel, boxes, sel, counts = _ext.prepare_scan_crops(points, masks, edges, n_obj, num_points_objects,
+                                                              num_points_relation, padding, seed)
+    else:
+        raise ValueError("prepare_scan: downsample must be 'strata' or 'voxel'")
     batch = {
         "scan_id": scan_id, "take_idx": take_idx,
         "obj_points": obj.permute(0, 2, 1).contiguous(),       # channel-first, like collate_fn (or_dataset.py:67-68)
@@ -70,9 +148,10 @@ def prepare_scan(points: torch.Tensor, masks: torch.Tensor, n_obj: int, num_poin
     return batch
 
 
-def synthetic_fused_scan(n_obj=9, points=300000, seed=0, device="cuda"):
-    """A room-sized cloud with `n_obj` blob-shaped instances + context points, metric coordinates (metres), for tests and
-    the end-to-end benchmark (the 4D-OR scans are not in the tree)."""
+def synthetic_fused_scan(n_obj=9, points=300000, seed=0, device="cuda", scale=1.0):
+    """A room-sized cloud with `n_obj` blob-shaped instances + context points, metric coordinates (metres; `scale` = 1000
+    gives the millimetres of the 4D-OR scans, which is what the voxel ladder's sizes 15 ... 95 refer to), for tests and the
+    end-to-end benchmark (the 4D-OR scans are not in the tree)."""
     g = torch.Generator().manual_seed(seed)
     centres = torch.rand(n_obj, 3, generator=g) * torch.tensor([4.0, 4.0, 1.5]) + torch.tensor([0.5, 0.5, 0.2])
     sizes = torch.rand(n_obj, 3, generator=g) * 0.4 + 0.15
@@ -88,5 +167,5 @@ def synthetic_fused_scan(n_obj=9, points=300000, seed=0, device="cuda"):
     mask.append(torch.zeros(rest, dtype=torch.int32))
     xyz, mask = torch.cat(xyz), torch.cat(mask)
     perm = torch.randperm(xyz.size(0), generator=g)
-    pts = torch.cat([xyz[perm], torch.rand(xyz.size(0), 3, generator=g)], dim=1)
+    pts = torch.cat([xyz[perm] * float(scale), torch.rand(xyz.size(0), 3, generator=g)], dim=1)
     return pts.to(device), mask[perm].to(device)

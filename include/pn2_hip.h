@@ -385,6 +385,12 @@ int pn2_group_concat_rows_bf16(int B, int N, int m, int ns, int C, int use_xyz, 
  * Deterministic parts restate the reference exactly; the sampler replaces open3d's voxel trace + numpy's global
  * generator (not reproducible) by a seeded one with the same two regimes.
  */
+/* One rung of the reference's voxel ladder (data_preparation_utils.py:37-49, open3d voxel_down_sample_and_trace):
+ * keys[i] = voxel (13 bits per axis) << 3 | octant of point i for voxels of edge `size` anchored at min_bound - size/2,
+ * double-precision arithmetic like open3d; points with equal keys share a slot of the trace matrix (the slot keeps the
+ * LAST of them).  pts (n, ld) fp32 rows, min_bound (3) fp32 = per-axis minimum of the same rows. */
+int pn2_prep_voxel_keys(int n, int ld, const float *pts, const float *min_bound, double size, long long *keys,
+                        void *stream);
 int pn2_prep_num_chunks(int P);
 int pn2_prep_object_boxes(int P, int ld, int n_obj, float padding, const float *points, const int *masks,
                           unsigned *keys, float *boxes, void *stream);

@@ -65,3 +65,34 @@ def prepare(points, masks, n_obj, t_obj, t_rel, padding, seed):
         (obj_out if c < n_obj else rel_out).append(rows)
     return (np.stack(obj_out), np.stack(rel_out), np.array([np.concatenate(b) for b in boxes]), np.concatenate(sel_all),
             np.array([len(m) for m in members]), np.array(edges).T)
+
+
+# ---------------------------------------------------------------------------------------------- voxel ladder (:37-49)
+def voxel_trace(xyz, size, min_bound):
+    """open3d's PointCloud.voxel_down_sample_and_trace(size, min_bound, max_bound)[1], restated from the library's
+    documented algorithm (open3d is not installed: "parity unpinned" for this function — pinned only by the hand-derived
+    known answers in tests/test_prep_cpu.py): double precision, voxel origin = min_bound - size / 2, one row per occupied
+    voxel, eight columns = octants (bit c set when the point lies in the upper half of the voxel along axis c), each
+    holding the LAST point index that fell into it, -1 where none did."""
+    origin = np.asarray(min_bound, dtype=np.float64) - size * 0.5
+    ref = (np.asarray(xyz, dtype=np.float64) - origin) / size
+    vox = np.floor(ref)
+    octant = ((ref - vox) >= 0.5).astype(np.int64) @ np.array([1, 2, 4])
+    rows = {}
+    for i, (v, o) in enumerate(zip(map(tuple, vox.astype(np.int64)), octant)):
+        rows.setdefault(v, [-1] * 8)[o] = i
+    return np.array(list(rows.values()), dtype=np.int64).reshape(-1, 8)
+
+
+def downsample_candidates(pointset, target_N):
+    """data_preparation_utils.py:41-47: (best_choice, rung) — the candidate set the final np.random.choice draws from."""
+    xyz = np.asarray(pointset)[:, :3].astype(np.float32)
+    mn = xyz.min(0)
+    best, rung = np.arange(len(xyz)), -1
+    for r, size in enumerate(range(15, 100, 5)):
+        choice = np.unique(voxel_trace(xyz, size, mn))[1:]
+        if len(choice) > target_N:
+            best, rung = choice, r
+        else:
+            break
+    return best, rung

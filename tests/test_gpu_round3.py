@@ -146,3 +146,63 @@ def test_with_images_config_in_mixed_precision():
     assert set(g16) == set(g32) and all(bool(torch.isfinite(v).all()) for v in g16.values())
     gi = "full_image_feature_reduction.weight"
     assert float((g16[gi] - g32[gi]).norm() / g32[gi].norm()) < 0.5
+
+
+# ------------------------------------------------------------------------------------ (f)3: voxel down-sample, cache
+@pytest.mark.parametrize("n,target,seed", [(20000, 4000, 0), (60000, 8000, 1), (5000, 4000, 2), (3000, 4000, 3), (9000, 1000, 4)])
+def test_voxel_ladder_downsample_matches_the_numpy_restatement(n, target, seed):
+    """calculate_downsample_indices (SGH/dataset/data_preparation_utils.py:37-49) on the GPU: the same rung of the
+    15 ... 95 ladder and the SAME candidate set (last point per occupied voxel-octant slot, ascending, first entry
+    dropped) as the numpy restatement of open3d's voxel_down_sample_and_trace; the final draw is a seeded subset of it
+    without repetition; fewer points than the target: draws with replacement."""
+    import numpy as np
+    import prep_oracle
+    from scene_graph_prediction.scene_graph_helpers.dataset import gpu_preparation as gp
+    rng = np.random.default_rng(seed)
+    # an object-sized blob in millimetres (the scans' unit), with duplicated points and a dense core
+    pts = (rng.normal(size=(n, 3)) * np.array([300.0, 200.0, 150.0]) + 1000.0).astype(np.float32)
+    pts[n // 2:n // 2 + 50] = pts[:50]
+    cloud = torch.from_numpy(np.concatenate([pts, rng.random((n, 3)).astype(np.float32)], 1)).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    pick, best, rung = gp.calculate_downsample_indices(cloud, target, gen, return_candidates=True)
+    assert pick.shape == (target,) and int(pick.min()) >= 0 and int(pick.max()) < n
+    if n < target:
+        assert rung == -2 and len(torch.unique(pick)) < target        # with replacement
+        return
+    want, want_rung = prep_oracle.downsample_candidates(pts, target)
+    assert rung == want_rung
+    assert np.array_equal(best.cpu().numpy(), want)
+    assert len(torch.unique(pick)) == target                            # without replacement
+    assert bool(torch.isin(pick, best).all())
+
+
+def test_voxel_mode_scan_preparation_and_sample_cache(tmp_path):
+    """prepare_scan(downsample='voxel') on a millimetre-scale scan: crops drawn from the voxel-thinned candidates (spatially
+    uniform: the reference's behaviour), same layout as the strata mode; the prepared sample goes through the reference's
+    .npz cache format (or_dataset.py:94-120) and back."""
+    from scene_graph_prediction.scene_graph_helpers.dataset import cache, gpu_preparation as gp
+    pts, masks = gp.synthetic_fused_scan(4, 80000, seed=2, device="cuda", scale=1000.0)
+    names = ["Patient", "instrument_table", "human_1", "anesthesia_equipment"]
+    kw = dict(padding=0.2 * 1000.0, seed=9, object_names=names, scan_id="4_000131",
+              gt_class=torch.zeros(4, dtype=torch.int64), gt_rels=torch.zeros(12, dtype=torch.int64))
+    a = gp.prepare_scan(pts, masks, 4, 1000, 2000, downsample="voxel", **kw)
+    b = gp.prepare_scan(pts, masks, 4, 1000, 2000, downsample="strata", **kw)
+    assert a["obj_points"].shape == b["obj_points"].shape == (4, 6, 1000)
+    assert a["rel_points"].shape == b["rel_points"].shape == (12, 7, 2000)
+    assert torch.equal(a["prep"]["boxes"], b["prep"]["boxes"]) and torch.equal(a["prep"]["members"], b["prep"]["members"])
+    sel = a["prep"]["selection"].view(-1)
+    first = sel[:1000]
+    assert len(torch.unique(first)) == 1000 and bool((masks[first.long()] == 1).all())      # distinct members of object 1
+    # voxel thinning spreads the sample: the nearest-neighbour distance inside the crop is larger than for a uniform draw
+    def nn(idx):
+        p = pts[idx.long(), :3]
+        d = torch.cdist(p, p) + torch.eye(len(p), device=p.device) * 1e9
+        return float(d.min(dim=1).values.median())
+    assert nn(first) > nn(b["prep"]["selection"].view(-1)[:1000])
+    xyz = a["rel_points"][:, :3]
+    assert float(xyz.mean(dim=2).abs().max()) < 1e-4 and abs(float(xyz.norm(dim=1).max()) - 1.0) < 1e-5
+    # cache round trip in the reference's format
+    s1 = cache.cached(tmp_path, "4_000131", lambda: a, device="cuda")
+    s2 = cache.cached(tmp_path, "4_000131", lambda: (_ for _ in ()).throw(AssertionError("cache miss")), device="cuda")
+    for k in ("obj_points", "rel_points", "edge_indices", "relation_objects_one_hot", "gt_class", "gt_rels"):
+        assert torch.equal(s1[k].cpu(), a[k].cpu()) and torch.equal(s2[k].cpu(), a[k].cpu()) and s2[k].is_cuda
