@@ -253,14 +253,23 @@ def roofline_of(top, pmc_applies=True):
         roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"]}
     traffic, traffic_src = None, None
-    kname = {"pn2_mlp_gemm": "mlp_gemm_kernel", "pn2_mlp_wgrad": "mlp_wgrad_kernel",
+    kname = {"pn2_mlp_gemm": "mlp_gemm_kernel", "pn2_mlp_gemm_pool": "mlp_gemm_kernel", "pn2_mlp_wgrad": "mlp_wgrad_kernel",
              "pn2_mlp_bwd_fused": "mlp_bwd_fused_kernel", "pn2_mlp_bwd_fused_fold": "mlp_bwd_fused2_kernel",
+             "pn2_pool_bwd": "pool_bwd64_kernel",
              "pn2_bn_relu_rows_max": "bn_relu_rows_max_kernel",
              "pn2_group_concat_rows": "group_concat_rows_wide4_kernel",
-             "pn2_group_rows_grad": "group_rows_grad_csr_kernel"}.get(top["kernel"])
-    # newest committed counter summary of the default command first (tools/profile_round.sh + tools/summarise_profile.py)
-    for fname, key, scale in (("r02_backbone_counters.json", "hbm_MB_per_launch", 1e6),
-                              ("r01_hbm_traffic_per_kernel.json", "hbm_bytes_per_launch", 1.0)):
+             "pn2_group_rows_grad": "group_rows_grad_csr_kernel",
+             "pn2_mlp_gemm_bf16": "mlp_gemm_bf16_kernel", "pn2_mlp_wgrad_bf16": "mlp_wgrad_bf16_kernel",
+             "pn2_mlp_bwd_bf16": "mlp_bwd_bf16_kernel", "pn2_bn_relu_rows_max_bf16": "bn_relu_rows_max_bf16_v8_kernel",
+             "pn2_group_concat_rows_bf16": "group_concat_rows_bf16_wide8_kernel"}.get(top["kernel"])
+    bf16 = "bf16" in top["kernel"]
+    # newest committed counter summary of the command first (tools/profile_round.sh + tools/summarise_profile.py); the
+    # fp32 and the bf16 default commands have their own files
+    files = ((("r03_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r02_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6))
+             if bf16 else
+             (("r03_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r02_backbone_counters.json", "hbm_MB_per_launch", 1e6),
+              ("r01_hbm_traffic_per_kernel.json", "hbm_bytes_per_launch", 1.0)))
+    for fname, key, scale in files:
         tf = os.path.join(REPO, "profiles", fname)
         if not (pmc_applies and kname and os.path.exists(tf)) or traffic is not None:
             continue
