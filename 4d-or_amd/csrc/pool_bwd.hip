@@ -23,6 +23,7 @@
 // y_{L-1} registers already have.
 #include "pn2_common.h"
 #include "mlp_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -671,6 +672,288 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   }
 }
 
+// K = 128: the same organisation (row lists, lanes = rows for S, lanes = columns for T), eight waves, one workgroup per
+// CU.  Every wave owns one of the eight 32 x 32 blocks of a G and two of the sixteen Gram blocks.  G (64 KB) lives in
+// LDS (B fragments read per step: the registers hold the 64 T accumulators instead); W' (N x 128: up to 128 KB) does not
+// fit next to it and is gathered from L2 — lane r reads the 64-byte slab W'[n][16 w .. 16 w + 15] of ITS list entry.
+// A thread files two (group, column) entries per tile (four groups x 256 columns at ns = 16).
+__global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a) {
+  constexpr int K = 128, NW = 8, THREADS = 512;
+  constexpr int LDZ = K + 1, LDT = K + 4, LDG = K + 1;
+  constexpr int CG = K / 4;           // 32 threads per row
+  constexpr int RP = THREADS / CG;    // 16 rows per pass
+  constexpr int NPASS = TM / RP;      // 4
+  constexpr int NPAD = 256;           // entries per group, padded (N <= 256)
+  constexpr int GMAX = 4;             // groups per tile (ns >= 16)
+  constexpr int EPT = GMAX * NPAD / THREADS;   // entries a thread files per tile (2)
+  constexpr int KQ = 64;              // T: wave = (64-column quarter of N) x (64-column half of K)
+  constexpr int KS = K / NW;          // S: 16-column slab of K per wave
+  constexpr int CAP = 16;             // N / ns = 8 entries per row on average at the headline shape
+  constexpr int OVC = GMAX * NPAD;
+  __shared__ float zt[TM * LDZ];
+  __shared__ __attribute__((aligned(16))) float st[TM * LDT];
+  __shared__ float gl[K * LDG];
+  __shared__ __attribute__((aligned(16))) float prm[4 * K];
+  __shared__ int cnt[TM + 1];
+  __shared__ int lst_n[TM * CAP];
+  __shared__ float lst_c[TM * CAP];
+  __shared__ int ovf_rn[OVC];
+  __shared__ float ovf_c[OVC];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long M = a.M;
+  const int N = a.N, ns = a.ns;
+  const long long R = M / ns;
+  const long long ntiles = (M + TM - 1) / TM;
+  const int ngt = ns >= TM ? 1 : TM / ns;
+
+  const int c4 = tid % CG, r0 = tid / CG;
+  for (int i = tid; i < 4 * K; i += THREADS) prm[i] = a.finp[i];
+  for (int i = tid; i < K * K; i += THREADS) gl[(i / K) * LDG + (i % K)] = a.G[i];
+  if (tid <= TM) cnt[tid] = 0;
+  const int rb = wave >> 2, cb = wave & 3;               // a G block
+  const int ib = wave >> 1, jb0 = (wave & 1) * 2;        // Gram blocks (ib, jb0), (ib, jb0 + 1)
+  const float vreg = a.v[cb * 32 + (lane & 31)];
+  const int tn0 = (wave & 3) * 64, tk0 = (wave >> 2) * KQ;
+
+  f32x16 accZ, accG[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { accZ[r] = 0.f; accG[0][r] = 0.f; accG[1][r] = 0.f; }
+  float tacc[KQ];
+#pragma unroll
+  for (int kk = 0; kk < KQ; ++kk) tacc[kk] = 0.f;
+  float zsum[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int yoff = (r0 * K + 4 * c4) * 4;
+  f32x4 ycur[NPASS], ynxt[NPASS];
+  auto load_tile = [&](long long tile, f32x4 (&y)[NPASS]) {
+    const long long m0 = tile * TM;
+    const rsrc_t rs_ = make_rsrc(a.Yp + (size_t)m0 * K, (M - m0) * K * 4);
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i)
+      y[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, yoff, i * RP * K * 4, 0));
+  };
+  int ea[EPT], ta[GMAX];
+  float ec[EPT], tg[GMAX];
+  auto load_idx = [&](long long tile) {
+    const long long g_first = tile * TM / ns;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+      const int e = tid + THREADS * u;
+      const int egi = e / NPAD, en = e % NPAD;
+      const long long g = g_first + egi;
+      const bool ok = egi < ngt && g < R && en < N;
+      ea[u] = ok ? a.arg[(size_t)(ok ? g : 0) * N + (ok ? en : 0)] : -(1 << 20);
+      ec[u] = ok ? a.gPm[(size_t)(ok ? g : 0) * N + (ok ? en : 0)] : 0.f;
+    }
+#pragma unroll
+    for (int gi = 0; gi < GMAX; ++gi) {
+      const long long g = g_first + gi;
+      const int n = tn0 + lane;
+      const bool ok = gi < ngt && g < R && n < N;
+      ta[gi] = ok ? a.arg[(size_t)(ok ? g : 0) * N + (ok ? n : 0)] : -(1 << 20);
+      tg[gi] = ok ? a.gPm[(size_t)(ok ? g : 0) * N + (ok ? n : 0)] : 0.f;
+    }
+  };
+
+  long long tile = blockIdx.x;
+  if (tile < ntiles) {
+    load_tile(tile, ycur);
+    load_idx(tile);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long long m0 = tile * TM;
+    const int mrem = (int)((M - m0) < (long long)TM ? (M - m0) : (long long)TM);
+    const long long g_first = m0 / ns;
+    // ---- (A) activation tile; this thread's entries filed under their arg-max rows ----
+    {
+      const f32x4 sc = *reinterpret_cast<const f32x4 *>(&prm[2 * K + 4 * c4]);
+      const f32x4 sh = *reinterpret_cast<const f32x4 *>(&prm[3 * K + 4 * c4]);
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        const int row = r0 + RP * i;
+        const bool valid = row < mrem;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float z = fmaxf(__fmaf_rn(ycur[i][j], sc[j], sh[j]), 0.f);
+          z = valid ? z : 0.f;
+          zsum[j] += z;
+          zt[row * LDZ + 4 * c4 + j] = z;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < EPT; ++u) {
+        const int e = tid + THREADS * u;
+        const int row = (int)((g_first + e / NPAD) * ns - m0) + ea[u];
+        if ((unsigned)row < (unsigned)TM && ec[u] != 0.f) {
+          const int rank = atomicAdd(&cnt[row], 1);
+          if (rank < CAP) {
+            lst_n[row * CAP + rank] = e % NPAD;
+            lst_c[row * CAP + rank] = ec[u];
+          } else {
+            const int o = atomicAdd(&cnt[TM], 1);
+            ovf_rn[o] = (row << 16) | (e % NPAD);
+            ovf_c[o] = ec[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const long long nt = (tile + gridDim.x) < ntiles ? tile + gridDim.x : tile;
+    load_tile(nt, ynxt);
+
+    // ---- (B) sparse parts ----
+    {
+      // S: lane = tile row, registers = this wave's KS columns; W' slabs gathered from L2 (two list slots per step)
+      float sreg[KS];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) sreg[kk] = 0.f;
+      const int filed = cnt[lane];
+      const int mine = filed < CAP ? filed : CAP;
+      // one list slot per step, the next slot's (column, coefficient) read ahead of this slot's gather
+      int nn = mine > 0 ? lst_n[lane * CAP] : 0;
+      float cn = mine > 0 ? lst_c[lane * CAP] : 0.f;
+      for (int c = 0; __ballot(c < mine) != 0ull; ++c) {
+        const int n1 = nn;
+        const float c1 = cn;
+        const bool more = c + 1 < mine;
+        nn = more ? lst_n[lane * CAP + c + 1] : 0;
+        cn = more ? lst_c[lane * CAP + c + 1] : 0.f;
+        f32x4 w[KS / 4];
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) w[q] = *reinterpret_cast<const f32x4 *>(a.Wp + (size_t)n1 * K + wave * KS + 4 * q);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) sreg[kk] = __fmaf_rn(c1, w[kk >> 2][kk & 3], sreg[kk]);
+      }
+      const int nov = __builtin_amdgcn_readfirstlane(cnt[TM]);
+      for (int o = 0; o < nov; ++o) {                      // rows with more than CAP entries: one lane at a time
+        const int rn = __builtin_amdgcn_readfirstlane(ovf_rn[o]);
+        const float cf = (rn >> 16) == lane ? ovf_c[o] : 0.f;
+        const float *wr = a.Wp + (size_t)(rn & 0xffff) * K + wave * KS;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) sreg[kk] = __fmaf_rn(cf, wr[kk], sreg[kk]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; kk += 4) {
+        f32x4 o4 = {sreg[kk], sreg[kk + 1], sreg[kk + 2], sreg[kk + 3]};
+        *reinterpret_cast<f32x4 *>(&st[lane * LDT + wave * KS + kk]) = o4;
+      }
+    }
+    // T: lanes = columns n of this wave's quarter, registers = its 64 columns k
+#pragma unroll
+    for (int gi = 0; gi < GMAX; ++gi) {
+      if (gi < ngt) {
+        const int base = (int)((g_first + gi) * ns - m0);
+        int rt = base + ta[gi];
+        const bool ok = (unsigned)rt < (unsigned)TM;
+        const float cf = ok ? tg[gi] : 0.f;
+        rt = ok ? rt : 0;
+        const float *zr = &zt[rt * LDZ + tk0];
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+          tacc[kk] = __fmaf_rn(cf, zr[kk], tacc[kk]);
+          if ((kk & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    load_idx(nt);
+
+    // ---- (C) matrix products ----
+    {
+      const float *za = &zt[(rb * 32 + (lane & 31)) * LDZ + (lane >> 5)];
+      const float *gb_ = &gl[(lane >> 5) * LDG + cb * 32 + (lane & 31)];
+#pragma unroll
+      for (int s = 0; s < K / 2; ++s) {
+        accZ = __builtin_amdgcn_mfma_f32_32x32x2f32(za[2 * s], gb_[2 * s * LDG], accZ, 0, 0, 0);
+        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+      const float *ga = &zt[(lane >> 5) * LDZ + ib * 32 + (lane & 31)];
+      const float *gb = &zt[(lane >> 5) * LDZ + jb0 * 32 + (lane & 31)];
+#pragma unroll
+      for (int s = 0; s < TM / 2; ++s) {
+        const float av = ga[2 * s * LDZ];
+        accG[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gb[2 * s * LDZ], accG[0], 0, 0, 0);
+        accG[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gb[2 * s * LDZ + 32], accG[1], 0, 0, 0);
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    // ---- (D) a G + v + S into the staging tile; the row lists are free again ----
+    {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = st[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + cb * 32 + (lane & 31)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + cb * 32 + (lane & 31)] = (accZ[r] + vreg) + t[r];
+        accZ[r] = 0.f;
+      }
+      if (tid <= TM) cnt[tid] = 0;
+    }
+    __syncthreads();
+    // ---- (E) mask, statistics, store ----
+    {
+      const rsrc_t rso = make_rsrc(a.Gout + (size_t)m0 * K, (M - m0) * K * 4);
+      const f32x4 mu = *reinterpret_cast<const f32x4 *>(&prm[4 * c4]);
+      const f32x4 rs = *reinterpret_cast<const f32x4 *>(&prm[K + 4 * c4]);
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        const int row = r0 + RP * i;
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(&st[row * LDT + 4 * c4]);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g = zt[row * LDZ + 4 * c4 + j] > 0.f ? q[j] : 0.f;
+          o[j] = g;
+          cs1[j] += g;
+          cs2[j] = __fmaf_rn(g, (ycur[i][j] - mu[j]) * rs[j], cs2[j]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), rso,
+                                               yoff, i * RP * K * 4, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) ycur[i] = ynxt[i];
+  }
+
+  // ---- flush ----
+  float *prec = a.part + (size_t)blockIdx.x * (K * K + K + (size_t)N * K);
+  __syncthreads();
+  float *rbuf = st;                                      // [THREADS][4], three rounds
+  float t3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int round = 0; round < 3; ++round) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rbuf[tid * 4 + j] = round == 0 ? zsum[j] : (round == 1 ? cs1[j] : cs2[j]);
+    __syncthreads();
+    if (tid < K) {
+      float t = 0.f;
+      for (int q = 0; q < RP; ++q) t += rbuf[((q * CG + (tid >> 2)) * 4) + (tid & 3)];
+      t3[round] = t;
+    }
+    __syncthreads();
+  }
+  if (tid < K) {
+    prec[K * K + tid] = t3[0];
+    atomicAdd(a.sums + tid, (double)t3[1]);
+    atomicAdd(a.sums + K + tid, (double)t3[2]);
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      prec[i * K + (jb0 + b) * 32 + (lane & 31)] = accG[b][r];
+    }
+  float *pt = prec + K * K + K;
+  if (tn0 + lane < N) {
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) pt[(size_t)(tn0 + lane) * K + tk0 + kk] = tacc[kk];
+  }
+}
+
 // G = W^T diag(c2) W, v = W^T c3, W' = diag(c1) W  (consts = [c1 | c2 | c3] x N from pn2_bn_bwd_consts)
 __global__ __launch_bounds__(128) void pool_bwd_setup_kernel(int N, int K, const float *__restrict__ W,
                                                             const float *__restrict__ consts, float *__restrict__ G,
@@ -735,9 +1018,11 @@ extern "C" int pn2_pool_bwd_supported(int N, int K, int ns) {
   if (!((K == 64 || K == 128) && N >= 1 && N <= 256 && (ns == 16 || ns == 32 || ns == 64 || ns == 128))) return 0;
   const int ngt = ns >= 64 ? 1 : 64 / ns;
   if (K == 64 && N <= 128) return ngt * (N <= 64 ? 64 : 128) <= 512;      // one (group, column) entry per thread
-  // index registers: (64 / ns) groups x ceil(N / 64) entry batches per tile must fit eight batches
-  const int nbc = K == 64 ? 4 : (N <= 128 ? 2 : 4);
-  return ngt * nbc <= 8;
+  // K = 128: W' (N x 128 floats) is gathered from L2 — N / ns entries per row and 512 bytes each.  At ns = 16 (16 entries
+  // per row on average, 512 KB of W' per 64-row tile against 32 KB of y) the gather, not the matrix products, is the
+  // kernel's time (measured 1.24 ms vs 0.46 ms for the materialised path at 256k rows): such layers stay on that path
+  if (K == 128) return ns >= 32 && getenv("PN2_POOL_K128_OFF") == nullptr;
+  return ngt * 4 <= 8;                                                     // K = 64, N > 128: the index-register kernel
 }
 
 extern "C" size_t pn2_pool_bwd_workspace_bytes(long long M, int N, int K) {
@@ -784,8 +1069,7 @@ extern "C" int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, 
     else if (N <= 128) hipLaunchKernelGGL((pool_bwd64_kernel<2>), dim3(grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((pool_bwd_kernel<2, 64, false>), dim3(grid), dim3(256), 0, s, a);
   } else {
-    if (N <= 128) hipLaunchKernelGGL((pool_bwd_kernel<4, 16, false>), dim3(grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((pool_bwd_kernel<4, 32, false>), dim3(grid), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(pool_bwd128_kernel, dim3(grid), dim3(512), 0, s, a);
   }
   const int slices = grid >= 64 ? 16 : 1;
   hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((unsigned)((rec + 255) / 256), slices), dim3(256), 0, s, grid, (int)rec,

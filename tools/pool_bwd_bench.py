@@ -5,7 +5,7 @@ sys.path[:0] = [os.path.join(REPO, "4d-or_amd")]
 import torch
 from pointnet2_ops import _ext as e
 
-SHAPES = [(4194304, 64, 128, 64), (1048576, 128, 256, 32)]
+SHAPES = [(4194304, 64, 128, 64), (1048576, 128, 256, 32), (262144, 128, 256, 16), (131072, 128, 256, 16)]
 dev = torch.device("cuda:0")
 for M, K, N, ns in SHAPES:
     torch.manual_seed(0)
