@@ -49,27 +49,17 @@ def fps_sweep(dev):
     for B, N, m, variants in cases:
         x = unit_ball(B, N, 3).to(dev)
         for mode, g in variants:
-            os.environ["PN2_FPS_MODE"] = mode
             nc = None
             if isinstance(g, tuple):
                 nc, g = g
-            if nc:
-                os.environ["PN2_FPS_NC"] = str(nc)
-            else:
-                os.environ.pop("PN2_FPS_NC", None)
-            if g:
-                os.environ["PN2_FPS_G"] = str(g)
-            else:
-                os.environ.pop("PN2_FPS_G", None)
+            # variants are forced through the library's test hook (the PN2_FPS_* environment switches were removed in round 2)
             try:
-                t = timeit(lambda: _ext.furthest_point_sampling(x, m), iters=3, warm=1)
+                with _ext.fps_plan_override(mode, g=g or 0, nc=nc or 0):
+                    t = timeit(lambda: _ext.furthest_point_sampling(x, m), iters=3, warm=1)
                 report(f"fps_sweep B{B} N{N} m{m} {mode} NC{nc} G{g}", t, B * (12 * N + 4 * m),
                        us_per_round=round(t / (m - 1) * 1e6, 3))
             except RuntimeError as e:
                 print("fps_sweep", B, N, mode, g, "->", e, flush=True)
-    os.environ.pop("PN2_FPS_MODE", None)
-    os.environ.pop("PN2_FPS_G", None)
-    os.environ.pop("PN2_FPS_NC", None)
 
 
 def mlp_sweep(dev):
