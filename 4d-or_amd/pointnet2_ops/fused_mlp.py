@@ -34,6 +34,10 @@ FUSED_BACKWARD = True
 #: the max-pooled last layer of a stack never materialises its (M, C_out) output: the forward GEMM reduces the group
 #: maxima in its epilogue (pn2_mlp_gemm_pool), the backward runs in Gram form from y_{L-1} alone (pn2_pool_bwd)
 POOL_FUSED = True
+#: (measurement switch, tools only: PN2_POOL_FUSED=0 python bench.py ... runs the materialised path for an A/B)
+import os as _os
+if _os.environ.get("PN2_POOL_FUSED") == "0":
+    POOL_FUSED = False
 
 #: arithmetic of the shared-MLP stacks.  float32 = exact fp32 MFMA (the parity path, default).  bfloat16 = the MI355X
 #: counterpart of the reference's 16-bit AMP training (scene_graph_prediction/main.py:64 `precision=16`): activations
@@ -133,7 +137,12 @@ class _FusedMLP(Function):
         # pooled last layer without its output tensor: needs the Gram-form backward whenever anything needs a gradient
         Kl, Nl = layers[-1][0].in_channels, layers[-1][0].out_channels
         needs_grad = any(ctx.needs_input_grad)
-        pool_fused = bool(POOL_FUSED and ns and L >= 2 and M % ns == 0 and getattr(e, "pool_layer_supported", None)
+        # grouped input: only for CROWDED balls (group[7], see fused_group_mlp_pool) — with sparse balls most slots of a
+        # neighbourhood repeat its first hit, the arg-max ties go to row 0 and nearly all of a group's columns land on one
+        # or two rows: the row lists of pn2_pool_bwd overflow into their one-row-at-a-time path and the materialised
+        # kernels are 2-4x faster (measured on the scene-graph encoders, profiles/r03_sgp8_pool_ab.md)
+        want = True if group is None or len(group) < 8 or group[7] is None else bool(group[7])
+        pool_fused = bool(POOL_FUSED and want and ns and L >= 2 and M % ns == 0 and getattr(e, "pool_layer_supported", None)
                           and e.pool_layer_supported(Kl, Nl, ns) and (not needs_grad or e.pool_bwd_supported(Nl, Kl, ns)))
         pooled_parts = None
         for l, (conv, bn) in enumerate(layers):
@@ -575,7 +584,7 @@ class _SegmentedGroupMLP(Function):
             sub = _SegCtx((ctx.needs_input_grad[0],))
             sub.x_rows = rows_all[c0:c1].view(-1, rows_all.size(-1))
             sub.fin_out = [None if F is None else F[s] for F in fin_bufs]
-            g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius)
+            g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius, None, group[7] if len(group) > 7 else None)
             with torch.cuda.stream(fork.stream(s)):
                 out, arg = inner.forward(sub, None if x is None else x[c0:c1], ns, layers, g, *params)
             subs.append(sub)
@@ -640,14 +649,16 @@ def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0) -> torch.Tens
 
 
 def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius,
-                         clouds_per_scan: Optional[Sequence[int]] = None, inv=None) -> torch.Tensor:
+                         clouds_per_scan: Optional[Sequence[int]] = None, inv=None, crowded: Optional[bool] = None) -> torch.Tensor:
     """Ball-query neighbourhoods -> shared MLP -> max, one autograd node:
     xyz (B,N,3), new_xyz (B,m,3), feats_rows (B,N,C)|None, idx (B,m,ns) -> (B, m, C_out).
     `clouds_per_scan` (sums to B): BatchNorm batch statistics per scan (see _SegmentedGroupMLP)."""
     layers = parse_stack(mlp)
     assert layers is not None
     B, m, ns = idx.shape
-    group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius, inv)    # inv: (ptr, refs) of the whole batch's idx
+    # inv: (ptr, refs) of the whole batch's idx; crowded: N r^3 > 4 nsample (pointnet2_modules.crowded_balls) -> the pooled
+    # last layer runs without its output tensor (csrc/pool_bwd.hip)
+    group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius, inv, crowded)
     if clouds_per_scan is not None and len(clouds_per_scan) > 1:
         if sum(clouds_per_scan) != B:
             raise RuntimeError("fused_group_mlp_pool: clouds_per_scan must sum to the number of clouds")

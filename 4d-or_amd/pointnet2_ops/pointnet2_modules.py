@@ -167,7 +167,8 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
             if idx is None:
                 idx = grouper.query(xyz, new_xyz)
             return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
-                                                  grouper.normalize_xyz, grouper.radius, clouds_per_scan=sizes)
+                                                  grouper.normalize_xyz, grouper.radius, clouds_per_scan=sizes,
+                                                  crowded=crowded_balls(grouper, xyz.size(1)))
         split = lambda t: [None] * len(sizes) if t is None else t.split_with_sizes(sizes)
         parts = [sa_scale_rows(grouper, mlp, x, nx, f, i, _whole_batch=True)
                  for x, nx, f, i in zip(split(xyz), split(new_xyz), split(feats_rows), split(idx))]
@@ -178,7 +179,8 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
         if idx is None:
             idx = grouper.query(xyz, new_xyz)
         return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
-                                              grouper.normalize_xyz, grouper.radius, inv=inv)
+                                              grouper.normalize_xyz, grouper.radius, inv=inv,
+                                              crowded=crowded_balls(grouper, xyz.size(1)))
     if idx is not None:
         g = pointnet2_utils.group_concat_rows(xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
                                               grouper.normalize_xyz, grouper.radius, inv=inv)
