@@ -588,7 +588,7 @@ struct FpsPlan {
   int NC;    // cooperative: clouds per cluster
 };
 
-const int kPptSteps[] = {1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 20, 24};
+const int kPptSteps[] = {1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 20, 24, 26};   // 26: only the 1024-thread cluster kernel (21 + 4 PPT VGPRs <= 128)
 
 int round_ppt(int ppt) {
   for (int c : kPptSteps)
@@ -654,10 +654,18 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false) {
     // 32 x 50k -> 2048), but a resident FPS workgroup pins 160 of the 512 VGPRs per lane on its CU for its whole
     // run and halves the occupancy of every co-running 8-wave GEMM workgroup there; on 128 CUs instead of 256 the
     // other half of the chip runs the step undisturbed and the step is 0.8 ms shorter (tools/corun_probe.py).
+    // Round 3: FEWER still — the 1024-thread kernel needs 21 + 4 PPT registers, so a workgroup can hold up to 26 points
+    // per lane (125 VGPRs: the whole register file of its CU) and a 50k-point cloud fits TWO workgroups: 64 CUs for the
+    // SA1 sampling of 32 clouds instead of 128.  A round gets slower (26 instead of 14 points per lane to scan, 3.0 vs
+    // 2.6 us) but the CU-time the co-running step loses halves.
     int cbs = 512;
     if (NC == 1 && !ov.G && few_cus && G >= 4) {
-      const int wp = round_ppt((N + (G / 2) * 1024 - 1) / ((G / 2) * 1024));
-      if (wp >= 8 && wp <= 16) { cbs = 1024; G /= 2; }
+      int g2 = G / 2;
+      while (g2 > 2 && round_ppt((N + (g2 / 2) * 1024 - 1) / ((g2 / 2) * 1024)) > 0 &&
+             round_ppt((N + (g2 / 2) * 1024 - 1) / ((g2 / 2) * 1024)) <= 26)
+        g2 /= 2;
+      const int wp = round_ppt((N + g2 * 1024 - 1) / (g2 * 1024));
+      if (wp >= 8 && wp <= 26) { cbs = 1024; G = g2; }
     }
     if (ov.coop_bs == 1024 && NC == 1) cbs = 1024;
     const int ppt = round_ppt((N + G * cbs - 1) / (G * cbs));
@@ -665,7 +673,7 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false) {
     // residency: 512-thread cluster workgroups fit at least three to a CU (two are counted on), 1024-thread ones one
     const long long cap = cbs == 1024 ? (long long)ncus : max_coop_wgs;
     if (G <= kCoopMaxG && (long long)(B / NC) * G <= cap && ppt > 0 && NC * ppt <= 28 &&
-        (cbs == 512 || (ppt >= 8 && ppt <= 16))) {
+        (cbs == 512 ? ppt <= 24 : (ppt >= 8 && ppt <= 26))) {
       c.mode = 1; c.G = G; c.PPT = ppt; c.NC = NC; c.BS = cbs;
     }
   }
@@ -857,6 +865,9 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
         case 12: PN2_FPS_COOP_W(12); break;
         case 14: PN2_FPS_COOP_W(14); break;
         case 16: PN2_FPS_COOP_W(16); break;
+        case 20: PN2_FPS_COOP_W(20); break;
+        case 24: PN2_FPS_COOP_W(24); break;
+        case 26: PN2_FPS_COOP_W(26); break;
         default: return PN2_EINVAL;
       }
 #undef PN2_FPS_COOP_W
