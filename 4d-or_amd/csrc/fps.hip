@@ -619,7 +619,7 @@ int device_cus() {
   return cus[dev];
 }
 
-FpsPlan fps_plan(int B, int N, int m, bool few_cus = false) {
+FpsPlan fps_plan(int B, int N, int m, bool few_cus = false, bool fewest = false) {
   FpsPlan p = {2, 1, 1024, 0, 1};
   if (m <= 1) { p.mode = 0; p.BS = 512; p.PPT = 1; return p; }
   const FpsOverride ov = g_fps_override;
@@ -661,7 +661,7 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false) {
     int cbs = 512;
     if (NC == 1 && !ov.G && few_cus && G >= 4) {
       int g2 = G / 2;
-      while (g2 > 2 && round_ppt((N + (g2 / 2) * 1024 - 1) / ((g2 / 2) * 1024)) > 0 &&
+      while (fewest && g2 > 2 && round_ppt((N + (g2 / 2) * 1024 - 1) / ((g2 / 2) * 1024)) > 0 &&
              round_ppt((N + (g2 / 2) * 1024 - 1) / ((g2 / 2) * 1024)) <= 26)
         g2 /= 2;
       const int wp = round_ppt((N + g2 * 1024 - 1) / (g2 * 1024));
@@ -795,7 +795,7 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
                                               void *workspace, size_t workspace_bytes,
                                               int *idxs, int flags, void *stream) {
   if (B < 0 || N < 0) return PN2_EINVAL;
-  if (flags & ~PN2_FPS_FEW_CUS) return PN2_EINVAL;
+  if (flags & ~(PN2_FPS_FEW_CUS | PN2_FPS_FEWEST_CUS)) return PN2_EINVAL;
   if (m <= 0 || B == 0) return PN2_OK;  // EXT/src/sampling_gpu.cu:73
   if (N <= 0) return PN2_EINVAL;
   if (!xyz || !idxs) return PN2_ENULL;
@@ -803,7 +803,7 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
   const int bs = ref_opt_n_threads(N);
   int L = 0;
   while ((1 << L) < bs) ++L;
-  const FpsPlan plan = fps_plan(B, N, m, (flags & PN2_FPS_FEW_CUS) != 0);
+  const FpsPlan plan = fps_plan(B, N, m, flags != 0, (flags & PN2_FPS_FEWEST_CUS) != 0);
   const size_t need = pn2_fps_workspace_bytes(B, N, m);       // same for both cooperative shapes
   if (need) {
     if (!workspace) return PN2_ENULL;

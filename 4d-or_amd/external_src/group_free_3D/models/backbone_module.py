@@ -47,7 +47,11 @@ class Pointnet2Backbone(nn.Module):
         geo = {"sa": [], "fp": []}
         levels = [xyz]
         # FPS shape that leaves half of the CUs to the co-running step (include/pn2_hip.h: PN2_FPS_FEW_CUS)
-        with getattr(pointnet2_utils._ext, "background_geometry", contextlib.nullcontext)():
+        # fp32 steps (13+ ms of matrix kernels) are longer than the sampling chain: give the sampling as few CUs as possible;
+        # the bf16 step is shorter than the chain and wants the faster 128-CU shape
+        from pointnet2_ops import fused_mlp
+        bg = getattr(pointnet2_utils._ext, "background_geometry", None)
+        with (bg(fewest=fused_mlp.mlp_dtype() == torch.float32) if bg is not None else contextlib.nullcontext()):
             for i in (1, 2, 3, 4):
                 # levels 2-4 gather features that carry a gradient (level 1 reads the input colours)
                 g = getattr(self, f"sa{i}").sample_and_query(levels[-1], inverse_index=i > 1)

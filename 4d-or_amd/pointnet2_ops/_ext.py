@@ -279,15 +279,17 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None, label=None):
 #: kernels (identical results; tests flip it to compare both implementations, or force the cell list with "force")
 BALL_QUERY_GRID = True
 PN2_FPS_FEW_CUS = 1
+PN2_FPS_FEWEST_CUS = 2
 _sched = threading.local()
 
 
 @contextlib.contextmanager
-def background_geometry():
+def background_geometry(fewest=False):
     """FPS calls made inside run with PN2_FPS_FEW_CUS (include/pn2_hip.h): for geometry that is prefetched on a
-    side stream while a training step runs on the main one.  Results are identical."""
+    side stream while a training step runs on the main one.  `fewest`: PN2_FPS_FEWEST_CUS — trade sampling latency for
+    CUs (the step next to it is longer than the sampling chain).  Results are identical."""
     prev = getattr(_sched, "few_cus", False)
-    _sched.few_cus = True
+    _sched.few_cus = PN2_FPS_FEW_CUS | (PN2_FPS_FEWEST_CUS if fewest else 0)
     try:
         yield
     finally:
@@ -306,7 +308,7 @@ def furthest_point_sampling(points, nsamples):
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=points.device) if ws_bytes else None
     if getattr(_sched, "few_cus", False):
         _call("pn2_furthest_point_sampling_ex", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
-              PN2_FPS_FEW_CUS, alg_bytes=B * (12 * N + 4 * nsamples), label="pn2_furthest_point_sampling")
+              int(_sched.few_cus), alg_bytes=B * (12 * N + 4 * nsamples), label="pn2_furthest_point_sampling")
     else:
         _call("pn2_furthest_point_sampling", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
               alg_bytes=B * (12 * N + 4 * nsamples))

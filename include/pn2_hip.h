@@ -65,6 +65,11 @@ int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz,
  * next to compute kernels (geometry of the next batch prefetched during a training step): pick the cooperative shape
  * that occupies half as many CUs (1024-thread cluster workgroups) instead of the one with the shortest latency. */
 #define PN2_FPS_FEW_CUS 1
+/* PN2_FPS_FEWEST_CUS (with or without PN2_FPS_FEW_CUS): as few CUs as the register file allows — up to 26 points per
+ * lane in 1024-thread workgroups, e.g. TWO workgroups per 50k-point cloud: 64 CUs for 32 clouds instead of 128 (256 for
+ * the latency-optimal shape).  The sampling itself takes longer (3.0 vs 2.6 us per round); worth it when the step it
+ * runs next to is longer than the sampling chain anyway (fp32 training step: 16.8 -> 16.3 ms; not the bf16 one). */
+#define PN2_FPS_FEWEST_CUS 2
 int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *xyz,
                                    void *workspace, size_t workspace_bytes,
                                    int *idxs, int flags, void *stream);

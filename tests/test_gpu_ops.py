@@ -51,9 +51,10 @@ def test_fps_few_cus_hint_is_bit_exact(ext, B, N, m, kind):
     many CUs) only changes the schedule, never the indices."""
     xyz = clouds(B, N, kind, seed=N * 7 + m)
     want = O.furthest_point_sampling(xyz, m)
-    with ext.background_geometry():
-        got = ext.furthest_point_sampling(dev(xyz), m).cpu()
-    assert torch.equal(got, want)
+    for fewest in (False, True):          # PN2_FPS_FEW_CUS, + PN2_FPS_FEWEST_CUS (two 1024-thread workgroups per 50k cloud)
+        with ext.background_geometry(fewest=fewest):
+            got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+        assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("mode,g", [("resident", None), ("stream", None), ("coop", 2), ("coop", 8), ("coop", 32), (None, None)])
