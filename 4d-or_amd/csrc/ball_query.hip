@@ -99,6 +99,186 @@ __global__ __launch_bounds__(256) void ball_query_kernel(int N, int m, int bpc, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// SLAB cell list (round 3): a cell list that keeps the reference's index order WITHOUT sorting.
+// The scan above is the right shape for "first nsample hits in ascending index" but tests every point of the prefix it
+// walks (~0.5 hits per 64 tests at the headline shape); the cell list below tests only the 27 neighbouring cells but
+// loses the index order (rank sort, and a crowded ball overflows its collection cap).  Here the cloud is cut into SLABS of
+// 2048 CONSECUTIVE indices and every slab gets its own cell list:
+//   build : one workgroup per (slab, cloud) — cell of a point = floor(coordinate / h) modulo 16 per axis (a HASH grid: no
+//           bounding box pass; cells that alias only add candidates that fail the distance test), LDS histogram + scan +
+//           scatter of (x, y, z, index in slab) records, one packed (start | count << 16) word per cell;
+//   query : one wave per centre walks the slabs in order.  Lanes = 27 cells x 2 slots test the cell's records and set
+//           bit `index in slab` of a 2048-bit mask in LDS — 64 lanes x 32 bits, so lane i afterwards holds indices
+//           [32 i, 32 i + 32) of the slab: a popcount + a wave prefix sum give every set bit its output slot, in ascending
+//           index order, for free.  The walk stops as soon as the row holds nsample hits (crowded balls: after a few
+//           slabs), the row is padded with the first hit.
+// Exactness.  Same distance expression and strict '<' as the scan.  A hit implies |p - c| <= r (1 + 2^-22) per axis in real
+// arithmetic; the window [c - rw, c + rw], rw = r 1.0001^2, is mapped to cells in DOUBLE precision with h = rw 1.0001, so it
+// spans at most three cells per axis and contains the cell of every hit as long as |coordinate / h| < 2^32 (error of the
+// double arithmetic 2^-19 cells against a margin of 1e-4).  Points beyond that (or non-finite) mark their slab, centres
+// beyond that mark themselves: such a (centre, slab) pair tests ALL records of the slab through the same mask — slow,
+// never wrong.  The mask makes duplicates harmless, the order inside a cell irrelevant.
+constexpr int kSlab = 2048;                       // indices per slab = 64 lanes x 32 mask bits
+constexpr int kSlabCells = 16 * 16 * 16;          // hash grid per slab
+constexpr int kSlabTable = kSlabCells + 16;       // words per (cloud, slab): cells | [4096] = "holds a wild point"
+
+// inclusive prefix sum over the 64 lanes on the DPP network (row shifts inside the rows of 16, then the row totals
+// broadcast into the rows above): six VALU instructions, no LDS crossbar
+__device__ __forceinline__ int slab_wave_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+__device__ __forceinline__ bool slab_tame(double t) { return fabs(t) < 4294967296.0; }   // false for NaN / inf too
+__device__ __forceinline__ int slab_cell1(double t) {                                    // floor(t) mod 16, t tame
+  const double f = floor(t);
+  return (int)(f - 16.0 * floor(f * 0.0625));
+}
+
+__global__ __launch_bounds__(256) void bq_slab_build_kernel(int N, int nslab, double inv_h,
+                                                           const float *__restrict__ xyz,
+                                                           unsigned *__restrict__ table, float4 *__restrict__ recs) {
+  __shared__ int hist[kSlabCells];
+  __shared__ int wsum[4];
+  __shared__ int wild;
+  const int tid = threadIdx.x, lane = pn2_lane(), wv = tid >> 6;
+  const int sl = blockIdx.x, b = blockIdx.y;
+  const int base = sl * kSlab;
+  const int len = N - base < kSlab ? N - base : kSlab;
+  const float *P = xyz + ((size_t)b * N + base) * 3;
+  for (int i = tid; i < kSlabCells; i += 256) hist[i] = 0;
+  if (tid == 0) wild = 0;
+  __syncthreads();
+  float px[8], py[8], pz[8];
+  int cell[8], rank[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int k = tid + u * 256;
+    cell[u] = -1;
+    if (k < len) {
+      px[u] = P[(size_t)k * 3 + 0]; py[u] = P[(size_t)k * 3 + 1]; pz[u] = P[(size_t)k * 3 + 2];
+      const double tx = (double)px[u] * inv_h, ty = (double)py[u] * inv_h, tz = (double)pz[u] * inv_h;
+      if (slab_tame(tx) && slab_tame(ty) && slab_tame(tz)) {
+        cell[u] = (slab_cell1(tz) * 16 + slab_cell1(ty)) * 16 + slab_cell1(tx);
+      } else {
+        cell[u] = 0;
+        wild = 1;
+      }
+      rank[u] = atomicAdd(&hist[cell[u]], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the 4096 counts: thread t owns cells [16 t, 16 t + 16)
+  int c[16], sum = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { c[i] = hist[tid * 16 + i]; sum += c[i]; }
+  int inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(inc, d);
+    if (lane >= d) inc += v;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int off = inc - sum;
+  for (int w = 0; w < wv; ++w) off += wsum[w];
+  unsigned *T = table + ((size_t)b * nslab + sl) * kSlabTable;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    hist[tid * 16 + i] = off;
+    T[tid * 16 + i] = (unsigned)off | ((unsigned)c[i] << 16);
+    off += c[i];
+  }
+  if (tid < 16) T[kSlabCells + tid] = (unsigned)wild;
+  __syncthreads();
+  float4 *R = recs + (size_t)b * N + base;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (cell[u] >= 0) R[hist[cell[u]] + rank[u]] = make_float4(px[u], py[u], pz[u], __int_as_float(tid + u * 256));
+  }
+}
+
+__global__ __launch_bounds__(256) void bq_slab_query_kernel(int N, int m, int nslab, float r2, int ns, double inv_h,
+                                                           double rw, const float *__restrict__ new_xyz,
+                                                           const unsigned *__restrict__ table,
+                                                           const float4 *__restrict__ recs, int *__restrict__ idx,
+                                                           long long centres) {
+  __shared__ unsigned s_mask[4][64];
+  const int lane = pn2_lane();
+  const int wv = threadIdx.x >> 6;
+  const long long g = (long long)blockIdx.x * 4 + wv;
+  if (g >= centres) return;                                     // wave-uniform; no block barriers below
+  const int b = (int)(g / m);
+  const float qx = new_xyz[g * 3 + 0], qy = new_xyz[g * 3 + 1], qz = new_xyz[g * 3 + 2];
+  int *row = idx + g * ns;
+  volatile unsigned *mask = s_mask[wv];
+  mask[lane] = 0u;
+
+  // lane -> (cell of the 3 x 3 x 3 window, slot); the window starts at the cell of c - rw on every axis
+  const double tx = ((double)qx - rw) * inv_h, ty = ((double)qy - rw) * inv_h, tz = ((double)qz - rw) * inv_h;
+  const bool tame = slab_tame(tx) && slab_tame(ty) && slab_tame(tz);
+  const int k = lane >> 1, slot = lane & 1;
+  int mycell = -1;
+  if (tame && k < 27) {
+    const int ox = k % 3, oy = (k / 3) % 3, oz = k / 9;
+    mycell = (((slab_cell1(tz) + oz) & 15) * 16 + ((slab_cell1(ty) + oy) & 15)) * 16 + ((slab_cell1(tx) + ox) & 15);
+  }
+  const unsigned *T = table + (size_t)b * nslab * kSlabTable;
+  const float4 *R = recs + (size_t)b * N;
+  int cnt = 0, first = 0;
+  unsigned wnext = mycell >= 0 ? T[mycell] : 0u;
+  for (int sl = 0; sl < nslab && cnt < ns; ++sl, T += kSlabTable, R += kSlab) {
+    const unsigned w = wnext;
+    if (sl + 1 < nslab && mycell >= 0) wnext = T[kSlabTable + mycell];
+    const bool all = !tame || T[kSlabCells] != 0u;              // wave-uniform
+    if (!all) {
+      const int beg = (int)(w & 0xffffu), len = (int)(w >> 16);
+      for (int j = slot; j < len; j += 2) {
+        const float4 p = R[beg + j];
+        if (pn2_sq3(qx - p.x, qy - p.y, qz - p.z) < r2) {
+          const int li = __float_as_int(p.w);
+          atomicOr((unsigned *)&mask[li >> 5], 1u << (li & 31));
+        }
+      }
+    } else {
+      const int len = N - sl * kSlab < kSlab ? N - sl * kSlab : kSlab;
+      for (int j = lane; j < len; j += 64) {
+        const float4 p = R[j];
+        if (pn2_sq3(qx - p.x, qy - p.y, qz - p.z) < r2) {
+          const int li = __float_as_int(p.w);
+          atomicOr((unsigned *)&mask[li >> 5], 1u << (li & 31));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // LDS operations of a wave retire in order
+    unsigned word = mask[lane];
+    const u64 some = __ballot(word != 0u);
+    if (some == 0ull) continue;
+    mask[lane] = 0u;
+    const int pc = __popc(word);
+    const int inc = slab_wave_scan(pc);
+    if (cnt == 0) {
+      const int fl = __builtin_ctzll(some);
+      first = sl * kSlab + fl * 32 + __builtin_ctz((unsigned)__builtin_amdgcn_readlane((int)word, fl));
+    }
+    int o = cnt + inc - pc;
+    const int at = sl * kSlab + lane * 32;
+    while (word != 0u && o < ns) {
+      row[o++] = at + __builtin_ctz(word);
+      word &= word - 1u;
+    }
+    cnt += __builtin_amdgcn_readlane(inc, 63);
+  }
+  // pad with the first hit (zero row for an empty ball): EXT/src/ball_query_gpu.cu:34-38
+  for (int s = (cnt < ns ? cnt : ns) + lane; s < ns; s += 64) row[s] = first;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Cell-list ("uniform grid") ball query.  The brute-force kernel above walks the cloud in index order and stops after
 // `nsample` hits, which is efficient when balls are crowded (a 0.2-ball in a 50k-point room holds ~400 points: the scan
 // ends after ~8k points).  It is hopeless when they are not: the scene-graph encoders query r = 0.1 / 0.2 balls in
@@ -379,38 +559,55 @@ extern "C" int pn2_ball_query(int B, int N, int m, float radius, int nsample,
   return pn2_check_launch();
 }
 
-// Workspace of the cell-list path: 0 = this shape runs the plain index-order scan (small clouds, huge nsample).
-// Which algorithm: the cell list pays when balls are SPARSE.  The host cannot see the coordinates, so it estimates the
-// hits per ball for a cloud that fills the unit ball (the 4D-OR clouds are normalised that way, zero_mean of
-// data_preparation_utils.py:12-18): E = N r^3.  Measured (tools/microbench.py): E = 8 and 64 with nsample 16 / 32 —
-// cell list 1.5-4x faster; E = 130 / nsample 32 and E = 400 / nsample 64 — the early-exit scan is faster.  Results are
-// identical either way.
-extern "C" size_t pn2_ball_query_workspace_bytes(int B, int N, int m, float radius, int nsample) {
-  if (B <= 0 || m <= 0 || N < 2048 || nsample <= 0 || nsample > kGridCap || !(radius > 0.f)) return 0;
-  if ((double)N * radius * radius * radius > 4.0 * nsample) return 0;
-  return pn2_ball_query_grid_bytes(B, N, nsample);
-}
+// Which algorithm.  The host cannot see the coordinates, so it estimates the hits per ball for a cloud that fills the
+// unit ball (the 4D-OR clouds are normalised that way, zero_mean of data_preparation_utils.py:12-18): E = N r^3.
+//   PN2_BQ_SCAN  : index-order scan with early exit — no workspace; small clouds, very crowded balls (short walks);
+//   PN2_BQ_CELLS : one cell list per cloud + rank sort — sparse balls, nsample <= 256 (round 2; by name only);
+//   PN2_BQ_SLABS : one cell list per 2048-index slab + bit-mask order — everything whose scan would walk >= 3072 points.
+// Results are identical whichever runs.  Measurements: DESIGN.md 4c.
+namespace {
+bool bq_radius_ok(float radius) { return radius > 0.f && radius < 3.0e38f; }
 
-// Raw requirement of the cell-list kernels (0: shape not covered — nsample beyond the collection cap); a caller that
-// passes this much workspace to pn2_ball_query_ws gets the cell list whatever the density estimate says.
-extern "C" size_t pn2_ball_query_grid_bytes(int B, int N, int nsample) {
+size_t bq_slab_bytes(int B, int N) {
+  const size_t nslab = ((size_t)N + kSlab - 1) / kSlab;
+  return (size_t)B * N * 16 + (size_t)B * nslab * kSlabTable * 4 + 256;
+}
+size_t bq_cells_bytes(int B, int N, int nsample) {
   if (B <= 0 || N <= 0 || nsample <= 0 || nsample > kGridCap) return 0;
   const size_t per_cloud = (size_t)kGridHdr * 4 + (size_t)(kGridMaxG * kGridMaxG * kGridMaxG + 1) * 4 + (size_t)N * 16;
   return (size_t)B * per_cloud + 256;
 }
 
-extern "C" int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
-                                 int *idx, void *workspace, size_t workspace_bytes, void *stream) {
-  if (B < 0 || N < 0 || m < 0 || nsample < 0) return PN2_EINVAL;
-  const size_t need = pn2_ball_query_grid_bytes(B, N, nsample);
-  // the cell edge is sized from the radius: a negative / non-finite radius (r*r is still a valid threshold for the
-  // scan) would make cells smaller than the ball and the 27-cell search miss hits — such calls take the scan
-  if (need == 0 || !workspace || workspace_bytes == 0 || m == 0 || !(radius > 0.f) || !(radius < 3.0e38f))
-    return pn2_ball_query(B, N, m, radius, nsample, new_xyz, xyz, idx, stream);
-  if (workspace_bytes < need) return PN2_ENOSPC;
-  if (!new_xyz || !idx || !xyz) return PN2_ENULL;
-  if (((uintptr_t)workspace & 15) != 0) return PN2_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
+// The scan walks L = N min(1, nsample / E) points per centre (E = N r^3: estimated hits per ball), the slab walk visits
+// ceil(L / 2048) slabs at a roughly constant price each: measured crossover L ~ 3000 (tools/bq_bench.py).
+// The per-cloud cell list is never the automatic choice any more (the slabs match or beat it on every measured shape but
+// one); it stays available by name.
+int bq_auto(int B, int N, int m, float radius, int nsample) {
+  if (B <= 0 || B > 65535 || m <= 0 || N < 2048 || nsample <= 0 || !bq_radius_ok(radius)) return PN2_BQ_SCAN;
+  const double E = (double)N * radius * radius * radius;
+  const double L = E > nsample ? (double)N * nsample / E : (double)N;
+  return L >= 3072.0 ? PN2_BQ_SLABS : PN2_BQ_SCAN;
+}
+
+int bq_run_slabs(int B, int N, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                 void *workspace, hipStream_t s) {
+  const int nslab = (N + kSlab - 1) / kSlab;
+  const long long centres = (long long)B * m;
+  const long long blocks = (centres + 3) / 4;
+  if (blocks > 0x7fffffffLL || B > 65535) return PN2_EINVAL;
+  // hit bound rq = r 1.0001, window rw = rq 1.0001, cell edge h = rw 1.0001 (see the kernel header)
+  const double rw = (double)radius * 1.0001 * 1.0001, inv_h = 1.0 / (rw * 1.0001);
+  float4 *recs = (float4 *)workspace;
+  unsigned *table = (unsigned *)((char *)workspace + (size_t)B * N * 16);
+  hipLaunchKernelGGL(bq_slab_build_kernel, dim3((unsigned)nslab, (unsigned)B), dim3(256), 0, s, N, nslab, inv_h, xyz, table,
+                     recs);
+  hipLaunchKernelGGL(bq_slab_query_kernel, dim3((unsigned)blocks), dim3(256), 0, s, N, m, nslab, radius * radius, nsample,
+                     inv_h, rw, new_xyz, table, recs, idx, centres);
+  return pn2_check_launch();
+}
+
+int bq_run_cells(int B, int N, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                 void *workspace, hipStream_t s) {
   // records first (16-byte aligned), then the cell starts, then the headers
   float4 *recs = (float4 *)workspace;
   int *starts = (int *)((char *)workspace + (size_t)B * N * 16);
@@ -424,6 +621,58 @@ extern "C" int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample,
   hipLaunchKernelGGL(bq_grid_query_kernel, dim3((unsigned)blocks), dim3(256), 0, s, N, m, r2, nsample, new_xyz, xyz, hdrs,
                      starts, recs, idx, centres);
   return pn2_check_launch();
+}
+}  // namespace
+
+// Workspace of a given algorithm for a shape; 0 = the algorithm does not cover the shape (or needs none: the scan).
+extern "C" size_t pn2_ball_query_algo_bytes(int algo, int B, int N, int m, float radius, int nsample) {
+  if (B <= 0 || N <= 0 || m <= 0 || nsample <= 0 || !bq_radius_ok(radius)) return 0;
+  if (algo == PN2_BQ_CELLS) return bq_cells_bytes(B, N, nsample);
+  if (algo == PN2_BQ_SLABS) return B <= 65535 ? bq_slab_bytes(B, N) : 0;
+  return 0;
+}
+
+// The algorithm the library would pick for the shape, and its workspace.
+extern "C" int pn2_ball_query_auto(int B, int N, int m, float radius, int nsample) {
+  return bq_auto(B, N, m, radius, nsample);
+}
+extern "C" size_t pn2_ball_query_workspace_bytes(int B, int N, int m, float radius, int nsample) {
+  return pn2_ball_query_algo_bytes(bq_auto(B, N, m, radius, nsample), B, N, m, radius, nsample);
+}
+
+// Raw requirement of the per-cloud cell list (kept from round 2: a caller that passes exactly this much workspace to
+// pn2_ball_query_ws gets the cell list whatever the density estimate says).
+extern "C" size_t pn2_ball_query_grid_bytes(int B, int N, int nsample) { return bq_cells_bytes(B, N, nsample); }
+
+// Explicit algorithm.  A shape the algorithm does not cover, a missing / short / misaligned workspace, or a radius the
+// cell edge cannot be sized from (non-positive, non-finite: r * r is still a valid threshold for the scan) -> the scan.
+extern "C" int pn2_ball_query_algo(int algo, int B, int N, int m, float radius, int nsample, const float *new_xyz,
+                                   const float *xyz, int *idx, void *workspace, size_t workspace_bytes, void *stream) {
+  if (B < 0 || N < 0 || m < 0 || nsample < 0) return PN2_EINVAL;
+  if (algo != PN2_BQ_SCAN && algo != PN2_BQ_CELLS && algo != PN2_BQ_SLABS) return PN2_EINVAL;
+  const size_t need = pn2_ball_query_algo_bytes(algo, B, N, m, radius, nsample);
+  if (need == 0 || !workspace || workspace_bytes < need || ((uintptr_t)workspace & 15) != 0)
+    return pn2_ball_query(B, N, m, radius, nsample, new_xyz, xyz, idx, stream);
+  if (!new_xyz || !idx || !xyz) return PN2_ENULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (algo == PN2_BQ_SLABS) return bq_run_slabs(B, N, m, radius, nsample, new_xyz, xyz, idx, workspace, s);
+  return bq_run_cells(B, N, m, radius, nsample, new_xyz, xyz, idx, workspace, s);
+}
+
+// Automatic choice with the workspace the caller has: the shape's own algorithm when the workspace holds it, else the
+// per-cloud cell list when it holds that (pn2_ball_query_grid_bytes), else the scan.
+extern "C" int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                                 int *idx, void *workspace, size_t workspace_bytes, void *stream) {
+  if (B < 0 || N < 0 || m < 0 || nsample < 0) return PN2_EINVAL;
+  int algo = bq_auto(B, N, m, radius, nsample);
+  size_t need = pn2_ball_query_algo_bytes(algo, B, N, m, radius, nsample);
+  if (algo == PN2_BQ_SCAN || need == 0 || workspace_bytes < need) {
+    algo = PN2_BQ_CELLS;
+    need = pn2_ball_query_algo_bytes(algo, B, N, m, radius, nsample);
+    if (need == 0 || workspace_bytes < need) algo = PN2_BQ_SCAN;
+  }
+  if (workspace && ((uintptr_t)workspace & 15) != 0) return PN2_EINVAL;
+  return pn2_ball_query_algo(algo, B, N, m, radius, nsample, new_xyz, xyz, idx, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

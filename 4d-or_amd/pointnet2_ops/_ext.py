@@ -52,6 +52,7 @@ _SIGNATURES = {
     "pn2_gather_points_grad": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_ball_query": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_ball_query_ws": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp],
+    "pn2_ball_query_algo": [_c_int, _c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp],
     "pn2_ball_query_unique_resample": [ctypes.c_longlong, _c_int, ctypes.c_uint, _c_vp, _c_vp, _c_vp],
     "pn2_group_points": [_c_int] * 5 + [_c_vp] * 4,
     "pn2_group_points_grad": [_c_int] * 5 + [_c_vp] * 4,
@@ -126,6 +127,10 @@ _lib.pn2_prep_num_chunks.argtypes = [_c_int]
 _lib.pn2_prep_num_chunks.restype = _c_int
 _lib.pn2_ball_query_grid_bytes.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_ball_query_grid_bytes.restype = _c_sz
+_lib.pn2_ball_query_algo_bytes.argtypes = [_c_int, _c_int, _c_int, _c_int, _c_f32, _c_int]
+_lib.pn2_ball_query_algo_bytes.restype = _c_sz
+_lib.pn2_ball_query_auto.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int]
+_lib.pn2_ball_query_auto.restype = _c_int
 _lib.pn2_fps_status_offset.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_status_offset.restype = ctypes.c_longlong
 _lib.pn2_fps_set_plan_override.argtypes = [_c_int] * 5
@@ -152,6 +157,7 @@ EXPECTED_ABI_VERSION = 3
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
+                                               "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_bwd_bf16_supported", "pn2_pool_bwd_supported",
@@ -278,6 +284,7 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None, label=None):
 #: let the library route sparse-ball queries (clouds >= 2048 points, estimated N r^3 <= 4 nsample) through the cell-list
 #: kernels (identical results; tests flip it to compare both implementations, or force the cell list with "force")
 BALL_QUERY_GRID = True
+BQ_SCAN, BQ_CELLS, BQ_SLABS = 0, 1, 2                  # include/pn2_hip.h: PN2_BQ_*
 PN2_FPS_FEW_CUS = 1
 PN2_FPS_FEWEST_CUS = 2
 _sched = threading.local()
@@ -366,15 +373,17 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.size(1)
     nsample = int(nsample)
     idx = torch.empty(B, m, nsample, dtype=torch.int32, device=new_xyz.device)  # kernel writes every slot
-    if BALL_QUERY_GRID == "force":
-        ws_bytes = int(_lib.pn2_ball_query_grid_bytes(B, N, nsample))
+    # BALL_QUERY_GRID: True = the library's choice per shape, False = scan, "force" / "cells" / "slabs" = that algorithm
+    # (tests and measurements; a shape the algorithm does not cover runs the scan)
+    if BALL_QUERY_GRID is True:
+        algo = int(_lib.pn2_ball_query_auto(B, N, m, float(radius), nsample))
     else:
-        ws_bytes = int(_lib.pn2_ball_query_workspace_bytes(B, N, m, float(radius), nsample)) if BALL_QUERY_GRID else 0
+        algo = {False: BQ_SCAN, "force": BQ_CELLS, "cells": BQ_CELLS, "slabs": BQ_SLABS}[BALL_QUERY_GRID]
+    ws_bytes = int(_lib.pn2_ball_query_algo_bytes(algo, B, N, m, float(radius), nsample))
     if ws_bytes:
-        # cell-list path (sparse balls): scratch for the binned cloud, no initialisation needed
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=new_xyz.device)
-        _call("pn2_ball_query_ws", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx), _ptr(ws),
-              ws_bytes, alg_bytes=B * (12 * N + 12 * m + 4 * m * nsample), label="pn2_ball_query")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=new_xyz.device)      # scratch, no initialisation needed
+        _call("pn2_ball_query_algo", new_xyz, algo, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx),
+              _ptr(ws), ws_bytes, alg_bytes=B * (12 * N + 12 * m + 4 * m * nsample), label="pn2_ball_query")
     else:
         _call("pn2_ball_query", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx),
               alg_bytes=B * (12 * N + 12 * m + 4 * m * nsample))

@@ -111,18 +111,30 @@ int pn2_ball_query(int B, int N, int m, float radius, int nsample,
                    const float *new_xyz, const float *xyz, int *idx,
                    void *stream);
 
-/* Cell-list variant of the same operator (identical results): the cloud is binned once into cells of edge >= radius and
- * a centre only tests the points of its 27 neighbouring cells; the hits are rank-sorted by index, which reproduces the
- * reference's "first nsample in ascending index + first-hit padding" exactly.  Pays when balls are sparse (the
- * scene-graph encoders: radius 0.1 / 0.2 in 4000 / 8000-point clouds, where the index-order scan never exits early).
- * Crowded balls (estimated N r^3 > 4 nsample, or N < 2048) are better served by the early-exit scan:
- * pn2_ball_query_workspace_bytes() == 0 means the shape is served by the plain scan (pn2_ball_query_ws then ignores the
- * workspace); otherwise `workspace` (16-byte aligned, no initialisation needed) must hold that many bytes.
+/* Accelerated variants of the same operator (identical results, bit for bit).  Three algorithms:
+ *   PN2_BQ_SCAN  — the index-order scan of pn2_ball_query (early exit after nsample hits); no workspace;
+ *   PN2_BQ_CELLS — per-cloud cell list (cells of edge >= radius, 27 neighbouring cells, hits rank-sorted by index): pays
+ *                  when balls are SPARSE (the scene-graph encoders: radius 0.1 / 0.2 in 4000 / 8000-point clouds, where
+ *                  the scan never exits early); nsample <= 256;
+ *   PN2_BQ_SLABS — one hash-grid cell list per slab of 2048 consecutive indices; hits set bits of a 2048-bit mask, which
+ *                  yields them in ascending index without a sort; the walk over the slabs stops after nsample hits: pays
+ *                  when balls are CROWDED (the SA levels of the backbone).
+ * pn2_ball_query_auto() is the library's choice for a shape (estimated hits per ball N r^3 against 4 nsample; small
+ * clouds scan), pn2_ball_query_workspace_bytes() the workspace of that choice (0: scan), pn2_ball_query_algo_bytes() the
+ * workspace of a given algorithm (0: shape not covered).  `workspace`: 16-byte aligned, no initialisation needed.
+ * pn2_ball_query_ws runs the automatic choice when the workspace holds it, else the per-cloud cell list when it holds
+ * pn2_ball_query_grid_bytes(), else the scan; pn2_ball_query_algo runs the named algorithm (scan when the shape or the
+ * workspace does not allow it, or when radius is not positive and finite).
  */
+enum { PN2_BQ_SCAN = 0, PN2_BQ_CELLS = 1, PN2_BQ_SLABS = 2 };
+int pn2_ball_query_auto(int B, int N, int m, float radius, int nsample);
 size_t pn2_ball_query_workspace_bytes(int B, int N, int m, float radius, int nsample);
-size_t pn2_ball_query_grid_bytes(int B, int N, int nsample);   /* raw requirement: forces the cell list */
+size_t pn2_ball_query_algo_bytes(int algo, int B, int N, int m, float radius, int nsample);
+size_t pn2_ball_query_grid_bytes(int B, int N, int nsample);   /* = algo_bytes(PN2_BQ_CELLS, ...) */
 int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                       int *idx, void *workspace, size_t workspace_bytes, void *stream);
+int pn2_ball_query_algo(int algo, int B, int N, int m, float radius, int nsample, const float *new_xyz,
+                        const float *xyz, int *idx, void *workspace, size_t workspace_bytes, void *stream);
 
 /* sample_uniformly / ret_unique_cnt of the Group-Free-3D QueryAndGroup
  *   (GF3D/pointnet2/pointnet2_utils.py:327-336: a host loop of torch.unique + torch.randint per region).

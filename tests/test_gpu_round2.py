@@ -444,7 +444,7 @@ def test_cell_list_ball_query_is_bit_exact(B, N, m, ns, r, kind):
     new_xyz = new_xyz.contiguous()
     want = oracle_ext.OracleRowsExt.ball_query(new_xyz, xyz, r, ns)
     results = {}
-    for mode in ("force", False, True):                 # cell list forced, index-order scan, the library's own choice
+    for mode in ("force", "slabs", False, True):        # cell list / slab cell lists forced, index-order scan, the library's choice
         _ext.BALL_QUERY_GRID = mode
         try:
             results[mode] = _ext.ball_query(new_xyz.cuda(), xyz.cuda(), r, ns).cpu()

@@ -206,3 +206,63 @@ def test_voxel_mode_scan_preparation_and_sample_cache(tmp_path):
     s2 = cache.cached(tmp_path, "4_000131", lambda: (_ for _ in ()).throw(AssertionError("cache miss")), device="cuda")
     for k in ("obj_points", "rel_points", "edge_indices", "relation_objects_one_hot", "gt_class", "gt_rels"):
         assert torch.equal(s1[k].cpu(), a[k].cpu()) and torch.equal(s2[k].cpu(), a[k].cpu()) and s2[k].is_cuda
+
+
+# ------------------------------------------------------------------------------------ ball query, slab cell lists
+def _bq_cloud(kind, B, N, rng):
+    import numpy as np
+    if kind == "grid":
+        side = int(round(N ** (1 / 3))) + 1
+        g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)[:N].astype(np.float32) * np.float32(0.1)
+        return np.stack([g[rng.permutation(N)] for _ in range(B)])
+    p = rng.normal(size=(B, N, 3))
+    xyz = (p / np.linalg.norm(p, axis=2, keepdims=True) * rng.random((B, N, 1)) ** (1 / 3)).astype(np.float32)
+    if kind == "dup":
+        xyz[:, N // 2:] = xyz[:, :N - N // 2]
+    if kind == "far":                                            # the cloud sits 300 cell widths from the origin, negative side
+        xyz += np.array([-90.0, 120.0, -60.0], dtype=np.float32)
+    if kind == "wide":                                           # extent >> 16 cells: hash cells alias
+        xyz *= np.float32(40.0)
+    if kind == "wild":                                           # coordinates the cell arithmetic gives up on + non-finite
+        xyz[:, 5] = np.float32(3e12)
+        xyz[:, 7] = np.float32(-1e30)
+        xyz[:, 11, 0] = np.nan
+        xyz[:, 2100 % N, 1] = np.inf
+    return xyz
+
+
+@pytest.mark.parametrize("B,N,m,r,ns,kind", [(2, 50000, 2048, 0.2, 64, "ball"), (3, 2048, 1024, 0.4, 32, "ball"),
+                                             (2, 5000, 130, 0.35, 16, "dup"), (1, 20000, 700, 0.3, 48, "grid"),
+                                             (2, 3000, 64, 0.5, 128, "ball"), (2, 4096, 100, 0.45, 7, "ball"),
+                                             (2, 6000, 300, 0.3, 32, "far"), (2, 9000, 257, 2.0, 24, "wide"),
+                                             (2, 4500, 200, 0.3, 20, "wild"), (1, 2049, 33, 2.5, 300, "ball"),
+                                             (2, 1500, 50, 0.1, 8, "ball"), (1, 70000, 512, 0.05, 16, "ball")])
+def test_slab_cell_list_ball_query_is_bit_exact(B, N, m, r, ns, kind):
+    """query_ball_point_kernel (EXT/src/ball_query_gpu.cu:9-44) through the slab cell lists (one hash grid per 2048
+    consecutive indices, hits as bits of a 2048-bit mask): the oracle's indices bit for bit — first nsample hits in
+    ascending index, first-hit padding, empty balls, duplicated points, points exactly on a lattice (d^2 == r^2 cases),
+    ragged m and N, a ball larger than the cloud with nsample > 256, sparse balls, clouds far from the origin, extents
+    beyond the 16-cell period, coordinates beyond the cell arithmetic, NaN / inf points and centres."""
+    import numpy as np
+    import oracle_ext
+    from pointnet2_ops import _ext
+    rng = np.random.default_rng(N + m)
+    xyz = torch.from_numpy(_bq_cloud(kind, B, N, rng))
+    centres = xyz[:, rng.permutation(N)[:m]].clone()
+    centres[:, -1] = 50.0 if kind != "wide" else 5000.0          # an empty ball
+    if kind == "wild":
+        centres[:, 0] = xyz[:, 5]                                # a centre beyond the cell arithmetic: hits its own point
+        centres[:, 1, 2] = float("nan")
+        centres[:, 2, 0] = float("inf")
+    assert _ext._lib.pn2_ball_query_algo_bytes(_ext.BQ_SLABS, B, N, m, r, ns) > 0
+    want = oracle_ext.OracleRowsExt.ball_query(centres, xyz, r, ns)
+    got = {}
+    prev = _ext.BALL_QUERY_GRID
+    try:
+        for mode in ("slabs", False, True):
+            _ext.BALL_QUERY_GRID = mode
+            got[mode] = _ext.ball_query(centres.cuda(), xyz.cuda(), r, ns).cpu()
+    finally:
+        _ext.BALL_QUERY_GRID = prev
+    for mode, g in got.items():
+        assert torch.equal(g, want), mode
