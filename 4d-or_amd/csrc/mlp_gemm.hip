@@ -17,6 +17,8 @@
 //     PRO_BNRELU  relu(x * p0[k] + p1[k])            = ReLU(BatchNorm(y_{l-1})) of the previous layer
 //     PRO_GY      p0[k]*g + p1[k]*y + p2[k]          = dL/dy_l from dL/dz_l (BatchNorm backward, see below)
 //     PRO_POOLG   same, with g gathered from the pooled gradient through the arg-max
+//     PRO_FIRST   relu((X0 W0^T) * p0[k] + p1[k])    = the stack's FIRST layer recomputed from its <= 8-column input rows
+//                                                      X0 [M][K0] (the grouped xyz / colour rows): y_0 is never stored
 //   epilogue:
 //     EPI_STATS   column sums of out and out^2 (fp64 atomics)  -> BatchNorm batch statistics
 //     EPI_MASK    out *= [BN(yprev) > 0]; column sums of out and out * yhat_prev
@@ -60,6 +62,9 @@ struct GemmArgs {
   float *pmax;       // [M/psz][N], psz = min(ns, 32): maximum of the (sign-adjusted) raw output over each partial row group
   int *parg;         // [M/psz][N] row of that maximum inside the partial group (first one among equals)
   const float *sgn;  // [N] +-1: sign the weight rows were multiplied with
+  // PRO_FIRST: X = X0 [M][K0] (input rows of the stack), W0 [K][K0] (first layer's weight), p0 / p1 = its BatchNorm scale / shift
+  const float *W0;
+  int K0;
 };
 
 constexpr int BM = 128;
@@ -92,11 +97,20 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   __shared__ float Ws[2][NTT * 32 * LD];
   __shared__ float red[2][NTT * 32];
   constexpr bool POOLE = EPI == EPI_POOL;
+  // PRO_FIRST: the A tile is COMPUTED while it is staged: a[row][k] = relu(bn_0(X0[row] . W0[k])), eight FMAs per element
+  // from the 128 x 8 input tile (LDS, two copies by tile parity) and W0's row k (LDS, [Kpad][8], zero padded).
+  // The input rows ride the register ring in place of the A registers, one STEP AHEAD of the weights: a tile's rows must
+  // be in LDS (and behind a barrier) before its first chunk is staged.
+  constexpr bool FIRST = PRO == PRO_FIRST;
+  constexpr int XW = 8;
+  constexpr int XPT = BM * XW / THREADS;       // input-tile elements per thread
+  constexpr int ARN = FIRST ? XPT : APT;       // A registers of a ring entry
+  __shared__ __attribute__((aligned(16))) float Xs[FIRST ? 2 * BM * XW : 4];
   // per-input-column prologue parameters (p0, p1, p2), staged once and ZERO beyond K: a padded
   // column then evaluates to relu(0*x + 0) = 0 (v_max_f32 drops a NaN operand) resp. 0*g + 0*y + 0,
   // so ragged K needs no masks.  (A global load inside the step loop would be the youngest entry of
   // the in-order vmcnt queue and waiting for it would drain the whole prefetch ring.)
-  extern __shared__ float prm[];               // [3][Kpad], Kpad = nchunks * KC
+  extern __shared__ __attribute__((aligned(16))) float prm[];   // [3][Kpad], Kpad = nchunks * KC (+ PRO_FIRST: W0 as [Kpad][8])
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -119,6 +133,22 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
       prm[Kpad + i] = in ? a.p1[i] : 0.f;
       if (TWO || POOL) prm[2 * Kpad + i] = in ? a.p2[i] : 0.f;
     }
+  }
+  float *w0s = prm + 3 * Kpad;
+  const int K0 = FIRST ? a.K0 : 0;
+  // PRO_FIRST: thread -> (row tid / 8 + (THREADS / 8) i, column tid % 8) of an input tile; columns past K0 read zeros
+  const int xoff = (FIRST && (tid % XW) < K0) ? ((tid / XW) * K0 + (tid % XW)) * 4 : kOobOffset;
+  const int xpass = (THREADS / XW) * K0 * 4;
+  if (FIRST) {
+    for (int i = tid; i < Kpad * XW; i += THREADS) {
+      const int k = i / XW, j = i % XW;
+      w0s[i] = (k < K && j < K0) ? a.W0[(size_t)k * K0 + j] : 0.f;
+    }
+    // input rows of the first tile (every later tile arrives through the ring)
+    const long long xm0 = (long long)blockIdx.x * BM;
+    const rsrc_t rsx = make_rsrc(a.X + (size_t)xm0 * K0, (M - xm0) * K0 * 4);
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) Xs[tid + THREADS * i] = bload(rsx, xoff, i * xpass);
   }
 
   f32x16 acc[NT];
@@ -144,8 +174,8 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   constexpr int PGR = POOL ? (((BM / 16 + 1) * KC + THREADS - 1) / THREADS) : 1;   // supports ns >= 16
   const long long ngroups = POOL ? (M + a.ns - 1) / a.ns : 0;
 
-  float ra0[APT], rb0[TWO ? APT : 1], rw0[WPT], pg0[PGR];
-  float ra1[APT], rb1[TWO ? APT : 1], rw1[WPT], pg1[PGR];
+  float ra0[ARN], rb0[TWO ? APT : 1], rw0[WPT], pg0[PGR];
+  float ra1[ARN], rb1[TWO ? APT : 1], rw1[WPT], pg1[PGR];
   int pa0[PGR], pa1[PGR];
 
   // (tile, chunk) cursors: L = next step to LOAD, S = next step to STORE to LDS, C = step computed.
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   long long l_tile = blockIdx.x, s_tile = blockIdx.x, c_tile = blockIdx.x;
   int l_chunk = 0, s_chunk = 0, c_chunk = 0;
 
-  auto load_step = [&](float (&ra)[APT], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int (&pa)[PGR],
+  auto load_step = [&](float (&ra)[ARN], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int (&pa)[PGR],
                        float (&pg)[PGR]) {
     const long long m0 = l_tile * BM;
     const long long left = (M - m0) * K * 4;                // bytes from the tile's first row to the end
@@ -171,7 +201,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
         pa[e] = bload_i(rsa, aoff, soff + e * apass);
         pg[e] = bload(rsg, aoff, soff + e * apass);
       }
-    } else {
+    } else if (!FIRST) {
       const rsrc_t rs = make_rsrc(a.X + (size_t)m0 * K, left);
 #pragma unroll
       for (int i = 0; i < APT; ++i) ra[i] = bload(rs, aoff, soff + i * apass);
@@ -188,6 +218,13 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
     l_chunk = wrap ? 0 : l_chunk;
     const long long nt = l_tile + (wrap ? (long long)gridDim.x : 0ll);
     l_tile = nt < ntiles ? nt : last_tile;
+    if (FIRST) {
+      // input rows of the tile of the NEXT step (the cursor has just moved there)
+      const long long xm0 = l_tile * BM;
+      const rsrc_t rsx = make_rsrc(a.X + (size_t)xm0 * K0, (M - xm0) * K0 * 4);
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) ra[FIRST ? i : 0] = bload(rsx, xoff, i * xpass);
+    }
   };
 
   // prologue transform + LDS write of the OLDEST loaded step.  No masks: rows past M and weight
@@ -196,7 +233,8 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   // prologue non-zero; the epilogue clears their accumulators before the statistics.
   long long p_tile = blockIdx.x;   // cursor of the step whose sparse patch is pending (PRO_POOLG)
   int p_chunk = 0;
-  auto store_step = [&](float (&ra)[APT], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int buf) {
+  int s_par = 0;                   // PRO_FIRST: parity of the tile the store cursor is in (selects the input-tile copy)
+  auto store_step = [&](float (&ra)[ARN], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int buf) {
     p_tile = s_tile;
     p_chunk = s_chunk;
     const int k = s_chunk * KC + kk;
@@ -208,9 +246,27 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
     }
     const bool kin = k < K;
     float *Ad = &As[buf][r0 * LD + kk];
+    float4 wa = {0.f, 0.f, 0.f, 0.f}, wb = wa;
+    const float *xt = Xs + s_par * (BM * XW) + r0 * XW;
+    if (FIRST) {
+      const float4 *wq = reinterpret_cast<const float4 *>(w0s + k * XW);
+      wa = wq[0]; wb = wq[1];
+    }
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
-      float v = ra[i];
+      float v = 0.f;
+      if (FIRST) {
+        // y_0[row][k] as the MFMA would accumulate it: one FMA chain over the input columns, ascending
+        const float4 *xr = reinterpret_cast<const float4 *>(xt + RSTEP * i * XW);
+        const float4 xa = xr[0], xb = xr[1];
+        v = __fmul_rn(xa.x, wa.x);
+        v = __fmaf_rn(xa.y, wa.y, v); v = __fmaf_rn(xa.z, wa.z, v); v = __fmaf_rn(xa.w, wa.w, v);
+        v = __fmaf_rn(xb.x, wb.x, v); v = __fmaf_rn(xb.y, wb.y, v); v = __fmaf_rn(xb.z, wb.z, v);
+        v = __fmaf_rn(xb.w, wb.w, v);
+        v = fmaxf(__fmaf_rn(v, q0, q1), 0.f);
+      } else {
+        v = ra[FIRST ? 0 : i];
+      }
       if (PRO == PRO_NONE) v = kin ? v : 0.f;
       if (PRO == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, q0, q1), 0.f);
       if (TWO) v = __fmaf_rn(q0, v, __fmaf_rn(q1, rb[TWO ? i : 0], q2));
@@ -225,6 +281,12 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
     s_chunk = wrap ? 0 : s_chunk;
     const long long nt = s_tile + (wrap ? (long long)gridDim.x : 0ll);
     s_tile = nt < ntiles ? nt : last_tile;
+    if (FIRST) {
+      // input rows of the next step's tile -> their copy (the same tile: the same values over themselves)
+      s_par ^= wrap ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) Xs[s_par * (BM * XW) + tid + THREADS * i] = ra[FIRST ? i : 0];
+    }
   };
 
   // sparse arg-max patch of the step stored last (runs between two barriers)
@@ -284,8 +346,8 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
 
   // one pipeline iteration: compute the current step from LDS buffer `buf`; (la, lb, lw) receive
   // the loads of two steps ahead, (sa, sb, sw) hold the next step and are written to buffer buf^1
-  auto iteration = [&](int buf, float (&la)[APT], float (&lb)[TWO ? APT : 1], float (&lw)[WPT], int (&lpa)[PGR],
-                       float (&lpg)[PGR], float (&sa)[APT], float (&sb)[TWO ? APT : 1], float (&sw)[WPT],
+  auto iteration = [&](int buf, float (&la)[ARN], float (&lb)[TWO ? APT : 1], float (&lw)[WPT], int (&lpa)[PGR],
+                       float (&lpg)[PGR], float (&sa)[ARN], float (&sb)[TWO ? APT : 1], float (&sw)[WPT],
                        int (&spa)[PGR], float (&spg)[PGR]) {
     const bool last_chunk = c_chunk == nchunks - 1;
     const long long m0 = c_tile * BM;
@@ -938,7 +1000,7 @@ void launch_one(const GemmArgs &a, hipStream_t s, int grid_override = 0) {
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   dim3 grid((unsigned)gx, ny);
-  const size_t prm_bytes = PRO == PRO_NONE ? 0 : 3 * (size_t)((a.K + KC - 1) / KC * KC) * sizeof(float);
+  const size_t prm_bytes = PRO == PRO_NONE ? 0 : (PRO == PRO_FIRST ? 11 : 3) * (size_t)((a.K + KC - 1) / KC * KC) * sizeof(float);
   hipLaunchKernelGGL((mlp_gemm_kernel<NT, KC, CW, PRO, EPI>), grid, dim3(256 * CW), prm_bytes, s, a);
 }
 
@@ -1011,6 +1073,65 @@ extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const f
   else if (pro == PRO_GY && epi == EPI_NONE) launch_by_width<PRO_GY, EPI_NONE>(a, tiles, s);
   else if (pro == PRO_POOLG && epi == EPI_NONE) launch_by_width<PRO_POOLG, EPI_NONE>(a, tiles, s);
   else return PN2_EINVAL;
+  return pn2_check_launch();
+}
+
+namespace {
+// Batch statistics of the first layer from the Gram matrix of its input: y_0 = X0 W0^T is linear in X0, so
+//   sum_r y_0[r][n] = W0[n] . (1^T X0),   sum_r y_0[r][n]^2 = W0[n] (X0^T X0) W0[n]^T   (fp64; gram as rows_gram_kernel
+// writes it: [K0 * K0] upper triangle mirrored + [K0] column sums)
+__global__ void first_layer_stats_kernel(int N, int K0, const float *__restrict__ W0, const double *__restrict__ gram,
+                                         double *__restrict__ stats) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < K0; ++i) {
+    const double wi = (double)W0[n * K0 + i];
+    s1 += wi * gram[K0 * K0 + i];
+    double t = 0.0;
+    for (int j = 0; j < K0; ++j) t += gram[i * K0 + j] * (double)W0[n * K0 + j];
+    s2 += wi * t;
+  }
+  stats[n] = s1;
+  stats[N + n] = s2 > 0.0 ? s2 : 0.0;
+}
+}  // namespace
+
+extern "C" int pn2_first_layer_stats(int N, int K0, const float *W0, const double *gram, double *stats, void *stream) {
+  if (N <= 0 || K0 < 1 || K0 > 8) return PN2_EINVAL;
+  if (!W0 || !gram || !stats) return PN2_ENULL;
+  hipLaunchKernelGGL(first_layer_stats_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, N, K0, W0,
+                     gram, stats);
+  return pn2_check_launch();
+}
+
+// Second layer of a stack whose first layer is recomputed on the fly (PRO_FIRST): Y = relu(bn_0(X0 W0^T)) W^T.
+extern "C" int pn2_mlp_gemm_first_supported(int K0, int K, int N) {
+  return K0 >= 1 && K0 <= 8 && K >= 1 && K <= 128 && N >= 1 && N <= 128;
+}
+
+extern "C" int pn2_mlp_gemm_first(long long M, int K0, int K, int N, int epi, const float *X0, const float *W0,
+                                  const float *scale0, const float *shift0, const float *W, float *Y, double *stats,
+                                  void *stream) {
+  if (M < 0 || !pn2_mlp_gemm_first_supported(K0, K, N) || (epi != EPI_NONE && epi != EPI_STATS)) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!X0 || !W0 || !scale0 || !shift0 || !W || !Y) return PN2_ENULL;
+  if (epi == EPI_STATS && !stats) return PN2_ENULL;
+  if ((M + BM - 1) / BM > 0x7fffffffLL) return PN2_EINVAL;
+  GemmArgs a = {};
+  a.X = X0; a.W0 = W0; a.K0 = K0; a.p0 = scale0; a.p1 = shift0; a.W = W; a.Y = Y; a.stats = stats;
+  a.M = M; a.K = K; a.N = N; a.pro = PRO_FIRST; a.epi = epi;
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = (N + 31) / 32;
+  if (epi == EPI_STATS) {
+    if (tiles <= 1) launch_one<1, 32, 1, PRO_FIRST, EPI_STATS>(a, s);
+    else if (tiles <= 2) launch_one<2, 32, 1, PRO_FIRST, EPI_STATS>(a, s, 512);
+    else launch_one<2, 16, 2, PRO_FIRST, EPI_STATS>(a, s, 768);
+  } else {
+    if (tiles <= 1) launch_one<1, 32, 1, PRO_FIRST, EPI_NONE>(a, s);
+    else if (tiles <= 2) launch_one<2, 32, 1, PRO_FIRST, EPI_NONE>(a, s, 512);
+    else launch_one<2, 16, 2, PRO_FIRST, EPI_NONE>(a, s, 768);
+  }
   return pn2_check_launch();
 }
 

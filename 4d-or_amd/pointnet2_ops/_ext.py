@@ -91,6 +91,10 @@ _SIGNATURES = {
     "pn2_mlp_bwd_fused_fold": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 +
                               [_c_int] + [_c_vp] * 4,
     "pn2_rows_gram": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp],
+    "pn2_first_layer_stats": [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_mlp_gemm_first": [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 8,
+    "pn2_mlp_bwd_fused_fold_first": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 +
+                                    [_c_int] + [_c_vp] * 4,
     "pn2_mlp_gemm_bf16": [ctypes.c_longlong] + [_c_int] * 8 + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
     "pn2_mlp_wgrad_bf16": [ctypes.c_longlong] + [_c_int] * 6 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
@@ -141,6 +145,8 @@ _lib.pn2_mlp_bwd_bf16_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_bf16_supported.restype = _c_int
 _lib.pn2_mlp_bwd_fused_fold_supported.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_fold_supported.restype = _c_int
+_lib.pn2_mlp_gemm_first_supported.argtypes = [_c_int, _c_int, _c_int]
+_lib.pn2_mlp_gemm_first_supported.restype = _c_int
 _lib.pn2_pool_bwd_supported.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_pool_bwd_supported.restype = _c_int
 _lib.pn2_pool_bwd_workspace_bytes.argtypes = [ctypes.c_longlong, _c_int, _c_int]
@@ -160,6 +166,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
+                                               "pn2_mlp_gemm_first_supported",
                                                "pn2_mlp_bwd_bf16_supported", "pn2_pool_bwd_supported",
                                                "pn2_pool_bwd_workspace_bytes",
                                                "pn2_last_hip_error", "pn2_strerror"])
@@ -834,6 +841,49 @@ def mlp_bwd_fused_fold(Yl, consts, W, Yprev, a_fin, X, gmode, G=None, arg=None, 
           int(ns), _ptr(W), _ptr(Yprev), _ptr(a_fin), _ptr(X), K0, _ptr(sums), _ptr(dW), _ptr(P1),
           alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + M * K + M * K0 + N * K), alg_flops=4 * M * N * K,
           tag=(f"M{M},N{N},K{K},g{int(gmode)},fold{K0}" if DETAIL_TAGS else None))
+    return sums, dW, P1
+
+
+def mlp_gemm_first_supported(K0, K, N):
+    return bool(_lib.pn2_mlp_gemm_first_supported(int(K0), int(K), int(N)))
+
+
+def first_layer_stats(W0, gram, stats):
+    """stats (2,N0) f64 = column sums of y_0 = X W0^T and of y_0^2, from gram = rows_gram(X) (no pass over y_0)."""
+    N0, K0 = W0.shape
+    _call("pn2_first_layer_stats", W0, N0, K0, _ptr(W0), _ptr(gram), _ptr(stats))
+    return stats
+
+
+def mlp_gemm_first(X0, W0, fin0, W, epi=EPI_NONE, stats=None):
+    """Y (M,N) = relu(bn_0(X0 W0^T)) W^T: the second layer of a stack with the first one recomputed from its input rows
+    X0 (M,K0 <= 8) — y_0 is never written (csrc/mlp_gemm.hip PRO_FIRST).  fin0 (4,N0) of pn2_bn_finalize."""
+    _f32(X0, "X0"); _f32(W0, "W0"); _f32(W, "W"); _f32(fin0, "fin0")
+    M, K0 = X0.shape
+    N, K = W.shape
+    if tuple(W0.shape) != (K, K0) or tuple(fin0.shape) != (4, K):
+        raise RuntimeError("mlp_gemm_first: W0 (K,K0), fin0 (4,K), W (N,K) expected")
+    Y = torch.empty(M, N, dtype=torch.float32, device=W.device)
+    _call("pn2_mlp_gemm_first", W, M, K0, K, N, int(epi), _ptr(X0), _ptr(W0), _ptr(fin0[2]), _ptr(fin0[3]), _ptr(W), _ptr(Y),
+          _ptr(stats), alg_bytes=4 * (M * K0 + M * N + N * K), alg_flops=2 * M * N * K + 2 * M * K * K0,
+          tag=(f"M{M},K0{K0},K{K},N{N},epi{int(epi)}" if DETAIL_TAGS else None))
+    return Y
+
+
+def mlp_bwd_fused_fold_first(Yl, consts, W, W0, a_fin, X, gmode, G=None, arg=None, gP=None, ns=0, sums=None, dW=None, P1=None):
+    """mlp_bwd_fused_fold when the forward was mlp_gemm_first: y_{l-1} is recomputed from X and W0 (K,K0)."""
+    M, N = Yl.shape
+    K, K0 = W0.shape
+    if sums is None:
+        sums = torch.zeros(2, K, dtype=torch.float64, device=Yl.device)
+    if dW is None:
+        dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
+    if P1 is None:
+        P1 = torch.zeros(K, K0, dtype=torch.float32, device=Yl.device)
+    _call("pn2_mlp_bwd_fused_fold_first", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP),
+          int(ns), _ptr(W), _ptr(W0), _ptr(a_fin), _ptr(X), K0, _ptr(sums), _ptr(dW), _ptr(P1),
+          alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + M * K0 + N * K), alg_flops=4 * M * N * K + 2 * M * K * K0,
+          tag=(f"M{M},N{N},K{K},g{int(gmode)},first{K0}" if DETAIL_TAGS else None))
     return sums, dW, P1
 
 

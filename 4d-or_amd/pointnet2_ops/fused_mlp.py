@@ -39,6 +39,13 @@ import os as _os
 if _os.environ.get("PN2_POOL_FUSED") == "0":
     POOL_FUSED = False
 
+#: a first layer with <= 8 input columns (grouped xyz / colour rows) never materialises its output either: its batch
+#: statistics come from the 8 x 8 Gram matrix of the rows, the second layer recomputes it while staging its A tiles
+#: (pn2_mlp_gemm_first) and so does the backward (pn2_mlp_bwd_fused_fold_first)
+FIRST_FREE = True
+if _os.environ.get("PN2_FIRST_FREE") == "0":
+    FIRST_FREE = False
+
 #: arithmetic of the shared-MLP stacks.  float32 = exact fp32 MFMA (the parity path, default).  bfloat16 = the MI355X
 #: counterpart of the reference's 16-bit AMP training (scene_graph_prediction/main.py:64 `precision=16`): activations
 #: between the layers stored as bf16, bf16 MFMA with fp32 accumulation, fp32 weights / BatchNorm statistics / weight
@@ -145,6 +152,20 @@ class _FusedMLP(Function):
         pool_fused = bool(POOL_FUSED and want and ns and L >= 2 and M % ns == 0 and getattr(e, "pool_layer_supported", None)
                           and e.pool_layer_supported(Kl, Nl, ns) and (not needs_grad or e.pool_bwd_supported(Nl, Kl, ns)))
         pooled_parts = None
+        # first layer without its output tensor: when gradients are needed, only if the backward will take the fold path
+        K0 = x.size(1)
+        bn0 = layers[0][1]
+        need_dgrad0 = ctx.needs_input_grad[0] and (group is None or ctx.feat_shape is not None)
+        first_free = bool(
+            FIRST_FREE and L >= 2 and K0 <= 8 and not (pool_fused and L == 2) and getattr(e, "mlp_gemm_first", None)
+            and e.mlp_gemm_first_supported(K0, layers[0][0].out_channels, layers[1][0].out_channels)
+            and (not needs_grad or ((bn0.training or bn0.running_mean is None) and FUSED_BACKWARD and not need_dgrad0
+                                    and e.mlp_bwd_fused_fold_supported(layers[1][0].out_channels,
+                                                                       layers[0][0].out_channels, K0))))
+        gram = W0c = None
+        if first_free:
+            gram = e.rows_gram(x, e.zero_arena(x.device, [((K0 * K0 + K0,), torch.float64)])[0])
+            W0c = params[0].view(layers[0][0].out_channels, K0).contiguous()
         for l, (conv, bn) in enumerate(layers):
             W = params[3 * l].view(conv.out_channels, conv.in_channels)
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
@@ -156,7 +177,13 @@ class _FusedMLP(Function):
                 pooled_parts = e.mlp_gemm_pool(cur, Wf, sgn, ns, p=p, stats=stat_bufs[l]) + (sgn,)
             if use_batch:
                 stats = stat_bufs[l]
-                y = None if pooled_parts is not None else e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
+                if first_free and l == 0:
+                    y = None
+                    e.first_layer_stats(W.contiguous(), gram, stats)
+                elif first_free and l == 1:
+                    y = e.mlp_gemm_first(x, W0c, fins[0], W.contiguous(), epi=e.EPI_STATS, stats=stats)
+                else:
+                    y = None if pooled_parts is not None else e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
                 momentum = 0.0
                 rm = rv = nbt = None
                 if (bn.training and bn.track_running_stats and bn.running_mean is not None
@@ -171,7 +198,12 @@ class _FusedMLP(Function):
                 fo = getattr(ctx, "fin_out", None)          # segmented call: this scan's block of the layer's (S,4,C) buffer
                 fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt, out=None if fo is None else fo[l])
             else:
-                y = None if pooled_parts is not None else e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
+                if first_free and l == 0:
+                    y = None
+                elif first_free and l == 1:
+                    y = e.mlp_gemm_first(x, W0c, fins[0], W.contiguous(), epi=e.EPI_NONE)
+                else:
+                    y = None if pooled_parts is not None else e.mlp_gemm(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
                 rstd = torch.rsqrt(bn.running_var + bn.eps)
                 scale = gamma * rstd
                 fin = torch.stack([bn.running_mean, rstd, scale, beta - bn.running_mean * scale]).contiguous()
@@ -188,11 +220,15 @@ class _FusedMLP(Function):
             out, arg = e.bn_relu_apply(ys[-1], fins[-1]), None
         ctx.ns, ctx.L, ctx.batch_flags = ns, L, batch_flags
         ctx.pool_fused = pooled_parts is not None
+        ctx.first_free = first_free
         ctx.shapes = [params[3 * l].shape for l in range(L)]
         saved = [x] + ys + fins + [params[3 * l] for l in range(L)] + [params[3 * l + 1] for l in range(L)]
         if ns:
             saved += [out, arg, yraw]
             ctx.mark_non_differentiable(arg)
+        # (a piece of the shared zero slab: its version counter moves with every in-place op on a sibling piece, so it
+        # travels as an attribute like the geometry tensors, not through save_for_backward)
+        ctx.gram = gram
         ctx.save_for_backward(*saved)
         return (out, arg) if ns else out
 
@@ -218,6 +254,9 @@ class _FusedMLP(Function):
         fold = (L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0]
                 and not (ctx.pool_fused and L == 2)          # (layer 1 is then the pooled layer: Gram-form kernel)
                 and e.mlp_bwd_fused_fold_supported(Ws[1].size(0), Ws[1].size(1), K0))
+        first_free = getattr(ctx, "first_free", False)
+        if first_free and not fold:
+            raise RuntimeError("fused_mlp: the first layer's output was not stored but the backward cannot fold it")
         arena = e.zero_arena(x.device, [((2, Ws[-1].size(0)), f64)] + [((2, Ws[l].size(1)), f64) for l in range(L)] +
                              [(tuple(Ws[l].shape), f32) for l in range(L)] +
                              ([((Ws[0].size(0), K0), f32), ((K0 * K0 + K0,), f64)] if fold else []))
@@ -255,12 +294,18 @@ class _FusedMLP(Function):
                 consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l == 1 and fold:
-                sums, dW, P1 = e.mlp_bwd_fused_fold(ys[1], consts, Ws[1].contiguous(), ys[0], fins[0], x, gmode, G=G, arg=arg,
-                                                    gP=gPm, ns=ns, sums=sums_in[1], dW=dWs[1], P1=arena[1 + 2 * L])
+                if first_free:
+                    sums, dW, P1 = e.mlp_bwd_fused_fold_first(ys[1], consts, Ws[1].contiguous(), Ws[0].contiguous(), fins[0], x,
+                                                              gmode, G=G, arg=arg, gP=gPm, ns=ns, sums=sums_in[1], dW=dWs[1],
+                                                              P1=arena[1 + 2 * L])
+                else:
+                    sums, dW, P1 = e.mlp_bwd_fused_fold(ys[1], consts, Ws[1].contiguous(), ys[0], fins[0], x, gmode, G=G,
+                                                        arg=arg, gP=gPm, ns=ns, sums=sums_in[1], dW=dWs[1],
+                                                        P1=arena[1 + 2 * L])
                 grads[3] = dW.view(ctx.shapes[1])
                 continue
             if l == 0 and fold:
-                gram = e.rows_gram(x, arena[2 + 2 * L])
+                gram = ctx.gram if first_free else e.rows_gram(x, arena[2 + 2 * L])
                 grads[0] = e.first_layer_dw(consts, P1, Ws[0].contiguous(), gram).view(ctx.shapes[0])
                 continue
             if l > 0 and FUSED_BACKWARD and e.mlp_bwd_fused_supported(Ws[l].size(0), Ws[l].size(1)):
@@ -581,7 +626,8 @@ class _SegmentedGroupMLP(Function):
         subs, outs, args, c0 = [], [], [], 0
         for s, n_clouds in enumerate(sizes):
             c1 = c0 + n_clouds
-            sub = _SegCtx((ctx.needs_input_grad[0],))
+            # (x, ns, layers, group, *params) of the inner node <- (x, ns, layers, group, sizes, inner, *params) here
+            sub = _SegCtx(tuple(ctx.needs_input_grad[:4]) + tuple(ctx.needs_input_grad[6:]))
             sub.x_rows = rows_all[c0:c1].view(-1, rows_all.size(-1))
             sub.fin_out = [None if F is None else F[s] for F in fin_bufs]
             g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius, None, group[7] if len(group) > 7 else None)

@@ -281,6 +281,25 @@ int pn2_mlp_bwd_fused_fold(long long M, int N, int K, int gmode, const float *G,
 int pn2_rows_gram(long long M, int K0, const float *X, double *gram, void *stream);
 int pn2_first_layer_dw(int N, int K0, const float *consts, const float *P1, const float *W0,
                        const double *gram, float *dW0, void *stream);
+
+/* The first layer of a stack WITHOUT its output tensor (round 3).  y_0 = X0 W0^T has K0 <= 8 input columns (the grouped
+ * relative xyz + colours of OPS/pointnet2_utils.py:317-328): writing it and reading it back twice costs 3 x 4 M N0 bytes,
+ * recomputing an element costs 8 FMAs.
+ *   pn2_first_layer_stats : stats[2][N0] (fp64, overwritten) = column sums of y_0 and y_0^2 from gram = pn2_rows_gram(X0)
+ *                           (y_0 is linear in X0: W0 (1^T X0) and W0 (X0^T X0) W0^T) -> pn2_bn_finalize as usual;
+ *   pn2_mlp_gemm_first    : Y[M][N] = relu(X0 W0^T * scale0 + shift0) W^T, epi = 0 (none) | 1 (column sums for the
+ *                           batch statistics of Y); K (= N0) and N <= 128;
+ *   pn2_mlp_bwd_fused_fold_first : pn2_mlp_bwd_fused_fold with y_{l-1} recomputed from X and W0 [K][K0] (ReLU mask,
+ *                           BatchNorm-backward sums and the wgrad operand); same outputs. */
+int pn2_first_layer_stats(int N0, int K0, const float *W0, const double *gram, double *stats, void *stream);
+int pn2_mlp_gemm_first_supported(int K0, int K, int N);
+int pn2_mlp_gemm_first(long long M, int K0, int K, int N, int epi, const float *X0, const float *W0,
+                       const float *scale0, const float *shift0, const float *W, float *Y, double *stats,
+                       void *stream);
+int pn2_mlp_bwd_fused_fold_first(long long M, int N, int K, int gmode, const float *G, const float *Yl,
+                                 const float *consts, const int *arg, const float *gP, int ns, const float *W,
+                                 const float *W0, const float *a_fin, const float *X, int K0, double *sums,
+                                 float *dW, float *P1, void *stream);
 int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, const float *G,
                   const float *Yl, const float *consts, const int *arg, const float *gP, int ns,
                   const float *X, const float *a_fin, float *dW, void *stream);

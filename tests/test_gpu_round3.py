@@ -266,3 +266,63 @@ def test_slab_cell_list_ball_query_is_bit_exact(B, N, m, r, ns, kind):
         _ext.BALL_QUERY_GRID = prev
     for mode, g in got.items():
         assert torch.equal(g, want), mode
+
+
+# ------------------------------------------------------------------------------------ first layer without its output
+@pytest.mark.parametrize("M,K0,N0,N1", [(128 * 37 + 5, 6, 64, 64), (999, 3, 48, 40), (64 * 300, 8, 64, 128),
+                                        (70, 1, 33, 64), (128 * 600, 6, 64, 64), (4096, 7, 96, 128), (513, 6, 32, 32)])
+def test_second_layer_gemm_recomputing_the_first_matches_the_two_gemms(M, K0, N0, N1):
+    """pn2_mlp_gemm_first (A tiles computed from the <= 8-column input rows) == pn2_mlp_gemm(PRO_BNRELU) on the stored
+    first-layer output; pn2_first_layer_stats (from the Gram matrix of the rows) == the GEMM's column sums."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(M + N1)
+    X0 = (torch.randn(M, K0, generator=g) + 0.3).cuda()
+    W0 = (torch.randn(N0, K0, generator=g) * 0.5).cuda()
+    W1 = (torch.randn(N1, N0, generator=g) * 0.2).cuda()
+    gamma = (torch.rand(N0, generator=g) + 0.5).cuda()
+    gamma[::5] *= -1
+    beta = (torch.randn(N0, generator=g) * 0.2).cuda()
+    st0 = torch.zeros(2, N0, dtype=torch.float64, device="cuda")
+    y0 = e.mlp_gemm(X0, W0, pro=e.PRO_NONE, epi=e.EPI_STATS, stats=st0)
+    st0g = e.first_layer_stats(W0, e.rows_gram(X0), torch.empty_like(st0))
+    torch.testing.assert_close(st0g, st0, rtol=2e-6, atol=1e-6 * M)
+    fin0 = e.bn_finalize(st0, M, gamma, beta, 1e-5, 0.0, None, None)
+    st_ref = torch.zeros(2, N1, dtype=torch.float64, device="cuda")
+    st_new = torch.zeros_like(st_ref)
+    ref = e.mlp_gemm(y0, W1, pro=e.PRO_BNRELU, epi=e.EPI_STATS, p=(fin0[2], fin0[3]), stats=st_ref)
+    got = e.mlp_gemm_first(X0, W0, fin0, W1, epi=e.EPI_STATS, stats=st_new)
+    # the recomputation runs the MFMA's FMA chain over the input columns: identical activations, identical products
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    torch.testing.assert_close(st_new, st_ref, rtol=1e-6, atol=1e-6)
+    got2 = e.mlp_gemm_first(X0, W0, fin0, W1, epi=e.EPI_NONE)
+    assert torch.equal(got2, ref)
+
+
+@pytest.mark.parametrize("M,K0,N0,N1,ns", [(64 * 37, 6, 64, 64, 0), (1000, 3, 48, 40, 0), (64 * 4096 + 192, 6, 64, 64, 64),
+                                           (16 * 61, 8, 64, 64, 16), (130, 1, 33, 64, 0)])
+def test_fold_backward_recomputing_the_first_layer_matches_the_stored_one(M, K0, N0, N1, ns):
+    """pn2_mlp_bwd_fused_fold_first == pn2_mlp_bwd_fused_fold on the stored y_0: BatchNorm-backward sums, dW_1 and
+    P1 = gz^T X (reductions: atomics order only), dense and pooled gradient modes."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(M + N1 + ns)
+    X0 = (torch.randn(M, K0, generator=g) + 0.3).cuda()
+    W0 = (torch.randn(N0, K0, generator=g) * 0.5).cuda()
+    W1 = (torch.randn(N1, N0, generator=g) * 0.2).cuda()
+    gamma = (torch.rand(N0, generator=g) + 0.5).cuda()
+    beta = (torch.randn(N0, generator=g) * 0.2).cuda()
+    st0 = torch.zeros(2, N0, dtype=torch.float64, device="cuda")
+    y0 = e.mlp_gemm(X0, W0, pro=e.PRO_NONE, epi=e.EPI_STATS, stats=st0)
+    fin0 = e.bn_finalize(st0, M, gamma, beta, 1e-5, 0.0, None, None)
+    y1 = e.mlp_gemm(y0, W1, pro=e.PRO_BNRELU, epi=e.EPI_NONE, p=(fin0[2], fin0[3]))
+    consts = (torch.randn(3, N1, generator=g) * 0.3).cuda().contiguous()
+    if ns:
+        gmode, G = e.PRO_POOLG, None
+        arg = torch.randint(0, ns, (M // ns, N1), generator=g, dtype=torch.int32).cuda()
+        gP = torch.randn(M // ns, N1, generator=g).cuda()
+    else:
+        gmode, G, arg, gP = e.PRO_GY, torch.randn(M, N1, generator=g).cuda(), None, None
+    a = e.mlp_bwd_fused_fold(y1, consts, W1, y0, fin0, X0, gmode, G=G, arg=arg, gP=gP, ns=ns)
+    b = e.mlp_bwd_fused_fold_first(y1, consts, W1, W0, fin0, X0, gmode, G=G, arg=arg, gP=gP, ns=ns)
+    for u, v, name in zip(a, b, ("sums", "dW", "P1")):
+        scale = float(u.abs().max()) + 1e-12
+        assert float((u - v).abs().max()) <= 2e-5 * scale, (name, float((u - v).abs().max()), scale)
