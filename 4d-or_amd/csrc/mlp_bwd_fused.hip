@@ -41,8 +41,6 @@ struct BwdArgs {
   const float *X;
   float *P1;
   int K0;
-  // RECOMP (fold only): y_{l-1} = X W0^T is recomputed from the X tile instead of read (Yprev is NULL): W0 [K][K0]
-  const float *W0;
 };
 
 template <int GMODE, int NTN, int KTN, int R>
@@ -313,15 +311,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(const BwdArgs a) {
 // so this kernel only reduces P1 = gz^T X (16 x K0 FMAs per lane and tile, X tile broadcast from LDS); X^T X and 1^T X
 // come from rows_gram_kernel and first_layer_dw_kernel combines them once the constants exist.  Saves the M x K store
 // here and the whole first-layer wgrad kernel (which re-read gz and y_{l-1}).
-//
-// RECOMP (with FOLD): y_{l-1} itself is not read either — the forward never stored it (PRO_FIRST of mlp_gemm.hip).  The
-// X tiles run one tile AHEAD of the other operands through a ring of three LDS copies, and staging a tile computes
-// y_{l-1}[row][k] = X[row] . W0[k] (the forward's FMA chain) into a raw copy (mask and yhat of the epilogue) next to
-// relu(bn(.)) (wgrad operand): 8 FMAs per element instead of a 4-byte read — the kernel was HBM-bound on three M x 64
-// streams, now it reads two.
-template <int GMODE, int NTN, bool FOLD = false, bool RECOMP = false>
+template <int GMODE, int NTN, bool FOLD = false>
 __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
-  static_assert(FOLD || !RECOMP, "recomputation needs the X tile of the fold");
   constexpr bool POOL = GMODE == PRO_POOLG;
   constexpr int XW = 8;                         // padded width of the X tile
   constexpr int R = 64, KTN = 2;
@@ -341,9 +332,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   float *act0 = gyT0 + 2 * GY_SZ;               // [2][R][KP]
   float *Wl = act0 + 2 * ACT_SZ;                // [NP][KP]
   float *red = Wl + NP * KP;                    // [2][KP]
-  float *Xs0 = red + 2 * KP;                    // FOLD: [2][R][XW] (RECOMP: [3]) + [KP][XW] for the final reduction
-  constexpr int XNB = RECOMP ? 3 : 2;
-  float *y0s0 = Xs0 + XNB * R * XW + KP * XW;   // RECOMP: [2][R][KP] raw y_{l-1}
+  float *Xs0 = red + 2 * KP;                    // FOLD: [2][R][XW] (+ [KP][XW] for the final reduction)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -366,11 +355,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   const int ak = tid % KP, ar0 = tid / KP;
   const int akc = ak < K ? ak : (K - 1);
   const float a_sc = a.a_scale[akc], a_sh = a.a_shift[akc];
-  float w0r[RECOMP ? XW : 1];
-  if (RECOMP) {
-#pragma unroll
-    for (int j = 0; j < XW; ++j) w0r[RECOMP ? j : 0] = (ak < K && j < a.K0) ? a.W0[(size_t)ak * a.K0 + j] : 0.f;
-  }
   const int goff = (gr0 * N + gn) * 4, gpass = GROWS * N * 4;
   const int aoff = (ar0 * K + ak) * 4, apass = AROWS * K * 4;
   const unsigned ns = POOL ? (unsigned)a.ns : 1u;
@@ -435,25 +419,21 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
 #pragma unroll
       for (int i = 0; i < GPT; ++i) rg[POOL ? 0 : i] = bload(rsg, goff, i * gpass);
     }
-    if (!RECOMP) {
-      const rsrc_t rsp = make_rsrc(a.Yprev + (size_t)m0 * K, (M - m0) * K * 4);
+    const rsrc_t rsp = make_rsrc(a.Yprev + (size_t)m0 * K, (M - m0) * K * 4);
 #pragma unroll
-      for (int i = 0; i < APT; ++i) rp[i] = bload(rsp, aoff, i * apass);
-    }
+    for (int i = 0; i < APT; ++i) rp[i] = bload(rsp, aoff, i * apass);
   };
 
   // registers (tile `st`) -> LDS buffer `buf`; keeps the patch operands of that tile in (spa, spg)
   int spa[PG];
   float spg[PG];
   long long p_m0 = 0;
-  // RECOMP: ring position of the X copy of the tile being COMPUTED (xq), staged (xq + 1) and written (xq + 2), mod 3
-  int xq = 0, xq_stage = 0;
   auto stage = [&](long long st, int buf, float (&rg)[RGN], float (&ry)[GPT], float (&rp)[APT], int (&pa)[PG],
                    float (&pg)[PG], float &rx) {
     const long long m0 = st * R;
     float *gyT = gyT0 + buf * GY_SZ;
     float *act = act0 + buf * ACT_SZ;
-    if (FOLD && !RECOMP) Xs0[buf * (R * XW) + tid] = rx;
+    if (FOLD) Xs0[buf * (R * XW) + tid] = rx;
     float gv[GPT];
 #pragma unroll
     for (int i = 0; i < GPT; ++i)
@@ -465,25 +445,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < GPT; ++i) gyT[gn * LDT + gr0 + GROWS * i] = gv[i];
-    if (RECOMP) {
-      const float *xt = Xs0 + xq_stage * (R * XW) + ar0 * XW;     // the tile's X rows: staged one iteration ago
-      float *y0 = y0s0 + buf * ACT_SZ;
 #pragma unroll
-      for (int i = 0; i < APT; ++i) {
-        const float4 *xr = reinterpret_cast<const float4 *>(xt + AROWS * i * XW);
-        const float4 xa = xr[0], xb = xr[1];
-        float y = __fmul_rn(xa.x, w0r[0]);
-        y = __fmaf_rn(xa.y, w0r[RECOMP ? 1 : 0], y); y = __fmaf_rn(xa.z, w0r[RECOMP ? 2 : 0], y);
-        y = __fmaf_rn(xa.w, w0r[RECOMP ? 3 : 0], y); y = __fmaf_rn(xb.x, w0r[RECOMP ? 4 : 0], y);
-        y = __fmaf_rn(xb.y, w0r[RECOMP ? 5 : 0], y); y = __fmaf_rn(xb.z, w0r[RECOMP ? 6 : 0], y);
-        y = __fmaf_rn(xb.w, w0r[RECOMP ? 7 : 0], y);
-        y0[(ar0 + AROWS * i) * KP + ak] = y;
-        act[(ar0 + AROWS * i) * KP + ak] = fmaxf(__fmaf_rn(y, a_sc, a_sh), 0.f);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < APT; ++i) act[(ar0 + AROWS * i) * KP + ak] = fmaxf(__fmaf_rn(rp[i], a_sc, a_sh), 0.f);
-    }
+    for (int i = 0; i < APT; ++i) act[(ar0 + AROWS * i) * KP + ak] = fmaxf(__fmaf_rn(rp[i], a_sc, a_sh), 0.f);
     if (POOL) {
 #pragma unroll
       for (int e = 0; e < PG; ++e) { spa[e] = pa[e]; spg[e] = pg[e]; }
@@ -513,28 +476,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   // one pipeline iteration: tile `tile` is in LDS buffer `buf`, (rg, ry, ...) hold tile+stride and are staged into
   // buf^1, then refilled with tile+3*stride (the other register set holds tile+2*stride)
   auto iteration = [&](int buf, float (&rg)[RGN], float (&ry)[GPT], float (&rp)[APT], int (&pa)[PG], float (&pg)[PG],
-                       float &rx, float &rx_other) {
+                       float &rx) {
     const long long m0 = tile * R;
     const long long t1 = clampt(tile + stride), t3 = clampt(tile + 3 * stride);
     const float *gyT = gyT0 + buf * GY_SZ;
     const float *act = act0 + buf * ACT_SZ;
-    const int xbuf = RECOMP ? xq : buf;            // X copy of the tile being computed
-    if (RECOMP) {
-      // the other register set holds tile + 2 stride: its X rows go into the ring now, two tiles ahead of their use
-      xq_stage = xq == 2 ? 0 : xq + 1;
-      Xs0[(xq_stage == 2 ? 0 : xq_stage + 1) * (R * XW) + tid] = rx_other;
-    }
     if (dgrad_role) {
       float yp[16];
-      if (RECOMP) {
-        const float *y0 = y0s0 + buf * ACT_SZ + (d_rb * 32 + 4 * lh) * KP + dcol;
+      const rsrc_t rsq = make_rsrc(a.Yprev + (size_t)m0 * K, (M - m0) * K * 4);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yp[r] = y0[((r & 3) + 8 * (r >> 2)) * KP];
-      } else {
-        const rsrc_t rsq = make_rsrc(a.Yprev + (size_t)m0 * K, (M - m0) * K * 4);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yp[r] = bload(rsq, yoff, ((r & 3) + 8 * (r >> 2)) * rowpitch);
-      }
+      for (int r = 0; r < 16; ++r) yp[r] = bload(rsq, yoff, ((r & 3) + 8 * (r >> 2)) * rowpitch);
       stage(t1, buf ^ 1, rg, ry, rp, pa, pg, rx);
       load_tile(t3, rg, ry, rp, pa, pg, rx);
 #pragma unroll
@@ -555,7 +506,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
         s2 = __fmaf_rn(v, (y - e_m) * e_r, s2);
         if (FOLD) {
           if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the X-tile reads from being hoisted en bloc
-          const float4 *xr = reinterpret_cast<const float4 *>(Xs0 + xbuf * (R * XW) +
+          const float4 *xr = reinterpret_cast<const float4 *>(Xs0 + buf * (R * XW) +
                                                               (d_rb * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)) * XW);
           const float4 xa = xr[0], xb = xr[1];                    // two broadcast ds_read_b128
           const f2 v2 = {v, v};
@@ -590,16 +541,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
       __syncthreads();
     }
     tile += stride;
-    if (RECOMP) xq = xq == 2 ? 0 : xq + 1;
   };
 
   load_tile(tile, rg0, ry0, rp0, pa0, pg0, rx0);
   load_tile(clampt(tile + stride), rg1, ry1, rp1, pa1, pg1, rx1);
-  if (RECOMP) {
-    Xs0[tid] = rx0;                              // X of the first two tiles: ring positions 0 and 1
-    Xs0[R * XW + tid] = rx1;
-  }
-  __syncthreads();                               // resident weights (and the first X tiles) visible
+  __syncthreads();                               // resident weights visible
   stage(tile, 0, rg0, ry0, rp0, pa0, pg0, rx0);
   load_tile(clampt(tile + 2 * stride), rg0, ry0, rp0, pa0, pg0, rx0);
   __syncthreads();
@@ -609,13 +555,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   }
   // single-exit pair loop + peeled odd iteration (see mlp_gemm_kernel): set 1 holds tile+stride, set 0 tile+2*stride
   for (long long pair = my_tiles >> 1; pair > 0; --pair) {
-    iteration(0, rg1, ry1, rp1, pa1, pg1, rx1, rx0);
-    iteration(1, rg0, ry0, rp0, pa0, pg0, rx0, rx1);
+    iteration(0, rg1, ry1, rp1, pa1, pg1, rx1);
+    iteration(1, rg0, ry0, rp0, pa0, pg0, rx0);
   }
-  if (my_tiles & 1) iteration(0, rg1, ry1, rp1, pa1, pg1, rx1, rx0);
+  if (my_tiles & 1) iteration(0, rg1, ry1, rp1, pa1, pg1, rx1);
 
   // ---- flush the column sums (dgrad waves; both row blocks of a column add up in LDS) ----
-  float *redP = Xs0 + XNB * R * XW;              // FOLD: [KP][XW]
+  float *redP = Xs0 + 2 * R * XW;                // FOLD: [KP][XW]
   for (int i = tid; i < 2 * KP; i += 512) red[i] = 0.f;
   if (FOLD) redP[tid] = 0.f;                     // KP * XW == 512
   __syncthreads();
@@ -656,14 +602,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused2_kernel(const BwdArgs a) {
   }
 }
 
-template <int GMODE, int NTN, bool FOLD = false, bool RECOMP = false>
+template <int GMODE, int NTN, bool FOLD = false>
 int launch_fused2(const BwdArgs &a, hipStream_t s) {
   constexpr int NP = NTN * 32, KP = 64, R = 64;
   constexpr size_t lds_bytes = (size_t)(2 * NP * (R + 1) + 2 * R * KP + NP * KP + 2 * KP +
-                                        (FOLD ? (RECOMP ? 3 : 2) * R * 8 + KP * 8 : 0) + (RECOMP ? 2 * R * KP : 0)) *
-                               sizeof(float);
+                                        (FOLD ? 2 * R * 8 + KP * 8 : 0)) * sizeof(float);
   static_assert(lds_bytes <= 160 * 1024, "LDS budget of one CU");
-  auto kern = mlp_bwd_fused2_kernel<GMODE, NTN, FOLD, RECOMP>;
+  auto kern = mlp_bwd_fused2_kernel<GMODE, NTN, FOLD>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -701,7 +646,6 @@ int launch_fused(const BwdArgs &a, hipStream_t s) {
 template <int GMODE>
 int dispatch_fused(const BwdArgs &a, hipStream_t s) {
   const int ntn = a.N <= 64 ? 2 : 4, ktn = a.K <= 64 ? 2 : 4;
-  if (a.X && !a.Yprev) return (ntn == 2 && ktn == 2) ? launch_fused2<GMODE, 2, true, true>(a, s) : PN2_EINVAL;
   if (a.X) return (ntn == 2 && ktn == 2) ? launch_fused2<GMODE, 2, true>(a, s) : PN2_EINVAL;
   // N, K <= 64: role-specialised version 2 (1.16 vs 1.31 ms at M = 4.2M); N = 128: version 1 (1.67 vs 2.44 ms —
   // the two register sets of 64 x 128 gy tiles push version 2 past 256 VGPRs).
@@ -734,7 +678,7 @@ extern "C" int pn2_mlp_bwd_fused(long long M, int N, int K, int gmode, const flo
   a.arg = arg; a.gP = gP; a.W = W; a.Yprev = Yprev;
   a.a_mean = a_fin; a.a_rstd = a_fin + K; a.a_scale = a_fin + 2 * (size_t)K; a.a_shift = a_fin + 3 * (size_t)K;
   a.Gout = Gout; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K; a.ns = ns;
-  a.X = nullptr; a.P1 = nullptr; a.K0 = 0; a.W0 = nullptr;
+  a.X = nullptr; a.P1 = nullptr; a.K0 = 0;
   hipStream_t s = (hipStream_t)stream;
   return gmode == PRO_GY ? dispatch_fused<PRO_GY>(a, s) : dispatch_fused<PRO_POOLG>(a, s);
 }
@@ -843,28 +787,7 @@ extern "C" int pn2_mlp_bwd_fused_fold(long long M, int N, int K, int gmode, cons
   a.arg = arg; a.gP = gP; a.W = W; a.Yprev = Yprev;
   a.a_mean = a_fin; a.a_rstd = a_fin + K; a.a_scale = a_fin + 2 * (size_t)K; a.a_shift = a_fin + 3 * (size_t)K;
   a.Gout = nullptr; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K; a.ns = ns;
-  a.X = X; a.P1 = P1; a.K0 = K0; a.W0 = nullptr;
-  hipStream_t s = (hipStream_t)stream;
-  return gmode == PRO_GY ? dispatch_fused<PRO_GY>(a, s) : dispatch_fused<PRO_POOLG>(a, s);
-}
-
-// The same fold when the forward never stored y_{l-1} (pn2_mlp_gemm_first): it is recomputed from X and W0 [K][K0].
-extern "C" int pn2_mlp_bwd_fused_fold_first(long long M, int N, int K, int gmode, const float *G, const float *Yl,
-                                            const float *consts, const int *arg, const float *gP, int ns, const float *W,
-                                            const float *W0, const float *a_fin, const float *X, int K0, double *sums,
-                                            float *dW, float *P1, void *stream) {
-  if (M < 0 || !pn2_mlp_bwd_fused_fold_supported(N, K, K0)) return PN2_EINVAL;
-  if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
-  if (M == 0) return PN2_OK;
-  if (!Yl || !consts || !W || !W0 || !a_fin || !X || !sums || !dW || !P1) return PN2_ENULL;
-  if (gmode == PRO_GY && !G) return PN2_ENULL;
-  if (gmode == PRO_POOLG && (!arg || !gP || ns < 16 || M >= 0x7fffffffLL)) return PN2_EINVAL;
-  BwdArgs a;
-  a.G = G; a.Yl = Yl; a.c1 = consts; a.c2 = consts + N; a.c3 = consts + 2 * (size_t)N;
-  a.arg = arg; a.gP = gP; a.W = W; a.Yprev = nullptr;
-  a.a_mean = a_fin; a.a_rstd = a_fin + K; a.a_scale = a_fin + 2 * (size_t)K; a.a_shift = a_fin + 3 * (size_t)K;
-  a.Gout = nullptr; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K; a.ns = ns;
-  a.X = X; a.P1 = P1; a.K0 = K0; a.W0 = W0;
+  a.X = X; a.P1 = P1; a.K0 = K0;
   hipStream_t s = (hipStream_t)stream;
   return gmode == PRO_GY ? dispatch_fused<PRO_GY>(a, s) : dispatch_fused<PRO_POOLG>(a, s);
 }
