@@ -806,39 +806,60 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
 
     // ---- (B) sparse parts ----
     {
-      // S: lane = tile row, registers = this wave's KS columns; W' slabs gathered from L2 (two list slots per step)
-      float sreg[KS];
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) sreg[kk] = 0.f;
-      const int filed = cnt[lane];
+      // S: wave w owns the tile rows 8w .. 8w + 7 and ALL K columns (lane l: columns 2l, 2l + 1).  A list entry is then
+      // one coalesced 512-byte row of W' with a wave-uniform coefficient — as lanes = rows (round-3 first version) every
+      // wave gathered its own 64-byte slice of the same 64 rows per step: 16k cache-line requests per tile through the one
+      // texture-address unit of the CU, which was the kernel's time.  Eight list slots are fetched back to back (an
+      // empty slot reads row 0 with coefficient 0: no branches between the loads).
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const int rl = lane >> 3, c0 = lane & 7;               // lane -> (row of the wave's eight, list slot)
+      const int myrow = wave * 8 + rl;
+      const int filed = cnt[myrow];
       const int mine = filed < CAP ? filed : CAP;
-      // one list slot per step, the next slot's (column, coefficient) read ahead of this slot's gather
-      int nn = mine > 0 ? lst_n[lane * CAP] : 0;
-      float cn = mine > 0 ? lst_c[lane * CAP] : 0.f;
-      for (int c = 0; __ballot(c < mine) != 0ull; ++c) {
-        const int n1 = nn;
-        const float c1 = cn;
-        const bool more = c + 1 < mine;
-        nn = more ? lst_n[lane * CAP + c + 1] : 0;
-        cn = more ? lst_c[lane * CAP + c + 1] : 0.f;
-        f32x4 w[KS / 4];
+      const bool va = c0 < mine, vb = c0 + 8 < mine;
+      const int n_a = va ? lst_n[myrow * CAP + c0] : 0, n_b = vb ? lst_n[myrow * CAP + c0 + 8] : 0;
+      const float c_a = va ? lst_c[myrow * CAP + c0] : 0.f, c_b = vb ? lst_c[myrow * CAP + c0 + 8] : 0.f;
+      const bool second = __ballot(vb) != 0ull;              // any of the wave's rows with more than eight entries
+      const float *wl = a.Wp + 2 * lane;
 #pragma unroll
-        for (int q = 0; q < KS / 4; ++q) w[q] = *reinterpret_cast<const f32x4 *>(a.Wp + (size_t)n1 * K + wave * KS + 4 * q);
+      for (int r = 0; r < 8; ++r) {
+        f2 acc = {0.f, 0.f};
+        f2 w[8];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) sreg[kk] = __fmaf_rn(c1, w[kk >> 2][kk & 3], sreg[kk]);
+        for (int q = 0; q < 8; ++q) {
+          const int n = __builtin_amdgcn_readlane(n_a, 8 * r + q);
+          w[q] = *reinterpret_cast<const f2 *>(wl + (size_t)n * K);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_a), 8 * r + q));
+          acc = __builtin_elementwise_fma(f2{cf, cf}, w[q], acc);
+        }
+        if (second) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int n = __builtin_amdgcn_readlane(n_b, 8 * r + q);
+            w[q] = *reinterpret_cast<const f2 *>(wl + (size_t)n * K);
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_b), 8 * r + q));
+            acc = __builtin_elementwise_fma(f2{cf, cf}, w[q], acc);
+          }
+        }
+        *reinterpret_cast<f2 *>(&st[(wave * 8 + r) * LDT + 2 * lane]) = acc;
+        __builtin_amdgcn_sched_barrier(0);                  // one row at a time (eight 8-byte loads in flight)
       }
       const int nov = __builtin_amdgcn_readfirstlane(cnt[TM]);
-      for (int o = 0; o < nov; ++o) {                      // rows with more than CAP entries: one lane at a time
+      for (int o = 0; o < nov; ++o) {                      // rows with more than CAP entries: their wave, one entry at a time
         const int rn = __builtin_amdgcn_readfirstlane(ovf_rn[o]);
-        const float cf = (rn >> 16) == lane ? ovf_c[o] : 0.f;
-        const float *wr = a.Wp + (size_t)(rn & 0xffff) * K + wave * KS;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) sreg[kk] = __fmaf_rn(cf, wr[kk], sreg[kk]);
-      }
-#pragma unroll
-      for (int kk = 0; kk < KS; kk += 4) {
-        f32x4 o4 = {sreg[kk], sreg[kk + 1], sreg[kk + 2], sreg[kk + 3]};
-        *reinterpret_cast<f32x4 *>(&st[lane * LDT + wave * KS + kk]) = o4;
+        const int orow = rn >> 16;
+        if ((orow >> 3) == wave) {
+          const float cf = ovf_c[o];
+          const f2 wv = *reinterpret_cast<const f2 *>(wl + (size_t)(rn & 0xffff) * K);
+          f2 *dst = reinterpret_cast<f2 *>(&st[orow * LDT + 2 * lane]);
+          *dst = __builtin_elementwise_fma(f2{cf, cf}, wv, *dst);
+        }
       }
     }
     // T: lanes = columns n of this wave's quarter, registers = its 64 columns k
@@ -1021,7 +1042,7 @@ extern "C" int pn2_pool_bwd_supported(int N, int K, int ns) {
   // K = 128: W' (N x 128 floats) is gathered from L2 — N / ns entries per row and 512 bytes each.  At ns = 16 (16 entries
   // per row on average, 512 KB of W' per 64-row tile against 32 KB of y) the gather, not the matrix products, is the
   // kernel's time (measured 1.24 ms vs 0.46 ms for the materialised path at 256k rows): such layers stay on that path
-  if (K == 128) return ns >= 32 && getenv("PN2_POOL_K128_OFF") == nullptr;
+  if (K == 128) return ns >= (getenv("PN2_POOL_K128_NS16") ? 16 : 32) && getenv("PN2_POOL_K128_OFF") == nullptr;
   return ngt * 4 <= 8;                                                     // K = 64, N > 128: the index-register kernel
 }
 
