@@ -678,6 +678,10 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
 // fit next to it and is gathered from L2 — lane r reads the 64-byte slab W'[n][16 w .. 16 w + 15] of ITS list entry.
 // A thread files two (group, column) entries per tile (four groups x 256 columns at ns = 16).
 __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a) {
+#ifdef PB_PROF
+  long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = __builtin_readcyclecounter();
+#endif
   constexpr int K = 128, NW = 8, THREADS = 512;
   constexpr int LDZ = K + 1, LDT = K + 4, LDG = K + 1;
   constexpr int CG = K / 4;           // 32 threads per row
@@ -800,7 +804,9 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
         }
       }
     }
+    PB_T(0)
     __syncthreads();
+    PB_T(1)
     const long long nt = (tile + gridDim.x) < ntiles ? tile + gridDim.x : tile;
     load_tile(nt, ynxt);
 
@@ -862,6 +868,7 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
         }
       }
     }
+    PB_T(2)
     // T: lanes = columns n of this wave's quarter, registers = its 64 columns k
 #pragma unroll
     for (int gi = 0; gi < GMAX; ++gi) {
@@ -880,6 +887,7 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
       }
     }
     load_idx(nt);
+    PB_T(8)
 
     // ---- (C) matrix products ----
     {
@@ -900,7 +908,9 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
         if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    PB_T(3)
     __syncthreads();
+    PB_T(4)
     // ---- (D) a G + v + S into the staging tile; the row lists are free again ----
     {
       float t[16];
@@ -913,7 +923,9 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
       }
       if (tid <= TM) cnt[tid] = 0;
     }
+    PB_T(5)
     __syncthreads();
+    PB_T(6)
     // ---- (E) mask, statistics, store ----
     {
       const rsrc_t rso = make_rsrc(a.Gout + (size_t)m0 * K, (M - m0) * K * 4);
@@ -937,7 +949,14 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
     }
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) ycur[i] = ynxt[i];
+    PB_T(7)
   }
+#ifdef PB_PROF
+  if (lane == 0 && blockIdx.x < 64) {
+    long long *dst = (long long *)a.Gout + (blockIdx.x * 8 + wave) * 10;      // (experiment build only: clobbers the first rows of the output)
+    for (int i = 0; i < 10; ++i) dst[i] = prof[i];
+  }
+#endif
 
   // ---- flush ----
   float *prec = a.part + (size_t)blockIdx.x * (K * K + K + (size_t)N * K);

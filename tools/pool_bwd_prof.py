@@ -1,11 +1,12 @@
-"""Per-phase cycle counts of pool_bwd64_kernel (library built with -DPB_PROF: csrc/exp/libpn2_PROF.so)."""
+"""Per-phase cycle counts of pool_bwd64_kernel (argument "128": pool_bwd128_kernel; all waves share one role there) from
+a library built with -DPB_PROF: csrc/exp/libpn2_PROF.so."""
 import ctypes, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "4d-or_amd")]
 os.environ["PN2_HIP_LIB"] = os.path.join(REPO, "4d-or_amd/csrc/exp/libpn2_PROF.so")
 import torch
 from pointnet2_ops import _ext as e
-M, K, N, ns = 4194304, 64, 128, 64
+M, K, N, ns = (1048576, 128, 256, 32) if "128" in sys.argv[1:] else (4194304, 64, 128, 64)
 dev = torch.device("cuda:0")
 R = M // ns
 yp = torch.randn(M, K, device=dev)
@@ -24,7 +25,8 @@ for _ in range(2):
 torch.cuda.synchronize()
 grid = 256
 prof = Gout.view(-1)[:64 * 8 * 10 * 2].view(torch.int64).view(64, 8, 10).cpu().double()
-names = ["A stage", "barrier1", "B sparse", "C mfma", "barrier2", "D epi", "barrier3", "E store", "-", "loop head"]
+names = ["A stage", "barrier1", "B sparse" if K == 64 else "B: S", "C mfma", "barrier2", "D epi", "barrier3", "E store",
+         "-" if K == 64 else "B: T", "loop head"]
 tiles = (M // 64) / grid
 print("tiles per WG", tiles)
 for role, sl in (("waves0-3 (aG+S)", slice(0, 4)), ("waves4-7 (gram+T)", slice(4, 8))):
