@@ -1124,12 +1124,14 @@ extern "C" int pn2_mlp_gemm_first(long long M, int K0, int K, int N, int epi, co
   hipStream_t s = (hipStream_t)stream;
   const int tiles = (N + 31) / 32;
   if (epi == EPI_STATS) {
+    // 64-wide outputs: the 4-wave, 16-chunk variant (94 VGPRs, 26 KB of LDS: four workgroups per CU) — 0.461 ms at the SA1
+    // shape against 0.477 for <2, 32, 1> (169 VGPRs), 0.463 for <1, 32, 2>, 0.494 for <1, 16, 2> (tools/fold_bench.py)
     if (tiles <= 1) launch_one<1, 32, 1, PRO_FIRST, EPI_STATS>(a, s);
-    else if (tiles <= 2) launch_one<2, 32, 1, PRO_FIRST, EPI_STATS>(a, s, 512);
+    else if (tiles <= 2) launch_one<2, 16, 1, PRO_FIRST, EPI_STATS>(a, s, 1024);
     else launch_one<2, 16, 2, PRO_FIRST, EPI_STATS>(a, s, 768);
   } else {
     if (tiles <= 1) launch_one<1, 32, 1, PRO_FIRST, EPI_NONE>(a, s);
-    else if (tiles <= 2) launch_one<2, 32, 1, PRO_FIRST, EPI_NONE>(a, s, 512);
+    else if (tiles <= 2) launch_one<2, 16, 1, PRO_FIRST, EPI_NONE>(a, s, 1024);
     else launch_one<2, 16, 2, PRO_FIRST, EPI_NONE>(a, s, 768);
   }
   return pn2_check_launch();
