@@ -63,3 +63,44 @@ def test_ctypes_signatures_have_the_header_arity():
             assert len(_ext._SIGNATURES[name]) == n, name
             seen += 1
     assert seen == len(_ext._SIGNATURES)
+
+
+def test_host_side_routing_predicates():
+    """The shape predicates are plain host functions: which ball-query algorithm / which fused kernels a shape takes, and
+    the workspace each algorithm asks for (include/pn2_hip.h: PN2_BQ_SCAN 0 | _CELLS 1 | _SLABS 2)."""
+    lib = ctypes.CDLL(LIB)
+    f32, i32, sz = ctypes.c_float, ctypes.c_int, ctypes.c_size_t
+    lib.pn2_ball_query_auto.argtypes = [i32, i32, i32, f32, i32]
+    lib.pn2_ball_query_auto.restype = i32
+    lib.pn2_ball_query_algo_bytes.argtypes = [i32, i32, i32, i32, f32, i32]
+    lib.pn2_ball_query_algo_bytes.restype = sz
+    lib.pn2_ball_query_workspace_bytes.argtypes = [i32, i32, i32, f32, i32]
+    lib.pn2_ball_query_workspace_bytes.restype = sz
+    lib.pn2_ball_query_grid_bytes.argtypes = [i32, i32, i32]
+    lib.pn2_ball_query_grid_bytes.restype = sz
+    auto = lib.pn2_ball_query_auto
+    # headline SA1: a scan would walk 50000 * 64 / 400 = 8000 points per centre -> slabs; SA2-SA4: short walks -> scan
+    assert auto(32, 50000, 2048, 0.2, 64) == 2
+    assert auto(32, 2048, 1024, 0.4, 32) == 0 and auto(32, 1024, 512, 0.8, 16) == 0 and auto(32, 512, 256, 1.2, 16) == 0
+    # scene-graph encoders: sparse balls in 4000 / 8000-point clouds never exit early -> slabs; very crowded -> scan
+    assert auto(72, 8000, 512, 0.1, 16) == 2 and auto(288, 4000, 512, 0.2, 32) == 2
+    assert auto(72, 8000, 512, 0.4, 128) == 0
+    # radii the cell edge cannot be sized from, empty problems
+    for r in (0.0, -1.0, float("inf"), float("nan")):
+        assert auto(4, 50000, 512, r, 32) == 0 and lib.pn2_ball_query_algo_bytes(2, 4, 50000, 512, r, 32) == 0
+    assert auto(0, 50000, 512, 0.2, 32) == 0
+    # workspaces: the scan has none; slabs = 16 B per point + a 16 KB table (+ 64 B) per slab of 2048 indices
+    assert lib.pn2_ball_query_algo_bytes(0, 32, 50000, 2048, 0.2, 64) == 0
+    assert lib.pn2_ball_query_algo_bytes(2, 32, 50000, 2048, 0.2, 64) == 32 * 50000 * 16 + 32 * 25 * (4096 + 16) * 4 + 256
+    assert lib.pn2_ball_query_workspace_bytes(32, 50000, 2048, 0.2, 64) == lib.pn2_ball_query_algo_bytes(2, 32, 50000, 2048, 0.2, 64)
+    assert lib.pn2_ball_query_algo_bytes(1, 32, 50000, 2048, 0.2, 64) == lib.pn2_ball_query_grid_bytes(32, 50000, 64) > 0
+    assert lib.pn2_ball_query_algo_bytes(1, 32, 50000, 2048, 0.2, 300) == 0          # cell list: nsample <= 256
+    # fused shared-MLP predicates
+    lib.pn2_mlp_gemm_first_supported.argtypes = [i32, i32, i32]
+    lib.pn2_mlp_bwd_fused_fold_supported.argtypes = [i32, i32, i32]
+    lib.pn2_pool_bwd_supported.argtypes = [i32, i32, i32]
+    assert lib.pn2_mlp_gemm_first_supported(6, 64, 64) and lib.pn2_mlp_gemm_first_supported(8, 128, 128)
+    assert not lib.pn2_mlp_gemm_first_supported(9, 64, 64) and not lib.pn2_mlp_gemm_first_supported(6, 256, 64)
+    assert lib.pn2_mlp_bwd_fused_fold_supported(64, 64, 6) and not lib.pn2_mlp_bwd_fused_fold_supported(128, 64, 6)
+    assert lib.pn2_pool_bwd_supported(128, 64, 64) and lib.pn2_pool_bwd_supported(256, 128, 32)
+    assert not lib.pn2_pool_bwd_supported(256, 128, 16)                               # SA3 / SA4: materialised path
