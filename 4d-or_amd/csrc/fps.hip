@@ -312,19 +312,274 @@ struct __attribute__((aligned(16))) FpsFinal {
 // so the tie order is unchanged) are streamed from memory each round with their running distances in `tail_td`
 // (B x N floats).  The streamed part is what the round costs (20 bytes per point and round); holding 40 % of a 200k
 // cloud in registers and using all 256 CUs instead of 64 is 2.4x faster than the one-workgroup streaming kernel.
-template <int BS, int PPT, int NC, bool TAIL = false>
+// ---- spatial bucketing for the cluster kernel (round 3) --------------------------------------------------------
+// A round of the cluster kernel costs ~0.9 us of synchronisation plus ~0.1 us per point slot of every lane (measured:
+// 32 x 50k on two 1024-thread workgroups per cloud, 26 slots: 3.6 us; the same cluster on 4096 points: 0.87 us) — and
+// almost all of the distance updates are no-ops: after a few hundred samples a new sample only lowers the running distance
+// of points in its neighbourhood.  The reference's result does not depend on WHICH thread holds a point (the arg-max key
+// carries the reference's rank of the point's index), so the points are first permuted into spatially compact groups:
+// one workgroup per cloud bins the cloud into 16^3 cells of its bounding box, in Morton order of the cells (histogram,
+// scan, scatter of (x, y, z, index) records; the order inside a cell is whatever the atomics give — it does not matter).
+// A wave of the cluster kernel then owns 64 * PPT CONSECUTIVE records, i.e. a compact blob with a small bounding box, and
+// skips the whole update of a round when the new sample is farther from that box than the wave's largest running
+// distance: no running distance can change (see the kernel), the wave re-publishes its cached candidate.
+constexpr int kBucketCells = 4096;
+
+__device__ __forceinline__ int fps_cell(float x, float y, float z, const float *bb) {
+  // bb: min[3], 16 / extent[3] (0 for a flat axis); NaN / out-of-range coordinates land in cell 0 / 15 of the axis
+  const float tx = (x - bb[0]) * bb[3], ty = (y - bb[1]) * bb[4], tz = (z - bb[2]) * bb[5];
+  const int qx = tx >= 0.f ? (tx < 15.f ? (int)tx : 15) : 0;
+  const int qy = ty >= 0.f ? (ty < 15.f ? (int)ty : 15) : 0;
+  const int qz = tz >= 0.f ? (tz < 15.f ? (int)tz : 15) : 0;
+  int m = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    m |= (((qx >> b) & 1) << (3 * b)) | (((qy >> b) & 1) << (3 * b + 1)) | (((qz >> b) & 1) << (3 * b + 2));
+  return m;
+}
+
+__global__ __launch_bounds__(1024) void fps_bucket_kernel(int N, int Nstride, const float *__restrict__ xyz,
+                                                          float4 *__restrict__ rec) {
+  __shared__ float red[6][16];
+  __shared__ float bb[6];
+  __shared__ int hist[kBucketCells];
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = pn2_lane(), wave = t >> 6;
+  const float *P = xyz + (size_t)blockIdx.x * N * 3;
+  float4 *R = rec + (size_t)blockIdx.x * Nstride;
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int k = t; k < N; k += 1024) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = P[(size_t)k * 3 + c];
+      if (v >= -3.0e38f && v <= 3.0e38f) { mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); }   // finite values only
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
+    if (lane == 0) { red[c][wave] = mn[c]; red[3 + c][wave] = mx[c]; }
+  }
+  for (int i = t; i < kBucketCells; i += 1024) hist[i] = 0;
+  __syncthreads();
+  if (t < 3) {
+    float a = red[t][0], b = red[3 + t][0];
+    for (int w = 1; w < 16; ++w) { a = fminf(a, red[t][w]); b = fmaxf(b, red[3 + t][w]); }
+    bb[t] = a;
+    bb[3 + t] = b > a ? 16.f / (b - a) : 0.f;
+  }
+  __syncthreads();
+  for (int k = t; k < N; k += 1024)
+    atomicAdd(&hist[fps_cell(P[(size_t)k * 3], P[(size_t)k * 3 + 1], P[(size_t)k * 3 + 2], bb)], 1);
+  __syncthreads();
+  int c4[4], sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { c4[i] = hist[4 * t + i]; sum += c4[i]; }
+  int inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(inc, d);
+    if (lane >= d) inc += v;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int off = inc - sum;
+  for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { hist[4 * t + i] = off; off += c4[i]; }
+  __syncthreads();
+  for (int k = t; k < N; k += 1024) {
+    const float x = P[(size_t)k * 3], y = P[(size_t)k * 3 + 1], z = P[(size_t)k * 3 + 2];
+    const int pos = atomicAdd(&hist[fps_cell(x, y, z, bb)], 1);
+    R[pos] = make_float4(x, y, z, __int_as_float(k));
+  }
+}
+
+// ---- bucketed kernel: ONE workgroup per cloud, running distances in L2, only the touched buckets updated ----------
+// With the cloud binned (fps_bucket_kernel) into buckets of 64 S consecutive records, a round only has to update the
+// buckets the new sample can reach: a bucket whose bounding box is farther from the sample than its largest running
+// distance cannot change (simulated on a 50k-point ball, 2048 samples: 26 of 782 buckets per round on average, 18 in the
+// second half).  So the points do not have to sit in registers, and a cloud does not have to be spread over several
+// workgroups that then pay ~1.9 us per round for their hand-off: the records (x, y, z, index) and the running distances
+// stay in memory (800 KB + 200 KB for 50k points: L2-resident), ONE workgroup of 16 waves owns the cloud, thread b keeps
+// bucket b's bounding box in registers and its cached candidate (arg-max key, coordinates, largest distance) in LDS.
+//   A  every thread tests its bucket against the new sample; the reachable ones are appended to a list (LDS)
+//   B  wave w updates the listed buckets w, w + 16, ...: 64 records per slot, min with the stored distance, wave
+//      arg-max of the reference's key (distance bits, rank of the point's index) -> the bucket's cache
+//   C  block arg-max over the bucket caches = the reference's winner (the key is the reference's order)
+// Three barriers per round, no spinning, any number of clouds (no residency requirement).  Exactness as in the cluster
+// kernel: identical fp32 distances, skipped updates are provably no-ops (lb (1 - 2e-6) <= every computed distance of the
+// bucket), ties through the rank.
+constexpr int kBucketMaxBuckets = 1024;
+
+template <int S>
+__global__ __launch_bounds__(1024) void fps_bucketed_kernel(int N, int Nstride, int m, int L,
+                                                           const float *__restrict__ xyz,
+                                                           const float4 *__restrict__ rec, float *__restrict__ tdist,
+                                                           int *__restrict__ idxs) {
+  constexpr int NW = 16, PB = 64 * S;
+  __shared__ u64 s_key[kBucketMaxBuckets];
+  __shared__ float s_cx[kBucketMaxBuckets], s_cy[kBucketMaxBuckets], s_cz[kBucketMaxBuckets], s_maxd[kBucketMaxBuckets];
+  __shared__ int s_list[kBucketMaxBuckets];
+  __shared__ float s_bb[6][kBucketMaxBuckets];
+  __shared__ int s_nact;
+  __shared__ FpsSlot s_slots[2][16];
+
+  const int t = threadIdx.x, lane = pn2_lane();
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int q = blockIdx.x;
+  const float *P = xyz + (size_t)q * N * 3;
+  const float4 *R = rec + (size_t)q * Nstride;
+  float *T = tdist + (size_t)q * Nstride;
+  int *out = idxs + (size_t)q * m;
+  const int nb = (N + PB - 1) / PB;
+
+  // ---- prologue: running distances, bounding boxes and (empty) caches of the buckets; wave w: buckets w, w + 16, ...
+  for (int b = wave; b < nb; b += NW) {
+    float x0 = 3.0e38f, y0 = 3.0e38f, z0 = 3.0e38f, x1 = -3.0e38f, y1 = -3.0e38f, z1 = -3.0e38f;
+    bool any = false;
+#pragma unroll
+    for (int sl = 0; sl < S; ++sl) {
+      const int pos = b * PB + sl * 64 + lane;
+      bool valid = false;
+      if (pos < N) {
+        const float4 r = R[pos];
+        valid = !((double)pn2_sq3(r.x, r.y, r.z) <= 1e-3);      // EXT/src/sampling_gpu.cu:100-101
+        if (valid) {
+          x0 = fminf(x0, r.x); y0 = fminf(y0, r.y); z0 = fminf(z0, r.z);
+          x1 = fmaxf(x1, r.x); y1 = fmaxf(y1, r.y); z1 = fmaxf(z1, r.z);
+        }
+      }
+      if (pos < Nstride) T[pos] = valid ? 1e10f : -1.f;
+      any |= valid;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      x0 = fminf(x0, __shfl_xor(x0, o)); y0 = fminf(y0, __shfl_xor(y0, o)); z0 = fminf(z0, __shfl_xor(z0, o));
+      x1 = fmaxf(x1, __shfl_xor(x1, o)); y1 = fmaxf(y1, __shfl_xor(y1, o)); z1 = fmaxf(z1, __shfl_xor(z1, o));
+    }
+    const bool some = __ballot(any) != 0ull;
+    if (lane == 0) {
+      s_bb[0][b] = x0; s_bb[1][b] = y0; s_bb[2][b] = z0; s_bb[3][b] = x1; s_bb[4][b] = y1; s_bb[5][b] = z1;
+      s_key[b] = 0ull;
+      s_cx[b] = 0.f; s_cy[b] = 0.f; s_cz[b] = 0.f;
+      s_maxd[b] = some ? 1e10f : -1.f;                          // (a bucket without candidates is never reachable)
+    }
+  }
+  if (t == 0) { s_nact = 0; out[0] = 0; }                        // :87
+  __syncthreads();
+  const bool mine = t < nb;
+  const float bx0 = mine ? s_bb[0][t] : 0.f, by0 = mine ? s_bb[1][t] : 0.f, bz0 = mine ? s_bb[2][t] : 0.f;
+  const float bx1 = mine ? s_bb[3][t] : 0.f, by1 = mine ? s_bb[4][t] : 0.f, bz1 = mine ? s_bb[5][t] : 0.f;
+  const float p0x = P[0], p0y = P[1], p0z = P[2];
+  float ox = p0x, oy = p0y, oz = p0z;
+
+  for (int j = 1; j < m; ++j) {
+    // ---- A: reachable buckets
+    {
+      bool act = false;
+      if (mine) {
+        const float ex = fmaxf(fmaxf(bx0 - ox, ox - bx1), 0.f), ey = fmaxf(fmaxf(by0 - oy, oy - by1), 0.f),
+                    ez = fmaxf(fmaxf(bz0 - oz, oz - bz1), 0.f);
+        const float lb = (ex * ex + ey * ey + ez * ez) * 0.999998f;
+        act = !(lb >= s_maxd[t]);
+      }
+      const u64 am = __ballot(act);
+      if (am) {                                                 // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_nact, __popcll(am));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (act) s_list[base + pn2_prefix_popc(am)] = t;
+      }
+    }
+    __syncthreads();
+    // ---- B: update the listed buckets
+    {
+      const int nact = s_nact;
+      auto update = [&](int b, const float4 (&r)[S], const float (&t0)[S]) {
+        u64 best = 0ull;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) {
+          const int pos = b * PB + sl * 64 + lane;
+          const float d = pn2_sq3(r[sl].x - ox, r[sl].y - oy, r[sl].z - oz);
+          const float d2 = fps_min(d, t0[sl]);                  // (-1 stays -1: skipped points and padding)
+          if (pos < Nstride) T[pos] = d2;
+          const u64 pk = d2 >= 0.f ? fps_pack(d2, (unsigned)__float_as_int(r[sl].w), L) : 0ull;
+          if (pk > best) { best = pk; cx = r[sl].x; cy = r[sl].y; cz = r[sl].z; }
+        }
+        const u64 wmax = fps_wave_max_key(best);
+        const u64 who = __ballot(best == wmax);
+        const int wl = __ffsll((long long)who) - 1;
+        const float wx = pn2_readlane_f32(cx, wl), wy = pn2_readlane_f32(cy, wl), wz = pn2_readlane_f32(cz, wl);
+        if (lane == 0) {
+          s_key[b] = wmax;
+          s_cx[b] = wx; s_cy[b] = wy; s_cz[b] = wz;
+          s_maxd[b] = wmax ? __uint_as_float((unsigned)(wmax >> 32) - 1u) : -1.f;
+        }
+      };
+      auto fetch = [&](int b, float4 (&r)[S], float (&t0)[S]) {
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) {
+          const int pos = b * PB + sl * 64 + lane;
+          const bool in = pos < Nstride;
+          r[sl] = in ? R[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+          t0[sl] = in ? T[pos] : -1.f;
+        }
+      };
+      // up to four buckets in flight per wave: the first rounds list every bucket (49 per wave at 50k points), and a
+      // bucket is one L2 round trip
+      constexpr int FL = S <= 2 ? 4 : 2;
+      for (int a = wave; a < nact; a += FL * NW) {
+        int bq[FL];
+        bool on[FL];
+        float4 rq[FL][S];
+        float uq[FL][S];
+#pragma unroll
+        for (int f = 0; f < FL; ++f) {
+          on[f] = a + f * NW < nact;                            // wave-uniform
+          bq[f] = s_list[on[f] ? a + f * NW : a];
+          if (on[f]) fetch(bq[f], rq[f], uq[f]);
+        }
+#pragma unroll
+        for (int f = 0; f < FL; ++f)
+          if (on[f]) update(bq[f], rq[f], uq[f]);
+      }
+    }
+    __syncthreads();
+    // ---- C: block arg-max over the bucket caches
+    {
+      if (t == 0) s_nact = 0;
+      const u64 key = mine ? s_key[t] : 0ull;
+      const u64 wmax = fps_wave_max_key(key);
+      const u64 who = __ballot(key == wmax && mine);
+      const int wl = who ? __ffsll((long long)who) - 1 : 0;
+      const int wb = wave * 64 + wl;                           // bucket of the wave's candidate
+      const bool has = wmax != 0ull;
+      const float sx = has ? s_cx[wb] : p0x, sy = has ? s_cy[wb] : p0y, sz = has ? s_cz[wb] : p0z;
+      const u64 gmax = fps_block_exchange<NW>(s_slots[j & 1], wmax, lane == 0, sx, sy, sz, ox, oy, oz);
+      if (t == 0) out[j] = gmax ? (int)fps_unrank(~(unsigned)gmax, L) : 0;
+    }
+  }
+}
+
+template <int BS, int PPT, int NC, bool TAIL = false, bool BUCK = false>
 __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L, int G,
                                                      const float *__restrict__ xyz,
                                                      int *__restrict__ idxs,
                                                      u64 *__restrict__ slots,
                                                      int *__restrict__ status,
-                                                     float *__restrict__ tail_td = nullptr) {
+                                                     float *__restrict__ tail_td = nullptr,
+                                                     const float4 *__restrict__ rec = nullptr) {
   static_assert(!TAIL || NC == 1, "streamed tail: one cloud per cluster");
+  static_assert(!BUCK || (NC == 1 && !TAIL), "bucketed points: one cloud per cluster, everything in registers");
   constexpr int NW = BS / 64;
   static_assert(NC <= NW, "one sweeping wave per cloud");
   __shared__ FpsSlot lds_slots[2][NC][16];
   __shared__ unsigned lds_vals[NC][kCoopFields][kCoopMaxG];
   __shared__ FpsFinal lds_fin[2][NC];
+  // BUCK: reference index of every point slot of the workgroup (the arg-max key needs it for the tied candidates only)
+  __shared__ int permk[BUCK ? BS * PPT : 1];
 
   const int nclusters = B / NC;
   const int q = blockIdx.x % nclusters;   // a cluster's workgroups share blockIdx % 8 (one XCD) when nclusters % 8 == 0
@@ -337,6 +592,8 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
   const int k0 = g * BS + t;
   const int kstride = G * BS;
   float p0x[NC], p0y[NC], p0z[NC], ox[NC], oy[NC], oz[NC];
+  // BUCK: bounding box of the wave's valid points, its cached candidate and its largest running distance
+  float bbx0 = 3.0e38f, bby0 = 3.0e38f, bbz0 = 3.0e38f, bbx1 = -3.0e38f, bby1 = -3.0e38f, bbz1 = -3.0e38f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float *P = xyz + (size_t)(q * NC + c) * N * 3;
@@ -345,7 +602,23 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
       const int k = k0 + i * kstride;
       float x = 0.f, y = 0.f, z = 0.f;
       bool valid = false;
-      if (k < N) {
+      if constexpr (BUCK) {
+        // wave (g, w) owns the records [b 64 PPT, +64 PPT) of the binned cloud, b = w G + g: neighbouring blobs — the ones
+        // a sample activates together — sit in different workgroups and on different SIMDs
+        const int pos = (wave * G + g) * (64 * PPT) + i * 64 + lane;
+        int kk = 0;
+        if (pos < N) {
+          const float4 r = rec[(size_t)q * N + pos];
+          x = r.x; y = r.y; z = r.z; kk = __float_as_int(r.w);
+          const float mag = pn2_sq3(x, y, z);
+          valid = !((double)mag <= 1e-3);
+        }
+        permk[wave * (64 * PPT) + i * 64 + lane] = kk;
+        if (valid) {
+          bbx0 = fminf(bbx0, x); bby0 = fminf(bby0, y); bbz0 = fminf(bbz0, z);
+          bbx1 = fmaxf(bbx1, x); bby1 = fmaxf(bby1, y); bbz1 = fmaxf(bbz1, z);
+        }
+      } else if (k < N) {
         x = P[(size_t)k * 3 + 0];
         y = P[(size_t)k * 3 + 1];
         z = P[(size_t)k * 3 + 2];
@@ -360,6 +633,20 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
     if (g == 0 && t == 0) idxs[(size_t)(q * NC + c) * m] = 0;
   }
 
+  u64 c_wmax = 0ull;
+  float c_sx = 0.f, c_sy = 0.f, c_sz = 0.f, c_maxd = 1e10f;
+  if constexpr (BUCK) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      bbx0 = fminf(bbx0, __shfl_xor(bbx0, o)); bby0 = fminf(bby0, __shfl_xor(bby0, o)); bbz0 = fminf(bbz0, __shfl_xor(bbz0, o));
+      bbx1 = fmaxf(bbx1, __shfl_xor(bbx1, o)); bby1 = fmaxf(bby1, __shfl_xor(bby1, o)); bbz1 = fmaxf(bbz1, __shfl_xor(bbz1, o));
+    }
+    bbx0 = pn2_readlane_f32(bbx0, 0); bby0 = pn2_readlane_f32(bby0, 0); bbz0 = pn2_readlane_f32(bbz0, 0);
+    bbx1 = pn2_readlane_f32(bbx1, 0); bby1 = pn2_readlane_f32(bby1, 0); bbz1 = pn2_readlane_f32(bbz1, 0);
+    c_sx = p0x[0]; c_sy = p0y[0]; c_sz = p0z[0];
+    __syncthreads();                                            // permk complete
+  }
+
   for (int j = 1; j < m; ++j) {
     // ---- scan + wave arg-max of every cloud, winners into this round's LDS slots ----
     if constexpr (NC == 1) {
@@ -368,6 +655,22 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
       // readlanes of the winning lane.  ~140 VALU instructions per round instead of ~230 (per-point compare +
       // two selects, 64-bit key reduction, 3*PPT-select coordinate chain).  The FPS co-runs with the MFMA kernels of
       // the training step and fp32 VALU time is exactly what it takes away from them.
+      // BUCK: every point p of the wave lies in its bounding box, so its distance to the new sample is at least the
+      // box's: computed in fp32 both carry a few ulp, lb (1 - 2e-6) <= d(p) for every p.  If that bound is not below the
+      // wave's largest running distance, min(d, td) = td for all of them: nothing changes, the cached candidate stands.
+      bool active = true;
+      if constexpr (BUCK) {
+        const float ex = fmaxf(fmaxf(bbx0 - ox[0], ox[0] - bbx1), 0.f), ey = fmaxf(fmaxf(bby0 - oy[0], oy[0] - bby1), 0.f),
+                    ez = fmaxf(fmaxf(bbz0 - oz[0], oz[0] - bbz1), 0.f);
+        const float lb = (ex * ex + ey * ey + ez * ez) * 0.999998f;
+        active = __builtin_amdgcn_readfirstlane((int)!(lb >= c_maxd)) != 0;
+#ifdef FPS_STATS
+        if (lane == 0) { atomicAdd(status + 2, 1); if (active) atomicAdd(status + 1, 1); }
+#endif
+      }
+      u64 wmax = c_wmax;
+      float sx = c_sx, sy = c_sy, sz = c_sz;
+      if (active) {
       float best = -1.f;
       if constexpr (PPT % 2 == 0) {
         // two points per packed instruction (v_pk_add/mul/fma_f32): the same IEEE operations in the same order as
@@ -396,8 +699,8 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
       // (threadIdx-derived values are divergent to the compiler even when they are not: without the readfirstlane
       // the whole resolution below is compiled with exec masks and v_readfirstlane waterfalls)
       const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-      u64 wmax = 0ull;
-      float sx = p0x[0], sy = p0y[0], sz = p0z[0];
+      wmax = 0ull;
+      sx = p0x[0]; sy = p0y[0]; sz = p0z[0];
       if (whi != 0u) {
         const unsigned target = whi - 1u;                         // bits of the wave's largest distance
         u64 tied = __ballot(hi == whi);                           // usually exactly one lane
@@ -406,6 +709,17 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
         while (tied) {                                            // scalar loop over the tied lanes
           const int l = __ffsll((long long)tied) - 1;
           tied &= tied - 1;
+          if constexpr (BUCK) {
+            // the slots of a lane are in no particular index order: every slot that holds the maximum is a candidate
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+              if ((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(td[i]), l) == target) {   // wave-uniform
+                const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane(permk[wave_u * (64 * PPT) + i * 64 + l]);
+                const unsigned lo = ~fps_rank(k, L);
+                if (lo >= best_lo) { best_lo = lo; wl = l; wbi = i; }
+              }
+            }
+          } else {
           int bi = 0;
 #pragma unroll
           for (int i = PPT - 1; i >= 0; --i)                      // first (smallest k) slot holding the maximum
@@ -413,6 +727,7 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
           const unsigned k = (unsigned)(g * BS + wave_u * 64 + l + bi * kstride);
           const unsigned lo = ~fps_rank(k, L);
           if (lo >= best_lo) { best_lo = lo; wl = l; wbi = bi; }  // keys are unique: '>' or first
+          }
         }
         wmax = ((u64)whi << 32) | best_lo;
 #pragma unroll
@@ -422,6 +737,11 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
           }
         }
       }
+      if constexpr (BUCK) {
+        c_wmax = wmax; c_sx = sx; c_sy = sy; c_sz = sz;
+        c_maxd = whi != 0u ? __uint_as_float(whi - 1u) : -1.f;
+      }
+      }   // active
       if constexpr (TAIL) {
         // streamed points of this thread: k = k0 + i * kstride, i = PPT, PPT + 1, ...
         const float *P = xyz + (size_t)q * N * 3;
@@ -583,7 +903,7 @@ int ref_opt_n_threads(int work_size) {
 //     that keeps <= 16 point slots per lane (larger clusters sweep more granules);
 //     every cluster workgroup must be resident, hence B*G <= 256.
 struct FpsPlan {
-  int mode;  // 0 resident, 1 cooperative, 2 streaming, 3 cooperative with a streamed tail
+  int mode;  // 0 resident, 1 cooperative, 2 streaming, 3 cooperative with a streamed tail, 4 bucketed (PPT = slots per bucket)
   int G, BS, PPT;
   int NC;    // cooperative: clouds per cluster
 };
@@ -600,10 +920,11 @@ int round_ppt(int ppt) {
 // against the oracle on shapes the heuristic would route elsewhere.  Process-global, unset by default; never read from
 // the environment.
 struct FpsOverride {
-  int mode;      // -1 none | 0 resident | 1 cooperative | 2 streaming | 3 cooperative with a streamed tail
+  int mode;      // -1 none | 0 resident | 1 cooperative | 2 streaming | 3 cooperative with a streamed tail | 4 bucketed
   int G, NC, coop_bs, bs;   // 0 = heuristic
 };
 FpsOverride g_fps_override = {-1, 0, 0, 0, 0};
+bool g_fps_bucketing = true;     // (pn2_fps_set_bucketing: tests and measurements compare both forms)
 
 // Number of CUs of the current device (a CPX/DPX partition reports its own count); every cluster workgroup must be
 // resident at once, so the cluster shapes are sized from this instead of a hard-coded 256.
@@ -703,6 +1024,19 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false, bool fewest = false)
   const bool want_hybrid = ov.mode == 3;
   if (want_hybrid && h.mode == 3) return h;
 
+  // bucketed: one workgroup per cloud, 64 S records per bucket, at most 1024 buckets.  Chosen where a cluster would be
+  // (clouds beyond 16k points): 32 x 50k -> 2048 in 3.x ms on 32 CUs against 5.3 ms on 128 / 7.3 ms on 64
+  FpsPlan k = {-1, 1, 1024, 0, 1};
+  {
+    int S = 1;
+    while (S < 8 && (long long)N > 65536LL * S) S *= 2;
+    if ((long long)N <= 65536LL * S) { k.mode = 4; k.PPT = S; }
+  }
+  if (ov.mode == 4 && k.mode == 4) return k;
+  // ... when the batch does not fit the chip's registers any more (~20k points per CU): 64 x 200k points 42 -> 13 ms per
+  // step of samplings; a batch that does fit (32 x 50k: 1.6M of 5.2M slots) is as fast on a cluster (4.9 vs 4.8 ms)
+  if (ov.mode < 0 && g_fps_bucketing && k.mode == 4 && N > 16384 && (long long)B * N > (long long)ncus * 1024 * 20) return k;
+
   if (want_coop && c.mode == 1) return c;
   if (want_resident && r.mode == 0) return r;
   if (r.mode == 0 && (N <= 16384 || c.mode != 1)) return r;
@@ -769,20 +1103,54 @@ struct CoopSerial {
 
 }  // namespace
 
+namespace {
+size_t fps_align256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
 extern "C" int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, int bs) {
-  if (mode < -1 || mode > 3 || G < 0 || NC < 0) return PN2_EINVAL;
+  if (mode < -1 || mode > 4 || G < 0 || NC < 0) return PN2_EINVAL;
   g_fps_override = {mode, G, NC, coop_bs, bs};
+  return PN2_OK;
+}
+
+// Test / measurement hook: spatial bucketing of the cluster kernels on (default) / off.  Results never depend on it.
+extern "C" int pn2_fps_set_bucketing(int on) {
+  g_fps_bucketing = on != 0;
   return PN2_OK;
 }
 
 // cluster plans also reserve the streaming kernel's B x N floats behind the hand-off slots: the fallback when the
 // cluster would not be resident on this device
+namespace {
+int bucket_stride(int N, int S) { return (N + 64 * S - 1) / (64 * S) * (64 * S); }
+size_t bucketed_bytes(int B, int N, int S) {
+  const size_t ns = (size_t)bucket_stride(N, S);
+  return fps_align256((size_t)B * ns * 16) + (size_t)B * ns * sizeof(float);
+}
+}  // namespace
+
 extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int m) {
   if (B <= 0 || N <= 0 || m <= 1) return 0;
+  // the largest layout any plan of this shape can ask for (scheduling hints, the bucketing switch and the plan override
+  // change the plan, not the workspace a caller has to bring)
+  const bool save = g_fps_bucketing;
+  g_fps_bucketing = false;
   const FpsPlan p = fps_plan(B, N, m);
-  if (p.mode == 0) return 0;
-  if (p.mode == 1 || p.mode == 3) return (size_t)B * kCoopCloudBytes + 256 + (size_t)B * (size_t)N * sizeof(float);
-  return (size_t)B * (size_t)N * sizeof(float);
+  g_fps_bucketing = true;
+  const FpsPlan kb = fps_plan(B, N, m);
+  g_fps_bucketing = save;
+  size_t need = 0;
+  // cluster plans: hand-off slots | status | B x N floats (streaming fallback / streamed tail) | B x N binned records
+  if (p.mode == 1 || p.mode == 3)
+    need = (size_t)B * kCoopCloudBytes + 256 + fps_align256((size_t)B * (size_t)N * sizeof(float)) + (size_t)B * (size_t)N * 16;
+  else if (p.mode == 2) need = (size_t)B * (size_t)N * sizeof(float);
+  if (kb.mode == 4 || g_fps_override.mode == 4) {
+    int S = 1;
+    while (S < 8 && (long long)N > 65536LL * S) S *= 2;
+    const size_t nk = bucketed_bytes(B, N, S);
+    need = need > nk ? need : nk;
+  }
+  return need;
 }
 
 extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz,
@@ -810,6 +1178,20 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     if (workspace_bytes < need) return PN2_ENOSPC;
   }
 
+  if (plan.mode == 4) {
+    const int S = plan.PPT, ns = bucket_stride(N, S);
+    float4 *rec = (float4 *)workspace;
+    float *td = (float *)((char *)workspace + fps_align256((size_t)B * ns * 16));
+    if (((uintptr_t)workspace & 15) != 0) return PN2_EINVAL;
+    hipLaunchKernelGGL(fps_bucket_kernel, dim3((unsigned)B), dim3(1024), 0, s, N, ns, xyz, rec);
+    switch (S) {
+      case 1: hipLaunchKernelGGL(fps_bucketed_kernel<1>, dim3((unsigned)B), dim3(1024), 0, s, N, ns, m, L, xyz, rec, td, idxs); break;
+      case 2: hipLaunchKernelGGL(fps_bucketed_kernel<2>, dim3((unsigned)B), dim3(1024), 0, s, N, ns, m, L, xyz, rec, td, idxs); break;
+      case 4: hipLaunchKernelGGL(fps_bucketed_kernel<4>, dim3((unsigned)B), dim3(1024), 0, s, N, ns, m, L, xyz, rec, td, idxs); break;
+      default: hipLaunchKernelGGL(fps_bucketed_kernel<8>, dim3((unsigned)B), dim3(1024), 0, s, N, ns, m, L, xyz, rec, td, idxs); break;
+    }
+    return pn2_check_launch();
+  }
   const size_t head = (size_t)B * kCoopCloudBytes + 256;
   float *tail = (plan.mode == 1 || plan.mode == 3) ? (float *)((char *)workspace + head) : (float *)workspace;
   bool fits = true;
@@ -821,7 +1203,8 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     const unsigned grid = (unsigned)(B * plan.G);
     if ((fits = coop_fits((const void *)kfn, 1024, grid))) {
       CoopSerial chain(s);
-      hipLaunchKernelGGL(kfn, dim3(grid), dim3(1024), 0, s, B, N, m, L, plan.G, xyz, idxs, slots, status, tail);
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(1024), 0, s, B, N, m, L, plan.G, xyz, idxs, slots, status, tail,
+                         (const float4 *)nullptr);
       return pn2_check_launch();
     }
   }
@@ -831,12 +1214,26 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     if (hipMemsetAsync(workspace, 0, head, s) != hipSuccess) return pn2_check_launch();
     const dim3 grid((unsigned)((B / plan.NC) * plan.G));
     CoopSerial chain(s);
+    // bucketed points (fps_bucket_kernel): one cloud per cluster, at least eight point slots per lane to skip
+    float4 *rec = (float4 *)((char *)workspace + head + fps_align256((size_t)B * (size_t)N * sizeof(float)));
+    // ... and 1024-thread workgroups, i.e. the shapes of a sampling that runs next to a training step (scheduling hints)
+    // or a forced one: there the skipped updates are VALU time handed to the co-running kernels (same-box A/B of the
+    // default step 15.45 -> 15.12 ms); the latency-optimal 512-thread clusters gain nothing (the round is the hand-off)
+    const bool buck = plan.NC == 1 && plan.PPT >= 8 && plan.BS == 1024 && g_fps_bucketing;
+    if (buck) hipLaunchKernelGGL(fps_bucket_kernel, dim3((unsigned)B), dim3(1024), 0, s, N, N, xyz, rec);
+#define PN2_FPS_COOP_B(BSZ, PPT)                                                                    \
+  {                                                                                                 \
+    auto kfn = fps_coop_kernel<BSZ, PPT, 1, false, true>;                                           \
+    if ((fits = coop_fits((const void *)kfn, BSZ, grid.x)))                                         \
+      hipLaunchKernelGGL(kfn, grid, dim3(BSZ), 0, s, B, N, m, L, plan.G, xyz, idxs, slots, status,  \
+                         (float *)nullptr, (const float4 *)rec);                                    \
+  }
 #define PN2_FPS_COOP(PPT, NC)                                                                       \
   {                                                                                                 \
     auto kfn = fps_coop_kernel<512, PPT, NC>;                                                       \
     if ((fits = coop_fits((const void *)kfn, 512, grid.x)))                                         \
       hipLaunchKernelGGL(kfn, grid, dim3(512), 0, s, B, N, m, L, plan.G, xyz, idxs, slots, status,  \
-                         (float *)nullptr);                                                         \
+                         (float *)nullptr, (const float4 *)nullptr);                                \
   }
 #define PN2_FPS_COOP_NC(NC)                                                                         \
   switch (plan.PPT) {                                                                               \
@@ -857,8 +1254,21 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     auto kfn = fps_coop_kernel<1024, PPT, 1>;                                                         \
     if ((fits = coop_fits((const void *)kfn, 1024, grid.x)))                                          \
       hipLaunchKernelGGL(kfn, grid, dim3(1024), 0, s, B, N, m, L, plan.G, xyz, idxs, slots, status,   \
-                         (float *)nullptr);                                                           \
+                         (float *)nullptr, (const float4 *)nullptr);                                  \
   }
+      if (buck) {
+        switch (plan.PPT) {
+          case 8: PN2_FPS_COOP_B(1024, 8); break;
+          case 10: PN2_FPS_COOP_B(1024, 10); break;
+          case 12: PN2_FPS_COOP_B(1024, 12); break;
+          case 14: PN2_FPS_COOP_B(1024, 14); break;
+          case 16: PN2_FPS_COOP_B(1024, 16); break;
+          case 20: PN2_FPS_COOP_B(1024, 20); break;
+          case 24: PN2_FPS_COOP_B(1024, 24); break;
+          case 26: PN2_FPS_COOP_B(1024, 26); break;
+          default: return PN2_EINVAL;
+        }
+      } else
       switch (plan.PPT) {
         case 8: PN2_FPS_COOP_W(8); break;
         case 10: PN2_FPS_COOP_W(10); break;
@@ -893,6 +1303,7 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     }
 #undef PN2_FPS_COOP_NC
 #undef PN2_FPS_COOP
+#undef PN2_FPS_COOP_B
     if (fits) return pn2_check_launch();
   }
 

@@ -139,6 +139,10 @@ _lib.pn2_fps_status_offset.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_status_offset.restype = ctypes.c_longlong
 _lib.pn2_fps_set_plan_override.argtypes = [_c_int] * 5
 _lib.pn2_fps_set_plan_override.restype = _c_int
+_lib.pn2_fps_set_bucketing.argtypes = [_c_int]
+_lib.pn2_fps_set_bucketing.restype = _c_int
+if os.environ.get("PN2_FPS_BUCKETING") == "0":       # measurement switch (tools, A/B runs of bench.py)
+    _lib.pn2_fps_set_bucketing(0)
 _lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_supported.restype = _c_int
 _lib.pn2_mlp_bwd_bf16_supported.argtypes = [_c_int, _c_int]
@@ -161,7 +165,7 @@ ABI_VERSION = int(_lib.pn2_abi_version())
 #: error instead of an AttributeError on the first missing symbol
 EXPECTED_ABI_VERSION = 3
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
-                                               "pn2_fps_status_offset", "pn2_fps_set_plan_override",
+                                               "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
@@ -334,7 +338,17 @@ def furthest_point_sampling(points, nsamples):
     return out
 
 
-_FPS_MODES = {None: -1, "resident": 0, "coop": 1, "stream": 2, "hybrid": 3}
+_FPS_MODES = {None: -1, "resident": 0, "coop": 1, "stream": 2, "hybrid": 3, "bucketed": 4}
+
+
+@contextlib.contextmanager
+def fps_bucketing(on):
+    """Test / measurement hook (pn2_fps_set_bucketing): spatial bucketing of the cluster FPS kernels on / off."""
+    _lib.pn2_fps_set_bucketing(1 if on else 0)
+    try:
+        yield
+    finally:
+        _lib.pn2_fps_set_bucketing(1)
 
 
 @contextlib.contextmanager

@@ -84,6 +84,11 @@ long long pn2_fps_status_offset(int B, int N, int m);
 /* Test hook: force a kernel variant (mode: -1 heuristic | 0 resident | 1 cluster | 2 streaming | 3 cluster with a
  * streamed tail) and cluster shape (0 = heuristic).  Process-global; results never depend on it. */
 int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, int bs);
+/* Cluster variants with >= 8 point slots per lane first bin the cloud into spatially compact groups of 64 x slots points
+ * (one extra launch, records in the workspace) so that a wave can skip a round's distance updates when the new sample is
+ * farther from its bounding box than its largest running distance.  Test / measurement hook: 0 switches
+ * that off.  Process-global; results never depend on it. */
+int pn2_fps_set_bucketing(int on);
 /* Test hook for the multi-workgroup FPS variant: returns the status word a
  * launch left in `workspace` (0 ok, 1 a bounded inter-workgroup wait expired,
  * <0 query failed).  Synchronises `stream`; never used on the hot path. */

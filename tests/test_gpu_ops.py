@@ -57,19 +57,23 @@ def test_fps_few_cus_hint_is_bit_exact(ext, B, N, m, kind):
         assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("mode,g", [("resident", None), ("stream", None), ("coop", 2), ("coop", 8), ("coop", 32), (None, None)])
+@pytest.mark.parametrize("mode,g", [("resident", None), ("stream", None), ("coop", 2), ("coop", 8), ("coop", 32), (None, None),
+                                    ("bucketed", None), ("coop_plain", 2), ("coop_plain", 8)])
 @pytest.mark.parametrize("B,N,m,kind", [(2, 9000, 300, "uniform"), (3, 20000, 150, "dup"), (1, 50000, 200, "zero_tail"),
                                         (32, 50000, 40, "uniform"), (5, 5000, 64, "grid")])
 def test_fps_every_kernel_variant_agrees_with_oracle(ext, monkeypatch, mode, g, B, N, m, kind):
-    """resident / streaming / cooperative (G workgroups per cloud) kernels are
-    interchangeable: identical indices for identical input."""
+    """resident / streaming / cooperative (G workgroups per cloud; with and without the spatially binned points) /
+    bucketed (one workgroup per cloud over the binned cloud) kernels are interchangeable: identical indices for
+    identical input."""
+    plain = mode == "coop_plain"
+    mode = "coop" if plain else mode
     if mode == "resident" and N > 24576:
         pytest.skip("does not fit the register file of one workgroup")
     if mode == "coop" and (B * g > 256 or (N + g - 1) // g > 512 * 24):
         pytest.skip("cluster does not fit")
     xyz = clouds(B, N, kind, seed=N + B)
     want = O.furthest_point_sampling(xyz, m)
-    with ext.fps_plan_override(mode=mode, g=g or 0):
+    with ext.fps_bucketing(not plain), ext.fps_plan_override(mode=mode, g=g or 0):
         got = ext.furthest_point_sampling(dev(xyz), m).cpu()      # (a failed cluster hand-off asserts on the device)
     assert torch.equal(got, want)
 
