@@ -94,6 +94,20 @@ def test_fps_cluster_with_streamed_tail_agrees_with_oracle(ext, monkeypatch, g, 
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("B,N,m,kind", [(2, 100000, 48, "uniform"), (3, 60000, 64, "dup"), (1, 250000, 40, "zero_tail"),
+                                        (1, 300001, 24, "uniform"), (64, 30000, 24, "uniform"), (2, 30000, 50, "grid"),
+                                        (2, 20481, 32, "uniform"), (3, 700, 40, "uniform"), (2, 64, 64, "dup")])
+def test_fps_bucketed_kernel_agrees_with_oracle(ext, B, N, m, kind):
+    """One workgroup per cloud over the spatially binned cloud (csrc/fps.hip, fps_bucketed_kernel): buckets of 64, 128,
+    256 and 512 records (N up to 65536 S), ragged last buckets, clouds smaller than a workgroup, duplicates and lattice
+    ties (the reference's rank decides), skipped points, every point sampled (m = N)."""
+    xyz = clouds(B, N, kind, seed=N + B)
+    want = O.furthest_point_sampling(xyz, m)
+    with ext.fps_plan_override(mode="bucketed"):
+        got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("B", [130, 300])
 def test_fps_many_large_clouds(ext, B):
     """More clouds than a cluster shape admits: 130 x 30k -> one 1024-thread workgroup per cloud with a streamed tail
