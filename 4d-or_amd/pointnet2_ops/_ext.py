@@ -139,6 +139,14 @@ _lib.pn2_fps_status_offset.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_status_offset.restype = ctypes.c_longlong
 _lib.pn2_fps_set_plan_override.argtypes = [_c_int] * 5
 _lib.pn2_fps_set_plan_override.restype = _c_int
+_lib.pn2_event_create.argtypes = []
+_lib.pn2_event_create.restype = _c_vp
+_lib.pn2_event_record.argtypes = [_c_vp, _c_vp]
+_lib.pn2_event_record.restype = _c_int
+_lib.pn2_event_elapsed_ms.argtypes = [_c_vp, _c_vp, ctypes.POINTER(ctypes.c_float)]
+_lib.pn2_event_elapsed_ms.restype = _c_int
+_lib.pn2_event_destroy.argtypes = [_c_vp]
+_lib.pn2_event_destroy.restype = _c_int
 _lib.pn2_fps_set_bucketing.argtypes = [_c_int]
 _lib.pn2_fps_set_bucketing.restype = _c_int
 if os.environ.get("PN2_FPS_BUCKETING") == "0":       # measurement switch (tools, A/B runs of bench.py)
@@ -166,6 +174,7 @@ ABI_VERSION = int(_lib.pn2_abi_version())
 EXPECTED_ABI_VERSION = 3
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing",
+                                               "pn2_event_create", "pn2_event_record", "pn2_event_elapsed_ms", "pn2_event_destroy",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
@@ -235,21 +244,42 @@ class KernelTimer:
     ~1 ms per 200-launch step); launches on a stream other than `main_stream` are reported
     under `name@side` (work prefetched off the critical path)."""
 
-    def __init__(self, main_stream=None):
+    def __init__(self, main_stream=None, pool=1536):
         self.records = []          # (name, start_event, end_event, algorithmic_bytes, algorithmic_flops)
         self.enabled = True
         self.main_stream = main_stream
+        # fence-free timing events from the library (pn2_event_*), created up front: a torch.cuda.Event record flushes the
+        # L2 (~20 us of queue time each, ~11 ms per sampled step of 250 launches)
+        self._free = [_lib.pn2_event_create() for _ in range(pool)]
+        self._all = list(self._free)
+
+    def event(self):
+        if not self._free:
+            ev = _lib.pn2_event_create()
+            self._all.append(ev)
+            return ev
+        return self._free.pop()
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
+        ms = ctypes.c_float()
         for name, s, e, nbytes, nflops in self.records:
             d = out.setdefault(name, {"calls": 0, "ms": 0.0, "alg_bytes": 0, "alg_flops": 0})
             d["calls"] += 1
-            d["ms"] += s.elapsed_time(e)
+            if _lib.pn2_event_elapsed_ms(s, e, ctypes.byref(ms)) != 0:
+                _fail("pn2_event_elapsed_ms failed")
+            d["ms"] += float(ms.value)
             d["alg_bytes"] += nbytes
             d["alg_flops"] += nflops
         return out
+
+    def __del__(self):
+        try:
+            for ev in self._all:
+                _lib.pn2_event_destroy(ev)
+        except Exception:
+            pass
 
 
 TIMER = None  # set to a KernelTimer() to profile
@@ -277,10 +307,10 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0, tag=None, label=None):
     with torch.cuda.device(ref.device):
         stream = torch.cuda.current_stream(ref.device).cuda_stream
         if TIMER is not None and TIMER.enabled:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
+            ev0, ev1 = TIMER.event(), TIMER.event()
+            _lib.pn2_event_record(ev0, stream)
             rc = getattr(_lib, name)(*args, stream)
-            ev1.record()
+            _lib.pn2_event_record(ev1, stream)
             label = (label or name) if tag is None else f"{label or name}[{tag}]"
             if TIMER.main_stream is not None and stream != TIMER.main_stream:
                 label += "@side"

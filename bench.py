@@ -626,8 +626,9 @@ def main():
     if not args.no_kernel_timing:
         timer = _ext.KernelTimer(main_stream)
         _ext.TIMER = timer
-        # K < 4: every step; K < 24: one step in the middle of the timed region (two event records per launch serialise
-        # consecutive kernels: a sampled step is ~3 ms longer); longer runs: two steps
+        # K < 4: every step; K < 24: one step in the middle of the timed region; longer runs: two steps.  (The events are the
+        # library's fence-free ones, pn2_event_*: with torch.cuda.Event — a system-scope release per record — a sampled step
+        # was ~11 ms longer, 0.55 ms per step of a 20-step run; now ~2 ms)
         if args.steps < 4:
             sampled = set(range(args.steps))
         elif args.steps < 24:

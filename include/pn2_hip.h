@@ -45,6 +45,12 @@ int pn2_abi_version(void);
 const char *pn2_strerror(int code);
 /* Last hipError_t observed by a failing launch on this thread (0 if none). */
 int pn2_last_hip_error(void);
+/* Timing events without the system-scope fence of a default HIP event (timestamps only; measurement code such as bench.py's
+ * per-kernel table): create / record on a stream / elapsed milliseconds between two recorded events / destroy. */
+void *pn2_event_create(void);
+int pn2_event_record(void *ev, void *stream);
+int pn2_event_elapsed_ms(void *start, void *stop, float *ms);
+int pn2_event_destroy(void *ev);
 
 /* ------------------------------------------------------------------ A5 ---
  * furthest_point_sampling   (EXT/include/sampling.h:6,
