@@ -34,7 +34,9 @@ class Pointnet2Backbone(nn.Module):
     @staticmethod
     def _break_up_pc(pc):
         xyz = pc[..., 0:3].contiguous()
-        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        # (B, C, N) as a transposed VIEW of point-major rows: the rows path takes the rows back without a copy (the
+        # reference's .transpose(1, 2).contiguous() followed by as_rows was two passes over the colours per step)
+        features = pc[..., 3:].contiguous().transpose(1, 2) if pc.size(-1) > 3 else None
         return xyz, features
 
     @torch.no_grad()
