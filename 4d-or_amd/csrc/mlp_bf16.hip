@@ -582,9 +582,14 @@ struct BwdBf16Args {
   float *dW;                // [N][K] ACCUMULATES
   long long M;
   int N, K, ns;
+  // FOLD (layer l-1 is the stack's first layer, its input rows X [M][8] bf16 — K0 <= 8 real columns, zero padded — need no
+  // gradient): Gout is not stored, P1 [K][K0] += Gout^T X is reduced instead (the first-layer fold of csrc/mlp_bwd_fused.hip)
+  const bf16 *X;
+  float *P1;
+  int K0;
 };
 
-template <int NTN, int KTK, int GMODE>
+template <int NTN, int KTK, int GMODE, bool FOLD = false>
 __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args a) {
   constexpr int MT = 64, MP = MT + 8;
   constexpr int NB = NTN * 32, KB = KTK * 32, NP = NB + 8, KP = KB + 8;
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
   bf16 *sO = sXT + KB * MP;                          // [MT][KP]
   float *sC = (float *)(sO + MT * KP);               // c1 | c2 | c3 [NB], then mean | rstd | scale | shift [KB]
   float *sF = sC + 3 * NB;
+  float *sXr = sF + 4 * KB;                          // FOLD: [MT][8] input rows of the tile (fp32), then [KB][8] for the flush
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = a.N, K = a.K;                        // == NB, KB (checked by the host wrapper)
@@ -636,6 +642,11 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
   float s1[DT], s2[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) s1[i] = s2[i] = 0.f;
+  float px[FOLD ? DT : 1][8];
+#pragma unroll
+  for (int i = 0; i < (FOLD ? DT : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) px[i][j] = 0.f;
 
   constexpr int CGn = NB / 8, CGk = KB / 8;
   constexpr int GT = (32 * CGn + 511) / 512;         // gy tasks per thread (row pair x 8 columns)
@@ -643,8 +654,13 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
   const long long ntiles = (a.M + MT - 1) / MT;
 
   u32x4 rg0[GT], rg1[GT], ry0[GT], ry1[GT], rx0[XT], rx1[XT];
+  u32x4 rxr = {0u, 0u, 0u, 0u};
   auto issue = [&](long long tile) {
     const long long row0 = tile * MT, left = a.M - row0;
+    if constexpr (FOLD) {
+      const rsrc_t rX0 = make_rsrc((const char *)a.X + (size_t)row0 * 16, left * 16);
+      rxr = bload128(rX0, tid < MT ? tid * 16 : kOobOffset, 0);
+    }
     const rsrc_t rG = make_rsrc((const char *)(GMODE == PRO_GY ? a.G : a.Yl) + (size_t)row0 * N * 2, left * N * 2);
     const rsrc_t rY = make_rsrc((const char *)a.Yl + (size_t)row0 * N * 2, left * N * 2);
     const rsrc_t rX = make_rsrc((const char *)a.Yprev + (size_t)row0 * K * 2, left * K * 2);
@@ -672,6 +688,12 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
   for (; tile < ntiles; tile += gridDim.x) {
     const long long row0 = tile * MT;
     __syncthreads();                                 // previous tile: MFMA reads and the output store are done
+    if constexpr (FOLD) {
+      if (tid < MT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sXr[tid * 8 + 2 * e] = bf_lo(rxr[e]); sXr[tid * 8 + 2 * e + 1] = bf_hi(rxr[e]); }
+      }
+    }
     // ---- commit: gy tile (row-major + transposed), activation tile (raw row-major + activated transposed)
 #pragma unroll
     for (int i = 0; i < GT; ++i) {
@@ -768,7 +790,19 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
           const float vr = (float)vb;
           s1[d] += vr;
           s2[d] = fmaf(vr, (yp - mean) * rstd, s2[d]);
-          *cell = vb;
+          if constexpr (FOLD) {
+            if ((e & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // keep the X-row reads from being hoisted en bloc
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const float4 xa = *(const float4 *)&sXr[m * 8], xb = *(const float4 *)&sXr[m * 8 + 4];
+            const f2 v2 = {vr, vr};
+            f2 *pp = reinterpret_cast<f2 *>(px[FOLD ? d : 0]);
+            pp[0] = __builtin_elementwise_fma(v2, f2{xa.x, xa.y}, pp[0]);   // v_pk_fma_f32
+            pp[1] = __builtin_elementwise_fma(v2, f2{xa.z, xa.w}, pp[1]);
+            pp[2] = __builtin_elementwise_fma(v2, f2{xb.x, xb.y}, pp[2]);
+            pp[3] = __builtin_elementwise_fma(v2, f2{xb.z, xb.w}, pp[3]);
+          } else {
+            *cell = vb;
+          }
         }
       }
     }
@@ -789,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
       }
     }
     __syncthreads();                                           // masked tile complete in sO
-    {
+    if constexpr (!FOLD) {
       const long long left = a.M - row0;
       const rsrc_t rO = make_rsrc((char *)a.Gout + (size_t)row0 * K * 2, left * K * 2);
       for (int t = tid; t < MT * CGk; t += 512) {
@@ -815,6 +849,26 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
   }
   __syncthreads();
   for (int i = tid; i < 2 * KB; i += 512) atomicAdd(a.sums + (size_t)(i / KB) * K + (i % KB), (double)red[i]);
+  if constexpr (FOLD) {
+    __syncthreads();
+    float *redP = sXr;                                         // [KB][8]
+    for (int i = tid; i < KB * 8; i += 512) redP[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const int t = wave + 8 * d;
+      if (t < 2 * KTK) {
+        const int k = (t % KTK) * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&redP[k * 8 + j], px[FOLD ? d : 0][j]);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < KB * 8; i += 512) {
+      const int k = i >> 3, j = i & 7;
+      if (j < a.K0) atomicAdd(a.P1 + (size_t)k * a.K0 + j, redP[i]);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
     const int t = wave + 8 * i;
@@ -830,11 +884,12 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
   }
 }
 
-template <int NTN, int KTK, int GMODE>
+template <int NTN, int KTK, int GMODE, bool FOLD = false>
 int launch_bwd(const BwdBf16Args &a, hipStream_t s) {
   constexpr int MT = 64, MP = MT + 8, NB = NTN * 32, KB = KTK * 32, NP = NB + 8, KP = KB + 8;
-  const size_t lds = (size_t)(KB * NP + MT * NP + NB * MP + KB * MP + MT * KP) * 2 + (size_t)(3 * NB + 4 * KB) * 4;
-  auto kfn = mlp_bwd_bf16_kernel<NTN, KTK, GMODE>;
+  const size_t lds = (size_t)(KB * NP + MT * NP + NB * MP + KB * MP + MT * KP) * 2 + (size_t)(3 * NB + 4 * KB) * 4 +
+                     (FOLD ? (size_t)(MT > KB ? MT : KB) * 8 * 4 : 0);
+  auto kfn = mlp_bwd_bf16_kernel<NTN, KTK, GMODE, FOLD>;
   static bool big_lds = false;
   if (lds > 64 * 1024 && !big_lds) {
     if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -846,6 +901,17 @@ int launch_bwd(const BwdBf16Args &a, hipStream_t s) {
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), lds, s, a);
   return pn2_check_launch();
+}
+
+template <int GMODE>
+int dispatch_bwd_fold(const BwdBf16Args &a, hipStream_t s) {
+  switch ((a.N / 32) * 8 + a.K / 32) {
+    case 1 * 8 + 1: return launch_bwd<1, 1, GMODE, true>(a, s);
+    case 1 * 8 + 2: return launch_bwd<1, 2, GMODE, true>(a, s);
+    case 2 * 8 + 1: return launch_bwd<2, 1, GMODE, true>(a, s);
+    case 2 * 8 + 2: return launch_bwd<2, 2, GMODE, true>(a, s);
+    default: return PN2_EINVAL;
+  }
 }
 
 template <int GMODE>
@@ -1166,8 +1232,113 @@ extern "C" int pn2_mlp_bwd_bf16(long long M, int N, int K, int gmode, const void
   BwdBf16Args a;
   a.G = (const bf16 *)G; a.Yl = (const bf16 *)Yl; a.consts = consts; a.arg = arg; a.gP = gP; a.Wt = Wt;
   a.Yprev = (const bf16 *)Yprev; a.a_fin = a_fin; a.Gout = (bf16 *)Gout; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K;
-  a.ns = ns;
+  a.ns = ns; a.X = nullptr; a.P1 = nullptr; a.K0 = 0;
   return gmode == PRO_GY ? dispatch_bwd<PRO_GY>(a, (hipStream_t)stream) : dispatch_bwd<PRO_POOLG>(a, (hipStream_t)stream);
+}
+
+// First-layer fold on the bf16 path: as pn2_mlp_bwd_bf16 for the layer above a stack's FIRST layer whose input rows X
+// ([M][8] bf16: K0 <= 8 columns, zero padded) need no gradient — the masked input gradient is not stored, P1 [K][K0] +=
+// its product with X is reduced instead (pn2_first_layer_dw then needs no pass over g and y_0).  N, K in {32, 64}.
+extern "C" int pn2_mlp_bwd_bf16_fold_supported(int N, int K, int K0) {
+  return (N == 32 || N == 64) && (K == 32 || K == 64) && K0 >= 1 && K0 <= 8;
+}
+extern "C" int pn2_mlp_bwd_bf16_fold(long long M, int N, int K, int gmode, const void *G, const void *Yl, const float *consts,
+                                     const int *arg, const float *gP, int ns, const float *Wt, const void *Yprev,
+                                     const float *a_fin, const void *X, int K0, double *sums, float *dW, float *P1,
+                                     void *stream) {
+  if (M < 0 || !pn2_mlp_bwd_bf16_fold_supported(N, K, K0)) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Yl || !consts || !Wt || !Yprev || !a_fin || !X || !sums || !dW || !P1) return PN2_ENULL;
+  if (gmode == PRO_GY && !G) return PN2_ENULL;
+  if (gmode == PRO_POOLG && (!arg || !gP || ns <= 0)) return PN2_ENULL;
+  if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
+  if (((uintptr_t)Yl & 15) || ((uintptr_t)G & 15) || ((uintptr_t)Yprev & 15) || ((uintptr_t)X & 15)) return PN2_EINVAL;
+  BwdBf16Args a;
+  a.G = (const bf16 *)G; a.Yl = (const bf16 *)Yl; a.consts = consts; a.arg = arg; a.gP = gP; a.Wt = Wt;
+  a.Yprev = (const bf16 *)Yprev; a.a_fin = a_fin; a.Gout = nullptr; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K;
+  a.ns = ns; a.X = (const bf16 *)X; a.P1 = P1; a.K0 = K0;
+  return gmode == PRO_GY ? dispatch_bwd_fold<PRO_GY>(a, (hipStream_t)stream)
+                         : dispatch_bwd_fold<PRO_POOLG>(a, (hipStream_t)stream);
+}
+
+namespace {
+// gram[K0*K0] += X^T X, gram[K0*K0 + k] += column sums of X for bf16 rows of pitch 8 (pn2_rows_gram of the fp32 path)
+__global__ __launch_bounds__(256) void rows_gram_bf16_kernel(long long M, int K0, const bf16 *__restrict__ X,
+                                                             double *__restrict__ gram) {
+  __shared__ double part[4][8 * 8 + 8];
+  double ds[8][8], dc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    dc[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ds[i][j] = 0.0;
+  }
+  float sf[8][8], cf[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    cf[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sf[i][j] = 0.f;
+  }
+  int n = 0;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+    const u32x4 w = *(const u32x4 *)(X + (size_t)r * 8);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(w[e]); x[2 * e + 1] = bf_hi(w[e]); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      cf[i] += x[i];
+#pragma unroll
+      for (int j = i; j < 8; ++j) sf[i][j] = fmaf(x[i], x[j], sf[i][j]);
+    }
+    if (++n == 64) {
+      n = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        dc[i] += (double)cf[i]; cf[i] = 0.f;
+#pragma unroll
+        for (int j = i; j < 8; ++j) { ds[i][j] += (double)sf[i][j]; sf[i][j] = 0.f; }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    double v = dc[i] + (double)cf[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) part[wave][64 + i] = v;
+#pragma unroll
+    for (int j = i; j < 8; ++j) {
+      double w2 = ds[i][j] + (double)sf[i][j];
+      for (int o = 32; o > 0; o >>= 1) w2 += __shfl_xor(w2, o);
+      if (lane == 0) part[wave][i * 8 + j] = w2;
+    }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < 72) {
+    const int i = t < 64 ? t / 8 : t - 64, j = t < 64 ? t % 8 : 0;
+    if (t >= 64) {
+      if (i < K0) atomicAdd(gram + K0 * K0 + i, part[0][t] + part[1][t] + part[2][t] + part[3][t]);
+    } else if (i < K0 && j < K0) {
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      const int u = lo * 8 + hi;
+      atomicAdd(gram + i * K0 + j, part[0][u] + part[1][u] + part[2][u] + part[3][u]);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int pn2_rows_gram_bf16(long long M, int K0, const void *X, double *gram, void *stream) {
+  if (M < 0 || K0 < 1 || K0 > 8) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!X || !gram || ((uintptr_t)X & 15)) return PN2_ENULL;
+  long long blocks = (M + 256 * 64 - 1) / (256 * 64);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(rows_gram_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, K0,
+                     (const bf16 *)X, gram);
+  return pn2_check_launch();
 }
 
 extern "C" int pn2_bn_relu_apply_bf16(long long M, int N, const void *y, const float *fin, float *out, void *stream) {

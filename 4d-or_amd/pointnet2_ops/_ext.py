@@ -96,6 +96,9 @@ _SIGNATURES = {
     "pn2_mlp_bwd_fused_fold_first": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 +
                                     [_c_int] + [_c_vp] * 4,
     "pn2_mlp_gemm_bf16": [ctypes.c_longlong] + [_c_int] * 8 + [_c_vp] * 7 + [_c_int] + [_c_vp] * 6,
+    "pn2_mlp_bwd_bf16_fold": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 + [_c_int] +
+                             [_c_vp] * 4,
+    "pn2_rows_gram_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp],
     "pn2_mlp_wgrad_bf16": [ctypes.c_longlong] + [_c_int] * 6 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
     "pn2_bn_relu_apply_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -157,6 +160,8 @@ _lib.pn2_mlp_bwd_bf16_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_bf16_supported.restype = _c_int
 _lib.pn2_mlp_bwd_fused_fold_supported.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_fold_supported.restype = _c_int
+_lib.pn2_mlp_bwd_bf16_fold_supported.argtypes = [_c_int, _c_int, _c_int]
+_lib.pn2_mlp_bwd_bf16_fold_supported.restype = _c_int
 _lib.pn2_mlp_gemm_first_supported.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_mlp_gemm_first_supported.restype = _c_int
 _lib.pn2_pool_bwd_supported.argtypes = [_c_int, _c_int, _c_int]
@@ -179,7 +184,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
-                                               "pn2_mlp_gemm_first_supported",
+                                               "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
                                                "pn2_mlp_bwd_bf16_supported", "pn2_pool_bwd_supported",
                                                "pn2_pool_bwd_workspace_bytes",
                                                "pn2_last_hip_error", "pn2_strerror"])
@@ -1155,6 +1160,28 @@ def mlp_gemm_bf16(X, W, pro=PRO_NONE, epi=EPI_NONE, X2=None, p=None, arg=None, g
           alg_bytes=nbytes, alg_flops=2 * M * N * K,
           tag=(f"M{M},K{K},N{N},pro{int(pro)},epi{int(epi)}" if DETAIL_TAGS else None))
     return Y
+
+
+def mlp_bwd_bf16_fold_supported(N, K, K0):
+    return bool(_lib.pn2_mlp_bwd_bf16_fold_supported(int(N), int(K), int(K0)))
+
+
+def mlp_bwd_bf16_fold(Yl, consts, Wt, Yprev, a_fin, X, K0, gmode, G=None, arg=None, gP=None, ns=0, sums=None, dW=None, P1=None):
+    """mlp_bwd_bf16 for the layer above the first one, X (M, 8) bf16 its input rows without a gradient: no Gout,
+    P1 (K, K0) += gz^T X instead -> (sums, dW, P1)."""
+    M, N = Yl.shape
+    K = Yprev.size(1)
+    _call("pn2_mlp_bwd_bf16_fold", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP), int(ns),
+          _ptr(Wt), _ptr(Yprev), _ptr(a_fin), _ptr(X), int(K0), _ptr(sums), _ptr(dW), _ptr(P1),
+          alg_bytes=2 * (M * N * (2 if gmode == PRO_GY else 1) + M * K + 8 * M) + 4 * N * K, alg_flops=4 * M * N * K,
+          tag=(f"M{M},N{N},K{K},g{int(gmode)},fold{int(K0)}" if DETAIL_TAGS else None))
+    return sums, dW, P1
+
+
+def rows_gram_bf16(X, K0, gram):
+    """gram (K0*K0 + K0,) f64 += [X^T X | column sums] for bf16 rows X (M, 8) with K0 real columns."""
+    _call("pn2_rows_gram_bf16", X, X.size(0), int(K0), _ptr(X), _ptr(gram), alg_bytes=16 * X.size(0))
+    return gram
 
 
 def mlp_wgrad_bf16(Yl, consts, X, gmode, amode, K, G=None, arg=None, gP=None, ns=0, a_fin=None, dW=None):

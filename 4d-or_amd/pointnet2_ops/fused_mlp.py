@@ -43,6 +43,8 @@ if _os.environ.get("PN2_POOL_FUSED") == "0":
 #: statistics come from the 8 x 8 Gram matrix of the rows, the second layer recomputes it while staging its A tiles
 #: (pn2_mlp_gemm_first) and so does the backward (pn2_mlp_bwd_fused_fold_first)
 FIRST_FREE = True
+#: bf16 path: first-layer fold of the backward (pn2_mlp_bwd_bf16_fold); PN2_BF16_FOLD=0 switches it off for an A/B
+BF16_FOLD = _os.environ.get("PN2_BF16_FOLD") != "0"
 if _os.environ.get("PN2_FIRST_FREE") == "0":
     FIRST_FREE = False
 
@@ -426,8 +428,16 @@ class _FusedMLPBf16(Function):
         g_out = g_out.contiguous()
         f64, f32 = torch.float64, torch.float32
         need_dgrad0 = ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None)
+        # first-layer fold (csrc/mlp_bf16.hip, FOLD): as on the fp32 path — the layer above the first one reduces gz^T X
+        # instead of storing gz when the (<= 8-column, bf16, pitch 8) input rows need no gradient
+        k_in = ctx.k_in
+        fold = bool(BF16_FOLD and L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0]
+                    and x.dtype == torch.bfloat16 and x.size(1) == 8 and k_in <= 8
+                    and getattr(e, "mlp_bwd_bf16_fold", None)
+                    and e.mlp_bwd_bf16_fold_supported(Ws[1].size(0), Ws[1].size(1), k_in))
         arena = e.zero_arena(x.device, [((2, Ws[-1].size(0)), f64)] + [((2, Ws[l].size(1)), f64) for l in range(L)] +
-                             [(tuple(Ws[l].shape), f32) for l in range(L)])
+                             [(tuple(Ws[l].shape), f32) for l in range(L)] +
+                             ([((Ws[0].size(0), k_in), f32), ((k_in * k_in + k_in,), f64)] if fold else []))
         sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:1 + 2 * L]
         if ns:
             pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
@@ -436,6 +446,7 @@ class _FusedMLPBf16(Function):
         else:
             G, sums = e.bn_relu_bwd_prep_bf16(ys[-1], g_out, fins[-1], sums=sums0)
             gmode, arg, gPm = e.PRO_GY, None, None
+        P1 = None
 
         grads = [None] * (3 * L)
         gx = None
@@ -448,6 +459,16 @@ class _FusedMLPBf16(Function):
             else:
                 consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            if l == 1 and fold:
+                sums, dW, P1 = e.mlp_bwd_bf16_fold(ys[1], consts, Wt, ys[0], fins[0], x, k_in, gmode, G=G, arg=arg, gP=gPm, ns=ns,
+                                                   sums=sums_in[1], dW=dWs[1], P1=arena[1 + 2 * L])
+                grads[3] = dW.view(ctx.shapes[1])
+                gmode, arg, gPm, G = e.PRO_GY, None, None, None
+                continue
+            if l == 0 and fold:
+                gram = e.rows_gram_bf16(x, k_in, arena[2 + 2 * L])
+                grads[0] = e.first_layer_dw(consts, P1, Ws[0].contiguous(), gram).view(ctx.shapes[0])
+                continue
             if l > 0 and FUSED_BACKWARD and e.mlp_bwd_bf16_supported(Ws[l].size(0), Ws[l].size(1)):
                 # hidden layer: dgrad + wgrad from one read of (g, y_l, y_{l-1})
                 G, sums, dW = e.mlp_bwd_bf16(ys[l], consts, Wt, ys[l - 1], fins[l - 1], gmode, G=G, arg=arg, gP=gPm, ns=ns,

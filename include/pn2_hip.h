@@ -390,6 +390,15 @@ int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, const float
  *     (gpre bf16); pooled outputs, arg-max and raw arg-max values stay fp32 / int32 (C % 2 == 0).
  *   pn2_group_concat_rows_bf16: pn2_group_concat_rows writing bf16 rows of pitch ldo (% 8 == 0), pad columns zeroed.
  */
+/* First-layer fold on the bf16 path (round 3): pn2_mlp_bwd_bf16 for the layer above a stack's FIRST layer whose input rows
+ * X ([M][8] bf16: K0 <= 8 columns, zero padded — what pn2_group_concat_rows_bf16 writes) need no gradient: the masked input
+ * gradient is not stored, P1 [K][K0] += its product with X is reduced instead; pn2_rows_gram_bf16 + pn2_first_layer_dw then
+ * give the first layer's weight gradient without a pass over g and y_0.  N, K in {32, 64}. */
+int pn2_mlp_bwd_bf16_fold_supported(int N, int K, int K0);
+int pn2_mlp_bwd_bf16_fold(long long M, int N, int K, int gmode, const void *G, const void *Yl, const float *consts,
+                          const int *arg, const float *gP, int ns, const float *Wt, const void *Yprev,
+                          const float *a_fin, const void *X, int K0, double *sums, float *dW, float *P1, void *stream);
+int pn2_rows_gram_bf16(long long M, int K0, const void *X, double *gram, void *stream);
 int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
                       const void *X, const void *X2, const float *p0, const float *p1, const float *p2,
                       const int *arg, const float *gP, int ns, const float *W, void *Y, double *stats,

@@ -214,6 +214,48 @@ def test_one_pass_backward_bf16_equals_the_two_kernels(M, N, K, ns, pooled):
     torch.testing.assert_close(sums[1], (o * ((yprev.float() - fin[0]) * fin[1]).double()).sum(0), rtol=1e-4, atol=1e-5 * M)
 
 
+@pytest.mark.parametrize("M,N,K,K0,ns", [(3000, 64, 64, 6, 16), (2500, 64, 32, 3, 32), (1999, 32, 64, 8, 64), (777, 32, 32, 7, 16),
+                                         (64 * 700, 64, 64, 6, 64)])
+@pytest.mark.parametrize("pooled", [False, True])
+def test_one_pass_backward_bf16_with_the_first_layer_fold(M, N, K, K0, ns, pooled):
+    """pn2_mlp_bwd_bf16_fold == pn2_mlp_bwd_bf16 without the stored input gradient: same column sums and weight gradient,
+    P1 = Gout^T X of the gradient the plain kernel stores; pn2_rows_gram_bf16 == the Gram matrix of the rows."""
+    from pointnet2_ops import _ext as e
+    assert e.mlp_bwd_bf16_fold_supported(N, K, K0)
+    g = torch.Generator().manual_seed(M + N + K + K0)
+    M = M // ns * ns if pooled else M
+    y = torch.randn(M, N, generator=g).to(BF).cuda()
+    yprev = torch.randn(M, K, generator=g).to(BF).cuda()
+    X = torch.zeros(M, 8)
+    X[:, :K0] = torch.randn(M, K0, generator=g) + 0.3
+    X = X.to(BF).cuda()
+    Wt = (torch.randn(N, K, generator=g) / N ** 0.5).cuda().t().contiguous()
+    c = torch.stack([torch.randn(N, generator=g), torch.randn(N, generator=g) * 0.1, torch.randn(N, generator=g) * 0.05]).cuda()
+    fin = torch.stack([torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5, torch.rand(K, generator=g) + 0.5,
+                       torch.randn(K, generator=g) * 0.3]).cuda().contiguous()
+    if pooled:
+        R = M // ns
+        arg = torch.randint(0, ns, (R, N), generator=g, dtype=torch.int32).cuda()
+        gP, G, gmode = torch.randn(R, N, generator=g).cuda(), None, e.PRO_POOLG
+    else:
+        G, arg, gP, gmode = torch.randn(M, N, generator=g).to(BF).cuda(), None, None, e.PRO_GY
+    Gout, sums, dW = e.mlp_bwd_bf16(y, c, Wt, yprev, fin, gmode, G=G, arg=arg, gP=gP, ns=ns if pooled else 0)
+    s2 = torch.zeros(2, K, dtype=torch.float64, device="cuda")
+    dW2 = torch.zeros(N, K, device="cuda")
+    P1 = torch.zeros(K, K0, device="cuda")
+    e.mlp_bwd_bf16_fold(y, c, Wt, yprev, fin, X, K0, gmode, G=G, arg=arg, gP=gP, ns=ns if pooled else 0, sums=s2, dW=dW2, P1=P1)
+    torch.testing.assert_close(s2, sums, rtol=1e-4, atol=1e-5 * M)
+    _close(dW2, dW, rel=1e-3, what="dW")
+    want = Gout.float().t().double() @ X.float()[:, :K0].double()
+    scale = float(want.abs().max()) + 1e-9
+    assert float((P1.double() - want).abs().max()) <= 2e-4 * scale
+    gram = torch.zeros(K0 * K0 + K0, dtype=torch.float64, device="cuda")
+    e.rows_gram_bf16(X, K0, gram)
+    Xd = X.float()[:, :K0].double()
+    torch.testing.assert_close(gram[:K0 * K0].view(K0, K0), Xd.t() @ Xd, rtol=1e-5, atol=1e-6 * M)
+    torch.testing.assert_close(gram[K0 * K0:], Xd.sum(0), rtol=1e-5, atol=1e-6 * M)
+
+
 @pytest.mark.parametrize("B,N,m,ns", [(3, 700, 40, 16), (2, 300, 37, 11), (5, 90, 3, 9), (2, 256, 21, 6)])
 def test_group_concat_rows_bf16_matches_fp32_kernel(B, N, m, ns):
     from pointnet2_ops import _ext as e
