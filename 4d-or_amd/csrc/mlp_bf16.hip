@@ -67,13 +67,33 @@ struct GemmBf16Args {
   int Nfull;          // stride of the per-column vectors (stats, e_fin): the full output width when N is a column block
   int Kp;             // K rounded up to KC
   int wres;           // weights resident in LDS
+  // Batched scans with PER-SCAN statistics (segment table): blockIdx.y = scan s owns rows [seg[s], seg[s+1]) and its own
+  // block of every per-channel array — p0/p1/p2 + s*pstride, stats + s*sstride, e_fin + s*estride; W is shared.
+  const long long *seg;
+  long long seg_max;  // host: rows of the longest segment (grid)
+  int nseg, pstride, sstride, estride;
+  int vcap;           // the persistent grid a call of ONE scan would get at most (see the virtual workgroups of the kernel)
 };
 
 // ---------------------------------------------------------------------------------------------- forward / dgrad
 // Workgroup = 4 x CW waves: wave (wr, wc) owns rows wr*32.. of the 128-row tile and the NT 32-column tiles wc*NT.. .
 // CW = 2 keeps the accumulators of N > 128 within 128 VGPRs per lane (two workgroups of 8 waves per CU).
 template <int NT, int CW, int PRO, int EPI, bool XF32, bool YF32>
-__global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf16Args a) {
+__global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf16Args a_in) {
+  GemmBf16Args a = a_in;
+  if (a.seg) {                                      // this workgroup's scan: shift every row / per-channel pointer
+    const int sg = blockIdx.y;
+    const long long r0 = a.seg[sg];
+    a.M = a.seg[sg + 1] - r0;
+    a.X = (const char *)a.X + (size_t)r0 * a.ldx * (XF32 ? 4 : 2);
+    a.Y = (char *)a.Y + (size_t)r0 * a.ldy * (YF32 ? 4 : 2);
+    if constexpr (PRO == PRO_GY || PRO == PRO_POOLG) a.X2 += (size_t)r0 * a.ldx;
+    if constexpr (PRO == PRO_POOLG) { a.arg += (size_t)(r0 / a.ns) * a.K; a.gP += (size_t)(r0 / a.ns) * a.K; }
+    if constexpr (PRO != PRO_NONE) { a.p0 += (size_t)sg * a.pstride; a.p1 += (size_t)sg * a.pstride; }
+    if constexpr (PRO == PRO_GY || PRO == PRO_POOLG) a.p2 += (size_t)sg * a.pstride;
+    if constexpr (EPI != EPI_NONE) a.stats += (size_t)sg * a.sstride;
+    if constexpr (EPI == EPI_MASK) { a.Yprev += (size_t)r0 * a.ldy; a.e_fin += (size_t)sg * a.estride; }
+  }
   constexpr int NTH = 256 * CW;                     // threads
   constexpr int NTT = NT * CW;                      // column tiles of the workgroup
   // LDS: [ W tile | prologue parameters | A chunk, re-used by the ReLU-backward epilogue as the y_{l-1} / output tile ]
@@ -135,7 +155,6 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
   float s1[NT], s2[NT], e_mean[NT], e_rstd[NT], e_sc[NT], e_sh[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    s1[nt] = s2[nt] = 0.f;
     const int c = (wc * NT + nt) * 32 + (lane & 31);
     if constexpr (EPI == EPI_MASK) {
       const bool ok = c < N;
@@ -153,7 +172,17 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
   const int lr = tid / (2 * CW), lk = (tid % (2 * CW)) * (8 * J);
   const int xs = XF32 ? 4 : 2;
 
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Virtual workgroups: the fp32 column sums are grouped per workgroup (tiles w, w + grid, ...) before they meet in fp64 —
+  // a scan of a segmented call keeps the grouping its OWN call would have (grid = min(vcap, its tiles)): this workgroup
+  // plays the virtual workgroups blockIdx.x, blockIdx.x + gridDim.x, ... of that grid one after the other, each with its
+  // own sums and flush, so the scan's statistics — and every bf16 rounding downstream — are those of the single-scan
+  // call.  Without a table: one virtual workgroup = this one.
+  const int vstride = a.seg ? (int)(ntiles < a.vcap ? ntiles : a.vcap) : (int)gridDim.x;
+  for (int vwg = blockIdx.x; vwg < vstride; vwg += gridDim.x) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
+
+  for (long long tile = vwg; tile < ntiles; tile += vstride) {
     const long long row0 = tile * TM;
     const long long rows_left = a.M - row0;
     const rsrc_t rX = make_rsrc((const char *)a.X + (size_t)row0 * a.ldx * xs, rows_left * a.ldx * xs);
@@ -342,7 +371,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
   if constexpr (EPI != EPI_NONE) {
     // lanes l and l+32 hold the same column; 4 waves hold different rows: reduce through LDS, one fp64 atomic per column
     __syncthreads();
-    float *red = (float *)smem;                      // [2][4][NTT*32]
+    float *red = (float *)sA;                        // [2][4][NTT*32] <= 10 KB of the 18 KB A chunk (the weights stay)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const float t1 = s1[nt] + __shfl_xor(s1[nt], 32);
@@ -361,6 +390,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
       }
     }
   }
+  }   // virtual workgroups (the next one's first chunk commit follows a barrier)
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient
@@ -380,13 +410,29 @@ struct WgradBf16Args {
   float *dW;          // [N][K] ACCUMULATES
   long long M;
   int N, K, ldx, ns;
+  // segment table (see GemmBf16Args): blockIdx.z = scan; consts + s*3N, a_fin + s*4K; dW is the scans' SUM
+  const long long *seg;
+  long long seg_max;
+  int nseg;
 };
 
 template <int MT>
 __device__ __forceinline__ int swz(int feature, int m) { return m ^ (((feature >> 3) & (MT / 8 - 1)) << 3); }
 
 template <int NTW, int KTB, int MT, int GMODE, int AMODE, bool XF32>
-__global__ __launch_bounds__(256, 2) void mlp_wgrad_bf16_kernel(const WgradBf16Args a) {
+__global__ __launch_bounds__(256, 2) void mlp_wgrad_bf16_kernel(const WgradBf16Args a_in) {
+  WgradBf16Args a = a_in;
+  if (a.seg) {
+    const int sg = blockIdx.z;
+    const long long r0 = a.seg[sg];
+    a.M = a.seg[sg + 1] - r0;
+    a.Yl += (size_t)r0 * a.N;
+    if constexpr (GMODE == PRO_GY) a.G += (size_t)r0 * a.N;
+    if constexpr (GMODE == PRO_POOLG) { a.arg += (size_t)(r0 / a.ns) * a.N; a.gP += (size_t)(r0 / a.ns) * a.N; }
+    a.X = (const char *)a.X + (size_t)r0 * a.ldx * (XF32 ? 4 : 2);
+    a.consts += (size_t)sg * 3 * a.N;
+    if constexpr (AMODE == PRO_BNRELU) a.a_fin += (size_t)sg * 4 * a.K;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MP = MT + 8;                          // pitch in bf16 elements
   constexpr int NB = 4 * NTW * 32;                    // gy features held (>= N)
@@ -587,10 +633,29 @@ struct BwdBf16Args {
   const bf16 *X;
   float *P1;
   int K0;
+  // segment table (see GemmBf16Args): blockIdx.y = scan; consts + s*3N, a_fin + s*4K, sums + s*2K; dW is the scans' SUM
+  const long long *seg;
+  long long seg_max;
+  int nseg;
+  int vcap;                 // grid cap of a single-scan call (virtual workgroups, see mlp_gemm_bf16_kernel)
 };
 
 template <int NTN, int KTK, int GMODE, bool FOLD = false>
-__global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args a) {
+__global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args a_in) {
+  BwdBf16Args a = a_in;
+  if (a.seg) {
+    const int sg = blockIdx.y;
+    const long long r0 = a.seg[sg];
+    a.M = a.seg[sg + 1] - r0;
+    a.Yl += (size_t)r0 * a.N;
+    if constexpr (GMODE == PRO_GY) a.G += (size_t)r0 * a.N;
+    if constexpr (GMODE == PRO_POOLG) { a.arg += (size_t)(r0 / a.ns) * a.N; a.gP += (size_t)(r0 / a.ns) * a.N; }
+    a.Yprev += (size_t)r0 * a.K;
+    if constexpr (!FOLD) a.Gout += (size_t)r0 * a.K;
+    a.consts += (size_t)sg * 3 * a.N;
+    a.a_fin += (size_t)sg * 4 * a.K;
+    a.sums += (size_t)sg * 2 * a.K;
+  }
   constexpr int MT = 64, MP = MT + 8;
   constexpr int NB = NTN * 32, KB = KTK * 32, NP = NB + 8, KP = KB + 8;
   constexpr int DT = (2 * KTK + 7) / 8;              // dgrad tiles per wave
@@ -640,8 +705,6 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
 #pragma unroll
     for (int e = 0; e < 16; ++e) accw[i][e] = 0.f;
   float s1[DT], s2[DT];
-#pragma unroll
-  for (int i = 0; i < DT; ++i) s1[i] = s2[i] = 0.f;
   float px[FOLD ? DT : 1][8];
 #pragma unroll
   for (int i = 0; i < (FOLD ? DT : 1); ++i)
@@ -683,9 +746,14 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
     }
   };
 
-  long long tile = blockIdx.x;
+  // virtual workgroups: a scan of a segmented call keeps the per-workgroup grouping of ITS OWN call's column sums
+  const int vstride = a.seg ? (int)(ntiles < a.vcap ? ntiles : a.vcap) : (int)gridDim.x;
+  for (int vwg = blockIdx.x; vwg < vstride; vwg += gridDim.x) {
+#pragma unroll
+  for (int i = 0; i < DT; ++i) s1[i] = s2[i] = 0.f;
+  long long tile = vwg;
   if (tile < ntiles) issue(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile += vstride) {
     const long long row0 = tile * MT;
     __syncthreads();                                 // previous tile: MFMA reads and the output store are done
     if constexpr (FOLD) {
@@ -761,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
       }
     }
     __syncthreads();
-    if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);   // next tile's loads fly behind this tile's MFMAs
+    if (tile + vstride < ntiles) issue(tile + vstride);       // next tile's loads fly behind this tile's MFMAs
 
     // ---- dgrad tiles of this wave
 #pragma unroll
@@ -833,9 +901,9 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
     }
   }
 
-  // ---- flush: column sums (LDS reduction over the waves that share a column tile) and dW
+  // ---- flush: column sums (LDS reduction over the waves that share a column tile); dW after the last virtual workgroup
   __syncthreads();
-  float *red = (float *)smem;                                  // [2][KB], zeroed
+  float *red = (float *)sGY;                                   // [2][KB], zeroed (<= 1 KB of the gy tile; the weights stay)
   for (int i = tid; i < 2 * KB; i += 512) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
@@ -849,6 +917,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args 
   }
   __syncthreads();
   for (int i = tid; i < 2 * KB; i += 512) atomicAdd(a.sums + (size_t)(i / KB) * K + (i % KB), (double)red[i]);
+  }   // virtual workgroups
   if constexpr (FOLD) {
     __syncthreads();
     float *redP = sXr;                                         // [KB][8]
@@ -896,10 +965,15 @@ int launch_bwd(const BwdBf16Args &a, hipStream_t s) {
       return pn2_check_launch();
     big_lds = true;
   }
-  const long long ntiles = (a.M + MT - 1) / MT;
+  const long long ntiles = ((a.seg ? a.seg_max : a.M) + MT - 1) / MT;
   long long grid = lds > 80 * 1024 ? 256 : 512;
+  BwdBf16Args b = a;
+  b.vcap = (int)grid;
+  const int nseg = a.seg ? a.nseg : 1;
+  if (nseg > 1) grid = (grid + nseg - 1) / nseg;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), lds, s, a);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)grid, (unsigned)nseg), dim3(512), lds, s, b);
   return pn2_check_launch();
 }
 
@@ -986,8 +1060,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_prep_bf16_kernel(long long M,
 __global__ __launch_bounds__(256) void bn_relu_rows_max_bf16_kernel(size_t total /* R*C/2 */, int ns, int C,
                                                                    const bf16 *__restrict__ y,
                                                                    const float *__restrict__ fin, float *__restrict__ out,
-                                                                   int *__restrict__ arg, float *__restrict__ yraw) {
+                                                                   int *__restrict__ arg, float *__restrict__ yraw,
+                                                                   const long long *__restrict__ seg) {
   const int CV = C / 2;
+  if (seg) {                                         // blockIdx.y = scan: its groups and its (4,C) finalize block
+    const size_t g0 = (size_t)(seg[blockIdx.y] / ns);
+    total = ((size_t)(seg[blockIdx.y + 1] / ns) - g0) * CV;
+    y += g0 * ns * C; out += g0 * C; arg += g0 * C; yraw += g0 * C;
+    fin += (size_t)blockIdx.y * 4 * C;
+  }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const size_t r = e / CV;
     const int c = (int)(e - r * CV) * 2;
@@ -1056,10 +1137,14 @@ int launch_gemm(GemmBf16Args a, hipStream_t s) {
       return pn2_check_launch();
     big_lds = true;
   }
-  const long long ntiles = (a.M + TM - 1) / TM;
+  const long long ntiles = ((a.seg ? a.seg_max : a.M) + TM - 1) / TM;
   long long grid = lds > 80 * 1024 ? 256 : 512;             // persistent: as many workgroups per CU as the LDS admits
+  a.vcap = (int)grid;
+  const int nseg = a.seg ? a.nseg : 1;
+  if (nseg > 1) grid = (grid + nseg - 1) / nseg;            // (the scans share the chip)
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256 * CW), lds, s, a);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)grid, (unsigned)nseg), dim3(256 * CW), lds, s, a);
   return pn2_check_launch();
 }
 
@@ -1090,11 +1175,13 @@ int launch_wgrad(const WgradBf16Args &a, hipStream_t s) {
     big_lds = true;
   }
   const unsigned kblocks = (unsigned)((a.K + KB - 1) / KB);
-  const long long ntiles = (a.M + MT - 1) / MT;
-  long long gx = 512 / kblocks;
+  const long long ntiles = ((a.seg ? a.seg_max : a.M) + MT - 1) / MT;
+  const int nseg = a.seg ? a.nseg : 1;
+  long long gx = 512 / kblocks / nseg;
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)gx, kblocks), dim3(256), lds, s, a);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)gx, kblocks, (unsigned)nseg), dim3(256), lds, s, a);
   return pn2_check_launch();
 }
 
@@ -1120,10 +1207,13 @@ int pn2_mlp_gemm_bf16_block(GemmBf16Args a, int n0, int nb, int ys, int pro, int
 
 }  // namespace
 
-extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
-                                 const void *X, const void *X2, const float *p0, const float *p1, const float *p2,
-                                 const int *arg, const float *gP, int ns, const float *W, void *Y, double *stats,
-                                 const void *Yprev, const float *e_fin, void *stream) {
+namespace {
+struct SegTab { const long long *ptr; int nseg; long long max_rows; int pstride; };
+
+int gemm_bf16_impl(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
+                   const void *X, const void *X2, const float *p0, const float *p1, const float *p2,
+                   const int *arg, const float *gP, int ns, const float *W, void *Y, double *stats,
+                   const void *Yprev, const float *e_fin, const SegTab &sg, void *stream) {
   if (M < 0 || K <= 0 || N <= 0 || K > 4096 || ldx < K || ldy < N) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!W || !Y) return PN2_ENULL;
@@ -1140,6 +1230,8 @@ extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, in
   a.X = X; a.X2 = (const bf16 *)X2; a.p0 = p0; a.p1 = p1; a.p2 = p2; a.arg = arg; a.gP = gP; a.W = W; a.Y = Y;
   a.stats = stats; a.Yprev = (const bf16 *)Yprev; a.e_fin = e_fin; a.M = M; a.K = K; a.N = N; a.ldx = ldx; a.ldy = ldy;
   a.ns = ns; a.Kp = (K + KC - 1) / KC * KC; a.wres = 0; a.Nfull = N;
+  a.seg = sg.ptr; a.nseg = sg.nseg; a.seg_max = sg.max_rows; a.pstride = sg.pstride; a.sstride = 2 * N; a.estride = 4 * N;
+  a.vcap = 0;
   hipStream_t s = (hipStream_t)stream;
   // Column blocks (A re-read per block, the second time from L2) in two cases: outputs wider than the 320 columns a
   // workgroup covers (the input gradient of a 512-column FP stack), and weights that do not fit LDS at full width — a
@@ -1158,6 +1250,31 @@ extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, in
     return PN2_OK;
   }
   return pn2_mlp_gemm_bf16_block(a, 0, N, y_f32 ? 4 : 2, pro, epi, x_f32, y_f32, s);
+}
+}  // namespace
+
+extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
+                                 const void *X, const void *X2, const float *p0, const float *p1, const float *p2,
+                                 const int *arg, const float *gP, int ns, const float *W, void *Y, double *stats,
+                                 const void *Yprev, const float *e_fin, void *stream) {
+  return gemm_bf16_impl(M, K, N, pro, epi, x_f32, y_f32, ldx, ldy, X, X2, p0, p1, p2, arg, gP, ns, W, Y, stats, Yprev, e_fin,
+                        SegTab{nullptr, 1, 0, 0}, stream);
+}
+
+// Batched scans with per-scan BatchNorm statistics in ONE launch: the M rows are nseg scans, scan s = rows
+// [seg[s], seg[s+1]) (device array of nseg + 1 offsets, multiples of ns for PRO_POOLG; seg_max = the longest scan, for the
+// grid); every per-channel operand is an array of per-scan blocks — p0 / p1 / p2 at a pitch of `pstride` floats (forward:
+// the scale / shift rows of the (S,4,K) finalize blocks, pstride = 4K; backward: the (S,3,K) constants, 3K), stats
+// (S,2,N), e_fin (S,4,N).  Same arithmetic per scan as nseg separate calls (tiles never straddle two scans).
+extern "C" int pn2_mlp_gemm_bf16_seg(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
+                                     const void *X, const void *X2, const float *p0, const float *p1, const float *p2,
+                                     int pstride, const int *arg, const float *gP, int ns, const float *W, void *Y,
+                                     double *stats, const void *Yprev, const float *e_fin, const long long *seg, int nseg,
+                                     long long seg_max, void *stream) {
+  if (!seg) return PN2_ENULL;
+  if (nseg < 1 || nseg > 65535 || seg_max < 0 || seg_max > M) return PN2_EINVAL;
+  return gemm_bf16_impl(M, K, N, pro, epi, x_f32, y_f32, ldx, ldy, X, X2, p0, p1, p2, arg, gP, ns, W, Y, stats, Yprev, e_fin,
+                        SegTab{seg, nseg, seg_max, pstride}, stream);
 }
 
 namespace {
@@ -1189,9 +1306,10 @@ int pn2_mlp_gemm_bf16_block(GemmBf16Args a, int n0, int nb, int ys, int pro, int
 }
 }  // namespace
 
-extern "C" int pn2_mlp_wgrad_bf16(long long M, int N, int K, int gmode, int amode, int x_f32, int ldx, const void *G,
-                                  const void *Yl, const float *consts, const int *arg, const float *gP, int ns,
-                                  const void *X, const float *a_fin, float *dW, void *stream) {
+namespace {
+int wgrad_bf16_impl(long long M, int N, int K, int gmode, int amode, int x_f32, int ldx, const void *G,
+                    const void *Yl, const float *consts, const int *arg, const float *gP, int ns,
+                    const void *X, const float *a_fin, float *dW, const SegTab &sg, void *stream) {
   if (M < 0 || N <= 0 || K <= 0 || N > 384 || N % 8 != 0 || ldx < K) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!Yl || !consts || !X || !dW) return PN2_ENULL;
@@ -1204,6 +1322,7 @@ extern "C" int pn2_mlp_wgrad_bf16(long long M, int N, int K, int gmode, int amod
   WgradBf16Args a;
   a.G = (const bf16 *)G; a.Yl = (const bf16 *)Yl; a.consts = consts; a.arg = arg; a.gP = gP; a.X = X; a.a_fin = a_fin;
   a.dW = dW; a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ns = ns;
+  a.seg = sg.ptr; a.nseg = sg.nseg; a.seg_max = sg.max_rows;
   hipStream_t s = (hipStream_t)stream;
   if (gmode == PRO_GY) {
     if (amode == PRO_BNRELU) return dispatch_wgrad<PRO_GY, PRO_BNRELU, false>(a, s);
@@ -1211,6 +1330,26 @@ extern "C" int pn2_mlp_wgrad_bf16(long long M, int N, int K, int gmode, int amod
   }
   if (amode == PRO_BNRELU) return dispatch_wgrad<PRO_POOLG, PRO_BNRELU, false>(a, s);
   return x_f32 ? dispatch_wgrad<PRO_POOLG, PRO_NONE, true>(a, s) : dispatch_wgrad<PRO_POOLG, PRO_NONE, false>(a, s);
+}
+}  // namespace
+
+extern "C" int pn2_mlp_wgrad_bf16(long long M, int N, int K, int gmode, int amode, int x_f32, int ldx, const void *G,
+                                  const void *Yl, const float *consts, const int *arg, const float *gP, int ns,
+                                  const void *X, const float *a_fin, float *dW, void *stream) {
+  return wgrad_bf16_impl(M, N, K, gmode, amode, x_f32, ldx, G, Yl, consts, arg, gP, ns, X, a_fin, dW, SegTab{nullptr, 1, 0, 0},
+                         stream);
+}
+
+// pn2_mlp_wgrad_bf16 over nseg scans (see pn2_mlp_gemm_bf16_seg): consts (S,3,N), a_fin (S,4,K); dW [N][K] receives the SUM
+// over the scans (the step's loss is the mean of the scans' losses; its 1/S is part of the incoming gradient).
+extern "C" int pn2_mlp_wgrad_bf16_seg(long long M, int N, int K, int gmode, int amode, int x_f32, int ldx, const void *G,
+                                      const void *Yl, const float *consts, const int *arg, const float *gP, int ns,
+                                      const void *X, const float *a_fin, float *dW, const long long *seg, int nseg,
+                                      long long seg_max, void *stream) {
+  if (!seg) return PN2_ENULL;
+  if (nseg < 1 || nseg > 65535 || seg_max < 0 || seg_max > M) return PN2_EINVAL;
+  return wgrad_bf16_impl(M, N, K, gmode, amode, x_f32, ldx, G, Yl, consts, arg, gP, ns, X, a_fin, dW,
+                         SegTab{seg, nseg, seg_max, 0}, stream);
 }
 
 extern "C" int pn2_mlp_bwd_bf16_supported(int N, int K) {
@@ -1233,6 +1372,28 @@ extern "C" int pn2_mlp_bwd_bf16(long long M, int N, int K, int gmode, const void
   a.G = (const bf16 *)G; a.Yl = (const bf16 *)Yl; a.consts = consts; a.arg = arg; a.gP = gP; a.Wt = Wt;
   a.Yprev = (const bf16 *)Yprev; a.a_fin = a_fin; a.Gout = (bf16 *)Gout; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K;
   a.ns = ns; a.X = nullptr; a.P1 = nullptr; a.K0 = 0;
+  a.seg = nullptr; a.nseg = 1; a.seg_max = 0;
+  return gmode == PRO_GY ? dispatch_bwd<PRO_GY>(a, (hipStream_t)stream) : dispatch_bwd<PRO_POOLG>(a, (hipStream_t)stream);
+}
+
+// pn2_mlp_bwd_bf16 over nseg scans (see pn2_mlp_gemm_bf16_seg): consts (S,3,N), a_fin (S,4,K), sums (S,2,K); dW = the SUM.
+extern "C" int pn2_mlp_bwd_bf16_seg(long long M, int N, int K, int gmode, const void *G, const void *Yl, const float *consts,
+                                    const int *arg, const float *gP, int ns, const float *Wt, const void *Yprev,
+                                    const float *a_fin, void *Gout, double *sums, float *dW, const long long *seg, int nseg,
+                                    long long seg_max, void *stream) {
+  if (M < 0 || !pn2_mlp_bwd_bf16_supported(N, K)) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Yl || !consts || !Wt || !Yprev || !a_fin || !Gout || !sums || !dW || !seg) return PN2_ENULL;
+  if (nseg < 1 || nseg > 65535 || seg_max < 0 || seg_max > M) return PN2_EINVAL;
+  if (gmode == PRO_GY && !G) return PN2_ENULL;
+  if (gmode == PRO_POOLG && (!arg || !gP || ns <= 0)) return PN2_ENULL;
+  if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
+  if (((uintptr_t)Yl & 15) || ((uintptr_t)G & 15) || ((uintptr_t)Yprev & 15) || ((uintptr_t)Gout & 15)) return PN2_EINVAL;
+  BwdBf16Args a;
+  a.G = (const bf16 *)G; a.Yl = (const bf16 *)Yl; a.consts = consts; a.arg = arg; a.gP = gP; a.Wt = Wt;
+  a.Yprev = (const bf16 *)Yprev; a.a_fin = a_fin; a.Gout = (bf16 *)Gout; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K;
+  a.ns = ns; a.X = nullptr; a.P1 = nullptr; a.K0 = 0;
+  a.seg = seg; a.nseg = nseg; a.seg_max = seg_max;
   return gmode == PRO_GY ? dispatch_bwd<PRO_GY>(a, (hipStream_t)stream) : dispatch_bwd<PRO_POOLG>(a, (hipStream_t)stream);
 }
 
@@ -1257,6 +1418,7 @@ extern "C" int pn2_mlp_bwd_bf16_fold(long long M, int N, int K, int gmode, const
   a.G = (const bf16 *)G; a.Yl = (const bf16 *)Yl; a.consts = consts; a.arg = arg; a.gP = gP; a.Wt = Wt;
   a.Yprev = (const bf16 *)Yprev; a.a_fin = a_fin; a.Gout = nullptr; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K;
   a.ns = ns; a.X = (const bf16 *)X; a.P1 = P1; a.K0 = K0;
+  a.seg = nullptr; a.nseg = 1; a.seg_max = 0;
   return gmode == PRO_GY ? dispatch_bwd_fold<PRO_GY>(a, (hipStream_t)stream)
                          : dispatch_bwd_fold<PRO_POOLG>(a, (hipStream_t)stream);
 }
@@ -1371,11 +1533,18 @@ namespace {
 __global__ __launch_bounds__(256) void bn_relu_rows_max_bf16_v8_kernel(size_t total /* R*C/8 */, int ns, int C,
                                                                       const bf16 *__restrict__ y,
                                                                       const float *__restrict__ fin, float *__restrict__ out,
-                                                                      int *__restrict__ arg, float *__restrict__ yraw) {
+                                                                      int *__restrict__ arg, float *__restrict__ yraw,
+                                                                      const long long *__restrict__ seg) {
   typedef unsigned u4v __attribute__((ext_vector_type(4)));
   typedef float f4v __attribute__((ext_vector_type(4)));
   typedef int i4v __attribute__((ext_vector_type(4)));
   const int CV = C / 8;
+  if (seg) {                                         // blockIdx.y = scan: its groups and its (4,C) finalize block
+    const size_t g0 = (size_t)(seg[blockIdx.y] / ns);
+    total = ((size_t)(seg[blockIdx.y + 1] / ns) - g0) * CV;
+    y += g0 * ns * C; out += g0 * C; arg += g0 * C; yraw += g0 * C;
+    fin += (size_t)blockIdx.y * 4 * C;
+  }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const size_t r = e / CV;
     const int c = (int)(e - r * CV) * 8;
@@ -1411,19 +1580,37 @@ __global__ __launch_bounds__(256) void bn_relu_rows_max_bf16_v8_kernel(size_t to
 }
 }  // namespace
 
-extern "C" int pn2_bn_relu_rows_max_bf16(long long R, int ns, int C, const void *y, const float *fin, float *out,
-                                         int *arg, float *yraw, void *stream) {
+namespace {
+int rows_max_bf16_impl(long long R, int ns, int C, const void *y, const float *fin, float *out, int *arg, float *yraw,
+                       const long long *seg, int nseg, long long seg_max, void *stream) {
   if (R < 0 || ns <= 0 || C <= 0 || C % 2 != 0) return PN2_EINVAL;
   if (R == 0) return PN2_OK;
   if (!y || !fin || !out || !arg || !yraw) return PN2_ENULL;
+  const size_t Rg = seg ? (size_t)(seg_max / ns) : (size_t)R;           // groups a grid row covers
+  const unsigned gy = seg ? (unsigned)nseg : 1u;
   if (C % 8 == 0 && !(((uintptr_t)y | (uintptr_t)out | (uintptr_t)arg | (uintptr_t)yraw) & 15)) {
     const size_t total8 = (size_t)R * C / 8;
-    hipLaunchKernelGGL(bn_relu_rows_max_bf16_v8_kernel, dim3(capped_grid(total8)), dim3(256), 0, (hipStream_t)stream, total8,
-                       ns, C, (const bf16 *)y, fin, out, arg, yraw);
+    hipLaunchKernelGGL(bn_relu_rows_max_bf16_v8_kernel, dim3(capped_grid(Rg * C / 8, 16384 / gy + 1), gy), dim3(256), 0,
+                       (hipStream_t)stream, total8, ns, C, (const bf16 *)y, fin, out, arg, yraw, seg);
     return pn2_check_launch();
   }
   const size_t total = (size_t)R * C / 2;
-  hipLaunchKernelGGL(bn_relu_rows_max_bf16_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream, total, ns,
-                     C, (const bf16 *)y, fin, out, arg, yraw);
+  hipLaunchKernelGGL(bn_relu_rows_max_bf16_kernel, dim3(capped_grid(Rg * C / 2, 16384 / gy + 1), gy), dim3(256), 0,
+                     (hipStream_t)stream, total, ns, C, (const bf16 *)y, fin, out, arg, yraw, seg);
   return pn2_check_launch();
+}
+}  // namespace
+
+extern "C" int pn2_bn_relu_rows_max_bf16(long long R, int ns, int C, const void *y, const float *fin, float *out,
+                                         int *arg, float *yraw, void *stream) {
+  return rows_max_bf16_impl(R, ns, C, y, fin, out, arg, yraw, nullptr, 1, 0, stream);
+}
+
+// The same over nseg scans with per-scan constants: seg = ROW offsets of the scans in y (multiples of ns), fin (S,4,C).
+extern "C" int pn2_bn_relu_rows_max_bf16_seg(long long R, int ns, int C, const void *y, const float *fin, float *out,
+                                             int *arg, float *yraw, const long long *seg, int nseg, long long seg_max,
+                                             void *stream) {
+  if (!seg) return PN2_ENULL;
+  if (nseg < 1 || nseg > 65535 || seg_max < 0) return PN2_EINVAL;
+  return rows_max_bf16_impl(R, ns, C, y, fin, out, arg, yraw, seg, nseg, seg_max, stream);
 }

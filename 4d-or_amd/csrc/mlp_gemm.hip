@@ -844,7 +844,7 @@ constexpr int kPrepRows = 16;   // minimum rows per block of the two backward-pr
 // Rows per block: 16 up to 64k rows (the measured optimum at the headline shapes, see bn_relu_bwd_prep_kernel), then as many
 // as keep the grid near 4096 blocks — every block ends with 2 N fp64 atomics onto the SAME 2 N addresses, and with 18 000
 // blocks (scene-graph encoders, 295k pooled rows) those serialised atomics, not the rows, were the kernel's time.
-inline int prep_rows_per_block(long long rows) {
+__host__ __device__ inline int prep_rows_per_block(long long rows) {
   if (rows <= 65536) return kPrepRows;
   const long long r = (rows + 4095) / 4096;
   return (int)((r + kPrepRows - 1) / kPrepRows * kPrepRows);
@@ -947,9 +947,19 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int C, 
                                                            const float *__restrict__ pooled,
                                                            const float *__restrict__ gP,
                                                            const float *__restrict__ fin,
-                                                           float *__restrict__ gPm, double *__restrict__ sums) {
+                                                           float *__restrict__ gPm, double *__restrict__ sums,
+                                                           const long long *__restrict__ seg, int ns) {
   __shared__ float part[2][256];                 // see bn_relu_bwd_prep_kernel
+  if (seg) {                                     // blockIdx.y = scan: its pooled rows, its (4,C) finalize block, its sums
+    const long long g0 = seg[blockIdx.y] / ns;
+    R = seg[blockIdx.y + 1] / ns - g0;
+    yraw += (size_t)g0 * C; pooled += (size_t)g0 * C; gP += (size_t)g0 * C; gPm += (size_t)g0 * C;
+    fin += (size_t)blockIdx.y * 4 * C;
+    sums += (size_t)blockIdx.y * 2 * C;
+    rpb = prep_rows_per_block(R);                // the blocks — and with them the fp32 partial sums — of the scan's own call
+  }
   const long long r0 = (long long)blockIdx.x * rpb;
+  if (r0 >= R) return;
   const int cw = C < 256 ? C : 256;
   const int groups = 256 / cw;
   const int grp = threadIdx.x / cw;
@@ -1410,7 +1420,123 @@ extern "C" int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const fl
   if (!yraw || !pooled || !gP || !fin || !gPm || !sums) return PN2_ENULL;
   const int rpb = prep_rows_per_block(R);
   hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0,
-                     (hipStream_t)stream, R, C, rpb, yraw, pooled, gP, fin, gPm, sums);
+                     (hipStream_t)stream, R, C, rpb, yraw, pooled, gP, fin, gPm, sums, (const long long *)nullptr, 1);
+  return pn2_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ batched scans
+// Per-scan BatchNorm statistics of a block-diagonal batch in ONE launch per kernel (the arithmetic of the reference's
+// DataLoader(batch_size=1) steps, SGP/main.py:54-56, at the whole-batch launch count): `seg` = nseg + 1 ROW offsets of the
+// scans in the stack's row tensors (device), every per-channel operand an array of per-scan blocks.
+extern "C" int pn2_pool_bwd_prep_seg(long long R, int C, const float *yraw, const float *pooled, const float *gP,
+                                     const float *fin, float *gPm, double *sums, const long long *seg, int nseg,
+                                     long long seg_max, int ns, void *stream) {
+  if (R < 0 || C <= 0 || ns <= 0 || nseg < 1 || nseg > 65535 || seg_max < 0) return PN2_EINVAL;
+  if (R == 0) return PN2_OK;
+  if (!yraw || !pooled || !gP || !fin || !gPm || !sums || !seg) return PN2_ENULL;
+  // every scan is cut into the blocks of its own call (rows per block from ITS row count, in the kernel): at most 4096
+  // blocks for any count, fewer than rows / 16
+  const long long Rs = seg_max / ns;                                  // pooled rows of the longest scan
+  long long gx = (Rs + kPrepRows - 1) / kPrepRows;
+  if (gx > 4096) gx = 4096;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3((unsigned)gx, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, R, C,
+                     kPrepRows, yraw, pooled, gP, fin, gPm, sums, seg, ns);
+  return pn2_check_launch();
+}
+
+namespace {
+// pn2_bn_finalize for nseg scans: stats (S,2,N) -> fin (S,4,N); count of scan s = its rows.  (Running statistics: the
+// S momentum updates in scan order are pn2_bn_running_update's.)
+__global__ __launch_bounds__(128) void bn_finalize_seg_kernel(int S, int N, const long long *__restrict__ seg,
+                                                             const double *__restrict__ stats,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float eps, float *__restrict__ out) {
+  const int c = blockIdx.x * 128 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (c >= N || s >= S) return;
+  const double rows = (double)(seg[s + 1] - seg[s]);
+  const double count = rows > 0.0 ? rows : 1.0;
+  const double *st = stats + (size_t)s * 2 * N;
+  float *o = out + (size_t)s * 4 * N;
+  const double mean = st[c] / count;
+  double var = st[N + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f;
+  const float b = beta ? beta[c] : 0.f;
+  const float scale = g * rstd;
+  o[c] = (float)mean;
+  o[N + c] = rstd;
+  o[2 * N + c] = scale;
+  o[3 * N + c] = b - (float)mean * scale;
+}
+
+// pn2_bn_bwd_consts for nseg scans: sums (S,2,N), fin (S,4,N) -> consts (S,3,N); dgamma / dbeta = the SUM over the scans,
+// accumulated in scan order by the channel's thread (deterministic); optional weight transposition as there.
+__global__ void bn_bwd_consts_seg_kernel(int S, int N, const long long *__restrict__ seg, const double *__restrict__ sums,
+                                         const float *__restrict__ gamma, const float *__restrict__ fin, int use_batch_stats,
+                                         float *__restrict__ consts, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                         const float *__restrict__ W, int K, int k0, float *__restrict__ Wt) {
+  if (W) {
+    const int total = (K - k0) * N;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+      const int k = e / N, n = e - k * N;
+      Wt[e] = W[(size_t)n * K + k0 + k];
+    }
+  }
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const float g = gamma ? gamma[c] : 1.f;
+  float dgs = 0.f, dbs = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const double rows = (double)(seg[s + 1] - seg[s]);
+    const double count = rows > 0.0 ? rows : 1.0;
+    const double db = sums[(size_t)s * 2 * N + c], dg = sums[(size_t)s * 2 * N + N + c];
+    const float *f = fin + (size_t)s * 4 * N;
+    const float mean = f[c], rstd = f[N + c];
+    const float c1 = g * rstd;
+    float c2 = 0.f, c3 = 0.f;
+    if (use_batch_stats) {
+      c2 = (float)(-(double)c1 * (double)rstd * dg / count);
+      c3 = (float)(-(double)c1 * db / count - (double)c2 * (double)mean);
+    }
+    float *o = consts + (size_t)s * 3 * N;
+    o[c] = c1;
+    o[N + c] = c2;
+    o[2 * N + c] = c3;
+    // per-scan fp32 rounding, then summed in fp32 in scan order: what S single-scan backward passes accumulate into .grad
+    dgs = s ? dgs + (float)dg : (float)dg;
+    dbs = s ? dbs + (float)db : (float)db;
+  }
+  if (dgamma) dgamma[c] = dgs;
+  if (dbeta) dbeta[c] = dbs;
+}
+}  // namespace
+
+extern "C" int pn2_bn_finalize_seg(int S, int N, const long long *seg, const double *stats, const float *gamma,
+                                   const float *beta, float eps, float *fin, void *stream) {
+  if (S <= 0 || S > 65535 || N <= 0) return PN2_EINVAL;
+  if (!seg || !stats || !fin) return PN2_ENULL;
+  hipLaunchKernelGGL(bn_finalize_seg_kernel, dim3((N + 127) / 128, S), dim3(128), 0, (hipStream_t)stream, S, N, seg, stats,
+                     gamma, beta, eps, fin);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_bn_bwd_consts_seg(int S, int N, const long long *seg, const double *sums, const float *gamma,
+                                     const float *fin, int use_batch_stats, float *consts, float *dgamma, float *dbeta,
+                                     const float *W, int K, int k0, float *Wt, void *stream) {
+  if (S <= 0 || N <= 0) return PN2_EINVAL;
+  if (!seg || !sums || !fin || !consts) return PN2_ENULL;
+  if (W && (!Wt || K <= 0 || k0 < 0 || k0 >= K)) return PN2_EINVAL;
+  unsigned blocks = (unsigned)((N + 127) / 128), threads = 128;
+  if (W) {
+    threads = 256;
+    blocks = (unsigned)(((size_t)N * (K - k0) + 4095) / 4096);
+    if (blocks < (unsigned)((N + 255) / 256)) blocks = (unsigned)((N + 255) / 256);
+  }
+  hipLaunchKernelGGL(bn_bwd_consts_seg_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, S, N, seg, sums, gamma,
+                     fin, use_batch_stats, consts, dgamma, dbeta, W, K, k0, Wt);
   return pn2_check_launch();
 }
 

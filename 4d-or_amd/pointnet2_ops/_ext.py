@@ -18,6 +18,7 @@ the C ABI of ``include/pn2_hip.h``) through ctypes:
 There is NO fallback: if the shared library is missing or a kernel launch
 fails this module raises.  torch is used for device memory and streams only.
 """
+import collections
 import contextlib
 import ctypes
 import os
@@ -117,6 +118,18 @@ _SIGNATURES = {
     "pn2_mlp_gemm_pool": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_pool_finalize": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 8,
     "pn2_pool_bwd": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 10 + [_c_sz, _c_vp],
+    # batched scans with per-scan statistics (segment table)
+    "pn2_mlp_gemm_bf16_seg": [ctypes.c_longlong] + [_c_int] * 8 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 2 + [_c_int] +
+                             [_c_vp] * 6 + [_c_int, ctypes.c_longlong, _c_vp],
+    "pn2_mlp_wgrad_bf16_seg": [ctypes.c_longlong] + [_c_int] * 6 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 +
+                              [_c_int, ctypes.c_longlong, _c_vp],
+    "pn2_mlp_bwd_bf16_seg": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7 +
+                            [_c_int, ctypes.c_longlong, _c_vp],
+    "pn2_bn_relu_rows_max_bf16_seg": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 6 + [_c_int, ctypes.c_longlong, _c_vp],
+    "pn2_pool_bwd_prep_seg": [ctypes.c_longlong, _c_int] + [_c_vp] * 7 + [_c_int, ctypes.c_longlong, _c_int, _c_vp],
+    "pn2_bn_finalize_seg": [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_f32, _c_vp, _c_vp],
+    "pn2_bn_bwd_consts_seg": [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int,
+                              _c_vp, _c_vp],
 }
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here == ABI mismatch: fail loudly
@@ -964,6 +977,63 @@ def bn_running_update(fins, eps, decay, w, wu, running_mean, running_var, num_ba
           _ptr(running_var), _ptr(num_batches_tracked))
 
 
+class SegTable:
+    """Row ranges of the scans of a batched call with per-scan statistics: `rows` (host ints, rows of every scan in the
+    stack's row tensors), `ptr` (S + 1 int64 offsets on the device).  Built once per (device, rows) signature — from host
+    numbers, i.e. with a copy, which a stream capture does not allow: the first eager step creates it."""
+    _CACHE = collections.OrderedDict()
+    _MAX = 1024
+
+    def __init__(self, device, rows):
+        self.rows = tuple(int(r) for r in rows)
+        self.nseg = len(self.rows)
+        self.max_rows = max(self.rows) if self.rows else 0
+        self.total = sum(self.rows)
+        off = [0]
+        for r in self.rows:
+            off.append(off[-1] + r)
+        self.ptr = torch.tensor(off, dtype=torch.int64, device=device)
+
+    @classmethod
+    def get(cls, device, rows):
+        key = (device, tuple(int(r) for r in rows))
+        hit = cls._CACHE.get(key)
+        if hit is None:
+            if len(cls._CACHE) >= cls._MAX:
+                cls._CACHE.popitem(last=False)
+            hit = cls._CACHE[key] = cls(device, rows)
+        else:
+            cls._CACHE.move_to_end(key)
+        return hit
+
+
+def bn_finalize_seg(stats, seg, gamma, beta, eps, out=None):
+    """stats (S,2,N) f64 of the scans of `seg` -> fin (S,4,N) = per scan [mean | rstd | scale | shift]."""
+    S, two, N = stats.shape
+    if S != seg.nseg or two != 2:
+        raise RuntimeError("bn_finalize_seg: stats must be (S, 2, N) for the S scans of the segment table")
+    fin = out if out is not None else torch.empty(S, 4, N, dtype=torch.float32, device=stats.device)
+    _call("pn2_bn_finalize_seg", stats, S, N, _ptr(seg.ptr), _ptr(stats), _ptr(gamma), _ptr(beta), float(eps), _ptr(fin))
+    return fin
+
+
+def bn_bwd_consts_seg(sums, seg, gamma, fin, use_batch_stats, W=None, k0=0):
+    """sums (S,2,N), fin (S,4,N) -> (consts (S,3,N), dgamma (N), dbeta (N) = sums over the scans[, Wt])."""
+    S, two, N = sums.shape
+    if S != seg.nseg or two != 2:
+        raise RuntimeError("bn_bwd_consts_seg: sums must be (S, 2, N) for the S scans of the segment table")
+    consts = torch.empty(S, 3, N, dtype=torch.float32, device=sums.device)
+    dgamma = torch.empty(N, dtype=torch.float32, device=sums.device)
+    dbeta = torch.empty(N, dtype=torch.float32, device=sums.device)
+    Wt, K = None, 0
+    if W is not None:
+        K = W.size(1)
+        Wt = torch.empty(K - int(k0), N, dtype=torch.float32, device=sums.device)
+    _call("pn2_bn_bwd_consts_seg", sums, S, N, _ptr(seg.ptr), _ptr(sums), _ptr(gamma), _ptr(fin), int(bool(use_batch_stats)),
+          _ptr(consts), _ptr(dgamma), _ptr(dbeta), _ptr(W), int(K), int(k0), _ptr(Wt))
+    return (consts, dgamma, dbeta) if W is None else (consts, dgamma, dbeta, Wt)
+
+
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None, out=None):
     """fin (4,N) = [mean | rstd | scale | shift]; updates the running statistics in place and, if given, bumps the int64
     scalar `num_batches_tracked` (what _BatchNorm.forward does with a separate add_ kernel per layer).
@@ -1091,9 +1161,16 @@ def pool_bwd(Yp, fin_p, W, consts, arg, gPm, ns, sums):
     return Gout, dW
 
 
-def pool_bwd_prep(yraw, pooled, gP, fin, sums=None):
+def pool_bwd_prep(yraw, pooled, gP, fin, sums=None, seg=None, ns=0):
+    """`seg` (SegTable over the un-pooled rows, `ns` rows per pooled row): fin (S,4,C), sums (S,2,C) per scan."""
     R, C = pooled.shape
     gPm = torch.empty_like(pooled)
+    if seg is not None:
+        if sums is None:
+            sums = torch.zeros(seg.nseg, 2, C, dtype=torch.float64, device=pooled.device)
+        _call("pn2_pool_bwd_prep_seg", pooled, R, C, _ptr(yraw), _ptr(pooled), _ptr(gP), _ptr(fin), _ptr(gPm), _ptr(sums),
+              _ptr(seg.ptr), seg.nseg, seg.max_rows, int(ns), alg_bytes=16 * R * C)
+        return gPm, sums
     if sums is None:
         sums = torch.zeros(2, C, dtype=torch.float64, device=pooled.device)
     _call("pn2_pool_bwd_prep", pooled, R, C, _ptr(yraw), _ptr(pooled), _ptr(gP), _ptr(fin), _ptr(gPm),
@@ -1138,7 +1215,7 @@ def group_concat_rows_bf16(xyz, new_xyz, feats_rows, idx, use_xyz, normalize, ra
 
 
 def mlp_gemm_bf16(X, W, pro=PRO_NONE, epi=EPI_NONE, X2=None, p=None, arg=None, gP=None, ns=0, stats=None, Yprev=None,
-                  e_fin=None, M=None, out_f32=False):
+                  e_fin=None, M=None, out_f32=False, seg=None):
     """Y (M, N) = pro(X) (M, K) @ W (N, K)^T on the bf16 MFMA path.  X: bf16 rows (pitch = X.size(1), a multiple of 8, may
     exceed K with zero pad columns) or fp32 rows (pro 0 only); W fp32; Y bf16 (fp32 when out_f32)."""
     _f32(W, "W")
@@ -1155,6 +1232,20 @@ def mlp_gemm_bf16(X, W, pro=PRO_NONE, epi=EPI_NONE, X2=None, p=None, arg=None, g
     eb = 4 if x_f32 else 2
     nbytes = (M * ldx * eb * (2 if pro == PRO_GY else 1) + M * N * (4 if out_f32 else 2) * (2 if epi == EPI_MASK else 1)
               + 4 * N * K)
+    if seg is not None:
+        # `p`: (S, K) VIEWS into the per-scan blocks — fin[:, 2], fin[:, 3] of an (S,4,K) finalize buffer (pitch 4K) or
+        # consts[:, i] of the (S,3,K) constants (pitch 3K); stats (S,2,N), e_fin (S,4,N)
+        pstride = 0
+        if p0 is not None:
+            if any(q is not None and (q.dim() != 2 or q.size(0) != seg.nseg or q.stride(1) != 1 or q.stride(0) != p0.stride(0))
+                   for q in (p0, p1, p2)):
+                raise RuntimeError("mlp_gemm_bf16(seg=...): p must be (S, K) views with one common scan pitch")
+            pstride = int(p0.stride(0))
+        _call("pn2_mlp_gemm_bf16_seg", W, M, K, N, int(pro), int(epi), int(x_f32), int(bool(out_f32)), ldx, N, _ptr(X),
+              _ptr(X2), _ptr(p0), _ptr(p1), _ptr(p2), pstride, _ptr(arg), _ptr(gP), int(ns), _ptr(W), _ptr(Y), _ptr(stats),
+              _ptr(Yprev), _ptr(e_fin), _ptr(seg.ptr), seg.nseg, seg.max_rows, alg_bytes=nbytes, alg_flops=2 * M * N * K,
+              tag=(f"M{M},K{K},N{N},pro{int(pro)},epi{int(epi)},S{seg.nseg}" if DETAIL_TAGS else None))
+        return Y
     _call("pn2_mlp_gemm_bf16", W, M, K, N, int(pro), int(epi), int(x_f32), int(bool(out_f32)), ldx, N, _ptr(X), _ptr(X2),
           _ptr(p0), _ptr(p1), _ptr(p2), _ptr(arg), _ptr(gP), int(ns), _ptr(W), _ptr(Y), _ptr(stats), _ptr(Yprev), _ptr(e_fin),
           alg_bytes=nbytes, alg_flops=2 * M * N * K,
@@ -1184,12 +1275,21 @@ def rows_gram_bf16(X, K0, gram):
     return gram
 
 
-def mlp_wgrad_bf16(Yl, consts, X, gmode, amode, K, G=None, arg=None, gP=None, ns=0, a_fin=None, dW=None):
-    """dW (N, K) fp32 += gy^T @ act; Yl / G bf16 (M, N); X bf16 (M, ldx >= K) or fp32 rows (amode 0)."""
+def mlp_wgrad_bf16(Yl, consts, X, gmode, amode, K, G=None, arg=None, gP=None, ns=0, a_fin=None, dW=None, seg=None):
+    """dW (N, K) fp32 += gy^T @ act; Yl / G bf16 (M, N); X bf16 (M, ldx >= K) or fp32 rows (amode 0).
+    `seg`: consts (S,3,N), a_fin (S,4,K) per scan; dW = the sum over the scans."""
     M, N = Yl.shape
     x_f32 = X.dtype == torch.float32
     if dW is None:
         dW = torch.zeros(N, int(K), dtype=torch.float32, device=Yl.device)
+    if seg is not None:
+        _call("pn2_mlp_wgrad_bf16_seg", Yl, M, N, int(K), int(gmode), int(amode), int(x_f32), X.size(1), _ptr(G), _ptr(Yl),
+              _ptr(consts), _ptr(arg), _ptr(gP), int(ns), _ptr(X), _ptr(a_fin), _ptr(dW), _ptr(seg.ptr), seg.nseg,
+              seg.max_rows,
+              alg_bytes=2 * M * N * (2 if gmode == PRO_GY else 1) + M * X.size(1) * (4 if x_f32 else 2) + 4 * N * int(K),
+              alg_flops=2 * M * N * int(K),
+              tag=(f"M{M},N{N},K{K},g{int(gmode)},a{int(amode)},S{seg.nseg}" if DETAIL_TAGS else None))
+        return dW
     _call("pn2_mlp_wgrad_bf16", Yl, M, N, int(K), int(gmode), int(amode), int(x_f32), X.size(1), _ptr(G), _ptr(Yl),
           _ptr(consts), _ptr(arg), _ptr(gP), int(ns), _ptr(X), _ptr(a_fin), _ptr(dW),
           alg_bytes=2 * M * N * (2 if gmode == PRO_GY else 1) + M * X.size(1) * (4 if x_f32 else 2) + 4 * N * int(K),
@@ -1201,12 +1301,23 @@ def mlp_bwd_bf16_supported(N, K):
     return bool(_lib.pn2_mlp_bwd_bf16_supported(int(N), int(K)))
 
 
-def mlp_bwd_bf16(Yl, consts, Wt, Yprev, a_fin, gmode, G=None, arg=None, gP=None, ns=0, sums=None, dW=None):
+def mlp_bwd_bf16(Yl, consts, Wt, Yprev, a_fin, gmode, G=None, arg=None, gP=None, ns=0, sums=None, dW=None, seg=None):
     """One-pass backward of a hidden layer on bf16 tensors -> (Gout (M,K) bf16, sums (2,K) f64, dW (N,K) f32).
-    Wt = the layer's weights transposed (K, N) fp32; `sums` / `dW`: pre-zeroed accumulators (optional)."""
+    Wt = the layer's weights transposed (K, N) fp32; `sums` / `dW`: pre-zeroed accumulators (optional).
+    `seg`: consts (S,3,N), a_fin (S,4,K), sums (S,2,K) per scan; dW = the sum over the scans."""
     M, N = Yl.shape
     K = Yprev.size(1)
     Gout = torch.empty(M, K, dtype=torch.bfloat16, device=Yl.device)
+    if seg is not None:
+        if sums is None:
+            sums = torch.zeros(seg.nseg, 2, K, dtype=torch.float64, device=Yl.device)
+        if dW is None:
+            dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
+        _call("pn2_mlp_bwd_bf16_seg", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP), int(ns),
+              _ptr(Wt), _ptr(Yprev), _ptr(a_fin), _ptr(Gout), _ptr(sums), _ptr(dW), _ptr(seg.ptr), seg.nseg, seg.max_rows,
+              alg_bytes=2 * (M * N * (2 if gmode == PRO_GY else 1) + 2 * M * K) + 4 * N * K, alg_flops=4 * M * N * K,
+              tag=(f"M{M},N{N},K{K},g{int(gmode)},S{seg.nseg}" if DETAIL_TAGS else None))
+        return Gout, sums, dW
     if sums is None:
         sums = torch.zeros(2, K, dtype=torch.float64, device=Yl.device)
     if dW is None:
@@ -1236,13 +1347,17 @@ def bn_relu_bwd_prep_bf16(y, gout, fin, sums=None):
     return gpre, sums
 
 
-def bn_relu_rows_max_bf16(y, fin, ns):
+def bn_relu_rows_max_bf16(y, fin, ns, seg=None):
     _bf16(y, "y")
     M, C = y.shape
     R = M // int(ns)
     out = torch.empty(R, C, dtype=torch.float32, device=y.device)
     arg = torch.empty(R, C, dtype=torch.int32, device=y.device)
     yraw = torch.empty(R, C, dtype=torch.float32, device=y.device)
+    if seg is not None:                               # fin (S,4,C): per-scan constants
+        _call("pn2_bn_relu_rows_max_bf16_seg", y, R, int(ns), C, _ptr(y), _ptr(fin), _ptr(out), _ptr(arg), _ptr(yraw),
+              _ptr(seg.ptr), seg.nseg, seg.max_rows, alg_bytes=2 * M * C + 12 * R * C)
+        return out, arg, yraw
     _call("pn2_bn_relu_rows_max_bf16", y, R, int(ns), C, _ptr(y), _ptr(fin), _ptr(out), _ptr(arg), _ptr(yraw),
           alg_bytes=2 * M * C + 12 * R * C)
     return out, arg, yraw

@@ -367,15 +367,24 @@ class _FusedMLPBf16(Function):
         M = x.size(0)
         L = len(layers)
         ys, fins, batch_flags = [], [], []
-        stat_bufs = e.zero_arena(x.device, [((2, conv.out_channels), torch.float64) for conv, _ in layers])
+        # segment table (a _SegTableMLP call): the rows are S scans with their own batch statistics — every per-channel
+        # buffer gets a leading scan dimension and each kernel walks the scans in its grid (csrc: pn2_*_seg)
+        seg = getattr(ctx, "seg", None)
+        lead = () if seg is None else (seg.nseg,)
+        stat_bufs = e.zero_arena(x.device, [(lead + (2, conv.out_channels), torch.float64) for conv, _ in layers])
         cur = x
         for l, (conv, bn) in enumerate(layers):
             W = params[3 * l].view(conv.out_channels, conv.in_channels)
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
             use_batch = bn.training or bn.running_mean is None
             pro = e.PRO_NONE if l == 0 else e.PRO_BNRELU
-            p = None if l == 0 else (fins[-1][2], fins[-1][3])
-            if use_batch:
+            p = None if l == 0 else ((fins[-1][2], fins[-1][3]) if seg is None else (fins[-1][:, 2], fins[-1][:, 3]))
+            if seg is not None:
+                if not use_batch:
+                    raise RuntimeError("fused_mlp: a segment table needs training-mode BatchNorm in every layer")
+                y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stat_bufs[l], seg=seg)
+                fin = e.bn_finalize_seg(stat_bufs[l], seg, gamma, beta, bn.eps)       # (running statistics: the caller)
+            elif use_batch:
                 stats = stat_bufs[l]
                 y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
                 momentum = 0.0
@@ -402,7 +411,9 @@ class _FusedMLPBf16(Function):
             cur = y
         yraw = None
         if ns:
-            out, arg, yraw = e.bn_relu_rows_max_bf16(ys[-1], fins[-1], ns)
+            out, arg, yraw = e.bn_relu_rows_max_bf16(ys[-1], fins[-1], ns, seg=seg)
+        elif seg is not None:
+            raise RuntimeError("fused_mlp: a segment table needs a pooled stack")
         else:
             out, arg = e.bn_relu_apply_bf16(ys[-1], fins[-1]), None
         ctx.ns, ctx.L, ctx.batch_flags, ctx.k_in = ns, L, batch_flags, k_in
@@ -431,17 +442,20 @@ class _FusedMLPBf16(Function):
         # first-layer fold (csrc/mlp_bf16.hip, FOLD): as on the fp32 path — the layer above the first one reduces gz^T X
         # instead of storing gz when the (<= 8-column, bf16, pitch 8) input rows need no gradient
         k_in = ctx.k_in
-        fold = bool(BF16_FOLD and L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0]
+        seg = getattr(ctx, "seg", None)
+        lead = () if seg is None else (seg.nseg,)
+        fold = bool(BF16_FOLD and seg is None and L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0]
                     and x.dtype == torch.bfloat16 and x.size(1) == 8 and k_in <= 8
                     and getattr(e, "mlp_bwd_bf16_fold", None)
                     and e.mlp_bwd_bf16_fold_supported(Ws[1].size(0), Ws[1].size(1), k_in))
-        arena = e.zero_arena(x.device, [((2, Ws[-1].size(0)), f64)] + [((2, Ws[l].size(1)), f64) for l in range(L)] +
+        arena = e.zero_arena(x.device, [(lead + (2, Ws[-1].size(0)), f64)] +
+                             [(lead + (2, Ws[l].size(1)), f64) for l in range(L)] +
                              [(tuple(Ws[l].shape), f32) for l in range(L)] +
                              ([((Ws[0].size(0), k_in), f32), ((k_in * k_in + k_in,), f64)] if fold else []))
         sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:1 + 2 * L]
         if ns:
             pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
-            gPm, sums = e.pool_bwd_prep(yraw, pooled, g_out, fins[-1], sums=sums0)
+            gPm, sums = e.pool_bwd_prep(yraw, pooled, g_out, fins[-1], sums=sums0, seg=seg, ns=ns)
             gmode, G = e.PRO_POOLG, None
         else:
             G, sums = e.bn_relu_bwd_prep_bf16(ys[-1], g_out, fins[-1], sums=sums0)
@@ -452,8 +466,13 @@ class _FusedMLPBf16(Function):
         gx = None
         for l in range(L - 1, -1, -1):
             need_dgrad = l > 0 or need_dgrad0
-            if need_dgrad:
-                k0 = 3 if (l == 0 and ctx.group is not None and ctx.group[3]) else 0
+            k0 = 3 if (l == 0 and ctx.group is not None and ctx.group[3]) else 0
+            if seg is not None:
+                res = e.bn_bwd_consts_seg(sums, seg, gammas[l], fins[l], ctx.batch_flags[l],
+                                          W=Ws[l].contiguous() if need_dgrad else None, k0=k0)
+                consts, dgamma, dbeta = res[:3]
+                Wt = res[3] if need_dgrad else None
+            elif need_dgrad:
                 consts, dgamma, dbeta, Wt = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l],
                                                             W=Ws[l].contiguous(), k0=k0)
             else:
@@ -472,27 +491,27 @@ class _FusedMLPBf16(Function):
             if l > 0 and FUSED_BACKWARD and e.mlp_bwd_bf16_supported(Ws[l].size(0), Ws[l].size(1)):
                 # hidden layer: dgrad + wgrad from one read of (g, y_l, y_{l-1})
                 G, sums, dW = e.mlp_bwd_bf16(ys[l], consts, Wt, ys[l - 1], fins[l - 1], gmode, G=G, arg=arg, gP=gPm, ns=ns,
-                                             sums=sums_in[l], dW=dWs[l])
+                                             sums=sums_in[l], dW=dWs[l], seg=seg)
                 grads[3 * l] = dW.view(ctx.shapes[l])
                 gmode, arg, gPm = e.PRO_GY, None, None
                 continue
             act = x if l == 0 else ys[l - 1]
             dW = e.mlp_wgrad_bf16(ys[l], consts, act, gmode, e.PRO_NONE if l == 0 else e.PRO_BNRELU, Ws[l].size(1),
-                                  G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1], dW=dWs[l])
+                                  G=G, arg=arg, gP=gPm, ns=ns, a_fin=None if l == 0 else fins[l - 1], dW=dWs[l], seg=seg)
             grads[3 * l] = dW.view(ctx.shapes[l])
             if need_dgrad:
-                p = (consts[0], consts[1], consts[2])
+                p = (consts[0], consts[1], consts[2]) if seg is None else (consts[:, 0], consts[:, 1], consts[:, 2])
                 if l > 0:
                     sums = sums_in[l]
                     G = e.mlp_gemm_bf16(G, Wt, pro=gmode, epi=e.EPI_MASK, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns,
-                                        stats=sums, Yprev=ys[l - 1], e_fin=fins[l - 1], M=M)
+                                        stats=sums, Yprev=ys[l - 1], e_fin=fins[l - 1], M=M, seg=seg)
                     gmode, arg, gPm = e.PRO_GY, None, None
                 else:
                     # gradient rows of a grouped first layer stay bf16 (the scatter / per-point sum accumulates in fp32);
                     # a plain row input gets its fp32 gradient directly
                     rows_bf16 = ctx.group is not None and Wt.size(0) % 4 == 0
                     gx = e.mlp_gemm_bf16(G, Wt, pro=gmode, epi=e.EPI_NONE, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns, M=M,
-                                         out_f32=not rows_bf16)
+                                         out_f32=not rows_bf16, seg=seg)
         if gx is not None and ctx.group is not None:
             idx = ctx.group[2]
             Bq, npoint, nsample = idx.shape
@@ -693,6 +712,53 @@ class _SegmentedGroupMLP(Function):
         return (gx, None, None, None, None, None, *acc)
 
 
+#: per-scan statistics through the kernels' segment tables (ONE launch per kernel for all scans of the batch) where the stack
+#: allows it — bf16 node, pooled, every BatchNorm in training mode; False: the per-scan loop of _SegmentedGroupMLP
+SEG_TABLE = _os.environ.get("PN2_SEG_TABLE", "1") != "0"
+
+
+def seg_table_ok(layers, ns, inner) -> bool:
+    return bool(SEG_TABLE and inner is _FusedMLPBf16 and ns and getattr(_ext(), "bn_finalize_seg", None)
+                and all(bn.training or bn.running_mean is None for _, bn in layers))
+
+
+def seg_table_supported(mlp: nn.Module, x: torch.Tensor, ns: int) -> bool:
+    """`mlp` over rows like `x` can take fused_shared_mlp(..., rows_per_scan=...)."""
+    if not supported(mlp, x, ns):
+        return False
+    layers = parse_stack(mlp)
+    return seg_table_ok(layers, ns, _node(layers, ns))
+
+
+class _SegTableMLP(Function):
+    """A pooled stack over a batch of S scans with PER-SCAN BatchNorm statistics at the launch count of one call: the inner
+    node runs ONCE over all rows with the scans' row ranges as a segment table (csrc: pn2_*_seg — per-scan sums, finalize
+    blocks and backward constants inside the kernels; weight gradients summed over the scans), then the running statistics
+    receive the S momentum updates in scan order.  Same arithmetic per scan as _SegmentedGroupMLP's loop (a scan's row
+    tiles, sums and constants are its own), i.e. the reference's one-scan steps (SGP/main.py:54-56)."""
+
+    @staticmethod
+    def forward(ctx, x, ns, layers, group, rows_per_scan, inner, *params):
+        # (x, ns, layers, group, *params) of the inner node <- (x, ns, layers, group, rows_per_scan, inner, *params) here
+        sub = _SegCtx(tuple(ctx.needs_input_grad[:4]) + tuple(ctx.needs_input_grad[6:]))
+        dev = (x if x is not None else group[0]).device
+        sub.seg = _ext().SegTable.get(dev, rows_per_scan)
+        out, arg = inner.forward(sub, x, ns, layers, group, *params)
+        L = len(layers)
+        if sub.seg.total != sub.saved_tensors[0].size(0):
+            raise RuntimeError("fused_mlp: the scans' row counts must sum to the rows of the stack")
+        _update_running_stats(layers, list(sub.saved_tensors[1 + L:1 + 2 * L]), list(rows_per_scan))
+        ctx.sub, ctx.inner = sub, inner
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, g_out, *unused):
+        res = ctx.inner.backward(ctx.sub, g_out)
+        ctx.sub = None
+        return (res[0], None, None, None, None, None, *res[4:])
+
+
 def _node(layers, ns):
     """The autograd node for the current arithmetic (set_mlp_dtype) that covers this stack."""
     if _MLP_DTYPE == torch.bfloat16 and getattr(_ext(), "HAS_BF16_MLP", False) and _bf16_ok(layers, ns):
@@ -707,11 +773,21 @@ def _params(layers):
     return params
 
 
-def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0) -> torch.Tensor:
-    """x (M, C_in) rows -> (M, C_out) [ns == 0] or (M // ns, C_out) max-pooled over groups of ns rows."""
+def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0, rows_per_scan: Optional[Sequence[int]] = None
+                     ) -> torch.Tensor:
+    """x (M, C_in) rows -> (M, C_out) [ns == 0] or (M // ns, C_out) max-pooled over groups of ns rows.
+    `rows_per_scan` (sums to M, multiples of ns): BatchNorm batch statistics per scan — only for stacks with
+    seg_table_ok(); other callers split the rows themselves."""
     layers = parse_stack(mlp)
     assert layers is not None, "fused_shared_mlp: unsupported stack (call supported() first)"
-    res = _node(layers, ns).apply(x, int(ns), layers, None, *_params(layers))
+    node = _node(layers, ns)
+    if rows_per_scan is not None and len(rows_per_scan) > 1:
+        if not seg_table_ok(layers, ns, node):
+            raise RuntimeError("fused_shared_mlp: rows_per_scan needs a stack with segment-table support")
+        if sum(rows_per_scan) != x.size(0) or any(r % int(ns) for r in rows_per_scan):
+            raise RuntimeError("fused_shared_mlp: rows_per_scan must sum to the rows and be multiples of ns")
+        return _SegTableMLP.apply(x, int(ns), layers, None, tuple(int(r) for r in rows_per_scan), node, *_params(layers))[0]
+    res = node.apply(x, int(ns), layers, None, *_params(layers))
     return res[0] if ns else res
 
 
@@ -729,6 +805,12 @@ def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz,
     if clouds_per_scan is not None and len(clouds_per_scan) > 1:
         if sum(clouds_per_scan) != B:
             raise RuntimeError("fused_group_mlp_pool: clouds_per_scan must sum to the number of clouds")
+        node = _node(layers, ns)
+        if seg_table_ok(layers, ns, node):
+            res = _SegTableMLP.apply(None if feats_rows is None else feats_rows.contiguous(), int(ns), layers, group,
+                                     tuple(int(v) * m * ns for v in clouds_per_scan), node, *_params(layers))
+            return res[0].view(B, m, -1)
+        group = group[:6] + (None,) + group[7:]          # (the loop slices the clouds: no whole-batch inverse index)
         res = _SegmentedGroupMLP.apply(None if feats_rows is None else feats_rows.contiguous(), int(ns), layers, group,
                                        tuple(int(v) for v in clouds_per_scan), _node(layers, ns), *_params(layers))
     else:

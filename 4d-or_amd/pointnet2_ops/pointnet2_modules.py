@@ -167,8 +167,20 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
             if idx is None:
                 idx = grouper.query(xyz, new_xyz)
             return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
-                                                  grouper.normalize_xyz, grouper.radius, clouds_per_scan=sizes,
+                                                  grouper.normalize_xyz, grouper.radius, clouds_per_scan=sizes, inv=inv,
                                                   crowded=crowded_balls(grouper, xyz.size(1)))
+        if _FUSED_MLP and idx is None and not isinstance(grouper, pointnet2_utils.QueryAndGroup):
+            # group-all (or any grouper without statistics of its own): group the whole batch once, then ONE call of the
+            # stack with the scans' row ranges as a segment table — where the stack's kernels take one
+            g = grouper.forward_rows(xyz, new_xyz, feats_rows)
+            Bg, npoint, nsample, width = g.shape
+            rows = g.reshape(-1, width)
+            if fused_mlp.seg_table_supported(mlp, rows, nsample):
+                per = npoint * nsample
+                return fused_mlp.fused_shared_mlp(mlp, rows, nsample, rows_per_scan=[n * per for n in sizes]
+                                                  ).view(Bg, npoint, -1)
+            parts = [mlp_pool_rows(mlp, gs) for gs in g.split_with_sizes(sizes)]
+            return torch.cat(parts, dim=0)
         split = lambda t: [None] * len(sizes) if t is None else t.split_with_sizes(sizes)
         parts = [sa_scale_rows(grouper, mlp, x, nx, f, i, _whole_batch=True)
                  for x, nx, f, i in zip(split(xyz), split(new_xyz), split(feats_rows), split(idx))]

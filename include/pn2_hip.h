@@ -422,6 +422,43 @@ int pn2_group_concat_rows_bf16(int B, int N, int m, int ns, int C, int use_xyz, 
                                int ldo, const float *xyz, const float *new_xyz, const float *feats,
                                const int *idx, void *out, void *stream);
 
+/* ------------------------------------------------ batched scans, per-scan BatchNorm statistics (segment table) ---
+ * The reference trains on ONE scan per step (scene_graph_prediction/main.py:54-56, DataLoader(batch_size=1)): every
+ * training-mode BatchNorm of the encoders (OPS/pointnet2_modules.py:9-19 shared MLPs) sees the clouds of one scan.  A
+ * block-diagonal batch of S scans keeps that arithmetic when the statistics are taken PER SCAN; these entry points do so
+ * at the launch count of ONE call instead of S: the M rows of a stack are S scans, scan s = rows [seg[s], seg[s+1])
+ * (`seg`: S + 1 row offsets on the device, multiples of `ns` wherever a pooled operand is involved; `seg_max` = rows of the
+ * longest scan, sizes the grid), grid.y (z for the weight gradient) walks the scans, and every per-channel operand is an
+ * array of per-scan blocks: statistics / sums (S,2,C) fp64, finalize blocks fin (S,4,C), backward constants (S,3,C).  Row
+ * tiles never straddle two scans, so each scan's sums, outputs and gradients are those of its own call; weight-gradient
+ * accumulators (dW, and dgamma / dbeta of pn2_bn_bwd_consts_seg) receive the SUM over the scans — the 1/S of the mean loss
+ * arrives with the incoming gradient.  Running statistics: pn2_bn_running_update on the (S,4,C) finalize blocks.
+ *   pn2_mlp_gemm_bf16_seg: p0 / p1 / p2 point at scan 0's vector, scan s's lies `pstride` floats further (4K for the
+ *                          scale / shift rows of fin, 3K for the rows of the constants); stats (S,2,N), e_fin (S,4,N).
+ *   pn2_mlp_wgrad_bf16_seg / pn2_mlp_bwd_bf16_seg: consts (S,3,N), a_fin (S,4,K), sums (S,2,K).
+ *   pn2_bn_relu_rows_max_bf16_seg / pn2_pool_bwd_prep_seg: seg in rows of the UN-pooled tensor, fin (S,4,C), sums (S,2,C).
+ *   pn2_bn_finalize_seg: count of scan s = seg[s+1] - seg[s].   pn2_bn_bwd_consts_seg: likewise; W / Wt as there. */
+int pn2_mlp_gemm_bf16_seg(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
+                          const void *X, const void *X2, const float *p0, const float *p1, const float *p2, int pstride,
+                          const int *arg, const float *gP, int ns, const float *W, void *Y, double *stats,
+                          const void *Yprev, const float *e_fin, const long long *seg, int nseg, long long seg_max,
+                          void *stream);
+int pn2_mlp_wgrad_bf16_seg(long long M, int N, int K, int gmode, int amode, int x_f32, int ldx, const void *G,
+                           const void *Yl, const float *consts, const int *arg, const float *gP, int ns, const void *X,
+                           const float *a_fin, float *dW, const long long *seg, int nseg, long long seg_max, void *stream);
+int pn2_mlp_bwd_bf16_seg(long long M, int N, int K, int gmode, const void *G, const void *Yl, const float *consts,
+                         const int *arg, const float *gP, int ns, const float *Wt, const void *Yprev, const float *a_fin,
+                         void *Gout, double *sums, float *dW, const long long *seg, int nseg, long long seg_max, void *stream);
+int pn2_bn_relu_rows_max_bf16_seg(long long R, int ns, int C, const void *y, const float *fin, float *out, int *arg,
+                                  float *yraw, const long long *seg, int nseg, long long seg_max, void *stream);
+int pn2_pool_bwd_prep_seg(long long R, int C, const float *yraw, const float *pooled, const float *gP, const float *fin,
+                          float *gPm, double *sums, const long long *seg, int nseg, long long seg_max, int ns, void *stream);
+int pn2_bn_finalize_seg(int S, int N, const long long *seg, const double *stats, const float *gamma, const float *beta,
+                        float eps, float *fin, void *stream);
+int pn2_bn_bwd_consts_seg(int S, int N, const long long *seg, const double *sums, const float *gamma, const float *fin,
+                          int use_batch_stats, float *consts, float *dgamma, float *dbeta, const float *W, int K, int k0,
+                          float *Wt, void *stream);
+
 /* ----------------------------------------------------------------- (f)3 ---
  * Per-object / per-pair crops of a fused scan on the GPU: the step in front of the hot path
  *   (SGH/dataset/data_preparation_utils.py:110-125 object crops, :173-224 pair crops, :37-49 re-sampling, :12-18
