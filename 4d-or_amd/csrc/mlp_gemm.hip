@@ -1446,30 +1446,43 @@ extern "C" int pn2_pool_bwd_prep_seg(long long R, int C, const float *yraw, cons
 }
 
 namespace {
-// pn2_bn_finalize for nseg scans: stats (S,2,N) -> fin (S,4,N); count of scan s = its rows.  (Running statistics: the
-// S momentum updates in scan order are pn2_bn_running_update's.)
+// pn2_bn_finalize for nseg scans: stats (S,2,N) -> fin (S,4,N); count of scan s = its rows.  A channel's thread walks the
+// scans IN ORDER, so the running statistics receive the S momentum updates exactly as S calls of bn_finalize_kernel
+// (= S single-scan training steps) apply them; an empty scan leaves them alone.
 __global__ __launch_bounds__(128) void bn_finalize_seg_kernel(int S, int N, const long long *__restrict__ seg,
                                                              const double *__restrict__ stats,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                             float eps, float *__restrict__ out) {
+                                                             float eps, float momentum, float *__restrict__ running_mean,
+                                                             float *__restrict__ running_var,
+                                                             long long *__restrict__ num_batches_tracked,
+                                                             float *__restrict__ out) {
   const int c = blockIdx.x * 128 + threadIdx.x;
-  const int s = blockIdx.y;
-  if (c >= N || s >= S) return;
-  const double rows = (double)(seg[s + 1] - seg[s]);
-  const double count = rows > 0.0 ? rows : 1.0;
-  const double *st = stats + (size_t)s * 2 * N;
-  float *o = out + (size_t)s * 4 * N;
-  const double mean = st[c] / count;
-  double var = st[N + c] / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += S;
+  if (c >= N) return;
   const float g = gamma ? gamma[c] : 1.f;
   const float b = beta ? beta[c] : 0.f;
-  const float scale = g * rstd;
-  o[c] = (float)mean;
-  o[N + c] = rstd;
-  o[2 * N + c] = scale;
-  o[3 * N + c] = b - (float)mean * scale;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
+  for (int s = 0; s < S; ++s) {
+    const double rows = (double)(seg[s + 1] - seg[s]);
+    const double count = rows > 0.0 ? rows : 1.0;
+    const double *st = stats + (size_t)s * 2 * N;
+    float *o = out + (size_t)s * 4 * N;
+    const double mean = st[c] / count;
+    double var = st[N + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = g * rstd;
+    o[c] = (float)mean;
+    o[N + c] = rstd;
+    o[2 * N + c] = scale;
+    o[3 * N + c] = b - (float)mean * scale;
+    if (running_mean && rows > 0.0) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      rm = (1.f - momentum) * rm + momentum * (float)mean;
+      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+    }
+  }
+  if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
 // pn2_bn_bwd_consts for nseg scans: sums (S,2,N), fin (S,4,N) -> consts (S,3,N); dgamma / dbeta = the SUM over the scans,
@@ -1515,11 +1528,13 @@ __global__ void bn_bwd_consts_seg_kernel(int S, int N, const long long *__restri
 }  // namespace
 
 extern "C" int pn2_bn_finalize_seg(int S, int N, const long long *seg, const double *stats, const float *gamma,
-                                   const float *beta, float eps, float *fin, void *stream) {
-  if (S <= 0 || S > 65535 || N <= 0) return PN2_EINVAL;
+                                   const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                   long long *num_batches_tracked, float *fin, void *stream) {
+  if (S <= 0 || N <= 0) return PN2_EINVAL;
   if (!seg || !stats || !fin) return PN2_ENULL;
-  hipLaunchKernelGGL(bn_finalize_seg_kernel, dim3((N + 127) / 128, S), dim3(128), 0, (hipStream_t)stream, S, N, seg, stats,
-                     gamma, beta, eps, fin);
+  if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
+  hipLaunchKernelGGL(bn_finalize_seg_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, S, N, seg, stats,
+                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, fin);
   return pn2_check_launch();
 }
 

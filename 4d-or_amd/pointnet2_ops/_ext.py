@@ -127,7 +127,7 @@ _SIGNATURES = {
                             [_c_int, ctypes.c_longlong, _c_vp],
     "pn2_bn_relu_rows_max_bf16_seg": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 6 + [_c_int, ctypes.c_longlong, _c_vp],
     "pn2_pool_bwd_prep_seg": [ctypes.c_longlong, _c_int] + [_c_vp] * 7 + [_c_int, ctypes.c_longlong, _c_int, _c_vp],
-    "pn2_bn_finalize_seg": [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_f32, _c_vp, _c_vp],
+    "pn2_bn_finalize_seg": [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_bwd_consts_seg": [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int,
                               _c_vp, _c_vp],
 }
@@ -1007,13 +1007,18 @@ class SegTable:
         return hit
 
 
-def bn_finalize_seg(stats, seg, gamma, beta, eps, out=None):
-    """stats (S,2,N) f64 of the scans of `seg` -> fin (S,4,N) = per scan [mean | rstd | scale | shift]."""
+def bn_finalize_seg(stats, seg, gamma, beta, eps, momentum=0.0, running_mean=None, running_var=None,
+                    num_batches_tracked=None, out=None):
+    """stats (S,2,N) f64 of the scans of `seg` -> fin (S,4,N) = per scan [mean | rstd | scale | shift]; the running
+    statistics (optional) receive the S momentum updates in scan order, `num_batches_tracked` (int64 scalar) += S."""
     S, two, N = stats.shape
     if S != seg.nseg or two != 2:
         raise RuntimeError("bn_finalize_seg: stats must be (S, 2, N) for the S scans of the segment table")
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        _fail("bn_finalize_seg: num_batches_tracked must be int64")
     fin = out if out is not None else torch.empty(S, 4, N, dtype=torch.float32, device=stats.device)
-    _call("pn2_bn_finalize_seg", stats, S, N, _ptr(seg.ptr), _ptr(stats), _ptr(gamma), _ptr(beta), float(eps), _ptr(fin))
+    _call("pn2_bn_finalize_seg", stats, S, N, _ptr(seg.ptr), _ptr(stats), _ptr(gamma), _ptr(beta), float(eps),
+          float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(fin))
     return fin
 
 

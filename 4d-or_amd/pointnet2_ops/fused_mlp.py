@@ -383,7 +383,12 @@ class _FusedMLPBf16(Function):
                 if not use_batch:
                     raise RuntimeError("fused_mlp: a segment table needs training-mode BatchNorm in every layer")
                 y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stat_bufs[l], seg=seg)
-                fin = e.bn_finalize_seg(stat_bufs[l], seg, gamma, beta, bn.eps)       # (running statistics: the caller)
+                rm = rv = nbt = None
+                if bn.training and bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None:
+                    rm, rv, nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+                # running statistics: the S momentum updates in scan order inside the kernel (a cumulative average,
+                # momentum None, needs the batch count on the host: _SegTableMLP applies it afterwards)
+                fin = e.bn_finalize_seg(stat_bufs[l], seg, gamma, beta, bn.eps, 0.0 if rm is None else bn.momentum, rm, rv, nbt)
             elif use_batch:
                 stats = stat_bufs[l]
                 y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
@@ -747,7 +752,8 @@ class _SegTableMLP(Function):
         L = len(layers)
         if sub.seg.total != sub.saved_tensors[0].size(0):
             raise RuntimeError("fused_mlp: the scans' row counts must sum to the rows of the stack")
-        _update_running_stats(layers, list(sub.saved_tensors[1 + L:1 + 2 * L]), list(rows_per_scan))
+        _update_running_stats(layers, [F if bn.momentum is None else None                 # (the others: in the finalize kernel)
+                                       for (_, bn), F in zip(layers, sub.saved_tensors[1 + L:1 + 2 * L])], list(rows_per_scan))
         ctx.sub, ctx.inner = sub, inner
         ctx.mark_non_differentiable(arg)
         return out, arg

@@ -417,8 +417,17 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
         main.wait_stream(side)
         batch = dict(scan, geometry=state["geo"])
         record_stream_tree(batch["geometry"], main)
-        state["geo"] = launch_geometry()
+        state["geo"] = None if late_geometry else launch_geometry()
         return batch
+
+    # Where the next scan's geometry is enqueued: at the start of the step it shares the chip with the encoders' forward
+    # GEMMs; between forward and backward ("late") it runs beside the backward of the heads and the GCN — a few hundred
+    # launch-bound kernels of microseconds each, during which the chip is otherwise ~70 % idle (profiles/r03_sgp_gaps.md)
+    late_geometry = side is not None and fused is None and args.geometry_launch == "backward" and not args.graphs
+
+    def launch_late_geometry():
+        if late_geometry and state["geo"] is None:
+            state["geo"] = launch_geometry()
 
     if args.graphs:
         # the step (with the geometry as an INPUT: its tensors are copied into the graph's static buffers) is one replay;
@@ -444,7 +453,9 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
             else:
                 opt.zero_grad(set_to_none=True)
             obj, rel = net(batch)
-            model.loss(obj, rel, batch).backward()
+            loss = model.loss(obj, rel, batch)
+            launch_late_geometry()
+            loss.backward()
             if sync is not None:
                 sync.sync()
             opt.step()
@@ -517,6 +528,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=50000)
+    ap.add_argument("--geometry-launch", choices=["start", "backward"], default="backward",
+                    help="sgp workload: enqueue the next scan's geometry at the start of the step or between forward and backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scenes", type=int, default=2)
     ap.add_argument("--no-kernel-timing", action="store_true")

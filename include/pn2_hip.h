@@ -432,12 +432,14 @@ int pn2_group_concat_rows_bf16(int B, int N, int m, int ns, int C, int use_xyz, 
  * array of per-scan blocks: statistics / sums (S,2,C) fp64, finalize blocks fin (S,4,C), backward constants (S,3,C).  Row
  * tiles never straddle two scans, so each scan's sums, outputs and gradients are those of its own call; weight-gradient
  * accumulators (dW, and dgamma / dbeta of pn2_bn_bwd_consts_seg) receive the SUM over the scans — the 1/S of the mean loss
- * arrives with the incoming gradient.  Running statistics: pn2_bn_running_update on the (S,4,C) finalize blocks.
+ * arrives with the incoming gradient.
  *   pn2_mlp_gemm_bf16_seg: p0 / p1 / p2 point at scan 0's vector, scan s's lies `pstride` floats further (4K for the
  *                          scale / shift rows of fin, 3K for the rows of the constants); stats (S,2,N), e_fin (S,4,N).
  *   pn2_mlp_wgrad_bf16_seg / pn2_mlp_bwd_bf16_seg: consts (S,3,N), a_fin (S,4,K), sums (S,2,K).
  *   pn2_bn_relu_rows_max_bf16_seg / pn2_pool_bwd_prep_seg: seg in rows of the UN-pooled tensor, fin (S,4,C), sums (S,2,C).
- *   pn2_bn_finalize_seg: count of scan s = seg[s+1] - seg[s].   pn2_bn_bwd_consts_seg: likewise; W / Wt as there. */
+ *   pn2_bn_finalize_seg: count of scan s = seg[s+1] - seg[s]; running_mean / running_var (optional) receive the S momentum
+ *                        updates in scan order — what S calls of pn2_bn_finalize do —, num_batches_tracked += S.
+ *   pn2_bn_bwd_consts_seg: counts likewise; W / Wt as in pn2_bn_bwd_consts. */
 int pn2_mlp_gemm_bf16_seg(long long M, int K, int N, int pro, int epi, int x_f32, int y_f32, int ldx, int ldy,
                           const void *X, const void *X2, const float *p0, const float *p1, const float *p2, int pstride,
                           const int *arg, const float *gP, int ns, const float *W, void *Y, double *stats,
@@ -454,7 +456,8 @@ int pn2_bn_relu_rows_max_bf16_seg(long long R, int ns, int C, const void *y, con
 int pn2_pool_bwd_prep_seg(long long R, int C, const float *yraw, const float *pooled, const float *gP, const float *fin,
                           float *gPm, double *sums, const long long *seg, int nseg, long long seg_max, int ns, void *stream);
 int pn2_bn_finalize_seg(int S, int N, const long long *seg, const double *stats, const float *gamma, const float *beta,
-                        float eps, float *fin, void *stream);
+                        float eps, float momentum, float *running_mean, float *running_var,
+                        long long *num_batches_tracked, float *fin, void *stream);
 int pn2_bn_bwd_consts_seg(int S, int N, const long long *seg, const double *sums, const float *gamma, const float *fin,
                           int use_batch_stats, float *consts, float *dgamma, float *dbeta, const float *W, int K, int k0,
                           float *Wt, void *stream);

@@ -58,7 +58,13 @@ def test_segmented_forward_gemm_equals_one_call_per_scan(S, K, N, pro, epi):
             fins.append(e.bn_finalize(st, r, gamma, beta, 1e-5, 0.0, None, None))
         r0 += r
     if epi:
-        fin = e.bn_finalize_seg(stats, seg, gamma, beta, 1e-5)
+        rm, rv, nbt = torch.randn(N, device="cuda"), torch.rand(N, device="cuda") + 0.5, torch.zeros((), dtype=torch.int64, device="cuda")
+        rm2, rv2, nbt2 = rm.clone(), rv.clone(), nbt.clone()
+        for s, r in enumerate(rows):      # S calls of the single-scan finalize, in scan order
+            st_s = stats[s].contiguous()
+            e.bn_finalize(st_s, r, gamma, beta, 1e-5, 0.1, rm2, rv2, nbt2)
+        fin = e.bn_finalize_seg(stats, seg, gamma, beta, 1e-5, 0.1, rm, rv, nbt)
+        assert torch.equal(rm, rm2) and torch.equal(rv, rv2) and int(nbt) == int(nbt2) == S
         torch.testing.assert_close(fin, torch.stack(fins), rtol=1e-5, atol=1e-6)
         fin_exact = torch.stack(fins).contiguous()
         out, arg, yraw = e.bn_relu_rows_max_bf16(Y, fin_exact, ns, seg=seg)

@@ -39,6 +39,9 @@ else:
     def step():
         bench.train_step(model, opt, pc)
 
+if os.environ.get("PN2_MLP_DTYPE"):                 # PN2_MLP_DTYPE=bf16 python tools/host_profile.py sgp8
+    from pointnet2_ops import fused_mlp
+    fused_mlp.set_mlp_dtype(os.environ["PN2_MLP_DTYPE"])
 for _ in range(3):
     step()
 torch.cuda.synchronize()
@@ -50,3 +53,4 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
+st.sort_stats("cumtime").print_stats(45)
