@@ -54,3 +54,5 @@ torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
 st.sort_stats("cumtime").print_stats(45)
+if os.environ.get("PN2_PROFILE_CALLERS"):           # e.g. PN2_PROFILE_CALLERS="contiguous|torch.cat|torch.zeros"
+    st.print_callers(os.environ["PN2_PROFILE_CALLERS"])
