@@ -1179,6 +1179,11 @@ int launch_wgrad(const WgradBf16Args &a, hipStream_t s) {
   const int nseg = a.seg ? a.nseg : 1;
   long long gx = 512 / kblocks / nseg;
   if (gx < 1) gx = 1;
+  {  // few rows: the N x KB block of float atomics every workgroup ends with outweighs its rows (see pn2_mlp_wgrad)
+    long long cap = (a.seg ? a.seg_max : a.M) / 512;
+    if (cap < 64) cap = 64;
+    if (gx > cap) gx = cap;
+  }
   if (gx > ntiles) gx = ntiles;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(kfn, dim3((unsigned)gx, kblocks, (unsigned)nseg), dim3(256), lds, s, a);
