@@ -3,6 +3,7 @@ include/pn2_hip.h declares (no compute calls here: there is no GPU)."""
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -104,3 +105,36 @@ def test_host_side_routing_predicates():
     assert lib.pn2_mlp_bwd_fused_fold_supported(64, 64, 6) and not lib.pn2_mlp_bwd_fused_fold_supported(128, 64, 6)
     assert lib.pn2_pool_bwd_supported(128, 64, 64) and lib.pn2_pool_bwd_supported(256, 128, 32)
     assert not lib.pn2_pool_bwd_supported(256, 128, 16)                               # SA3 / SA4: materialised path
+
+
+def test_segment_table_host_side():
+    """The host side of the batched-scans entry points (include/pn2_hip.h "batched scans"): row offsets of the scans, the
+    cache per (device, rows) signature, the routing predicate (bf16 node, pooled stack, every BatchNorm in training mode),
+    and the argument checks of the launchers that need no GPU (null table, scan count, longest scan beyond M)."""
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "4d-or_amd"))
+    from pointnet2_ops import _ext as e
+    from pointnet2_ops import fused_mlp
+    from pointnet2_ops.pointnet2_modules import build_shared_mlp
+    t = e.SegTable.get(torch.device("cpu"), [48, 0, 160, 16])
+    assert t.ptr.tolist() == [0, 48, 48, 208, 224] and t.ptr.dtype == torch.int64
+    assert (t.nseg, t.max_rows, t.total) == (4, 160, 224)
+    assert e.SegTable.get(torch.device("cpu"), (48, 0, 160, 16)) is t
+    mlp = build_shared_mlp([6, 64, 128], bn=True).train()
+    layers = fused_mlp.parse_stack(mlp)
+    assert fused_mlp.seg_table_ok(layers, 16, fused_mlp._FusedMLPBf16)
+    assert not fused_mlp.seg_table_ok(layers, 16, fused_mlp._FusedMLP)          # fp32 stacks loop over the scans
+    assert not fused_mlp.seg_table_ok(layers, 0, fused_mlp._FusedMLPBf16)       # un-pooled stack
+    mlp.eval()
+    assert not fused_mlp.seg_table_ok(fused_mlp.parse_stack(mlp), 16, fused_mlp._FusedMLPBf16)   # running statistics
+    lib = ctypes.CDLL(LIB)
+    ll, i32, vp = ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p
+    lib.pn2_mlp_gemm_bf16_seg.argtypes = [ll] + [i32] * 8 + [vp] * 5 + [i32] + [vp] * 2 + [i32] + [vp] * 6 + [i32, ll, vp]
+    base = [128, 64, 64, 0, 0, 0, 0, 64, 64] + [None] * 5 + [0, None, None, 0, None, None, None, None, None]
+    assert lib.pn2_mlp_gemm_bf16_seg(*base, None, 2, 64, None) != 0                       # no table
+    dummy = ctypes.cast(ctypes.create_string_buffer(64), vp)
+    assert lib.pn2_mlp_gemm_bf16_seg(*base, dummy, 0, 64, None) != 0                      # no scans
+    assert lib.pn2_mlp_gemm_bf16_seg(*base, dummy, 2, 129, None) != 0                     # longest scan beyond M
+    lib.pn2_bn_finalize_seg.argtypes = [i32, i32, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp, vp]
+    assert lib.pn2_bn_finalize_seg(0, 64, dummy, dummy, None, None, 1e-5, 0.1, None, None, None, dummy, None) != 0
+    assert lib.pn2_bn_finalize_seg(2, 64, dummy, dummy, None, None, 1e-5, 0.1, dummy, None, None, dummy, None) != 0  # mean w/o var
