@@ -243,9 +243,10 @@ def kernel_table(table, steps):
     return rows
 
 
-def roofline_of(top, pmc_applies=True):
+def roofline_of(top, pmc_applies=True, pmc_files=None):
     """`roofline` object for the dominant critical-path kernel row (`pmc_applies`: the committed PMC traffic was
-    collected on the default command — backbone workload, 32 x 50k — and is quoted for that command only)."""
+    collected on the default command — backbone workload, 32 x 50k — and is quoted for that command only; `pmc_files`:
+    the counter summaries of ANOTHER command that has its own committed passes, e.g. the 8-scan bf16 scene-graph step)."""
     if top["bound"] == "mfma":
         roof = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["TFLOPps"],
                 "peak": top.get("mfma_peak_TFLOPps", F32_MFMA_PEAK_TFLOPS), "unit": "TFLOP/s", "frac": top["frac"]}
@@ -269,6 +270,8 @@ def roofline_of(top, pmc_applies=True):
              if bf16 else
              (("r03_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r02_backbone_counters.json", "hbm_MB_per_launch", 1e6),
               ("r01_hbm_traffic_per_kernel.json", "hbm_bytes_per_launch", 1.0)))
+    if pmc_files is not None:
+        files, pmc_applies = tuple((f, "hbm_MB_per_launch", 1e6) for f in pmc_files), True
     for fname, key, scale in files:
         tf = os.path.join(REPO, "profiles", fname)
         if not (pmc_applies and kname and os.path.exists(tf)) or traffic is not None:
@@ -514,7 +517,10 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
             main_rows = [r for r in rows if not r["kernel"].endswith("@side")]
             out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
             if main_rows:
-                out["roofline"] = roofline_of(main_rows[0], False)
+                # the one scene-graph command with committed counter passes (tools/profile_round.sh r03_sgp8_bf16 ...)
+                own = (["r03_sgp8_bf16_counters.json"] if (S == 8 and args.dtype == "bf16" and model.per_scan_statistics
+                                                           and not args.with_prep and world == 1) else None)
+                out["roofline"] = roofline_of(main_rows[0], False, own)
         emit_json(out, args)
     if distributed:
         dist.destroy_process_group()
