@@ -205,6 +205,32 @@ __global__ __launch_bounds__(kBlock) void segment_bn_bwd_kernel(int C, int ldx, 
   }
 }
 
+// Running statistics of a BatchNorm1d after the training-mode steps of S scans, in scan order: running <- (1 - m) running
+// + m stat_s with the unbiased variance n/(n-1) var, as torch.nn.functional.batch_norm updates them once per call
+// (EXT network_PointNet.py heads: nn.BatchNorm1d(512) / (256) with running statistics, :198-203).  mean / rstd (S,C) as
+// segment_bn_fwd_kernel leaves them; a scan of fewer than 1 row is skipped.
+__global__ __launch_bounds__(kBlock) void segment_bn_running_kernel(int S, int C, const float *__restrict__ mean,
+                                                                   const float *__restrict__ rstd,
+                                                                   const int64_t *__restrict__ ptr, float eps, float momentum,
+                                                                   float *__restrict__ rm, float *__restrict__ rv,
+                                                                   long long *__restrict__ nbt) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c == 0 && nbt) *nbt += S;
+  if (c >= C) return;
+  float m = rm[c], v = rv[c];
+  for (int s = 0; s < S; ++s) {
+    const float n = (float)(ptr[s + 1] - ptr[s]);
+    if (!(n > 0.f)) continue;
+    const float r = rstd[(size_t)s * C + c];
+    float var = fmaxf(1.0f / (r * r) - eps, 0.f);
+    var = var * n / fmaxf(n - 1.f, 1.f);
+    m = (1.f - momentum) * m + momentum * mean[(size_t)s * C + c];
+    v = (1.f - momentum) * v + momentum * var;
+  }
+  rm[c] = m;
+  rv[c] = v;
+}
+
 inline unsigned row_grid(long long rows) {
   long long g = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
   if (g > 16384) g = 16384;
@@ -298,5 +324,17 @@ extern "C" int pn2_segment_bn_rows_grad(int64_t R, int C, int ldx, int col0, int
   hipLaunchKernelGGL(segment_bn_bwd_kernel, dim3((unsigned)((C + kBlock - 1) / kBlock), (unsigned)S), dim3(kBlock), 0,
                      (hipStream_t)stream, C, ldx, col0, relu, grad_out, x, ptr, gamma, beta, mean, rstd, grad_x,
                      dgamma_part, dbeta_part);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_segment_bn_running_update(int64_t S, int C, const float *mean, const float *rstd, const int64_t *ptr,
+                                             float eps, float momentum, float *running_mean, float *running_var,
+                                             long long *num_batches_tracked, void *stream) {
+  if (S < 0 || C < 0 || S > 0x7fffffff) return PN2_EINVAL;
+  if (S == 0 || C == 0) return PN2_OK;
+  if (!mean || !rstd || !ptr || !running_mean || !running_var) return PN2_ENULL;
+  hipLaunchKernelGGL(segment_bn_running_kernel, dim3((unsigned)((C + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (int)S, C, mean, rstd, ptr, eps, momentum, running_mean, running_var,
+                     num_batches_tracked);
   return pn2_check_launch();
 }

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "pn2_segment_bn_rows": [_c_i64, _c_int, _c_int, _c_int, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_f32, _c_int, _c_vp, _c_vp,
                             _c_vp, _c_vp],
     "pn2_segment_bn_rows_grad": [_c_i64, _c_int, _c_int, _c_int, _c_i64] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 4,
+    "pn2_segment_bn_running_update": [_c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_prep_object_boxes": [_c_int, _c_int, _c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_prep_chunk_counts": [_c_int] * 4 + [_c_vp] * 6,
     "pn2_prep_select": [_c_int] * 6 + [ctypes.c_uint] + [_c_vp] * 7,
@@ -781,7 +782,22 @@ def segment_bn_rows_grad(grad_out, x, ptr, gamma, beta, mean, rstd, relu, col0=0
     _call("pn2_segment_bn_rows_grad", x, R, C, x.size(1), int(col0), S, _ptr(grad_out), _ptr(x), _ptr(ptr), _ptr(gamma),
           _ptr(beta), _ptr(mean), _ptr(rstd), int(bool(relu)), _ptr(gx), _ptr(dg), _ptr(db),
           alg_bytes=12 * R * C + 16 * S * C)
+    if S == 1:                                   # (one scan: its partial sums ARE the gradients — no reduction launches)
+        return gx, dg.view(C), db.view(C)
     return gx, dg.sum(0), db.sum(0)
+
+
+def segment_bn_running_update(mean, rstd, ptr, eps, momentum, running_mean, running_var, num_batches_tracked=None):
+    """Running statistics after the S per-scan training batches whose (mean, rstd) (S,C) segment_bn_rows returned: the S
+    momentum updates in scan order, unbiased variance, `num_batches_tracked` += S — one launch."""
+    _f32(mean, "mean"); _f32(rstd, "rstd"); _i64(ptr, "ptr"); _f32(running_mean, "running_mean"); _f32(running_var, "running_var")
+    S, C = mean.shape
+    if ptr.numel() != S + 1 or running_mean.numel() != C or running_var.numel() != C:
+        raise RuntimeError("segment_bn_running_update: mean / rstd (S,C), ptr (S+1), running statistics (C) expected")
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        _fail("segment_bn_running_update: num_batches_tracked must be int64")
+    _call("pn2_segment_bn_running_update", mean, S, C, _ptr(mean), _ptr(rstd), _ptr(ptr), float(eps), float(momentum),
+          _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked))
 
 
 # ---------------------------------------------- fused shared-MLP kernels (A10)

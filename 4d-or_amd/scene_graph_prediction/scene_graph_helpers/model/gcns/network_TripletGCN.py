@@ -146,6 +146,30 @@ class SceneBatch:
         return self.map_tensors(lambda t: t.to(device, non_blocking=True))
 
 
+class OneScan:
+    """The (node_ptr, edge_ptr) row offsets of ONE scan on the device: lets a single-scan step take the fused per-scan
+    BatchNorm (+ReLU) kernel — one launch forward and one backward per BatchNorm1d instead of torch's three + ReLU resp. two
+    + the ReLU mask — with the very arithmetic a batch of scans gets.  Cached per (device, rows): built from host numbers
+    (a copy, not capturable), so the first, eager step of a signature creates it."""
+    _CACHE = {}
+    _MAX = 4096
+
+    def __init__(self, device, n_nodes, n_edges):
+        self.node_ptr = torch.tensor([0, int(n_nodes)], dtype=torch.int64, device=device)
+        self.edge_ptr = torch.tensor([0, int(n_edges)], dtype=torch.int64, device=device)
+        self.num_scenes = 1
+
+    @classmethod
+    def get(cls, device, n_nodes, n_edges):
+        key = (device, int(n_nodes), int(n_edges))
+        hit = cls._CACHE.get(key)
+        if hit is None:
+            if len(cls._CACHE) >= cls._MAX:
+                cls._CACHE.clear()
+            hit = cls._CACHE[key] = cls(device, n_nodes, n_edges)
+        return hit
+
+
 class _SegmentBNReLU(Function):
     """BatchNorm1d(track_running_stats=False) [+ ReLU] with per-scan statistics (one launch for all scans)."""
 

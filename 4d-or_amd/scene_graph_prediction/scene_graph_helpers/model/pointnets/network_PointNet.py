@@ -21,9 +21,14 @@ def scan_batch_norm(bn: nn.BatchNorm1d, x, ptr):
     y, mean, rstd = SegmentBatchNorm.apply(x, ptr, bn.weight, bn.bias, bn.eps)
     if bn.running_mean is not None:
         with torch.no_grad():
+            S = mean.size(0)
+            if bn.momentum is not None and x.is_cuda:                              # one launch (pn2_segment_bn_running_update)
+                from pointnet2_ops import _ext
+                _ext.segment_bn_running_update(mean, rstd, ptr, bn.eps, float(bn.momentum), bn.running_mean, bn.running_var,
+                                               bn.num_batches_tracked)
+                return y
             n = (ptr[1:] - ptr[:-1]).to(x.dtype).unsqueeze(1)                      # rows per scan
             var = (1.0 / (rstd * rstd) - bn.eps).clamp_min(0) * n / (n - 1).clamp_min(1)
-            S = mean.size(0)
             if bn.momentum is None:                                                # cumulative average
                 for s in range(S):
                     bn.num_batches_tracked += 1

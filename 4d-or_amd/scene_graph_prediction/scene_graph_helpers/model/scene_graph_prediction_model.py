@@ -20,6 +20,7 @@ was attached with ``attach_image_model``).  The batch then carries either ``full
 CNN) or ``full_image_features`` (6, num_features) computed by it ahead of time.
 """
 import contextlib
+import os
 from collections import defaultdict
 
 import torch
@@ -28,7 +29,7 @@ import torch.optim as optim
 from torch import nn
 
 from pointnet2_ops.pointnet2_modules import per_scan_statistics
-from scene_graph_prediction.scene_graph_helpers.model.gcns.network_TripletGCN import TripletGCNModel
+from scene_graph_prediction.scene_graph_helpers.model.gcns.network_TripletGCN import OneScan, TripletGCNModel
 from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet import PointNetCls, PointNetRelCls
 from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet2 import PointNetfeat as PointNetfeat2
 
@@ -115,6 +116,11 @@ class SGPNModelWrapper(nn.Module):
     #: arithmetic of S single-scan steps of the reference (main.py:54-56) with their gradients averaged.  False: the encoders
     #: and heads normalise over the whole batch (fewer launches, a different — larger-batch — BatchNorm).
     per_scan_statistics = True
+    #: a single scan on the GPU through the fused per-scan BatchNorm kernels too (38 launches fewer per step).  Off by
+    #: default: measured on one box, 1 scan per step, 115.9 / 116.4 scans/s without vs 113.5 / 115.3 with — a Python autograd
+    #: Function + C call per BatchNorm costs the host thread as much as torch's four native launches, and the step is bound
+    #: by the host thread, not by the launch count (PN2_ONE_SCAN_SEGMENTS=1 switches it on)
+    one_scan_segments = os.environ.get("PN2_ONE_SCAN_SEGMENTS", "0") == "1"
 
     def forward(self, batch, return_meta_data=False):
         geo = batch.get("geometry")
@@ -125,8 +131,15 @@ class SGPNModelWrapper(nn.Module):
         with (per_scan_statistics(scenes.nodes_per_scene, scenes.edges_per_scene) if per_scan else contextlib.nullcontext()):
             obj_feature = self.obj_encoder(batch["obj_points"], geometry=None if geo is None else geo["obj"])
             rel_feature = self.rel_encoder(batch["rel_points"], geometry=None if geo is None else geo["rel"])
+        gcn_scenes = scenes
+        if scenes is None and self.one_scan_segments and obj_feature.is_cuda and rel_feature.size(0) >= 2:
+            # one scan on the GPU: the BatchNorm1d layers of the GCN and (training) of the heads through the per-scan kernel
+            # of the batched path — same statistics, a third of the launches (network_TripletGCN.OneScan)
+            gcn_scenes = OneScan.get(obj_feature.device, obj_feature.size(0), rel_feature.size(0))
+            if self.training and obj_feature.size(0) >= 2:
+                node_ptr, edge_ptr = gcn_scenes.node_ptr, gcn_scenes.edge_ptr
         gcn_obj_feature, gcn_rel_feature = self.gcn(obj_feature, rel_feature, batch["edge_indices"], batch.get("edge_csr"),
-                                                    scenes=scenes)
+                                                    scenes=gcn_scenes)
         obj_cls = self.obj_predictor(gcn_obj_feature if self.mconfig["OBJ_PRED_FROM_GCN"] else obj_feature,
                                      scan_ptr=node_ptr)
         if self.with_images:

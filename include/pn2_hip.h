@@ -578,6 +578,12 @@ int pn2_segment_bn_rows_grad(int64_t R, int C, int ldx, int col0, int64_t S, con
                              const float *x, const int64_t *ptr, const float *gamma, const float *beta,
                              const float *mean, const float *rstd, int relu, float *grad_x,
                              float *dgamma_part, float *dbeta_part, void *stream);
+/* Running statistics of a BatchNorm1d WITH running statistics (the classification heads, network_PointNet.py:198-203) after
+ * the S per-scan batches of pn2_segment_bn_rows, applied in scan order like S calls of F.batch_norm(training=True):
+ * running <- (1 - momentum) running + momentum stat_s, variance unbiased (n_s / (n_s - 1)), num_batches_tracked += S. */
+int pn2_segment_bn_running_update(int64_t S, int C, const float *mean, const float *rstd, const int64_t *ptr, float eps,
+                                  float momentum, float *running_mean, float *running_var, long long *num_batches_tracked,
+                                  void *stream);
 
 /* ----------------------------------------------------------------- (f)4 ---
  * Graphormer pre-processing of the role-prediction task (role_prediction/graphormer/algos.pyx:11-89, called from
