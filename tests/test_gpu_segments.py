@@ -206,3 +206,30 @@ def test_stack_with_segment_table_equals_the_per_scan_loop(case):
     finally:
         fused_mlp.SEG_TABLE = True
         fused_mlp.set_mlp_dtype(prev)
+
+
+def test_head_batch_norm_per_scan_running_statistics_equal_sequential_batch_norm_calls():
+    """scan_batch_norm on the GPU (pn2_segment_bn_rows + pn2_segment_bn_running_update) == S calls of
+    F.batch_norm(training=True) on the scans' rows, in order: outputs, running mean / variance, num_batches_tracked."""
+    import torch.nn.functional as F
+    from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet import scan_batch_norm
+    g = torch.Generator().manual_seed(5)
+    rows = [9, 4, 72, 2, 30]
+    C = 96
+    x = (torch.randn(sum(rows), C, generator=g) * 2 + 0.5).cuda()
+    ptr = torch.tensor([0] + list(torch.tensor(rows).cumsum(0)), dtype=torch.int64, device="cuda")
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2)
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    ref = copy.deepcopy(bn)
+    y = scan_batch_norm(bn, x, ptr)
+    r0, parts = 0, []
+    for r in rows:
+        parts.append(F.batch_norm(x[r0:r0 + r], ref.running_mean, ref.running_var, ref.weight, ref.bias, True, ref.momentum, ref.eps))
+        ref.num_batches_tracked += 1
+        r0 += r
+    torch.testing.assert_close(y, torch.cat(parts), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, ref.running_var, rtol=2e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == len(rows)
