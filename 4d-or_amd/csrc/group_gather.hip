@@ -444,15 +444,34 @@ __global__ __launch_bounds__(kBlock) void group_rows_grad_vec_kernel(
         }
       }
       while (others) {                                               // wave-uniform walk over the other hits
-        const int q = __builtin_ctzll(others);
-        others &= others - 1;
-        const int ii = __builtin_amdgcn_readlane(myi, q);
-        const size_t e = (row0 + s0 + q) * (size_t)ldg + col0;
-        float *dst = base + (size_t)ii * C;
+        // FOUR hits per round: their row loads are independent and fly together — one hit at a time, every hit paid a full
+        // memory latency before its atomics could issue (half-full balls: 33 genuine hits of 64 slots at the scene-graph
+        // encoders' second level, where this walk is most of the kernel)
+        constexpr int U = 4;
+        size_t eu[U];
+        float *du[U];
+        int nq = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          eu[u] = 0; du[u] = base;
+          if (others) {
+            const int q = __builtin_ctzll(others);
+            others &= others - 1;
+            eu[u] = (row0 + s0 + q) * (size_t)ldg + col0;
+            du[u] = base + (size_t)__builtin_amdgcn_readlane(myi, q) * C;
+            nq = u + 1;
+          }
+        }
         for (int c = lane; c < C; c += 64) {
-          const float gv = BF ? __builtin_bit_cast(float, (unsigned)((const unsigned short *)grad_out)[e + c] << 16)
-                              : ((const float *)grad_out)[e + c];
-          atomicAdd(dst + c, gv);
+          float gv[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            gv[u] = u < nq ? (BF ? __builtin_bit_cast(float, (unsigned)((const unsigned short *)grad_out)[eu[u] + c] << 16)
+                                 : ((const float *)grad_out)[eu[u] + c])
+                           : 0.f;
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (u < nq) atomicAdd(du[u] + c, gv[u]);
         }
       }
     }
