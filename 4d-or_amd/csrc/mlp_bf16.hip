@@ -197,6 +197,16 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
       for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
     u32x4 ra[J], rb[J];                              // prefetched raw 16-byte groups (g / x and y)
+    // PRO_POOLG: the (arg-max row, pooled gradient) entries of the next chunk travel with its row loads — entry
+    // t = tid + e * NTH of the ngr x KC entries a chunk has (ns >= 32: one per thread); fetched inside patch_pool they were
+    // two dependent-latency global loads between two barriers, once per chunk
+    constexpr bool PFON = NT * CW < 10;              // (the widest variant has no registers to spare: loads in patch_pool)
+    constexpr int PF = 2;
+    int pf_arg[PF];
+    float pf_g[PF];
+    const long long pg0 = PRO == PRO_POOLG ? row0 / a.ns : 0;
+    const long long plast = (row0 + TM - 1 < a.M - 1 ? row0 + TM - 1 : a.M - 1);
+    const int ngr = PRO == PRO_POOLG ? (int)(plast / a.ns - pg0) + 1 : 0;
     auto issue = [&](int kc) {
       if constexpr (!XF32) {
 #pragma unroll
@@ -205,6 +215,21 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
           const int off = k < a.ldx ? (lr * a.ldx + k) * 2 : kOobOffset;
           if constexpr (PRO != PRO_POOLG) ra[j] = bload128(rX, off, 0);
           if constexpr (PRO == PRO_GY || PRO == PRO_POOLG) rb[j] = bload128(rX2, off, 0);
+        }
+      }
+    };
+    auto issue_pool = [&](int kc) {
+      if constexpr (PRO == PRO_POOLG && PFON) {
+#pragma unroll
+        for (int e = 0; e < PF; ++e) {
+          const int t = tid + e * NTH, gi = t >> 6, k = kc * KC + (t & 63);
+          pf_arg[e] = -1;
+          pf_g[e] = 0.f;
+          if (gi < ngr && k < K) {
+            const size_t o = (size_t)(pg0 + gi) * K + k;
+            pf_arg[e] = a.arg[o];
+            pf_g[e] = a.gP[o];
+          }
         }
       }
     };
@@ -262,10 +287,20 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
     // instead of testing every element against the arg-max (two scattered loads per element) the dense tile
     // c2*y + c3 is staged first and c1*gP is added at the arg-max rows of the neighbourhoods this tile intersects
     auto patch_pool = [&](int kc) {
-      const long long g0 = row0 / a.ns;
-      const long long last = (row0 + TM - 1 < a.M - 1 ? row0 + TM - 1 : a.M - 1);
-      const int ngr = (int)(last / a.ns - g0) + 1;
-      for (int t = tid; t < ngr * KC; t += NTH) {
+      const long long g0 = pg0;
+      if constexpr (PFON)
+#pragma unroll
+      for (int e = 0; e < PF; ++e) {                 // the prefetched entries
+        const int t = tid + e * NTH, gi = t >> 6, kk = t & 63;
+        if (pf_arg[e] >= 0) {
+          const long long row = (g0 + gi) * a.ns + pf_arg[e] - row0;
+          if (row >= 0 && row < TM && row0 + row < a.M) {
+            bf16 *cell = &sA[(int)row * AP + kk];
+            *cell = (bf16)fmaf(sP[kc * KC + kk], pf_g[e], (float)*cell);
+          }
+        }
+      }
+      for (int t = tid + (PFON ? PF * NTH : 0); t < ngr * KC; t += NTH) {   // ns < 16 (CW = 1) only
         const int gi = t >> 6, kk = t & 63, k = kc * KC + kk;
         if (k < K) {
           const size_t o = (size_t)(g0 + gi) * K + k;
@@ -279,6 +314,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
     };
 
     issue(0);
+    issue_pool(0);
     for (int kc = 0; kc < nchunks; ++kc) {
       __syncthreads();                               // the previous chunk's fragment reads are done
       commit(kc);
@@ -287,6 +323,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
       if constexpr (PRO == PRO_POOLG) {
         __syncthreads();
         patch_pool(kc);
+        if (kc + 1 < nchunks) issue_pool(kc + 1);    // in flight during this chunk's matrix products
       }
       __syncthreads();
       const int kb = a.wres ? kc * KC : 0;
@@ -477,6 +514,29 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad_bf16_kernel(const WgradBf16A
 
     // ---- gy tile -> sG (transposed, packed row pairs)
     {
+      // PRO_POOLG: this tile's (arg-max row, pooled gradient) entries are requested BEFORE the dense part is staged —
+      // entry t = tid + e * 256 of the ngr x Nr it has; loaded inside the patch loop below they were ngr rounds of two
+      // global loads each, exposed between two barriers
+      constexpr int PFW = NTW * KTB >= 6 ? 4 : 8;
+      int pf_arg[PFW];
+      float pf_g[PFW];
+      const int Nr = (N + 255) & ~255;
+      const long long q0 = GMODE == PRO_POOLG ? row0 / a.ns : 0;
+      const long long qlast = (row0 + MT - 1 < a.M - 1 ? row0 + MT - 1 : a.M - 1);
+      const int ngr = GMODE == PRO_POOLG ? (int)(qlast / a.ns - q0) + 1 : 0;
+      if constexpr (GMODE == PRO_POOLG) {
+#pragma unroll
+        for (int e = 0; e < PFW; ++e) {
+          const int t = tid + e * 256, gi = t / Nr, n = t - gi * Nr;
+          pf_arg[e] = -1;
+          pf_g[e] = 0.f;
+          if (gi < ngr && n < N) {
+            const size_t o = (size_t)(q0 + gi) * N + n;
+            pf_arg[e] = a.arg[o];
+            pf_g[e] = a.gP[o];
+          }
+        }
+      }
       const rsrc_t rG = make_rsrc((const char *)(GMODE == PRO_GY ? a.G : a.Yl) + (size_t)row0 * N * 2, rows_left * N * 2);
       const rsrc_t rY = make_rsrc((const char *)a.Yl + (size_t)row0 * N * 2, rows_left * N * 2);
       const int tasks = (MT / 2) * CG;
@@ -514,11 +574,20 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad_bf16_kernel(const WgradBf16A
       if constexpr (GMODE == PRO_POOLG) {
         // one non-zero per (neighbourhood, feature): add c1 * gP at the arg-max row of every neighbourhood in this tile
         __syncthreads();
-        const long long q0 = row0 / a.ns;
-        const long long last = (row0 + MT - 1 < a.M - 1 ? row0 + MT - 1 : a.M - 1);
-        const int ngr = (int)(last / a.ns - q0) + 1;
-        for (int gi = 0; gi < ngr; ++gi) {
-          for (int n = tid; n < N; n += 256) {
+#pragma unroll
+        for (int e = 0; e < PFW; ++e) {
+          const int t = tid + e * 256, gi = t / Nr, n = t - gi * Nr;
+          if (pf_arg[e] >= 0) {
+            const long long row = (q0 + gi) * a.ns + pf_arg[e] - row0;
+            if (row >= 0 && row < MT && row0 + row < a.M) {
+              bf16 *cell = &sG[n * MP + swz<MT>(n, (int)row)];
+              *cell = (bf16)fmaf(sC[n], pf_g[e], (float)*cell);
+            }
+          }
+        }
+        for (int t = tid + PFW * 256; t < ngr * Nr; t += 256) {   // more than PFW entries per thread (small ns, wide N)
+          const int gi = t / Nr, n = t - gi * Nr;
+          if (n < N) {
             const size_t o = (size_t)(q0 + gi) * N + n;
             const long long row = (q0 + gi) * a.ns + a.arg[o] - row0;
             if (row >= 0 && row < MT && row0 + row < a.M) {
@@ -1155,7 +1224,12 @@ int dispatch_nt(const GemmBf16Args &a, hipStream_t s) {
     case 1: return launch_gemm<1, 1, PRO, EPI, XF32, YF32>(a, s);
     case 2: return launch_gemm<2, 1, PRO, EPI, XF32, YF32>(a, s);
     case 3: return launch_gemm<3, 1, PRO, EPI, XF32, YF32>(a, s);
-    case 4: return launch_gemm<4, 1, PRO, EPI, XF32, YF32>(a, s);
+    case 4:
+      // resident weights that leave room for ONE workgroup per CU (K = 256 -> N = 128: 68 KB + tile): eight waves on the
+      // tile instead of four — the staging / patch / epilogue phases between the barriers get twice the threads and every
+      // SIMD a second wave (same column sums: a column's partial sums do not depend on CW)
+      if (!XF32 && gemm_lds_need(a.N, a.Kp, PRO, EPI) > 80 * 1024) return launch_gemm<2, 2, PRO, EPI, XF32, YF32>(a, s);
+      return launch_gemm<4, 1, PRO, EPI, XF32, YF32>(a, s);
     case 5: case 6: return launch_gemm<3, 2, PRO, EPI, XF32, YF32>(a, s);
     case 7: case 8: return launch_gemm<4, 2, PRO, EPI, XF32, YF32>(a, s);
     case 9: case 10: return launch_gemm<5, 2, PRO, EPI, XF32, YF32>(a, s);
@@ -1199,6 +1273,9 @@ int dispatch_wgrad(const WgradBf16Args &a, hipStream_t s) {
   }
   if (a.N <= 256) {
     if (a.K <= 32) return launch_wgrad<2, 1, 64, GMODE, AMODE, XF32>(a, s);
+    // 64 < K <= 128 (the pooled 128 -> 256 layers): ALL of K in one block — with two 64-wide blocks the 256-wide gy / y_l
+    // tiles, two thirds of the kernel's bytes, were read twice (128 accumulator registers per lane instead of 64)
+    if (a.K > 64 && a.K <= 128) return launch_wgrad<2, 4, 64, GMODE, AMODE, XF32>(a, s);
     return launch_wgrad<2, 2, 64, GMODE, AMODE, XF32>(a, s);
   }
   if (a.N <= 384) {
