@@ -1269,13 +1269,17 @@ int dispatch_wgrad(const WgradBf16Args &a, hipStream_t s) {
   if (a.N <= 128) {
     if (a.K <= 32) return launch_wgrad<1, 1, 128, GMODE, AMODE, XF32>(a, s);
     if (a.K <= 64) return launch_wgrad<1, 2, 128, GMODE, AMODE, XF32>(a, s);
+    // every K block re-reads the gy / y_l tiles: K = 131 (128 features + xyz) as ONE 160-wide block instead of 128 + 3
+    // (0.27 -> 0.22 ms at 1M rows; K = 259 as 160 + 99 instead of 128 + 128 + 3 measured slower next to the sampling kernels)
+    if constexpr (GMODE == PRO_GY)                   // (the pooled-gradient form has no registers for a fifth tile)
+      if (a.K > 128 && a.K <= 160) return launch_wgrad<1, 5, 128, GMODE, AMODE, XF32>(a, s);
     return launch_wgrad<1, 4, 128, GMODE, AMODE, XF32>(a, s);
   }
   if (a.N <= 256) {
     if (a.K <= 32) return launch_wgrad<2, 1, 64, GMODE, AMODE, XF32>(a, s);
     // 64 < K <= 128 (the pooled 128 -> 256 layers): ALL of K in one block — with two 64-wide blocks the 256-wide gy / y_l
-    // tiles, two thirds of the kernel's bytes, were read twice (128 accumulator registers per lane instead of 64)
-    if (a.K > 64 && a.K <= 128) return launch_wgrad<2, 4, 64, GMODE, AMODE, XF32>(a, s);
+    // tiles, two thirds of the kernel's bytes, were read once per block (128 accumulator registers per lane instead of 64)
+    if (a.K > 64 && a.K <= 128) return launch_wgrad<2, 4, 64, GMODE, AMODE, XF32>(a, s);   // (wider K: small M, the blocks are the parallelism)
     return launch_wgrad<2, 2, 64, GMODE, AMODE, XF32>(a, s);
   }
   if (a.N <= 384) {
