@@ -710,7 +710,11 @@ struct BwdBf16Args {
 };
 
 template <int NTN, int KTK, int GMODE, bool FOLD = false>
-__global__ __launch_bounds__(512, 2) void mlp_bwd_bf16_kernel(const BwdBf16Args a_in) {
+// (HIP's second launch-bounds argument is waves per SIMD, not workgroups per CU.  The FOLD variants took 144-156 registers
+// under "2": three waves per SIMD, i.e. ONE eight-wave workgroup per CU.  Capped at 128 they spill 24-88 bytes outside
+// the tile loop's matrix products and two workgroups share a CU: 4.2M x 64 x 64 fold 0.59 -> 0.48 ms.  The 128 x 128
+// non-fold variants lose with the same cap (0.22 -> 0.25 ms) and keep their registers.)
+__global__ __launch_bounds__(512, FOLD ? 4 : 2) void mlp_bwd_bf16_kernel(const BwdBf16Args a_in) {
   BwdBf16Args a = a_in;
   if (a.seg) {
     const int sg = blockIdx.y;
