@@ -713,7 +713,7 @@ template <int NTN, int KTK, int GMODE, bool FOLD = false>
 // (HIP's second launch-bounds argument is waves per SIMD, not workgroups per CU.  The FOLD variants took 144-156 registers
 // under "2": three waves per SIMD, i.e. ONE eight-wave workgroup per CU.  Capped at 128 they spill 24-88 bytes outside
 // the tile loop's matrix products and two workgroups share a CU: 4.2M x 64 x 64 fold 0.59 -> 0.48 ms.  The 128 x 128
-// non-fold variants lose with the same cap (0.22 -> 0.25 ms) and keep their registers.)
+// non-fold variants lose with the same cap (0.22 -> 0.25 ms; pooled form at 18.9M rows 5.06 -> 5.23 ms) and keep their registers.)
 __global__ __launch_bounds__(512, FOLD ? 4 : 2) void mlp_bwd_bf16_kernel(const BwdBf16Args a_in) {
   BwdBf16Args a = a_in;
   if (a.seg) {
@@ -1275,8 +1275,12 @@ int dispatch_wgrad(const WgradBf16Args &a, hipStream_t s) {
     if (a.K <= 64) return launch_wgrad<1, 2, 128, GMODE, AMODE, XF32>(a, s);
     // every K block re-reads the gy / y_l tiles: K = 131 (128 features + xyz) as ONE 160-wide block instead of 128 + 3
     // (0.27 -> 0.22 ms at 1M rows; K = 259 as 160 + 99 instead of 128 + 128 + 3 measured slower next to the sampling kernels)
-    if constexpr (GMODE == PRO_GY)                   // (the pooled-gradient form has no registers for a fifth tile)
+    if constexpr (GMODE == PRO_GY) {                 // (the pooled-gradient form has no registers for a fifth tile)
       if (a.K > 128 && a.K <= 160) return launch_wgrad<1, 5, 128, GMODE, AMODE, XF32>(a, s);
+    }
+    // K = 195 (the scene-graph encoders' 192 features + xyz): 128 + 67 read gy / y_l twice; one 224-wide block on 64-row
+    // tiles (112 accumulator registers): 18.9M rows 4.86 -> 3.89 ms
+    if (a.K > 160 && a.K <= 224 && !XF32) return launch_wgrad<1, 7, 64, GMODE, AMODE, XF32>(a, s);
     return launch_wgrad<1, 4, 128, GMODE, AMODE, XF32>(a, s);
   }
   if (a.N <= 256) {
