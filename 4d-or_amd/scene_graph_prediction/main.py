@@ -50,7 +50,7 @@ def train(model, config, scans, device, epochs=1, graphs=False, rank=0, world=1,
     they would otherwise sit in the buffer as zeros and take AdamW's weight decay; rank 0's initial weights are broadcast.
     Returns the list of (step, loss) of this rank."""
     import torch.distributed as dist
-    from runtime import FlatGrads, GeometryPrefetcher, GraphedTrainStep
+    from runtime import FlatGrads, GeometryPrefetcher, GraphedTrainStep, ScheduledGC
     model.train()
     flat = None
     if graphs or world > 1:
@@ -71,26 +71,30 @@ def train(model, config, scans, device, epochs=1, graphs=False, rank=0, world=1,
         flat = FlatGrads(model.parameters())
     mine = scans[rank::world]
     history = []
-    for epoch in range(epochs):
-        device_scans = (to_device(scan, device) for scan in mine)
-        # the next scan's sampling geometry is prefetched on a side stream (GPU only)
-        it = GeometryPrefetcher(model.precompute_geometry, device_scans) if device.type == "cuda" else device_scans
-        for i, batch in enumerate(it):
-            if graphed is not None:
-                loss, rel_pred = graphed(batch)
-                model.update_metrics(batch, rel_pred, split="train")
-            else:
-                if flat is not None:
-                    flat.zero_()
+    # cyclic-GC passes on the loop's schedule (runtime/gc_schedule.py): an automatic generation-2 pass stops the enqueueing
+    # thread for longer than its lead over the GPU
+    with ScheduledGC(every=200) as sgc:
+        for epoch in range(epochs):
+            device_scans = (to_device(scan, device) for scan in mine)
+            # the next scan's sampling geometry is prefetched on a side stream (GPU only)
+            it = GeometryPrefetcher(model.precompute_geometry, device_scans) if device.type == "cuda" else device_scans
+            for i, batch in enumerate(it):
+                if graphed is not None:
+                    loss, rel_pred = graphed(batch)
+                    model.update_metrics(batch, rel_pred, split="train")
                 else:
-                    opt.zero_grad(set_to_none=True)
-                loss = model.training_step(batch, i)
-                loss.backward()
-                if flat is not None:
-                    flat.all_reduce_mean()
-                opt.step()
-            history.append((epoch * len(mine) + i, float(loss.detach())))
-            log(f"[rank {rank}] epoch {epoch} step {i}: loss {history[-1][1]:.4f}")
+                    if flat is not None:
+                        flat.zero_()
+                    else:
+                        opt.zero_grad(set_to_none=True)
+                    loss = model.training_step(batch, i)
+                    loss.backward()
+                    if flat is not None:
+                        flat.all_reduce_mean()
+                    opt.step()
+                sgc.step()
+                history.append((epoch * len(mine) + i, float(loss.detach())))
+                log(f"[rank {rank}] epoch {epoch} step {i}: loss {history[-1][1]:.4f}")
     return history
 
 

@@ -110,3 +110,25 @@ def test_two_rank_gloo_flat_gradient_allreduce(tmp_path):
     res = torch.load(out)
     torch.testing.assert_close(res["reduced"], (res["local"][0] + res["local"][1]) / 2, atol=1e-7, rtol=1e-6)
     assert torch.equal(res["params"][0], res["params"][1])
+
+
+def test_scheduled_gc_freezes_disables_and_restores():
+    """runtime.ScheduledGC: automatic collector off inside, young-generation pass every `every` steps, state restored."""
+    import gc
+    from runtime import ScheduledGC
+    assert gc.isenabled()
+    with ScheduledGC(every=2) as sgc:
+        assert not gc.isenabled() and gc.get_freeze_count() > 0
+
+        class Node:
+            pass
+        a, b = Node(), Node()
+        a.other, b.other = b, a            # a reference cycle only the collector can free
+        import weakref
+        w = weakref.ref(a)
+        del a, b
+        sgc.step()
+        assert w() is not None             # no pass yet, and the automatic collector is off
+        sgc.step()
+        assert w() is None                 # collected at the second step boundary
+    assert gc.isenabled() and gc.get_freeze_count() == 0
