@@ -126,7 +126,10 @@ def test_gemm_bf16_dgrad_modes(M, Nl, Kl, ns, pooled):
 
 @pytest.mark.parametrize("M,N,K,kind", [(1000, 128, 64, "bf"), (3000, 64, 64, "bf"), (2000, 256, 128, "bf"), (777, 128, 6, "f32"),
                                         (1500, 128, 136, "pad131"), (900, 288, 256, "bf"), (640, 128, 259, "f32"),
-                                        (1100, 64, 7, "f32"), (512, 256, 512, "bf")])
+                                        (1100, 64, 7, "f32"), (512, 256, 512, "bf"),
+                                        # one-block routes of the K = 131 / 195 first layers and the 128 -> 256 pooled layers
+                                        (1300, 128, 200, "pad195"), (1216, 96, 200, "pad195"), (700, 128, 192, "bf"),
+                                        (1900, 200, 128, "bf"), (2100, 128, 160, "bf")])
 @pytest.mark.parametrize("pooled", [False, True])
 def test_wgrad_bf16(M, N, K, kind, pooled):
     from pointnet2_ops import _ext as e
@@ -149,8 +152,8 @@ def test_wgrad_bf16(M, N, K, kind, pooled):
     if kind == "f32":
         X = torch.randn(M, K, generator=g).cuda()
         act, amode, a_fin, Ktrue = _r(X), e.PRO_NONE, None, K
-    elif kind == "pad131":
-        Ktrue = 131
+    elif kind in ("pad131", "pad195"):
+        Ktrue = int(kind[3:])
         X = torch.zeros(M, K)
         X[:, :Ktrue] = torch.randn(M, Ktrue, generator=g)
         X = X.to(BF).cuda()
