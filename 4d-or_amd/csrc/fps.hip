@@ -22,6 +22,7 @@
 //    running distance of -1, which can never beat best = -1.
 //  * Clouds too large for the register file use the streaming kernel with the
 //    running distances in a caller-provided workspace.
+#include <atomic>
 #include "pn2_common.h"
 
 #include <math.h>
@@ -924,7 +925,7 @@ struct FpsOverride {
   int G, NC, coop_bs, bs;   // 0 = heuristic
 };
 FpsOverride g_fps_override = {-1, 0, 0, 0, 0};
-bool g_fps_bucketing = true;     // (pn2_fps_set_bucketing: tests and measurements compare both forms)
+std::atomic<bool> g_fps_bucketing{true};     // (pn2_fps_set_bucketing: tests and measurements compare both forms)
 
 // Number of CUs of the current device (a CPX/DPX partition reports its own count); every cluster workgroup must be
 // resident at once, so the cluster shapes are sized from this instead of a hard-coded 256.
@@ -940,7 +941,10 @@ int device_cus() {
   return cus[dev];
 }
 
-FpsPlan fps_plan(int B, int N, int m, bool few_cus = false, bool fewest = false) {
+// `bucketing`: -1 = the process-wide switch, 0 / 1 = as given (pn2_fps_workspace_bytes sizes both layouts without touching
+// the switch other host threads read)
+FpsPlan fps_plan(int B, int N, int m, bool few_cus = false, bool fewest = false, int bucketing = -1) {
+  const bool use_bucketing = bucketing < 0 ? g_fps_bucketing.load(std::memory_order_relaxed) : bucketing != 0;
   FpsPlan p = {2, 1, 1024, 0, 1};
   if (m <= 1) { p.mode = 0; p.BS = 512; p.PPT = 1; return p; }
   const FpsOverride ov = g_fps_override;
@@ -1035,7 +1039,7 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false, bool fewest = false)
   if (ov.mode == 4 && k.mode == 4) return k;
   // ... when the batch does not fit the chip's registers any more (~20k points per CU): 64 x 200k points 42 -> 13 ms per
   // step of samplings; a batch that does fit (32 x 50k: 1.6M of 5.2M slots) is as fast on a cluster (4.9 vs 4.8 ms)
-  if (ov.mode < 0 && g_fps_bucketing && k.mode == 4 && N > 16384 && (long long)B * N > (long long)ncus * 1024 * 20) return k;
+  if (ov.mode < 0 && use_bucketing && k.mode == 4 && N > 16384 && (long long)B * N > (long long)ncus * 1024 * 20) return k;
 
   if (want_coop && c.mode == 1) return c;
   if (want_resident && r.mode == 0) return r;
@@ -1115,9 +1119,10 @@ extern "C" int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, i
 
 // Test / measurement hook: spatial bucketing of the cluster kernels on (default) / off.  Results never depend on it.
 extern "C" int pn2_fps_set_bucketing(int on) {
-  g_fps_bucketing = on != 0;
+  g_fps_bucketing.store(on != 0, std::memory_order_relaxed);
   return PN2_OK;
 }
+extern "C" int pn2_fps_get_bucketing(void) { return g_fps_bucketing.load(std::memory_order_relaxed) ? 1 : 0; }
 
 // cluster plans also reserve the streaming kernel's B x N floats behind the hand-off slots: the fallback when the
 // cluster would not be resident on this device
@@ -1133,12 +1138,8 @@ extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int m) {
   if (B <= 0 || N <= 0 || m <= 1) return 0;
   // the largest layout any plan of this shape can ask for (scheduling hints, the bucketing switch and the plan override
   // change the plan, not the workspace a caller has to bring)
-  const bool save = g_fps_bucketing;
-  g_fps_bucketing = false;
-  const FpsPlan p = fps_plan(B, N, m);
-  g_fps_bucketing = true;
-  const FpsPlan kb = fps_plan(B, N, m);
-  g_fps_bucketing = save;
+  const FpsPlan p = fps_plan(B, N, m, false, false, 0);
+  const FpsPlan kb = fps_plan(B, N, m, false, false, 1);
   size_t need = 0;
   // cluster plans: hand-off slots | status | B x N floats (streaming fallback / streamed tail) | B x N binned records
   if (p.mode == 1 || p.mode == 3)
@@ -1219,7 +1220,7 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     // ... and 1024-thread workgroups, i.e. the shapes of a sampling that runs next to a training step (scheduling hints)
     // or a forced one: there the skipped updates are VALU time handed to the co-running kernels (same-box A/B of the
     // default step 15.45 -> 15.12 ms); the latency-optimal 512-thread clusters gain nothing (the round is the hand-off)
-    const bool buck = plan.NC == 1 && plan.PPT >= 8 && plan.BS == 1024 && g_fps_bucketing;
+    const bool buck = plan.NC == 1 && plan.PPT >= 8 && plan.BS == 1024 && g_fps_bucketing.load(std::memory_order_relaxed);
     if (buck) hipLaunchKernelGGL(fps_bucket_kernel, dim3((unsigned)B), dim3(1024), 0, s, N, N, xyz, rec);
 #define PN2_FPS_COOP_B(BSZ, PPT)                                                                    \
   {                                                                                                 \

@@ -166,6 +166,8 @@ _lib.pn2_event_destroy.argtypes = [_c_vp]
 _lib.pn2_event_destroy.restype = _c_int
 _lib.pn2_fps_set_bucketing.argtypes = [_c_int]
 _lib.pn2_fps_set_bucketing.restype = _c_int
+_lib.pn2_fps_get_bucketing.argtypes = []
+_lib.pn2_fps_get_bucketing.restype = _c_int
 if os.environ.get("PN2_FPS_BUCKETING") == "0":       # measurement switch (tools, A/B runs of bench.py)
     _lib.pn2_fps_set_bucketing(0)
 _lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
@@ -192,7 +194,7 @@ ABI_VERSION = int(_lib.pn2_abi_version())
 #: error instead of an AttributeError on the first missing symbol
 EXPECTED_ABI_VERSION = 3
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
-                                               "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing",
+                                               "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
                                                "pn2_event_create", "pn2_event_record", "pn2_event_elapsed_ms", "pn2_event_destroy",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
@@ -393,11 +395,12 @@ _FPS_MODES = {None: -1, "resident": 0, "coop": 1, "stream": 2, "hybrid": 3, "buc
 @contextlib.contextmanager
 def fps_bucketing(on):
     """Test / measurement hook (pn2_fps_set_bucketing): spatial bucketing of the cluster FPS kernels on / off."""
+    prev = int(_lib.pn2_fps_get_bucketing())
     _lib.pn2_fps_set_bucketing(1 if on else 0)
     try:
         yield
     finally:
-        _lib.pn2_fps_set_bucketing(1)
+        _lib.pn2_fps_set_bucketing(prev)        # what it was (PN2_FPS_BUCKETING=0 processes stay off)
 
 
 @contextlib.contextmanager

@@ -1,14 +1,19 @@
 """The reference's per-scan sample cache (SGH/dataset/or_dataset.py:94-120): ``np.savez_compressed(path, sample)`` of ONE
 python dict per scan — read back with ``np.load(path, allow_pickle=True)['arr_0'].item()`` — holding the prepared crops so
-that ``data_preparation`` (open3d, ~seconds per scan) runs once per scan.  Same file format and keys, so caches written by
-the reference load here and the other way round:
+that ``data_preparation`` (open3d, ~seconds per scan) runs once per scan.  Same file format, keys AND tensor layout, so
+caches written by the reference load here and the other way round:
 
     scan_id, objs_json, instance2mask, obj_points, rel_points, gt_class, gt_rels, edge_indices,
     relation_objects_one_hot, rel_hand_points
 
-(or_dataset.py:101-118).  Tensors are stored as the torch CPU tensors / numpy arrays they are in the sample; keys this
-build does not produce (``instance2mask``, ``rel_hand_points``: hand locations for the augmentations) are written as None
-unless the caller supplies them."""
+(or_dataset.py:101-118).  What the file holds is the PRE-collate sample of ``ORDataset.__getitem__`` — point-major
+``obj_points (n_obj, P, 6)``, ``rel_points (E, P, 7)``, ``edge_indices (E, 2)``, ``gt_class`` as ``data_preparation``
+returned it — and ``ORDataset.collate_fn`` (or_dataset.py:63-74) turns it into what the model consumes: channel-first
+clouds, ``edge_indices (2, E)``, flat int64 ``gt_class``, ``take_idx`` from the scan id.  The tensors this build works with
+(``gpu_preparation.prepare_scan``, ``synthetic.synthetic_scan``) are the POST-collate ones, so ``save_sample`` undoes the
+collate before writing and ``load_sample`` / ``cached`` apply it after reading (``collate_sample``).  Keys this build does
+not produce (``instance2mask``, ``rel_hand_points``: hand locations for the augmentations) are written as None unless the
+caller supplies them."""
 import os
 from pathlib import Path
 from typing import Callable, Dict, Optional
@@ -24,34 +29,79 @@ def cache_path(folder, scan_id: str) -> Path:
     return Path(folder) / f"{scan_id}.npz"                             # or_dataset.py:94
 
 
-def save_sample(folder, sample: Dict) -> Path:
-    """Write `sample` in the reference's cache format (tensors moved to the host; GPU-side extras dropped)."""
-    path = cache_path(folder, sample["scan_id"])
-    os.makedirs(path.parent, exist_ok=True)
+def take_of(scan_id) -> int:
+    """or_dataset.py:72: ``int(scan_id.split('_')[0])``; ids that do not start with a take number (synthetic scans) -> 0."""
+    try:
+        return int(str(scan_id).split("_")[0])
+    except ValueError:
+        return 0
+
+
+def collate_sample(sample: Dict) -> Dict:
+    """``ORDataset.collate_fn`` (or_dataset.py:63-74) on one cached (pre-collate) sample; returns a new dict."""
+    out = dict(sample)
+    for k in ("obj_points", "rel_points"):
+        if out.get(k) is not None:
+            out[k] = torch.as_tensor(out[k]).permute(0, 2, 1).contiguous()      # (n, P, C) -> (n, C, P)
+    if out.get("gt_class") is not None:
+        out["gt_class"] = torch.as_tensor(out["gt_class"]).flatten().long()
+    if out.get("edge_indices") is not None:
+        out["edge_indices"] = torch.as_tensor(out["edge_indices"]).t().contiguous()   # (E, 2) -> (2, E)
+    for k in ("gt_rels", "relation_objects_one_hot"):
+        if out.get(k) is not None:
+            out[k] = torch.as_tensor(out[k])
+    out["take_idx"] = take_of(out.get("scan_id", ""))
+    return out
+
+
+def uncollate_sample(sample: Dict) -> Dict:
+    """The inverse of ``collate_sample`` for the keys of the cache file: model-ready tensors -> the reference's stored
+    layout (host tensors)."""
     out = {}
     for k in CACHE_KEYS:
         v = sample.get(k)
-        out[k] = v.detach().cpu() if torch.is_tensor(v) else v
-    np.savez_compressed(str(path), out)                                # or_dataset.py:120: one pickled dict under 'arr_0'
+        v = v.detach().cpu() if torch.is_tensor(v) else v
+        if v is not None and k in ("obj_points", "rel_points"):
+            v = v.permute(0, 2, 1).contiguous()                        # (n, C, P) -> (n, P, C)
+        if v is not None and k == "edge_indices":
+            v = v.t().contiguous()                                     # (2, E) -> (E, 2)
+        out[k] = v
+    return out
+
+
+def save_sample(folder, sample: Dict) -> Path:
+    """Write the model-ready `sample` in the reference's cache format (pre-collate layout, tensors on the host; GPU-side
+    extras dropped)."""
+    path = cache_path(folder, sample["scan_id"])
+    os.makedirs(path.parent, exist_ok=True)
+    np.savez_compressed(str(path), uncollate_sample(sample))           # or_dataset.py:120: one pickled dict under 'arr_0'
     return path
 
 
-def load_sample(folder, scan_id: str) -> Optional[Dict]:
+def load_raw(folder, scan_id: str) -> Optional[Dict]:
+    """The stored dict exactly as the reference's ``__getitem__`` reads it (or_dataset.py:96); None on a miss."""
     path = cache_path(folder, scan_id)
     if not path.exists():
         return None
-    return np.load(str(path), allow_pickle=True)["arr_0"].item()       # or_dataset.py:96
+    return np.load(str(path), allow_pickle=True)["arr_0"].item()
+
+
+def load_sample(folder, scan_id: str) -> Optional[Dict]:
+    """The cached scan as the model consumes it (collated); None on a miss."""
+    raw = load_raw(folder, scan_id)
+    return None if raw is None else collate_sample(raw)
 
 
 def cached(folder, scan_id: str, prepare: Callable[[], Dict], device=None) -> Dict:
     """or_dataset.py:94-120: the cached sample if there is one, else `prepare()` (e.g. gpu_preparation.prepare_scan on the
-    resident scan) written to the cache.  `device`: move the tensors there (the model wants them on the GPU)."""
+    resident scan; model-ready layout) written to the cache.  Either way the result is model-ready.  `device`: move the
+    tensors there (the model wants them on the GPU)."""
     sample = load_sample(folder, scan_id)
     if sample is None:
         sample = prepare()
         sample.setdefault("scan_id", scan_id)
         save_sample(folder, sample)
-        sample = {k: sample.get(k) for k in CACHE_KEYS} | {k: v for k, v in sample.items() if k in ("take_idx",)}
+        sample = {k: sample.get(k) for k in CACHE_KEYS} | {"take_idx": sample.get("take_idx", take_of(scan_id))}
     if device is not None:
         sample = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sample.items()}
     return sample

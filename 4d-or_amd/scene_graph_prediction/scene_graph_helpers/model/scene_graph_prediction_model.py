@@ -260,9 +260,10 @@ class SGPNModelWrapper(nn.Module):
             preds[take].extend(p[edge_ptr[s]:edge_ptr[s + 1]])
             gts[take].extend(g[edge_ptr[s]:edge_ptr[s + 1]])
 
-    def evaluate_predictions(self, epoch_loss, split):
+    def evaluate_predictions(self, epoch_loss, split, print_reports=False, log=print):
         """Per-take and overall precision / recall / F1 (sklearn classification_report, like the
-        reference); returns {'macro_f1', 'macro_prec', 'macro_rec', 'weighted_*', 'per_take'}."""
+        reference); returns {'macro_f1', 'macro_prec', 'macro_rec', 'weighted_*', 'per_take'}.  `print_reports`: also
+        print the text reports the reference prints (:216-218, :230-235: "Take k", "<split> Results:")."""
         from sklearn.metrics import classification_report
         if split not in ("train", "val"):
             raise NotImplementedError()
@@ -276,8 +277,15 @@ class SGPNModelWrapper(nn.Module):
             per_take[take] = classification_report(gts[take], preds[take], labels=labels,
                                                    target_names=self.relationNames, output_dict=True,
                                                    zero_division=0)
+            if print_reports:
+                log(f"\nTake {take}\n")
+                log(classification_report(gts[take], preds[take], labels=labels, target_names=self.relationNames,
+                                          zero_division=0))
         res = classification_report(all_gt, all_pred, labels=labels, target_names=self.relationNames,
                                     output_dict=True, zero_division=0)
+        if print_reports:
+            log(f"{split} Results:\n")
+            log(classification_report(all_gt, all_pred, labels=labels, target_names=self.relationNames, zero_division=0))
         return {"epoch_loss": float(epoch_loss), "macro_f1": res["macro avg"]["f1-score"],
                 "macro_prec": res["macro avg"]["precision"], "macro_rec": res["macro avg"]["recall"],
                 "weighted_f1": res["weighted avg"]["f1-score"], "weighted_prec": res["weighted avg"]["precision"],

@@ -95,6 +95,7 @@ int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, int bs);
  * farther from its bounding box than its largest running distance.  Test / measurement hook: 0 switches
  * that off.  Process-global; results never depend on it. */
 int pn2_fps_set_bucketing(int on);
+int pn2_fps_get_bucketing(void);   /* the current value (1 / 0), so that a scoped override can restore it */
 /* Test hook for the multi-workgroup FPS variant: returns the status word a
  * launch left in `workspace` (0 ok, 1 a bounded inter-workgroup wait expired,
  * <0 query failed).  Synchronises `stream`; never used on the hot path. */

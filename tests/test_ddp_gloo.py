@@ -153,7 +153,7 @@ def _runner_worker(rank, world, port, out):
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0                            # deterministic steps (the local reference below re-runs them)
-    scans = [synthetic_scan(3, 300, 400, seed=i, scan_id=f"s{i}") for i in range(4)]
+    scans = [synthetic_scan(3, 300, 400, seed=i, scan_id=f"s{i}") for i in range(5)]     # ODD count on 2 ranks
 
     # reference: what this rank's first step computes locally, from rank 0's weights
     torch.manual_seed(7)
@@ -181,7 +181,8 @@ def _runner_worker(rank, world, port, out):
         hist = runner.train(model, cfg, scans, device, epochs=1, rank=rank, world=world, log=lambda *_: None)
     finally:
         torch.optim.AdamW.step = orig_step
-    assert len(hist) == 2                        # 4 scans over 2 ranks
+    assert len(hist) == 2                        # 5 scans over 2 ranks: the fifth is dropped, both ranks run 2 steps (a
+                                                 # rank with a third step would hang in its all-reduce: ADVICE r03)
     frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
     assert frozen and all(".backbone.fc_layer." in n for n in frozen)
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])

@@ -132,3 +132,32 @@ def test_scheduled_gc_freezes_disables_and_restores():
         sgc.step()
         assert w() is None                 # collected at the second step boundary
     assert gc.isenabled() and gc.get_freeze_count() == 0
+
+
+def test_scheduled_gc_full_pass_frees_promoted_cycles_and_keeps_a_disabled_collector_off():
+    """a cycle that survives a young pass sits in the oldest generation, which gc.collect(1) never visits — every
+    `full_every`-th scheduled pass is a full one; __exit__ restores gc.isenabled() instead of enabling unconditionally."""
+    import gc
+    import weakref
+    from runtime import ScheduledGC
+
+    class Node:
+        pass
+    with ScheduledGC(every=1, full_every=3) as sgc:
+        a, b = Node(), Node()
+        a.other, b.other = b, a
+        w = weakref.ref(a)
+        sgc.step()                          # young pass while the cycle is ALIVE: promoted to the oldest generation
+        sgc.step()                          # (twice: generation 0 -> 1 -> 2)
+        del a, b
+        gc.collect(1)
+        assert w() is not None              # what the old schedule did forever: the young pass cannot see it
+        sgc.step()                          # third scheduled pass = full collection
+        assert w() is None
+    gc.disable()
+    try:
+        with ScheduledGC(every=5):
+            pass
+        assert not gc.isenabled()           # the caller had it off: stays off
+    finally:
+        gc.enable()

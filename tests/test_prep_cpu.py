@@ -53,5 +53,11 @@ def test_sample_cache_has_the_reference_format(tmp_path):
     stored = raw["arr_0"].item()
     assert tuple(stored) == cache.CACHE_KEYS
     for k in ("obj_points", "rel_points", "edge_indices", "gt_class", "gt_rels", "relation_objects_one_hot"):
-        assert torch.equal(torch.as_tensor(stored[k]), scan[k]) and torch.equal(torch.as_tensor(b[k]), scan[k])
+        assert torch.equal(torch.as_tensor(a[k]), scan[k]) and torch.equal(torch.as_tensor(b[k]), scan[k])   # model-ready both times
+    # on disk: the reference's PRE-collate layout (or_dataset.py:101-118 before collate_fn :63-74)
+    assert torch.equal(stored["obj_points"], scan["obj_points"].permute(0, 2, 1))
+    assert torch.equal(stored["rel_points"], scan["rel_points"].permute(0, 2, 1))
+    assert torch.equal(stored["edge_indices"], scan["edge_indices"].t())
+    for k in ("gt_class", "gt_rels", "relation_objects_one_hot"):
+        assert torch.equal(stored[k], scan[k])
     assert stored["scan_id"] == "4_000131" and stored["objs_json"] == scan["objs_json"] and a["scan_id"] == b["scan_id"]
