@@ -278,34 +278,42 @@ def roofline_of(top, pmc_applies=True, pmc_files=None):
         roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"],
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": top["frac"]}
     traffic, traffic_src = None, None
-    kname = {"pn2_mlp_gemm": "mlp_gemm_kernel", "pn2_mlp_gemm_pool": "mlp_gemm_kernel", "pn2_mlp_wgrad": "mlp_wgrad_kernel",
-             "pn2_mlp_bwd_fused": "mlp_bwd_fused_kernel", "pn2_mlp_bwd_fused_fold": "mlp_bwd_fused2_kernel",
-             "pn2_pool_bwd": "pool_bwd64_kernel",
-             "pn2_bn_relu_rows_max": "bn_relu_rows_max_kernel",
-             "pn2_group_concat_rows": "group_concat_rows_wide4_kernel",
-             "pn2_group_rows_grad": "group_rows_grad_csr_kernel",
-             "pn2_mlp_gemm_bf16": "mlp_gemm_bf16_kernel", "pn2_mlp_wgrad_bf16": "mlp_wgrad_bf16_kernel",
-             "pn2_mlp_bwd_bf16": "mlp_bwd_bf16_kernel", "pn2_bn_relu_rows_max_bf16": "bn_relu_rows_max_bf16_v8_kernel",
-             "pn2_group_concat_rows_bf16": "group_concat_rows_bf16_wide8_kernel"}.get(top["kernel"])
+    # PMC records are keyed by C-ABI entry point (`entry:<name>`: tools/kernel_keys.py maps every traced instantiation to the
+    # entry point that launches it), so `traffic` and `alg_bytes_per_launch` describe the same launches; counter files
+    # written before round 4 only have kernel-family keys (second element, mixes e.g. the pooled GEMM into pn2_mlp_gemm)
+    legacy = {"pn2_mlp_gemm": "mlp_gemm_kernel", "pn2_mlp_gemm_pool": "mlp_gemm_kernel", "pn2_mlp_wgrad": "mlp_wgrad_kernel",
+              "pn2_mlp_bwd_fused": "mlp_bwd_fused_kernel", "pn2_mlp_bwd_fused_fold": "mlp_bwd_fused2_kernel",
+              "pn2_pool_bwd": "pool_bwd64_kernel",
+              "pn2_bn_relu_rows_max": "bn_relu_rows_max_kernel",
+              "pn2_group_concat_rows": "group_concat_rows_wide4_kernel",
+              "pn2_group_rows_grad": "group_rows_grad_csr_kernel",
+              "pn2_mlp_gemm_bf16": "mlp_gemm_bf16_kernel", "pn2_mlp_wgrad_bf16": "mlp_wgrad_bf16_kernel",
+              "pn2_mlp_bwd_bf16": "mlp_bwd_bf16_kernel", "pn2_bn_relu_rows_max_bf16": "bn_relu_rows_max_bf16_v8_kernel",
+              "pn2_group_concat_rows_bf16": "group_concat_rows_bf16_wide8_kernel"}.get(top["kernel"])
+    kname = ("entry:" + top["kernel"], legacy)
     bf16 = "bf16" in top["kernel"]
     # newest committed counter summary of the command first (tools/profile_round.sh + tools/summarise_profile.py); the
     # fp32 and the bf16 default commands have their own files
-    files = ((("r03_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r02_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6))
+    files = ((("r04_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6),
+              ("r02_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6))
              if bf16 else
-             (("r03_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r02_backbone_counters.json", "hbm_MB_per_launch", 1e6),
+             (("r04_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_counters.json", "hbm_MB_per_launch", 1e6),
+              ("r02_backbone_counters.json", "hbm_MB_per_launch", 1e6),
               ("r01_hbm_traffic_per_kernel.json", "hbm_bytes_per_launch", 1.0)))
     if pmc_files is not None:
         files, pmc_applies = tuple((f, "hbm_MB_per_launch", 1e6) for f in pmc_files), True
     for fname, key, scale in files:
         tf = os.path.join(REPO, "profiles", fname)
-        if not (pmc_applies and kname and os.path.exists(tf)) or traffic is not None:
+        if not (pmc_applies and os.path.exists(tf)) or traffic is not None:
             continue
         try:
-            rec = json.load(open(tf))["kernels"].get(kname)
-            if rec and rec.get(key):
-                traffic = int(rec[key] * scale)
+            recs = json.load(open(tf))["kernels"]
+            hit = next((k for k in kname if k and recs.get(k, {}).get(key)), None)
+            if hit:
+                traffic = int(recs[hit][key] * scale)
                 traffic_src = ("PMC FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE per launch, separate rocprofv3 "
-                               f"passes over this command: profiles/{fname}")
+                               f"passes over this command: profiles/{fname}, record `{hit}`"
+                               + ("" if hit.startswith("entry:") else " (kernel family: all instantiations)"))
         except Exception:
             pass
     roof.update({"traffic": traffic, "traffic_source": traffic_src,

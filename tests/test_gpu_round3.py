@@ -62,7 +62,7 @@ def test_pooled_layer_without_materialised_output_equals_gemm_plus_rows_max(ns, 
 # ---------------------------------------------------------------------------------- BASELINE configs[3]: with_images
 def _image_scan(seed):
     from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import synthetic_scan
-    scan = synthetic_scan(4, 1500, 2000, seed=seed)
+    scan = synthetic_scan(9, 1500, 2000, seed=seed)       # 9 objects / 72 edges: the modal real scan
     g = torch.Generator().manual_seed(seed + 100)
     scan["full_image_features"] = torch.randn(6, 2048, generator=g)      # what the (external) 2-D CNN emits per view
     return scan
@@ -109,12 +109,10 @@ def test_with_images_config_on_the_hip_path_matches_the_oracle_backend():
     assert abs(loss_g - loss_r) < 1e-4
     assert set(g_g) == set(g_r) and "full_image_feature_reduction.weight" in g_g
     for k in g_r:
-        # the GCN's BatchNorm1d over the 4 nodes / 12 edges of ONE scan is ill-conditioned (fp32 vs fp64 of the same GCN
-        # on the CPU differ by 4.5e-4 per parameter, tools/gcn_conditioning.py) and everything upstream
-        # inherits it: 5e-2 in norm (single entries of a GCN weight move by up to 8e-2 of the largest one, identical with
-        # and without the pooled-layer kernels);
-        # biases in front of a BatchNorm have an exactly-zero true gradient, hence the absolute floor
-        assert float((g_g[k] - g_r[k]).norm()) <= 5e-2 * float(g_r[k].norm()) + 1e-4, k      # in norm: single entries move more
+        # 9 nodes / 72 edges per BatchNorm1d (the modal real scan; the 4-node scan this test used before is ill-conditioned:
+        # fp32 vs fp64 of the same GCN on the CPU differ by 4.5e-4 per parameter there, tools/gcn_conditioning.py): 1e-2 in
+        # norm; biases in front of a BatchNorm have an exactly-zero true gradient, hence the absolute floor
+        assert float((g_g[k] - g_r[k]).norm()) <= 1e-2 * float(g_r[k].norm()) + 1e-4, k      # in norm: single entries move more
 
 
 def test_with_images_config_in_mixed_precision():
@@ -141,7 +139,7 @@ def test_with_images_config_in_mixed_precision():
         obj16, rel16, g16 = run()
     finally:
         fused_mlp.set_mlp_dtype(prev)
-    # log-probabilities of magnitude 2-3; the 4-node / 12-edge BatchNorms of the GCN amplify the bf16 rounding (measured 0.10)
+    # log-probabilities of magnitude 2-3; the per-scan BatchNorms of the GCN amplify the bf16 rounding (4-node scan: 0.10)
     assert float((obj16 - obj32).abs().max()) < 0.25 and float((rel16 - rel32).abs().max()) < 0.25
     assert set(g16) == set(g32) and all(bool(torch.isfinite(v).all()) for v in g16.values())
     gi = "full_image_feature_reduction.weight"

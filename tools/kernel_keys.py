@@ -1,0 +1,41 @@
+"""Keys under which a traced kernel launch is aggregated (tools/profile_round.sh, tools/summarise_profile.py, bench.py).
+
+A launch counts towards (1) its kernel FAMILY (`mlp_gemm_kernel`: every instantiation — what the kernel-stats tables show),
+(2) for template families whose instantiations are different entry points, its INSTANTIATION (`mlp_gemm_kernel<PRO_BNRELU,
+EPI_STATS>`), and (3) the C-ABI ENTRY POINT it was launched by (`entry:pn2_mlp_gemm`), so that `roofline.traffic` (PMC bytes
+per launch) and `alg_bytes_per_launch` (bench.py, per entry point) describe the same population of launches
+(the family average mixed the pooled and first-layer variants into `pn2_mlp_gemm`)."""
+import re
+
+PRO = {0: "PRO_NONE", 1: "PRO_BNRELU", 2: "PRO_GY", 3: "PRO_POOLG", 4: "PRO_FIRST"}      # csrc/mlp_common.h
+EPI = {0: "EPI_NONE", 1: "EPI_STATS", 2: "EPI_MASK", 3: "EPI_POOL"}
+
+ENTRY_OF_FAMILY = {
+    "mlp_wgrad_kernel": "pn2_mlp_wgrad", "mlp_bwd_fused_kernel": "pn2_mlp_bwd_fused", "mlp_bwd_fused2_kernel": "pn2_mlp_bwd_fused_fold",
+    "mlp_bwd_first_kernel": "pn2_mlp_bwd_fused_fold_first", "pool_bwd64_kernel": "pn2_pool_bwd", "pool_bwd128_kernel": "pn2_pool_bwd",
+    "bn_relu_rows_max_kernel": "pn2_bn_relu_rows_max", "group_concat_rows_wide4_kernel": "pn2_group_concat_rows",
+    "group_concat_rows_narrow_kernel": "pn2_group_concat_rows", "group_concat_rows_kernel": "pn2_group_concat_rows",
+    "group_rows_grad_csr_kernel": "pn2_group_rows_grad", "group_rows_grad_kernel": "pn2_group_rows_grad",
+    "mlp_gemm_bf16_kernel": "pn2_mlp_gemm_bf16", "mlp_wgrad_bf16_kernel": "pn2_mlp_wgrad_bf16", "mlp_bwd_bf16_kernel": "pn2_mlp_bwd_bf16",
+    "bn_relu_rows_max_bf16_v8_kernel": "pn2_bn_relu_rows_max_bf16", "group_concat_rows_bf16_wide8_kernel": "pn2_group_concat_rows_bf16",
+    "bq_fused_group_kernel": "pn2_ball_query_group", "bq_slab_query_kernel": "pn2_ball_query", "bq_slab_build_kernel": "pn2_ball_query",
+}
+
+
+def family(name: str) -> str:
+    m = re.search(r"([A-Za-z_0-9]+_kernel)", name)
+    return m.group(1) if m else "other"
+
+
+def keys(name: str):
+    fam = family(name)
+    out = [fam]
+    if fam == "mlp_gemm_kernel":
+        m = re.search(r"mlp_gemm_kernel<\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)", name)
+        if m:
+            pro, epi = int(m.group(4)), int(m.group(5))
+            out.append(f"mlp_gemm_kernel<{PRO.get(pro, pro)},{EPI.get(epi, epi)}>")
+            out.append("entry:" + ("pn2_mlp_gemm_pool" if epi == 3 else "pn2_mlp_gemm_first" if pro == 4 else "pn2_mlp_gemm"))
+    elif fam in ENTRY_OF_FAMILY:
+        out.append("entry:" + ENTRY_OF_FAMILY[fam])
+    return out

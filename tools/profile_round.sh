@@ -18,17 +18,17 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-forma
 # kernel's cycles (MI355X_MICROARCH.md, rocprofv3 PMC slots): busy fraction = MFMA_BUSY / (GUI_ACTIVE x 1024 SIMDs)
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $O/mfma --output-format csv -- $CMD > $O/mfma.log 2>&1
 python - <<PY
-import csv, glob, json, re, collections
+import csv, glob, json, re, collections, sys
 O = "$O"
-def short(n):
-    m = re.search(r"([A-Za-z_0-9]+_kernel)", n)
-    return m.group(1) if m else "other"
+sys.path.insert(0, "$R/tools")
+from kernel_keys import keys      # family | instantiation (mlp_gemm_kernel<PRO,EPI>) | entry:<C-ABI entry point>
 def agg(sub, counter):
     tot = collections.defaultdict(float); cnt = collections.Counter()
     for f in glob.glob(f"{O}/{sub}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter: continue
-            k = short(r["Kernel_Name"]); tot[k] += float(r["Counter_Value"]); cnt[k] += 1
+            for k in keys(r["Kernel_Name"]):
+                tot[k] += float(r["Counter_Value"]); cnt[k] += 1
     return tot, cnt
 fe, fc = agg("fetch", "FETCH_SIZE"); wr, wc = agg("write", "WRITE_SIZE")
 out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- " + "$CMD".replace("$R/", "") + " (separate passes)",

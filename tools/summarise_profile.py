@@ -17,24 +17,25 @@ src = os.path.join(repo, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(repo, "profiles")
 
 
-def short(n):
-    m = re.search(r"([A-Za-z_0-9]+_kernel)", n)
-    return m.group(1) if m else "other"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_keys import keys  # noqa: E402  (family | instantiation | entry:<C-ABI entry point>)
 
 
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "kernel_stats.md"), os.path.join(dst, f"{tag}_kernel_stats.md"))
 dur = {}
 for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
-    k = short(r["Name"])
-    d = dur.setdefault(k, [0, 0.0])
-    d[0] += int(r["Calls"])
-    d[1] += float(r["TotalDurationNs"])
+    for k in keys(r["Name"]):
+        d = dur.setdefault(k, [0, 0.0])
+        d[0] += int(r["Calls"])
+        d[1] += float(r["TotalDurationNs"])
 hbm = json.load(open(os.path.join(src, "hbm_traffic_per_kernel.json")))
 mf = json.load(open(os.path.join(src, "mfma_util_per_kernel.json")))
 out = {"commands": {"kernel_stats": "rocprofv3 --kernel-trace --stats -- <bench command>", "hbm": hbm["command"], "mfma": mf["command"]},
        "corrections": "FETCH_SIZE x2 (gfx950); GRBM_GUI_ACTIVE / 8 XCDs = kernel cycles; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                       "(kernel cycles x 1024 SIMDs); effective clock = kernel cycles / traced average duration",
+       "keys": "kernel family (all instantiations) | instantiation `mlp_gemm_kernel<PRO,EPI>` | `entry:<C-ABI entry point>` = the "
+               "launches bench.py's per-entry-point rows (alg_bytes_per_launch) describe (tools/kernel_keys.py)",
        "kernels": {}}
 for k in sorted(set(hbm["kernels"]) | set(mf["kernels"])):
     e = {}
