@@ -118,9 +118,21 @@ __global__ __launch_bounds__(256) void ball_query_kernel(int N, int m, int bpc, 
 // double arithmetic 2^-19 cells against a margin of 1e-4).  Points beyond that (or non-finite) mark their slab, centres
 // beyond that mark themselves: such a (centre, slab) pair tests ALL records of the slab through the same mask — slow,
 // never wrong.  The mask makes duplicates harmless, the order inside a cell irrelevant.
-constexpr int kSlab = 2048;                       // indices per slab = 64 lanes x 32 mask bits
+// Round 4: the slab is a template parameter — 2048 W consecutive indices, W in {1, 4}.  A crowded ball finds its nsample hits
+// in ONE slab when the slab holds about nsample / r^3 indices (unit-ball clouds): the dependent chain table word ->
+// records -> LDS mask -> output is then walked once or twice per centre instead of four times (headline shape: 16 hits per
+// 2048-index slab, 64 wanted), and the table shrinks from 13 MB to 3.7 MB per batch.  Lane i of the mask owns indices
+// [32 W i, 32 W (i + 1)) of the slab, W words read back with one LDS instruction.  The row is assembled in LDS and
+// written with coalesced stores; with FUSE the same wave then emits the GROUPED rows of its neighbourhood — what
+// group_points_kernel (EXT/src/group_points_gpu.cu:8-28) x 2 + the subtraction / concatenation of QueryAndGroup.forward
+// (OPS/pointnet2_utils.py:317-328) produce — so the index row never travels back through HBM between the two kernels.
+// Workgroups are dealt to XCDs by cloud (hardware round-robin: workgroup p runs on XCD p mod 8), so a cloud's records and
+// table are fetched into ONE L2 instead of all eight.
+constexpr int kSlab = 2048;                       // indices per slab unit = 64 lanes x 32 mask bits
 constexpr int kSlabCells = 16 * 16 * 16;          // hash grid per slab
 constexpr int kSlabTable = kSlabCells + 16;       // words per (cloud, slab): cells | [4096] = "holds a wild point"
+constexpr int kFuseMaxNs = 256;                   // index row staged in LDS (per wave) up to this many samples
+constexpr int kFuseMaxRow = 16;                   // floats per grouped row the fused emission covers (3 + C)
 
 // inclusive prefix sum over the 64 lanes on the DPP network (row shifts inside the rows of 16, then the row totals
 // broadcast into the rows above): six VALU instructions, no LDS crossbar
@@ -140,25 +152,28 @@ __device__ __forceinline__ int slab_cell1(double t) {                           
   return (int)(f - 16.0 * floor(f * 0.0625));
 }
 
-__global__ __launch_bounds__(256) void bq_slab_build_kernel(int N, int nslab, double inv_h,
-                                                           const float *__restrict__ xyz,
-                                                           unsigned *__restrict__ table, float4 *__restrict__ recs) {
+// one workgroup of 256 W threads per (slab, cloud): 8 points per thread
+template <int W>
+__global__ __launch_bounds__(256 * W) void bq_slab_build_kernel(int N, int nslab, double inv_h,
+                                                               const float *__restrict__ xyz,
+                                                               unsigned *__restrict__ table, float4 *__restrict__ recs) {
+  constexpr int T = 256 * W, SL = kSlab * W, CPT = kSlabCells / T, NW = T / 64;
   __shared__ int hist[kSlabCells];
-  __shared__ int wsum[4];
+  __shared__ int wsum[NW];
   __shared__ int wild;
   const int tid = threadIdx.x, lane = pn2_lane(), wv = tid >> 6;
   const int sl = blockIdx.x, b = blockIdx.y;
-  const int base = sl * kSlab;
-  const int len = N - base < kSlab ? N - base : kSlab;
+  const int base = sl * SL;
+  const int len = N - base < SL ? N - base : SL;
   const float *P = xyz + ((size_t)b * N + base) * 3;
-  for (int i = tid; i < kSlabCells; i += 256) hist[i] = 0;
+  for (int i = tid; i < kSlabCells; i += T) hist[i] = 0;
   if (tid == 0) wild = 0;
   __syncthreads();
   float px[8], py[8], pz[8];
   int cell[8], rank[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const int k = tid + u * 256;
+    const int k = tid + u * T;
     cell[u] = -1;
     if (k < len) {
       px[u] = P[(size_t)k * 3 + 0]; py[u] = P[(size_t)k * 3 + 1]; pz[u] = P[(size_t)k * 3 + 2];
@@ -173,10 +188,10 @@ __global__ __launch_bounds__(256) void bq_slab_build_kernel(int N, int nslab, do
     }
   }
   __syncthreads();
-  // exclusive scan of the 4096 counts: thread t owns cells [16 t, 16 t + 16)
-  int c[16], sum = 0;
+  // exclusive scan of the 4096 counts: thread t owns cells [CPT t, CPT t + CPT)
+  int c[CPT], sum = 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { c[i] = hist[tid * 16 + i]; sum += c[i]; }
+  for (int i = 0; i < CPT; ++i) { c[i] = hist[tid * CPT + i]; sum += c[i]; }
   int inc = sum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -187,66 +202,92 @@ __global__ __launch_bounds__(256) void bq_slab_build_kernel(int N, int nslab, do
   __syncthreads();
   int off = inc - sum;
   for (int w = 0; w < wv; ++w) off += wsum[w];
-  unsigned *T = table + ((size_t)b * nslab + sl) * kSlabTable;
+  unsigned *Tb = table + ((size_t)b * nslab + sl) * kSlabTable;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    hist[tid * 16 + i] = off;
-    T[tid * 16 + i] = (unsigned)off | ((unsigned)c[i] << 16);
+  for (int i = 0; i < CPT; ++i) {
+    hist[tid * CPT + i] = off;
+    Tb[tid * CPT + i] = (unsigned)off | ((unsigned)c[i] << 16);    // start < 8192, count <= 8192: 16 bits each
     off += c[i];
   }
-  if (tid < 16) T[kSlabCells + tid] = (unsigned)wild;
+  if (tid < 16) Tb[kSlabCells + tid] = (unsigned)wild;
   __syncthreads();
   float4 *R = recs + (size_t)b * N + base;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    if (cell[u] >= 0) R[hist[cell[u]] + rank[u]] = make_float4(px[u], py[u], pz[u], __int_as_float(tid + u * 256));
+    if (cell[u] >= 0) R[hist[cell[u]] + rank[u]] = make_float4(px[u], py[u], pz[u], __int_as_float(tid + u * T));
   }
 }
 
+struct BqFuse {              // grouped-row emission (FUSE): out[g][s][0:Cx] = (xyz[idx] - centre) (/ radius), [Cx:Cx+C] = feats[idx]
+  const float *xyz;          // (B, N, 3)
+  const float *feats;        // (B, N, C) point-major or null (C = 0)
+  float *rows;               // (B, m, ns, Cx + C)
+  int C, Cx, normalize;
+  float radius;
+};
+
+template <int W, bool FUSE>
 __global__ __launch_bounds__(256) void bq_slab_query_kernel(int N, int m, int nslab, float r2, int ns, double inv_h,
                                                            double rw, const float *__restrict__ new_xyz,
                                                            const unsigned *__restrict__ table,
                                                            const float4 *__restrict__ recs, int *__restrict__ idx,
-                                                           long long centres) {
-  __shared__ unsigned s_mask[4][64];
+                                                           long long centres, long long blocks, BqFuse fz) {
+  constexpr int SL = kSlab * W;
+  __shared__ unsigned s_mask[4][64 * W];
+  __shared__ int s_idx[FUSE ? 4 : 1][FUSE ? kFuseMaxNs : 1];
+  __shared__ float s_rows[FUSE ? 4 : 1][FUSE ? 64 * kFuseMaxRow : 1];
   const int lane = pn2_lane();
   const int wv = threadIdx.x >> 6;
-  const long long g = (long long)blockIdx.x * 4 + wv;
+  // XCD-aware order: physical workgroup p runs on XCD p mod 8; XCD x takes the x-th eighth of the (cloud-major) centres
+  const long long per = (blocks + 7) >> 3;
+  const long long lb = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (lb >= blocks) return;
+  const long long g = lb * 4 + wv;
   if (g >= centres) return;                                     // wave-uniform; no block barriers below
   const int b = (int)(g / m);
   const float qx = new_xyz[g * 3 + 0], qy = new_xyz[g * 3 + 1], qz = new_xyz[g * 3 + 2];
   int *row = idx + g * ns;
   volatile unsigned *mask = s_mask[wv];
-  mask[lane] = 0u;
+#pragma unroll
+  for (int k = 0; k < W; ++k) mask[lane * W + k] = 0u;
 
   // lane -> (cell of the 3 x 3 x 3 window, slot); the window starts at the cell of c - rw on every axis
   const double tx = ((double)qx - rw) * inv_h, ty = ((double)qy - rw) * inv_h, tz = ((double)qz - rw) * inv_h;
   const bool tame = slab_tame(tx) && slab_tame(ty) && slab_tame(tz);
-  const int k = lane >> 1, slot = lane & 1;
+  const int kc = lane >> 1, slot = lane & 1;
   int mycell = -1;
-  if (tame && k < 27) {
-    const int ox = k % 3, oy = (k / 3) % 3, oz = k / 9;
+  if (tame && kc < 27) {
+    const int ox = kc % 3, oy = (kc / 3) % 3, oz = kc / 9;
     mycell = (((slab_cell1(tz) + oz) & 15) * 16 + ((slab_cell1(ty) + oy) & 15)) * 16 + ((slab_cell1(tx) + ox) & 15);
   }
   const unsigned *T = table + (size_t)b * nslab * kSlabTable;
   const float4 *R = recs + (size_t)b * N;
   int cnt = 0, first = 0;
   unsigned wnext = mycell >= 0 ? T[mycell] : 0u;
-  for (int sl = 0; sl < nslab && cnt < ns; ++sl, T += kSlabTable, R += kSlab) {
+  for (int sl = 0; sl < nslab && cnt < ns; ++sl, T += kSlabTable, R += SL) {
     const unsigned w = wnext;
     if (sl + 1 < nslab && mycell >= 0) wnext = T[kSlabTable + mycell];
     const bool all = !tame || T[kSlabCells] != 0u;              // wave-uniform
     if (!all) {
       const int beg = (int)(w & 0xffffu), len = (int)(w >> 16);
-      for (int j = slot; j < len; j += 2) {
-        const float4 p = R[beg + j];
-        if (pn2_sq3(qx - p.x, qy - p.y, qz - p.z) < r2) {
-          const int li = __float_as_int(p.w);
-          atomicOr((unsigned *)&mask[li >> 5], 1u << (li & 31));
+      // four records in flight per lane (a cell of an 8192-index slab holds ~16 at the headline density)
+      for (int j = slot; j < len; j += 8) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jj = j + 2 * u;
+          p[u] = R[beg + (jj < len ? jj : j)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j + 2 * u < len && pn2_sq3(qx - p[u].x, qy - p[u].y, qz - p[u].z) < r2) {
+            const int li = __float_as_int(p[u].w);
+            atomicOr((unsigned *)&mask[li >> 5], 1u << (li & 31));
+          }
         }
       }
     } else {
-      const int len = N - sl * kSlab < kSlab ? N - sl * kSlab : kSlab;
+      const int len = N - sl * SL < SL ? N - sl * SL : SL;
       for (int j = lane; j < len; j += 64) {
         const float4 p = R[j];
         if (pn2_sq3(qx - p.x, qy - p.y, qz - p.z) < r2) {
@@ -256,26 +297,69 @@ __global__ __launch_bounds__(256) void bq_slab_query_kernel(int N, int m, int ns
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // LDS operations of a wave retire in order
-    unsigned word = mask[lane];
-    const u64 some = __ballot(word != 0u);
+    unsigned word[W];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < W; ++k) { word[k] = mask[lane * W + k]; any |= word[k] != 0u; }
+    const u64 some = __ballot(any);
     if (some == 0ull) continue;
-    mask[lane] = 0u;
-    const int pc = __popc(word);
+    int pc = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) { mask[lane * W + k] = 0u; pc += __popc(word[k]); }
     const int inc = slab_wave_scan(pc);
+    const int at = sl * SL + lane * 32 * W;
     if (cnt == 0) {
-      const int fl = __builtin_ctzll(some);
-      first = sl * kSlab + fl * 32 + __builtin_ctz((unsigned)__builtin_amdgcn_readlane((int)word, fl));
+      int mine = 0;
+#pragma unroll
+      for (int k = W - 1; k >= 0; --k)
+        if (word[k] != 0u) mine = at + k * 32 + __builtin_ctz(word[k]);
+      first = __builtin_amdgcn_readlane(mine, __builtin_ctzll(some));
     }
     int o = cnt + inc - pc;
-    const int at = sl * kSlab + lane * 32;
-    while (word != 0u && o < ns) {
-      row[o++] = at + __builtin_ctz(word);
-      word &= word - 1u;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      unsigned wk = word[k];
+      while (wk != 0u && o < ns) {
+        const int hit = at + k * 32 + __builtin_ctz(wk);
+        if (FUSE) s_idx[wv][o] = hit; else row[o] = hit;
+        ++o;
+        wk &= wk - 1u;
+      }
     }
     cnt += __builtin_amdgcn_readlane(inc, 63);
   }
   // pad with the first hit (zero row for an empty ball): EXT/src/ball_query_gpu.cu:34-38
-  for (int s = (cnt < ns ? cnt : ns) + lane; s < ns; s += 64) row[s] = first;
+  if (!FUSE) {
+    for (int s = (cnt < ns ? cnt : ns) + lane; s < ns; s += 64) row[s] = first;
+    return;
+  }
+  for (int s = (cnt < ns ? cnt : ns) + lane; s < ns; s += 64) s_idx[wv][s] = first;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  // the index row (coalesced) and the grouped rows: 64 slots at a time, each lane gathers its slot's point, the row
+  // block goes through LDS so that the stores are contiguous 256-byte runs (a neighbourhood's rows are one contiguous block)
+  const int Cx = fz.Cx, C = fz.C, RW = Cx + C;
+  const float *X = fz.xyz + (size_t)b * N * 3;
+  const float *F = fz.feats ? fz.feats + (size_t)b * N * C : nullptr;
+  float *out = fz.rows + (size_t)g * ns * RW;
+  volatile float *rb = s_rows[wv];
+  for (int s0 = 0; s0 < ns; s0 += 64) {
+    const int s = s0 + lane;
+    const int nrow = ns - s0 < 64 ? ns - s0 : 64;
+    if (s < ns) {
+      const int i = s_idx[wv][s];
+      row[s] = i;
+      if (Cx) {
+        float rx = X[(size_t)i * 3 + 0] - qx, ry = X[(size_t)i * 3 + 1] - qy, rz = X[(size_t)i * 3 + 2] - qz;
+        if (fz.normalize) { rx = __fdiv_rn(rx, fz.radius); ry = __fdiv_rn(ry, fz.radius); rz = __fdiv_rn(rz, fz.radius); }
+        rb[lane * RW + 0] = rx; rb[lane * RW + 1] = ry; rb[lane * RW + 2] = rz;
+      }
+      for (int c = 0; c < C; ++c) rb[lane * RW + Cx + c] = F[(size_t)i * C + c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const int total = nrow * RW;
+    for (int e = lane; e < total; e += 64) out[(size_t)s0 * RW + e] = rb[e];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -589,20 +673,43 @@ int bq_auto(int B, int N, int m, float radius, int nsample) {
   return L >= 3072.0 ? PN2_BQ_SLABS : PN2_BQ_SCAN;
 }
 
+// Slab width: a ball finds nsample hits in about nsample / (2048 r^3) slabs of 2048 indices (unit-ball clouds); from 1.5
+// on, slabs of 8192 indices walk the dependent table -> records -> mask chain less often (and a sparse ball in a cloud of up
+// to 8192 points sees the whole cloud as ONE cell list).  Results never depend on it.
+int bq_slab_w(int N, float radius, int nsample) {
+  if (N <= kSlab) return 1;
+  const double per = (double)nsample / (2048.0 * (double)radius * radius * radius);
+  return per > 1.5 ? 4 : 1;
+}
+
 int bq_run_slabs(int B, int N, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
-                 void *workspace, hipStream_t s) {
-  const int nslab = (N + kSlab - 1) / kSlab;
+                 void *workspace, hipStream_t s, const BqFuse *fuse = nullptr, int force_w = 0) {
+  const int W = force_w ? force_w : bq_slab_w(N, radius, nsample);
+  const int SL = kSlab * W;
+  const int nslab = (N + SL - 1) / SL;
   const long long centres = (long long)B * m;
   const long long blocks = (centres + 3) / 4;
-  if (blocks > 0x7fffffffLL || B > 65535) return PN2_EINVAL;
+  const long long grid = ((blocks + 7) / 8) * 8;                  // XCD-aware order: eight equal shares
+  if (grid > 0x7fffffffLL || B > 65535) return PN2_EINVAL;
   // hit bound rq = r 1.0001, window rw = rq 1.0001, cell edge h = rw 1.0001 (see the kernel header)
   const double rw = (double)radius * 1.0001 * 1.0001, inv_h = 1.0 / (rw * 1.0001);
   float4 *recs = (float4 *)workspace;
   unsigned *table = (unsigned *)((char *)workspace + (size_t)B * N * 16);
-  hipLaunchKernelGGL(bq_slab_build_kernel, dim3((unsigned)nslab, (unsigned)B), dim3(256), 0, s, N, nslab, inv_h, xyz, table,
-                     recs);
-  hipLaunchKernelGGL(bq_slab_query_kernel, dim3((unsigned)blocks), dim3(256), 0, s, N, m, nslab, radius * radius, nsample,
-                     inv_h, rw, new_xyz, table, recs, idx, centres);
+  const float r2 = radius * radius;   // fp32, EXT/src/ball_query_gpu.cu:22
+  BqFuse fz = fuse ? *fuse : BqFuse{nullptr, nullptr, nullptr, 0, 0, 0, 1.f};
+#define PN2_BQ_LAUNCH(WW)                                                                                              \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL(bq_slab_build_kernel<WW>, dim3((unsigned)nslab, (unsigned)B), dim3(256 * WW), 0, s, N, nslab,   \
+                       inv_h, xyz, table, recs);                                                                       \
+    if (fuse)                                                                                                          \
+      hipLaunchKernelGGL((bq_slab_query_kernel<WW, true>), dim3((unsigned)grid), dim3(256), 0, s, N, m, nslab, r2,     \
+                         nsample, inv_h, rw, new_xyz, table, recs, idx, centres, blocks, fz);                          \
+    else                                                                                                               \
+      hipLaunchKernelGGL((bq_slab_query_kernel<WW, false>), dim3((unsigned)grid), dim3(256), 0, s, N, m, nslab, r2,    \
+                         nsample, inv_h, rw, new_xyz, table, recs, idx, centres, blocks, fz);                          \
+  } while (0)
+  if (W == 4) PN2_BQ_LAUNCH(4); else PN2_BQ_LAUNCH(1);
+#undef PN2_BQ_LAUNCH
   return pn2_check_launch();
 }
 
@@ -673,6 +780,33 @@ extern "C" int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample,
   }
   if (workspace && ((uintptr_t)workspace & 15) != 0) return PN2_EINVAL;
   return pn2_ball_query_algo(algo, B, N, m, radius, nsample, new_xyz, xyz, idx, workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ball query + grouping as ONE pass (round 4): query_ball_point_kernel (EXT/src/ball_query_gpu.cu:9-44), the two
+// group_points_kernel gathers (EXT/src/group_points_gpu.cu:8-28) and the centre subtraction / concatenation of
+// QueryAndGroup.forward (OPS/pointnet2_utils.py:317-328; GF3D's `/= radius`) — SURVEY.md 8d "fused ball_query+group".
+// The wave that finds a centre's hits (slab cell lists, above) also emits the neighbourhood's grouped rows; idx is kept
+// for the backward.  Covers nsample <= 256 and rows of at most 16 floats (first levels: xyz + colours); everything else
+// stays pn2_ball_query_* + pn2_group_concat_rows.  Bit-identical to that pair.
+extern "C" int pn2_ball_query_group_supported(int B, int N, int m, float radius, int nsample, int C, int use_xyz) {
+  const int RW = (use_xyz ? 3 : 0) + C;
+  return (B > 0 && B <= 65535 && N > 0 && m > 0 && nsample > 0 && nsample <= kFuseMaxNs && C >= 0 && RW > 0 &&
+          RW <= kFuseMaxRow && bq_radius_ok(radius)) ? 1 : 0;
+}
+extern "C" size_t pn2_ball_query_group_workspace_bytes(int B, int N) { return B > 0 && N > 0 ? bq_slab_bytes(B, N) : 0; }
+
+extern "C" int pn2_ball_query_group(int B, int N, int m, float radius, int nsample, int C, int use_xyz, int normalize,
+                                    const float *new_xyz, const float *xyz, const float *feats, int *idx, float *rows,
+                                    void *workspace, size_t workspace_bytes, int slab_w, void *stream) {
+  if (B < 0 || N < 0 || m < 0 || nsample < 0 || C < 0) return PN2_EINVAL;
+  if (B == 0 || m == 0 || nsample == 0) return PN2_OK;
+  if (!pn2_ball_query_group_supported(B, N, m, radius, nsample, C, use_xyz)) return PN2_EINVAL;
+  if (slab_w != 0 && slab_w != 1 && slab_w != 4) return PN2_EINVAL;
+  if (!new_xyz || !xyz || !idx || !rows || (C > 0 && !feats)) return PN2_ENULL;
+  if (!workspace || workspace_bytes < bq_slab_bytes(B, N) || ((uintptr_t)workspace & 15) != 0) return PN2_EINVAL;
+  BqFuse fz{xyz, C > 0 ? feats : nullptr, rows, C, use_xyz ? 3 : 0, normalize ? 1 : 0, radius};
+  return bq_run_slabs(B, N, m, radius, nsample, new_xyz, xyz, idx, workspace, (hipStream_t)stream, &fz, slab_w);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -54,9 +54,12 @@ class Pointnet2Backbone(nn.Module):
         from pointnet2_ops import fused_mlp
         bg = getattr(pointnet2_utils._ext, "background_geometry", None)
         with (bg(fewest=fused_mlp.mlp_dtype() == torch.float32) if bg is not None else contextlib.nullcontext()):
+            feats0 = (pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 and not pointcloud.requires_grad else None)
             for i in (1, 2, 3, 4):
-                # levels 2-4 gather features that carry a gradient (level 1 reads the input colours)
-                g = getattr(self, f"sa{i}").sample_and_query(levels[-1], inverse_index=i > 1)
+                # levels 2-4 gather features that carry a gradient; level 1 reads the input colours: its grouped rows come
+                # out of the ball query itself (pn2_ball_query_group) here, off the step's critical path
+                g = getattr(self, f"sa{i}").sample_and_query(levels[-1], inverse_index=i > 1,
+                                                             feats_rows=feats0 if i == 1 else None)
                 geo["sa"].append(g)
                 levels.append(g["new_xyz"])
             geo["fp"].append(self.fp1.interpolation(levels[3], levels[4]))

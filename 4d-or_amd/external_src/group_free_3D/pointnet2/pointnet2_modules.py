@@ -38,7 +38,8 @@ class PointnetSAModuleVotes(nn.Module):
             mlp[0] += 3                      # in place like the reference (:205-207)
         self.mlp_module = pt_utils.SharedMLP(mlp, bn=bn)
 
-    def sample_and_query(self, xyz: torch.Tensor, inds: torch.Tensor = None, inverse_index: bool = False):
+    def sample_and_query(self, xyz: torch.Tensor, inds: torch.Tensor = None, inverse_index: bool = False,
+                         feats_rows: torch.Tensor = None):
         """The data-only part of the module (no parameters, no features): FPS indices, sampled centres
         and ball-query neighbourhoods.  Lets a pipeline compute the geometry of the NEXT batch on a side
         stream while the current batch trains (see Pointnet2Backbone.precompute_geometry).
@@ -48,11 +49,17 @@ class PointnetSAModuleVotes(nn.Module):
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         new_xyz = pointnet2_utils.gather_operation(
             xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
-        idx = self.grouper.query(xyz, new_xyz)
+        # `feats_rows` (B,N,C): this level's input features are data (input colours: no gradient) -> the query kernel emits
+        # the grouped rows as well where it covers them (pn2_ball_query_group), next to idx
+        rows = None
+        if feats_rows is not None and self.pooling == "max":
+            idx, rows = _pm._query_maybe_fused(self.grouper, xyz, new_xyz, feats_rows)
+        else:
+            idx = self.grouper.query(xyz, new_xyz)
         inv = _pm.build_inverse_indices([self.grouper], [idx], xyz.size(1))[0] if inverse_index else None
         # sample_uniformly / ret_unique_cnt: the count belongs to THIS query (the grouper's last_unique_cnt is overwritten
         # by the next call — a geometry computed ahead of time must carry its own)
-        return {"inds": inds, "new_xyz": new_xyz, "idx": idx, "inv": inv, "n_src": xyz.size(1),
+        return {"inds": inds, "new_xyz": new_xyz, "idx": idx, "inv": inv, "rows": rows, "n_src": xyz.size(1),
                 "unique_cnt": getattr(self.grouper, "last_unique_cnt", None) if self.ret_unique_cnt else None}
 
     def _check_geometry(self, xyz, geometry):
@@ -72,7 +79,8 @@ class PointnetSAModuleVotes(nn.Module):
         if geometry is not None and self.pooling == "max" and _pm._rows_path_ok(xyz, features):
             self._check_geometry(xyz, geometry)
             rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, geometry["new_xyz"],
-                                     pointnet2_utils.as_rows(features), idx=geometry["idx"], inv=geometry.get("inv"))
+                                     pointnet2_utils.as_rows(features), idx=geometry["idx"], inv=geometry.get("inv"),
+                                     rows=geometry.get("rows"))
             out = (geometry["new_xyz"], pointnet2_utils.rows_to_channels(rows), geometry["inds"])
             return out + (geometry.get("unique_cnt"),) if self.ret_unique_cnt else out
         if inds is None:
@@ -85,12 +93,11 @@ class PointnetSAModuleVotes(nn.Module):
                 xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
 
         if self.npoint is not None and _pm._rows_path_ok(xyz, features):
-            idx = self.grouper.query(xyz, new_xyz)
             feats_rows = pointnet2_utils.as_rows(features)
-            if self.pooling == "max":
-                rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, new_xyz, feats_rows, idx=idx)
+            if self.pooling == "max":                # (the ball query runs inside: fused with the grouping where it can be)
+                rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, new_xyz, feats_rows, idx=None)
             else:
-                rows = self._pool_rows(xyz, new_xyz, feats_rows, idx)
+                rows = self._pool_rows(xyz, new_xyz, feats_rows, self.grouper.query(xyz, new_xyz))
             out = (new_xyz, pointnet2_utils.rows_to_channels(rows), inds)
             return out + (self.grouper.last_unique_cnt,) if self.ret_unique_cnt else out
 

@@ -38,8 +38,8 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.pn2_abi_version.restype = ctypes.c_int
-if int(_lib.pn2_abi_version()) != 3:
-    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 3: "
+if int(_lib.pn2_abi_version()) != 4:
+    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 4: "
                       f"rebuild it (`make -C {os.path.join(_PKG_DIR, 'csrc')}`)")
 
 _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -55,6 +55,7 @@ _SIGNATURES = {
     "pn2_ball_query_ws": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp],
     "pn2_ball_query_algo": [_c_int, _c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp],
     "pn2_ball_query_unique_resample": [ctypes.c_longlong, _c_int, ctypes.c_uint, _c_vp, _c_vp, _c_vp],
+    "pn2_ball_query_group": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_int, _c_int, _c_int] + [_c_vp] * 6 + [_c_sz, _c_int, _c_vp],
     "pn2_group_points": [_c_int] * 5 + [_c_vp] * 4,
     "pn2_group_points_grad": [_c_int] * 5 + [_c_vp] * 4,
     "pn2_three_nn": [_c_int] * 3 + [_c_vp] * 5,
@@ -152,6 +153,10 @@ _lib.pn2_ball_query_algo_bytes.argtypes = [_c_int, _c_int, _c_int, _c_int, _c_f3
 _lib.pn2_ball_query_algo_bytes.restype = _c_sz
 _lib.pn2_ball_query_auto.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int]
 _lib.pn2_ball_query_auto.restype = _c_int
+_lib.pn2_ball_query_group_supported.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_int, _c_int]
+_lib.pn2_ball_query_group_supported.restype = _c_int
+_lib.pn2_ball_query_group_workspace_bytes.argtypes = [_c_int, _c_int]
+_lib.pn2_ball_query_group_workspace_bytes.restype = _c_sz
 _lib.pn2_fps_status_offset.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_status_offset.restype = ctypes.c_longlong
 _lib.pn2_fps_set_plan_override.argtypes = [_c_int] * 5
@@ -192,12 +197,13 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 #: the header revision this binding was written against: a stale prebuilt libpn2_hip.so fails here with a version
 #: error instead of an AttributeError on the first missing symbol
-EXPECTED_ABI_VERSION = 3
+EXPECTED_ABI_VERSION = 4
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
                                                "pn2_event_create", "pn2_event_record", "pn2_event_elapsed_ms", "pn2_event_destroy",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
+                                               "pn2_ball_query_group_supported", "pn2_ball_query_group_workspace_bytes",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
@@ -461,6 +467,48 @@ def ball_query(new_xyz, xyz, radius, nsample):
         _call("pn2_ball_query", new_xyz, B, N, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx),
               alg_bytes=B * (12 * N + 12 * m + 4 * m * nsample))
     return idx
+
+
+def ball_query_group_supported(B, N, m, radius, nsample, C, use_xyz=True) -> bool:
+    """Shapes pn2_ball_query_group covers (nsample <= 256, 3 + C <= 16 floats per grouped row)."""
+    return bool(_lib.pn2_ball_query_group_supported(int(B), int(N), int(m), float(radius), int(nsample), int(C),
+                                                    int(bool(use_xyz))))
+
+
+def ball_query_group_pays(B, N, m, radius, nsample) -> bool:
+    """The fused query + grouping runs on the slab cell lists: taken where the library would pick them for the query alone
+    (crowded balls in large clouds, sparse balls in clouds of >= 2048 points); elsewhere the scan + the grouping kernel
+    are faster (tools/bq_bench.py)."""
+    return int(_lib.pn2_ball_query_auto(int(B), int(N), int(m), float(radius), int(nsample))) == BQ_SLABS
+
+
+def ball_query_group(new_xyz, xyz, feats_rows, radius, nsample, use_xyz=True, normalize=False, slab_w=0):
+    """Ball query AND QueryAndGroup's gather / centre subtraction / concat in one pass (pn2_ball_query_group):
+    new_xyz (B,m,3), xyz (B,N,3), feats_rows (B,N,C)|None -> (idx (B,m,nsample) i32, rows (B,m,nsample,Cx+C) f32);
+    bit-identical to ball_query + group_concat_rows.  EXT/src/ball_query_gpu.cu:9-44, group_points_gpu.cu:8-28,
+    OPS/pointnet2_utils.py:317-328."""
+    _f32(new_xyz, "new_xyz"); _f32(xyz, "xyz")
+    others = [(xyz, "xyz")]
+    C = 0
+    if feats_rows is not None:
+        _f32(feats_rows, "features")
+        C = feats_rows.size(2)
+        others.append((feats_rows, "features"))
+    _same_device((new_xyz, "new_xyz"), *others)
+    B, m = new_xyz.size(0), new_xyz.size(1)
+    N = xyz.size(1)
+    nsample = int(nsample)
+    Cx = 3 if use_xyz else 0
+    if not ball_query_group_supported(B, N, m, radius, nsample, C, use_xyz):
+        _fail(f"pn2_ball_query_group does not cover nsample {nsample}, row width {Cx + C} (radius {radius})")
+    idx = torch.empty(B, m, nsample, dtype=torch.int32, device=new_xyz.device)
+    rows = torch.empty(B, m, nsample, Cx + C, dtype=torch.float32, device=new_xyz.device)
+    ws_bytes = int(_lib.pn2_ball_query_group_workspace_bytes(B, N))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=new_xyz.device)          # scratch, no initialisation needed
+    _call("pn2_ball_query_group", new_xyz, B, N, m, float(radius), nsample, C, int(bool(use_xyz)), int(bool(normalize)),
+          _ptr(new_xyz), _ptr(xyz), _ptr(feats_rows), _ptr(idx), _ptr(rows), _ptr(ws), ws_bytes, int(slab_w),
+          alg_bytes=B * (12 * N + 12 * m + 4 * C * N + 4 * (Cx + C) * m * nsample + 4 * m * nsample))
+    return idx, rows
 
 
 def ball_query_unique_resample(idx, seed, want_cnt=True):

@@ -134,6 +134,8 @@ class _FusedMLP(Function):
             xyz, new_xyz, idx, use_xyz, normalize, radius = group[:6]
             ctx.feat_shape = None if x is None else tuple(x.shape)
             pre = getattr(ctx, "x_rows", None)          # a segmented call groups the whole batch once and hands in the rows
+            if pre is None and len(group) > 8 and group[8] is not None:
+                pre = group[8]                          # rows the fused query + grouping kernel emitted next to idx
             x = pre if pre is not None else e.group_concat_rows(
                 xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize,
                 radius).view(-1, (3 if use_xyz else 0) + (0 if x is None else x.size(2)))
@@ -661,6 +663,8 @@ class _SegmentedGroupMLP(Function):
         feats = None if x is None else x.contiguous()
         if inner is _FusedMLPBf16:
             rows_all = e.group_concat_rows_bf16(xyz, new_xyz, feats, idx, use_xyz, normalize, radius)
+        elif len(group) > 8 and group[8] is not None:
+            rows_all = group[8]                         # emitted by the fused query + grouping kernel
         else:
             rows_all = e.group_concat_rows(xyz, new_xyz, feats, idx, use_xyz, normalize, radius)
         # per layer ONE (S,4,C) buffer for the scans' (mean | rstd | scale | shift) blocks: the running-statistics update
@@ -675,7 +679,8 @@ class _SegmentedGroupMLP(Function):
             sub = _SegCtx(tuple(ctx.needs_input_grad[:4]) + tuple(ctx.needs_input_grad[6:]))
             sub.x_rows = rows_all[c0:c1].view(-1, rows_all.size(-1))
             sub.fin_out = [None if F is None else F[s] for F in fin_bufs]
-            g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius, None, group[7] if len(group) > 7 else None)
+            g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius, None, group[7] if len(group) > 7 else None,
+                 None)
             with torch.cuda.stream(fork.stream(s)):
                 out, arg = inner.forward(sub, None if x is None else x[c0:c1], ns, layers, g, *params)
             subs.append(sub)
@@ -798,7 +803,8 @@ def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0, rows_per_scan
 
 
 def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius,
-                         clouds_per_scan: Optional[Sequence[int]] = None, inv=None, crowded: Optional[bool] = None) -> torch.Tensor:
+                         clouds_per_scan: Optional[Sequence[int]] = None, inv=None, crowded: Optional[bool] = None,
+                         rows=None) -> torch.Tensor:
     """Ball-query neighbourhoods -> shared MLP -> max, one autograd node:
     xyz (B,N,3), new_xyz (B,m,3), feats_rows (B,N,C)|None, idx (B,m,ns) -> (B, m, C_out).
     `clouds_per_scan` (sums to B): BatchNorm batch statistics per scan (see _SegmentedGroupMLP)."""
@@ -807,7 +813,14 @@ def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz,
     B, m, ns = idx.shape
     # inv: (ptr, refs) of the whole batch's idx; crowded: N r^3 > 4 nsample (pointnet2_modules.crowded_balls) -> the pooled
     # last layer runs without its output tensor (csrc/pool_bwd.hip)
-    group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius, inv, crowded)
+    if rows is not None:
+        width = (3 if use_xyz else 0) + (0 if feats_rows is None else feats_rows.size(2))
+        if tuple(rows.shape) != (B, m, ns, width) or rows.dtype != torch.float32 or rows.device != idx.device:
+            raise RuntimeError(f"fused_group_mlp_pool: pre-grouped rows must be fp32 ({B}, {m}, {ns}, {width}) on {idx.device}")
+        rows = rows.contiguous()
+    # rows: the grouped rows (B, m, ns, [3+]C) fp32 if the query kernel already emitted them (pn2_ball_query_group)
+    group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius, inv, crowded,
+             None if rows is None else rows.detach())
     if clouds_per_scan is not None and len(clouds_per_scan) > 1:
         if sum(clouds_per_scan) != B:
             raise RuntimeError("fused_group_mlp_pool: clouds_per_scan must sum to the number of clouds")

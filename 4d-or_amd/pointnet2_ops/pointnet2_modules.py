@@ -154,7 +154,8 @@ def _trains_batchnorm(mlp: nn.Module) -> bool:
                for m in mlp.modules())
 
 
-def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _whole_batch=False, inv=None) -> torch.Tensor:
+def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _whole_batch=False, inv=None,
+                  rows=None) -> torch.Tensor:
     """One SA scale on the rows path: group -> shared MLP -> max -> (B, npoint, C_out).
     Ball-query groupers with a fusable MLP run as a single autograd node (gather, MLP, pool and
     the scatter of the feature gradient); anything else goes through forward_rows + mlp_pool_rows."""
@@ -165,10 +166,10 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
                 and (grouper.use_xyz or feats_rows is not None)
                 and fused_mlp.supported(mlp, xyz if feats_rows is None else feats_rows, grouper.nsample)):
             if idx is None:
-                idx = grouper.query(xyz, new_xyz)
+                idx, rows = _query_maybe_fused(grouper, xyz, new_xyz, feats_rows)
             return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
                                                   grouper.normalize_xyz, grouper.radius, clouds_per_scan=sizes, inv=inv,
-                                                  crowded=crowded_balls(grouper, xyz.size(1)))
+                                                  crowded=crowded_balls(grouper, xyz.size(1)), rows=rows)
         if _FUSED_MLP and idx is None and not isinstance(grouper, pointnet2_utils.QueryAndGroup):
             # group-all (or any grouper without statistics of its own): group the whole batch once, then ONE call of the
             # stack with the scans' row ranges as a segment table — where the stack's kernels take one
@@ -189,15 +190,24 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
             and (grouper.use_xyz or feats_rows is not None)
             and fused_mlp.supported(mlp, xyz if feats_rows is None else feats_rows, grouper.nsample)):
         if idx is None:
-            idx = grouper.query(xyz, new_xyz)
+            idx, rows = _query_maybe_fused(grouper, xyz, new_xyz, feats_rows)
         return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
                                               grouper.normalize_xyz, grouper.radius, inv=inv,
-                                              crowded=crowded_balls(grouper, xyz.size(1)))
+                                              crowded=crowded_balls(grouper, xyz.size(1)), rows=rows)
     if idx is not None:
         g = pointnet2_utils.group_concat_rows(xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
                                               grouper.normalize_xyz, grouper.radius, inv=inv)
         return mlp_pool_rows(mlp, g)
     return mlp_pool_rows(mlp, grouper.forward_rows(xyz, new_xyz, feats_rows))
+
+
+def _query_maybe_fused(grouper, xyz, new_xyz, feats_rows):
+    """(idx, rows | None) for a fused-MLP SA scale: the ball query and — where one kernel can do both (first levels: rows of
+    at most 16 floats, fp32 arithmetic) — the grouped rows from the same pass (pn2_ball_query_group)."""
+    from pointnet2_ops import fused_mlp
+    if fused_mlp.mlp_dtype() == torch.float32 and grouper.fused_query_ok(xyz, new_xyz, feats_rows):
+        return grouper.query_rows(xyz, new_xyz, feats_rows)
+    return grouper.query(xyz, new_xyz), None
 
 
 def crowded_balls(grouper, n_src: int) -> bool:
@@ -255,17 +265,26 @@ class _PointnetSAModuleBase(nn.Module):
         picked = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), sel)
         return picked.transpose(1, 2).contiguous()
 
-    def sample_and_query(self, xyz: torch.Tensor, inverse_index: bool = False):
+    def sample_and_query(self, xyz: torch.Tensor, inverse_index: bool = False, feats_rows: Optional[torch.Tensor] = None):
         """The data-only part of the module (no parameters, no features): sampled centres and the ball-query
         neighbourhoods of every scale.  A training loop that already holds the next clouds can run this on a side
         stream while the current ones train and pass the result as `geometry=` (identical results).
         `inverse_index`: the features of this level will need a gradient — also build the inverse of crowded
         neighbourhood indices, which turns the backward's atomic scatter into a per-point sum."""
         new_xyz = self._sample(xyz)
-        idx = [g.query(xyz, new_xyz) if (new_xyz is not None and isinstance(g, pointnet2_utils.QueryAndGroup)) else None
-               for g in self.groupers]
+        idx, rows = [], []
+        for g in self.groupers:
+            if new_xyz is None or not isinstance(g, pointnet2_utils.QueryAndGroup):
+                idx.append(None), rows.append(None)
+            elif feats_rows is not None:
+                # `feats_rows` (B,N,C): the level's input features are DATA (colours / masks of the input cloud, no
+                # gradient) -> the grouped rows can be produced right here, by the query kernel itself where it covers them
+                i, r = _query_maybe_fused(g, xyz, new_xyz, feats_rows)
+                idx.append(i), rows.append(r)
+            else:
+                idx.append(g.query(xyz, new_xyz)), rows.append(None)
         inv = build_inverse_indices(self.groupers, idx, xyz.size(1)) if inverse_index else [None] * len(idx)
-        return {"new_xyz": new_xyz, "idx": idx, "inv": inv, "n_src": xyz.size(1)}
+        return {"new_xyz": new_xyz, "idx": idx, "inv": inv, "rows": rows, "n_src": xyz.size(1)}
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor], geometry=None
                 ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
@@ -275,7 +294,7 @@ class _PointnetSAModuleBase(nn.Module):
         if geometry is not None and _rows_path_ok(xyz, features):
             self._check_geometry(xyz, geometry)
             return geometry["new_xyz"], self._forward_rows(xyz, geometry["new_xyz"], features, geometry["idx"],
-                                                           geometry.get("inv"))
+                                                           geometry.get("inv"), geometry.get("rows"))
         new_xyz = self._sample(xyz)
         if _rows_path_ok(xyz, features):
             return new_xyz, self._forward_rows(xyz, new_xyz, features)
@@ -314,14 +333,15 @@ class _PointnetSAModuleBase(nn.Module):
                     or tuple(i.shape[:2]) != (B, self.npoint) or i.size(2) != g.nsample):
                 raise RuntimeError(f"geometry: idx must be int32 ({B}, {self.npoint}, {g.nsample}) on {xyz.device}")
 
-    def _forward_rows(self, xyz, new_xyz, features, idx=None, inv=None):
+    def _forward_rows(self, xyz, new_xyz, features, idx=None, inv=None, rows=None):
         feats_rows = pointnet2_utils.as_rows(features)
         B = xyz.size(0)
         pooled = []
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             pooled.append(sa_scale_rows(grouper, mlp, xyz, new_xyz, feats_rows,
                                         idx=None if idx is None else idx[k],
-                                        inv=None if inv is None else inv[k]))        # (B, npoint, C_out)
+                                        inv=None if inv is None else inv[k],
+                                        rows=None if rows is None else rows[k]))     # (B, npoint, C_out)
         rows = pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=2)
         return pointnet2_utils.rows_to_channels(rows)           # (B, sum C_out, npoint) view
 

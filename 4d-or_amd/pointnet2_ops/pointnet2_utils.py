@@ -274,6 +274,31 @@ class QueryAndGroup(nn.Module):
             self.last_unique_cnt = _ext.ball_query_unique_resample(idx, seed, want_cnt=True)
         return idx
 
+    def fused_query_ok(self, xyz, new_xyz, feats_rows) -> bool:
+        """The ball query of this grouper and the grouping of `feats_rows` can run as ONE kernel (pn2_ball_query_group:
+        fp32 rows of at most 16 floats, nsample <= 256, no sample_uniformly redraw between query and grouping) and the
+        shape is one where the slab cell lists pay (crowded balls in large clouds / clouds of >= 2048 points)."""
+        fn = getattr(_ext, "ball_query_group", None)
+        if fn is None or self.sample_uniformly or new_xyz is None or not (self.use_xyz or feats_rows is not None):
+            return False
+        if not xyz.is_cuda or xyz.dtype != torch.float32 or (feats_rows is not None and feats_rows.dtype != torch.float32):
+            return False
+        B, N, m = xyz.size(0), xyz.size(1), new_xyz.size(1)
+        C = 0 if feats_rows is None else feats_rows.size(2)
+        return bool(_ext.ball_query_group_supported(B, N, m, self.radius, self.nsample, C, self.use_xyz)
+                    and _ext.ball_query_group_pays(B, N, m, self.radius, self.nsample))
+
+    def query_rows(self, xyz, new_xyz, feats_rows=None):
+        """(idx (B,npoint,nsample) i32, rows (B,npoint,nsample,[3+]C) f32) WITHOUT autograd — the fused query + grouping
+        kernel where `fused_query_ok`, else the two kernels.  Identical results either way.  For callers that handle the
+        feature gradient themselves (fused_mlp: scatter through idx in its own backward) or need none (input colours)."""
+        with torch.no_grad():
+            feats = None if feats_rows is None else feats_rows.detach().contiguous()
+            if self.fused_query_ok(xyz, new_xyz, feats):
+                return _ext.ball_query_group(new_xyz, xyz, feats, self.radius, self.nsample, self.use_xyz, self.normalize_xyz)
+            idx = self.query(xyz, new_xyz)
+            return idx, _ext.group_concat_rows(xyz, new_xyz, feats, idx, self.use_xyz, self.normalize_xyz, self.radius)
+
     def forward(self, xyz, new_xyz, features=None):
         idx = self.query(xyz, new_xyz)
         centres = new_xyz.transpose(1, 2).unsqueeze(-1)

@@ -41,9 +41,12 @@ class PointNet2ClassificationSSG(nn.Module):
         """The coordinate-only part of the forward (FPS chain + ball queries of every SA level; no parameters):
         lets a loop prepare the next clouds on a side stream.  Pass the result as `geometry=`."""
         xyz = pointcloud[..., 0:3].contiguous()
+        # the first level groups the INPUT features (colours / instance mask: data, no gradient): its grouped rows can be
+        # emitted by the ball query itself (pn2_ball_query_group), ahead of the step like the rest of the geometry
+        feats0 = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 and not pointcloud.requires_grad else None
         geo = []
         for k, sa in enumerate(self.SA_modules):
-            g = sa.sample_and_query(xyz, inverse_index=k > 0)      # the first level gathers input features (no gradient)
+            g = sa.sample_and_query(xyz, inverse_index=k > 0, feats_rows=feats0 if k == 0 else None)
             geo.append(g)
             xyz = g["new_xyz"]
             if xyz is None:                      # group-all level: nothing below depends on coordinates

@@ -128,9 +128,10 @@ int pn2_ball_query(int B, int N, int m, float radius, int nsample,
  *   PN2_BQ_CELLS — per-cloud cell list (cells of edge >= radius, 27 neighbouring cells, hits rank-sorted by index): pays
  *                  when balls are SPARSE (the scene-graph encoders: radius 0.1 / 0.2 in 4000 / 8000-point clouds, where
  *                  the scan never exits early); nsample <= 256;
- *   PN2_BQ_SLABS — one hash-grid cell list per slab of 2048 consecutive indices; hits set bits of a 2048-bit mask, which
- *                  yields them in ascending index without a sort; the walk over the slabs stops after nsample hits: pays
- *                  when balls are CROWDED (the SA levels of the backbone).
+ *   PN2_BQ_SLABS — one hash-grid cell list per slab of 2048 (or, where a ball needs more than ~1.5 such slabs for its
+ *                  nsample hits, 8192) consecutive indices; hits set bits of a per-slab mask, which yields them in
+ *                  ascending index without a sort; the walk over the slabs stops after nsample hits: pays when balls
+ *                  are CROWDED (the SA levels of the backbone).
  * pn2_ball_query_auto() is the library's choice for a shape (estimated hits per ball N r^3 against 4 nsample; small
  * clouds scan), pn2_ball_query_workspace_bytes() the workspace of that choice (0: scan), pn2_ball_query_algo_bytes() the
  * workspace of a given algorithm (0: shape not covered).  `workspace`: 16-byte aligned, no initialisation needed.
@@ -147,6 +148,25 @@ int pn2_ball_query_ws(int B, int N, int m, float radius, int nsample, const floa
                       int *idx, void *workspace, size_t workspace_bytes, void *stream);
 int pn2_ball_query_algo(int algo, int B, int N, int m, float radius, int nsample, const float *new_xyz,
                         const float *xyz, int *idx, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Ball query + grouping in ONE pass (round 4; SURVEY.md 8d "fused ball_query+group").  Replaces, for one SA scale,
+ *   query_ball_point_kernel      EXT/src/ball_query_gpu.cu:9-44
+ *   group_points_kernel (x 2)    EXT/src/group_points_gpu.cu:8-28
+ *   QueryAndGroup.forward tail   OPS/pointnet2_utils.py:317-328 (centre subtraction in place, concat with the features;
+ *                                with `normalize` != 0 the `grouped_xyz /= radius` of GF3D/pointnet2/pointnet2_utils.py:343-344)
+ * The wave that finds a centre's first `nsample` hits (slab cell lists: ascending index without a sort) also emits the
+ * neighbourhood's grouped rows:  rows[b,j,s,0:Cx] = (xyz[b,idx[b,j,s]] - new_xyz[b,j]) (/ radius),
+ * rows[b,j,s,Cx:Cx+C] = feats[b,idx[b,j,s],0:C]  (Cx = use_xyz ? 3 : 0) — and idx (B,m,nsample), kept for the backward.
+ * Bit-identical to pn2_ball_query + pn2_group_concat_rows.  xyz (B,N,3); new_xyz (B,m,3); feats (B,N,C) point-major or
+ * NULL (C = 0).  Covers nsample <= 256 and Cx + C <= 16 (pn2_ball_query_group_supported); `workspace`: 16-byte aligned,
+ * pn2_ball_query_group_workspace_bytes(B, N), no initialisation.  `slab_w`: 0 = the library's choice of slab width,
+ * 1 / 4 = slabs of 2048 / 8192 consecutive indices (test and measurement hook; results never depend on it).
+ * Algorithmic bytes: B (12 N + 12 m + 4 C N + 4 (Cx + C) m nsample + 4 m nsample). */
+int pn2_ball_query_group_supported(int B, int N, int m, float radius, int nsample, int C, int use_xyz);
+size_t pn2_ball_query_group_workspace_bytes(int B, int N);
+int pn2_ball_query_group(int B, int N, int m, float radius, int nsample, int C, int use_xyz, int normalize,
+                         const float *new_xyz, const float *xyz, const float *feats, int *idx, float *rows,
+                         void *workspace, size_t workspace_bytes, int slab_w, void *stream);
 
 /* sample_uniformly / ret_unique_cnt of the Group-Free-3D QueryAndGroup
  *   (GF3D/pointnet2/pointnet2_utils.py:327-336: a host loop of torch.unique + torch.randint per region).

@@ -33,6 +33,42 @@ def _unit_ball(B, N, seed):
     return p / p.norm(dim=2, keepdim=True) * torch.rand(B, N, 1, generator=g).pow(1 / 3)
 
 
+def _f64_level(sa, xyz, feats_cn, idx, new_xyz, gout, radius, need_feat_grad):
+    """float64 truth of one SA level's training step (grouping through the ORACLE's indices, conv1x1 + train-mode BatchNorm +
+    ReLU per layer, max over the neighbourhood, loss = sum(out * gout)): parameter gradients in layer order (weight, gamma,
+    beta per layer) and, if asked, the gradient of the input features.  Decides WHICH of two fp32 results is closer to the
+    true gradient: sums over 10^5..10^6 rows in front of a BatchNorm cancel by three orders of magnitude, so two correct
+    fp32 implementations differ by more than any fixed 1e-4."""
+    B, m, ns = idx.shape
+    f = feats_cn.double().transpose(1, 2).contiguous().requires_grad_(need_feat_grad)           # (B, N, C)
+    b = torch.arange(B).view(B, 1, 1)
+    rel = (xyz[b, idx.long()] - new_xyz.unsqueeze(2))
+    rel = (rel / torch.tensor(radius, dtype=torch.float32)).double()                           # fp32 division like the kernels
+    h = torch.cat([rel, f[b, idx.long()]], dim=3).view(-1, 3 + f.size(2))
+    params = []
+    convs = [mod for mod in sa.mlp_module.modules() if isinstance(mod, torch.nn.Conv2d)]
+    bns = [mod for mod in sa.mlp_module.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+    for conv, bn in zip(convs, bns):
+        W = conv.weight.detach().double().view(conv.out_channels, -1).requires_grad_(True)
+        ga, be = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+        params += [W, ga, be]
+        y = h @ W.t()
+        mean, var = y.mean(0), y.var(0, unbiased=False)
+        h = torch.relu((y - mean) / torch.sqrt(var + bn.eps) * ga + be)
+    out = h.view(B, m, ns, -1).max(dim=2).values.transpose(1, 2)                                # (B, C, m)
+    (out * gout.double()).sum().backward()
+    return [p_.grad for p_ in params], (f.grad.transpose(1, 2) if need_feat_grad else None), out.detach()
+
+
+def _closer_than_the_fp32_oracle(name, got, ref32, truth, slack=3.0, floor=2e-5):
+    """`got` (HIP) must be as close to the float64 `truth` as the fp32 oracle-backend result `ref32` is (x slack), or within
+    `floor` of the tensor's largest entry."""
+    scale = float(truth.abs().max())
+    e_got, e_ref = float((got.double() - truth).abs().max()), float((ref32.double() - truth).abs().max())
+    print(f"\n[{name}] max|hip - f64| {e_got:.3e}, max|oracle fp32 - f64| {e_ref:.3e}, max|f64| {scale:.3e}", end="")
+    assert e_got <= max(slack * e_ref, floor * scale), (name, e_got, e_ref, scale)
+
+
 class _Calls:
     """Counts the calls of the named `_ext` entry points while the HIP backend runs (which route did the level take?)."""
 
@@ -84,10 +120,12 @@ def test_sa1_at_crowded_density_takes_the_headline_route_and_matches_the_oracle(
     err = float((nf_g - nf_r).abs().max())
     print(f"\n[crowded SA1] features: max abs err {err:.3e} (max |ref| {float(nf_r.abs().max()):.2f})", end="")
     torch.testing.assert_close(nf_g, nf_r, atol=1e-4, rtol=1e-4)
-    for k in g_r:
-        e = float((g_g[k] - g_r[k]).abs().max())
-        print(f"\n[crowded SA1] d{k}: max abs err {e:.3e} (max |ref| {float(g_r[k].abs().max()):.3f})", end="")
-        torch.testing.assert_close(g_g[k], g_r[k], atol=1e-4, rtol=1e-3)
+    # parameter gradients: sums over 262 144 rows in front of BatchNorms — judged against a float64 truth (see _f64_level)
+    idx_r = oracle_ext.OracleRowsExt.ball_query(nx_r, xyz, 0.2, 64)
+    truth, _, out64 = _f64_level(sa, xyz, rgb, idx_r, nx_r, gout, 0.2, False)
+    assert float((nf_g.double() - out64).abs().max()) < 1e-4
+    for (k, _p), t in zip(sa.named_parameters(), truth):
+        _closer_than_the_fp32_oracle(f"crowded SA1 d{k}", g_g[k].view(t.shape), g_r[k].view(t.shape), t)
     for k in b_r:                                                          # running statistics of the three BatchNorms
         torch.testing.assert_close(b_g[k].float(), b_r[k].float(), atol=1e-5, rtol=1e-4)
 
@@ -123,8 +161,114 @@ def test_sa2_at_crowded_density_with_feature_gradient_matches_the_oracle():
     assert calls.count == {"mlp_gemm_pool": 1, "pool_bwd": 1, "group_rows_grad_csr": 1}, calls.count
     assert torch.equal(inds_g, inds_r)
     torch.testing.assert_close(nf_g, nf_r, atol=1e-4, rtol=1e-4)
-    e = float((gf_g - gf_r).abs().max())
-    print(f"\n[crowded SA2] d features: max abs err {e:.3e} (max |ref| {float(gf_r.abs().max()):.3f})", end="")
-    torch.testing.assert_close(gf_g, gf_r, atol=1e-4, rtol=1e-3)
-    for k in g_r:
-        torch.testing.assert_close(g_g[k], g_r[k], atol=1e-4, rtol=1e-3)
+    nx_r = xyz[torch.arange(2)[:, None], inds_r.long()]
+    idx_r = oracle_ext.OracleRowsExt.ball_query(nx_r, xyz, 0.4, 32)
+    truth, gf64, out64 = _f64_level(sa, xyz, feats, idx_r, nx_r, gout, 0.4, True)
+    assert float((nf_g.double() - out64).abs().max()) < 1e-4
+    _closer_than_the_fp32_oracle("crowded SA2 d features", gf_g, gf_r, gf64)
+    for (k, _p), t in zip(sa.named_parameters(), truth):
+        _closer_than_the_fp32_oracle(f"crowded SA2 d{k}", g_g[k].view(t.shape), g_r[k].view(t.shape), t)
+
+
+# ------------------------------------------------------------------------------------ ball query + grouping as ONE kernel
+def _r3_cases():
+    import test_gpu_round3 as t3
+    mark = [m for m in t3.test_slab_cell_list_ball_query_is_bit_exact.pytestmark if m.name == "parametrize"][0]
+    return list(mark.args[1])
+
+
+def _r2_cases():
+    import test_gpu_round2 as t2
+    mark = [m for m in t2.test_cell_list_ball_query_is_bit_exact.pytestmark if m.name == "parametrize"][0]
+    return list(mark.args[1])
+
+
+def _check_fused(centres, xyz, r, ns, C, normalize, use_xyz=True):
+    """pn2_ball_query_group for both slab widths == oracle indices, == pn2_group_concat_rows on those indices (bit for
+    bit) == the oracle's grouping."""
+    from pointnet2_ops import _ext
+    B, N, _ = xyz.shape
+    g = torch.Generator().manual_seed(N + ns)
+    feats = torch.rand(B, N, C, generator=g) if C else None
+    want_idx = oracle_ext.OracleRowsExt.ball_query(centres, xyz, r, ns)
+    want_rows = oracle_ext.OracleRowsExt.group_concat_rows(xyz, centres, feats, want_idx, use_xyz, normalize, r)
+    cx, cc, cf = xyz.cuda(), centres.cuda(), None if feats is None else feats.cuda()
+    if not _ext.ball_query_group_supported(B, N, centres.size(1), r, ns, C, use_xyz):
+        with pytest.raises(RuntimeError):
+            _ext.ball_query_group(cc, cx, cf, r, ns, use_xyz, normalize)
+        return False
+    for w in (1, 4, 0):
+        idx, rows = _ext.ball_query_group(cc, cx, cf, r, ns, use_xyz, normalize, slab_w=w)
+        assert torch.equal(idx.cpu(), want_idx), f"slab_w {w}: indices differ from the oracle"
+        two = _ext.group_concat_rows(cx, cc, cf, idx, use_xyz, normalize, r)
+        # NaN coordinates (the 'wild' clouds) make rows NaN in both: compare bit patterns
+        assert torch.equal(rows.view(torch.int32), two.view(torch.int32)), f"slab_w {w}: rows differ from pn2_group_concat_rows"
+        a, b = rows.cpu(), want_rows
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        assert torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0)), f"slab_w {w}: rows differ from the oracle"
+    return True
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_fused_ball_query_group_on_the_round3_clouds(case):
+    """EXT/src/ball_query_gpu.cu:9-44 + group_points_gpu.cu:8-28 + OPS/pointnet2_utils.py:317-328 as one kernel, on the twelve
+    clouds of the slab test (50k headline shape, duplicates, lattice points with d^2 = r^2, r larger than the cloud, clouds
+    far from the origin, hash aliasing, coordinates beyond the cell arithmetic, NaN / inf): both slab widths."""
+    import numpy as np
+    import test_gpu_round3 as t3
+    B, N, m, r, ns, kind = _r3_cases()[case]
+    rng = np.random.default_rng(N + m)
+    xyz = torch.from_numpy(t3._bq_cloud(kind, B, N, rng))
+    centres = xyz[:, rng.permutation(N)[:m]].clone()
+    centres[:, -1] = 50.0 if kind != "wide" else 5000.0
+    if kind == "wild":
+        centres[:, 0] = xyz[:, 5]
+        centres[:, 1, 2] = float("nan")
+        centres[:, 2, 0] = float("inf")
+    _check_fused(centres.contiguous(), xyz, r, ns, C=3, normalize=True)
+
+
+@pytest.mark.parametrize("case", range(11))
+def test_fused_ball_query_group_on_the_round2_clouds(case):
+    """... and on the eleven clouds of the cell-list test (planes, duplicates, crowded clusters, centres outside the cloud,
+    nsample beyond 256 -> not covered: the binding raises and callers keep the two kernels), with 0 / 4 / 13 feature
+    columns and without radius normalisation."""
+    import test_gpu_round2 as t2
+    B, N, m, ns, r, kind = _r2_cases()[case]
+    xyz = t2._bq_cloud(B, N, kind, seed=N + m)
+    g = torch.Generator().manual_seed(7)
+    sel = torch.randint(0, N, (B, m), generator=g)
+    new_xyz = xyz[torch.arange(B)[:, None], sel].clone()
+    new_xyz[:, ::5] += torch.randn(B, (m + 4) // 5, 3, generator=g) * r
+    new_xyz[:, -1] = 40.0
+    _check_fused(new_xyz.contiguous(), xyz, r, ns, C=(0, 4, 13)[case % 3], normalize=case % 2 == 0)
+
+
+def test_fused_query_feeds_the_sa_level_with_identical_results():
+    """The SA level consumes the rows the query kernel emitted (geometry['rows']) — outputs and gradients bit-identical to
+    the two-kernel route; a prefetched geometry carries them for level 1 (input colours)."""
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    from pointnet2_ops import _ext, pointnet2_modules as pm
+    torch.manual_seed(3)
+    net = Pointnet2Backbone(input_feature_dim=3).cuda().train()
+    pc = torch.cat([_unit_ball(2, 20000, 31), torch.rand(2, 20000, 3)], dim=2).cuda()
+    with _Calls(_ext, ["ball_query_group", "group_concat_rows"]) as calls:
+        geo = net.precompute_geometry(pc)
+        assert geo["sa"][0]["rows"] is not None and calls.count["ball_query_group"] == 1
+        a = net(pc, geometry=geo)
+        a["fp2_features"].square().mean().backward()
+        n_group = calls.count["group_concat_rows"]
+    ga = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net.zero_grad()
+    geo2 = net.precompute_geometry(pc)
+    geo2["sa"][0]["rows"] = None                                      # the two-kernel route
+    with _Calls(_ext, ["group_concat_rows"]) as calls2:
+        b = net(pc, geometry=geo2)
+        b["fp2_features"].square().mean().backward()
+    assert calls2.count["group_concat_rows"] == n_group + 1
+    assert torch.equal(geo["sa"][0]["idx"], geo2["sa"][0]["idx"])
+    for k in ("sa1_features", "sa2_features", "fp2_features"):
+        assert torch.equal(a[k], b[k]), k
+    for n, p in net.named_parameters():
+        if "sa1" in n:                                                # (deeper levels: atomic order in the weight gradients)
+            torch.testing.assert_close(p.grad, ga[n], atol=1e-6, rtol=1e-5)

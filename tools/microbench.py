@@ -1,5 +1,6 @@
 """Per-kernel micro-benchmarks at BASELINE config-2 shapes.
-Prints one JSON line per kernel: time, algorithmic bytes, achieved GB/s."""
+Prints one JSON line per kernel: time, algorithmic bytes (SURVEY.md 8d formulas), achieved GB/s, `frac_of_8TBps` and,
+beside it, north_star's `target` of 0.60 for the HBM-bound grouping / query kernels (FPS is latency-bound: no target)."""
 import json
 import os
 import sys
@@ -32,10 +33,12 @@ def timeit(fn, iters=10, warm=2):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-def report(name, t, nbytes, **kw):
-    print(json.dumps(dict(kernel=name, ms=round(t * 1e3, 4), alg_MB=round(nbytes / 1e6, 2),
-                          GBps=round(nbytes / t / 1e9, 1), frac_of_8TBps=round(nbytes / t / 8e12, 4), **kw)),
-          flush=True)
+def report(name, t, nbytes, target=0.60, **kw):
+    row = dict(kernel=name, ms=round(t * 1e3, 4), alg_MB=round(nbytes / 1e6, 2), GBps=round(nbytes / t / 1e9, 1),
+               frac_of_8TBps=round(nbytes / t / 8e12, 4))
+    if target is not None:
+        row["target"] = target                      # north_star: >= 60 % of the HBM roofline for ball-query + group
+    print(json.dumps(dict(row, **kw)), flush=True)
 
 
 def fps_sweep(dev):
@@ -110,18 +113,18 @@ def main():
     feats_rows = feats.transpose(1, 2).contiguous()
 
     t = timeit(lambda: _ext.furthest_point_sampling(xyz, m), iters=3, warm=1)
-    report("fps", t, B * (12 * N + 4 * m), B=B, N=N, m=m, us_per_round=round(t / (m - 1) * 1e6, 3))
+    report("fps", t, B * (12 * N + 4 * m), target=None, B=B, N=N, m=m, us_per_round=round(t / (m - 1) * 1e6, 3))
     sel = _ext.furthest_point_sampling(xyz, m)
     new_xyz = torch.gather(xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
 
     for (n2, m2) in ((2048, 1024), (1024, 512), (512, 256)):
         x2 = xyz[:, :n2].contiguous()
         t = timeit(lambda: _ext.furthest_point_sampling(x2, m2), iters=5)
-        report(f"fps_{n2}_{m2}", t, B * (12 * n2 + 4 * m2), us_per_round=round(t / (m2 - 1) * 1e6, 3))
+        report(f"fps_{n2}_{m2}", t, B * (12 * n2 + 4 * m2), target=None, us_per_round=round(t / (m2 - 1) * 1e6, 3))
     for (b2, n2, m2) in ((72, 8000, 512), (9, 4000, 512)):
         x2 = unit_ball(b2, n2, 1).to(dev)
         t = timeit(lambda: _ext.furthest_point_sampling(x2, m2), iters=5)
-        report(f"fps_B{b2}_{n2}_{m2}", t, b2 * (12 * n2 + 4 * m2), us_per_round=round(t / (m2 - 1) * 1e6, 3))
+        report(f"fps_B{b2}_{n2}_{m2}", t, b2 * (12 * n2 + 4 * m2), target=None, us_per_round=round(t / (m2 - 1) * 1e6, 3))
 
     t = timeit(lambda: _ext.ball_query(new_xyz, xyz, r, ns))
     report("ball_query", t, B * (12 * N + 12 * m + 4 * m * ns), r=r, ns=ns)
@@ -138,8 +141,19 @@ def main():
     t = timeit(lambda: _ext.group_points_grad(go, idx, N))
     report("group_points_grad_C3", t, B * (4 * m * ns + 4 * C * m * ns + 4 * C * N))
 
-    t = timeit(lambda: _ext.group_concat_rows(xyz, new_xyz, feats_rows, idx, True, True, r))
-    report("group_concat_rows_C3", t, B * (4 * m * ns + 12 * N + 12 * m + 4 * C * N + 4 * (3 + C) * m * ns))
+    t_g = timeit(lambda: _ext.group_concat_rows(xyz, new_xyz, feats_rows, idx, True, True, r))
+    report("group_concat_rows_C3", t_g, B * (4 * m * ns + 12 * N + 12 * m + 4 * C * N + 4 * (3 + C) * m * ns))
+    # ball query + grouping as ONE kernel (pn2_ball_query_group) against the pair it replaces; SURVEY.md 8d: fused
+    # (idx kept) = B (12 N + 12 m + 4 C N + 4 (3 + C) m ns + 4 m ns) = 156.7 MB at this shape
+    fused_bytes = B * (12 * N + 12 * m + 4 * C * N + 4 * (3 + C) * m * ns + 4 * m * ns)
+    t_q = timeit(lambda: _ext.ball_query(new_xyz, xyz, r, ns))
+    report("ball_query+group_concat_rows_C3 (two kernels)", t_q + t_g, fused_bytes, r=r, ns=ns)
+    for w in (1, 4, 0):
+        t = timeit(lambda: _ext.ball_query_group(new_xyz, xyz, feats_rows, r, ns, True, True, slab_w=w))
+        report(f"ball_query_group_fused_C3 slab_w={w or 'auto'}", t, fused_bytes, r=r, ns=ns,
+               note="query + (xyz - centre) / r + colours in one pass, idx kept for the backward")
+    i_f, r_f = _ext.ball_query_group(new_xyz, xyz, feats_rows, r, ns, True, True)
+    assert torch.equal(i_f, idx) and torch.equal(r_f, _ext.group_concat_rows(xyz, new_xyz, feats_rows, idx, True, True, r))
     gr = torch.rand(B, m, ns, 3 + C, device=dev)
     t = timeit(lambda: _ext.group_rows_grad(gr, idx, N, C, 3))
     report("group_rows_grad_C3", t, B * (4 * m * ns + 4 * C * m * ns + 4 * C * N))
