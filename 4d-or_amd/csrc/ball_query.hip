@@ -218,6 +218,8 @@ __global__ __launch_bounds__(256 * W) void bq_slab_build_kernel(int N, int nslab
   }
 }
 
+struct Row3 { float a, b, c; };   // 12 bytes, 4-byte aligned: global_load_dwordx3
+
 struct BqFuse {              // grouped-row emission (FUSE): out[g][s][0:Cx] = (xyz[idx] - centre) (/ radius), [Cx:Cx+C] = feats[idx]
   const float *xyz;          // (B, N, 3)
   const float *feats;        // (B, N, C) point-major or null (C = 0)
@@ -226,30 +228,37 @@ struct BqFuse {              // grouped-row emission (FUSE): out[g][s][0:Cx] = (
   float radius;
 };
 
-template <int W, bool FUSE>
-__global__ __launch_bounds__(256) void bq_slab_query_kernel(int N, int m, int nslab, float r2, int ns, double inv_h,
+// LDS traffic of a wave is ordered (one LDS queue per CU, in order per wave): lanes may read what other lanes of the wave
+// wrote once the counter has drained.  The arrays are indexed as __shared__ objects (ds_* instructions; a pointer into
+// them that loses its address space becomes flat_* with a full wait each) and the compiler is told not to move LDS
+// accesses across the points where lanes exchange data.
+__device__ __forceinline__ void slab_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
+// FUSE: 0 = indices only; 6 = grouped rows of exactly 3 + 3 floats (xyz + colours: the first level of the backbone and of
+// the object encoder) with every row offset a compile-time constant; 1 = grouped rows of any covered width
+template <int W, int FUSE>
+__global__ __launch_bounds__(256, 8) void bq_slab_query_kernel(int N, int m, int nslab, float r2, int ns, double inv_h,
                                                            double rw, const float *__restrict__ new_xyz,
                                                            const unsigned *__restrict__ table,
                                                            const float4 *__restrict__ recs, int *__restrict__ idx,
-                                                           long long centres, long long blocks, BqFuse fz) {
+                                                           int centres, int blocks, BqFuse fz) {
   constexpr int SL = kSlab * W;
   __shared__ unsigned s_mask[4][64 * W];
   __shared__ int s_idx[FUSE ? 4 : 1][FUSE ? kFuseMaxNs : 1];
-  __shared__ float s_rows[FUSE ? 4 : 1][FUSE ? 64 * kFuseMaxRow : 1];
+  __shared__ float s_rows[FUSE ? 4 : 1][FUSE == 6 ? 64 * 6 : (FUSE ? 64 * kFuseMaxRow : 1)];
   const int lane = pn2_lane();
   const int wv = threadIdx.x >> 6;
   // XCD-aware order: physical workgroup p runs on XCD p mod 8; XCD x takes the x-th eighth of the (cloud-major) centres
-  const long long per = (blocks + 7) >> 3;
-  const long long lb = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int per = (blocks + 7) >> 3;
+  const int lb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (lb >= blocks) return;
-  const long long g = lb * 4 + wv;
+  const int g = lb * 4 + wv;
   if (g >= centres) return;                                     // wave-uniform; no block barriers below
-  const int b = (int)(g / m);
-  const float qx = new_xyz[g * 3 + 0], qy = new_xyz[g * 3 + 1], qz = new_xyz[g * 3 + 2];
-  int *row = idx + g * ns;
-  volatile unsigned *mask = s_mask[wv];
+  const int b = (int)((unsigned)g / (unsigned)m);
+  const float qx = new_xyz[(size_t)g * 3 + 0], qy = new_xyz[(size_t)g * 3 + 1], qz = new_xyz[(size_t)g * 3 + 2];
+  int *row = idx + (size_t)g * ns;
 #pragma unroll
-  for (int k = 0; k < W; ++k) mask[lane * W + k] = 0u;
+  for (int k = 0; k < W; ++k) s_mask[wv][lane * W + k] = 0u;
 
   // lane -> (cell of the 3 x 3 x 3 window, slot); the window starts at the cell of c - rw on every axis
   const double tx = ((double)qx - rw) * inv_h, ty = ((double)qy - rw) * inv_h, tz = ((double)qz - rw) * inv_h;
@@ -270,20 +279,28 @@ __global__ __launch_bounds__(256) void bq_slab_query_kernel(int N, int m, int ns
     const bool all = !tame || T[kSlabCells] != 0u;              // wave-uniform
     if (!all) {
       const int beg = (int)(w & 0xffffu), len = (int)(w >> 16);
-      // four records in flight per lane (a cell of an 8192-index slab holds ~16 at the headline density)
-      for (int j = slot; j < len; j += 8) {
-        float4 p[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int jj = j + 2 * u;
-          p[u] = R[beg + (jj < len ? jj : j)];
+      // four records in flight per lane (a cell of an 8192-index slab holds ~16 at the headline density): one pointer, four
+      // loads at constant offsets — a load past the cell's last record reads a neighbouring record (the table follows the
+      // records in the workspace: never out of the allocation) and is discarded by the count test
+      const float4 *P = R + beg + slot;
+      for (int j = slot; j < len; j += 8, P += 8) {
+        const float4 p0 = P[0], p1 = P[2], p2 = P[4], p3 = P[6];
+        const int left = len - j;                                 // records of this lane's slot sequence still inside: u < left / 2
+        if (pn2_sq3(qx - p0.x, qy - p0.y, qz - p0.z) < r2) {
+          const int li = __float_as_int(p0.w);
+          atomicOr(&s_mask[wv][li >> 5], 1u << (li & 31));
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (j + 2 * u < len && pn2_sq3(qx - p[u].x, qy - p[u].y, qz - p[u].z) < r2) {
-            const int li = __float_as_int(p[u].w);
-            atomicOr((unsigned *)&mask[li >> 5], 1u << (li & 31));
-          }
+        if (left > 2 && pn2_sq3(qx - p1.x, qy - p1.y, qz - p1.z) < r2) {
+          const int li = __float_as_int(p1.w);
+          atomicOr(&s_mask[wv][li >> 5], 1u << (li & 31));
+        }
+        if (left > 4 && pn2_sq3(qx - p2.x, qy - p2.y, qz - p2.z) < r2) {
+          const int li = __float_as_int(p2.w);
+          atomicOr(&s_mask[wv][li >> 5], 1u << (li & 31));
+        }
+        if (left > 6 && pn2_sq3(qx - p3.x, qy - p3.y, qz - p3.z) < r2) {
+          const int li = __float_as_int(p3.w);
+          atomicOr(&s_mask[wv][li >> 5], 1u << (li & 31));
         }
       }
     } else {
@@ -292,20 +309,20 @@ __global__ __launch_bounds__(256) void bq_slab_query_kernel(int N, int m, int ns
         const float4 p = R[j];
         if (pn2_sq3(qx - p.x, qy - p.y, qz - p.z) < r2) {
           const int li = __float_as_int(p.w);
-          atomicOr((unsigned *)&mask[li >> 5], 1u << (li & 31));
+          atomicOr(&s_mask[wv][li >> 5], 1u << (li & 31));
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // LDS operations of a wave retire in order
+    slab_lds_sync();
     unsigned word[W];
     bool any = false;
 #pragma unroll
-    for (int k = 0; k < W; ++k) { word[k] = mask[lane * W + k]; any |= word[k] != 0u; }
+    for (int k = 0; k < W; ++k) { word[k] = s_mask[wv][lane * W + k]; any |= word[k] != 0u; }
     const u64 some = __ballot(any);
     if (some == 0ull) continue;
     int pc = 0;
 #pragma unroll
-    for (int k = 0; k < W; ++k) { mask[lane * W + k] = 0u; pc += __popc(word[k]); }
+    for (int k = 0; k < W; ++k) { s_mask[wv][lane * W + k] = 0u; pc += __popc(word[k]); }
     const int inc = slab_wave_scan(pc);
     const int at = sl * SL + lane * 32 * W;
     if (cnt == 0) {
@@ -327,6 +344,7 @@ __global__ __launch_bounds__(256) void bq_slab_query_kernel(int N, int m, int ns
       }
     }
     cnt += __builtin_amdgcn_readlane(inc, 63);
+    slab_lds_sync();                                            // the mask words are clear before the next slab's hits land
   }
   // pad with the first hit (zero row for an empty ball): EXT/src/ball_query_gpu.cu:34-38
   if (!FUSE) {
@@ -334,31 +352,54 @@ __global__ __launch_bounds__(256) void bq_slab_query_kernel(int N, int m, int ns
     return;
   }
   for (int s = (cnt < ns ? cnt : ns) + lane; s < ns; s += 64) s_idx[wv][s] = first;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  slab_lds_sync();
   // the index row (coalesced) and the grouped rows: 64 slots at a time, each lane gathers its slot's point, the row
   // block goes through LDS so that the stores are contiguous 256-byte runs (a neighbourhood's rows are one contiguous block)
-  const int Cx = fz.Cx, C = fz.C, RW = Cx + C;
+  const int Cx = FUSE == 6 ? 3 : fz.Cx, C = FUSE == 6 ? 3 : fz.C, RW = Cx + C;
   const float *X = fz.xyz + (size_t)b * N * 3;
   const float *F = fz.feats ? fz.feats + (size_t)b * N * C : nullptr;
   float *out = fz.rows + (size_t)g * ns * RW;
-  volatile float *rb = s_rows[wv];
+#pragma unroll 1
   for (int s0 = 0; s0 < ns; s0 += 64) {
     const int s = s0 + lane;
     const int nrow = ns - s0 < 64 ? ns - s0 : 64;
     if (s < ns) {
       const int i = s_idx[wv][s];
       row[s] = i;
+      // one 12-byte load per row where the row is three floats (coordinates, colours): a scattered access costs the
+      // CU's address unit a pass per LANE, whatever its width
       if (Cx) {
-        float rx = X[(size_t)i * 3 + 0] - qx, ry = X[(size_t)i * 3 + 1] - qy, rz = X[(size_t)i * 3 + 2] - qz;
+        const Row3 p = *reinterpret_cast<const Row3 *>(X + (size_t)i * 3);
+        float rx = p.a - qx, ry = p.b - qy, rz = p.c - qz;
         if (fz.normalize) { rx = __fdiv_rn(rx, fz.radius); ry = __fdiv_rn(ry, fz.radius); rz = __fdiv_rn(rz, fz.radius); }
-        rb[lane * RW + 0] = rx; rb[lane * RW + 1] = ry; rb[lane * RW + 2] = rz;
+        s_rows[wv][lane * RW + 0] = rx; s_rows[wv][lane * RW + 1] = ry; s_rows[wv][lane * RW + 2] = rz;
       }
-      for (int c = 0; c < C; ++c) rb[lane * RW + Cx + c] = F[(size_t)i * C + c];
+      if (C == 3) {
+        const Row3 f = *reinterpret_cast<const Row3 *>(F + (size_t)i * 3);
+        s_rows[wv][lane * RW + Cx + 0] = f.a; s_rows[wv][lane * RW + Cx + 1] = f.b; s_rows[wv][lane * RW + Cx + 2] = f.c;
+      } else if ((C & 3) == 0) {
+#pragma unroll 1
+        for (int c = 0; c < C; c += 4) {
+          const float4 f = *reinterpret_cast<const float4 *>(F + (size_t)i * C + c);
+          s_rows[wv][lane * RW + Cx + c + 0] = f.x; s_rows[wv][lane * RW + Cx + c + 1] = f.y;
+          s_rows[wv][lane * RW + Cx + c + 2] = f.z; s_rows[wv][lane * RW + Cx + c + 3] = f.w;
+        }
+      } else {
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) s_rows[wv][lane * RW + Cx + c] = F[(size_t)i * C + c];
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    slab_lds_sync();
     const int total = nrow * RW;
-    for (int e = lane; e < total; e += 64) out[(size_t)s0 * RW + e] = rb[e];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (FUSE == 6 && nrow == 64) {
+      float *o = out + (size_t)s0 * 6 + lane;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o[k * 64] = s_rows[wv][k * 64 + lane];
+    } else {
+#pragma unroll 2
+      for (int e = lane; e < total; e += 64) out[(size_t)s0 * RW + e] = s_rows[wv][e];
+    }
+    slab_lds_sync();
   }
 }
 
@@ -690,25 +731,26 @@ int bq_run_slabs(int B, int N, int m, float radius, int nsample, const float *ne
   const long long centres = (long long)B * m;
   const long long blocks = (centres + 3) / 4;
   const long long grid = ((blocks + 7) / 8) * 8;                  // XCD-aware order: eight equal shares
-  if (grid > 0x7fffffffLL || B > 65535) return PN2_EINVAL;
+  if (centres > 0x7fffffffLL - 64 || B > 65535) return PN2_EINVAL;     // (the kernel indexes centres with 32 bits)
   // hit bound rq = r 1.0001, window rw = rq 1.0001, cell edge h = rw 1.0001 (see the kernel header)
   const double rw = (double)radius * 1.0001 * 1.0001, inv_h = 1.0 / (rw * 1.0001);
   float4 *recs = (float4 *)workspace;
   unsigned *table = (unsigned *)((char *)workspace + (size_t)B * N * 16);
   const float r2 = radius * radius;   // fp32, EXT/src/ball_query_gpu.cu:22
   BqFuse fz = fuse ? *fuse : BqFuse{nullptr, nullptr, nullptr, 0, 0, 0, 1.f};
-#define PN2_BQ_LAUNCH(WW)                                                                                              \
-  do {                                                                                                                 \
-    hipLaunchKernelGGL(bq_slab_build_kernel<WW>, dim3((unsigned)nslab, (unsigned)B), dim3(256 * WW), 0, s, N, nslab,   \
-                       inv_h, xyz, table, recs);                                                                       \
-    if (fuse)                                                                                                          \
-      hipLaunchKernelGGL((bq_slab_query_kernel<WW, true>), dim3((unsigned)grid), dim3(256), 0, s, N, m, nslab, r2,     \
-                         nsample, inv_h, rw, new_xyz, table, recs, idx, centres, blocks, fz);                          \
-    else                                                                                                               \
-      hipLaunchKernelGGL((bq_slab_query_kernel<WW, false>), dim3((unsigned)grid), dim3(256), 0, s, N, m, nslab, r2,    \
-                         nsample, inv_h, rw, new_xyz, table, recs, idx, centres, blocks, fz);                          \
-  } while (0)
-  if (W == 4) PN2_BQ_LAUNCH(4); else PN2_BQ_LAUNCH(1);
+#define PN2_BQ_LAUNCH(WW, FF)                                                                                          \
+  hipLaunchKernelGGL((bq_slab_query_kernel<WW, FF>), dim3((unsigned)grid), dim3(256), 0, s, N, m, nslab, r2, nsample,  \
+                     inv_h, rw, new_xyz, table, recs, idx, (int)centres, (int)blocks, fz)
+  const int ff = !fuse ? 0 : (fz.Cx == 3 && fz.C == 3 ? 6 : 1);
+  if (W == 4) {
+    hipLaunchKernelGGL(bq_slab_build_kernel<4>, dim3((unsigned)nslab, (unsigned)B), dim3(1024), 0, s, N, nslab, inv_h, xyz,
+                       table, recs);
+    if (ff == 0) PN2_BQ_LAUNCH(4, 0); else if (ff == 6) PN2_BQ_LAUNCH(4, 6); else PN2_BQ_LAUNCH(4, 1);
+  } else {
+    hipLaunchKernelGGL(bq_slab_build_kernel<1>, dim3((unsigned)nslab, (unsigned)B), dim3(256), 0, s, N, nslab, inv_h, xyz,
+                       table, recs);
+    if (ff == 0) PN2_BQ_LAUNCH(1, 0); else if (ff == 6) PN2_BQ_LAUNCH(1, 6); else PN2_BQ_LAUNCH(1, 1);
+  }
 #undef PN2_BQ_LAUNCH
   return pn2_check_launch();
 }

@@ -135,7 +135,7 @@ class _FusedMLP(Function):
             ctx.feat_shape = None if x is None else tuple(x.shape)
             pre = getattr(ctx, "x_rows", None)          # a segmented call groups the whole batch once and hands in the rows
             if pre is None and len(group) > 8 and group[8] is not None:
-                pre = group[8]                          # rows the fused query + grouping kernel emitted next to idx
+                pre = group[8].view(-1, group[8].size(-1))     # rows the fused query + grouping kernel emitted next to idx
             x = pre if pre is not None else e.group_concat_rows(
                 xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize,
                 radius).view(-1, (3 if use_xyz else 0) + (0 if x is None else x.size(2)))
