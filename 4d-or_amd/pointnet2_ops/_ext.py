@@ -66,6 +66,8 @@ _SIGNATURES = {
     "pn2_bn_running_update": [_c_int, _c_int, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
     "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
+    "pn2_group_lift_rows": [_c_int] * 6 + [_c_f32] + [_c_vp] * 8,
+    "pn2_group_lift_rows_grad": [_c_int] * 6 + [_c_f32] + [_c_vp] * 10,
     "pn2_group_rows_grad_csr_bf16": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_rows_grad_bf16": [_c_int] * 7 + [_c_vp] * 4,
     "pn2_rows_max": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -153,6 +155,8 @@ _lib.pn2_ball_query_algo_bytes.argtypes = [_c_int, _c_int, _c_int, _c_int, _c_f3
 _lib.pn2_ball_query_algo_bytes.restype = _c_sz
 _lib.pn2_ball_query_auto.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int]
 _lib.pn2_ball_query_auto.restype = _c_int
+_lib.pn2_group_lift_supported.argtypes = [_c_int]
+_lib.pn2_group_lift_supported.restype = _c_int
 _lib.pn2_ball_query_group_supported.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_int, _c_int]
 _lib.pn2_ball_query_group_supported.restype = _c_int
 _lib.pn2_ball_query_group_workspace_bytes.argtypes = [_c_int, _c_int]
@@ -204,6 +208,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_ball_query_group_supported", "pn2_ball_query_group_workspace_bytes",
+                                               "pn2_group_lift_supported",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
@@ -683,6 +688,53 @@ def group_rows_grad_csr(grad_out, inv, n, c, col0, out=None):
     _call("pn2_group_rows_grad_csr" + sfx, grad_out, B, n, c, W, int(col0), B * m * ns, _ptr(grad_out), _ptr(ptr), _ptr(refs),
           _ptr(out), alg_bytes=B * (8 * m * ns + eb * c * m * ns + 4 * c * n + 4 * n), label="pn2_group_rows_grad")
     return out
+
+
+def group_lift_supported(n0) -> bool:
+    """First-layer widths pn2_group_lift_rows covers (multiples of 4 from 16 to 256)."""
+    return bool(_lib.pn2_group_lift_supported(int(n0)))
+
+
+def group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, radius, stats=None):
+    """The first conv of an SA stack applied BEFORE the grouping: P (B,N,N0) = per-point products f Wf^T, Wx (N0,3) the
+    coordinate columns -> Y0 (B*m*ns, N0) = P[idx] + Wx rel, rel = (xyz[idx] - new_xyz) (/ radius); `stats` (2,N0) f64 +=
+    column sums of y0 and y0^2.  Replaces group_points x 2 + cat + Conv2d 1x1 of the first layer
+    (EXT/src/group_points_gpu.cu:8-28, OPS/pointnet2_utils.py:317-328, OPS/pointnet2_modules.py:9-19)."""
+    _f32(P, "P"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _i32(idx, "idx"); _f32(Wx, "Wx")
+    _same_device((P, "P"), (xyz, "xyz"), (new_xyz, "new_xyz"), (idx, "idx"), (Wx, "Wx"), (stats, "stats"))
+    B, m, ns = idx.shape
+    N, N0 = xyz.size(1), P.size(-1)
+    if P.numel() != B * N * N0 or tuple(Wx.shape) != (N0, 3) or tuple(new_xyz.shape) != (B, m, 3):
+        _fail("group_lift_rows: P must be (B, N, N0), Wx (N0, 3), new_xyz (B, m, 3)")
+    Y = torch.empty(B * m * ns, N0, dtype=torch.float32, device=P.device)
+    _call("pn2_group_lift_rows", P, B, N, m, ns, N0, int(bool(normalize)), float(radius if radius is not None else 1.0),
+          _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(P), _ptr(Wx), _ptr(Y), _ptr(stats),
+          alg_bytes=B * (4 * m * ns + 12 * N + 12 * m + 4 * N0 * N + 4 * N0 * m * ns))
+    return Y
+
+
+def group_lift_rows_grad(G, Y0, consts, xyz, new_xyz, inv, ns, normalize, radius, dWx):
+    """Backward of group_lift_rows behind a BatchNorm: per row dL/dy0 = c1 g + c2 y0 + c3 (consts (3,N0)); ->
+    S (B,N,N0) = its sum over the rows that gathered each point (inverse index `inv` = (ptr, refs)); `dWx` (N0,3) +=
+    sum_r dL/dy0[r] rel[r]^T.  Replaces the first layer's M-row dgrad / wgrad GEMMs and group_points_grad_kernel
+    (EXT/src/group_points_gpu.cu:44-75)."""
+    _f32(G, "G"); _f32(Y0, "Y0"); _f32(consts, "consts"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(dWx, "dWx")
+    ptr, refs = inv
+    _i32(ptr, "ptr"); _i32(refs, "refs")
+    _same_device((G, "G"), (Y0, "Y0"), (consts, "consts"), (xyz, "xyz"), (new_xyz, "new_xyz"), (ptr, "ptr"), (refs, "refs"),
+                 (dWx, "dWx"))
+    B, N = xyz.size(0), xyz.size(1)
+    m = new_xyz.size(1)
+    M, N0 = G.shape
+    ns = int(ns)
+    if (tuple(Y0.shape) != (M, N0) or M != B * m * ns or ptr.numel() != B * N + 1 or refs.numel() != M
+            or tuple(consts.shape) != (3, N0) or tuple(dWx.shape) != (N0, 3)):
+        _fail("group_lift_rows_grad: shapes do not belong to one SA level")
+    S = torch.empty(B, N, N0, dtype=torch.float32, device=G.device)
+    _call("pn2_group_lift_rows_grad", G, B, N, m, ns, N0, int(bool(normalize)), float(radius if radius is not None else 1.0),
+          _ptr(xyz), _ptr(new_xyz), _ptr(G), _ptr(Y0), _ptr(consts), _ptr(ptr), _ptr(refs), _ptr(S), _ptr(dWx),
+          alg_bytes=8 * M + 8 * M * N0 + 4 * B * N * (N0 + 4) + 12 * B * m)
+    return S
 
 
 def rows_max(x):

@@ -48,6 +48,12 @@ BF16_FOLD = _os.environ.get("PN2_BF16_FOLD") != "0"
 if _os.environ.get("PN2_FIRST_FREE") == "0":
     FIRST_FREE = False
 
+#: the first layer of a grouped stack whose input is [relative xyz | C >= 16 feature channels] is applied BEFORE the grouping
+#: (csrc/group_lift.hip): W [rel | f[idx]] = Wx rel + (Wf f)[idx] — the feature product once per point instead of once per
+#: (centre, sample) row, no grouped tensor, no M-row dgrad / wgrad / scatter in the backward.  fp32 node, ungrouped input,
+#: and (when gradients are needed) an inverse neighbourhood index next to idx.  PN2_LIFT_FIRST=0 switches it off (A/B).
+LIFT_FIRST = _os.environ.get("PN2_LIFT_FIRST") != "0"
+
 #: arithmetic of the shared-MLP stacks.  float32 = exact fp32 MFMA (the parity path, default).  bfloat16 = the MI355X
 #: counterpart of the reference's 16-bit AMP training (scene_graph_prediction/main.py:64 `precision=16`): activations
 #: between the layers stored as bf16, bf16 MFMA with fp32 accumulation, fp32 weights / BatchNorm statistics / weight
@@ -130,20 +136,32 @@ class _FusedMLP(Function):
         scattered back through the neighbourhood indices in the same autograd node."""
         e = _ext()
         ctx.group = group
+        L = len(layers)
+        lift = False
+        feats = None
         if group is not None:
             xyz, new_xyz, idx, use_xyz, normalize, radius = group[:6]
             ctx.feat_shape = None if x is None else tuple(x.shape)
             pre = getattr(ctx, "x_rows", None)          # a segmented call groups the whole batch once and hands in the rows
             if pre is None and len(group) > 8 and group[8] is not None:
                 pre = group[8].view(-1, group[8].size(-1))     # rows the fused query + grouping kernel emitted next to idx
-            x = pre if pre is not None else e.group_concat_rows(
-                xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize,
-                radius).view(-1, (3 if use_xyz else 0) + (0 if x is None else x.size(2)))
-        x = x.contiguous()
-        M = x.size(0)
-        L = len(layers)
+            # first layer before the grouping (LIFT_FIRST): the rows are never formed
+            lift = bool(LIFT_FIRST and pre is None and x is not None and use_xyz and L >= 2 and x.size(2) >= 16
+                        and getattr(e, "group_lift_rows", None) and e.group_lift_supported(layers[0][0].out_channels)
+                        and (not any(ctx.needs_input_grad) or (len(group) > 6 and group[6] is not None)))
+            if lift:
+                feats = x.contiguous()
+                M, K0 = idx.numel(), 3 + feats.size(2)
+                x = None
+            else:
+                x = pre if pre is not None else e.group_concat_rows(
+                    xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize,
+                    radius).view(-1, (3 if use_xyz else 0) + (0 if x is None else x.size(2)))
+        if not lift:
+            x = x.contiguous()
+            M, K0 = x.size(0), x.size(1)
         ys, fins, batch_flags = [], [], []
-        stat_bufs = e.zero_arena(x.device, [((2, conv.out_channels), torch.float64) for conv, _ in layers])
+        stat_bufs = e.zero_arena((feats if lift else x).device, [((2, conv.out_channels), torch.float64) for conv, _ in layers])
         cur = x
         # pooled last layer without its output tensor: needs the Gram-form backward whenever anything needs a gradient
         Kl, Nl = layers[-1][0].in_channels, layers[-1][0].out_channels
@@ -157,7 +175,6 @@ class _FusedMLP(Function):
                           and e.pool_layer_supported(Kl, Nl, ns) and (not needs_grad or e.pool_bwd_supported(Nl, Kl, ns)))
         pooled_parts = None
         # first layer without its output tensor: when gradients are needed, only if the backward will take the fold path
-        K0 = x.size(1)
         bn0 = layers[0][1]
         need_dgrad0 = ctx.needs_input_grad[0] and (group is None or ctx.feat_shape is not None)
         first_free = bool(
@@ -181,7 +198,9 @@ class _FusedMLP(Function):
                 pooled_parts = e.mlp_gemm_pool(cur, Wf, sgn, ns, p=p, stats=stat_bufs[l]) + (sgn,)
             if use_batch:
                 stats = stat_bufs[l]
-                if first_free and l == 0:
+                if lift and l == 0:
+                    y = _lift_forward(e, feats, W, group, stats)
+                elif first_free and l == 0:
                     y = None
                     e.first_layer_stats(W.contiguous(), gram, stats)
                 elif first_free and l == 1:
@@ -202,7 +221,9 @@ class _FusedMLP(Function):
                 fo = getattr(ctx, "fin_out", None)          # segmented call: this scan's block of the layer's (S,4,C) buffer
                 fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt, out=None if fo is None else fo[l])
             else:
-                if first_free and l == 0:
+                if lift and l == 0:
+                    y = _lift_forward(e, feats, W, group, None)
+                elif first_free and l == 0:
                     y = None
                 elif first_free and l == 1:
                     y = e.mlp_gemm_first(x, W0c, fins[0], W.contiguous(), epi=e.EPI_NONE)
@@ -225,8 +246,9 @@ class _FusedMLP(Function):
         ctx.ns, ctx.L, ctx.batch_flags = ns, L, batch_flags
         ctx.pool_fused = pooled_parts is not None
         ctx.first_free = first_free
+        ctx.lift, ctx.M, ctx.K0 = lift, M, K0
         ctx.shapes = [params[3 * l].shape for l in range(L)]
-        saved = [x] + ys + fins + [params[3 * l] for l in range(L)] + [params[3 * l + 1] for l in range(L)]
+        saved = [feats if lift else x] + ys + fins + [params[3 * l] for l in range(L)] + [params[3 * l + 1] for l in range(L)]
         if ns:
             saved += [out, arg, yraw]
             ctx.mark_non_differentiable(arg)
@@ -246,7 +268,8 @@ class _FusedMLP(Function):
         fins = saved[1 + L:1 + 2 * L]
         Ws = [w.view(w.size(0), w.size(1)) for w in saved[1 + 2 * L:1 + 3 * L]]
         gammas = saved[1 + 3 * L:1 + 4 * L]
-        M = x.size(0)
+        lift = getattr(ctx, "lift", False)            # saved[0] is then the point-major feature tensor, not grouped rows
+        M = ctx.M if lift else x.size(0)
         g_out = g_out.contiguous()
 
         # every zero-initialised accumulator of this backward from one allocation / one fill
@@ -254,8 +277,8 @@ class _FusedMLP(Function):
         # first-layer fold (csrc/mlp_bwd_fused.hip): the layer above the first one reduces gz^T X instead of storing gz
         # when the first layer's input needs no gradient (raw coordinates / colours) and is at most 8 columns wide
         need_dgrad0 = ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None)
-        K0 = x.size(1)
-        fold = (L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0]
+        K0 = ctx.K0 if lift else x.size(1)
+        fold = (L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0] and not lift
                 and not (ctx.pool_fused and L == 2)          # (layer 1 is then the pooled layer: Gram-form kernel)
                 and e.mlp_bwd_fused_fold_supported(Ws[1].size(0), Ws[1].size(1), K0))
         first_free = getattr(ctx, "first_free", False)
@@ -263,7 +286,8 @@ class _FusedMLP(Function):
             raise RuntimeError("fused_mlp: the first layer's output was not stored but the backward cannot fold it")
         arena = e.zero_arena(x.device, [((2, Ws[-1].size(0)), f64)] + [((2, Ws[l].size(1)), f64) for l in range(L)] +
                              [(tuple(Ws[l].shape), f32) for l in range(L)] +
-                             ([((Ws[0].size(0), K0), f32), ((K0 * K0 + K0,), f64)] if fold else []))
+                             ([((Ws[0].size(0), K0), f32), ((K0 * K0 + K0,), f64)] if fold else []) +
+                             ([((Ws[0].size(0), 3), f32)] if lift else []))
         sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:1 + 2 * L]
         if ns:
             pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
@@ -276,6 +300,23 @@ class _FusedMLP(Function):
         grads = [None] * (3 * L)
         gx = None
         for l in range(L - 1, -1, -1):
+            if l == 0 and lift:
+                # first layer applied before the grouping: per-point sums of dL/dy0 through the inverse index, then GEMMs
+                # over the B N points (csrc/group_lift.hip)
+                consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[0], fins[0], ctx.batch_flags[0])
+                grads[1], grads[2] = dgamma, dbeta
+                if gmode != e.PRO_GY:
+                    raise RuntimeError("fused_mlp: the lifted first layer expects the dense gradient of the layer above")
+                xyz, new_xyz, idx, _u, normalize, radius = ctx.group[:6]
+                N0 = Ws[0].size(0)
+                dWx = arena[-1]
+                S = e.group_lift_rows_grad(G, ys[0], consts.contiguous(), xyz, new_xyz, ctx.group[6], idx.size(2), normalize,
+                                           radius, dWx).view(-1, N0)
+                dWf = torch.mm(S.t(), x.view(-1, K0 - 3))
+                grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
+                if need_dgrad0:
+                    gx = torch.mm(S, Ws[0][:, 3:]).view(ctx.feat_shape)
+                continue
             if l == L - 1 and ctx.pool_fused:
                 # pooled layer in Gram form: y_l was never stored (csrc/pool_bwd.hip)
                 consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
@@ -334,7 +375,7 @@ class _FusedMLP(Function):
                     G, gmode, arg, gPm = Gn, e.PRO_GY, None, None
                 else:
                     gx = e.mlp_gemm(G, Wt, pro=gmode, epi=e.EPI_NONE, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns, M=M)
-        if gx is not None and ctx.group is not None:
+        if gx is not None and ctx.group is not None and not lift:
             idx = ctx.group[2]
             Bq, npoint, nsample = idx.shape
             Bf, Nf, Cf = ctx.feat_shape
@@ -344,6 +385,15 @@ class _FusedMLP(Function):
             else:                        # (a segmented call hands in its zero-filled slice of the batch's gradient)
                 gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0, out=getattr(ctx, "gx_out", None))
         return (gx, None, None, None, *grads)
+
+
+def _lift_forward(e, feats, W, group, stats):
+    """y0 (B m ns, N0) of a grouped stack's first layer without the grouped rows: P = f Wf^T over the B N points (a plain
+    fp32 GEMM), then the gather + coordinate terms + column sums in one kernel (pn2_group_lift_rows)."""
+    xyz, new_xyz, idx, _use_xyz, normalize, radius = group[:6]
+    B, N, C = feats.shape
+    P = torch.mm(feats.view(B * N, C), W[:, 3:].t())
+    return e.group_lift_rows(P.view(B, N, -1), xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stats=stats)
 
 
 class _FusedMLPBf16(Function):

@@ -235,6 +235,28 @@ int pn2_group_rows_grad(int B, int N, int m, int ns, int C, int ldg, int col0,
                         const float *grad_out, const int *idx,
                         float *grad_feats, void *stream);
 
+/* The FIRST conv of an SA stack applied before the grouping (round 4, csrc/group_lift.hip).  A 1x1 convolution is linear
+ * and the grouping only copies:  W [rel | f[idx]] = Wx rel + (Wf f)[idx]  — the feature part of the product is taken once
+ * per point (B N rows) instead of once per (centre, sample) position (B m ns rows) and the grouped (B,m,ns,3+C) tensor of
+ * QueryAndGroup (OPS/pointnet2_utils.py:317-328; group_points_kernel EXT/src/group_points_gpu.cu:8-28) never exists.
+ *   pn2_group_lift_rows:      Y[(b m + j) ns + s][0:N0] = P[b, idx[b,j,s]][0:N0] + Wx rel[b,j,s],
+ *       rel = (xyz[b, idx] - new_xyz[b, j]) (/ radius when `normalize`), P (B N, N0) = f Wf^T, Wx (N0, 3);
+ *       stats (2, N0) f64 (may be NULL) += column sums of Y and Y^2 (the layer's BatchNorm batch statistics).
+ *   pn2_group_lift_rows_grad: per row dL/dy0 = c1 g + c2 y0 + c3 (consts (3, N0): BatchNorm's backward from the masked
+ *       gradient G the layer above left and the raw Y0);  S (B N, N0) = its sum over the rows that gathered each point
+ *       (ptr / refs of pn2_group_inverse_index; every row of S written, fixed order),  dWx (N0, 3) += sum_r dL/dy0[r] rel[r]^T
+ *       (fp32 atomics, once per workgroup).  The caller finishes with GEMMs over B N rows: dL/df = S Wf, dWf = S^T f.
+ *       Replaces the first layer's M-row dgrad / wgrad and group_points_grad_kernel (EXT/src/group_points_gpu.cu:44-75).
+ * N0 a multiple of 4 in [16, 256] (pn2_group_lift_supported); P, Y, G, Y0, S, consts 16-byte aligned.
+ * Algorithmic bytes: forward B (4 m ns + 12 N + 12 m + 4 N0 N + 4 N0 m ns); backward 8 M + 8 M N0 + 4 B N (N0 + 4). */
+int pn2_group_lift_supported(int N0);
+int pn2_group_lift_rows(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                        const float *new_xyz, const int *idx, const float *P, const float *Wx, float *Y, double *stats,
+                        void *stream);
+int pn2_group_lift_rows_grad(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                             const float *new_xyz, const float *G, const float *Y0, const float *consts, const int *ptr,
+                             const int *refs, float *S, float *dWx, void *stream);
+
 /* pn2_rows_max / pn2_rows_max_grad: F.max_pool2d(kernel=[1,ns]) of
  *   OPS/pointnet2_modules.py:67-70 in point-major layout.
  *   x (R,ns,C) -> out (R,C), arg (R,C) i32 (first maximal s, like torch's
