@@ -146,9 +146,16 @@ class _FusedMLP(Function):
             if pre is None and len(group) > 8 and group[8] is not None:
                 pre = group[8].view(-1, group[8].size(-1))     # rows the fused query + grouping kernel emitted next to idx
             # first layer before the grouping (LIFT_FIRST): the rows are never formed
+            # ... whenever the backward has (or, for crowded balls, may build) the inverse neighbourhood index it sums
+            # through: the route must not depend on whether the geometry was prefetched (identical results either way)
+            has_inv = len(group) > 6 and group[6] is not None
+            crowded = len(group) > 7 and bool(group[7])
             lift = bool(LIFT_FIRST and pre is None and x is not None and use_xyz and L >= 2 and x.size(2) >= 16
                         and getattr(e, "group_lift_rows", None) and e.group_lift_supported(layers[0][0].out_channels)
-                        and (not any(ctx.needs_input_grad) or (len(group) > 6 and group[6] is not None)))
+                        and (not any(ctx.needs_input_grad) or has_inv or crowded))
+            ctx.lift_inv = None
+            if lift and any(ctx.needs_input_grad) and not has_inv:
+                ctx.lift_inv = tuple(e.group_inverse_index(idx, xyz.size(1)))      # (not prefetched: built here)
             if lift:
                 feats = x.contiguous()
                 M, K0 = idx.numel(), 3 + feats.size(2)
@@ -310,7 +317,8 @@ class _FusedMLP(Function):
                 xyz, new_xyz, idx, _u, normalize, radius = ctx.group[:6]
                 N0 = Ws[0].size(0)
                 dWx = arena[-1]
-                S = e.group_lift_rows_grad(G, ys[0], consts.contiguous(), xyz, new_xyz, ctx.group[6], idx.size(2), normalize,
+                inv = ctx.group[6] if (len(ctx.group) > 6 and ctx.group[6] is not None) else ctx.lift_inv
+                S = e.group_lift_rows_grad(G, ys[0], consts.contiguous(), xyz, new_xyz, inv, idx.size(2), normalize,
                                            radius, dWx).view(-1, N0)
                 dWf = torch.mm(S.t(), x.view(-1, K0 - 3))
                 grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
@@ -392,7 +400,8 @@ def _lift_forward(e, feats, W, group, stats):
     fp32 GEMM), then the gather + coordinate terms + column sums in one kernel (pn2_group_lift_rows)."""
     xyz, new_xyz, idx, _use_xyz, normalize, radius = group[:6]
     B, N, C = feats.shape
-    P = torch.mm(feats.view(B * N, C), W[:, 3:].t())
+    # (the library's own fp32-MFMA GEMM: bit-reproducible from call to call, which a vendor GEMM's kernel choice is not)
+    P = e.mlp_gemm(feats.view(B * N, C), W[:, 3:].contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE)
     return e.group_lift_rows(P.view(B, N, -1), xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stats=stats)
 
 

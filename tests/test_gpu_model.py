@@ -110,13 +110,13 @@ def test_msg_encoder_gpu_matches_golden_fixture():
 
 def test_precomputed_geometry_on_a_side_stream_gives_identical_results(monkeypatch):
     """Backbone.precompute_geometry (run on another stream) + forward(geometry=...) == plain forward; the prefetched
-    geometry carries the inverse neighbourhood index of the crowded levels and the backward then uses the atomic-free
-    per-point sum (csrc/group_csr.hip)."""
+    geometry carries the inverse neighbourhood index of the crowded levels, through which the backward of their lifted
+    first layers sums per point (csrc/group_lift.hip; without a prefetched geometry the index is built in the step)."""
     from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
     from pointnet2_ops import _ext
     csr_calls = []
-    real_csr = _ext.group_rows_grad_csr
-    monkeypatch.setattr(_ext, "group_rows_grad_csr", lambda *a, **k: (csr_calls.append(1), real_csr(*a, **k))[1])
+    real_csr = _ext.group_lift_rows_grad
+    monkeypatch.setattr(_ext, "group_lift_rows_grad", lambda *a, **k: (csr_calls.append(1), real_csr(*a, **k))[1])
     torch.manual_seed(5)
     net = Pointnet2Backbone(input_feature_dim=3).cuda().eval()
     g = torch.Generator().manual_seed(6)
@@ -138,12 +138,12 @@ def test_precomputed_geometry_on_a_side_stream_gives_identical_results(monkeypat
     net.train()
     a = net(pc)["fp2_features"].square().mean()
     a.backward()
+    assert len(csr_calls) == 3                                    # SA2, SA3, SA4: per-point sums, index built in the step
     g0 = [p.grad.clone() for p in net.parameters()]
     net.zero_grad()
     b = net(pc, geometry=geo)["fp2_features"].square().mean()
-    assert not csr_calls
     b.backward()
-    assert len(csr_calls) == 3                                    # SA2, SA3, SA4 feature gradients
+    assert len(csr_calls) == 6                                    # ... and through the prefetched index
     assert abs(float(a.detach()) - float(b.detach())) < 1e-6
     for x, y in zip(g0, [p.grad for p in net.parameters()]):     # two train-mode runs: atomics-order noise only
         assert float((x - y).norm()) <= 2e-2 * float(x.norm()) + 1e-6
