@@ -14,8 +14,8 @@
 //   backward: dL/dy0 = c1 g + c2 y0 + c3 per row (BatchNorm backward of layer 0, from the masked gradient g the layer above
 //             left).  Its sum over the rows that gathered point (b, n) — S[b, n, :], walked through the inverse
 //             neighbourhood index of group_csr.hip — is all the feature side needs:  dL/df = S Wf,  dWf = S^T f (GEMMs over
-//             B N rows), and the coordinate columns  dWx = sum_r dL/dy0[r] rel[r]^T  are accumulated in the same walk
-//             (pn2_group_lift_rows_grad).  The atomic scatter of group_points_grad_kernel (EXT/src/group_points_gpu.cu:44-75),
+//             B N rows); S and the coordinate columns  dWx = sum_r dL/dy0[r] rel[r]^T  follow from four sums over the rows
+//             that do not involve the constants (pn2_group_lift_rows_grad: Sg, SR, Dg, RR, see the kernel).  The atomic scatter of group_points_grad_kernel (EXT/src/group_points_gpu.cu:44-75),
 //             the M x (3 + C) input gradient and the M-row weight-gradient GEMM disappear.
 // Arithmetic: y0 = fma(Wx2, rz, fma(Wx1, ry, fma(Wx0, rx, P))) in fp32 — the same real number as the reference's 3 + C term
 // dot product, summed in another order (tested at 1e-4 against the oracle like every MLP kernel).
@@ -140,89 +140,136 @@ struct LiftBwdArgs {
   const float *xyz;      // (B, N, 3)
   const float *new_xyz;  // (B m, 3)
   const float *G;        // (M, N0)  masked gradient dL/dz0 the layer above left
-  const float *Y0;       // (M, N0)  raw first-layer output
+  const float *P;        // (B N, N0) per-point products of the forward
+  const float *Wx;       // (N0, 3)
   const float *consts;   // (3, N0)  c1 | c2 | c3 of BatchNorm's backward
   const int *ptr;        // (B N + 1)
   const int *refs;       // (M)      row ids sorted by (point, row)
-  float *S;              // (B N, N0)
-  float *dWx;            // (N0, 3)  += (fp32 atomics, once per workgroup)
+  float *S;              // (B N, N0)  sum_r dL/dy0[r] over the rows that gathered the point
+  float *part;           // (workgroups of both passes, 3 N0 + 16) per-workgroup partials of dWx | RR (summed by lift_reduce_kernel:
+                         //          same-address atomics from 3 000 workgroups finishing together cost more than the walk)
+  int *heavy;            // [0] = number of heavy points (zero on entry), [1 ..] their ids
   int ns, N0, normalize;
   float radius;
   unsigned npoints;
 };
 
-// A wave per point (like group_rows_grad_csr_kernel): R sub-waves walk the point's rows R at a time, two 16-byte loads
-// (g, y0) per row and lane, four rows in flight.
+constexpr int kLiftHeavy = 192;     // a point gathered by more rows than this is walked by kLiftSplit waves in a second pass
+constexpr int kLiftSplit = 16;
+
+// wave-wide sum on the DPP network; every lane returns the total
+__device__ __forceinline__ float lift_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+  return pn2_readlane_f32(v, 63);
+}
+
+// The backward behind BatchNorm is AFFINE in the rows: dL/dy0[r] = c1 g[r] + c2 y0[r] + c3 with y0[r] = P[point] + Wx rel[r],
+// so the per-channel constants stay OUT of the walk over the rows (the first version carried them, Wx and P through the
+// loop: 118 VGPRs, four waves per SIMD).  Per point p with rows r:
+//     S[p]  = sum_r dL/dy0[r]          = c1 Sg + n (c2 P[p] + c3) + c2 Wx SR         Sg = sum_r g[r], SR = sum_r rel[r], n = rows
+//     dWx   = sum_r dL/dy0[r] rel[r]^T = c1 Dg + sum_p (c2 P[p] + c3) SR[p]^T + c2 Wx RR,   Dg = sum_r g[r] rel[r]^T, RR = sum_r rel rel^T
+// The loop sums g, rel and g rel^T; the constants enter once per point (S, the second term of dWx) and once per wave (c1 Dg);
+// RR is returned and the caller adds c2 Wx RR.  Both formulas are linear in (Sg, n, SR): a slice of a point's rows can be
+// finished on its own and ADDED — which is how heavy points are handled: ball queries return the first nsample hits in
+// index order, so with large radii (SA3 / SA4: r 0.8 / 1.2) the lowest indices of a cloud sit in nearly every ball — 500
+// rows on one point, none on most — and a wave per point leaves the kernel waiting for a few long serial walks (0.25 ms
+// for 77 MB).  Points with more than kLiftHeavy rows are only listed by the first pass (their S row zeroed) and walked by
+// kLiftSplit waves each in the second.
 template <int R>
-__global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_kernel(const LiftBwdArgs a) {
+__device__ __forceinline__ void lift_walk(const LiftBwdArgs &a, unsigned n, int p0, int p1, bool add, f4v &dx, f4v &dy, f4v &dz,
+                                          f4v &ex_, f4v &ey_, f4v &ez_, float (&rr)[6]) {
   constexpr int LPR = 64 / R;
-  __shared__ float red[3][4][4 * LPR];
-  const int lane = pn2_lane(), wv = threadIdx.x >> 6;
+  const int lane = pn2_lane();
   const int sub = lane / LPR, l = lane % LPR;
   const int N0 = a.N0, ns = a.ns;
   const bool live = 4 * l < N0;
-  f4v c1 = f4v{0.f, 0.f, 0.f, 0.f}, c2 = c1, c3 = c1;
-  if (live) {
-    c1 = *reinterpret_cast<const f4v *>(a.consts + 4 * l);
-    c2 = *reinterpret_cast<const f4v *>(a.consts + N0 + 4 * l);
-    c3 = *reinterpret_cast<const f4v *>(a.consts + 2 * N0 + 4 * l);
-  }
-  f4v dx = f4v{0.f, 0.f, 0.f, 0.f}, dy = dx, dz = dx;            // coordinate columns, summed over this wave's points
-  const unsigned nwaves = gridDim.x * (kLiftBlock / 64);
-  for (unsigned n = __builtin_amdgcn_readfirstlane(blockIdx.x * (kLiftBlock / 64) + wv); n < a.npoints; n += nwaves) {
-    const int p0 = a.ptr[n], p1 = a.ptr[n + 1];
-    const float px = a.xyz[(size_t)n * 3 + 0], py = a.xyz[(size_t)n * 3 + 1], pz = a.xyz[(size_t)n * 3 + 2];
-    f4v acc = f4v{0.f, 0.f, 0.f, 0.f};
-    for (int base = p0; base < p1; base += 64) {
-      const int cnt = p1 - base < 64 ? p1 - base : 64;
-      int myref = 0;
-      float rx = 0.f, ry = 0.f, rz = 0.f;
-      if (lane < cnt) {
-        myref = a.refs[base + lane];
-        const Row3f q = *reinterpret_cast<const Row3f *>(a.new_xyz + (size_t)((unsigned)myref / (unsigned)ns) * 3);
-        rx = px - q.a; ry = py - q.b; rz = pz - q.c;              // the forward's relative coordinates, bit for bit
-        if (a.normalize) { rx = __fdiv_rn(rx, a.radius); ry = __fdiv_rn(ry, a.radius); rz = __fdiv_rn(rz, a.radius); }
+  const float px = a.xyz[(size_t)n * 3 + 0], py = a.xyz[(size_t)n * 3 + 1], pz = a.xyz[(size_t)n * 3 + 2];
+  f4v acc = f4v{0.f, 0.f, 0.f, 0.f};
+  float srx = 0.f, sry = 0.f, srz = 0.f;                       // per-lane partials of SR
+  for (int base = p0; base < p1; base += 64) {
+    const int cnt = p1 - base < 64 ? p1 - base : 64;
+    int myref = 0;
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (lane < cnt) {
+      myref = a.refs[base + lane];
+      const Row3f q = *reinterpret_cast<const Row3f *>(a.new_xyz + (size_t)((unsigned)myref / (unsigned)ns) * 3);
+      rx = px - q.a; ry = py - q.b; rz = pz - q.c;              // the forward's relative coordinates, bit for bit
+      if (a.normalize) { rx = __fdiv_rn(rx, a.radius); ry = __fdiv_rn(ry, a.radius); rz = __fdiv_rn(rz, a.radius); }
+      srx += rx; sry += ry; srz += rz;
+      rr[0] = __fmaf_rn(rx, rx, rr[0]); rr[1] = __fmaf_rn(rx, ry, rr[1]); rr[2] = __fmaf_rn(rx, rz, rr[2]);
+      rr[3] = __fmaf_rn(ry, ry, rr[3]); rr[4] = __fmaf_rn(ry, rz, rr[4]); rr[5] = __fmaf_rn(rz, rz, rr[5]);
+    }
+    for (int t = 0; t * R < cnt; t += 4) {
+      f4v g[4];
+      float ex[4], ey[4], ez[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = (t + u) * R + sub;
+        const int src = i & 63;
+        const int r = __shfl(myref, src);
+        ex[u] = __shfl(rx, src); ey[u] = __shfl(ry, src); ez[u] = __shfl(rz, src);   // (0 beyond cnt: those rows add nothing)
+        g[u] = f4v{0.f, 0.f, 0.f, 0.f};
+        if (i < cnt && live) g[u] = *reinterpret_cast<const f4v *>(a.G + (size_t)r * N0 + 4 * l);
       }
-      for (int t = 0; t * R < cnt; t += 4) {
-        f4v g[4], y[4];
-        float ex[4], ey[4], ez[4];
-        bool ok[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = (t + u) * R + sub;
-          const int src = i & 63;
-          const int r = __shfl(myref, src);
-          ex[u] = __shfl(rx, src); ey[u] = __shfl(ry, src); ez[u] = __shfl(rz, src);
-          ok[u] = i < cnt && live;
-          g[u] = f4v{0.f, 0.f, 0.f, 0.f};
-          y[u] = g[u];
-          if (ok[u]) {
-            g[u] = *reinterpret_cast<const f4v *>(a.G + (size_t)r * N0 + 4 * l);
-            y[u] = *reinterpret_cast<const f4v *>(a.Y0 + (size_t)r * N0 + 4 * l);
-          }
-        }
+      for (int u = 0; u < 4; ++u) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (!ok[u]) continue;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float gy = __fmaf_rn(c1[c], g[u][c], __fmaf_rn(c2[c], y[u][c], c3[c]));
-            acc[c] = __fadd_rn(acc[c], gy);
-            dx[c] = __fmaf_rn(gy, ex[u], dx[c]);
-            dy[c] = __fmaf_rn(gy, ey[u], dy[c]);
-            dz[c] = __fmaf_rn(gy, ez[u], dz[c]);
-          }
+        for (int c = 0; c < 4; ++c) {
+          acc[c] = __fadd_rn(acc[c], g[u][c]);
+          dx[c] = __fmaf_rn(g[u][c], ex[u], dx[c]);
+          dy[c] = __fmaf_rn(g[u][c], ey[u], dy[c]);
+          dz[c] = __fmaf_rn(g[u][c], ez[u], dz[c]);
         }
       }
     }
-#pragma unroll
-    for (int d = 32; d >= LPR; d >>= 1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = __fadd_rn(acc[c], __shfl_xor(acc[c], d));
-    }
-    if (sub == 0 && live) *reinterpret_cast<f4v *>(a.S + (size_t)n * N0 + 4 * l) = acc;
   }
-  // coordinate columns: sub-waves -> waves (LDS) -> one fp32 atomic per entry and workgroup
+#pragma unroll
+  for (int d = 32; d >= LPR; d >>= 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = __fadd_rn(acc[c], __shfl_xor(acc[c], d));
+  }
+  const float tx = lift_wave_sum(srx), ty = lift_wave_sum(sry), tz = lift_wave_sum(srz);
+  const float cnt_f = (float)(p1 - p0);
+  // the constants enter here, once per point (short live ranges: the loop above does not carry them)
+  if (sub == 0 && live) {
+    const f4v c1 = *reinterpret_cast<const f4v *>(a.consts + 4 * l);
+    const f4v c2 = *reinterpret_cast<const f4v *>(a.consts + N0 + 4 * l);
+    const f4v c3 = *reinterpret_cast<const f4v *>(a.consts + 2 * N0 + 4 * l);
+    const f4v pp = *reinterpret_cast<const f4v *>(a.P + (size_t)n * N0 + 4 * l);
+    f4v sv;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float A = __fmaf_rn(c2[c], pp[c], c3[c]);                        // c2 P[p] + c3
+      const float w0 = a.Wx[(size_t)(4 * l + c) * 3 + 0], w1 = a.Wx[(size_t)(4 * l + c) * 3 + 1],
+                  w2 = a.Wx[(size_t)(4 * l + c) * 3 + 2];
+      const float wsr = __fmaf_rn(w2, tz, __fmaf_rn(w1, ty, w0 * tx));       // Wx SR
+      sv[c] = __fmaf_rn(c1[c], acc[c], __fmaf_rn(cnt_f, A, c2[c] * wsr));
+      ex_[c] = __fmaf_rn(A, tx, ex_[c]); ey_[c] = __fmaf_rn(A, ty, ey_[c]); ez_[c] = __fmaf_rn(A, tz, ez_[c]);
+    }
+    float *dst = a.S + (size_t)n * N0 + 4 * l;
+    if (add) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) atomicAdd(dst + c, sv[c]);
+    } else {
+      *reinterpret_cast<f4v *>(dst) = sv;
+    }
+  }
+}
+
+// flush of a wave's coordinate-column accumulators: c1 Dg + E and RR, sub-waves -> waves through LDS -> this workgroup's row
+// of the partials buffer
+template <int R>
+__device__ __forceinline__ void lift_flush(const LiftBwdArgs &a, unsigned row, f4v dx, f4v dy, f4v dz, f4v ex_, f4v ey_, f4v ez_,
+                                           const float (&rr)[6], float (*red)[4][256], float (*rrs)[16]) {
+  constexpr int LPR = 64 / R;
+  const int lane = pn2_lane(), wv = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const int N0 = a.N0;
 #pragma unroll
   for (int d = 32; d >= LPR; d >>= 1) {
 #pragma unroll
@@ -233,15 +280,91 @@ __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_kernel(const 
     }
   }
   if (sub == 0) {
+    f4v c1 = f4v{0.f, 0.f, 0.f, 0.f};
+    if (4 * l < N0) c1 = *reinterpret_cast<const f4v *>(a.consts + 4 * l);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { red[0][wv][4 * l + c] = dx[c]; red[1][wv][4 * l + c] = dy[c]; red[2][wv][4 * l + c] = dz[c]; }
+    for (int c = 0; c < 4; ++c) {      // (E lives in the sub == 0 lanes only)
+      red[0][wv][4 * l + c] = __fmaf_rn(c1[c], dx[c], ex_[c]);
+      red[1][wv][4 * l + c] = __fmaf_rn(c1[c], dy[c], ey_[c]);
+      red[2][wv][4 * l + c] = __fmaf_rn(c1[c], dz[c], ez_[c]);
+    }
+  }
+  {
+    const float t0 = lift_wave_sum(rr[0]), t1 = lift_wave_sum(rr[1]), t2 = lift_wave_sum(rr[2]);
+    const float t3 = lift_wave_sum(rr[3]), t4 = lift_wave_sum(rr[4]), t5 = lift_wave_sum(rr[5]);
+    // the full symmetric 3 x 3 matrix, row-major: xx xy xz | xy yy yz | xz yz zz
+    if (lane < 9)
+      rrs[wv][lane] = (lane == 0) ? t0 : (lane == 1 || lane == 3) ? t1 : (lane == 2 || lane == 6) ? t2 : (lane == 4) ? t3
+                      : (lane == 5 || lane == 7) ? t4 : t5;
   }
   __syncthreads();
+  float *prow = a.part + (size_t)row * (3 * N0 + 16);
   for (int e = threadIdx.x; e < 3 * N0; e += kLiftBlock) {
     const int d = e / N0, col = e % N0;
-    const float t = (red[d][0][col] + red[d][1][col]) + (red[d][2][col] + red[d][3][col]);
-    atomicAdd(a.dWx + (size_t)col * 3 + d, t);
+    prow[col * 3 + d] = (red[d][0][col] + red[d][1][col]) + (red[d][2][col] + red[d][3][col]);
   }
+  if (threadIdx.x < 9) prow[3 * N0 + threadIdx.x] = (rrs[0][threadIdx.x] + rrs[1][threadIdx.x]) + (rrs[2][threadIdx.x] + rrs[3][threadIdx.x]);
+}
+
+// column sums of the partials: out[0 : 3 N0] = dWx (without c2 Wx RR), out[3 N0 : 3 N0 + 9] = RR; fixed order
+__global__ __launch_bounds__(256) void lift_reduce_kernel(const float *__restrict__ part, int rows, int width, int pitch,
+                                                         float *__restrict__ out) {
+  __shared__ float red[256];
+  const int col = blockIdx.x;
+  float t = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) t += part[(size_t)r * pitch + col];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && col < width) out[col] = red[0];
+}
+
+// pass 1: a wave per point (like group_rows_grad_csr_kernel); heavy points are listed, their S row zeroed
+template <int R>
+__global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_kernel(const LiftBwdArgs a) {
+  constexpr int LPR = 64 / R;
+  __shared__ float red[3][4][256];
+  __shared__ float rrs[4][16];
+  const int lane = pn2_lane(), wv = threadIdx.x >> 6;
+  f4v dx = f4v{0.f, 0.f, 0.f, 0.f}, dy = dx, dz = dx, ex_ = dx, ey_ = dx, ez_ = dx;
+  float rr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const unsigned nwaves = gridDim.x * (kLiftBlock / 64);
+  for (unsigned n = __builtin_amdgcn_readfirstlane(blockIdx.x * (kLiftBlock / 64) + wv); n < a.npoints; n += nwaves) {
+    const int p0 = a.ptr[n], p1 = a.ptr[n + 1];
+    if (p1 - p0 > kLiftHeavy) {                                   // wave-uniform
+      if (lane == 0) a.heavy[1 + atomicAdd(a.heavy, 1)] = (int)n;
+      const int l = lane % LPR;
+      if (lane < LPR && 4 * l < a.N0) *reinterpret_cast<f4v *>(a.S + (size_t)n * a.N0 + 4 * l) = f4v{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    lift_walk<R>(a, n, p0, p1, false, dx, dy, dz, ex_, ey_, ez_, rr);
+  }
+  lift_flush<R>(a, blockIdx.x, dx, dy, dz, ex_, ey_, ez_, rr, red, rrs);
+}
+
+// pass 2: kLiftSplit waves per heavy point, each a contiguous slice of its rows, results added
+template <int R>
+__global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_heavy_kernel(const LiftBwdArgs a, unsigned row0) {
+  __shared__ float red[3][4][256];
+  __shared__ float rrs[4][16];
+  const int wv = threadIdx.x >> 6;
+  f4v dx = f4v{0.f, 0.f, 0.f, 0.f}, dy = dx, dz = dx, ex_ = dx, ey_ = dx, ez_ = dx;
+  float rr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const unsigned nwaves = gridDim.x * (kLiftBlock / 64);
+  const unsigned items = (unsigned)a.heavy[0] * kLiftSplit;
+  for (unsigned w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kLiftBlock / 64) + wv); w < items; w += nwaves) {
+    const unsigned n = (unsigned)a.heavy[1 + w / kLiftSplit];
+    const int k = (int)(w % kLiftSplit);
+    const int p0 = a.ptr[n], p1 = a.ptr[n + 1];
+    const int per = ((p1 - p0 + kLiftSplit - 1) / kLiftSplit + 63) & ~63;     // slices of whole 64-row batches
+    const int q0 = p0 + k * per, q1 = q0 + per < p1 ? q0 + per : p1;
+    if (q0 >= p1) continue;
+    lift_walk<R>(a, n, q0, q1, true, dx, dy, dz, ex_, ey_, ez_, rr);
+  }
+  lift_flush<R>(a, row0 + blockIdx.x, dx, dy, dz, ex_, ey_, ez_, rr, red, rrs);
 }
 
 bool lift_shape_ok(int N0) { return N0 >= 16 && N0 <= 256 && (N0 & 3) == 0; }
@@ -262,8 +385,10 @@ extern "C" int pn2_group_lift_rows(int B, int N, int m, int ns, int N0, int norm
   LiftFwdArgs a{xyz, new_xyz, idx, P, Wx, Y, stats, N, m, ns, N0, normalize ? 1 : 0, radius, (int)centres,
                 (int)((centres + 3) / 4)};
   // persistent grid: 8 XCD shares x up to 256 workgroups, every workgroup flushes its column sums once
+  // ... and at least four chunks (16 centres) per workgroup: the flush is 2 N0 fp64 atomics onto the same addresses
   const int per = (a.chunks + 7) / 8;
-  const int nwg = per < 256 ? per : 256;
+  int nwg = (per + 3) / 4;
+  nwg = nwg < 1 ? 1 : (nwg > 256 ? 256 : nwg);
   const dim3 grid((unsigned)(nwg * 8)), block(kLiftBlock);
   hipStream_t s = (hipStream_t)stream;
   if (N0 <= 64) hipLaunchKernelGGL(group_lift_rows_kernel<4>, grid, block, 0, s, a);
@@ -272,23 +397,50 @@ extern "C" int pn2_group_lift_rows(int B, int N, int m, int ns, int N0, int norm
   return pn2_check_launch();
 }
 
+namespace {
+constexpr unsigned kLiftGrid2 = 512;      // workgroups of the heavy pass: 2048 waves = 128 heavy points at a time
+unsigned lift_grid1(size_t npoints) {
+  const unsigned waves_wanted = 256u * 32u;
+  unsigned grid = (unsigned)((npoints < waves_wanted ? npoints : waves_wanted) + 3) / 4;
+  return grid == 0 ? 1 : grid;
+}
+size_t lift_heavy_bytes(int B, int m, int ns) {
+  const size_t M = (size_t)B * m * ns;
+  return ((M / kLiftHeavy + 2) * sizeof(int) + 255) & ~(size_t)255;     // a point is heavy with more than kLiftHeavy rows
+}
+}  // namespace
+
+extern "C" size_t pn2_group_lift_rows_grad_workspace_bytes(int B, int N, int m, int ns, int N0) {
+  if (B <= 0 || N <= 0 || m <= 0 || ns <= 0 || !lift_shape_ok(N0)) return 0;
+  return lift_heavy_bytes(B, m, ns) + (size_t)(lift_grid1((size_t)B * N) + kLiftGrid2) * (3 * N0 + 16) * sizeof(float);
+}
+
 extern "C" int pn2_group_lift_rows_grad(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
-                                        const float *new_xyz, const float *G, const float *Y0, const float *consts,
-                                        const int *ptr, const int *refs, float *S, float *dWx, void *stream) {
+                                        const float *new_xyz, const float *G, const float *P, const float *Wx,
+                                        const float *consts, const int *ptr, const int *refs, float *S, float *acc,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
   if (B < 0 || N < 0 || m < 0 || ns <= 0) return PN2_EINVAL;
   if (!lift_shape_ok(N0) || (normalize && !(radius > 0.f))) return PN2_EINVAL;
   const size_t npoints = (size_t)B * N;
   if (npoints == 0) return PN2_OK;
   if (npoints >= 0x7fffffffull || (long long)B * m * ns >= 0x7fffffffLL) return PN2_EINVAL;
-  if (!xyz || !new_xyz || !G || !Y0 || !consts || !ptr || !refs || !S || !dWx) return PN2_ENULL;
-  if ((((uintptr_t)G) | ((uintptr_t)Y0) | ((uintptr_t)S) | ((uintptr_t)consts)) & 15) return PN2_EINVAL;
-  LiftBwdArgs a{xyz, new_xyz, G, Y0, consts, ptr, refs, S, dWx, ns, N0, normalize ? 1 : 0, radius, (unsigned)npoints};
-  const unsigned waves_wanted = 256u * 32u;
-  unsigned grid = (unsigned)((npoints < waves_wanted ? npoints : waves_wanted) + 3) / 4;
-  if (grid == 0) grid = 1;
+  if (!xyz || !new_xyz || !G || !P || !Wx || !consts || !ptr || !refs || !S || !acc || !workspace) return PN2_ENULL;
+  if ((((uintptr_t)G) | ((uintptr_t)P) | ((uintptr_t)S) | ((uintptr_t)consts) | ((uintptr_t)workspace)) & 15) return PN2_EINVAL;
+  if (workspace_bytes < pn2_group_lift_rows_grad_workspace_bytes(B, N, m, ns, N0)) return PN2_ENOSPC;
   hipStream_t s = (hipStream_t)stream;
-  if (N0 <= 64) hipLaunchKernelGGL(group_lift_rows_grad_kernel<4>, dim3(grid), dim3(kLiftBlock), 0, s, a);
-  else if (N0 <= 128) hipLaunchKernelGGL(group_lift_rows_grad_kernel<2>, dim3(grid), dim3(kLiftBlock), 0, s, a);
-  else hipLaunchKernelGGL(group_lift_rows_grad_kernel<1>, dim3(grid), dim3(kLiftBlock), 0, s, a);
+  if (hipMemsetAsync(workspace, 0, sizeof(int), s) != hipSuccess) return PN2_ELAUNCH;
+  float *part = (float *)((char *)workspace + lift_heavy_bytes(B, m, ns));
+  LiftBwdArgs a{xyz, new_xyz, G, P, Wx, consts, ptr, refs, S, part, (int *)workspace, ns, N0, normalize ? 1 : 0, radius,
+                (unsigned)npoints};
+  const unsigned grid = lift_grid1(npoints);
+#define PN2_LIFT(RR_)                                                                                                  \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL(group_lift_rows_grad_kernel<RR_>, dim3(grid), dim3(kLiftBlock), 0, s, a);                       \
+    hipLaunchKernelGGL(group_lift_rows_grad_heavy_kernel<RR_>, dim3(kLiftGrid2), dim3(kLiftBlock), 0, s, a, grid);     \
+  } while (0)
+  if (N0 <= 64) PN2_LIFT(4); else if (N0 <= 128) PN2_LIFT(2); else PN2_LIFT(1);
+#undef PN2_LIFT
+  hipLaunchKernelGGL(lift_reduce_kernel, dim3((unsigned)(3 * N0 + 9)), dim3(256), 0, s, part, (int)(grid + kLiftGrid2),
+                     3 * N0 + 9, 3 * N0 + 16, acc);
   return pn2_check_launch();
 }

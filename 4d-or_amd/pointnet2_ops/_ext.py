@@ -67,7 +67,7 @@ _SIGNATURES = {
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
     "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_lift_rows": [_c_int] * 6 + [_c_f32] + [_c_vp] * 8,
-    "pn2_group_lift_rows_grad": [_c_int] * 6 + [_c_f32] + [_c_vp] * 10,
+    "pn2_group_lift_rows_grad": [_c_int] * 6 + [_c_f32] + [_c_vp] * 11 + [_c_sz, _c_vp],
     "pn2_group_rows_grad_csr_bf16": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_rows_grad_bf16": [_c_int] * 7 + [_c_vp] * 4,
     "pn2_rows_max": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -157,6 +157,8 @@ _lib.pn2_ball_query_auto.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int]
 _lib.pn2_ball_query_auto.restype = _c_int
 _lib.pn2_group_lift_supported.argtypes = [_c_int]
 _lib.pn2_group_lift_supported.restype = _c_int
+_lib.pn2_group_lift_rows_grad_workspace_bytes.argtypes = [_c_int] * 5
+_lib.pn2_group_lift_rows_grad_workspace_bytes.restype = _c_sz
 _lib.pn2_ball_query_group_supported.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_int, _c_int]
 _lib.pn2_ball_query_group_supported.restype = _c_int
 _lib.pn2_ball_query_group_workspace_bytes.argtypes = [_c_int, _c_int]
@@ -208,7 +210,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_ball_query_group_supported", "pn2_ball_query_group_workspace_bytes",
-                                               "pn2_group_lift_supported",
+                                               "pn2_group_lift_supported", "pn2_group_lift_rows_grad_workspace_bytes",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
@@ -713,27 +715,29 @@ def group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, radius, stats=None):
     return Y
 
 
-def group_lift_rows_grad(G, Y0, consts, xyz, new_xyz, inv, ns, normalize, radius, dWx):
-    """Backward of group_lift_rows behind a BatchNorm: per row dL/dy0 = c1 g + c2 y0 + c3 (consts (3,N0)); ->
-    S (B,N,N0) = its sum over the rows that gathered each point (inverse index `inv` = (ptr, refs)); `dWx` (N0,3) +=
-    sum_r dL/dy0[r] rel[r]^T.  Replaces the first layer's M-row dgrad / wgrad GEMMs and group_points_grad_kernel
-    (EXT/src/group_points_gpu.cu:44-75)."""
-    _f32(G, "G"); _f32(Y0, "Y0"); _f32(consts, "consts"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(dWx, "dWx")
+def group_lift_rows_grad(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, radius, acc):
+    """Backward of group_lift_rows behind a BatchNorm (include/pn2_hip.h): G (M,N0) masked gradient of the layer above, P
+    (B,N,N0) / Wx (N0,3) of the forward, consts (3,N0), inv = (ptr, refs) -> S (B,N,N0) = sum over the rows that gathered each
+    point of dL/dy0 = c1 g + c2 y0 + c3;  `acc` (3*N0 + 9) f32 <- [dWx (N0,3) without its c2 Wx RR term | RR (3,3)]."""
+    _f32(G, "G"); _f32(P, "P"); _f32(Wx, "Wx"); _f32(consts, "consts"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(acc, "acc")
     ptr, refs = inv
     _i32(ptr, "ptr"); _i32(refs, "refs")
-    _same_device((G, "G"), (Y0, "Y0"), (consts, "consts"), (xyz, "xyz"), (new_xyz, "new_xyz"), (ptr, "ptr"), (refs, "refs"),
-                 (dWx, "dWx"))
+    _same_device((G, "G"), (P, "P"), (Wx, "Wx"), (consts, "consts"), (xyz, "xyz"), (new_xyz, "new_xyz"), (ptr, "ptr"),
+                 (refs, "refs"), (acc, "acc"))
     B, N = xyz.size(0), xyz.size(1)
     m = new_xyz.size(1)
     M, N0 = G.shape
     ns = int(ns)
-    if (tuple(Y0.shape) != (M, N0) or M != B * m * ns or ptr.numel() != B * N + 1 or refs.numel() != M
-            or tuple(consts.shape) != (3, N0) or tuple(dWx.shape) != (N0, 3)):
+    if (P.numel() != B * N * N0 or M != B * m * ns or ptr.numel() != B * N + 1 or refs.numel() != M
+            or tuple(consts.shape) != (3, N0) or tuple(Wx.shape) != (N0, 3) or acc.numel() != 3 * N0 + 9):
         _fail("group_lift_rows_grad: shapes do not belong to one SA level")
     S = torch.empty(B, N, N0, dtype=torch.float32, device=G.device)
+    ws_bytes = int(_lib.pn2_group_lift_rows_grad_workspace_bytes(B, N, m, ns, N0))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
     _call("pn2_group_lift_rows_grad", G, B, N, m, ns, N0, int(bool(normalize)), float(radius if radius is not None else 1.0),
-          _ptr(xyz), _ptr(new_xyz), _ptr(G), _ptr(Y0), _ptr(consts), _ptr(ptr), _ptr(refs), _ptr(S), _ptr(dWx),
-          alg_bytes=8 * M + 8 * M * N0 + 4 * B * N * (N0 + 4) + 12 * B * m)
+          _ptr(xyz), _ptr(new_xyz), _ptr(G), _ptr(P), _ptr(Wx), _ptr(consts), _ptr(ptr), _ptr(refs), _ptr(S),
+          _ptr(acc), _ptr(ws), ws_bytes,
+          alg_bytes=8 * M + 4 * M * N0 + 4 * B * N * (2 * N0 + 4) + 12 * B * m)
     return S
 
 

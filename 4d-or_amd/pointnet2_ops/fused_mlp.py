@@ -206,7 +206,7 @@ class _FusedMLP(Function):
             if use_batch:
                 stats = stat_bufs[l]
                 if lift and l == 0:
-                    y = _lift_forward(e, feats, W, group, stats)
+                    y, ctx.lift_P = _lift_forward(e, feats, W, group, stats)
                 elif first_free and l == 0:
                     y = None
                     e.first_layer_stats(W.contiguous(), gram, stats)
@@ -229,7 +229,7 @@ class _FusedMLP(Function):
                 fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt, out=None if fo is None else fo[l])
             else:
                 if lift and l == 0:
-                    y = _lift_forward(e, feats, W, group, None)
+                    y, ctx.lift_P = _lift_forward(e, feats, W, group, None)
                 elif first_free and l == 0:
                     y = None
                 elif first_free and l == 1:
@@ -294,7 +294,7 @@ class _FusedMLP(Function):
         arena = e.zero_arena(x.device, [((2, Ws[-1].size(0)), f64)] + [((2, Ws[l].size(1)), f64) for l in range(L)] +
                              [(tuple(Ws[l].shape), f32) for l in range(L)] +
                              ([((Ws[0].size(0), K0), f32), ((K0 * K0 + K0,), f64)] if fold else []) +
-                             ([((Ws[0].size(0), 3), f32)] if lift else []))
+                             ([((3 * Ws[0].size(0) + 9,), f32)] if lift else []))
         sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:1 + 2 * L]
         if ns:
             pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
@@ -316,10 +316,13 @@ class _FusedMLP(Function):
                     raise RuntimeError("fused_mlp: the lifted first layer expects the dense gradient of the layer above")
                 xyz, new_xyz, idx, _u, normalize, radius = ctx.group[:6]
                 N0 = Ws[0].size(0)
-                dWx = arena[-1]
                 inv = ctx.group[6] if (len(ctx.group) > 6 and ctx.group[6] is not None) else ctx.lift_inv
-                S = e.group_lift_rows_grad(G, ys[0], consts.contiguous(), xyz, new_xyz, inv, idx.size(2), normalize,
-                                           radius, dWx).view(-1, N0)
+                Wx = Ws[0][:, :3].contiguous()
+                S = e.group_lift_rows_grad(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2), normalize,
+                                           radius, arena[-1]).view(-1, N0)
+                # dWx: the kernel left out c2 Wx RR (RR = sum_r rel rel^T is only complete after the launch)
+                dWx = torch.addcmul(arena[-1][:3 * N0].view(N0, 3), torch.mm(Wx, arena[-1][3 * N0:].view(3, 3)),
+                                    consts[1].unsqueeze(1))
                 dWf = torch.mm(S.t(), x.view(-1, K0 - 3))
                 grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
                 if need_dgrad0:
@@ -401,8 +404,9 @@ def _lift_forward(e, feats, W, group, stats):
     xyz, new_xyz, idx, _use_xyz, normalize, radius = group[:6]
     B, N, C = feats.shape
     # (the library's own fp32-MFMA GEMM: bit-reproducible from call to call, which a vendor GEMM's kernel choice is not)
-    P = e.mlp_gemm(feats.view(B * N, C), W[:, 3:].contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE)
-    return e.group_lift_rows(P.view(B, N, -1), xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stats=stats)
+    P = e.mlp_gemm(feats.view(B * N, C), W[:, 3:].contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
+    # (P travels to the backward as an attribute: 1/16 of y0's size, and the backward recomputes y0 from it)
+    return e.group_lift_rows(P, xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stats=stats), P
 
 
 class _FusedMLPBf16(Function):

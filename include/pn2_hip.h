@@ -242,20 +242,26 @@ int pn2_group_rows_grad(int B, int N, int m, int ns, int C, int ldg, int col0,
  *   pn2_group_lift_rows:      Y[(b m + j) ns + s][0:N0] = P[b, idx[b,j,s]][0:N0] + Wx rel[b,j,s],
  *       rel = (xyz[b, idx] - new_xyz[b, j]) (/ radius when `normalize`), P (B N, N0) = f Wf^T, Wx (N0, 3);
  *       stats (2, N0) f64 (may be NULL) += column sums of Y and Y^2 (the layer's BatchNorm batch statistics).
- *   pn2_group_lift_rows_grad: per row dL/dy0 = c1 g + c2 y0 + c3 (consts (3, N0): BatchNorm's backward from the masked
- *       gradient G the layer above left and the raw Y0);  S (B N, N0) = its sum over the rows that gathered each point
- *       (ptr / refs of pn2_group_inverse_index; every row of S written, fixed order),  dWx (N0, 3) += sum_r dL/dy0[r] rel[r]^T
- *       (fp32 atomics, once per workgroup).  The caller finishes with GEMMs over B N rows: dL/df = S Wf, dWf = S^T f.
+ *   pn2_group_lift_rows_grad: behind BatchNorm dL/dy0[r] = c1 g[r] + c2 y0[r] + c3 (consts (3, N0); G = the masked gradient
+ *       the layer above left; y0[r] = P[point] + Wx rel[r] is affine in the row, so it is never read or recomputed: the walk
+ *       sums g, rel and g rel^T and the constants enter once per point).  Through the inverse index (ptr / refs of
+ *       pn2_group_inverse_index):  S (B N, N0) = sum of dL/dy0 over the rows that gathered each point (every row written);
+ *       acc (3 N0 + 9) = [ dWx (N0, 3) = sum_r dL/dy0[r] rel[r]^T MINUS its last term c2 Wx RR | RR (3, 3) = sum_r rel[r] rel[r]^T ]
+ *       so that the caller can add that term (written, not accumulated: per-workgroup partials summed in a fixed order).  The caller finishes with GEMMs over B N rows:
+ *       dL/df = S Wf, dWf = S^T f.  Points gathered by more than 192 rows (low indices under large radii) are walked by 16 waves
+ *       each in a second launch and ADDED (their S is not bit-reproducible).  `workspace`: pn2_group_lift_rows_grad_workspace_bytes.
  *       Replaces the first layer's M-row dgrad / wgrad and group_points_grad_kernel (EXT/src/group_points_gpu.cu:44-75).
- * N0 a multiple of 4 in [16, 256] (pn2_group_lift_supported); P, Y, G, Y0, S, consts 16-byte aligned.
- * Algorithmic bytes: forward B (4 m ns + 12 N + 12 m + 4 N0 N + 4 N0 m ns); backward 8 M + 8 M N0 + 4 B N (N0 + 4). */
+ * N0 a multiple of 4 in [16, 256] (pn2_group_lift_supported); P, Y, G, S, consts 16-byte aligned.
+ * Algorithmic bytes: forward B (4 m ns + 12 N + 12 m + 4 N0 N + 4 N0 m ns); backward 8 M + 4 M N0 + 4 B N (2 N0 + 4). */
 int pn2_group_lift_supported(int N0);
 int pn2_group_lift_rows(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
                         const float *new_xyz, const int *idx, const float *P, const float *Wx, float *Y, double *stats,
                         void *stream);
 int pn2_group_lift_rows_grad(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
-                             const float *new_xyz, const float *G, const float *Y0, const float *consts, const int *ptr,
-                             const int *refs, float *S, float *dWx, void *stream);
+                             const float *new_xyz, const float *G, const float *P, const float *Wx, const float *consts,
+                             const int *ptr, const int *refs, float *S, float *acc, void *workspace,
+                             size_t workspace_bytes, void *stream);
+size_t pn2_group_lift_rows_grad_workspace_bytes(int B, int N, int m, int ns, int N0);
 
 /* pn2_rows_max / pn2_rows_max_grad: F.max_pool2d(kernel=[1,ns]) of
  *   OPS/pointnet2_modules.py:67-70 in point-major layout.

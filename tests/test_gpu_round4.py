@@ -306,14 +306,14 @@ def test_fused_query_feeds_the_sa_level_with_identical_results():
 
 
 # ------------------------------------------------------------------------------------ first layer before the grouping
-@pytest.mark.parametrize("B,N,m,ns,C,N0,normalize", [(2, 2048, 1024, 32, 128, 128, True), (3, 700, 130, 16, 256, 128, True),
-                                                     (2, 1000, 77, 48, 32, 64, False), (1, 513, 64, 80, 20, 256, True)])
-def test_lifted_first_layer_kernels_match_their_definition(B, N, m, ns, C, N0, normalize):
+@pytest.mark.parametrize("B,N,m,ns,C,N0,normalize,r", [(2, 2048, 1024, 32, 128, 128, True, 0.4), (3, 700, 130, 16, 256, 128, True, 0.4),
+                                                       (2, 1000, 77, 48, 32, 64, False, 0.4), (1, 513, 64, 80, 20, 256, True, 0.4),
+                                                       (2, 1024, 512, 16, 256, 128, True, 1.2)])     # r 1.2: heavy points
+def test_lifted_first_layer_kernels_match_their_definition(B, N, m, ns, C, N0, normalize, r):
     """pn2_group_lift_rows / _grad against plain torch (float64) on the same inputs: y0 = W [rel | f[idx]] row by row, its
-    column sums, and the backward's per-point sums S, coordinate columns dWx."""
+    column sums; the backward's per-point sums S of dL/dy0 (light points by one wave, heavy ones by sixteen) and dWx."""
     from pointnet2_ops import _ext as e
     g = torch.Generator().manual_seed(B * N + C)
-    r = 0.4
     xyz = _unit_ball(B, N, N + 1).cuda()
     sel = torch.stack([torch.randperm(N, generator=g)[:m] for _ in range(B)]).cuda()
     new_xyz = xyz[torch.arange(B, device="cuda")[:, None], sel].contiguous()
@@ -332,17 +332,21 @@ def test_lifted_first_layer_kernels_match_their_definition(B, N, m, ns, C, N0, n
     G = torch.randn(Y.shape, generator=g).cuda()
     consts = (torch.randn(3, N0, generator=g) * 0.5).cuda().contiguous()
     inv = e.group_inverse_index(idx, N)
-    dWx = torch.zeros(N0, 3, device="cuda")
-    S = e.group_lift_rows_grad(G, Y, consts, xyz, new_xyz, inv, ns, normalize, r, dWx)
-    gy = consts[0].double() * G.double() + consts[1].double() * Y.double() + consts[2].double()        # (M, N0)
-    S_want = torch.zeros(B * N, N0, dtype=torch.float64, device="cuda")
+    acc = torch.zeros(3 * N0 + 9, device="cuda")
+    S = e.group_lift_rows_grad(G, P, W[:, :3].contiguous(), consts, xyz, new_xyz, inv, ns, normalize, r, acc)
     flat = (idx.long() + (torch.arange(B, device="cuda") * N).view(B, 1, 1)).view(-1)
-    S_want.index_add_(0, flat, gy)
-    scale = float(S_want.abs().max())
-    assert float((S.view(-1, N0).double() - S_want).abs().max()) < 2e-6 * scale + 1e-6
-    dWx_want = gy.t() @ rows[:, :3].double()
-    assert float((dWx.double() - dWx_want).abs().max()) < 1e-5 * float(dWx_want.abs().max()) + 1e-5
-
+    rel = rows[:, :3].double()
+    c1, c2, c3 = consts.double()
+    gy = c1 * G.double() + c2 * Y.double() + c3                                    # dL/dy0 row by row
+    S_want = torch.zeros(B * N, N0, dtype=torch.float64, device="cuda").index_add_(0, flat, gy)
+    assert float((S.view(-1, N0).double() - S_want).abs().max()) < 1e-5 * float(S_want.abs().max()) + 1e-6
+    RR_want = rel.t() @ rel
+    assert float((acc[3 * N0:].view(3, 3).double() - RR_want).abs().max()) < 1e-5 * float(RR_want.abs().max()) + 1e-5
+    dWx = acc[:3 * N0].view(N0, 3).double() + c2.unsqueeze(1) * (W[:, :3].double() @ acc[3 * N0:].view(3, 3).double())
+    dWx_want = gy.t() @ rel
+    assert float((dWx - dWx_want).abs().max()) < 2e-5 * float(dWx_want.abs().max()) + 1e-5
+    counts = inv[0][1:] - inv[0][:-1]
+    print(f"\n[lift backward] rows per point: max {int(counts.max())}, heavy (> 192): {int((counts > 192).sum())}", end="")
 
 def test_lifted_first_layer_equals_the_grouped_route_at_module_level():
     """One SA level (SA3 of the backbone: 259 -> 128 -> 128 -> 256 on 1024-point clouds) with and without LIFT_FIRST: same
