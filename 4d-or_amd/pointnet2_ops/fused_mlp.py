@@ -323,10 +323,12 @@ class _FusedMLP(Function):
                 # dWx: the kernel left out c2 Wx RR (RR = sum_r rel rel^T is only complete after the launch)
                 dWx = torch.addcmul(arena[-1][:3 * N0].view(N0, 3), torch.mm(Wx, arena[-1][3 * N0:].view(3, 3)),
                                     consts[1].unsqueeze(1))
-                dWf = torch.mm(S.t(), x.view(-1, K0 - 3))
+                # dWf = S^T f and dL/df = S Wf over the B N points, on the library's own kernels (a vendor GEMM picks a
+                # 32 x 32 tile for the 128 x 128 x 65 536 reduction: 0.18 ms; pn2_mlp_wgrad is built for long reductions)
+                dWf = e.mlp_wgrad(S, _unit_consts(S.device, N0), x.view(-1, K0 - 3), e.PRO_GY, e.PRO_NONE, G=S)
                 grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
                 if need_dgrad0:
-                    gx = torch.mm(S, Ws[0][:, 3:]).view(ctx.feat_shape)
+                    gx = e.mlp_gemm(S, Ws[0][:, 3:].t().contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(ctx.feat_shape)
                 continue
             if l == L - 1 and ctx.pool_fused:
                 # pooled layer in Gram form: y_l was never stored (csrc/pool_bwd.hip)
@@ -396,6 +398,19 @@ class _FusedMLP(Function):
             else:                        # (a segmented call hands in its zero-filled slice of the batch's gradient)
                 gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0, out=getattr(ctx, "gx_out", None))
         return (gx, None, None, None, *grads)
+
+
+_UNIT_CONSTS = {}
+
+
+def _unit_consts(device, n):
+    """(3, n) constants (1, 0, 0): pn2_mlp_wgrad's gradient transform c1 g + c2 y + c3 as the identity.  Cached per
+    (device, width): created once, eagerly (a stream capture must not meet the allocation + fill)."""
+    key = (device, int(n))
+    t = _UNIT_CONSTS.get(key)
+    if t is None:
+        t = _UNIT_CONSTS[key] = torch.cat([torch.ones(1, n, device=device), torch.zeros(2, n, device=device)]).contiguous()
+    return t
 
 
 def _lift_forward(e, feats, W, group, stats):
