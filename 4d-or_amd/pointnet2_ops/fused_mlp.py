@@ -53,6 +53,10 @@ if _os.environ.get("PN2_FIRST_FREE") == "0":
 #: (centre, sample) row, no grouped tensor, no M-row dgrad / wgrad / scatter in the backward.  fp32 node, ungrouped input,
 #: and (when gradients are needed) an inverse neighbourhood index next to idx.  PN2_LIFT_FIRST=0 switches it off (A/B).
 LIFT_FIRST = _os.environ.get("PN2_LIFT_FIRST") != "0"
+#: ... also for SPARSE balls (the scene-graph encoders' second level: most slots of a neighbourhood repeat its first hit, a
+#: few points own hundreds of rows — the backward walks those with sixteen waves each), the inverse index built in the step:
+#: 8 scans per step, whole-batch statistics, fp32: 169 -> 242 scans/s.  PN2_LIFT_SPARSE=0 restores the grouped route (A/B).
+LIFT_SPARSE = _os.environ.get("PN2_LIFT_SPARSE") != "0"
 
 #: arithmetic of the shared-MLP stacks.  float32 = exact fp32 MFMA (the parity path, default).  bfloat16 = the MI355X
 #: counterpart of the reference's 16-bit AMP training (scene_graph_prediction/main.py:64 `precision=16`): activations
@@ -150,9 +154,8 @@ class _FusedMLP(Function):
             # through: the route must not depend on whether the geometry was prefetched (identical results either way)
             has_inv = len(group) > 6 and group[6] is not None
             crowded = len(group) > 7 and bool(group[7])
-            lift = bool(LIFT_FIRST and pre is None and x is not None and use_xyz and L >= 2 and x.size(2) >= 16
-                        and getattr(e, "group_lift_rows", None) and e.group_lift_supported(layers[0][0].out_channels)
-                        and (not any(ctx.needs_input_grad) or has_inv or crowded))
+            lift = bool(pre is None and _lift_eligible(e, layers, use_xyz, x)
+                        and (not any(ctx.needs_input_grad) or has_inv or crowded or LIFT_SPARSE))
             ctx.lift_inv = None
             if lift and any(ctx.needs_input_grad) and not has_inv:
                 ctx.lift_inv = tuple(e.group_inverse_index(idx, xyz.size(1)))      # (not prefetched: built here)
@@ -329,6 +332,9 @@ class _FusedMLP(Function):
                 grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
                 if need_dgrad0:
                     gx = e.mlp_gemm(S, Ws[0][:, 3:].t().contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(ctx.feat_shape)
+                    dst = getattr(ctx, "gx_out", None)       # (a segmented call: this scan's slice of the batch's gradient)
+                    if dst is not None:
+                        gx = dst.copy_(gx)
                 continue
             if l == L - 1 and ctx.pool_fused:
                 # pooled layer in Gram form: y_l was never stored (csrc/pool_bwd.hip)
@@ -398,6 +404,13 @@ class _FusedMLP(Function):
             else:                        # (a segmented call hands in its zero-filled slice of the batch's gradient)
                 gx = e.group_rows_grad(gx.view(Bq, npoint, nsample, Cf), idx, Nf, Cf, 0, out=getattr(ctx, "gx_out", None))
         return (gx, None, None, None, *grads)
+
+
+def _lift_eligible(e, layers, use_xyz, feats) -> bool:
+    """Shapes the lifted first layer covers: [relative xyz | >= 16 feature channels] into a stack of >= 2 layers whose first
+    width is a multiple of 4 up to 256 (fp32 node)."""
+    return bool(LIFT_FIRST and feats is not None and use_xyz and len(layers) >= 2 and feats.size(2) >= 16
+                and getattr(e, "group_lift_rows", None) and e.group_lift_supported(layers[0][0].out_channels))
 
 
 _UNIT_CONSTS = {}
@@ -739,7 +752,16 @@ class _SegmentedGroupMLP(Function):
         # (same-box A/B at 8 scans, bf16: 195.4 -> 202.4 scans/s)
         e = _ext()
         feats = None if x is None else x.contiguous()
-        if inner is _FusedMLPBf16:
+        # fp32 stacks whose first layer can be applied before the grouping (_lift_eligible) form no rows at all: every scan's
+        # inner call lifts, with its slice of ONE inverse index of the whole batch (rows and points of a scan are contiguous)
+        lift_all = bool(inner is _FusedMLP and _lift_eligible(e, layers, use_xyz, feats)
+                        and not (len(group) > 8 and group[8] is not None))
+        inv_all = None
+        if lift_all and any(ctx.needs_input_grad):
+            inv_all = group[6] if (len(group) > 6 and group[6] is not None) else tuple(e.group_inverse_index(idx, xyz.size(1)))
+        if lift_all:
+            rows_all = None
+        elif inner is _FusedMLPBf16:
             rows_all = e.group_concat_rows_bf16(xyz, new_xyz, feats, idx, use_xyz, normalize, radius)
         elif len(group) > 8 and group[8] is not None:
             rows_all = group[8]                         # emitted by the fused query + grouping kernel
@@ -755,9 +777,13 @@ class _SegmentedGroupMLP(Function):
             c1 = c0 + n_clouds
             # (x, ns, layers, group, *params) of the inner node <- (x, ns, layers, group, sizes, inner, *params) here
             sub = _SegCtx(tuple(ctx.needs_input_grad[:4]) + tuple(ctx.needs_input_grad[6:]))
-            sub.x_rows = rows_all[c0:c1].view(-1, rows_all.size(-1))
+            sub.x_rows = None if lift_all else rows_all[c0:c1].view(-1, rows_all.size(-1))
             sub.fin_out = [None if F is None else F[s] for F in fin_bufs]
-            g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius, None, group[7] if len(group) > 7 else None,
+            inv_s = None
+            if inv_all is not None:
+                r0, n_pts = c0 * m * idx.size(2), xyz.size(1)
+                inv_s = (inv_all[0][c0 * n_pts:c1 * n_pts + 1] - r0, inv_all[1][r0:c1 * m * idx.size(2)] - r0)
+            g = (xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], use_xyz, normalize, radius, inv_s, group[7] if len(group) > 7 else None,
                  None)
             with torch.cuda.stream(fork.stream(s)):
                 out, arg = inner.forward(sub, None if x is None else x[c0:c1], ns, layers, g, *params)
@@ -907,7 +933,7 @@ def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz,
             res = _SegTableMLP.apply(None if feats_rows is None else feats_rows.contiguous(), int(ns), layers, group,
                                      tuple(int(v) * m * ns for v in clouds_per_scan), node, *_params(layers))
             return res[0].view(B, m, -1)
-        group = group[:6] + (None,) + group[7:]          # (the loop slices the clouds: no whole-batch inverse index)
+        # (the loop slices the clouds: a whole-batch inverse index is only used, in slices, by lifted first layers)
         res = _SegmentedGroupMLP.apply(None if feats_rows is None else feats_rows.contiguous(), int(ns), layers, group,
                                        tuple(int(v) for v in clouds_per_scan), _node(layers, ns), *_params(layers))
     else:
