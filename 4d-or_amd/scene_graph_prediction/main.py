@@ -68,8 +68,9 @@ def train(model, config, scans, device, epochs=1, graphs=False, rank=0, world=1,
         for n, p in model.named_parameters():
             if ".backbone.fc_layer." in n:
                 p.requires_grad_(False)
-        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=model.lr,
-                                weight_decay=float(config["W_DECAY"]), capturable=bool(graphs))
+        live = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.AdamW(live, lr=model.lr, weight_decay=float(config["W_DECAY"]), capturable=bool(graphs),
+                                fused=bool(live) and all(p.is_cuda for p in live))
     else:
         opt = model.configure_optimizers(capturable=False)
     if world > 1:
