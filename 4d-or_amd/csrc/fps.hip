@@ -284,7 +284,9 @@ constexpr int kCoopMaxG = 32;
 // 3 workgroups fit a CU; we allow 2 per CU (256 CUs)
 constexpr int kCoopMaxWorkgroups = 512;
 constexpr int kCoopFields = 5;                                      // hi, lo, x, y, z
-constexpr size_t kCoopCloudBytes = 2ull * kCoopFields * kCoopMaxG * sizeof(u64);
+// (fps_multi_kernel: [2 parities][6 fields][64 sub-blobs] granules per cloud — the larger of the two layouts)
+constexpr size_t kCoopCloudBytes = 2ull * 6 * 64 * sizeof(u64);
+static_assert(kCoopCloudBytes >= 2ull * kCoopFields * kCoopMaxG * sizeof(u64), "cluster hand-off slots");
 constexpr unsigned kCoopSpinLimit = 1u << 22;
 
 __device__ __forceinline__ void coop_store(u64 *p, u64 v) {
@@ -885,6 +887,323 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
   }
 }
 
+// ---- cluster kernel with SEVERAL samples per hand-off (round 4) ----------------------------------------------------
+// A round of fps_coop_kernel is ~1.1 us of scan and ~1.9 us of inter-workgroup hand-off, and the hand-off is at the price
+// the hardware asks for a store -> poll round trip through L2.  The lever is FEWER hand-offs.  Every wave owns SUB
+// "sub-blobs" (consecutive records of the spatially binned cloud, PPT / SUB slots per lane each) and caches, per sub-blob,
+// its arg-max candidate c (key + coordinates) and `second`, the largest running distance among its OTHER points.  One
+// hand-off carries the candidates of ALL sub-blobs of the cloud (<= 64: one per lane of the sweeping wave), and every
+// workgroup then runs the same "mini FPS" over them:
+//   * sample 1 = the largest key — the reference's next sample;
+//   * every lane updates the running distance of ITS candidate with the accepted sample (the scan's arithmetic, so the
+//     value is the one the owning wave will compute).  Running distances only decrease: while d(c) stays STRICTLY above
+//     `second`, c is still its sub-blob's arg-max and (d(c), rank) its exact key — the sub-blob is CLEAN.  Otherwise it
+//     is DIRTY: all that is known is that every one of its points is at most `second` away;
+//   * the best clean candidate is the reference's next sample iff its distance is STRICTLY above every dirty bound: all
+//     other points of clean sub-blobs have smaller keys (keys are unique), all points of dirty ones smaller distances.
+//     Otherwise the list ends and the waves catch up.
+// Up to kMultiK samples per hand-off (numpy model on binned 50k clouds: 4.8 on average with 32 sub-blobs, 5.4 with 64;
+// a rule that declares every sub-blob an accepted sample can REACH dirty gives 2.4 / 2.9).  The waves then apply the
+// accepted samples that reach their sub-blobs (box test, as in fps_coop_kernel) in one pass.  Bit-exact by construction:
+// every accepted sample is proven to be the arg-max of the full update; checked against the lane-accurate oracle like
+// every other variant.
+constexpr int kMultiK = 8;
+constexpr int kMultiFields = 6;                                     // hi, lo, x, y, z, second
+constexpr int kMultiWords = kMultiFields * 64;                      // one parity: field-major, 64 sub-blobs
+// per cloud: [2 parities][6][64] candidate granules
+constexpr size_t kMultiCloudBytes = 2ull * kMultiWords * sizeof(u64);
+static_assert(kMultiCloudBytes <= kCoopCloudBytes, "hand-off area of a cloud");
+
+struct FpsMultiFin {
+  int cnt, abort, pad0, pad1;
+  float x[kMultiK], y[kMultiK], z[kMultiK];
+};
+
+__device__ __forceinline__ float fps_box_lb(float b0x, float b0y, float b0z, float b1x, float b1y, float b1z,
+                                            float ox, float oy, float oz) {
+  const float ex = fmaxf(fmaxf(b0x - ox, ox - b1x), 0.f), ey = fmaxf(fmaxf(b0y - oy, oy - b1y), 0.f),
+              ez = fmaxf(fmaxf(b0z - oz, oz - b1z), 0.f);
+  return (ex * ex + ey * ey + ez * ez) * 0.999998f;
+}
+
+template <int PPT, int SUB>
+__global__ __launch_bounds__(1024) void fps_multi_kernel(int B, int N, int m, int L, int G,
+                                                         const float *__restrict__ xyz,
+                                                         const float4 *__restrict__ rec,
+                                                         int *__restrict__ idxs,
+                                                         u64 *__restrict__ slots,
+                                                         int *__restrict__ status) {
+  constexpr int NW = 16;
+  constexpr int WSUB = NW * SUB;                                    // sub-blobs of a workgroup
+  static_assert(SUB == 1 || SUB == 2, "one or two sub-blobs per wave");
+  __shared__ int permk[1024 * PPT];                                 // reference index of every point slot
+  __shared__ unsigned s_val[kMultiFields][WSUB];                    // this workgroup's cached candidates
+  __shared__ unsigned s_cand[kMultiFields][64];                     // this hand-off's candidates of all sub-blobs
+  __shared__ FpsMultiFin s_fin;
+
+  const int q = blockIdx.x % B;                                     // cloud; a cluster shares blockIdx % 8 when B % 8 == 0
+  const int g = blockIdx.x / B;
+  const int t = threadIdx.x;
+  const int lane = pn2_lane();
+  const int wave = t >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int nsub = G * WSUB;                                        // <= 64 (host)
+
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  float b0x[SUB], b0y[SUB], b0z[SUB], b1x[SUB], b1y[SUB], b1z[SUB], c_maxd[SUB];
+  bool has_valid[SUB];
+#pragma unroll
+  for (int h = 0; h < SUB; ++h) {
+    b0x[h] = b0y[h] = b0z[h] = 3.0e38f;
+    b1x[h] = b1y[h] = b1z[h] = -3.0e38f;
+  }
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    // wave (g, w) owns the records [b 64 PPT, +64 PPT) of the binned cloud, b = w G + g (neighbouring blobs on different
+    // workgroups and SIMDs); its sub-blob h the slots [h PPT / SUB, (h + 1) PPT / SUB)
+    const int pos = (wave * G + g) * (64 * PPT) + i * 64 + lane;
+    float x = 0.f, y = 0.f, z = 0.f;
+    int kk = 0;
+    bool valid = false;
+    if (pos < N) {
+      const float4 r = rec[(size_t)q * N + pos];
+      x = r.x; y = r.y; z = r.z; kk = __float_as_int(r.w);
+      const float mag = pn2_sq3(x, y, z);
+      valid = !((double)mag <= 1e-3);
+    }
+    permk[wave * (64 * PPT) + i * 64 + lane] = kk;
+    px[i] = x; py[i] = y; pz[i] = z;
+    td[i] = valid ? 1e10f : -1.f;
+#pragma unroll
+    for (int h = 0; h < SUB; ++h) {
+      if (i >= h * PPT / SUB && i < (h + 1) * PPT / SUB && valid) {
+        b0x[h] = fminf(b0x[h], x); b0y[h] = fminf(b0y[h], y); b0z[h] = fminf(b0z[h], z);
+        b1x[h] = fmaxf(b1x[h], x); b1y[h] = fmaxf(b1y[h], y); b1z[h] = fmaxf(b1z[h], z);
+      }
+    }
+    // four record loads in flight at a time: with all PPT of them hoisted to the top (16 bytes each) the prologue, not
+    // the sampling loop, would set the kernel's register peak and push loop-carried values into scratch
+    if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int h = 0; h < SUB; ++h) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      b0x[h] = fminf(b0x[h], __shfl_xor(b0x[h], o)); b0y[h] = fminf(b0y[h], __shfl_xor(b0y[h], o));
+      b0z[h] = fminf(b0z[h], __shfl_xor(b0z[h], o));
+      b1x[h] = fmaxf(b1x[h], __shfl_xor(b1x[h], o)); b1y[h] = fmaxf(b1y[h], __shfl_xor(b1y[h], o));
+      b1z[h] = fmaxf(b1z[h], __shfl_xor(b1z[h], o));
+    }
+    b0x[h] = pn2_readlane_f32(b0x[h], 0); b0y[h] = pn2_readlane_f32(b0y[h], 0); b0z[h] = pn2_readlane_f32(b0z[h], 0);
+    b1x[h] = pn2_readlane_f32(b1x[h], 0); b1y[h] = pn2_readlane_f32(b1y[h], 0); b1z[h] = pn2_readlane_f32(b1z[h], 0);
+    has_valid[h] = b0x[h] <= b1x[h];                               // some valid point went into the box
+    c_maxd[h] = has_valid[h] ? 1e10f : -1.f;
+    if (lane == 0) {
+      const int sb = wave * SUB + h;
+#pragma unroll
+      for (int f = 0; f < kMultiFields; ++f) s_val[f][sb] = 0u;
+    }
+  }
+  const float *P0 = xyz + (size_t)q * N * 3;
+  const float p0x = P0[0], p0y = P0[1], p0z = P0[2];
+  if (t == 0) {
+    s_fin.cnt = 1; s_fin.abort = 0;
+    s_fin.x[0] = p0x; s_fin.y[0] = p0y; s_fin.z[0] = p0z;
+    if (g == 0) idxs[(size_t)q * m] = 0;
+  }
+  __syncthreads();
+
+  u64 *const base = slots + (size_t)q * (2 * kMultiWords);
+  int j = 1;                                                        // samples emitted so far
+  unsigned e = 0;                                                   // hand-offs so far
+  while (j < m) {
+    // ---- which (sample, sub-blob) pairs are live: lane l tests sample l / SUB against sub-blob l % SUB
+    const int cnt = __builtin_amdgcn_readfirstlane(s_fin.cnt);
+    u64 amask;
+    {
+      const int ls = lane / SUB < kMultiK ? lane / SUB : kMultiK - 1;
+      const float sxl = s_fin.x[ls], syl = s_fin.y[ls], szl = s_fin.z[ls];
+      const int h1 = SUB == 2 ? (lane & 1) : 0;
+      const float lb = fps_box_lb(h1 ? b0x[SUB - 1] : b0x[0], h1 ? b0y[SUB - 1] : b0y[0], h1 ? b0z[SUB - 1] : b0z[0],
+                                  h1 ? b1x[SUB - 1] : b1x[0], h1 ? b1y[SUB - 1] : b1y[0], h1 ? b1z[SUB - 1] : b1z[0],
+                                  sxl, syl, szl);
+      const float md = h1 ? c_maxd[SUB - 1] : c_maxd[0];
+      const bool hv = h1 ? has_valid[SUB - 1] : has_valid[0];
+      // first round: every sub-blob with a valid point takes the first sample (its cached candidate does not exist yet)
+      amask = __ballot(lane < cnt * SUB && (!(lb >= md) || (e == 0u && hv)));
+    }
+#pragma unroll
+    for (int h = 0; h < SUB; ++h) {
+      constexpr u64 kEven = 0x5555555555555555ull;
+      u64 mh = SUB == 2 ? (amask & (kEven << h)) : amask;
+      if (mh == 0ull) continue;                                     // wave-uniform: cached candidate stands
+      const int lo_i = h * PPT / SUB, hi_i = (h + 1) * PPT / SUB;
+      while (mh) {
+        const int bl = __ffsll((long long)mh) - 1;
+        mh &= mh - 1;
+        // (the sample again from LDS, by a uniform address: three registers per lane the 26-slot shape does not have)
+        const int sl = bl / SUB;
+        const float ox = pn2_readlane_f32(s_fin.x[sl], 0), oy = pn2_readlane_f32(s_fin.y[sl], 0),
+                    oz = pn2_readlane_f32(s_fin.z[sl], 0);
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+          if (i >= lo_i && i < hi_i) {
+            const float d = pn2_sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
+            td[i] = fps_min(d, td[i]);
+          }
+        }
+      }
+      // the lane's two largest running distances: b1 >= b2 (v_max + v_med3 per slot)
+      // (pinned instructions: as plain expressions the compiler canonicalises every operand that came out of the v_min
+      // asm (a v_max x, x each) and SINKS the second chain below the tied-lane loop, keeping all PPT prefix maxima alive
+      // for it — 26 registers this kernel does not have)
+      float best = -1.f, best2 = -1.f;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        if (i >= lo_i && i < hi_i) {
+          asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(best2) : "v"(best), "v"(td[i]));
+          asm volatile("v_max_f32 %0, %0, %1" : "+v"(best) : "v"(td[i]));
+        }
+      }
+      const unsigned hi = best >= 0.f ? __float_as_uint(best) + 1u : 0u;
+      const unsigned whi = pn2_wave_max_u32(hi);                    // wave-uniform
+      // (every result goes to the LDS slot where it is produced: carried to one common store they cost five registers
+      // the 26-slot shape does not have)
+      const int sb = wave_u * SUB + h;
+      unsigned best_lo = 0u;
+      if (whi != 0u) {
+        const unsigned target = whi - 1u;
+        u64 tied = __ballot(hi == whi);
+        int wl = 0, wbi = lo_i;
+        while (tied) {                                              // scalar loop over the tied lanes (usually one)
+          const int l = __ffsll((long long)tied) - 1;
+          tied &= tied - 1;
+#pragma unroll
+          for (int i = 0; i < PPT; ++i) {
+            if (i >= lo_i && i < hi_i) {
+              if ((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(td[i]), l) == target) {   // wave-uniform
+                const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane(permk[wave_u * (64 * PPT) + i * 64 + l]);
+                const unsigned lo = ~fps_rank(k, L);
+                if (lo >= best_lo) { best_lo = lo; wl = l; wbi = i; }
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+          if (i >= lo_i && i < hi_i) {
+            if (wbi == i && lane == wl) {                           // (wbi == i: wave-uniform, a scalar branch)
+              s_val[2][sb] = __float_as_uint(px[i]); s_val[3][sb] = __float_as_uint(py[i]);
+              s_val[4][sb] = __float_as_uint(pz[i]);
+            }
+          }
+        }
+        // largest running distance among the sub-blob's OTHER points: the winner's lane contributes its second largest
+        const float other = lane == wl ? best2 : best;
+        const unsigned second = pn2_wave_max_u32(other >= 0.f ? __float_as_uint(other) + 1u : 0u);
+        if (lane == 0) s_val[5][sb] = second;
+      } else if (lane == 0) {
+        s_val[2][sb] = __float_as_uint(p0x); s_val[3][sb] = __float_as_uint(p0y); s_val[4][sb] = __float_as_uint(p0z);
+        s_val[5][sb] = 0u;
+      }
+      c_maxd[h] = whi != 0u ? __uint_as_float(whi - 1u) : -1.f;
+      if (lane == 0) { s_val[0][sb] = whi; s_val[1][sb] = best_lo; }
+    }
+    ++e;
+    __syncthreads();
+
+    // ---- wave 0: publish this workgroup's candidates, collect the peers', mini FPS over all of them
+    if (wave == 0) {
+      u64 *par = base + (size_t)(e & 1u) * kMultiWords;
+      const bool live = lane < nsub;
+      const bool own = live && (lane / WSUB) == g;
+      if (own) {
+        const int sb = lane - g * WSUB;
+#pragma unroll
+        for (int f = 0; f < kMultiFields; ++f) {
+          const unsigned val = s_val[f][sb];
+          coop_store(par + f * 64 + lane, ((u64)e << 32) | (u64)val);
+          s_cand[f][lane] = val;
+        }
+      } else if (!live) {
+#pragma unroll
+        for (int f = 0; f < kMultiFields; ++f) s_cand[f][lane] = 0u;
+      }
+      bool failed = false;
+      unsigned spins = 0;
+      {
+        u64 w[kMultiFields];
+#pragma unroll
+        for (int f = 0; f < kMultiFields; ++f) w[f] = 0ull;
+        for (;;) {
+          bool ok = true;
+          if (live && !own) {
+#pragma unroll
+            for (int f = 0; f < kMultiFields; ++f) w[f] = coop_load(par + f * 64 + lane);
+#pragma unroll
+            for (int f = 0; f < kMultiFields; ++f) ok = ok && (unsigned)(w[f] >> 32) == e;
+          }
+          if (__all(ok)) break;
+          if (++spins > kCoopSpinLimit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        // everything the mini FPS needs goes through LDS (a lane's own entries, the winner's coordinates by a uniform
+        // read): at 26 point slots per lane the kernel has no registers to hold 64 candidates x 6 fields next to them
+        if (live && !own) {
+#pragma unroll
+          for (int f = 0; f < kMultiFields; ++f) s_cand[f][lane] = (unsigned)w[f];
+        }
+      }
+      int acc = 0;
+      if (!failed) {
+        // lane = sub-blob: its candidate's key, coordinates and CURRENT running distance (kept exact below), and the
+        // largest distance among its other points as of this hand-off
+        unsigned hi = s_cand[0][lane];
+        const unsigned lo = s_cand[1][lane], sec = s_cand[5][lane];
+        const float cx = __uint_as_float(s_cand[2][lane]), cy = __uint_as_float(s_cand[3][lane]),
+                    cz = __uint_as_float(s_cand[4][lane]);
+        bool dirty = false;
+        const int kmax = m - j < kMultiK ? m - j : kMultiK;
+        for (int k = 0; k < kmax; ++k) {
+          unsigned mhi, mlo;
+          const u64 who = pn2_wave_argmax_u32x2(dirty ? 0u : hi, dirty ? 0u : lo, mhi, mlo);
+          if (k > 0) {
+            const unsigned db = pn2_wave_max_u32(dirty ? sec : 0u);
+            if (!(mhi > db)) break;                                 // (also: no clean candidate left)
+          }
+          float sx = p0x, sy = p0y, sz = p0z;
+          int kidx = 0;
+          if (mhi != 0u) {
+            const int wl = __ffsll((long long)who) - 1;
+            sx = pn2_readlane_f32(cx, wl); sy = pn2_readlane_f32(cy, wl); sz = pn2_readlane_f32(cz, wl);
+            kidx = (int)fps_unrank(~mlo, L);
+          }
+          if (lane == 0) {
+            s_fin.x[k] = sx; s_fin.y[k] = sy; s_fin.z[k] = sz;
+            if (g == 0) idxs[(size_t)q * m + j + k] = kidx;
+          }
+          ++acc;
+          if (mhi == 0u) break;                                     // no valid point anywhere: index 0 (sampling_gpu.cu:90-91)
+          // the candidate's own update, with the arithmetic of the scan: while it stays STRICTLY above every other
+          // point of its sub-blob (whose distances only decrease) it is still the sub-blob's arg-max, with this key
+          if (hi != 0u) {
+            const float nd = fps_min(pn2_sq3(cx - sx, cy - sy, cz - sz), __uint_as_float(hi - 1u));
+            hi = __float_as_uint(nd) + 1u;
+            if (!(hi > sec)) dirty = true;                          // (the sample's own sub-blob: nd = 0)
+          }
+        }
+      }
+      if (lane == 0) {
+        s_fin.cnt = acc;
+        if (failed) { s_fin.abort = 1; atomicExch(status, 1); }
+      }
+    }
+    __syncthreads();
+    if (s_fin.abort) return;
+    j += __builtin_amdgcn_readfirstlane(s_fin.cnt);
+  }
+}
+
 constexpr int kFpsResidentMaxN = 1024 * 24;
 
 // EXT/include/cuda_utils.h:15-19 (same truncating double-log expression).
@@ -904,7 +1223,8 @@ int ref_opt_n_threads(int work_size) {
 //     that keeps <= 16 point slots per lane (larger clusters sweep more granules);
 //     every cluster workgroup must be resident, hence B*G <= 256.
 struct FpsPlan {
-  int mode;  // 0 resident, 1 cooperative, 2 streaming, 3 cooperative with a streamed tail, 4 bucketed (PPT = slots per bucket)
+  int mode;  // 0 resident, 1 cooperative, 2 streaming, 3 cooperative with a streamed tail, 4 bucketed (PPT = slots per bucket),
+             // 5 cluster with several samples per hand-off (fps_multi_kernel; NC = sub-blobs per wave)
   int G, BS, PPT;
   int NC;    // cooperative: clouds per cluster
 };
@@ -921,11 +1241,12 @@ int round_ppt(int ppt) {
 // against the oracle on shapes the heuristic would route elsewhere.  Process-global, unset by default; never read from
 // the environment.
 struct FpsOverride {
-  int mode;      // -1 none | 0 resident | 1 cooperative | 2 streaming | 3 cooperative with a streamed tail | 4 bucketed
+  int mode;      // -1 none | 0 resident | 1 cooperative | 2 streaming | 3 cooperative with a streamed tail | 4 bucketed | 5 multi
   int G, NC, coop_bs, bs;   // 0 = heuristic
 };
 FpsOverride g_fps_override = {-1, 0, 0, 0, 0};
 std::atomic<bool> g_fps_bucketing{true};     // (pn2_fps_set_bucketing: tests and measurements compare both forms)
+std::atomic<bool> g_fps_multi{true};         // (pn2_fps_set_multi: several samples per hand-off for cluster-sized clouds)
 
 // Number of CUs of the current device (a CPX/DPX partition reports its own count); every cluster workgroup must be
 // resident at once, so the cluster shapes are sized from this instead of a hard-coded 256.
@@ -1041,6 +1362,29 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false, bool fewest = false,
   // step of samplings; a batch that does fit (32 x 50k: 1.6M of 5.2M slots) is as fast on a cluster (4.9 vs 4.8 ms)
   if (ov.mode < 0 && use_bucketing && k.mode == 4 && N > 16384 && (long long)B * N > (long long)ncus * 1024 * 20) return k;
 
+  // several samples per hand-off: two (up to 53k points) or four 1024-thread workgroups per cloud over the binned records,
+  // 64 sub-blobs per cloud.  Replaces the one-sample cluster wherever it fits (fewer CUs AND fewer hand-offs).
+  FpsPlan mu = {-1, 2, 1024, 0, 2};
+  {
+    int G = 2;
+    if ((long long)N > 2LL * 1024 * 26) G = 4;
+    if (ov.mode == 5 && ov.G == 4) G = 4;
+    const int raw = (N + G * 1024 - 1) / (G * 1024);
+    // G 16 SUB <= 64 sub-blobs, one per lane of the sweeping wave; two per wave only up to 20 point slots per lane (the
+    // 24..26-slot instantiations with two sub-blobs need 30-70 registers more than a 1024-thread workgroup has: 8 vs 4.6 ms)
+    int sub = (G == 2 && raw <= 20) ? 2 : 1;
+    if (ov.mode == 5 && ov.NC == 1) sub = 1;
+    if (ov.mode == 5 && ov.NC == 2 && G == 2) sub = 2;
+    int ppt = -1;
+    if (sub == 2) { for (int c2 : {10, 12, 14, 16, 20, 24, 25, 26}) if (c2 >= raw) { ppt = c2; break; } }
+    else { for (int c2 : {14, 16, 20, 24, 25, 26}) if (c2 >= raw) { ppt = c2; break; } }
+    if (ppt > 0 && (long long)B * G <= ncus) { mu.mode = 5; mu.G = G; mu.PPT = ppt; mu.NC = sub; }
+  }
+  if (ov.mode == 5 && mu.mode == 5) return mu;
+  if (ov.mode < 0 && use_bucketing && g_fps_multi.load(std::memory_order_relaxed) && mu.mode == 5 && N > 16384 &&
+      c.mode == 1 && !(r.mode == 0 && N <= 16384))
+    return mu;
+
   if (want_coop && c.mode == 1) return c;
   if (want_resident && r.mode == 0) return r;
   if (r.mode == 0 && (N <= 16384 || c.mode != 1)) return r;
@@ -1112,7 +1456,7 @@ size_t fps_align256(size_t v) { return (v + 255) & ~(size_t)255; }
 }  // namespace
 
 extern "C" int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, int bs) {
-  if (mode < -1 || mode > 4 || G < 0 || NC < 0) return PN2_EINVAL;
+  if (mode < -1 || mode > 5 || G < 0 || NC < 0) return PN2_EINVAL;
   g_fps_override = {mode, G, NC, coop_bs, bs};
   return PN2_OK;
 }
@@ -1123,6 +1467,12 @@ extern "C" int pn2_fps_set_bucketing(int on) {
   return PN2_OK;
 }
 extern "C" int pn2_fps_get_bucketing(void) { return g_fps_bucketing.load(std::memory_order_relaxed) ? 1 : 0; }
+// Measurement hook: the several-samples-per-hand-off cluster kernel on (default) / off.  Results never depend on it.
+extern "C" int pn2_fps_set_multi(int on) {
+  g_fps_multi.store(on != 0, std::memory_order_relaxed);
+  return PN2_OK;
+}
+extern "C" int pn2_fps_get_multi(void) { return g_fps_multi.load(std::memory_order_relaxed) ? 1 : 0; }
 
 // cluster plans also reserve the streaming kernel's B x N floats behind the hand-off slots: the fallback when the
 // cluster would not be resident on this device
@@ -1142,7 +1492,7 @@ extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int m) {
   const FpsPlan kb = fps_plan(B, N, m, false, false, 1);
   size_t need = 0;
   // cluster plans: hand-off slots | status | B x N floats (streaming fallback / streamed tail) | B x N binned records
-  if (p.mode == 1 || p.mode == 3)
+  if (p.mode == 1 || p.mode == 3 || p.mode == 5 || kb.mode == 5)
     need = (size_t)B * kCoopCloudBytes + 256 + fps_align256((size_t)B * (size_t)N * sizeof(float)) + (size_t)B * (size_t)N * 16;
   else if (p.mode == 2) need = (size_t)B * (size_t)N * sizeof(float);
   if (kb.mode == 4 || g_fps_override.mode == 4) {
@@ -1194,7 +1544,7 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
     return pn2_check_launch();
   }
   const size_t head = (size_t)B * kCoopCloudBytes + 256;
-  float *tail = (plan.mode == 1 || plan.mode == 3) ? (float *)((char *)workspace + head) : (float *)workspace;
+  float *tail = (plan.mode == 1 || plan.mode == 3 || plan.mode == 5) ? (float *)((char *)workspace + head) : (float *)workspace;
   bool fits = true;
   if (plan.mode == 3) {
     u64 *slots = (u64 *)workspace;
@@ -1208,6 +1558,47 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
                          (const float4 *)nullptr);
       return pn2_check_launch();
     }
+  }
+  if (plan.mode == 5) {
+    u64 *slots = (u64 *)workspace;
+    int *status = (int *)((char *)workspace + (size_t)B * kCoopCloudBytes);
+    if (hipMemsetAsync(workspace, 0, head, s) != hipSuccess) return pn2_check_launch();
+    const dim3 grid((unsigned)(B * plan.G));
+    CoopSerial chain(s);
+    float4 *rec = (float4 *)((char *)workspace + head + fps_align256((size_t)B * (size_t)N * sizeof(float)));
+    hipLaunchKernelGGL(fps_bucket_kernel, dim3((unsigned)B), dim3(1024), 0, s, N, N, xyz, rec);
+#define PN2_FPS_MULTI(PPT, SUB)                                                                       \
+  {                                                                                                   \
+    auto kfn = fps_multi_kernel<PPT, SUB>;                                                            \
+    if ((fits = coop_fits((const void *)kfn, 1024, grid.x)))                                          \
+      hipLaunchKernelGGL(kfn, grid, dim3(1024), 0, s, B, N, m, L, plan.G, xyz, (const float4 *)rec,   \
+                         idxs, slots, status);                                                        \
+  }
+    if (plan.NC == 2) {
+      switch (plan.PPT) {
+        case 10: PN2_FPS_MULTI(10, 2); break;
+        case 12: PN2_FPS_MULTI(12, 2); break;
+        case 14: PN2_FPS_MULTI(14, 2); break;
+        case 16: PN2_FPS_MULTI(16, 2); break;
+        case 20: PN2_FPS_MULTI(20, 2); break;
+        case 24: PN2_FPS_MULTI(24, 2); break;
+        case 25: PN2_FPS_MULTI(25, 2); break;
+        case 26: PN2_FPS_MULTI(26, 2); break;
+        default: return PN2_EINVAL;
+      }
+    } else {
+      switch (plan.PPT) {
+        case 14: PN2_FPS_MULTI(14, 1); break;
+        case 16: PN2_FPS_MULTI(16, 1); break;
+        case 20: PN2_FPS_MULTI(20, 1); break;
+        case 24: PN2_FPS_MULTI(24, 1); break;
+        case 25: PN2_FPS_MULTI(25, 1); break;
+        case 26: PN2_FPS_MULTI(26, 1); break;
+        default: return PN2_EINVAL;
+      }
+    }
+#undef PN2_FPS_MULTI
+    if (fits) return pn2_check_launch();
   }
   if (plan.mode == 1) {
     u64 *slots = (u64 *)workspace;
@@ -1347,7 +1738,7 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
 extern "C" long long pn2_fps_status_offset(int B, int N, int m) {
   if (B <= 0 || N <= 0 || m <= 1) return -1;
   const FpsPlan p = fps_plan(B, N, m);
-  return (p.mode == 1 || p.mode == 3) ? (long long)((size_t)B * kCoopCloudBytes) : -1;
+  return (p.mode == 1 || p.mode == 3 || p.mode == 5) ? (long long)((size_t)B * kCoopCloudBytes) : -1;
 }
 
 // Test hook: status word of the last cooperative launch that used `workspace`

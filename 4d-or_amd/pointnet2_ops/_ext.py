@@ -38,8 +38,8 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.pn2_abi_version.restype = ctypes.c_int
-if int(_lib.pn2_abi_version()) != 4:
-    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 4: "
+if int(_lib.pn2_abi_version()) != 5:
+    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 5: "
                       f"rebuild it (`make -C {os.path.join(_PKG_DIR, 'csrc')}`)")
 
 _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -181,6 +181,12 @@ _lib.pn2_fps_get_bucketing.argtypes = []
 _lib.pn2_fps_get_bucketing.restype = _c_int
 if os.environ.get("PN2_FPS_BUCKETING") == "0":       # measurement switch (tools, A/B runs of bench.py)
     _lib.pn2_fps_set_bucketing(0)
+_lib.pn2_fps_set_multi.argtypes = [_c_int]
+_lib.pn2_fps_set_multi.restype = _c_int
+_lib.pn2_fps_get_multi.argtypes = []
+_lib.pn2_fps_get_multi.restype = _c_int
+if os.environ.get("PN2_FPS_MULTI") == "0":           # measurement switch: one sample per cluster hand-off (round 3)
+    _lib.pn2_fps_set_multi(0)
 _lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_supported.restype = _c_int
 _lib.pn2_mlp_bwd_bf16_supported.argtypes = [_c_int, _c_int]
@@ -203,9 +209,10 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 #: the header revision this binding was written against: a stale prebuilt libpn2_hip.so fails here with a version
 #: error instead of an AttributeError on the first missing symbol
-EXPECTED_ABI_VERSION = 4
+EXPECTED_ABI_VERSION = 5
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
+                                               "pn2_fps_set_multi", "pn2_fps_get_multi",
                                                "pn2_event_create", "pn2_event_record", "pn2_event_elapsed_ms", "pn2_event_destroy",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
@@ -402,7 +409,7 @@ def furthest_point_sampling(points, nsamples):
     return out
 
 
-_FPS_MODES = {None: -1, "resident": 0, "coop": 1, "stream": 2, "hybrid": 3, "bucketed": 4}
+_FPS_MODES = {None: -1, "resident": 0, "coop": 1, "stream": 2, "hybrid": 3, "bucketed": 4, "multi": 5}
 
 
 @contextlib.contextmanager
@@ -414,6 +421,17 @@ def fps_bucketing(on):
         yield
     finally:
         _lib.pn2_fps_set_bucketing(prev)        # what it was (PN2_FPS_BUCKETING=0 processes stay off)
+
+
+@contextlib.contextmanager
+def fps_multi(on):
+    """Measurement hook (pn2_fps_set_multi): several samples per cluster hand-off on / off.  Results never depend on it."""
+    prev = int(_lib.pn2_fps_get_multi())
+    _lib.pn2_fps_set_multi(1 if on else 0)
+    try:
+        yield
+    finally:
+        _lib.pn2_fps_set_multi(prev)
 
 
 @contextlib.contextmanager

@@ -88,7 +88,8 @@ int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *xyz,
  * must check it (the python binding asserts on the device, asynchronously). */
 long long pn2_fps_status_offset(int B, int N, int m);
 /* Test hook: force a kernel variant (mode: -1 heuristic | 0 resident | 1 cluster | 2 streaming | 3 cluster with a
- * streamed tail) and cluster shape (0 = heuristic).  Process-global; results never depend on it. */
+ * streamed tail | 4 one workgroup over the binned cloud | 5 cluster with several samples per hand-off) and cluster
+ * shape (0 = heuristic).  Process-global; results never depend on it. */
 int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, int bs);
 /* Cluster variants with >= 8 point slots per lane first bin the cloud into spatially compact groups of 64 x slots points
  * (one extra launch, records in the workspace) so that a wave can skip a round's distance updates when the new sample is
@@ -96,6 +97,12 @@ int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, int bs);
  * that off.  Process-global; results never depend on it. */
 int pn2_fps_set_bucketing(int on);
 int pn2_fps_get_bucketing(void);   /* the current value (1 / 0), so that a scoped override can restore it */
+/* Clouds of cluster size (16k < N <= 106k points) run on two or four 1024-thread workgroups that exchange the arg-max
+ * candidates of all 64 sub-blobs of the binned cloud per hand-off and accept SEVERAL samples from them whenever the next
+ * ones are provably the reference's.  Measurement hook: 0 restores one sample per hand-off.
+ * Process-global; results never depend on it. */
+int pn2_fps_set_multi(int on);
+int pn2_fps_get_multi(void);
 /* Test hook for the multi-workgroup FPS variant: returns the status word a
  * launch left in `workspace` (0 ok, 1 a bounded inter-workgroup wait expired,
  * <0 query failed).  Synchronises `stream`; never used on the hot path. */

@@ -140,6 +140,47 @@ def test_fps_multi_cloud_clusters_agree_with_oracle(ext, monkeypatch, nc, g, B, 
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("sub", [2, 1])
+@pytest.mark.parametrize("B,N,m,kind", [(2, 50000, 2048, "uniform"), (3, 50000, 700, "dup"), (2, 50000, 600, "zero_tail"),
+                                        (2, 30000, 300, "grid"), (32, 50000, 64, "uniform"), (2, 16500, 400, "uniform"),
+                                        (3, 20481, 257, "dup"), (2, 53248, 128, "uniform"), (1, 41000, 41000 // 16, "grid")])
+def test_fps_several_samples_per_hand_off_agree_with_oracle(ext, sub, B, N, m, kind):
+    """fps_multi_kernel (csrc/fps.hip, round 4): two 1024-thread workgroups per cloud exchange the arg-max candidates of
+    all sub-blobs per hand-off and accept every further sample that is provably the reference's next one.  64 sub-blobs
+    (two per wave) and 32 (one per wave); uniform clouds, duplicates (ties decided by the reference's rank), skipped
+    points, lattice ties, long runs (2048 samples = hundreds of hand-offs with 1..8 accepted samples each)."""
+    xyz = clouds(B, N, kind, seed=N + B + sub)
+    want = O.furthest_point_sampling(xyz, m)
+    with ext.fps_plan_override(mode="multi", nc=sub):
+        got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("B,N,m,kind", [(2, 60000, 500, "uniform"), (2, 100000, 300, "dup"), (1, 106496, 200, "zero_tail"),
+                                        (3, 53249, 300, "grid")])
+def test_fps_several_samples_four_workgroups_per_cloud(ext, B, N, m, kind):
+    """... and four workgroups per cloud (53k < N <= 106k points: one sub-blob per wave, 64 per cloud)."""
+    xyz = clouds(B, N, kind, seed=N + B)
+    want = O.furthest_point_sampling(xyz, m)
+    with ext.fps_plan_override(mode="multi"):
+        got = ext.furthest_point_sampling(dev(xyz), m).cpu()
+    assert torch.equal(got, want)
+
+
+def test_fps_multi_is_the_default_for_cluster_sized_clouds_and_can_be_switched_off(ext):
+    xyz = clouds(2, 50000, "uniform", seed=77)
+    want = O.furthest_point_sampling(xyz, 300)
+    for on in (True, False):
+        with ext.fps_multi(on):
+            assert torch.equal(ext.furthest_point_sampling(dev(xyz), 300).cpu(), want)
+            with ext.background_geometry(fewest=True):
+                assert torch.equal(ext.furthest_point_sampling(dev(xyz), 300).cpu(), want)
+    # degenerate: no valid point at all -> index 0 for every sample (sampling_gpu.cu:90-91), one per hand-off
+    z = torch.full((2, 20000, 3), 0.001)
+    with ext.fps_plan_override(mode="multi"):
+        assert torch.equal(ext.furthest_point_sampling(dev(z), 9).cpu(), torch.zeros(2, 9, dtype=torch.int32))
+
+
 def test_fps_all_skipped_and_m_zero(ext):
     xyz = torch.full((2, 700, 3), 0.001)
     assert torch.equal(ext.furthest_point_sampling(dev(xyz), 5).cpu(), torch.zeros(2, 5, dtype=torch.int32))
