@@ -33,7 +33,7 @@ struct LiftFwdArgs {
   const int *idx;        // (B, m, ns)
   const float *P;        // (B N, N0)   per-point products f Wf^T
   const float *Wx;       // (N0, 3)     coordinate columns of the first conv
-  float *Y;              // (B m ns, N0)
+  void *Y;               // (B m ns, N0) fp32, or bf16 (the mixed-precision stacks: the next layer's bf16 MFMA reads it)
   double *stats;         // (2, N0) += column sums of y0, y0^2 (or null)
   int N, m, ns, N0, normalize;
   float radius;
@@ -44,7 +44,13 @@ struct LiftFwdArgs {
 // centre at a time: lane s first resolves slot s (index + relative coordinates), the rows then stream R at a time with
 // four 16-byte gathers of P in flight per lane.  Workgroups walk the centres in the XCD-aware order of the ball query
 // (XCD x takes the x-th eighth: a cloud's P rows — 1 MB at SA2 — stay in one L2).
-template <int R>
+// bf16 rows: round to nearest even, like the epilogue of mlp_gemm_bf16 (whose statistics are those of the ROUNDED values too)
+__device__ __forceinline__ unsigned lift_bf_pack(float lo, float hi) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+}
+__device__ __forceinline__ float lift_bf_round(float f) { return (float)(__bf16)f; }
+
+template <int R, bool BF>
 __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_kernel(const LiftFwdArgs a) {
   constexpr int LPR = 64 / R;
   __shared__ float red[2][4][4 * LPR];
@@ -73,7 +79,8 @@ __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_kernel(const LiftF
     const float *X = a.xyz + (size_t)b * a.N * 3;
     const float *Pb = a.P + (size_t)b * a.N * N0;
     const int *row_idx = a.idx + (size_t)g * ns;
-    float *Yg = a.Y + (size_t)g * ns * N0;
+    float *Yg = (float *)a.Y + (size_t)g * ns * N0;                       // (fp32 rows)
+    uint2 *Yh = (uint2 *)a.Y + (size_t)g * ns * (N0 >> 2);                // (bf16 rows: four columns = 8 bytes per lane)
     for (int s0 = 0; s0 < ns; s0 += 64) {
       const int cnt = ns - s0 < 64 ? ns - s0 : 64;
       int mi = 0;
@@ -105,10 +112,14 @@ __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_kernel(const LiftF
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             y[c] = __fmaf_rn(wx2[c], ez[u], __fmaf_rn(wx1[c], ey[u], __fmaf_rn(wx0[c], ex[u], v[u][c])));
+            if constexpr (BF) y[c] = lift_bf_round(y[c]);
             s1[c] = __fadd_rn(s1[c], y[c]);
             s2[c] = __fmaf_rn(y[c], y[c], s2[c]);
           }
-          *reinterpret_cast<f4v *>(Yg + (size_t)(s0 + (t + u) * R + sub) * N0 + 4 * l) = y;
+          if constexpr (BF)
+            Yh[(size_t)(s0 + (t + u) * R + sub) * (N0 >> 2) + l] = uint2{lift_bf_pack(y[0], y[1]), lift_bf_pack(y[2], y[3])};
+          else
+            *reinterpret_cast<f4v *>(Yg + (size_t)(s0 + (t + u) * R + sub) * N0 + 4 * l) = y;
         }
       }
     }
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_kernel(const LiftF
 struct LiftBwdArgs {
   const float *xyz;      // (B, N, 3)
   const float *new_xyz;  // (B m, 3)
-  const float *G;        // (M, N0)  masked gradient dL/dz0 the layer above left
+  const void *G;         // (M, N0)  masked gradient dL/dz0 the layer above left: fp32, or bf16 (mixed-precision stacks)
   const float *P;        // (B N, N0) per-point products of the forward
   const float *Wx;       // (N0, 3)
   const float *consts;   // (3, N0)  c1 | c2 | c3 of BatchNorm's backward
@@ -180,7 +191,7 @@ __device__ __forceinline__ float lift_wave_sum(float v) {
 // rows on one point, none on most — and a wave per point leaves the kernel waiting for a few long serial walks (0.25 ms
 // for 77 MB).  Points with more than kLiftHeavy rows are only listed by the first pass (their S row zeroed) and walked by
 // kLiftSplit waves each in the second.
-template <int R>
+template <int R, bool BF>
 __device__ __forceinline__ void lift_walk(const LiftBwdArgs &a, unsigned n, int p0, int p1, bool add, f4v &dx, f4v &dy, f4v &dz,
                                           f4v &ex_, f4v &ey_, f4v &ez_, float (&rr)[6]) {
   constexpr int LPR = 64 / R;
@@ -214,7 +225,15 @@ __device__ __forceinline__ void lift_walk(const LiftBwdArgs &a, unsigned n, int 
         const int r = __shfl(myref, src);
         ex[u] = __shfl(rx, src); ey[u] = __shfl(ry, src); ez[u] = __shfl(rz, src);   // (0 beyond cnt: those rows add nothing)
         g[u] = f4v{0.f, 0.f, 0.f, 0.f};
-        if (i < cnt && live) g[u] = *reinterpret_cast<const f4v *>(a.G + (size_t)r * N0 + 4 * l);
+        if (i < cnt && live) {
+          if constexpr (BF) {
+            const uint2 w = reinterpret_cast<const uint2 *>(a.G)[(size_t)r * (N0 >> 2) + l];
+            g[u] = f4v{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xFFFF0000u),
+                       __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xFFFF0000u)};
+          } else {
+            g[u] = *reinterpret_cast<const f4v *>((const float *)a.G + (size_t)r * N0 + 4 * l);
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -323,7 +342,7 @@ __global__ __launch_bounds__(256) void lift_reduce_kernel(const float *__restric
 }
 
 // pass 1: a wave per point (like group_rows_grad_csr_kernel); heavy points are listed, their S row zeroed
-template <int R>
+template <int R, bool BF>
 __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_kernel(const LiftBwdArgs a) {
   constexpr int LPR = 64 / R;
   __shared__ float red[3][4][256];
@@ -340,13 +359,13 @@ __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_kernel(const 
       if (lane < LPR && 4 * l < a.N0) *reinterpret_cast<f4v *>(a.S + (size_t)n * a.N0 + 4 * l) = f4v{0.f, 0.f, 0.f, 0.f};
       continue;
     }
-    lift_walk<R>(a, n, p0, p1, false, dx, dy, dz, ex_, ey_, ez_, rr);
+    lift_walk<R, BF>(a, n, p0, p1, false, dx, dy, dz, ex_, ey_, ez_, rr);
   }
   lift_flush<R>(a, blockIdx.x, dx, dy, dz, ex_, ey_, ez_, rr, red, rrs);
 }
 
 // pass 2: kLiftSplit waves per heavy point, each a contiguous slice of its rows, results added
-template <int R>
+template <int R, bool BF>
 __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_heavy_kernel(const LiftBwdArgs a, unsigned row0) {
   __shared__ float red[3][4][256];
   __shared__ float rrs[4][16];
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_heavy_kernel(
     const int per = ((p1 - p0 + kLiftSplit - 1) / kLiftSplit + 63) & ~63;     // slices of whole 64-row batches
     const int q0 = p0 + k * per, q1 = q0 + per < p1 ? q0 + per : p1;
     if (q0 >= p1) continue;
-    lift_walk<R>(a, n, q0, q1, true, dx, dy, dz, ex_, ey_, ez_, rr);
+    lift_walk<R, BF>(a, n, q0, q1, true, dx, dy, dz, ex_, ey_, ez_, rr);
   }
   lift_flush<R>(a, row0 + blockIdx.x, dx, dy, dz, ex_, ey_, ez_, rr, red, rrs);
 }
@@ -372,9 +391,9 @@ bool lift_shape_ok(int N0) { return N0 >= 16 && N0 <= 256 && (N0 & 3) == 0; }
 
 extern "C" int pn2_group_lift_supported(int N0) { return lift_shape_ok(N0) ? 1 : 0; }
 
-extern "C" int pn2_group_lift_rows(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
-                                   const float *new_xyz, const int *idx, const float *P, const float *Wx, float *Y,
-                                   double *stats, void *stream) {
+namespace {
+int lift_rows_launch(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz, const float *new_xyz,
+                     const int *idx, const float *P, const float *Wx, void *Y, bool bf, double *stats, void *stream) {
   if (B < 0 || N < 0 || m < 0 || ns < 0) return PN2_EINVAL;
   if (!lift_shape_ok(N0) || (normalize && !(radius > 0.f))) return PN2_EINVAL;
   const long long centres = (long long)B * m;
@@ -391,10 +410,31 @@ extern "C" int pn2_group_lift_rows(int B, int N, int m, int ns, int N0, int norm
   nwg = nwg < 1 ? 1 : (nwg > 256 ? 256 : nwg);
   const dim3 grid((unsigned)(nwg * 8)), block(kLiftBlock);
   hipStream_t s = (hipStream_t)stream;
-  if (N0 <= 64) hipLaunchKernelGGL(group_lift_rows_kernel<4>, grid, block, 0, s, a);
-  else if (N0 <= 128) hipLaunchKernelGGL(group_lift_rows_kernel<2>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(group_lift_rows_kernel<1>, grid, block, 0, s, a);
+  if (bf) {
+    if (N0 <= 64) hipLaunchKernelGGL((group_lift_rows_kernel<4, true>), grid, block, 0, s, a);
+    else if (N0 <= 128) hipLaunchKernelGGL((group_lift_rows_kernel<2, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((group_lift_rows_kernel<1, true>), grid, block, 0, s, a);
+  } else {
+    if (N0 <= 64) hipLaunchKernelGGL((group_lift_rows_kernel<4, false>), grid, block, 0, s, a);
+    else if (N0 <= 128) hipLaunchKernelGGL((group_lift_rows_kernel<2, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((group_lift_rows_kernel<1, false>), grid, block, 0, s, a);
+  }
   return pn2_check_launch();
+}
+}  // namespace
+
+extern "C" int pn2_group_lift_rows(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                                   const float *new_xyz, const int *idx, const float *P, const float *Wx, float *Y,
+                                   double *stats, void *stream) {
+  return lift_rows_launch(B, N, m, ns, N0, normalize, radius, xyz, new_xyz, idx, P, Wx, Y, false, stats, stream);
+}
+
+// ... with bf16 rows (the mixed-precision stacks): Y (B m ns, N0) bf16, rounded to nearest even; `stats` are the column sums of
+// the ROUNDED values (the convention of pn2_mlp_gemm_bf16)
+extern "C" int pn2_group_lift_rows_bf16(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                                        const float *new_xyz, const int *idx, const float *P, const float *Wx, void *Y,
+                                        double *stats, void *stream) {
+  return lift_rows_launch(B, N, m, ns, N0, normalize, radius, xyz, new_xyz, idx, P, Wx, Y, true, stats, stream);
 }
 
 namespace {
@@ -415,10 +455,11 @@ extern "C" size_t pn2_group_lift_rows_grad_workspace_bytes(int B, int N, int m, 
   return lift_heavy_bytes(B, m, ns) + (size_t)(lift_grid1((size_t)B * N) + kLiftGrid2) * (3 * N0 + 16) * sizeof(float);
 }
 
-extern "C" int pn2_group_lift_rows_grad(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
-                                        const float *new_xyz, const float *G, const float *P, const float *Wx,
-                                        const float *consts, const int *ptr, const int *refs, float *S, float *acc,
-                                        void *workspace, size_t workspace_bytes, void *stream) {
+namespace {
+int lift_rows_grad_launch(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                          const float *new_xyz, const void *G, bool bf, const float *P, const float *Wx, const float *consts,
+                          const int *ptr, const int *refs, float *S, float *acc, void *workspace, size_t workspace_bytes,
+                          void *stream) {
   if (B < 0 || N < 0 || m < 0 || ns <= 0) return PN2_EINVAL;
   if (!lift_shape_ok(N0) || (normalize && !(radius > 0.f))) return PN2_EINVAL;
   const size_t npoints = (size_t)B * N;
@@ -433,14 +474,34 @@ extern "C" int pn2_group_lift_rows_grad(int B, int N, int m, int ns, int N0, int
   LiftBwdArgs a{xyz, new_xyz, G, P, Wx, consts, ptr, refs, S, part, (int *)workspace, ns, N0, normalize ? 1 : 0, radius,
                 (unsigned)npoints};
   const unsigned grid = lift_grid1(npoints);
-#define PN2_LIFT(RR_)                                                                                                  \
-  do {                                                                                                                 \
-    hipLaunchKernelGGL(group_lift_rows_grad_kernel<RR_>, dim3(grid), dim3(kLiftBlock), 0, s, a);                       \
-    hipLaunchKernelGGL(group_lift_rows_grad_heavy_kernel<RR_>, dim3(kLiftGrid2), dim3(kLiftBlock), 0, s, a, grid);     \
+#define PN2_LIFT(RR_, BF_)                                                                                                  \
+  do {                                                                                                                      \
+    hipLaunchKernelGGL((group_lift_rows_grad_kernel<RR_, BF_>), dim3(grid), dim3(kLiftBlock), 0, s, a);                     \
+    hipLaunchKernelGGL((group_lift_rows_grad_heavy_kernel<RR_, BF_>), dim3(kLiftGrid2), dim3(kLiftBlock), 0, s, a, grid);   \
   } while (0)
-  if (N0 <= 64) PN2_LIFT(4); else if (N0 <= 128) PN2_LIFT(2); else PN2_LIFT(1);
+  if (bf) { if (N0 <= 64) PN2_LIFT(4, true); else if (N0 <= 128) PN2_LIFT(2, true); else PN2_LIFT(1, true); }
+  else { if (N0 <= 64) PN2_LIFT(4, false); else if (N0 <= 128) PN2_LIFT(2, false); else PN2_LIFT(1, false); }
 #undef PN2_LIFT
   hipLaunchKernelGGL(lift_reduce_kernel, dim3((unsigned)(3 * N0 + 9)), dim3(256), 0, s, part, (int)(grid + kLiftGrid2),
                      3 * N0 + 9, 3 * N0 + 16, acc);
   return pn2_check_launch();
+}
+}  // namespace
+
+extern "C" int pn2_group_lift_rows_grad(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                                        const float *new_xyz, const float *G, const float *P, const float *Wx,
+                                        const float *consts, const int *ptr, const int *refs, float *S, float *acc,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+  return lift_rows_grad_launch(B, N, m, ns, N0, normalize, radius, xyz, new_xyz, G, false, P, Wx, consts, ptr, refs, S, acc,
+                               workspace, workspace_bytes, stream);
+}
+
+// ... with the masked gradient G (M, N0) in bf16 (what pn2_mlp_bwd_bf16 / pn2_mlp_gemm_bf16 leave for the layer below);
+// everything that is summed stays fp32
+extern "C" int pn2_group_lift_rows_grad_bf16(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                                             const float *new_xyz, const void *G, const float *P, const float *Wx,
+                                             const float *consts, const int *ptr, const int *refs, float *S, float *acc,
+                                             void *workspace, size_t workspace_bytes, void *stream) {
+  return lift_rows_grad_launch(B, N, m, ns, N0, normalize, radius, xyz, new_xyz, G, true, P, Wx, consts, ptr, refs, S, acc,
+                               workspace, workspace_bytes, stream);
 }

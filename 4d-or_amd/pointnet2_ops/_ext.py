@@ -68,6 +68,8 @@ _SIGNATURES = {
     "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_lift_rows": [_c_int] * 6 + [_c_f32] + [_c_vp] * 8,
     "pn2_group_lift_rows_grad": [_c_int] * 6 + [_c_f32] + [_c_vp] * 11 + [_c_sz, _c_vp],
+    "pn2_group_lift_rows_bf16": [_c_int] * 6 + [_c_f32] + [_c_vp] * 8,
+    "pn2_group_lift_rows_grad_bf16": [_c_int] * 6 + [_c_f32] + [_c_vp] * 11 + [_c_sz, _c_vp],
     "pn2_group_rows_grad_csr_bf16": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_rows_grad_bf16": [_c_int] * 7 + [_c_vp] * 4,
     "pn2_rows_max": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -715,21 +717,22 @@ def group_lift_supported(n0) -> bool:
     return bool(_lib.pn2_group_lift_supported(int(n0)))
 
 
-def group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, radius, stats=None):
+def group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, radius, stats=None, out_bf16=False):
     """The first conv of an SA stack applied BEFORE the grouping: P (B,N,N0) = per-point products f Wf^T, Wx (N0,3) the
     coordinate columns -> Y0 (B*m*ns, N0) = P[idx] + Wx rel, rel = (xyz[idx] - new_xyz) (/ radius); `stats` (2,N0) f64 +=
     column sums of y0 and y0^2.  Replaces group_points x 2 + cat + Conv2d 1x1 of the first layer
-    (EXT/src/group_points_gpu.cu:8-28, OPS/pointnet2_utils.py:317-328, OPS/pointnet2_modules.py:9-19)."""
+    (EXT/src/group_points_gpu.cu:8-28, OPS/pointnet2_utils.py:317-328, OPS/pointnet2_modules.py:9-19).
+    `out_bf16`: Y0 in bf16 (mixed-precision stacks; the statistics are those of the rounded values)."""
     _f32(P, "P"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _i32(idx, "idx"); _f32(Wx, "Wx")
     _same_device((P, "P"), (xyz, "xyz"), (new_xyz, "new_xyz"), (idx, "idx"), (Wx, "Wx"), (stats, "stats"))
     B, m, ns = idx.shape
     N, N0 = xyz.size(1), P.size(-1)
     if P.numel() != B * N * N0 or tuple(Wx.shape) != (N0, 3) or tuple(new_xyz.shape) != (B, m, 3):
         _fail("group_lift_rows: P must be (B, N, N0), Wx (N0, 3), new_xyz (B, m, 3)")
-    Y = torch.empty(B * m * ns, N0, dtype=torch.float32, device=P.device)
-    _call("pn2_group_lift_rows", P, B, N, m, ns, N0, int(bool(normalize)), float(radius if radius is not None else 1.0),
+    Y = torch.empty(B * m * ns, N0, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=P.device)
+    _call("pn2_group_lift_rows_bf16" if out_bf16 else "pn2_group_lift_rows", P, B, N, m, ns, N0, int(bool(normalize)), float(radius if radius is not None else 1.0),
           _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(P), _ptr(Wx), _ptr(Y), _ptr(stats),
-          alg_bytes=B * (4 * m * ns + 12 * N + 12 * m + 4 * N0 * N + 4 * N0 * m * ns))
+          alg_bytes=B * (4 * m * ns + 12 * N + 12 * m + 4 * N0 * N + (2 if out_bf16 else 4) * N0 * m * ns))
     return Y
 
 
@@ -737,7 +740,13 @@ def group_lift_rows_grad(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, rad
     """Backward of group_lift_rows behind a BatchNorm (include/pn2_hip.h): G (M,N0) masked gradient of the layer above, P
     (B,N,N0) / Wx (N0,3) of the forward, consts (3,N0), inv = (ptr, refs) -> S (B,N,N0) = sum over the rows that gathered each
     point of dL/dy0 = c1 g + c2 y0 + c3;  `acc` (3*N0 + 9) f32 <- [dWx (N0,3) without its c2 Wx RR term | RR (3,3)]."""
-    _f32(G, "G"); _f32(P, "P"); _f32(Wx, "Wx"); _f32(consts, "consts"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(acc, "acc")
+    bf = G.dtype == torch.bfloat16           # (mixed-precision stacks: the layer above leaves its masked gradient in bf16)
+    if bf:
+        if not G.is_contiguous() or not G.is_cuda:
+            _fail("group_lift_rows_grad: G must be a contiguous device tensor")
+    else:
+        _f32(G, "G")
+    _f32(P, "P"); _f32(Wx, "Wx"); _f32(consts, "consts"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(acc, "acc")
     ptr, refs = inv
     _i32(ptr, "ptr"); _i32(refs, "refs")
     _same_device((G, "G"), (P, "P"), (Wx, "Wx"), (consts, "consts"), (xyz, "xyz"), (new_xyz, "new_xyz"), (ptr, "ptr"),
@@ -752,10 +761,10 @@ def group_lift_rows_grad(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, rad
     S = torch.empty(B, N, N0, dtype=torch.float32, device=G.device)
     ws_bytes = int(_lib.pn2_group_lift_rows_grad_workspace_bytes(B, N, m, ns, N0))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
-    _call("pn2_group_lift_rows_grad", G, B, N, m, ns, N0, int(bool(normalize)), float(radius if radius is not None else 1.0),
+    _call("pn2_group_lift_rows_grad_bf16" if bf else "pn2_group_lift_rows_grad", G, B, N, m, ns, N0, int(bool(normalize)), float(radius if radius is not None else 1.0),
           _ptr(xyz), _ptr(new_xyz), _ptr(G), _ptr(P), _ptr(Wx), _ptr(consts), _ptr(ptr), _ptr(refs), _ptr(S),
           _ptr(acc), _ptr(ws), ws_bytes,
-          alg_bytes=8 * M + 4 * M * N0 + 4 * B * N * (2 * N0 + 4) + 12 * B * m)
+          alg_bytes=8 * M + (2 if bf else 4) * M * N0 + 4 * B * N * (2 * N0 + 4) + 12 * B * m)
     return S
 
 

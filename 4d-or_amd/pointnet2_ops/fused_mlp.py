@@ -57,6 +57,9 @@ LIFT_FIRST = _os.environ.get("PN2_LIFT_FIRST") != "0"
 #: few points own hundreds of rows — the backward walks those with sixteen waves each), the inverse index built in the step:
 #: 8 scans per step, whole-batch statistics, fp32: 169 -> 242 scans/s.  PN2_LIFT_SPARSE=0 restores the grouped route (A/B).
 LIFT_SPARSE = _os.environ.get("PN2_LIFT_SPARSE") != "0"
+#: ... and on the bf16 node (same kernels with bf16 rows: y0 and the gradient rows in bf16, per-point products and every sum
+#: in fp32).  PN2_BF16_LIFT=0 restores the grouped bf16 route (A/B).
+BF16_LIFT = _os.environ.get("PN2_BF16_LIFT") != "0"
 
 #: arithmetic of the shared-MLP stacks.  float32 = exact fp32 MFMA (the parity path, default).  bfloat16 = the MI355X
 #: counterpart of the reference's 16-bit AMP training (scene_graph_prediction/main.py:64 `precision=16`): activations
@@ -440,7 +443,7 @@ def _unit_consts(device, n):
     return t
 
 
-def _lift_forward(e, feats, W, group, stats):
+def _lift_forward(e, feats, W, group, stats, out_bf16=False):
     """y0 (B m ns, N0) of a grouped stack's first layer without the grouped rows: P = f Wf^T over the B N points (a plain
     fp32 GEMM), then the gather + coordinate terms + column sums in one kernel (pn2_group_lift_rows)."""
     xyz, new_xyz, idx, _use_xyz, normalize, radius = group[:6]
@@ -448,7 +451,7 @@ def _lift_forward(e, feats, W, group, stats):
     # (the library's own fp32-MFMA GEMM: bit-reproducible from call to call, which a vendor GEMM's kernel choice is not)
     P = e.mlp_gemm(feats.view(B * N, C), W[:, 3:].contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
     # (P travels to the backward as an attribute: 1/16 of y0's size, and the backward recomputes y0 from it)
-    return e.group_lift_rows(P, xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stats=stats), P
+    return e.group_lift_rows(P, xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stats=stats, out_bf16=out_bf16), P
 
 
 class _FusedMLPBf16(Function):
@@ -459,26 +462,42 @@ class _FusedMLPBf16(Function):
     def forward(ctx, x, ns, layers, group, *params):
         e = _ext()
         ctx.group = group
+        seg = getattr(ctx, "seg", None)
+        lift = False
+        feats = None
+        ctx.lift_inv = None
         if group is not None:
             xyz, new_xyz, idx, use_xyz, normalize, radius = group[:6]
             ctx.feat_shape = None if x is None else tuple(x.shape)
             k_in = (3 if use_xyz else 0) + (0 if x is None else x.size(2))
             pre = getattr(ctx, "x_rows", None)          # a segmented call groups the whole batch once and hands in the rows
-            if pre is None:
-                pre = e.group_concat_rows_bf16(xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz, normalize,
-                                               radius)
-            x = pre.view(-1, pre.size(-1))                                  # (M, pad8(k_in)) bf16, zero pad columns
+            # first layer before the grouping, as on the fp32 node (csrc/group_lift.hip): per-point products in fp32, y0 and
+            # the gradient rows in bf16 — no grouped tensor, no M-row first-layer GEMMs, no feature-gradient scatter
+            has_inv = len(group) > 6 and group[6] is not None
+            crowded = len(group) > 7 and bool(group[7])
+            lift = bool(BF16_LIFT and pre is None and seg is None and _lift_eligible(e, layers, use_xyz, x)
+                        and (not any(ctx.needs_input_grad) or has_inv or crowded or LIFT_SPARSE))
+            if lift:
+                if any(ctx.needs_input_grad) and not has_inv:
+                    ctx.lift_inv = tuple(e.group_inverse_index(idx, xyz.size(1)))      # (not prefetched: built here)
+                feats = x.contiguous()
+                x = None
+            else:
+                if pre is None:
+                    pre = e.group_concat_rows_bf16(xyz, new_xyz, None if x is None else x.contiguous(), idx, use_xyz,
+                                                   normalize, radius)
+                x = pre.view(-1, pre.size(-1))                              # (M, pad8(k_in)) bf16, zero pad columns
         else:
             x = x.contiguous()                                              # fp32 rows of any width
             k_in = x.size(1)
-        M = x.size(0)
+        M = idx.numel() if lift else x.size(0)
         L = len(layers)
         ys, fins, batch_flags = [], [], []
         # segment table (a _SegTableMLP call): the rows are S scans with their own batch statistics — every per-channel
         # buffer gets a leading scan dimension and each kernel walks the scans in its grid (csrc: pn2_*_seg)
-        seg = getattr(ctx, "seg", None)
         lead = () if seg is None else (seg.nseg,)
-        stat_bufs = e.zero_arena(x.device, [(lead + (2, conv.out_channels), torch.float64) for conv, _ in layers])
+        stat_bufs = e.zero_arena((feats if lift else x).device,
+                                 [(lead + (2, conv.out_channels), torch.float64) for conv, _ in layers])
         cur = x
         for l, (conv, bn) in enumerate(layers):
             W = params[3 * l].view(conv.out_channels, conv.in_channels)
@@ -498,7 +517,10 @@ class _FusedMLPBf16(Function):
                 fin = e.bn_finalize_seg(stat_bufs[l], seg, gamma, beta, bn.eps, 0.0 if rm is None else bn.momentum, rm, rv, nbt)
             elif use_batch:
                 stats = stat_bufs[l]
-                y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
+                if lift and l == 0:
+                    y, ctx.lift_P = _lift_forward(e, feats, W, group, stats, out_bf16=True)
+                else:
+                    y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
                 momentum = 0.0
                 rm = rv = nbt = None
                 if (bn.training and bn.track_running_stats and bn.running_mean is not None
@@ -513,7 +535,10 @@ class _FusedMLPBf16(Function):
                 fo = getattr(ctx, "fin_out", None)          # segmented call: this scan's block of the layer's (S,4,C) buffer
                 fin = e.bn_finalize(stats, M, gamma, beta, bn.eps, momentum, rm, rv, nbt, out=None if fo is None else fo[l])
             else:
-                y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
+                if lift and l == 0:
+                    y, ctx.lift_P = _lift_forward(e, feats, W, group, None, out_bf16=True)
+                else:
+                    y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_NONE, p=p)
                 rstd = torch.rsqrt(bn.running_var + bn.eps)
                 scale = gamma * rstd
                 fin = torch.stack([bn.running_mean, rstd, scale, beta - bn.running_mean * scale]).contiguous()
@@ -529,8 +554,9 @@ class _FusedMLPBf16(Function):
         else:
             out, arg = e.bn_relu_apply_bf16(ys[-1], fins[-1]), None
         ctx.ns, ctx.L, ctx.batch_flags, ctx.k_in = ns, L, batch_flags, k_in
+        ctx.lift, ctx.M = lift, M
         ctx.shapes = [params[3 * l].shape for l in range(L)]
-        saved = [x] + ys + fins + [params[3 * l] for l in range(L)] + [params[3 * l + 1] for l in range(L)]
+        saved = [feats if lift else x] + ys + fins + [params[3 * l] for l in range(L)] + [params[3 * l + 1] for l in range(L)]
         if ns:
             saved += [out, arg, yraw]
             ctx.mark_non_differentiable(arg)
@@ -547,7 +573,8 @@ class _FusedMLPBf16(Function):
         fins = saved[1 + L:1 + 2 * L]
         Ws = [w.view(w.size(0), w.size(1)) for w in saved[1 + 2 * L:1 + 3 * L]]
         gammas = saved[1 + 3 * L:1 + 4 * L]
-        M = x.size(0)
+        lift = getattr(ctx, "lift", False)            # saved[0] is then the point-major fp32 feature tensor, not grouped rows
+        M = ctx.M if lift else x.size(0)
         g_out = g_out.contiguous()
         f64, f32 = torch.float64, torch.float32
         need_dgrad0 = ctx.needs_input_grad[0] and (ctx.group is None or ctx.feat_shape is not None)
@@ -556,14 +583,15 @@ class _FusedMLPBf16(Function):
         k_in = ctx.k_in
         seg = getattr(ctx, "seg", None)
         lead = () if seg is None else (seg.nseg,)
-        fold = bool(BF16_FOLD and seg is None and L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0]
+        fold = bool(BF16_FOLD and not lift and seg is None and L >= 2 and FUSED_BACKWARD and not need_dgrad0 and ctx.batch_flags[0]
                     and x.dtype == torch.bfloat16 and x.size(1) == 8 and k_in <= 8
                     and getattr(e, "mlp_bwd_bf16_fold", None)
                     and e.mlp_bwd_bf16_fold_supported(Ws[1].size(0), Ws[1].size(1), k_in))
         arena = e.zero_arena(x.device, [(lead + (2, Ws[-1].size(0)), f64)] +
                              [(lead + (2, Ws[l].size(1)), f64) for l in range(L)] +
                              [(tuple(Ws[l].shape), f32) for l in range(L)] +
-                             ([((Ws[0].size(0), k_in), f32), ((k_in * k_in + k_in,), f64)] if fold else []))
+                             ([((Ws[0].size(0), k_in), f32), ((k_in * k_in + k_in,), f64)] if fold else []) +
+                             ([((3 * Ws[0].size(0) + 9,), f32)] if lift else []))
         sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:1 + 2 * L]
         if ns:
             pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
@@ -577,6 +605,29 @@ class _FusedMLPBf16(Function):
         grads = [None] * (3 * L)
         gx = None
         for l in range(L - 1, -1, -1):
+            if l == 0 and lift:
+                # first layer applied before the grouping: per-point sums of dL/dy0 (bf16 gradient rows, fp32 sums) through
+                # the inverse index, then fp32 GEMMs over the B N points — the fp32 node's code (csrc/group_lift.hip)
+                consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[0], fins[0], ctx.batch_flags[0])
+                grads[1], grads[2] = dgamma, dbeta
+                if gmode != e.PRO_GY or G is None:
+                    raise RuntimeError("fused_mlp: the lifted first layer expects the dense gradient of the layer above")
+                xyz, new_xyz, idx, _u, normalize, radius = ctx.group[:6]
+                N0, Kf = Ws[0].size(0), Ws[0].size(1) - 3
+                inv = ctx.group[6] if (len(ctx.group) > 6 and ctx.group[6] is not None) else ctx.lift_inv
+                Wx = Ws[0][:, :3].contiguous()
+                S = e.group_lift_rows_grad(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2), normalize,
+                                           radius, arena[-1]).view(-1, N0)
+                dWx = torch.addcmul(arena[-1][:3 * N0].view(N0, 3), torch.mm(Wx, arena[-1][3 * N0:].view(3, 3)),
+                                    consts[1].unsqueeze(1))
+                dWf = e.mlp_wgrad(S, _unit_consts(S.device, N0), x.view(-1, Kf), e.PRO_GY, e.PRO_NONE, G=S)
+                grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
+                if need_dgrad0:
+                    gx = e.mlp_gemm(S, Ws[0][:, 3:].t().contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(ctx.feat_shape)
+                    dst = getattr(ctx, "gx_out", None)
+                    if dst is not None:
+                        gx = dst.copy_(gx)
+                continue
             need_dgrad = l > 0 or need_dgrad0
             k0 = 3 if (l == 0 and ctx.group is not None and ctx.group[3]) else 0
             if seg is not None:
@@ -624,7 +675,7 @@ class _FusedMLPBf16(Function):
                     rows_bf16 = ctx.group is not None and Wt.size(0) % 4 == 0
                     gx = e.mlp_gemm_bf16(G, Wt, pro=gmode, epi=e.EPI_NONE, X2=ys[l], p=p, arg=arg, gP=gPm, ns=ns, M=M,
                                          out_f32=not rows_bf16, seg=seg)
-        if gx is not None and ctx.group is not None:
+        if gx is not None and ctx.group is not None and not lift:
             idx = ctx.group[2]
             Bq, npoint, nsample = idx.shape
             Bf, Nf, Cf = ctx.feat_shape

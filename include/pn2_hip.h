@@ -269,6 +269,16 @@ int pn2_group_lift_rows_grad(int B, int N, int m, int ns, int N0, int normalize,
                              const int *ptr, const int *refs, float *S, float *acc, void *workspace,
                              size_t workspace_bytes, void *stream);
 size_t pn2_group_lift_rows_grad_workspace_bytes(int B, int N, int m, int ns, int N0);
+/* The same pair for the mixed-precision stacks (round 4): Y (B m ns, N0) bf16 (rounded to nearest even; `stats` are the
+ * column sums of the rounded values, the convention of pn2_mlp_gemm_bf16) and G (M, N0) bf16 (what pn2_mlp_bwd_bf16 /
+ * pn2_mlp_gemm_bf16 leave for the layer below); P, S, every sum and the weight-gradient terms stay fp32. */
+int pn2_group_lift_rows_bf16(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                             const float *new_xyz, const int *idx, const float *P, const float *Wx, void *Y, double *stats,
+                             void *stream);
+int pn2_group_lift_rows_grad_bf16(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                                  const float *new_xyz, const void *G, const float *P, const float *Wx, const float *consts,
+                                  const int *ptr, const int *refs, float *S, float *acc, void *workspace,
+                                  size_t workspace_bytes, void *stream);
 
 /* pn2_rows_max / pn2_rows_max_grad: F.max_pool2d(kernel=[1,ns]) of
  *   OPS/pointnet2_modules.py:67-70 in point-major layout.

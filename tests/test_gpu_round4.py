@@ -348,6 +348,87 @@ def test_lifted_first_layer_kernels_match_their_definition(B, N, m, ns, C, N0, n
     counts = inv[0][1:] - inv[0][:-1]
     print(f"\n[lift backward] rows per point: max {int(counts.max())}, heavy (> 192): {int((counts > 192).sum())}", end="")
 
+@pytest.mark.parametrize("B,N,m,ns,C,N0,normalize,r", [(2, 2048, 1024, 32, 128, 128, True, 0.4), (2, 1000, 77, 48, 32, 64, False, 0.4),
+                                                       (1, 513, 64, 80, 20, 256, True, 0.4), (2, 1024, 512, 16, 256, 128, True, 1.2)])
+def test_lifted_first_layer_bf16_rows(B, N, m, ns, C, N0, normalize, r):
+    """The mixed-precision variants (pn2_group_lift_rows_bf16 / _grad_bf16): y0 = the fp32 kernel's rows rounded to nearest
+    even — bit for bit —, statistics of the ROUNDED values (the convention of pn2_mlp_gemm_bf16); the backward with bf16
+    gradient rows against the float64 definition on the same (bf16-representable) gradient."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(B * N + C + 1)
+    xyz = _unit_ball(B, N, N + 2).cuda()
+    sel = torch.stack([torch.randperm(N, generator=g)[:m] for _ in range(B)]).cuda()
+    new_xyz = xyz[torch.arange(B, device="cuda")[:, None], sel].contiguous()
+    idx = e.ball_query(new_xyz, xyz, r, ns)
+    f = torch.randn(B, N, C, generator=g).cuda()
+    W = (torch.randn(N0, 3 + C, generator=g) * 0.2).cuda()
+    P = torch.mm(f.view(-1, C), W[:, 3:].t()).view(B, N, N0)
+    Wx = W[:, :3].contiguous()
+    Y32 = e.group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, r)
+    stats = torch.zeros(2, N0, dtype=torch.float64, device="cuda")
+    Y = e.group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, r, stats=stats, out_bf16=True)
+    assert Y.dtype == torch.bfloat16 and torch.equal(Y, Y32.to(torch.bfloat16))
+    torch.testing.assert_close(stats[0], Y.double().sum(0), rtol=1e-6, atol=1e-6 * Y.size(0))
+    torch.testing.assert_close(stats[1], Y.double().square().sum(0), rtol=1e-6, atol=1e-6 * Y.size(0))
+    G = torch.randn(Y.shape, generator=g).cuda().to(torch.bfloat16)
+    consts = (torch.randn(3, N0, generator=g) * 0.5).cuda().contiguous()
+    inv = e.group_inverse_index(idx, N)
+    acc = torch.zeros(3 * N0 + 9, device="cuda")
+    S = e.group_lift_rows_grad(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, r, acc)
+    acc32 = torch.zeros(3 * N0 + 9, device="cuda")
+    S32 = e.group_lift_rows_grad(G.float(), P, Wx, consts, xyz, new_xyz, inv, ns, normalize, r, acc32)
+    # the same sums over the same values: only the atomics of the heavy points may reorder them
+    assert float((S - S32).abs().max()) <= 1e-5 * float(S32.abs().max()) + 1e-6
+    assert float((acc - acc32).abs().max()) <= 1e-5 * float(acc32.abs().max()) + 1e-6
+
+
+def test_lifted_first_layer_on_the_bf16_node_matches_the_grouped_bf16_route():
+    """One SA level on the bf16 node (SA3 of the backbone) with and without BF16_LIFT: features, feature gradients and
+    parameter gradients agree within the bf16 noise the grouped bf16 route itself has against fp32."""
+    from external_src.group_free_3D.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from pointnet2_ops import _ext, fused_mlp
+    torch.manual_seed(9)
+    sa = PointnetSAModuleVotes(npoint=512, radius=0.8, nsample=16, mlp=[256, 128, 128, 256], use_xyz=True,
+                               normalize_xyz=True).cuda().train()
+    xyz = _unit_ball(4, 1024, 41).cuda()
+    feats = torch.randn(4, 256, 1024, generator=torch.Generator().manual_seed(42)).cuda()
+    gout = torch.randn(4, 256, 512, generator=torch.Generator().manual_seed(43)).cuda()
+
+    def run(dtype, lift):
+        prev_l, fused_mlp.BF16_LIFT = fused_mlp.BF16_LIFT, lift
+        prev = fused_mlp.set_mlp_dtype(dtype)
+        try:
+            m = copy.deepcopy(sa)
+            f = feats.clone().requires_grad_(True)
+            geo = m.sample_and_query(xyz, inverse_index=True)
+            with _Calls(_ext, ["group_lift_rows", "group_lift_rows_grad", "group_concat_rows_bf16"]) as calls:
+                _nx, nf, _i = m(xyz, f, geometry=geo)
+                (nf * gout).sum().backward()
+            if dtype == torch.bfloat16:
+                assert calls.count["group_lift_rows"] == (1 if lift else 0), calls.count
+                assert calls.count["group_lift_rows_grad"] == (1 if lift else 0), calls.count
+                assert calls.count["group_concat_rows_bf16"] == (0 if lift else 1), calls.count
+            return nf.detach(), f.grad, {n: p.grad for n, p in m.named_parameters()}
+        finally:
+            fused_mlp.set_mlp_dtype(prev)
+            fused_mlp.BF16_LIFT = prev_l
+
+    ref = run(torch.float32, True)
+    a, b = run(torch.bfloat16, True), run(torch.bfloat16, False)
+
+    def errs(x):
+        e_f = float((x[0] - ref[0]).abs().max() / ref[0].abs().max())
+        e_g = float((x[1] - ref[1]).norm() / ref[1].norm())
+        e_w = max(float((x[2][k] - ref[2][k]).norm() / (ref[2][k].norm() + 1e-12)) for k in ref[2] if ref[2][k].norm() > 1e-6)
+        return e_f, e_g, e_w
+
+    ea, eb = errs(a), errs(b)
+    print(f"\n[bf16 SA3 vs fp32] lifted: fwd {ea[0]:.3e} gx {ea[1]:.3e} gw {ea[2]:.3e}; grouped: fwd {eb[0]:.3e} gx {eb[1]:.3e} gw {eb[2]:.3e}", end="")
+    # the criteria of tests/test_gpu_bf16.py::test_backbone_levels_bf16_close_to_fp32, and not worse than the grouped route
+    assert ea[0] <= 2e-2 and ea[1] <= 2e-1 and ea[2] <= 2e-1
+    assert ea[0] <= 2 * eb[0] + 1e-3 and ea[1] <= 2 * eb[1] + 1e-3 and ea[2] <= 2 * eb[2] + 1e-3
+
+
 def test_lifted_first_layer_equals_the_grouped_route_at_module_level():
     """One SA level (SA3 of the backbone: 259 -> 128 -> 128 -> 256 on 1024-point clouds) with and without LIFT_FIRST: same
     features, feature gradients and parameter gradients up to fp32 summation order."""
