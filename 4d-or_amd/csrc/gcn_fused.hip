@@ -1,0 +1,535 @@
+// gcn_fused.hip — the TripletGCN layer as a handful of fused per-scan kernels (round 4).
+//
+// Reference: scene_graph_prediction/scene_graph_helpers/model/gcns/network_TripletGCN.py:11-58 —
+//   message  : nn1(cat[x_i, e, x_j])  with nn1 = Linear(2 dn + de -> dh) BN ReLU Linear(dh -> 2 dh + de) BN ReLU   (:36-37, 45-47)
+//   split    : [:dh] | [dh : dh + de] | [dh + de :]; node message = first + last, new edge feature = middle         (:48-52)
+//   aggregate: scatter(add) of the node messages onto edge_index[1]                                                   (:54-58)
+//   update   : nn2 = Linear(dh -> dh) BN ReLU Linear(dh -> dn)                                                        (:38, 42-43)
+// with BatchNorm1d(track_running_stats=False) (:20): batch statistics of ONE scan's rows, in training and in evaluation.
+// Through torch + the row kernels of gcn_rows.hip that is ~60 launches forward and ~180 backward per layer for matrices of
+// 9 .. 110 rows: the step is bound by the host thread and by launch gaps, not by arithmetic (profiles/r03_sgp_gpu_busy_fraction.md).
+//
+// Here a scan's rows (<= 128: the dataset has at most 11 objects = 110 ordered pairs) are ONE workgroup's row range, so
+// everything BatchNorm needs is local to the workgroup that owns a 32-column tile of a Linear's output:
+//   pn2_gcn_linear          gather (the concatenation is never built) -> Linear on the fp32 matrix cores -> + bias ->
+//                           per-scan batch statistics (two passes over the accumulators) -> BN -> ReLU, one launch;
+//   pn2_gcn_linear_grad_w   the block's backward up to the weights: ReLU mask + BatchNorm backward (per-scan sums in
+//                           registers) -> gz (kept for the input gradient), dgamma / dbeta / dbias, and dW += gz^T A on the
+//                           matrix cores; the adjoint of split + aggregate ([g_agg[dst] | g_edge | g_agg[dst]]) is read in
+//                           place of a materialised gradient;
+//   pn2_gcn_linear_grad_x   input gradient gz W, written as rows or scattered through the triplet gather's adjoint
+//                           (x[dst] / e / x[src] column blocks).
+// v_mfma_f32_32x32x2_f32 throughout (exact fp32 products and sums, like the shared-MLP kernels); a wave's K loop splits the
+// reduction range in two halves, one per 32-lane group, so every lane streams CONTIGUOUS floats of its A row / W row
+// (16-byte loads).  Tested at 1e-4 against the oracle GCN (torch on the CPU restatement) like the unfused path.
+#include "pn2_common.h"
+
+namespace {
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int kGcnRows = 128;      // rows of one scan a workgroup covers: 4 waves x 32
+
+__device__ __forceinline__ f16v mfma2(float a, float b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// row of accumulator register q in a 32 x 32 tile: lane group h = lane / 32
+__device__ __forceinline__ int acc_row(int q, int h) { return 8 * (q >> 2) + 4 * h + (q & 3); }
+
+struct GcnTriplet {               // cat[x[dst], e, x[src]] as a virtual (E, 2 dn + de) matrix
+  const float *x, *e;
+  const int64_t *dst, *src;
+  int dn, de;
+};
+
+struct GcnFwdArgs {
+  const float *A;                 // AMODE 0: (R, lda) rows
+  int lda;
+  GcnTriplet t;                   // AMODE 1
+  const float *W, *bias;          // (N, K) row-major (torch Linear), (N) or null
+  const int64_t *ptr;             // (S + 1) row offsets of the scans
+  const float *gamma, *beta;      // BatchNorm (BN instantiation)
+  float eps;
+  float *Ypre, *Out, *mean, *rstd;   // (R, N) pre-BN, (R, N) result, (S, N), (S, N)
+  int K, N, relu;
+};
+
+// K loop of a 32 x 32 tile, software-pipelined: a ring of four 16-float blocks per operand (the loads of block i + 3 are in
+// flight while block i feeds the matrix core: at one wave per SIMD nothing else hides the ~1 us of an L2 round trip).
+// `pa(k)` / `pb(k)`: 16-byte loads of the lane's A row / W row at offset k of its half of the reduction range.
+template <class FA, class FB>
+__device__ __forceinline__ void gcn_kloop(int k_begin, int k_end, bool rv, FA pa, FB pb, f16v &acc) {
+  f4 ab[4][4], bb[4][4];
+  const int nblk = (k_end - k_begin) >> 4;
+  auto load = [&](int u, int blk) {
+    const int k = k_begin + 16 * blk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ab[u][j] = pa(k + 4 * j); bb[u][j] = pb(k + 4 * j); }
+  };
+  auto compute = [&](int u) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f4 av = ab[u][j];
+      if (!rv) av = f4{0.f, 0.f, 0.f, 0.f};
+      acc = mfma2(av.x, bb[u][j].x, acc); acc = mfma2(av.y, bb[u][j].y, acc);
+      acc = mfma2(av.z, bb[u][j].z, acc); acc = mfma2(av.w, bb[u][j].w, acc);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+    if (u < nblk) load(u, u);
+  for (int blk = 0; blk < nblk; blk += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (blk + u + 3 < nblk) load((u + 3) & 3, blk + u + 3);
+      if (blk + u < nblk) compute(u);
+    }
+  }
+}
+
+// Row tiles of a scan (T = 1 .. 4) and the split of the reduction range over the eight waves of a workgroup: a 32 x 32 tile
+// is ONE dependent chain of matrix-core instructions (64 cycles each, K / 2 of them), so the range is cut into 8 / T' parts
+// (T' = T rounded up to a power of two: every node matrix, <= 32 rows, runs on eight eighths) and the partial tiles meet in LDS.
+constexpr int kGcnWaves = 8;
+struct GcnSplit { int tile, part, nparts; };
+__device__ __forceinline__ GcnSplit gcn_split(int Rs, int w, int half_len) {
+  const int T = (Rs + 31) >> 5;
+  const int tp = T <= 1 ? 1 : (T == 2 ? 2 : 4);
+  int nparts = kGcnWaves / tp;
+  while (nparts > 1 && ((half_len / nparts) & 15 || (half_len % nparts))) nparts >>= 1;
+  GcnSplit sp;
+  sp.nparts = nparts;
+  sp.tile = w % tp;
+  sp.part = w / tp;
+  if (sp.part >= nparts) { sp.part = 0; sp.tile = 4; }             // (a spare wave: an empty tile)
+  return sp;
+}
+// sum of the partial accumulators of the waves that share a tile; the part-0 wave returns the total
+__device__ __forceinline__ void gcn_join(float (*part)[16][64], const GcnSplit &sp, int Rs, int w, int lane, f16v &acc) {
+  if (sp.nparts > 1) {                                             // (workgroup-uniform)
+    const int T = (Rs + 31) >> 5;
+    const int tp = T <= 1 ? 1 : (T == 2 ? 2 : 4);
+    if (sp.part != 0 && sp.tile < 4) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) part[w][q][lane] = acc[q];
+    }
+    __syncthreads();
+    if (sp.part == 0 && sp.tile < 4) {
+      for (int o = 1; o < sp.nparts; ++o) {
+        const int ow = sp.tile + tp * o;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += part[ow][q][lane];
+      }
+    }
+  }
+}
+
+// grid (N / 32, S), 256 threads: wave w = rows [32 w, 32 w + 32) of scan blockIdx.y (see gcn_split), columns [32 bx, +32)
+template <int AMODE, bool BN>
+__global__ __launch_bounds__(512) void gcn_linear_kernel(const GcnFwdArgs a) {
+  __shared__ float red[2][kGcnWaves][32];
+  __shared__ float part[kGcnWaves][16][64];
+  const int lane = pn2_lane(), wv = threadIdx.x >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int s = blockIdx.y, c0 = blockIdx.x * 32;
+  const long long r0 = a.ptr[s];
+  const int Rs = (int)(a.ptr[s + 1] - r0);
+  const int K = a.K, Kh = K >> 1;
+  const GcnSplit sp = gcn_split(Rs, wv, Kh);
+  const int w = sp.tile;                                           // row tile of this wave
+  const int row = 32 * w + c;
+  const bool rv = row < Rs;
+  f16v acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  if (32 * w < Rs) {                                              // wave-uniform: the tile has rows
+    const float *wrow = a.W + (size_t)(c0 + c) * K + h * Kh;
+    const int plen = Kh / sp.nparts, k_begin = sp.part * plen;
+    auto pb = [&](int k) { return *reinterpret_cast<const f4 *>(wrow + k); };
+    if constexpr (AMODE == 0) {
+      const float *arow = a.A + (size_t)(r0 + (rv ? row : 0)) * a.lda + h * Kh;
+      gcn_kloop(k_begin, k_begin + plen, rv, [&](int k) { return *reinterpret_cast<const f4 *>(arow + k); }, pb, acc);
+    } else {
+      const long long er = r0 + (rv ? row : 0);
+      const int dn = a.t.dn, de = a.t.de;
+      // p[kg] is element kg of the virtual concatenated row (segment boundaries are multiples of 32: a block never straddles one)
+      const float *p0 = a.t.x + (size_t)a.t.dst[er] * dn;
+      const float *p1 = a.t.e + (size_t)er * de - dn;
+      const float *p2 = a.t.x + (size_t)a.t.src[er] * dn - dn - de;
+      gcn_kloop(k_begin, k_begin + plen, rv, [&](int k) {
+        const int kg = h * Kh + k;
+        const float *p = kg < dn ? p0 : (kg < dn + de ? p1 : p2);
+        return *reinterpret_cast<const f4 *>(p + kg);
+      }, pb, acc);
+    }
+  }
+  gcn_join(part, sp, Rs, wv, lane, acc);
+  const bool owner = sp.part == 0 && w < 4;                        // this wave holds the finished tile `w`
+  const int col = c0 + c;
+  const float bias = a.bias ? a.bias[col] : 0.f;
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = acc[q] + bias;
+  if constexpr (BN) {
+    // batch statistics of the scan's rows, two passes over the accumulators (mean, then centred squares)
+    float s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (owner && 32 * w + acc_row(q, h) < Rs) s1 += v[q];
+    s1 += __shfl_xor(s1, 32);
+    if (h == 0) red[0][wv][c] = s1;
+    __syncthreads();
+    const float inv_n = 1.f / (float)Rs;
+    const float mean = (((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) +
+                        ((red[0][4][c] + red[0][5][c]) + (red[0][6][c] + red[0][7][c]))) * inv_n;
+    float s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (owner && 32 * w + acc_row(q, h) < Rs) { const float d = v[q] - mean; s2 = fmaf(d, d, s2); }
+    s2 += __shfl_xor(s2, 32);
+    if (h == 0) red[1][wv][c] = s2;
+    __syncthreads();
+    const float var = (((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])) +
+                       ((red[1][4][c] + red[1][5][c]) + (red[1][6][c] + red[1][7][c]))) * inv_n;   // biased, like F.batch_norm
+    const float rstd = 1.f / sqrtf(var + a.eps);
+    if (wv == 0 && h == 0) { a.mean[(size_t)s * a.N + col] = mean; a.rstd[(size_t)s * a.N + col] = rstd; }
+    const float g = a.gamma[col], b = a.beta[col];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int ri = 32 * w + acc_row(q, h);
+      if (owner && ri < Rs) {
+        const size_t o = (size_t)(r0 + ri) * a.N + col;
+        a.Ypre[o] = v[q];
+        float y = fmaf((v[q] - mean) * rstd, g, b);
+        if (a.relu) y = fmaxf(y, 0.f);
+        a.Out[o] = y;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int ri = 32 * w + acc_row(q, h);
+      if (owner && ri < Rs) a.Out[(size_t)(r0 + ri) * a.N + col] = a.relu ? fmaxf(v[q], 0.f) : v[q];
+    }
+  }
+}
+
+struct GcnGradWArgs {
+  // gradient of the block's result: GMODE 0 G (R, N); GMODE 1 the adjoint of split + aggregate, read in place:
+  // column n < dh: gagg[dst[r], n]; dh <= n < dh + de: gedge[r, n - dh]; else gagg[dst[r], n - dh - de]
+  const float *G, *gagg, *gedge;
+  int dh, dE;
+  const float *Ypre, *mean, *rstd, *gamma, *beta;     // BN: pre-BN values and the forward's statistics; !BN && relu: Ypre = result
+  int relu;
+  const int64_t *ptr;
+  const float *A;                                     // AMODE 0 input rows (R, lda)
+  int lda;
+  GcnTriplet t;                                       // AMODE 1 (also the dst of GMODE 1)
+  float *Gz;                                          // (R, N): gradient at the Linear's output
+  float *dW, *dbias, *dgamma, *dbeta;                 // += (zero on entry)
+  int K, N;
+};
+
+// grid (N / 32, S, K / 128), 256 threads.  Every wave repeats the (cheap) BatchNorm backward of the 32-column tile — lane
+// (c, h) owns column c and the rows of parity h, which IS the A-operand layout of gz^T for the weight gradient — and takes ONE
+// 32-column tile of K (tile 4 z + w); its rows of A are requested BEFORE the BatchNorm backward, so one L2 round trip covers both.
+template <int AMODE, int GMODE, bool BN>
+__global__ __launch_bounds__(256) void gcn_linear_grad_w_kernel(const GcnGradWArgs a) {
+  __shared__ int s_dst[kGcnRows], s_src[kGcnRows];
+  const int lane = pn2_lane(), w = threadIdx.x >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int s = blockIdx.y, c0 = blockIdx.x * 32;
+  const long long r0 = a.ptr[s];
+  const int Rs = (int)(a.ptr[s + 1] - r0);
+  const int N = a.N, K = a.K, col = c0 + c;
+  if constexpr (AMODE == 1 || GMODE == 1) {
+    for (int i = threadIdx.x; i < kGcnRows; i += 256) {
+      s_dst[i] = i < Rs ? (int)a.t.dst[r0 + i] : 0;
+      s_src[i] = (i < Rs && a.t.src) ? (int)a.t.src[r0 + i] : 0;
+    }
+    __syncthreads();
+  }
+  // this wave's tile of A: rows of parity h, column 32 t + c (requested first, consumed after the BatchNorm backward)
+  const int t = 4 * blockIdx.z + w;
+  float bv[64];
+  {
+    const int k = 32 * t + c;
+    int seg = 0;
+    if constexpr (AMODE == 1) seg = 32 * t < a.t.dn ? 0 : (32 * t < a.t.dn + a.t.de ? 1 : 2);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      bv[i] = 0.f;
+      if (2 * i < Rs && t < K / 32) {                              // wave-uniform
+        const int r = 2 * i + h, rc = r < Rs ? r : Rs - 1;
+        if constexpr (AMODE == 0) bv[i] = a.A[(size_t)(r0 + rc) * a.lda + k];
+        else bv[i] = seg == 0 ? a.t.x[(size_t)s_dst[rc] * a.t.dn + k]
+                     : (seg == 1 ? a.t.e[(size_t)(r0 + rc) * a.t.de + (k - a.t.dn)]
+                                 : a.t.x[(size_t)s_src[rc] * a.t.dn + (k - a.t.dn - a.t.de)]);
+      }
+    }
+  }
+  float gz[64], xh[BN ? 64 : 1];
+  float mean = 0.f, rstd = 1.f, gam = 1.f, bet = 0.f;
+  if constexpr (BN) {
+    mean = a.mean[(size_t)s * N + col]; rstd = a.rstd[(size_t)s * N + col];
+    gam = a.gamma[col]; bet = a.beta[col];
+  }
+  float s1 = 0.f, s2 = 0.f;
+  // rows in batches of eight per lane, every load unconditional (row clamped, value zeroed afterwards): behind per-row
+  // branches the loads of a batch cannot be in flight together and each costs a full L2 round trip
+#pragma unroll
+  for (int ib = 0; ib < 8; ++ib) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gz[8 * ib + j] = 0.f; if constexpr (BN) xh[8 * ib + j] = 0.f; }
+    if (16 * ib < Rs) {                                            // wave-uniform
+      float gv[8], yv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 2 * (8 * ib + j) + h, rc = r < Rs ? r : Rs - 1;
+        if constexpr (GMODE == 0) {
+          gv[j] = a.G[(size_t)(r0 + rc) * N + col];
+        } else {
+          gv[j] = col < a.dh ? a.gagg[(size_t)s_dst[rc] * a.dh + col]
+                  : (col < a.dh + a.dE ? a.gedge[(size_t)(r0 + rc) * a.dE + (col - a.dh)]
+                                       : a.gagg[(size_t)s_dst[rc] * a.dh + (col - a.dh - a.dE)]);
+        }
+        yv[j] = (BN || a.relu) ? a.Ypre[(size_t)(r0 + rc) * N + col] : 1.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = 8 * ib + j, r = 2 * i + h;
+        float g = r < Rs ? gv[j] : 0.f;
+        if constexpr (BN) {
+          const float x = r < Rs ? (yv[j] - mean) * rstd : 0.f;
+          if (a.relu && !(fmaf(x, gam, bet) > 0.f)) g = 0.f;
+          xh[i] = x;
+          s2 = fmaf(g, x, s2);
+        } else if (a.relu) {
+          if (!(yv[j] > 0.f)) g = 0.f;
+        }
+        gz[i] = g;
+        s1 += g;
+      }
+    }
+  }
+  s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 32);
+  float sb = s1;                                                   // sum of gz over the rows (the Linear's bias gradient)
+  if constexpr (BN) {
+    const float k1 = s1 / (float)Rs, k2 = s2 / (float)Rs, sc = gam * rstd;
+    sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (2 * i < Rs) {
+        gz[i] = 2 * i + h < Rs ? sc * (gz[i] - k1 - xh[i] * k2) : 0.f;
+        sb += gz[i];
+      }
+    }
+    sb += __shfl_xor(sb, 32);
+  }
+  if (w == 0 && blockIdx.z == 0) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+      if (2 * i < Rs && 2 * i + h < Rs) a.Gz[(size_t)(r0 + 2 * i + h) * N + col] = gz[i];
+    if (h == 0) {
+      if (a.dbias) atomicAdd(a.dbias + col, sb);
+      if constexpr (BN) { atomicAdd(a.dgamma + col, s2); atomicAdd(a.dbeta + col, s1); }
+    }
+  }
+  // dW[c0 + i, k] += sum_r gz[r, c0 + i] A[r, k]
+  if (t < K / 32) {
+    f16v acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+      if (2 * i < Rs) acc = mfma2(gz[i], bv[i], acc);              // (gz is 0 beyond the scan's rows)
+    const int k = 32 * t + c;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) atomicAdd(a.dW + (size_t)(c0 + acc_row(q, h)) * K + k, acc[q]);
+  }
+}
+
+struct GcnGradXArgs {
+  const float *Gz, *W;            // (R, N), (N, K)
+  const int64_t *ptr;
+  float *Gin;                     // OMODE 0: (R, K)
+  float *gx, *ge;                 // OMODE 1: gx (nodes, dn) += (zero on entry), ge (R, de) =
+  GcnTriplet t;
+  int N, K;
+};
+
+// grid (K / 32, S), 256 threads: wave = a row tile of the scan (and a part of the reduction range, gcn_split), input
+// columns [32 bx, +32).  Same four-deep ring as gcn_kloop; the W operand is one dword per reduction step (its rows are K apart).
+template <int OMODE>
+__global__ __launch_bounds__(512) void gcn_linear_grad_x_kernel(const GcnGradXArgs a) {
+  __shared__ float part[kGcnWaves][16][64];
+  const int lane = pn2_lane(), wv = threadIdx.x >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int s = blockIdx.y, k0 = blockIdx.x * 32;
+  const long long r0 = a.ptr[s];
+  const int Rs = (int)(a.ptr[s + 1] - r0);
+  const int N = a.N, K = a.K, Nh = N >> 1;
+  const GcnSplit sp = gcn_split(Rs, wv, Nh);
+  const int w = sp.tile;
+  const int row = 32 * w + c;
+  const bool rv = row < Rs;
+  f16v acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  if (32 * w < Rs) {
+    const float *arow = a.Gz + (size_t)(r0 + (rv ? row : 0)) * N + h * Nh;
+    const float *wcol = a.W + (size_t)(h * Nh) * K + k0 + c;
+    const int plen = Nh / sp.nparts, n_begin = sp.part * plen, nblk = plen >> 4;
+    f4 ab[4][4];
+    float bb[4][16];
+    auto load = [&](int u, int blk) {
+      const int n = n_begin + 16 * blk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ab[u][j] = *reinterpret_cast<const f4 *>(arow + n + 4 * j);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bb[u][j] = wcol[(size_t)(n + j) * K];
+    };
+    auto compute = [&](int u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f4 av = ab[u][j];
+        if (!rv) av = f4{0.f, 0.f, 0.f, 0.f};
+        acc = mfma2(av.x, bb[u][4 * j], acc); acc = mfma2(av.y, bb[u][4 * j + 1], acc);
+        acc = mfma2(av.z, bb[u][4 * j + 2], acc); acc = mfma2(av.w, bb[u][4 * j + 3], acc);
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (u < nblk) load(u, u);
+    for (int blk = 0; blk < nblk; blk += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (blk + u + 3 < nblk) load((u + 3) & 3, blk + u + 3);
+        if (blk + u < nblk) compute(u);
+      }
+    }
+  }
+  gcn_join(part, sp, Rs, wv, lane, acc);
+  if (sp.part != 0 || 32 * w >= Rs) return;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int ri = 32 * w + acc_row(q, h);
+    if (ri >= Rs) continue;
+    const long long er = r0 + ri;
+    if constexpr (OMODE == 0) {
+      a.Gin[(size_t)er * K + k0 + c] = acc[q];
+    } else {
+      const int dn = a.t.dn, de = a.t.de;
+      if (k0 < dn) atomicAdd(a.gx + (size_t)a.t.dst[er] * dn + k0 + c, acc[q]);
+      else if (k0 < dn + de) a.ge[(size_t)er * de + (k0 - dn) + c] = acc[q];
+      else atomicAdd(a.gx + (size_t)a.t.src[er] * dn + (k0 - dn - de) + c, acc[q]);
+    }
+  }
+}
+
+// split of nn1's result: new edge feature = columns [dh, dh + de) (+ ReLU between layers), one launch
+__global__ __launch_bounds__(256) void gcn_edge_slice_kernel(long long total4, int de4, int ld4, int off4, int relu,
+                                                            const f4 *__restrict__ hsrc, f4 *__restrict__ out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const long long r = i / de4;
+    const int j = (int)(i - r * de4);
+    f4 v = hsrc[r * ld4 + off4 + j];
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    out[i] = v;
+  }
+}
+
+bool gcn_dims_ok(int K, int N) { return K >= 32 && N >= 32 && K % 32 == 0 && N % 32 == 0; }
+}  // namespace
+
+extern "C" int pn2_gcn_fused_supported(int dn, int de, int dh, int max_rows_per_scan) {
+  return (dn >= 32 && de >= 32 && dh >= 32 && dn % 32 == 0 && de % 32 == 0 && dh % 32 == 0 && max_rows_per_scan <= kGcnRows) ? 1 : 0;
+}
+
+// Out (R, N) = [ReLU] [BN_scan] (A W^T + bias).  A: rows (R, lda) when `x` is null, else the virtual concatenation
+// cat[x[dst], e, x[src]] (K = 2 dn + de).  gamma null: no BatchNorm (Ypre / mean / rstd unused).
+extern "C" int pn2_gcn_linear(long long R, int S, int K, int N, const float *A, int lda, const float *x, const float *e,
+                              const long long *dst, const long long *src, int dn, int de, const float *W,
+                              const float *bias, const long long *ptr, const float *gamma, const float *beta, float eps,
+                              int relu, float *Ypre, float *Out, float *mean, float *rstd, void *stream) {
+  if (R < 0 || S < 0 || !gcn_dims_ok(K, N)) return PN2_EINVAL;
+  if (R == 0 || S == 0) return PN2_OK;
+  if (!W || !ptr || !Out) return PN2_ENULL;
+  const bool trip = x != nullptr;
+  if (trip ? (!e || !dst || !src || K != 2 * dn + de || dn % 32 || de % 32) : (!A || lda < K || (lda & 3))) return PN2_EINVAL;
+  if (gamma && (!beta || !Ypre || !mean || !rstd)) return PN2_ENULL;
+  GcnFwdArgs a{A, lda, {x, e, (const int64_t *)dst, (const int64_t *)src, dn, de}, W, bias, (const int64_t *)ptr, gamma, beta,
+               eps, Ypre, Out, mean, rstd, K, N, relu ? 1 : 0};
+  const dim3 grid((unsigned)(N / 32), (unsigned)S), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  if (trip) {
+    if (gamma) hipLaunchKernelGGL((gcn_linear_kernel<1, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gcn_linear_kernel<1, false>), grid, block, 0, s, a);
+  } else {
+    if (gamma) hipLaunchKernelGGL((gcn_linear_kernel<0, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gcn_linear_kernel<0, false>), grid, block, 0, s, a);
+  }
+  return pn2_check_launch();
+}
+
+// Backward of one block up to the weights.  G (R, N) gradient of the block's result — or, with gagg != null, the adjoint of
+// split + aggregate read in place (N = 2 dh + dE; dst required).  gamma null: no BatchNorm (relu: `Ypre` = the block's result).
+// Writes Gz (R, N); dW (N, K), dbias (N), dgamma (N), dbeta (N) += (the caller zeroes them once per step).
+extern "C" int pn2_gcn_linear_grad_w(long long R, int S, int K, int N, const float *G, const float *gagg, const float *gedge,
+                                     int dh, int dE, const float *Ypre, const float *mean, const float *rstd,
+                                     const float *gamma, const float *beta, int relu, const long long *ptr, const float *A,
+                                     int lda, const float *x, const float *e, const long long *dst, const long long *src,
+                                     int dn, int de, float *Gz, float *dW, float *dbias, float *dgamma, float *dbeta,
+                                     void *stream) {
+  if (R < 0 || S < 0 || !gcn_dims_ok(K, N)) return PN2_EINVAL;
+  if (R == 0 || S == 0) return PN2_OK;
+  if (!ptr || !Gz || !dW) return PN2_ENULL;
+  const bool trip = x != nullptr, adj = gagg != nullptr;
+  if (trip ? (!e || !dst || !src || K != 2 * dn + de || dn % 32 || de % 32) : (!A || lda < K)) return PN2_EINVAL;
+  if (adj ? (!gedge || !dst || N != 2 * dh + dE || dh % 32 || dE % 32) : !G) return PN2_EINVAL;
+  if (gamma && (!beta || !Ypre || !mean || !rstd || !dgamma || !dbeta)) return PN2_ENULL;
+  if (!gamma && relu && !Ypre) return PN2_ENULL;
+  GcnGradWArgs a{G, gagg, gedge, dh, dE, Ypre, mean, rstd, gamma, beta, relu ? 1 : 0, (const int64_t *)ptr, A, lda,
+                 {x, e, (const int64_t *)dst, (const int64_t *)src, dn, de}, Gz, dW, dbias, dgamma, dbeta, K, N};
+  const dim3 grid((unsigned)(N / 32), (unsigned)S, (unsigned)((K / 32 + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define PN2_GCN_GW(AM, GM)                                                                                  \
+  do {                                                                                                      \
+    if (gamma) hipLaunchKernelGGL((gcn_linear_grad_w_kernel<AM, GM, true>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((gcn_linear_grad_w_kernel<AM, GM, false>), grid, block, 0, s, a);               \
+  } while (0)
+  if (trip) { if (adj) PN2_GCN_GW(1, 1); else PN2_GCN_GW(1, 0); }
+  else { if (adj) PN2_GCN_GW(0, 1); else PN2_GCN_GW(0, 0); }
+#undef PN2_GCN_GW
+  return pn2_check_launch();
+}
+
+// Input gradient Gz W: rows Gin (R, K), or (x != null: only its dims are used through dn / de) scattered through the adjoint
+// of the triplet gather: gx (nodes, dn) += columns [0, dn) at dst and [dn + de, K) at src (zero on entry), ge (R, de) = the middle.
+extern "C" int pn2_gcn_linear_grad_x(long long R, int S, int K, int N, const float *Gz, const float *W, const long long *ptr,
+                                     float *Gin, float *gx, float *ge, const long long *dst, const long long *src, int dn,
+                                     int de, void *stream) {
+  if (R < 0 || S < 0 || !gcn_dims_ok(K, N)) return PN2_EINVAL;
+  if (R == 0 || S == 0) return PN2_OK;
+  if (!Gz || !W || !ptr) return PN2_ENULL;
+  const bool trip = gx != nullptr;
+  if (trip ? (!ge || !dst || !src || K != 2 * dn + de || dn % 32 || de % 32) : !Gin) return PN2_EINVAL;
+  GcnGradXArgs a{Gz, W, (const int64_t *)ptr, Gin, gx, ge, {nullptr, nullptr, (const int64_t *)dst, (const int64_t *)src, dn, de},
+                 N, K};
+  const dim3 grid((unsigned)(K / 32), (unsigned)S), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  if (trip) hipLaunchKernelGGL((gcn_linear_grad_x_kernel<1>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gcn_linear_grad_x_kernel<0>), grid, block, 0, s, a);
+  return pn2_check_launch();
+}
+
+// out (R, de) = [ReLU] h[:, off : off + de] of rows (R, ld): the new edge feature of a TripletGCN layer (:51)
+extern "C" int pn2_gcn_edge_slice(long long R, int ld, int off, int de, int relu, const float *hrows, float *out, void *stream) {
+  if (R < 0 || (ld & 3) || (off & 3) || (de & 3) || de <= 0 || off + de > ld) return PN2_EINVAL;
+  if (R == 0) return PN2_OK;
+  if (!hrows || !out) return PN2_ENULL;
+  const long long total4 = R * (de / 4);
+  long long blocks = (total4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gcn_edge_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total4, de / 4, ld / 4,
+                     off / 4, relu ? 1 : 0, (const f4 *)hrows, (f4 *)out);
+  return pn2_check_launch();
+}

@@ -84,6 +84,12 @@ _SIGNATURES = {
     "pn2_segment_bn_rows": [_c_i64, _c_int, _c_int, _c_int, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_f32, _c_int, _c_vp, _c_vp,
                             _c_vp, _c_vp],
     "pn2_segment_bn_rows_grad": [_c_i64, _c_int, _c_int, _c_int, _c_i64] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 4,
+    "pn2_gcn_linear": [_c_i64, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
+                       _c_vp, _c_vp, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
+    "pn2_gcn_linear_grad_w": [_c_i64, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_int] + [_c_vp] * 5 + [_c_int, _c_vp, _c_vp,
+                              _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int] + [_c_vp] * 5 + [_c_vp],
+    "pn2_gcn_linear_grad_x": [_c_i64, _c_int, _c_int, _c_int] + [_c_vp] * 8 + [_c_int, _c_int, _c_vp],
+    "pn2_gcn_edge_slice": [_c_i64, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp],
     "pn2_segment_bn_running_update": [_c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_prep_object_boxes": [_c_int, _c_int, _c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_prep_chunk_counts": [_c_int] * 4 + [_c_vp] * 6,
@@ -189,6 +195,8 @@ _lib.pn2_fps_get_multi.argtypes = []
 _lib.pn2_fps_get_multi.restype = _c_int
 if os.environ.get("PN2_FPS_MULTI") == "0":           # measurement switch: one sample per cluster hand-off (round 3)
     _lib.pn2_fps_set_multi(0)
+_lib.pn2_gcn_fused_supported.argtypes = [_c_int, _c_int, _c_int, _c_int]
+_lib.pn2_gcn_fused_supported.restype = _c_int
 _lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_supported.restype = _c_int
 _lib.pn2_mlp_bwd_bf16_supported.argtypes = [_c_int, _c_int]
@@ -214,7 +222,7 @@ ABI_VERSION = int(_lib.pn2_abi_version())
 EXPECTED_ABI_VERSION = 5
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
-                                               "pn2_fps_set_multi", "pn2_fps_get_multi",
+                                               "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_gcn_fused_supported",
                                                "pn2_event_create", "pn2_event_record", "pn2_event_elapsed_ms", "pn2_event_destroy",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
@@ -885,6 +893,95 @@ def segment_sum2_rows(src, order, rowptr, dim_size, h, col0, col1):
     out = torch.empty(int(dim_size), int(h), dtype=torch.float32, device=src.device)
     _call("pn2_segment_sum2_rows", src, E, int(h), int(dim_size), lds, int(col0), int(col1), _ptr(src), _ptr(order),
           _ptr(rowptr), _ptr(out), alg_bytes=8 * E * int(h) + 16 * E + 4 * int(dim_size) * int(h))
+    return out
+
+
+# ---- fused TripletGCN blocks (csrc/gcn_fused.hip): thin bindings — the autograd node that calls them
+# (network_TripletGCN._FusedTripletLayer) validates dtypes / contiguity once per layer, not once per launch
+def gcn_fused_supported(dn, de, dh, max_rows_per_scan):
+    return bool(_lib.pn2_gcn_fused_supported(int(dn), int(de), int(dh), int(max_rows_per_scan)))
+
+
+def gcn_linear(W, bias, ptr, S, A=None, triplet=None, bn=None, relu=False):
+    """[ReLU] [BN per scan] (A W^T + bias) in one launch.  A (R, K) rows, or triplet = (x, e, dst, src): the virtual
+    cat[x[dst], e, x[src]] (network_TripletGCN.py:46).  bn = (gamma, beta, eps) -> (out, ypre, mean, rstd), else out."""
+    N, K = W.shape
+    if triplet is not None:
+        x, e, dst, src = triplet
+        R, dn, de = e.size(0), x.size(1), e.size(1)
+        ref, a_ptr, lda = e, None, 0
+        tp = (_ptr(x), _ptr(e), _ptr(dst), _ptr(src), dn, de)
+    else:
+        R, lda = A.size(0), A.size(1)
+        ref, a_ptr = A, _ptr(A)
+        tp = (None, None, None, None, 0, 0)
+    out = torch.empty(R, N, dtype=torch.float32, device=ref.device)
+    if bn is not None:
+        gamma, beta, eps = bn
+        ypre = torch.empty(R, N, dtype=torch.float32, device=ref.device)
+        stat = torch.empty(2, S, N, dtype=torch.float32, device=ref.device)
+        _call("pn2_gcn_linear", ref, R, S, K, N, a_ptr, lda, *tp, _ptr(W), _ptr(bias), _ptr(ptr), _ptr(gamma), _ptr(beta),
+              float(eps), int(bool(relu)), _ptr(ypre), _ptr(out), _ptr(stat[0]), _ptr(stat[1]), alg_flops=2 * R * K * N)
+        return out, ypre, stat[0], stat[1]
+    _call("pn2_gcn_linear", ref, R, S, K, N, a_ptr, lda, *tp, _ptr(W), _ptr(bias), _ptr(ptr), None, None, 0.0,
+          int(bool(relu)), None, _ptr(out), None, None, alg_flops=2 * R * K * N)
+    return out
+
+
+def gcn_linear_grad_w(W_shape, ptr, S, dW, dbias, G=None, adjoint=None, bn=None, relu=False, ypre=None, A=None, triplet=None,
+                      dgamma=None, dbeta=None):
+    """Backward of a gcn_linear block up to the weights (include/pn2_hip.h): returns gz (R, N); dW / dbias / dgamma / dbeta
+    are accumulated (zeroed by the caller).  adjoint = (gagg, gedge, dst, dh, de): the gradient is the adjoint of split +
+    aggregate read in place.  bn = (ypre, mean, rstd, gamma, beta)."""
+    N, K = W_shape
+    if triplet is not None:
+        x, e, dst, src = triplet
+        R, dn, de = e.size(0), x.size(1), e.size(1)
+        ref, a_ptr, lda = e, None, 0
+        tp = [_ptr(x), _ptr(e), _ptr(dst), _ptr(src), dn, de]
+    else:
+        R, lda = A.size(0), A.size(1)
+        ref, a_ptr = A, _ptr(A)
+        tp = [None, None, None, None, 0, 0]
+    if adjoint is not None:
+        gagg, gedge, adst, dh, dE = adjoint
+        gp = (None, _ptr(gagg), _ptr(gedge), int(dh), int(dE))
+        if tp[2] is None:
+            tp[2] = _ptr(adst)
+    else:
+        gp = (_ptr(G), None, None, 0, 0)
+    gz = torch.empty(R, N, dtype=torch.float32, device=ref.device)
+    if bn is not None:
+        yp, mean, rstd, gamma, beta = bn
+        bp = (_ptr(yp), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta))
+    else:
+        bp = (_ptr(ypre), None, None, None, None)
+    _call("pn2_gcn_linear_grad_w", ref, R, S, K, N, *gp, *bp, int(bool(relu)), _ptr(ptr), a_ptr, lda, *tp, _ptr(gz), _ptr(dW),
+          _ptr(dbias), _ptr(dgamma), _ptr(dbeta), alg_flops=2 * R * K * N)
+    return gz
+
+
+def gcn_linear_grad_x(gz, W, ptr, S, scatter=None):
+    """gz W: (R, K) rows, or scatter = (gx, ge, dst, src, dn, de): gx (nodes, dn) += the x[dst] / x[src] column blocks
+    (zero on entry), ge (R, de) = the middle block (adjoint of the triplet gather)."""
+    R, N = gz.shape
+    K = W.size(1)
+    if scatter is not None:
+        gx, ge, dst, src, dn, de = scatter
+        _call("pn2_gcn_linear_grad_x", gz, R, S, K, N, _ptr(gz), _ptr(W), _ptr(ptr), None, _ptr(gx), _ptr(ge), _ptr(dst),
+              _ptr(src), int(dn), int(de), alg_flops=2 * R * K * N)
+        return None
+    gin = torch.empty(R, K, dtype=torch.float32, device=gz.device)
+    _call("pn2_gcn_linear_grad_x", gz, R, S, K, N, _ptr(gz), _ptr(W), _ptr(ptr), _ptr(gin), None, None, None, None, 0, 0,
+          alg_flops=2 * R * K * N)
+    return gin
+
+
+def gcn_edge_slice(h, off, de, relu):
+    """[ReLU] h[:, off:off+de] as a contiguous tensor (the new edge feature of a TripletGCN layer), one launch."""
+    R, ld = h.shape
+    out = torch.empty(R, int(de), dtype=torch.float32, device=h.device)
+    _call("pn2_gcn_edge_slice", h, R, ld, int(off), int(de), int(bool(relu)), _ptr(h), _ptr(out), alg_bytes=8 * R * int(de))
     return out
 
 

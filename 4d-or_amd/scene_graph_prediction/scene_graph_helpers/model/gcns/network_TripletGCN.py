@@ -34,6 +34,7 @@ edge gathers / scatters need nothing else (no edge crosses scans); the BatchNorm
 the statistics of EACH scan's rows, which ``pn2_segment_bn_rows`` does in one launch (+ReLU), so a batch of S scans gives
 exactly the S single-scan results.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -313,6 +314,67 @@ class _AggregateAdd(Function):
         return _ext.gather_rows(g.contiguous(), ctx.csr.dst, check=False), None
 
 
+# The whole layer as ~7 launches forward / ~9 backward (csrc/gcn_fused.hip) instead of ~60 / ~180 through torch + the row
+# kernels: scans of <= 128 edges and nodes (the dataset's scans have at most 110 / 11), dimensions multiples of 32.
+# PN2_GCN_FUSED=0 restores the unfused path (A/B); results agree within fp32 summation order.
+FUSED_LAYER = os.environ.get("PN2_GCN_FUSED") != "0"
+# ... up to this many scans per batch.  Measured on MI355X (tools/gcn_time.py, 2 layers, forward + backward): 1 scan 1.07 vs
+# 2.1 ms, 8 scans 0.76 vs 1.7 ms, 32 scans 1.87 vs 1.66 ms — the per-scan workgroups re-read the weights once per scan and
+# column tile (L2 traffic grows with the scan count), while the unfused path's library GEMMs see ONE tall matrix.
+FUSED_MAX_SCANS = 16
+
+
+class _FusedTripletLayer(Function):
+    """TripletGCN.forward (network_TripletGCN.py:40-58) as one autograd node over the fused per-scan kernels:
+    nn1 on the virtual cat[x_i, e, x_j] -> split -> aggregate -> nn2, BatchNorm statistics per scan."""
+
+    @staticmethod
+    def forward(ctx, x, e, csr, node_ptr, edge_ptr, S, relu_out, eps, *params):
+        W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4 = params
+        x, e = x.contiguous(), e.contiguous()
+        trip = (x, e, csr.dst, csr.src)
+        dh, de = W3.size(1), e.size(1)
+        h1, h1p, m1, r1 = _ext.gcn_linear(W1, b1, edge_ptr, S, triplet=trip, bn=(g1, be1, eps[0]), relu=True)
+        h2, h2p, m2, r2 = _ext.gcn_linear(W2, b2, edge_ptr, S, A=h1, bn=(g2, be2, eps[1]), relu=True)
+        # node message = first + last block, summed over edge_index[1] in edge order (:50, 54-58); edge feature = the middle
+        agg = _ext.segment_sum2_rows(h2, csr.order, csr.rowptr, csr.num_nodes, dh, 0, dh + de)
+        e_out = _ext.gcn_edge_slice(h2, dh, de, relu_out)
+        t, tp, m3, r3 = _ext.gcn_linear(W3, b3, node_ptr, S, A=agg, bn=(g3, be3, eps[2]), relu=True)
+        out = _ext.gcn_linear(W4, b4, node_ptr, S, A=t, relu=relu_out)
+        ctx.csr, ctx.S, ctx.relu_out = csr, S, relu_out
+        ctx.save_for_backward(x, e, node_ptr, edge_ptr, h1, h1p, m1, r1, h2p, m2, r2, agg, t, tp, m3, r3, out, e_out, *params)
+        return out, e_out
+
+    @staticmethod
+    def backward(ctx, g_out, g_e):
+        (x, e, node_ptr, edge_ptr, h1, h1p, m1, r1, h2p, m2, r2, agg, t, tp, m3, r3, out, e_out,
+         W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4) = ctx.saved_tensors
+        csr, S = ctx.csr, ctx.S
+        dn, de, dh = x.size(1), e.size(1), W3.size(1)
+        g_out, g_e = g_out.contiguous(), g_e.contiguous()
+        if ctx.relu_out:
+            g_e = torch.where(e_out > 0, g_e, torch.zeros((), device=g_e.device))
+        f32 = torch.float32
+        shapes = [(tuple(p_.shape), f32) for p_ in (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4)]
+        (dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2, dW3, db3, dg3, dbe3, dW4, db4, gx) = _ext.zero_arena(
+            x.device, shapes + [(tuple(x.shape), f32)])
+        gz4 = _ext.gcn_linear_grad_w(W4.shape, node_ptr, S, dW4, db4, G=g_out, relu=ctx.relu_out, ypre=out, A=t)
+        g_t = _ext.gcn_linear_grad_x(gz4, W4, node_ptr, S)
+        gz3 = _ext.gcn_linear_grad_w(W3.shape, node_ptr, S, dW3, db3, G=g_t, bn=(tp, m3, r3, g3, be3), relu=True, A=agg,
+                                     dgamma=dg3, dbeta=dbe3)
+        g_agg = _ext.gcn_linear_grad_x(gz3, W3, node_ptr, S)
+        # the adjoint of split + aggregate ([g_agg[dst] | g_e | g_agg[dst]]) is read in place by the kernel
+        gz2 = _ext.gcn_linear_grad_w(W2.shape, edge_ptr, S, dW2, db2, adjoint=(g_agg, g_e, csr.dst, dh, de),
+                                     bn=(h2p, m2, r2, g2, be2), relu=True, A=h1, dgamma=dg2, dbeta=dbe2)
+        g_h1 = _ext.gcn_linear_grad_x(gz2, W2, edge_ptr, S)
+        gz1 = _ext.gcn_linear_grad_w(W1.shape, edge_ptr, S, dW1, db1, G=g_h1, bn=(h1p, m1, r1, g1, be1), relu=True,
+                                     triplet=(x, e, csr.dst, csr.src), dgamma=dg1, dbeta=dbe1)
+        ge = torch.empty_like(e)
+        _ext.gcn_linear_grad_x(gz1, W1, edge_ptr, S, scatter=(gx, ge, csr.dst, csr.src, dn, de))
+        return (gx, ge, None, None, None, None, None, None,
+                dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2, dW3, db3, dg3, dbe3, dW4, db4)
+
+
 class TripletGCN(torch.nn.Module):
     def __init__(self, dim_node, dim_edge, dim_hidden, aggr="add", use_bn=True):
         super().__init__()
@@ -323,13 +385,39 @@ class TripletGCN(torch.nn.Module):
         self.nn1 = build_mlp([dim_node * 2 + dim_edge, dim_hidden, dim_hidden * 2 + dim_edge],
                              do_bn=use_bn, on_last=True)
         self.nn2 = build_mlp([dim_hidden, dim_hidden, dim_node], do_bn=use_bn)
+        self.use_bn = use_bn
 
-    def forward(self, x, edge_feature, edge_index, csr: Optional[EdgeCSR] = None, scenes: Optional[SceneBatch] = None):
+    def _fused_ok(self, x, edge_feature, scenes):
+        if not (FUSED_LAYER and self.use_bn and x.is_cuda and x.dtype == torch.float32 and edge_feature.dtype == torch.float32
+                and len(self.nn1) == 6 and len(self.nn2) == 4 and getattr(_ext, "gcn_linear", None)):
+            return False
+        if scenes is not None:
+            if scenes.num_scenes > FUSED_MAX_SCANS:
+                return False
+            rows = max(max(scenes.edges_per_scene), max(scenes.nodes_per_scene))
+        else:
+            rows = max(edge_feature.size(0), x.size(0))
+        return rows >= 2 and _ext.gcn_fused_supported(self.dim_node, self.dim_edge, self.dim_hidden, rows)
+
+    def forward(self, x, edge_feature, edge_index, csr: Optional[EdgeCSR] = None, scenes: Optional[SceneBatch] = None,
+                relu_out: bool = False):
+        """`relu_out`: apply the ReLU TripletGCNModel puts on both results between layers (:76-78) inside the layer."""
         csr = csr if csr is not None else EdgeCSR(edge_index, x.size(0))
+        if self._fused_ok(x, edge_feature, scenes):
+            ptrs = scenes if scenes is not None else OneScan.get(x.device, x.size(0), edge_feature.size(0))
+            n1, n2 = self.nn1, self.nn2
+            params = (n1[0].weight, n1[0].bias, n1[1].weight, n1[1].bias, n1[3].weight, n1[3].bias, n1[4].weight, n1[4].bias,
+                      n2[0].weight, n2[0].bias, n2[1].weight, n2[1].bias, n2[3].weight, n2[3].bias)
+            return _FusedTripletLayer.apply(x, edge_feature, csr, ptrs.node_ptr, ptrs.edge_ptr, ptrs.num_scenes, bool(relu_out),
+                                            (n1[1].eps, n1[4].eps, n2[1].eps), *params)
         gcn_x, gcn_e = self.propagate(csr, x=x, edge_feature=edge_feature, scenes=scenes)
         if scenes is not None:
-            return mlp_per_scene(self.nn2, gcn_x, scenes.node_ptr), gcn_e
-        return self.nn2(gcn_x), gcn_e
+            gcn_x = mlp_per_scene(self.nn2, gcn_x, scenes.node_ptr)
+        else:
+            gcn_x = self.nn2(gcn_x)
+        if relu_out:
+            gcn_x, gcn_e = torch.nn.functional.relu(gcn_x), torch.nn.functional.relu(gcn_e)
+        return gcn_x, gcn_e
 
     def _lift_after_linear(self, n_edges):
         first = self.nn1[0]
@@ -372,8 +460,7 @@ class TripletGCNModel(BaseNetwork):
         if csr is None:
             csr = EdgeCSR(edges_indices, node_feature.size(0))
         for i, gconv in enumerate(self.gconvs):
-            node_feature, edge_feature = gconv(node_feature, edge_feature, edges_indices, csr, scenes)
-            if i < self.num_layers - 1:
-                node_feature = torch.nn.functional.relu(node_feature)
-                edge_feature = torch.nn.functional.relu(edge_feature)
+            # ReLU on both results between layers only (:76-78), applied inside the layer (fused into its last kernels)
+            node_feature, edge_feature = gconv(node_feature, edge_feature, edges_indices, csr, scenes,
+                                               relu_out=i < self.num_layers - 1)
         return node_feature, edge_feature

@@ -644,6 +644,37 @@ int pn2_segment_bn_rows_grad(int64_t R, int C, int ldx, int col0, int64_t S, con
                              const float *x, const int64_t *ptr, const float *gamma, const float *beta,
                              const float *mean, const float *rstd, int relu, float *grad_x,
                              float *dgamma_part, float *dbeta_part, void *stream);
+/* ---- fused TripletGCN blocks (round 4; csrc/gcn_fused.hip) ----------------------------------------------------
+ * network_TripletGCN.py:11-58 for scans of <= 128 rows batched block-diagonally: `ptr` (S + 1) int64 row offsets of the
+ * scans, BatchNorm1d(track_running_stats=False) statistics per scan (:20), everything a BatchNorm needs local to the
+ * workgroup that owns a 32-column tile of a Linear's output of ONE scan.  K, N (and dn, de, dh) multiples of 32;
+ * pn2_gcn_fused_supported says whether a layer's dimensions / the longest scan fit.
+ *   pn2_gcn_linear         Out (R, N) = [ReLU][BN_scan](A W^T + bias); A rows (R, lda), or (x != NULL) the virtual
+ *                          cat[x[dst], e, x[src]] of :46 (K = 2 dn + de) — the concatenation is never built.  With gamma:
+ *                          Ypre (R, N) pre-BN values, mean / rstd (S, N) for the backward.
+ *   pn2_gcn_linear_grad_w  backward up to the weights: G (R, N) gradient of Out — or (gagg != NULL) the adjoint of split +
+ *                          aggregate (:48-58) read in place: [gagg[dst] | gedge | gagg[dst]], N = 2 dh + dE — through the
+ *                          ReLU mask and BatchNorm's backward -> Gz (R, N); dW (N, K) += Gz^T A, dbias (N) += column sums
+ *                          of Gz, dgamma / dbeta (N) += (all zeroed by the caller once per step; fp32 atomics across scans).
+ *                          gamma NULL: no BatchNorm (relu: Ypre = Out).
+ *   pn2_gcn_linear_grad_x  input gradient Gz W: Gin (R, K), or (gx != NULL) scattered through the adjoint of the triplet
+ *                          gather: gx (nodes, dn) += columns [0, dn) at dst and [dn + de, K) at src, ge (R, de) = the middle.
+ *   pn2_gcn_edge_slice     out (R, de) = [ReLU] h[:, off : off + de]  (the new edge feature, :51).
+ * FLOPs 2 R K N each; every operand is read once per 32-column tile (L2-resident at these sizes). */
+int pn2_gcn_fused_supported(int dn, int de, int dh, int max_rows_per_scan);
+int pn2_gcn_linear(long long R, int S, int K, int N, const float *A, int lda, const float *x, const float *e,
+                   const long long *dst, const long long *src, int dn, int de, const float *W, const float *bias,
+                   const long long *ptr, const float *gamma, const float *beta, float eps, int relu, float *Ypre,
+                   float *Out, float *mean, float *rstd, void *stream);
+int pn2_gcn_linear_grad_w(long long R, int S, int K, int N, const float *G, const float *gagg, const float *gedge, int dh,
+                          int dE, const float *Ypre, const float *mean, const float *rstd, const float *gamma,
+                          const float *beta, int relu, const long long *ptr, const float *A, int lda, const float *x,
+                          const float *e, const long long *dst, const long long *src, int dn, int de, float *Gz, float *dW,
+                          float *dbias, float *dgamma, float *dbeta, void *stream);
+int pn2_gcn_linear_grad_x(long long R, int S, int K, int N, const float *Gz, const float *W, const long long *ptr, float *Gin,
+                          float *gx, float *ge, const long long *dst, const long long *src, int dn, int de, void *stream);
+int pn2_gcn_edge_slice(long long R, int ld, int off, int de, int relu, const float *hrows, float *out, void *stream);
+
 /* Running statistics of a BatchNorm1d WITH running statistics (the classification heads, network_PointNet.py:198-203) after
  * the S per-scan batches of pn2_segment_bn_rows, applied in scan order like S calls of F.batch_norm(training=True):
  * running <- (1 - momentum) running + momentum stat_s, variance unbiased (n_s / (n_s - 1)), num_batches_tracked += S. */

@@ -226,13 +226,17 @@ def test_lifted_product_gather_and_two_window_segment_sum_are_bit_exact(E, N, H,
         _ext.gather2_add_rows(q.cuda(), p.cuda(), ia.cuda(), ib.cuda(), cola, ldp)      # window past the row
 
 
-@pytest.mark.parametrize("lifted", [True, False])
-def test_three_layer_gcn_on_64_block_diagonal_scenes_matches_oracle(lifted, monkeypatch):
+@pytest.mark.parametrize("route", ["fused", "lifted", "concat"])
+def test_three_layer_gcn_on_64_block_diagonal_scenes_matches_oracle(route, monkeypatch):
     """configs[4]'s "3-hop GNN" over 64 scenes batched block-diagonally (per-scene BatchNorm statistics,
-    network_TripletGCN.py:20): HIP kernels vs the oracle backend, forward and gradients, with the first Linear of the
-    triplet MLP lifted after the product (default) and in the literal concat form."""
+    network_TripletGCN.py:20): HIP kernels vs the oracle backend, forward and gradients — the fused per-scan layer kernels
+    (csrc/gcn_fused.hip, the default for scans of <= 128 rows), and the unfused path with the first Linear of the triplet
+    MLP lifted after the product resp. in the literal concat form."""
     from pointnet2_ops import _ext
     from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    lifted = route == "lifted"
+    monkeypatch.setattr(gcn, "FUSED_LAYER", route == "fused")
+    monkeypatch.setattr(gcn, "FUSED_MAX_SCANS", 64)        # (the default routes batches of more than 16 scans to the unfused path)
     monkeypatch.setattr(gcn, "LIFT_MIN_EDGES", 0 if lifted else 1 << 60)
     torch.manual_seed(5)
     model = gcn.TripletGCNModel(num_layers=3, dim_node=256, dim_edge=256, dim_hidden=512).train()
@@ -262,10 +266,15 @@ def test_three_layer_gcn_on_64_block_diagonal_scenes_matches_oracle(lifted, monk
             gcn._ext = saved
 
     ref = run("cpu", oracle_ext.OracleRowsExt)
+    calls = {"n": 0}
+    if route == "fused":
+        real = _ext.gcn_linear
+        monkeypatch.setattr(_ext, "gcn_linear", lambda *a_, **k_: (calls.__setitem__("n", calls["n"] + 1), real(*a_, **k_))[1])
     got = run("cuda", _ext)
+    assert calls["n"] == (12 if route == "fused" else 0)       # 3 layers x 4 Linear blocks went through the fused kernels
     for a, b, name in zip(got[:4], ref[:4], ("nodes", "edges", "grad nodes", "grad edges")):
         err = float((a - b).abs().max())
-        print(f"\n[gcn x64] {name}: max abs err {err:.3e} (max |ref| {float(b.abs().max()):.3f})", end="")
+        print(f"\n[gcn x64 {route}] {name}: max abs err {err:.3e} (max |ref| {float(b.abs().max()):.3f})", end="")
         assert err <= 2e-4 * max(1.0, float(b.abs().max())), name
     # parameter gradients: BatchNorm over the 4..11 node rows / 12..110 edge rows of ONE scan is ill-conditioned — the same
     # model in fp32 vs fp64 on the CPU (pure torch) already differs by 4.5e-4 in norm per parameter (tools/gcn_conditioning.py);

@@ -9,6 +9,7 @@
 """
 import copy
 
+import numpy as np
 import pytest
 import torch
 
@@ -461,3 +462,151 @@ def test_lifted_first_layer_equals_the_grouped_route_at_module_level():
     _same_up_to_sparse_argmax_flips("d features", gf_a, gf_b)
     for k in g_b:       # (a re-routed maximum moves a whole row of a weight gradient: compared in norm)
         assert float((g_a[k] - g_b[k]).norm()) <= 1e-2 * float(g_b[k].norm()) + 1e-6, k
+
+
+# ------------------------------------------------------------------------------------ fused TripletGCN blocks
+def _scan_rows(sizes, width, seed):
+    g = torch.Generator().manual_seed(seed)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    return ptr, torch.randn(int(ptr[-1]), width, generator=g)
+
+
+@pytest.mark.parametrize("K,N,relu,bn", [(512, 1280, True, True), (768, 512, True, True), (512, 256, False, False),
+                                         (64, 32, True, False), (96, 160, False, True)])
+def test_gcn_linear_block_matches_torch(K, N, relu, bn):
+    """pn2_gcn_linear / _grad_w / _grad_x (csrc/gcn_fused.hip) against float64 torch: Linear -> per-scan BatchNorm (batch
+    statistics of every scan's rows, biased variance) -> ReLU, forward and every gradient; scans of 2 .. 128 rows (ragged
+    row tiles, one-wave and four-wave scans)."""
+    from pointnet2_ops import _ext as e
+    sizes = [72, 2, 110, 9, 128, 33, 64]
+    ptr, A = _scan_rows(sizes, K, K + N)
+    g = torch.Generator().manual_seed(N)
+    W, b = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    gout = torch.randn(A.size(0), N, generator=g)
+    S = len(sizes)
+    d = lambda t_: t_.cuda()
+    if bn:
+        out, ypre, mean, rstd = e.gcn_linear(d(W), d(b), d(ptr), S, A=d(A), bn=(d(gamma), d(beta), 1e-5), relu=relu)
+    else:
+        out = e.gcn_linear(d(W), d(b), d(ptr), S, A=d(A), relu=relu)
+    # float64 reference through autograd
+    A64, W64, b64 = A.double().requires_grad_(True), W.double().requires_grad_(True), b.double().requires_grad_(True)
+    g64, be64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = A64 @ W64.t() + b64
+    if bn:
+        y = torch.cat([torch.nn.functional.batch_norm(y[ptr[i]:ptr[i + 1]], None, None, g64, be64, True, 0.0, 1e-5)
+                       for i in range(S)])
+    if relu:
+        y = y.relu()
+    (y * gout.double()).sum().backward()
+    assert float((out.cpu().double() - y.detach()).abs().max()) <= 1e-4 * max(1.0, float(y.detach().abs().max()))
+    f32 = torch.float32
+    dW, db, dg, dbe = e.zero_arena(torch.device("cuda"), [((N, K), f32), ((N,), f32), ((N,), f32), ((N,), f32)])
+    if bn:
+        gz = e.gcn_linear_grad_w((N, K), d(ptr), S, dW, db, G=d(gout), bn=(ypre, mean, rstd, d(gamma), d(beta)), relu=relu,
+                                 A=d(A), dgamma=dg, dbeta=dbe)
+    else:
+        gz = e.gcn_linear_grad_w((N, K), d(ptr), S, dW, db, G=d(gout), relu=relu, ypre=out, A=d(A))
+    gin = e.gcn_linear_grad_x(gz, d(W), d(ptr), S)
+
+    def close(name, got, want, tol=2e-4):
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= tol * max(1.0, float(want.abs().max())), (name, err)
+
+    close("grad input", gin, A64.grad)
+    close("grad weight", dW, W64.grad)
+    if bn:
+        close("dgamma", dg, g64.grad)
+        close("dbeta", dbe, be64.grad)
+        assert float(db.abs().max()) <= 1e-3          # a bias in front of a BatchNorm has no gradient
+    else:
+        close("grad bias", db, b64.grad)
+
+
+def test_gcn_triplet_gather_and_split_aggregate_adjoint_read_in_place():
+    """AMODE 1 (the virtual cat[x[dst], e, x[src]]), GMODE 1 (the adjoint of split + aggregate) and the scattering input
+    gradient against the materialised formulation (torch, float64)."""
+    from pointnet2_ops import _ext as e
+    dn = de = 64
+    dh = 96
+    n_objs = [4, 11, 3, 7]        # (a 2-edge scan makes BatchNorm's x-hat +-1 whatever the input: fp32-vs-fp64 noise of 1e-3)
+    edges, node_ptr, edge_ptr = [], [0], [0]
+    for n in n_objs:
+        ei = torch.tensor([[a, b] for a in range(n) for b in range(n) if a != b]).t() + node_ptr[-1]
+        edges.append(ei); node_ptr.append(node_ptr[-1] + n); edge_ptr.append(edge_ptr[-1] + ei.size(1))
+    ei = torch.cat(edges, 1).contiguous()
+    src, dst = ei[0].contiguous(), ei[1].contiguous()
+    Nn, E, S = node_ptr[-1], edge_ptr[-1], len(n_objs)
+    g = torch.Generator().manual_seed(3)
+    x, ef = torch.randn(Nn, dn, generator=g), torch.randn(E, de, generator=g)
+    K, N = 2 * dn + de, 2 * dh + de
+    W1, b1 = torch.randn(dh, K, generator=g) / K ** 0.5, torch.randn(dh, generator=g) * 0.1
+    W2, b2 = torch.randn(N, dh, generator=g) / dh ** 0.5, torch.randn(N, generator=g) * 0.1
+    gm1, bt1 = torch.rand(dh, generator=g) + 0.5, torch.randn(dh, generator=g) * 0.2
+    gm2, bt2 = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    g_agg, g_edge = torch.randn(Nn, dh, generator=g), torch.randn(E, de, generator=g)
+    eptr = torch.tensor(edge_ptr, dtype=torch.int64)
+    d = lambda t_: t_.cuda()
+    trip = (d(x), d(ef), d(dst), d(src))
+    h1, h1p, m1, r1 = e.gcn_linear(d(W1), d(b1), d(eptr), S, triplet=trip, bn=(d(gm1), d(bt1), 1e-5), relu=True)
+    h2, h2p, m2, r2 = e.gcn_linear(d(W2), d(b2), d(eptr), S, A=h1, bn=(d(gm2), d(bt2), 1e-5), relu=True)
+    # float64 reference
+    P = [t_.double().requires_grad_(True) for t_ in (x, ef, W1, b1, gm1, bt1, W2, b2, gm2, bt2)]
+    x6, e6, W16, b16, g16, t16, W26, b26, g26, t26 = P
+    bnf = lambda y, ga, be: torch.cat([torch.nn.functional.batch_norm(y[eptr[i]:eptr[i + 1]], None, None, ga, be, True, 0.0, 1e-5)
+                                       for i in range(S)])
+    cat = torch.cat([x6[dst], e6, x6[src]], 1)
+    a1 = bnf(cat @ W16.t() + b16, g16, t16).relu()
+    a2 = bnf(a1 @ W26.t() + b26, g26, t26).relu()
+    node = torch.zeros(Nn, dh, dtype=torch.float64).index_add_(0, dst, a2[:, :dh] + a2[:, dh + de:])
+    ((node * g_agg.double()).sum() + (a2[:, dh:dh + de] * g_edge.double()).sum()).backward()
+    assert float((h2.cpu().double() - a2.detach()).abs().max()) <= 2e-4 * max(1.0, float(a2.abs().max()))
+    f32 = torch.float32
+    dW2, db2, dg2, dbe2, dW1, db1, dg1, dbe1, gx = e.zero_arena(
+        torch.device("cuda"), [((N, dh), f32), ((N,), f32), ((N,), f32), ((N,), f32), ((dh, K), f32), ((dh,), f32), ((dh,), f32),
+                               ((dh,), f32), ((Nn, dn), f32)])
+    gz2 = e.gcn_linear_grad_w((N, dh), d(eptr), S, dW2, db2, adjoint=(d(g_agg), d(g_edge), d(dst), dh, de),
+                              bn=(h2p, m2, r2, d(gm2), d(bt2)), relu=True, A=h1, dgamma=dg2, dbeta=dbe2)
+    g_h1 = e.gcn_linear_grad_x(gz2, d(W2), d(eptr), S)
+    gz1 = e.gcn_linear_grad_w((dh, K), d(eptr), S, dW1, db1, G=g_h1, bn=(h1p, m1, r1, d(gm1), d(bt1)), relu=True, triplet=trip,
+                              dgamma=dg1, dbeta=dbe1)
+    ge = torch.empty(E, de, device="cuda")
+    e.gcn_linear_grad_x(gz1, d(W1), d(eptr), S, scatter=(gx, ge, d(dst), d(src), dn, de))
+    for name, got, want in (("dW2", dW2, W26.grad), ("dgamma2", dg2, g26.grad), ("dbeta2", dbe2, t26.grad), ("dW1", dW1, W16.grad),
+                            ("dgamma1", dg1, g16.grad), ("dbeta1", dbe1, t16.grad), ("grad x", gx, x6.grad), ("grad e", ge, e6.grad)):
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= 5e-4 * max(1.0, float(want.abs().max())), (name, err)
+    sl = e.gcn_edge_slice(h2, dh, de, True)
+    assert torch.equal(sl, h2[:, dh:dh + de].relu())
+
+
+def test_one_scan_triplet_gcn_takes_the_fused_layer_and_matches_the_unfused_path():
+    """The reference's regime (one scan per step, no SceneBatch): 9 objects / 72 ordered pairs, 2 layers, fused vs unfused
+    HIP path — results and every gradient."""
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    torch.manual_seed(11)
+    model = gcn.TripletGCNModel(num_layers=2, dim_node=256, dim_edge=256, dim_hidden=512).cuda().train()
+    n = 9
+    ei = torch.tensor([[a, b] for a in range(n) for b in range(n) if a != b]).t().contiguous().cuda()
+    g = torch.Generator().manual_seed(12)
+    x, ef = torch.randn(n, 256, generator=g).cuda(), torch.randn(n * (n - 1), 256, generator=g).cuda()
+
+    def run(fused):
+        prev, gcn.FUSED_LAYER = gcn.FUSED_LAYER, fused
+        try:
+            m = copy.deepcopy(model)
+            xx, ee = x.clone().requires_grad_(True), ef.clone().requires_grad_(True)
+            ox, oe = m(xx, ee, ei)
+            (ox.square().mean() + oe.square().mean()).backward()
+            return [ox.detach(), oe.detach(), xx.grad, ee.grad] + [q.grad for q in m.parameters()]
+        finally:
+            gcn.FUSED_LAYER = prev
+
+    a, b = run(True), run(False)
+    for i, (u, v) in enumerate(zip(a[:4], b[:4])):
+        assert float((u - v).abs().max()) <= 2e-4 * max(1.0, float(v.abs().max())), i
+    top = max(float(v.norm()) for v in b[4:])
+    for u, v in zip(a[4:], b[4:]):
+        if float(v.norm()) > 1e-6 * top:
+            assert float((u - v).norm() / v.norm()) <= 1e-2

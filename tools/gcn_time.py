@@ -1,4 +1,5 @@
-"""TripletGCN (2 layers, 256/256/512) forward+backward time on the GPU: lifted first Linear vs the literal concat form,
+"""TripletGCN (2 layers, 256/256/512) forward+backward time on the GPU: fused per-scan layer kernels vs the unfused path
+(lifted first Linear / literal concat form),
 for one scan (9 objects / 72 edges) and for block-diagonal batches of 8 / 32 / 64 scans.
     python tools/gcn_time.py            (GPU box; prints one JSON line per case)"""
 import json, os, sys
@@ -7,7 +8,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn  # noqa: E402
 
 
-def case(n_scans, lifted, iters=30):
+def case(n_scans, lifted, iters=30, fused=False):
+    gcn.FUSED_LAYER = fused
     gcn.LIFT_MIN_EDGES = 0 if lifted else 1 << 60
     torch.manual_seed(0)
     net = gcn.TripletGCNModel(2, dim_node=256, dim_edge=256, dim_hidden=512).cuda()
@@ -42,4 +44,5 @@ if __name__ == "__main__":
         row = {"scans": n_scans, "edges": 72 * n_scans}
         for lifted in (False, True):
             row["lifted_ms" if lifted else "concat_ms"] = round(case(n_scans, lifted), 3)
+        row["fused_ms"] = round(case(n_scans, False, fused=True), 3)        # csrc/gcn_fused.hip (round 4)
         print(json.dumps(row))
