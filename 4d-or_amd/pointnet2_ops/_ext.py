@@ -725,7 +725,7 @@ def group_lift_supported(n0) -> bool:
     return bool(_lib.pn2_group_lift_supported(int(n0)))
 
 
-def group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, radius, stats=None, out_bf16=False):
+def group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, radius, stats=None, out_bf16=False, out=None):
     """The first conv of an SA stack applied BEFORE the grouping: P (B,N,N0) = per-point products f Wf^T, Wx (N0,3) the
     coordinate columns -> Y0 (B*m*ns, N0) = P[idx] + Wx rel, rel = (xyz[idx] - new_xyz) (/ radius); `stats` (2,N0) f64 +=
     column sums of y0 and y0^2.  Replaces group_points x 2 + cat + Conv2d 1x1 of the first layer
@@ -737,7 +737,12 @@ def group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, radius, stats=None, out
     N, N0 = xyz.size(1), P.size(-1)
     if P.numel() != B * N * N0 or tuple(Wx.shape) != (N0, 3) or tuple(new_xyz.shape) != (B, m, 3):
         _fail("group_lift_rows: P must be (B, N, N0), Wx (N0, 3), new_xyz (B, m, 3)")
-    Y = torch.empty(B * m * ns, N0, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=P.device)
+    if out is not None:          # (a scan's rows of a batch's tensor: the per-scan calls of a segment-table stack)
+        if out.numel() != B * m * ns * N0 or out.dtype != (torch.bfloat16 if out_bf16 else torch.float32) or not out.is_contiguous():
+            _fail("group_lift_rows: out must be a contiguous (B m ns, N0) tensor of the output type")
+        Y = out
+    else:
+        Y = torch.empty(B * m * ns, N0, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=P.device)
     _call("pn2_group_lift_rows_bf16" if out_bf16 else "pn2_group_lift_rows", P, B, N, m, ns, N0, int(bool(normalize)), float(radius if radius is not None else 1.0),
           _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(P), _ptr(Wx), _ptr(Y), _ptr(stats),
           alg_bytes=B * (4 * m * ns + 12 * N + 12 * m + 4 * N0 * N + (2 if out_bf16 else 4) * N0 * m * ns))
@@ -774,6 +779,24 @@ def group_lift_rows_grad(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, rad
           _ptr(acc), _ptr(ws), ws_bytes,
           alg_bytes=8 * M + (2 if bf else 4) * M * N0 + 4 * B * N * (2 * N0 + 4) + 12 * B * m)
     return S
+
+
+def group_lift_rows_grad_scan(G_all, P, Wx, consts, xyz, new_xyz_all, ptr, refs_all, ns, normalize, radius, acc, S_out):
+    """pn2_group_lift_rows_grad[_bf16] for ONE scan of a batch whose inverse index, gradient rows and centres stay whole:
+    `xyz`, `P`, `ptr` (B' N + 1 entries) and `S_out` are the scan's slices (per point), `G_all` (M, N0), `new_xyz_all` and
+    `refs_all` the batch's tensors — row ids in `refs_all` index them directly, so nothing is copied or re-based.  The launch
+    is the one a single-scan step makes (same grid, same sums)."""
+    bf = G_all.dtype == torch.bfloat16
+    Bs, N = xyz.size(0), xyz.size(1)
+    m = new_xyz_all.size(1)
+    N0 = G_all.size(1)
+    ws_bytes = int(_lib.pn2_group_lift_rows_grad_workspace_bytes(Bs, N, m, int(ns), N0))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G_all.device)
+    _call("pn2_group_lift_rows_grad_bf16" if bf else "pn2_group_lift_rows_grad", G_all, Bs, N, m, int(ns), N0, int(bool(normalize)),
+          float(radius if radius is not None else 1.0), _ptr(xyz), _ptr(new_xyz_all), _ptr(G_all), _ptr(P), _ptr(Wx), _ptr(consts),
+          _ptr(ptr), _ptr(refs_all), _ptr(S_out), _ptr(acc), _ptr(ws), ws_bytes,
+          alg_bytes=(2 if bf else 4) * Bs * m * int(ns) * N0 + 4 * Bs * N * (2 * N0 + 4))
+    return S_out
 
 
 def rows_max(x):

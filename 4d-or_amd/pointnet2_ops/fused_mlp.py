@@ -60,6 +60,9 @@ LIFT_SPARSE = _os.environ.get("PN2_LIFT_SPARSE") != "0"
 #: ... and on the bf16 node (same kernels with bf16 rows: y0 and the gradient rows in bf16, per-point products and every sum
 #: in fp32).  PN2_BF16_LIFT=0 restores the grouped bf16 route (A/B).
 BF16_LIFT = _os.environ.get("PN2_BF16_LIFT") != "0"
+#: ... also inside segment-table stacks (per-scan statistics at the whole-batch launch count): the lifted layer is issued once
+#: per scan (the launches of single-scan steps), the rest of the stack through the table.  PN2_BF16_LIFT_SEG=0: grouped route.
+BF16_LIFT_SEG = _os.environ.get("PN2_BF16_LIFT_SEG") != "0"
 
 #: arithmetic of the shared-MLP stacks.  float32 = exact fp32 MFMA (the parity path, default).  bfloat16 = the MI355X
 #: counterpart of the reference's 16-bit AMP training (scene_graph_prediction/main.py:64 `precision=16`): activations
@@ -443,6 +446,25 @@ def _unit_consts(device, n):
     return t
 
 
+def _lift_forward_scans(e, feats, W, group, stat_blocks, seg):
+    """_lift_forward for a segment-table stack (bf16 node): ONE per-point GEMM for the batch, then one gather launch per scan
+    with that scan's (2, N0) block of the statistics — the launches (and sums) of single-scan steps."""
+    xyz, new_xyz, idx, _use_xyz, normalize, radius = group[:6]
+    B, N, C = feats.shape
+    N0 = W.size(0)
+    P = e.mlp_gemm(feats.view(B * N, C), W[:, 3:].contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
+    per = idx.size(1) * idx.size(2)
+    Y = torch.empty(B * per, N0, dtype=torch.bfloat16, device=feats.device)
+    Wx = W[:, :3].contiguous()
+    c0 = 0
+    for si, rows in enumerate(seg.rows):
+        c1 = c0 + rows // per
+        e.group_lift_rows(P[c0:c1], xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], Wx, normalize, radius, stats=stat_blocks[si],
+                          out_bf16=True, out=Y[c0 * per:c1 * per])
+        c0 = c1
+    return Y, P
+
+
 def _lift_forward(e, feats, W, group, stats, out_bf16=False):
     """y0 (B m ns, N0) of a grouped stack's first layer without the grouped rows: P = f Wf^T over the B N points (a plain
     fp32 GEMM), then the gather + coordinate terms + column sums in one kernel (pn2_group_lift_rows)."""
@@ -475,7 +497,10 @@ class _FusedMLPBf16(Function):
             # the gradient rows in bf16 — no grouped tensor, no M-row first-layer GEMMs, no feature-gradient scatter
             has_inv = len(group) > 6 and group[6] is not None
             crowded = len(group) > 7 and bool(group[7])
-            lift = bool(BF16_LIFT and pre is None and seg is None and _lift_eligible(e, layers, use_xyz, x)
+            # (with a segment table: one launch per scan for this layer — the launches of single-scan steps, each scan's
+            # column sums in its own block — and the table for the rest of the stack)
+            lift = bool(BF16_LIFT and pre is None and _lift_eligible(e, layers, use_xyz, x)
+                        and (seg is None or (BF16_LIFT_SEG and all(r % (idx.size(1) * idx.size(2)) == 0 for r in seg.rows)))
                         and (not any(ctx.needs_input_grad) or has_inv or crowded or LIFT_SPARSE))
             if lift:
                 if any(ctx.needs_input_grad) and not has_inv:
@@ -508,7 +533,10 @@ class _FusedMLPBf16(Function):
             if seg is not None:
                 if not use_batch:
                     raise RuntimeError("fused_mlp: a segment table needs training-mode BatchNorm in every layer")
-                y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stat_bufs[l], seg=seg)
+                if lift and l == 0:
+                    y, ctx.lift_P = _lift_forward_scans(e, feats, W, group, stat_bufs[0], seg)
+                else:
+                    y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stat_bufs[l], seg=seg)
                 rm = rv = nbt = None
                 if bn.training and bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None:
                     rm, rv, nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
@@ -608,18 +636,38 @@ class _FusedMLPBf16(Function):
             if l == 0 and lift:
                 # first layer applied before the grouping: per-point sums of dL/dy0 (bf16 gradient rows, fp32 sums) through
                 # the inverse index, then fp32 GEMMs over the B N points — the fp32 node's code (csrc/group_lift.hip)
-                consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[0], fins[0], ctx.batch_flags[0])
-                grads[1], grads[2] = dgamma, dbeta
                 if gmode != e.PRO_GY or G is None:
                     raise RuntimeError("fused_mlp: the lifted first layer expects the dense gradient of the layer above")
                 xyz, new_xyz, idx, _u, normalize, radius = ctx.group[:6]
                 N0, Kf = Ws[0].size(0), Ws[0].size(1) - 3
                 inv = ctx.group[6] if (len(ctx.group) > 6 and ctx.group[6] is not None) else ctx.lift_inv
                 Wx = Ws[0][:, :3].contiguous()
-                S = e.group_lift_rows_grad(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2), normalize,
-                                           radius, arena[-1]).view(-1, N0)
-                dWx = torch.addcmul(arena[-1][:3 * N0].view(N0, 3), torch.mm(Wx, arena[-1][3 * N0:].view(3, 3)),
-                                    consts[1].unsqueeze(1))
+                if seg is not None:
+                    # per-scan constants, one launch sequence per scan on that scan's points (the whole batch's gradient
+                    # rows, centres and row ids are indexed in place)
+                    consts, dgamma, dbeta = e.bn_bwd_consts_seg(sums, seg, gammas[0], fins[0], ctx.batch_flags[0])
+                    grads[1], grads[2] = dgamma, dbeta
+                    Bq, Nq = xyz.size(0), xyz.size(1)
+                    per = idx.size(1) * idx.size(2)
+                    accs = e.zero_arena(x.device, [((seg.nseg, 3 * N0 + 9), f32)])[0]
+                    S = torch.empty(Bq, Nq, N0, dtype=f32, device=x.device)
+                    c0 = 0
+                    for si, rows in enumerate(seg.rows):
+                        c1 = c0 + rows // per
+                        e.group_lift_rows_grad_scan(G, ctx.lift_P[c0:c1], Wx, consts[si], xyz[c0:c1], new_xyz,
+                                                    inv[0][c0 * Nq:c1 * Nq + 1], inv[1], idx.size(2), normalize, radius,
+                                                    accs[si], S[c0:c1])
+                        c0 = c1
+                    S = S.view(-1, N0)
+                    RR = accs[:, 3 * N0:].view(seg.nseg, 3, 3)
+                    dWx = accs[:, :3 * N0].view(seg.nseg, N0, 3).sum(0) + torch.einsum("sn,nk,skj->nj", consts[:, 1], Wx, RR)
+                else:
+                    consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[0], fins[0], ctx.batch_flags[0])
+                    grads[1], grads[2] = dgamma, dbeta
+                    S = e.group_lift_rows_grad(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2), normalize,
+                                               radius, arena[-1]).view(-1, N0)
+                    dWx = torch.addcmul(arena[-1][:3 * N0].view(N0, 3), torch.mm(Wx, arena[-1][3 * N0:].view(3, 3)),
+                                        consts[1].unsqueeze(1))
                 dWf = e.mlp_wgrad(S, _unit_consts(S.device, N0), x.view(-1, Kf), e.PRO_GY, e.PRO_NONE, G=S)
                 grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
                 if need_dgrad0:
@@ -819,7 +867,7 @@ class _SegmentedGroupMLP(Function):
         feats = None if x is None else x.contiguous()
         # fp32 stacks whose first layer can be applied before the grouping (_lift_eligible) form no rows at all: every scan's
         # inner call lifts, with its slice of ONE inverse index of the whole batch (rows and points of a scan are contiguous)
-        lift_all = bool(inner is _FusedMLP and _lift_eligible(e, layers, use_xyz, feats)
+        lift_all = bool((inner is _FusedMLP or (inner is _FusedMLPBf16 and BF16_LIFT)) and _lift_eligible(e, layers, use_xyz, feats)
                         and not (len(group) > 8 and group[8] is not None))
         inv_all = None
         if lift_all and any(ctx.needs_input_grad):
@@ -924,7 +972,7 @@ class _SegTableMLP(Function):
         sub.seg = _ext().SegTable.get(dev, rows_per_scan)
         out, arg = inner.forward(sub, x, ns, layers, group, *params)
         L = len(layers)
-        if sub.seg.total != sub.saved_tensors[0].size(0):
+        if sub.seg.total != (sub.M if getattr(sub, "lift", False) else sub.saved_tensors[0].size(0)):
             raise RuntimeError("fused_mlp: the scans' row counts must sum to the rows of the stack")
         _update_running_stats(layers, [F if bn.momentum is None else None                 # (the others: in the finalize kernel)
                                        for (_, bn), F in zip(layers, sub.saved_tensors[1 + L:1 + 2 * L])], list(rows_per_scan))
