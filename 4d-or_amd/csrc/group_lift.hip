@@ -505,3 +505,50 @@ extern "C" int pn2_group_lift_rows_grad_bf16(int B, int N, int m, int ns, int N0
   return lift_rows_grad_launch(B, N, m, ns, N0, normalize, radius, xyz, new_xyz, G, true, P, Wx, consts, ptr, refs, S, acc,
                                workspace, workspace_bytes, stream);
 }
+
+// ---- one host call for the S scans of a batch (segment-table stacks of the mixed-precision node, round 4) --------------
+// The launches are exactly those of S single-scan calls — scan s: clouds [c_s, c_s + clouds[s]), its own (2, N0) block of the
+// statistics resp. its own (3, N0) constants and (3 N0 + 9) accumulator row — issued from ONE C call instead of S trips through
+// the Python binding (the 32-scan step was bound by its host thread).  `clouds`: S host integers summing to B.
+extern "C" int pn2_group_lift_rows_scans(int S, const int *clouds, int B, int N, int m, int ns, int N0, int normalize,
+                                         float radius, const float *xyz, const float *new_xyz, const int *idx, const float *P,
+                                         const float *Wx, void *Y, int y_bf16, double *stats, void *stream) {
+  if (S < 0 || B < 0 || !clouds) return S < 0 || B < 0 ? PN2_EINVAL : PN2_ENULL;
+  long long c0 = 0;
+  for (int s = 0; s < S; ++s) {
+    const int nc = clouds[s];
+    if (nc < 0 || c0 + nc > B) return PN2_EINVAL;
+    const size_t rows = (size_t)c0 * m * ns;
+    void *Ys = y_bf16 ? (void *)((unsigned short *)Y + rows * N0) : (void *)((float *)Y + rows * N0);
+    const int rc = lift_rows_launch(nc, N, m, ns, N0, normalize, radius, xyz + (size_t)c0 * N * 3, new_xyz + (size_t)c0 * m * 3,
+                                    idx + rows, P + (size_t)c0 * N * N0, Wx, Ys, y_bf16 != 0,
+                                    stats ? stats + (size_t)s * 2 * N0 : nullptr, stream);
+    if (rc != PN2_OK) return rc;
+    c0 += nc;
+  }
+  return c0 == B ? PN2_OK : PN2_EINVAL;
+}
+
+// G (M, N0), new_xyz, refs: the whole batch's tensors (row ids index them in place); xyz, P, ptr, S_out: sliced per scan here.
+// consts (S, 3, N0), acc (S, 3 N0 + 9); `workspace`: pn2_group_lift_rows_grad_workspace_bytes of the LARGEST scan, reused
+// (the scans' launches are ordered on the stream).
+extern "C" int pn2_group_lift_rows_grad_scans(int S, const int *clouds, int B, int N, int m, int ns, int N0, int normalize,
+                                              float radius, const float *xyz, const float *new_xyz, const void *G, int g_bf16,
+                                              const float *P, const float *Wx, const float *consts, const int *ptr,
+                                              const int *refs, float *S_out, float *acc, void *workspace,
+                                              size_t workspace_bytes, void *stream) {
+  if (S < 0 || B < 0) return PN2_EINVAL;
+  if (!clouds) return PN2_ENULL;
+  long long c0 = 0;
+  for (int s = 0; s < S; ++s) {
+    const int nc = clouds[s];
+    if (nc < 0 || c0 + nc > B) return PN2_EINVAL;
+    const int rc = lift_rows_grad_launch(nc, N, m, ns, N0, normalize, radius, xyz + (size_t)c0 * N * 3, new_xyz, G, g_bf16 != 0,
+                                         P + (size_t)c0 * N * N0, Wx, consts + (size_t)s * 3 * N0, ptr + (size_t)c0 * N, refs,
+                                         S_out + (size_t)c0 * N * N0, acc + (size_t)s * (3 * N0 + 9), workspace, workspace_bytes,
+                                         stream);
+    if (rc != PN2_OK) return rc;
+    c0 += nc;
+  }
+  return c0 == B ? PN2_OK : PN2_EINVAL;
+}

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "pn2_group_lift_rows_grad": [_c_int] * 6 + [_c_f32] + [_c_vp] * 11 + [_c_sz, _c_vp],
     "pn2_group_lift_rows_bf16": [_c_int] * 6 + [_c_f32] + [_c_vp] * 8,
     "pn2_group_lift_rows_grad_bf16": [_c_int] * 6 + [_c_f32] + [_c_vp] * 11 + [_c_sz, _c_vp],
+    "pn2_group_lift_rows_scans": [_c_int, _c_vp] + [_c_int] * 6 + [_c_f32] + [_c_vp] * 6 + [_c_int, _c_vp, _c_vp],
+    "pn2_group_lift_rows_grad_scans": [_c_int, _c_vp] + [_c_int] * 6 + [_c_f32] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 8 + [_c_sz, _c_vp],
     "pn2_group_rows_grad_csr_bf16": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_rows_grad_bf16": [_c_int] * 7 + [_c_vp] * 4,
     "pn2_rows_max": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -781,21 +783,52 @@ def group_lift_rows_grad(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, rad
     return S
 
 
-def group_lift_rows_grad_scan(G_all, P, Wx, consts, xyz, new_xyz_all, ptr, refs_all, ns, normalize, radius, acc, S_out):
-    """pn2_group_lift_rows_grad[_bf16] for ONE scan of a batch whose inverse index, gradient rows and centres stay whole:
-    `xyz`, `P`, `ptr` (B' N + 1 entries) and `S_out` are the scan's slices (per point), `G_all` (M, N0), `new_xyz_all` and
-    `refs_all` the batch's tensors — row ids in `refs_all` index them directly, so nothing is copied or re-based.  The launch
-    is the one a single-scan step makes (same grid, same sums)."""
-    bf = G_all.dtype == torch.bfloat16
-    Bs, N = xyz.size(0), xyz.size(1)
-    m = new_xyz_all.size(1)
-    N0 = G_all.size(1)
-    ws_bytes = int(_lib.pn2_group_lift_rows_grad_workspace_bytes(Bs, N, m, int(ns), N0))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G_all.device)
-    _call("pn2_group_lift_rows_grad_bf16" if bf else "pn2_group_lift_rows_grad", G_all, Bs, N, m, int(ns), N0, int(bool(normalize)),
-          float(radius if radius is not None else 1.0), _ptr(xyz), _ptr(new_xyz_all), _ptr(G_all), _ptr(P), _ptr(Wx), _ptr(consts),
-          _ptr(ptr), _ptr(refs_all), _ptr(S_out), _ptr(acc), _ptr(ws), ws_bytes,
-          alg_bytes=(2 if bf else 4) * Bs * m * int(ns) * N0 + 4 * Bs * N * (2 * N0 + 4))
+_HOST_INTS = {}
+
+
+def _host_ints(vals):
+    """A C int array of host numbers (cached per tuple: the scans' cloud counts repeat every step)."""
+    key = tuple(int(v) for v in vals)
+    arr = _HOST_INTS.get(key)
+    if arr is None:
+        if len(_HOST_INTS) > 4096:
+            _HOST_INTS.clear()
+        arr = _HOST_INTS[key] = (ctypes.c_int * len(key))(*key)
+    return arr
+
+
+def group_lift_rows_scans(P, xyz, new_xyz, idx, Wx, normalize, radius, stats, clouds, out_bf16=True):
+    """group_lift_rows for the S scans of a batch in one host call: scan s = clouds[s] consecutive clouds, its column sums in
+    stats[s] (S, 2, N0).  Same launches as S calls (include/pn2_hip.h)."""
+    B, m, ns = idx.shape
+    N, N0 = xyz.size(1), P.size(-1)
+    Y = torch.empty(B * m * ns, N0, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=P.device)
+    arr = _host_ints(clouds)
+    _call("pn2_group_lift_rows_scans", P, len(arr), ctypes.cast(arr, ctypes.c_void_p), B, N, m, ns, N0, int(bool(normalize)),
+          float(radius if radius is not None else 1.0), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(P), _ptr(Wx), _ptr(Y),
+          int(bool(out_bf16)), _ptr(stats),
+          alg_bytes=B * (4 * m * ns + 12 * N + 12 * m + 4 * N0 * N + (2 if out_bf16 else 4) * N0 * m * ns),
+          label="pn2_group_lift_rows_bf16" if out_bf16 else "pn2_group_lift_rows")
+    return Y
+
+
+def group_lift_rows_grad_scans(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, radius, acc, clouds):
+    """group_lift_rows_grad for the S scans of a batch in one host call: consts (S, 3, N0), acc (S, 3 N0 + 9) zero on entry ->
+    S (B, N, N0).  Same launches as S single-scan calls."""
+    bf = G.dtype == torch.bfloat16
+    ptr, refs = inv
+    B, N = xyz.size(0), xyz.size(1)
+    m = new_xyz.size(1)
+    N0 = G.size(1)
+    S_out = torch.empty(B, N, N0, dtype=torch.float32, device=G.device)
+    arr = _host_ints(clouds)
+    ws_bytes = int(_lib.pn2_group_lift_rows_grad_workspace_bytes(max(arr), N, m, int(ns), N0))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
+    _call("pn2_group_lift_rows_grad_scans", G, len(arr), ctypes.cast(arr, ctypes.c_void_p), B, N, m, int(ns), N0,
+          int(bool(normalize)), float(radius if radius is not None else 1.0), _ptr(xyz), _ptr(new_xyz), _ptr(G), int(bf), _ptr(P),
+          _ptr(Wx), _ptr(consts), _ptr(ptr), _ptr(refs), _ptr(S_out), _ptr(acc), _ptr(ws), ws_bytes,
+          alg_bytes=(2 if bf else 4) * G.size(0) * N0 + 4 * B * N * (2 * N0 + 4),
+          label="pn2_group_lift_rows_grad_bf16" if bf else "pn2_group_lift_rows_grad")
     return S_out
 
 

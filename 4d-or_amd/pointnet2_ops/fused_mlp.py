@@ -454,14 +454,8 @@ def _lift_forward_scans(e, feats, W, group, stat_blocks, seg):
     N0 = W.size(0)
     P = e.mlp_gemm(feats.view(B * N, C), W[:, 3:].contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
     per = idx.size(1) * idx.size(2)
-    Y = torch.empty(B * per, N0, dtype=torch.bfloat16, device=feats.device)
-    Wx = W[:, :3].contiguous()
-    c0 = 0
-    for si, rows in enumerate(seg.rows):
-        c1 = c0 + rows // per
-        e.group_lift_rows(P[c0:c1], xyz[c0:c1], new_xyz[c0:c1], idx[c0:c1], Wx, normalize, radius, stats=stat_blocks[si],
-                          out_bf16=True, out=Y[c0 * per:c1 * per])
-        c0 = c1
+    Y = e.group_lift_rows_scans(P, xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stat_blocks,
+                                [rows // per for rows in seg.rows], out_bf16=True)
     return Y, P
 
 
@@ -650,14 +644,8 @@ class _FusedMLPBf16(Function):
                     Bq, Nq = xyz.size(0), xyz.size(1)
                     per = idx.size(1) * idx.size(2)
                     accs = e.zero_arena(x.device, [((seg.nseg, 3 * N0 + 9), f32)])[0]
-                    S = torch.empty(Bq, Nq, N0, dtype=f32, device=x.device)
-                    c0 = 0
-                    for si, rows in enumerate(seg.rows):
-                        c1 = c0 + rows // per
-                        e.group_lift_rows_grad_scan(G, ctx.lift_P[c0:c1], Wx, consts[si], xyz[c0:c1], new_xyz,
-                                                    inv[0][c0 * Nq:c1 * Nq + 1], inv[1], idx.size(2), normalize, radius,
-                                                    accs[si], S[c0:c1])
-                        c0 = c1
+                    S = e.group_lift_rows_grad_scans(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2),
+                                                     normalize, radius, accs, [rows // per for rows in seg.rows])
                     S = S.view(-1, N0)
                     RR = accs[:, 3 * N0:].view(seg.nseg, 3, 3)
                     dWx = accs[:, :3 * N0].view(seg.nseg, N0, 3).sum(0) + torch.einsum("sn,nk,skj->nj", consts[:, 1], Wx, RR)
