@@ -907,7 +907,7 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
 // accepted samples that reach their sub-blobs (box test, as in fps_coop_kernel) in one pass.  Bit-exact by construction:
 // every accepted sample is proven to be the arg-max of the full update; checked against the lane-accurate oracle like
 // every other variant.
-constexpr int kMultiK = 8;
+constexpr int kMultiK = 16;
 constexpr int kMultiFields = 6;                                     // hi, lo, x, y, z, second
 constexpr int kMultiWords = kMultiFields * 64;                      // one parity: field-major, 64 sub-blobs
 // per cloud: [2 parities][6][64] candidate granules
