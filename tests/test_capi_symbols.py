@@ -107,6 +107,61 @@ def test_host_side_routing_predicates():
     assert not lib.pn2_pool_bwd_supported(256, 128, 16)                               # SA3 / SA4: materialised path
 
 
+def test_round4_host_side_fps_and_gcn():
+    """Host functions of round 4, no GPU: the cluster FPS's hand-off area (several samples per hand-off: two parities x six
+    fields x 64 sub-blobs of 8-byte granules per cloud) sits in front of the status word whatever the plan switches say; the
+    measurement switch is scoped; the fused TripletGCN predicate (dimensions multiples of 32, scans of <= 128 rows)."""
+    lib = ctypes.CDLL(LIB)
+    i32, sz = ctypes.c_int, ctypes.c_size_t
+    lib.pn2_fps_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.pn2_fps_workspace_bytes.restype = sz
+    lib.pn2_fps_status_offset.argtypes = [i32, i32, i32]
+    lib.pn2_fps_status_offset.restype = ctypes.c_longlong
+    area = 2 * 6 * 64 * 8
+    for B, N in ((32, 50000), (8, 20000), (16, 100000)):
+        off = lib.pn2_fps_status_offset(B, N, 2048)
+        assert off == B * area
+        need = lib.pn2_fps_workspace_bytes(B, N, 2048)
+        # hand-off area | status | B N floats (streaming fallback) | B N binned 16-byte records
+        assert need >= B * area + 256 + B * N * 4 + B * N * 16
+        for on in (0, 1):                       # the switches change the plan, never what a caller has to bring
+            prev = lib.pn2_fps_get_multi()
+            lib.pn2_fps_set_multi(on)
+            try:
+                assert lib.pn2_fps_workspace_bytes(B, N, 2048) == need and lib.pn2_fps_status_offset(B, N, 2048) == off
+            finally:
+                lib.pn2_fps_set_multi(prev)
+    assert lib.pn2_fps_status_offset(32, 2048, 1024) == -1 and lib.pn2_fps_workspace_bytes(32, 2048, 1024) == 0   # one workgroup per cloud
+    assert lib.pn2_fps_set_plan_override(5, 0, 1, 0, 0) == 0 and lib.pn2_fps_set_plan_override(6, 0, 0, 0, 0) != 0
+    assert lib.pn2_fps_set_plan_override(-1, 0, 0, 0, 0) == 0
+    lib.pn2_gcn_fused_supported.argtypes = [i32, i32, i32, i32]
+    ok = lib.pn2_gcn_fused_supported
+    assert ok(256, 256, 512, 110) and ok(256, 256, 512, 128) and ok(64, 64, 96, 2)
+    assert not ok(256, 256, 512, 129) and not ok(250, 256, 512, 72) and not ok(256, 256, 16, 72)
+
+
+def test_triplet_gcn_on_cpu_tensors_takes_the_unfused_path():
+    """The fused per-scan layer is a GPU route: CPU tensors (the oracle backend of the parity tests) never reach it, and the
+    ReLU between layers is applied by the layer itself either way (network_TripletGCN.py:76-78)."""
+    import torch
+    import oracle_ext
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    saved = gcn._ext
+    gcn._ext = oracle_ext.OracleRowsExt
+    try:
+        torch.manual_seed(0)
+        layer = gcn.TripletGCN(32, 32, 64).train()
+        n = 4
+        ei = torch.tensor([[a, b] for a in range(n) for b in range(n) if a != b]).t().contiguous()
+        x, e = torch.randn(n, 32), torch.randn(n * (n - 1), 32)
+        assert not layer._fused_ok(x, e, None)
+        a_x, a_e = layer(x, e, ei)
+        b_x, b_e = layer(x, e, ei, relu_out=True)
+        assert torch.equal(b_x, a_x.relu()) and torch.equal(b_e, a_e.relu())
+    finally:
+        gcn._ext = saved
+
+
 def test_segment_table_host_side():
     """The host side of the batched-scans entry points (include/pn2_hip.h "batched scans"): row offsets of the scans, the
     cache per (device, rows) signature, the routing predicate (bf16 node, pooled stack, every BatchNorm in training mode),
