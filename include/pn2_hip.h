@@ -672,7 +672,10 @@ int pn2_segment_bn_rows_grad(int64_t R, int C, int ldx, int col0, int64_t S, con
  *   pn2_gcn_linear_grad_x  input gradient Gz W: Gin (R, K), or (gx != NULL) scattered through the adjoint of the triplet
  *                          gather: gx (nodes, dn) += columns [0, dn) at dst and [dn + de, K) at src, ge (R, de) = the middle.
  *   pn2_gcn_edge_slice     out (R, de) = [ReLU] h[:, off : off + de]  (the new edge feature, :51).
- * FLOPs 2 R K N each; every operand is read once per 32-column tile (L2-resident at these sizes). */
+ * FLOPs 2 R K N each; every operand is read once per 32-column tile (L2-resident at these sizes).
+ * PRECONDITION (the caller's, not checked on the device: `ptr` lives there): every scan has at most 128 rows — rows beyond
+ * the 128th of a scan would be left out of its statistics and results.  pn2_gcn_fused_supported(dn, de, dh, longest scan) is
+ * the host-side check; the python layer routes longer scans (and batches of more than 16 scans) to the unfused kernels. */
 int pn2_gcn_fused_supported(int dn, int de, int dh, int max_rows_per_scan);
 int pn2_gcn_linear(long long R, int S, int K, int N, const float *A, int lda, const float *x, const float *e,
                    const long long *dst, const long long *src, int dn, int de, const float *W, const float *bias,
