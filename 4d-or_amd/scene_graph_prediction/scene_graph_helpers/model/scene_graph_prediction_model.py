@@ -34,6 +34,17 @@ from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet
 from scene_graph_prediction.scene_graph_helpers.model.pointnets.network_PointNet2 import PointNetfeat as PointNetfeat2
 
 
+_ENCODER_STREAMS = {}
+
+
+def _encoder_stream(device):
+    """One extra stream per device for the object encoder (created once: a stream capture must not meet its creation)."""
+    st = _ENCODER_STREAMS.get(device)
+    if st is None:
+        st = _ENCODER_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 class SGPNModelWrapper(nn.Module):
     def __init__(self, config, num_class, num_rel, weights_obj, weights_rel, relationNames):
         super().__init__()
@@ -122,6 +133,9 @@ class SGPNModelWrapper(nn.Module):
     #: by the host thread, not by the launch count (PN2_ONE_SCAN_SEGMENTS=1 switches it on)
     one_scan_segments = os.environ.get("PN2_ONE_SCAN_SEGMENTS", "0") == "1"
 
+    #: object and relation encoder on two streams (forward and, through autograd, backward).  PN2_ENCODER_STREAMS=0: one stream.
+    encoder_streams = os.environ.get("PN2_ENCODER_STREAMS", "1") == "1"
+
     def forward(self, batch, return_meta_data=False):
         geo = batch.get("geometry")
         scenes = batch.get("scenes")          # block-diagonal batch of several scans (dataset/synthetic.py::collate_scans)
@@ -129,8 +143,22 @@ class SGPNModelWrapper(nn.Module):
         node_ptr = scenes.node_ptr if per_scan else None
         edge_ptr = scenes.edge_ptr if per_scan else None
         with (per_scan_statistics(scenes.nodes_per_scene, scenes.edges_per_scene) if per_scan else contextlib.nullcontext()):
-            obj_feature = self.obj_encoder(batch["obj_points"], geometry=None if geo is None else geo["obj"])
-            rel_feature = self.rel_encoder(batch["rel_points"], geometry=None if geo is None else geo["rel"])
+            if self.encoder_streams and batch["obj_points"].is_cuda and not torch.cuda.is_current_stream_capturing():
+                # (inside a stream capture the fork only adds graph edges: replay of the one-scan step 135 -> 68 scans/s)
+                # the two encoders share nothing until the GCN: the object encoder (9 small clouds per scan: kernels that
+                # fill a fraction of the chip) runs on a second stream next to the relation encoder (72 clouds of 8000
+                # points); autograd replays each encoder's backward on the stream its forward ran on
+                main = torch.cuda.current_stream(batch["obj_points"].device)
+                side = _encoder_stream(batch["obj_points"].device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    obj_feature = self.obj_encoder(batch["obj_points"], geometry=None if geo is None else geo["obj"])
+                rel_feature = self.rel_encoder(batch["rel_points"], geometry=None if geo is None else geo["rel"])
+                main.wait_stream(side)
+                obj_feature.record_stream(main)
+            else:
+                obj_feature = self.obj_encoder(batch["obj_points"], geometry=None if geo is None else geo["obj"])
+                rel_feature = self.rel_encoder(batch["rel_points"], geometry=None if geo is None else geo["rel"])
         gcn_scenes = scenes
         if scenes is None and self.one_scan_segments and obj_feature.is_cuda and rel_feature.size(0) >= 2:
             # one scan on the GPU: the BatchNorm1d layers of the GCN and (training) of the heads through the per-scan kernel
