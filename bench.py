@@ -550,8 +550,8 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
             main_rows = [r for r in rows if not r["kernel"].endswith("@side")]
             out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
             if main_rows:
-                # the one scene-graph command with committed counter passes (tools/profile_round.sh r03_sgp8_bf16 ...)
-                own = (["r03_sgp8_bf16_counters.json"] if (S == 8 and args.dtype == "bf16" and model.per_scan_statistics
+                # the one scene-graph command with committed counter passes (tools/profile_round.sh r04_sgp8_bf16 ...)
+                own = (["r04_sgp8_bf16_counters.json", "r03_sgp8_bf16_counters.json"] if (S == 8 and args.dtype == "bf16" and model.per_scan_statistics
                                                            and not args.with_prep and world == 1) else None)
                 out["roofline"] = roofline_of(main_rows[0], False, own)
         emit_json(out, args)

@@ -19,6 +19,10 @@ ENTRY_OF_FAMILY = {
     "mlp_gemm_bf16_kernel": "pn2_mlp_gemm_bf16", "mlp_wgrad_bf16_kernel": "pn2_mlp_wgrad_bf16", "mlp_bwd_bf16_kernel": "pn2_mlp_bwd_bf16",
     "bn_relu_rows_max_bf16_v8_kernel": "pn2_bn_relu_rows_max_bf16", "group_concat_rows_bf16_wide8_kernel": "pn2_group_concat_rows_bf16",
     "bq_fused_group_kernel": "pn2_ball_query_group", "bq_slab_query_kernel": "pn2_ball_query", "bq_slab_build_kernel": "pn2_ball_query",
+    "fps_multi_kernel": "pn2_furthest_point_sampling", "fps_coop_kernel": "pn2_furthest_point_sampling",
+    "fps_resident_kernel": "pn2_furthest_point_sampling", "fps_bucket_kernel": "pn2_furthest_point_sampling",
+    "gcn_linear_kernel": "pn2_gcn_linear", "gcn_linear_grad_w_kernel": "pn2_gcn_linear_grad_w",
+    "gcn_linear_grad_x_kernel": "pn2_gcn_linear_grad_x",
 }
 
 
@@ -36,6 +40,10 @@ def keys(name: str):
             pro, epi = int(m.group(4)), int(m.group(5))
             out.append(f"mlp_gemm_kernel<{PRO.get(pro, pro)},{EPI.get(epi, epi)}>")
             out.append("entry:" + ("pn2_mlp_gemm_pool" if epi == 3 else "pn2_mlp_gemm_first" if pro == 4 else "pn2_mlp_gemm"))
+    elif fam in ("group_lift_rows_kernel", "group_lift_rows_grad_kernel", "group_lift_rows_grad_heavy_kernel"):
+        # template <R, BF>: the bf16-row instantiations are launched by the _bf16 entry points
+        bf = re.search(r"_kernel<\s*\d+,\s*true", name) is not None
+        out.append("entry:" + ("pn2_group_lift_rows" if fam == "group_lift_rows_kernel" else "pn2_group_lift_rows_grad") + ("_bf16" if bf else ""))
     elif fam in ENTRY_OF_FAMILY:
         out.append("entry:" + ENTRY_OF_FAMILY[fam])
     return out
