@@ -1045,11 +1045,22 @@ __global__ __launch_bounds__(1024) void fps_multi_kernel(int B, int N, int m, in
         const int sl = bl / SUB;
         const float ox = pn2_readlane_f32(s_fin.x[sl], 0), oy = pn2_readlane_f32(s_fin.y[sl], 0),
                     oz = pn2_readlane_f32(s_fin.z[sl], 0);
+        // two slots per packed instruction (v_pk_add / mul / fma_f32): the IEEE operations of pn2_sq3 in its order —
+        // fma(dz, dz, fma(dx, dx, dy * dy)) — on both halves; an odd slot count leaves one scalar tail
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
           if (i >= lo_i && i < hi_i) {
-            const float d = pn2_sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
-            td[i] = fps_min(d, td[i]);
+            if (((i - lo_i) & 1) == 0 && i + 1 < hi_i) {
+              const f2 dx = f2{px[i], px[i + 1]} - o2x, dy = f2{py[i], py[i + 1]} - o2y, dz = f2{pz[i], pz[i + 1]} - o2z;
+              const f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+              td[i] = fps_min(d.x, td[i]);
+              td[i + 1] = fps_min(d.y, td[i + 1]);
+            } else if (((i - lo_i) & 1) == 0) {
+              const float d = pn2_sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
+              td[i] = fps_min(d, td[i]);
+            }
           }
         }
       }
@@ -1370,9 +1381,10 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false, bool fewest = false,
     if ((long long)N > 2LL * 1024 * 26) G = 4;
     if (ov.mode == 5 && ov.G == 4) G = 4;
     const int raw = (N + G * 1024 - 1) / (G * 1024);
-    // G 16 SUB <= 64 sub-blobs, one per lane of the sweeping wave; two per wave only up to 20 point slots per lane (the
-    // 24..26-slot instantiations with two sub-blobs need 30-70 registers more than a 1024-thread workgroup has: 8 vs 4.6 ms)
-    int sub = (G == 2 && raw <= 20) ? 2 : 1;
+    // G 16 SUB <= 64 sub-blobs, one per lane of the sweeping wave: two per wave wherever two workgroups hold the cloud.
+    // (With scalar distance arithmetic the 24..26-slot two-sub-blob instantiations needed 30-70 registers more than a
+    // 1024-thread workgroup has — 232-316 B of scratch, 8 vs 4.6 ms; with the packed form 8-40 B: 2.50 vs 2.95 ms at 25 slots.)
+    int sub = G == 2 ? 2 : 1;
     if (ov.mode == 5 && ov.NC == 1) sub = 1;
     if (ov.mode == 5 && ov.NC == 2 && G == 2) sub = 2;
     int ppt = -1;
