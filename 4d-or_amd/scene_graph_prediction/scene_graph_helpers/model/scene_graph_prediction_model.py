@@ -42,6 +42,11 @@ def _encoder_stream(device):
     st = _ENCODER_STREAMS.get(device)
     if st is None:
         st = _ENCODER_STREAMS[device] = torch.cuda.Stream(device=device)
+        # the object encoder's parameter gradients are produced on this stream and accumulated on the main one — on purpose
+        # (see forward); torch would warn about the mismatch once per process
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
     return st
 
 
@@ -151,8 +156,15 @@ class SGPNModelWrapper(nn.Module):
                 main = torch.cuda.current_stream(batch["obj_points"].device)
                 side = _encoder_stream(batch["obj_points"].device)
                 side.wait_stream(main)
+                # autograd runs a leaf's AccumulateGrad on the stream that was current when the node was CREATED (first use
+                # of the parameter in a graph) and the node can outlive the step: created on the side stream it would later
+                # run there even inside a stream capture of a single-stream step — outside the captured graph (replayed
+                # gradients of the object encoder were garbage).  A view of every parameter taken HERE creates the nodes on
+                # the main stream; the encoder's own uses then find them.
+                keep = [p_.view_as(p_) for p_ in self.obj_encoder.parameters() if p_.requires_grad] if torch.is_grad_enabled() else None
                 with torch.cuda.stream(side):
                     obj_feature = self.obj_encoder(batch["obj_points"], geometry=None if geo is None else geo["obj"])
+                del keep
                 rel_feature = self.rel_encoder(batch["rel_points"], geometry=None if geo is None else geo["rel"])
                 main.wait_stream(side)
                 obj_feature.record_stream(main)
