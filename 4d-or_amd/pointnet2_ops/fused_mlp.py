@@ -797,7 +797,11 @@ def _update_running_stats(layers, fins, rows_per_scan):
 #: streams the scans of a segmented call are spread over (1 = all on the calling stream).  One scan's layer chain is
 #: ~20 dependent kernels of 10-90 us each — most of them too small to fill 256 CUs and all of them paying their launch
 #: latency in series; the scans are independent, so chains on different streams overlap on the chip.
-SEGMENT_STREAMS = 2
+#: Streams are mapped onto FOUR hardware queues: the training stream, the geometry prefetch and the second encoder stream of
+#: the scene-graph model (SGPNModelWrapper.encoder_streams) take three, and from the fifth stream on two of them share a queue
+#: and run strictly one after the other (8 scans fp32: 1 stream here 199, 2 streams 194, 3-4 streams 122 scans/s; without the
+#: encoder fork 167 / 184).
+SEGMENT_STREAMS = 1 if _os.environ.get("PN2_ENCODER_STREAMS", "1") == "1" else 2
 _WORKERS = {}
 
 
