@@ -956,6 +956,7 @@ __global__ __launch_bounds__(1024) void fps_multi_kernel(int B, int N, int m, in
   for (int h = 0; h < SUB; ++h) {
     b0x[h] = b0y[h] = b0z[h] = 3.0e38f;
     b1x[h] = b1y[h] = b1z[h] = -3.0e38f;
+    has_valid[h] = false;
   }
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
@@ -977,6 +978,7 @@ __global__ __launch_bounds__(1024) void fps_multi_kernel(int B, int N, int m, in
 #pragma unroll
     for (int h = 0; h < SUB; ++h) {
       if (i >= h * PPT / SUB && i < (h + 1) * PPT / SUB && valid) {
+        has_valid[h] = true;
         b0x[h] = fminf(b0x[h], x); b0y[h] = fminf(b0y[h], y); b0z[h] = fminf(b0z[h], z);
         b1x[h] = fmaxf(b1x[h], x); b1y[h] = fmaxf(b1y[h], y); b1z[h] = fmaxf(b1z[h], z);
       }
@@ -996,7 +998,9 @@ __global__ __launch_bounds__(1024) void fps_multi_kernel(int B, int N, int m, in
     }
     b0x[h] = pn2_readlane_f32(b0x[h], 0); b0y[h] = pn2_readlane_f32(b0y[h], 0); b0z[h] = pn2_readlane_f32(b0z[h], 0);
     b1x[h] = pn2_readlane_f32(b1x[h], 0); b1y[h] = pn2_readlane_f32(b1y[h], 0); b1z[h] = pn2_readlane_f32(b1z[h], 0);
-    has_valid[h] = b0x[h] <= b1x[h];                               // some valid point went into the box
+    // some point of the sub-blob takes part (a NaN point does — EXT/src/sampling_gpu.cu:100-101 only skips |p|^2 <= 1e-3 —
+    // without entering the box: its running distance never changes, the forced first scan files it as a candidate)
+    has_valid[h] = __ballot(has_valid[h]) != 0ull;
     c_maxd[h] = has_valid[h] ? 1e10f : -1.f;
     if (lane == 0) {
       const int sb = wave * SUB + h;

@@ -167,6 +167,23 @@ def test_fps_several_samples_four_workgroups_per_cloud(ext, B, N, m, kind):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("n_nan", [7, 3000])
+def test_fps_several_samples_with_nan_points(ext, n_nan):
+    """NaN points take part in the reference's sampling (only |p|^2 <= 1e-3 is skipped, sampling_gpu.cu:100-101) and their
+    running distance never changes (fminf semantics of min, :106): the sampling keeps returning the NaN point of the
+    smallest rank.  A handful of them, and enough to fill whole sub-blobs of the binned cloud (no bounding box at all)."""
+    xyz = clouds(2, 40000, "uniform", seed=n_nan)
+    g = torch.Generator().manual_seed(n_nan)
+    for b in range(2):
+        xyz[b, torch.randperm(40000, generator=g)[:n_nan] + 0] = float("nan")
+    xyz[0, 0] = torch.tensor([0.3, 0.2, 0.1])               # (a finite first sample in cloud 0, a NaN one possible in cloud 1)
+    want = O.furthest_point_sampling(xyz, 40)
+    for sub in (2, 1):
+        with ext.fps_plan_override(mode="multi", nc=sub):
+            got = ext.furthest_point_sampling(dev(xyz), 40).cpu()
+        assert torch.equal(got, want), sub
+
+
 def test_fps_multi_is_the_default_for_cluster_sized_clouds_and_can_be_switched_off(ext):
     xyz = clouds(2, 50000, "uniform", seed=77)
     want = O.furthest_point_sampling(xyz, 300)
