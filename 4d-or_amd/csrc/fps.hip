@@ -485,7 +485,9 @@ __global__ __launch_bounds__(1024) void fps_bucketed_kernel(int N, int Nstride, 
         const float ex = fmaxf(fmaxf(bx0 - ox, ox - bx1), 0.f), ey = fmaxf(fmaxf(by0 - oy, oy - by1), 0.f),
                     ez = fmaxf(fmaxf(bz0 - oz, oz - bz1), 0.f);
         const float lb = (ex * ex + ey * ey + ez * ez) * 0.999998f;
-        act = !(lb >= s_maxd[t]);
+        // (first round: every bucket with a participating point — a bucket of NaN points only has no box, yet the
+        // reference samples them, EXT/src/sampling_gpu.cu:100-109)
+        act = !(lb >= s_maxd[t]) || (j == 1 && s_maxd[t] >= 0.f);
       }
       const u64 am = __ballot(act);
       if (am) {                                                 // wave-uniform
@@ -666,7 +668,8 @@ __global__ __launch_bounds__(BS) void fps_coop_kernel(int B, int N, int m, int L
         const float ex = fmaxf(fmaxf(bbx0 - ox[0], ox[0] - bbx1), 0.f), ey = fmaxf(fmaxf(bby0 - oy[0], oy[0] - bby1), 0.f),
                     ez = fmaxf(fmaxf(bbz0 - oz[0], oz[0] - bbz1), 0.f);
         const float lb = (ex * ex + ey * ey + ez * ez) * 0.999998f;
-        active = __builtin_amdgcn_readfirstlane((int)!(lb >= c_maxd)) != 0;
+        // (first round: every blob scans — a blob of NaN points only has no box at all, yet the reference samples them)
+        active = j == 1 || __builtin_amdgcn_readfirstlane((int)!(lb >= c_maxd)) != 0;
 #ifdef FPS_STATS
         if (lane == 0) { atomicAdd(status + 2, 1); if (active) atomicAdd(status + 1, 1); }
 #endif

@@ -182,6 +182,10 @@ def test_fps_several_samples_with_nan_points(ext, n_nan):
         with ext.fps_plan_override(mode="multi", nc=sub):
             got = ext.furthest_point_sampling(dev(xyz), 40).cpu()
         assert torch.equal(got, want), sub
+    with ext.fps_multi(False), ext.background_geometry(fewest=True):       # the one-sample cluster over the binned cloud
+        assert torch.equal(ext.furthest_point_sampling(dev(xyz), 40).cpu(), want)
+    with ext.fps_plan_override(mode="bucketed"):
+        assert torch.equal(ext.furthest_point_sampling(dev(xyz), 40).cpu(), want)
 
 
 def test_fps_multi_is_the_default_for_cluster_sized_clouds_and_can_be_switched_off(ext):
