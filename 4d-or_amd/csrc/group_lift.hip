@@ -38,6 +38,11 @@ struct LiftFwdArgs {
   int N, m, ns, N0, normalize;
   float radius;
   int centres, chunks;   // B m; centres dealt to workgroups in chunks of 4 (one per wave)
+  // segment table (grid.y = scan): ROW offsets of the scans (device), rows per cloud; every scan runs as its OWN call would —
+  // its clouds, its grid, its block of the statistics — so its sums are bit for bit those of a single-scan launch
+  const long long *seg;
+  int per;
+  long long row0;        // first row of the call in Y (0 without a table)
 };
 
 // LPR lanes per row (N0 = 4 LPR columns, 16 bytes per lane), R = 64 / LPR rows per wave instruction.  A wave owns one
@@ -50,8 +55,31 @@ __device__ __forceinline__ unsigned lift_bf_pack(float lo, float hi) {
 }
 __device__ __forceinline__ float lift_bf_round(float f) { return (float)(__bf16)f; }
 
+// grid of a forward call over `centres` centres: 8 XCD shares x up to 256 workgroups, at least four chunks (16 centres) per
+// workgroup (every workgroup ends with 2 N0 fp64 atomics onto the same addresses)
+__host__ __device__ inline int lift_fwd_grid(long long centres) {
+  const int chunks = (int)((centres + 3) / 4);
+  const int per = (chunks + 7) / 8;
+  int nwg = (per + 3) / 4;
+  nwg = nwg < 1 ? 1 : (nwg > 256 ? 256 : nwg);
+  return nwg * 8;
+}
+
 template <int R, bool BF>
-__global__ __launch_bounds__(kLiftBlock) void group_lift_rows_kernel(const LiftFwdArgs a) {
+__global__ __launch_bounds__(kLiftBlock) void group_lift_rows_kernel(const LiftFwdArgs a_in) {
+  LiftFwdArgs a = a_in;
+  unsigned gdim = gridDim.x;
+  if (a.seg) {
+    const long long r0 = a.seg[blockIdx.y], r1 = a.seg[blockIdx.y + 1];
+    const long long c0 = r0 / a.per, nc = (r1 - r0) / a.per;
+    a.xyz += (size_t)c0 * a.N * 3; a.new_xyz += (size_t)c0 * a.m * 3; a.idx += r0; a.P += (size_t)c0 * a.N * a.N0;
+    if (a.stats) a.stats += (size_t)blockIdx.y * 2 * a.N0;
+    a.row0 = r0;
+    a.centres = (int)(nc * a.m);
+    a.chunks = (a.centres + 3) / 4;
+    gdim = (unsigned)lift_fwd_grid(a.centres);
+    if (blockIdx.x >= gdim || nc == 0) return;                     // (workgroup-uniform)
+  }
   constexpr int LPR = 64 / R;
   __shared__ float red[2][4][4 * LPR];
   const int lane = pn2_lane(), wv = threadIdx.x >> 6;
@@ -69,7 +97,7 @@ __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_kernel(const LiftF
   }
   f4v s1 = f4v{0.f, 0.f, 0.f, 0.f}, s2 = s1;
   const int per = (a.chunks + 7) >> 3;                       // chunks per XCD share
-  const int nwg = gridDim.x >> 3;                            // workgroups per XCD share
+  const int nwg = gdim >> 3;                                 // workgroups per XCD share
   for (int ck = (int)(blockIdx.x >> 3); ck < per; ck += nwg) {
     const int chunk = (int)(blockIdx.x & 7) * per + ck;
     const int g = chunk * 4 + wv;
@@ -79,8 +107,8 @@ __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_kernel(const LiftF
     const float *X = a.xyz + (size_t)b * a.N * 3;
     const float *Pb = a.P + (size_t)b * a.N * N0;
     const int *row_idx = a.idx + (size_t)g * ns;
-    float *Yg = (float *)a.Y + (size_t)g * ns * N0;                       // (fp32 rows)
-    uint2 *Yh = (uint2 *)a.Y + (size_t)g * ns * (N0 >> 2);                // (bf16 rows: four columns = 8 bytes per lane)
+    float *Yg = (float *)a.Y + ((size_t)a.row0 + (size_t)g * ns) * N0;                  // (fp32 rows)
+    uint2 *Yh = (uint2 *)a.Y + ((size_t)a.row0 + (size_t)g * ns) * (N0 >> 2);           // (bf16 rows: four columns = 8 bytes per lane)
     for (int s0 = 0; s0 < ns; s0 += 64) {
       const int cnt = ns - s0 < 64 ? ns - s0 : 64;
       int mi = 0;
@@ -163,6 +191,11 @@ struct LiftBwdArgs {
   int ns, N0, normalize;
   float radius;
   unsigned npoints;
+  // segment table (grid.y = scan; see LiftFwdArgs): per-point tensors, the constants, the heavy list and the partials are
+  // the scan's own slices; G, new_xyz and refs stay the batch's (row ids index them in place)
+  const long long *seg;
+  int per, N;
+  unsigned heavy_stride, part_stride;      // ints / floats per scan
 };
 
 constexpr int kLiftHeavy = 192;     // a point gathered by more rows than this is walked by kLiftSplit waves in a second pass
@@ -325,10 +358,24 @@ __device__ __forceinline__ void lift_flush(const LiftBwdArgs &a, unsigned row, f
   if (threadIdx.x < 9) prow[3 * N0 + threadIdx.x] = (rrs[0][threadIdx.x] + rrs[1][threadIdx.x]) + (rrs[2][threadIdx.x] + rrs[3][threadIdx.x]);
 }
 
+// workgroups of pass 1 over `npoints` points
+__host__ __device__ inline unsigned lift_grid1(size_t npoints) {
+  const unsigned waves_wanted = 256u * 32u;
+  unsigned grid = (unsigned)((npoints < waves_wanted ? npoints : waves_wanted) + 3) / 4;
+  return grid == 0 ? 1 : grid;
+}
+
 // column sums of the partials: out[0 : 3 N0] = dWx (without c2 Wx RR), out[3 N0 : 3 N0 + 9] = RR; fixed order
 __global__ __launch_bounds__(256) void lift_reduce_kernel(const float *__restrict__ part, int rows, int width, int pitch,
-                                                         float *__restrict__ out) {
+                                                         float *__restrict__ out, const long long *__restrict__ seg, int per,
+                                                         int N, unsigned part_stride, int tail_rows) {
   __shared__ float red[256];
+  if (seg) {                                   // grid.y = scan: its partial rows (pass 1 of ITS point count + pass 2), its output row
+    const long long nc = (seg[blockIdx.y + 1] - seg[blockIdx.y]) / per;
+    rows = nc ? (int)lift_grid1((size_t)nc * N) + tail_rows : 0;
+    part += (size_t)blockIdx.y * part_stride;
+    out += (size_t)blockIdx.y * width;
+  }
   const int col = blockIdx.x;
   float t = 0.f;
   for (int r = threadIdx.x; r < rows; r += 256) t += part[(size_t)r * pitch + col];
@@ -341,16 +388,37 @@ __global__ __launch_bounds__(256) void lift_reduce_kernel(const float *__restric
   if (threadIdx.x == 0 && col < width) out[col] = red[0];
 }
 
+// a scan's view of the arguments (segment table); false: this workgroup has nothing to do.  `grid1`: pass-1 workgroups of
+// the scan's own call (= first partial row of its pass 2)
+__device__ __forceinline__ bool lift_bwd_scan(LiftBwdArgs &a, unsigned &grid1) {
+  grid1 = lift_grid1(a.npoints);
+  if (!a.seg) return true;
+  const long long r0 = a.seg[blockIdx.y], r1 = a.seg[blockIdx.y + 1];
+  const long long c0 = r0 / a.per, nc = (r1 - r0) / a.per;
+  const size_t p0 = (size_t)c0 * a.N;
+  a.xyz += p0 * 3; a.P += p0 * a.N0; a.S += p0 * a.N0; a.ptr += p0;
+  a.consts += (size_t)blockIdx.y * 3 * a.N0;
+  a.heavy += (size_t)blockIdx.y * a.heavy_stride;
+  a.part += (size_t)blockIdx.y * a.part_stride;
+  a.npoints = (unsigned)(nc * a.N);
+  grid1 = lift_grid1(a.npoints);
+  return nc != 0;
+}
+
 // pass 1: a wave per point (like group_rows_grad_csr_kernel); heavy points are listed, their S row zeroed
 template <int R, bool BF>
-__global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_kernel(const LiftBwdArgs a) {
+__global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_kernel(const LiftBwdArgs a_in) {
+  LiftBwdArgs a = a_in;
+  unsigned grid1;
+  if (!lift_bwd_scan(a, grid1) || blockIdx.x >= grid1) return;
+  const unsigned gdim = a.seg ? grid1 : gridDim.x;
   constexpr int LPR = 64 / R;
   __shared__ float red[3][4][256];
   __shared__ float rrs[4][16];
   const int lane = pn2_lane(), wv = threadIdx.x >> 6;
   f4v dx = f4v{0.f, 0.f, 0.f, 0.f}, dy = dx, dz = dx, ex_ = dx, ey_ = dx, ez_ = dx;
   float rr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const unsigned nwaves = gridDim.x * (kLiftBlock / 64);
+  const unsigned nwaves = gdim * (kLiftBlock / 64);
   for (unsigned n = __builtin_amdgcn_readfirstlane(blockIdx.x * (kLiftBlock / 64) + wv); n < a.npoints; n += nwaves) {
     const int p0 = a.ptr[n], p1 = a.ptr[n + 1];
     if (p1 - p0 > kLiftHeavy) {                                   // wave-uniform
@@ -366,7 +434,11 @@ __global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_kernel(const 
 
 // pass 2: kLiftSplit waves per heavy point, each a contiguous slice of its rows, results added
 template <int R, bool BF>
-__global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_heavy_kernel(const LiftBwdArgs a, unsigned row0) {
+__global__ __launch_bounds__(kLiftBlock) void group_lift_rows_grad_heavy_kernel(const LiftBwdArgs a_in, unsigned row0) {
+  LiftBwdArgs a = a_in;
+  unsigned grid1;
+  if (!lift_bwd_scan(a, grid1)) return;
+  if (a.seg) row0 = grid1;
   __shared__ float red[3][4][256];
   __shared__ float rrs[4][16];
   const int wv = threadIdx.x >> 6;
@@ -393,7 +465,9 @@ extern "C" int pn2_group_lift_supported(int N0) { return lift_shape_ok(N0) ? 1 :
 
 namespace {
 int lift_rows_launch(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz, const float *new_xyz,
-                     const int *idx, const float *P, const float *Wx, void *Y, bool bf, double *stats, void *stream) {
+                     const int *idx, const float *P, const float *Wx, void *Y, bool bf, double *stats, void *stream,
+                     const long long *seg = nullptr, int nseg = 0, int max_clouds = 0) {
+  if (seg && (nseg < 1 || nseg > 65535 || max_clouds < 1 || max_clouds > B)) return PN2_EINVAL;
   if (B < 0 || N < 0 || m < 0 || ns < 0) return PN2_EINVAL;
   if (!lift_shape_ok(N0) || (normalize && !(radius > 0.f))) return PN2_EINVAL;
   const long long centres = (long long)B * m;
@@ -402,13 +476,9 @@ int lift_rows_launch(int B, int N, int m, int ns, int N0, int normalize, float r
   if (!xyz || !new_xyz || !idx || !P || !Wx || !Y) return PN2_ENULL;
   if ((((uintptr_t)P) | ((uintptr_t)Y)) & 15) return PN2_EINVAL;
   LiftFwdArgs a{xyz, new_xyz, idx, P, Wx, Y, stats, N, m, ns, N0, normalize ? 1 : 0, radius, (int)centres,
-                (int)((centres + 3) / 4)};
-  // persistent grid: 8 XCD shares x up to 256 workgroups, every workgroup flushes its column sums once
-  // ... and at least four chunks (16 centres) per workgroup: the flush is 2 N0 fp64 atomics onto the same addresses
-  const int per = (a.chunks + 7) / 8;
-  int nwg = (per + 3) / 4;
-  nwg = nwg < 1 ? 1 : (nwg > 256 ? 256 : nwg);
-  const dim3 grid((unsigned)(nwg * 8)), block(kLiftBlock);
+                (int)((centres + 3) / 4), seg, m * ns, 0};
+  // without a table one call; with one: grid.y = scan, grid.x = the grid of the LARGEST scan (a scan's surplus workgroups exit)
+  const dim3 grid((unsigned)lift_fwd_grid(seg ? (long long)max_clouds * m : centres), (unsigned)(seg ? nseg : 1)), block(kLiftBlock);
   hipStream_t s = (hipStream_t)stream;
   if (bf) {
     if (N0 <= 64) hipLaunchKernelGGL((group_lift_rows_kernel<4, true>), grid, block, 0, s, a);
@@ -439,11 +509,6 @@ extern "C" int pn2_group_lift_rows_bf16(int B, int N, int m, int ns, int N0, int
 
 namespace {
 constexpr unsigned kLiftGrid2 = 512;      // workgroups of the heavy pass: 2048 waves = 128 heavy points at a time
-unsigned lift_grid1(size_t npoints) {
-  const unsigned waves_wanted = 256u * 32u;
-  unsigned grid = (unsigned)((npoints < waves_wanted ? npoints : waves_wanted) + 3) / 4;
-  return grid == 0 ? 1 : grid;
-}
 size_t lift_heavy_bytes(int B, int m, int ns) {
   const size_t M = (size_t)B * m * ns;
   return ((M / kLiftHeavy + 2) * sizeof(int) + 255) & ~(size_t)255;     // a point is heavy with more than kLiftHeavy rows
@@ -456,10 +521,42 @@ extern "C" size_t pn2_group_lift_rows_grad_workspace_bytes(int B, int N, int m, 
 }
 
 namespace {
+// workspace of a segment-table call: nseg x (heavy list | partial rows) of the LARGEST scan
+size_t lift_seg_heavy_bytes(int max_clouds, int m, int ns) { return lift_heavy_bytes(max_clouds, m, ns); }
+size_t lift_seg_part_floats(int max_clouds, int N, int N0) {
+  return (size_t)(lift_grid1((size_t)max_clouds * N) + kLiftGrid2) * (3 * N0 + 16);
+}
+
 int lift_rows_grad_launch(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
                           const float *new_xyz, const void *G, bool bf, const float *P, const float *Wx, const float *consts,
                           const int *ptr, const int *refs, float *S, float *acc, void *workspace, size_t workspace_bytes,
-                          void *stream) {
+                          void *stream, const long long *seg = nullptr, int nseg = 0, int max_clouds = 0) {
+  if (seg) {
+    if (nseg < 1 || nseg > 65535 || max_clouds < 1 || max_clouds > B || B < 0 || N <= 0 || m <= 0 || ns <= 0) return PN2_EINVAL;
+    if (!lift_shape_ok(N0) || (normalize && !(radius > 0.f))) return PN2_EINVAL;
+    if ((size_t)B * N >= 0x7fffffffull || (long long)B * m * ns >= 0x7fffffffLL) return PN2_EINVAL;
+    if (!xyz || !new_xyz || !G || !P || !Wx || !consts || !ptr || !refs || !S || !acc || !workspace) return PN2_ENULL;
+    if ((((uintptr_t)G) | ((uintptr_t)P) | ((uintptr_t)S) | ((uintptr_t)consts) | ((uintptr_t)workspace)) & 15) return PN2_EINVAL;
+    const size_t hb = lift_seg_heavy_bytes(max_clouds, m, ns), pf = lift_seg_part_floats(max_clouds, N, N0);
+    if (workspace_bytes < (size_t)nseg * (hb + pf * sizeof(float))) return PN2_ENOSPC;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, (size_t)nseg * hb, s) != hipSuccess) return PN2_ELAUNCH;      // every scan's heavy count
+    float *part = (float *)((char *)workspace + (size_t)nseg * hb);
+    LiftBwdArgs a{xyz, new_xyz, G, P, Wx, consts, ptr, refs, S, part, (int *)workspace, ns, N0, normalize ? 1 : 0, radius,
+                  (unsigned)((size_t)max_clouds * N), seg, m * ns, N, (unsigned)(hb / sizeof(int)), (unsigned)pf};
+    const unsigned grid = lift_grid1((size_t)max_clouds * N);
+#define PN2_LIFT_SEG(RR_, BF_)                                                                                                       \
+  do {                                                                                                                               \
+    hipLaunchKernelGGL((group_lift_rows_grad_kernel<RR_, BF_>), dim3(grid, (unsigned)nseg), dim3(kLiftBlock), 0, s, a);              \
+    hipLaunchKernelGGL((group_lift_rows_grad_heavy_kernel<RR_, BF_>), dim3(kLiftGrid2, (unsigned)nseg), dim3(kLiftBlock), 0, s, a, grid); \
+  } while (0)
+    if (bf) { if (N0 <= 64) PN2_LIFT_SEG(4, true); else if (N0 <= 128) PN2_LIFT_SEG(2, true); else PN2_LIFT_SEG(1, true); }
+    else { if (N0 <= 64) PN2_LIFT_SEG(4, false); else if (N0 <= 128) PN2_LIFT_SEG(2, false); else PN2_LIFT_SEG(1, false); }
+#undef PN2_LIFT_SEG
+    hipLaunchKernelGGL(lift_reduce_kernel, dim3((unsigned)(3 * N0 + 9), (unsigned)nseg), dim3(256), 0, s, part, 0, 3 * N0 + 9,
+                       3 * N0 + 16, acc, seg, m * ns, N, (unsigned)pf, (int)kLiftGrid2);
+    return pn2_check_launch();
+  }
   if (B < 0 || N < 0 || m < 0 || ns <= 0) return PN2_EINVAL;
   if (!lift_shape_ok(N0) || (normalize && !(radius > 0.f))) return PN2_EINVAL;
   const size_t npoints = (size_t)B * N;
@@ -472,7 +569,7 @@ int lift_rows_grad_launch(int B, int N, int m, int ns, int N0, int normalize, fl
   if (hipMemsetAsync(workspace, 0, sizeof(int), s) != hipSuccess) return PN2_ELAUNCH;
   float *part = (float *)((char *)workspace + lift_heavy_bytes(B, m, ns));
   LiftBwdArgs a{xyz, new_xyz, G, P, Wx, consts, ptr, refs, S, part, (int *)workspace, ns, N0, normalize ? 1 : 0, radius,
-                (unsigned)npoints};
+                (unsigned)npoints, nullptr, m * ns, N, 0u, 0u};
   const unsigned grid = lift_grid1(npoints);
 #define PN2_LIFT(RR_, BF_)                                                                                                  \
   do {                                                                                                                      \
@@ -483,7 +580,7 @@ int lift_rows_grad_launch(int B, int N, int m, int ns, int N0, int normalize, fl
   else { if (N0 <= 64) PN2_LIFT(4, false); else if (N0 <= 128) PN2_LIFT(2, false); else PN2_LIFT(1, false); }
 #undef PN2_LIFT
   hipLaunchKernelGGL(lift_reduce_kernel, dim3((unsigned)(3 * N0 + 9)), dim3(256), 0, s, part, (int)(grid + kLiftGrid2),
-                     3 * N0 + 9, 3 * N0 + 16, acc);
+                     3 * N0 + 9, 3 * N0 + 16, acc, (const long long *)nullptr, 1, 0, 0u, 0);
   return pn2_check_launch();
 }
 }  // namespace
@@ -506,49 +603,31 @@ extern "C" int pn2_group_lift_rows_grad_bf16(int B, int N, int m, int ns, int N0
                                workspace, workspace_bytes, stream);
 }
 
-// ---- one host call for the S scans of a batch (segment-table stacks of the mixed-precision node, round 4) --------------
-// The launches are exactly those of S single-scan calls — scan s: clouds [c_s, c_s + clouds[s]), its own (2, N0) block of the
-// statistics resp. its own (3, N0) constants and (3 N0 + 9) accumulator row — issued from ONE C call instead of S trips through
-// the Python binding (the 32-scan step was bound by its host thread).  `clouds`: S host integers summing to B.
-extern "C" int pn2_group_lift_rows_scans(int S, const int *clouds, int B, int N, int m, int ns, int N0, int normalize,
-                                         float radius, const float *xyz, const float *new_xyz, const int *idx, const float *P,
-                                         const float *Wx, void *Y, int y_bf16, double *stats, void *stream) {
-  if (S < 0 || B < 0 || !clouds) return S < 0 || B < 0 ? PN2_EINVAL : PN2_ENULL;
-  long long c0 = 0;
-  for (int s = 0; s < S; ++s) {
-    const int nc = clouds[s];
-    if (nc < 0 || c0 + nc > B) return PN2_EINVAL;
-    const size_t rows = (size_t)c0 * m * ns;
-    void *Ys = y_bf16 ? (void *)((unsigned short *)Y + rows * N0) : (void *)((float *)Y + rows * N0);
-    const int rc = lift_rows_launch(nc, N, m, ns, N0, normalize, radius, xyz + (size_t)c0 * N * 3, new_xyz + (size_t)c0 * m * 3,
-                                    idx + rows, P + (size_t)c0 * N * N0, Wx, Ys, y_bf16 != 0,
-                                    stats ? stats + (size_t)s * 2 * N0 : nullptr, stream);
-    if (rc != PN2_OK) return rc;
-    c0 += nc;
-  }
-  return c0 == B ? PN2_OK : PN2_EINVAL;
+// ---- the S scans of a batch in ONE launch (segment-table stacks of the mixed-precision node, round 4) --------------------
+// grid.y = scan: every scan runs exactly as its own single-scan call would — its clouds, the grid its centre / point count
+// gives (surplus workgroups of shorter scans exit), its (2, N0) block of the statistics resp. its (3, N0) constants and
+// (3 N0 + 9) accumulator row — so its sums are bit for bit those of a single-scan launch, at the launch count of one call.
+// `seg`: (nseg + 1) ROW offsets of the scans (device, int64; multiples of m ns), `max_clouds`: clouds of the largest scan.
+extern "C" int pn2_group_lift_rows_seg(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                                       const float *new_xyz, const int *idx, const float *P, const float *Wx, void *Y, int y_bf16,
+                                       double *stats, const long long *seg, int nseg, int max_clouds, void *stream) {
+  if (!seg) return PN2_ENULL;
+  return lift_rows_launch(B, N, m, ns, N0, normalize, radius, xyz, new_xyz, idx, P, Wx, Y, y_bf16 != 0, stats, stream, seg, nseg,
+                          max_clouds);
 }
 
-// G (M, N0), new_xyz, refs: the whole batch's tensors (row ids index them in place); xyz, P, ptr, S_out: sliced per scan here.
-// consts (S, 3, N0), acc (S, 3 N0 + 9); `workspace`: pn2_group_lift_rows_grad_workspace_bytes of the LARGEST scan, reused
-// (the scans' launches are ordered on the stream).
-extern "C" int pn2_group_lift_rows_grad_scans(int S, const int *clouds, int B, int N, int m, int ns, int N0, int normalize,
-                                              float radius, const float *xyz, const float *new_xyz, const void *G, int g_bf16,
-                                              const float *P, const float *Wx, const float *consts, const int *ptr,
-                                              const int *refs, float *S_out, float *acc, void *workspace,
-                                              size_t workspace_bytes, void *stream) {
-  if (S < 0 || B < 0) return PN2_EINVAL;
-  if (!clouds) return PN2_ENULL;
-  long long c0 = 0;
-  for (int s = 0; s < S; ++s) {
-    const int nc = clouds[s];
-    if (nc < 0 || c0 + nc > B) return PN2_EINVAL;
-    const int rc = lift_rows_grad_launch(nc, N, m, ns, N0, normalize, radius, xyz + (size_t)c0 * N * 3, new_xyz, G, g_bf16 != 0,
-                                         P + (size_t)c0 * N * N0, Wx, consts + (size_t)s * 3 * N0, ptr + (size_t)c0 * N, refs,
-                                         S_out + (size_t)c0 * N * N0, acc + (size_t)s * (3 * N0 + 9), workspace, workspace_bytes,
-                                         stream);
-    if (rc != PN2_OK) return rc;
-    c0 += nc;
-  }
-  return c0 == B ? PN2_OK : PN2_EINVAL;
+extern "C" size_t pn2_group_lift_rows_grad_seg_workspace_bytes(int nseg, int max_clouds, int N, int m, int ns, int N0) {
+  if (nseg <= 0 || max_clouds <= 0 || N <= 0 || m <= 0 || ns <= 0 || !lift_shape_ok(N0)) return 0;
+  return (size_t)nseg * (lift_seg_heavy_bytes(max_clouds, m, ns) + lift_seg_part_floats(max_clouds, N, N0) * sizeof(float));
+}
+
+// consts (nseg, 3, N0), acc (nseg, 3 N0 + 9); G, new_xyz, refs: the batch's tensors (row ids index them in place)
+extern "C" int pn2_group_lift_rows_grad_seg(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                                            const float *new_xyz, const void *G, int g_bf16, const float *P, const float *Wx,
+                                            const float *consts, const int *ptr, const int *refs, float *S_out, float *acc,
+                                            const long long *seg, int nseg, int max_clouds, void *workspace,
+                                            size_t workspace_bytes, void *stream) {
+  if (!seg) return PN2_ENULL;
+  return lift_rows_grad_launch(B, N, m, ns, N0, normalize, radius, xyz, new_xyz, G, g_bf16 != 0, P, Wx, consts, ptr, refs, S_out,
+                               acc, workspace, workspace_bytes, stream, seg, nseg, max_clouds);
 }

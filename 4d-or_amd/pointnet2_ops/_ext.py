@@ -70,8 +70,8 @@ _SIGNATURES = {
     "pn2_group_lift_rows_grad": [_c_int] * 6 + [_c_f32] + [_c_vp] * 11 + [_c_sz, _c_vp],
     "pn2_group_lift_rows_bf16": [_c_int] * 6 + [_c_f32] + [_c_vp] * 8,
     "pn2_group_lift_rows_grad_bf16": [_c_int] * 6 + [_c_f32] + [_c_vp] * 11 + [_c_sz, _c_vp],
-    "pn2_group_lift_rows_scans": [_c_int, _c_vp] + [_c_int] * 6 + [_c_f32] + [_c_vp] * 6 + [_c_int, _c_vp, _c_vp],
-    "pn2_group_lift_rows_grad_scans": [_c_int, _c_vp] + [_c_int] * 6 + [_c_f32] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 8 + [_c_sz, _c_vp],
+    "pn2_group_lift_rows_seg": [_c_int] * 6 + [_c_f32] + [_c_vp] * 6 + [_c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp],
+    "pn2_group_lift_rows_grad_seg": [_c_int] * 6 + [_c_f32] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 8 + [_c_int, _c_int, _c_vp, _c_sz, _c_vp],
     "pn2_group_rows_grad_csr_bf16": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_rows_grad_bf16": [_c_int] * 7 + [_c_vp] * 4,
     "pn2_rows_max": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -199,6 +199,8 @@ if os.environ.get("PN2_FPS_MULTI") == "0":           # measurement switch: one s
     _lib.pn2_fps_set_multi(0)
 _lib.pn2_gcn_fused_supported.argtypes = [_c_int, _c_int, _c_int, _c_int]
 _lib.pn2_gcn_fused_supported.restype = _c_int
+_lib.pn2_group_lift_rows_grad_seg_workspace_bytes.argtypes = [_c_int] * 6
+_lib.pn2_group_lift_rows_grad_seg_workspace_bytes.restype = _c_sz
 _lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
 _lib.pn2_mlp_bwd_fused_supported.restype = _c_int
 _lib.pn2_mlp_bwd_bf16_supported.argtypes = [_c_int, _c_int]
@@ -224,7 +226,7 @@ ABI_VERSION = int(_lib.pn2_abi_version())
 EXPECTED_ABI_VERSION = 5
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
-                                               "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_gcn_fused_supported",
+                                               "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_gcn_fused_supported", "pn2_group_lift_rows_grad_seg_workspace_bytes",
                                                "pn2_event_create", "pn2_event_record", "pn2_event_elapsed_ms", "pn2_event_destroy",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
@@ -783,50 +785,36 @@ def group_lift_rows_grad(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, rad
     return S
 
 
-_HOST_INTS = {}
-
-
-def _host_ints(vals):
-    """A C int array of host numbers (cached per tuple: the scans' cloud counts repeat every step)."""
-    key = tuple(int(v) for v in vals)
-    arr = _HOST_INTS.get(key)
-    if arr is None:
-        if len(_HOST_INTS) > 4096:
-            _HOST_INTS.clear()
-        arr = _HOST_INTS[key] = (ctypes.c_int * len(key))(*key)
-    return arr
-
-
-def group_lift_rows_scans(P, xyz, new_xyz, idx, Wx, normalize, radius, stats, clouds, out_bf16=True):
-    """group_lift_rows for the S scans of a batch in one host call: scan s = clouds[s] consecutive clouds, its column sums in
-    stats[s] (S, 2, N0).  Same launches as S calls (include/pn2_hip.h)."""
+def group_lift_rows_seg(P, xyz, new_xyz, idx, Wx, normalize, radius, stats, seg, out_bf16=True):
+    """group_lift_rows for the S scans of a segment table in ONE launch (grid.y = scan): scan s = the clouds of rows
+    [seg.ptr[s], seg.ptr[s+1]), its column sums in stats[s] (S, 2, N0) — bit for bit the sums of S single-scan launches
+    (include/pn2_hip.h)."""
     B, m, ns = idx.shape
     N, N0 = xyz.size(1), P.size(-1)
     Y = torch.empty(B * m * ns, N0, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=P.device)
-    arr = _host_ints(clouds)
-    _call("pn2_group_lift_rows_scans", P, len(arr), ctypes.cast(arr, ctypes.c_void_p), B, N, m, ns, N0, int(bool(normalize)),
-          float(radius if radius is not None else 1.0), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(P), _ptr(Wx), _ptr(Y),
-          int(bool(out_bf16)), _ptr(stats),
+    _call("pn2_group_lift_rows_seg", P, B, N, m, ns, N0, int(bool(normalize)), float(radius if radius is not None else 1.0),
+          _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(P), _ptr(Wx), _ptr(Y), int(bool(out_bf16)), _ptr(stats), _ptr(seg.ptr),
+          seg.nseg, seg.max_rows // (m * ns),
           alg_bytes=B * (4 * m * ns + 12 * N + 12 * m + 4 * N0 * N + (2 if out_bf16 else 4) * N0 * m * ns),
           label="pn2_group_lift_rows_bf16" if out_bf16 else "pn2_group_lift_rows")
     return Y
 
 
-def group_lift_rows_grad_scans(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, radius, acc, clouds):
-    """group_lift_rows_grad for the S scans of a batch in one host call: consts (S, 3, N0), acc (S, 3 N0 + 9) zero on entry ->
-    S (B, N, N0).  Same launches as S single-scan calls."""
+def group_lift_rows_grad_seg(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, radius, acc, seg):
+    """group_lift_rows_grad for the S scans of a segment table in ONE launch sequence: consts (S, 3, N0), acc (S, 3 N0 + 9)
+    -> S (B, N, N0).  Every scan's sums are those of its own single-scan call."""
     bf = G.dtype == torch.bfloat16
     ptr, refs = inv
     B, N = xyz.size(0), xyz.size(1)
     m = new_xyz.size(1)
     N0 = G.size(1)
     S_out = torch.empty(B, N, N0, dtype=torch.float32, device=G.device)
-    arr = _host_ints(clouds)
-    ws_bytes = int(_lib.pn2_group_lift_rows_grad_workspace_bytes(max(arr), N, m, int(ns), N0))
+    max_clouds = seg.max_rows // (m * int(ns))
+    ws_bytes = int(_lib.pn2_group_lift_rows_grad_seg_workspace_bytes(seg.nseg, max_clouds, N, m, int(ns), N0))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
-    _call("pn2_group_lift_rows_grad_scans", G, len(arr), ctypes.cast(arr, ctypes.c_void_p), B, N, m, int(ns), N0,
-          int(bool(normalize)), float(radius if radius is not None else 1.0), _ptr(xyz), _ptr(new_xyz), _ptr(G), int(bf), _ptr(P),
-          _ptr(Wx), _ptr(consts), _ptr(ptr), _ptr(refs), _ptr(S_out), _ptr(acc), _ptr(ws), ws_bytes,
+    _call("pn2_group_lift_rows_grad_seg", G, B, N, m, int(ns), N0, int(bool(normalize)),
+          float(radius if radius is not None else 1.0), _ptr(xyz), _ptr(new_xyz), _ptr(G), int(bf), _ptr(P), _ptr(Wx), _ptr(consts),
+          _ptr(ptr), _ptr(refs), _ptr(S_out), _ptr(acc), _ptr(seg.ptr), seg.nseg, max_clouds, _ptr(ws), ws_bytes,
           alg_bytes=(2 if bf else 4) * G.size(0) * N0 + 4 * B * N * (2 * N0 + 4),
           label="pn2_group_lift_rows_grad_bf16" if bf else "pn2_group_lift_rows_grad")
     return S_out

@@ -447,15 +447,14 @@ def _unit_consts(device, n):
 
 
 def _lift_forward_scans(e, feats, W, group, stat_blocks, seg):
-    """_lift_forward for a segment-table stack (bf16 node): ONE per-point GEMM for the batch, then one gather launch per scan
-    with that scan's (2, N0) block of the statistics — the launches (and sums) of single-scan steps."""
+    """_lift_forward for a segment-table stack (bf16 node): ONE per-point GEMM for the batch, then ONE gather launch whose
+    grid.y walks the scans — every scan with the grid and the (2, N0) statistics block of its own single-scan call."""
     xyz, new_xyz, idx, _use_xyz, normalize, radius = group[:6]
     B, N, C = feats.shape
     N0 = W.size(0)
     P = e.mlp_gemm(feats.view(B * N, C), W[:, 3:].contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
     per = idx.size(1) * idx.size(2)
-    Y = e.group_lift_rows_scans(P, xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stat_blocks,
-                                [rows // per for rows in seg.rows], out_bf16=True)
+    Y = e.group_lift_rows_seg(P, xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stat_blocks, seg, out_bf16=True)
     return Y, P
 
 
@@ -644,8 +643,8 @@ class _FusedMLPBf16(Function):
                     Bq, Nq = xyz.size(0), xyz.size(1)
                     per = idx.size(1) * idx.size(2)
                     accs = e.zero_arena(x.device, [((seg.nseg, 3 * N0 + 9), f32)])[0]
-                    S = e.group_lift_rows_grad_scans(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2),
-                                                     normalize, radius, accs, [rows // per for rows in seg.rows])
+                    S = e.group_lift_rows_grad_seg(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2),
+                                                   normalize, radius, accs, seg)
                     S = S.view(-1, N0)
                     RR = accs[:, 3 * N0:].view(seg.nseg, 3, 3)
                     dWx = accs[:, :3 * N0].view(seg.nseg, N0, 3).sum(0) + torch.einsum("sn,nk,skj->nj", consts[:, 1], Wx, RR)

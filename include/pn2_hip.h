@@ -279,18 +279,21 @@ int pn2_group_lift_rows_grad_bf16(int B, int N, int m, int ns, int N0, int norma
                                   const float *new_xyz, const void *G, const float *P, const float *Wx, const float *consts,
                                   const int *ptr, const int *refs, float *S, float *acc, void *workspace,
                                   size_t workspace_bytes, void *stream);
-/* ... and for the S scans of a batch in ONE host call (segment-table stacks): exactly the launches of S single-scan calls —
- * scan s covers clouds [c_s, c_s + clouds[s]) (`clouds`: S HOST integers summing to B), writes its rows of Y / its points of
- * S_out and uses its own (2, N0) block of `stats` resp. its own (3, N0) `consts` and (3 N0 + 9) row of `acc`.  G, new_xyz and
- * refs of the backward are the whole batch's tensors (row ids index them in place); `workspace` must hold
- * pn2_group_lift_rows_grad_workspace_bytes of the largest scan and is reused.  y_bf16 / g_bf16: bf16 rows. */
-int pn2_group_lift_rows_scans(int S, const int *clouds, int B, int N, int m, int ns, int N0, int normalize, float radius,
-                              const float *xyz, const float *new_xyz, const int *idx, const float *P, const float *Wx, void *Y,
-                              int y_bf16, double *stats, void *stream);
-int pn2_group_lift_rows_grad_scans(int S, const int *clouds, int B, int N, int m, int ns, int N0, int normalize, float radius,
-                                   const float *xyz, const float *new_xyz, const void *G, int g_bf16, const float *P,
-                                   const float *Wx, const float *consts, const int *ptr, const int *refs, float *S_out,
-                                   float *acc, void *workspace, size_t workspace_bytes, void *stream);
+/* ... and for the S scans of a batch in ONE launch (segment-table stacks): grid.y = scan, every scan runs exactly as its own
+ * single-scan call would (its clouds, the grid its centre / point count gives, its (2, N0) block of `stats` resp. its (3, N0)
+ * `consts` and (3 N0 + 9) row of `acc`), so its sums are bit for bit those of a single-scan launch.  `seg`: (nseg + 1) int64
+ * ROW offsets of the scans on the device (multiples of m ns), `max_clouds`: clouds of the largest scan.  G, new_xyz and refs of
+ * the backward are the whole batch's tensors (row ids index them in place); `workspace`:
+ * pn2_group_lift_rows_grad_seg_workspace_bytes.  y_bf16 / g_bf16: bf16 rows. */
+int pn2_group_lift_rows_seg(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                            const float *new_xyz, const int *idx, const float *P, const float *Wx, void *Y, int y_bf16,
+                            double *stats, const long long *seg, int nseg, int max_clouds, void *stream);
+size_t pn2_group_lift_rows_grad_seg_workspace_bytes(int nseg, int max_clouds, int N, int m, int ns, int N0);
+int pn2_group_lift_rows_grad_seg(int B, int N, int m, int ns, int N0, int normalize, float radius, const float *xyz,
+                                 const float *new_xyz, const void *G, int g_bf16, const float *P, const float *Wx,
+                                 const float *consts, const int *ptr, const int *refs, float *S_out, float *acc,
+                                 const long long *seg, int nseg, int max_clouds, void *workspace, size_t workspace_bytes,
+                                 void *stream);
 
 /* pn2_rows_max / pn2_rows_max_grad: F.max_pool2d(kernel=[1,ns]) of
  *   OPS/pointnet2_modules.py:67-70 in point-major layout.

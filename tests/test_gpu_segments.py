@@ -233,3 +233,47 @@ def test_head_batch_norm_per_scan_running_statistics_equal_sequential_batch_norm
     torch.testing.assert_close(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(bn.running_var, ref.running_var, rtol=2e-5, atol=1e-6)
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == len(rows)
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_lifted_first_layer_with_a_segment_table_equals_single_scan_launches(bf16):
+    """pn2_group_lift_rows_seg / _grad_seg (grid.y = scan): rows, per-scan column sums, per-point sums and the (3 N0 + 9)
+    accumulator rows are BIT-EQUAL to one pn2_group_lift_rows[_bf16] / _grad launch per scan on that scan's clouds — scans of
+    different sizes (the largest decides the grid, the others' surplus workgroups exit), sparse and heavy points."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(21)
+    clouds, N, m, ns, C, N0, r = [3, 7, 1, 5], 700, 96, 32, 64, 128, 0.45
+    B = sum(clouds)
+    xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1).cuda()
+    new_xyz = xyz[:, :m].contiguous()
+    idx = e.ball_query(new_xyz, xyz, r, ns)
+    P = torch.randn(B, N, N0, generator=g).cuda()
+    Wx = (torch.randn(N0, 3, generator=g) * 0.3).cuda()
+    seg = e.SegTable.get(xyz.device, [c * m * ns for c in clouds])
+    stats = torch.zeros(len(clouds), 2, N0, dtype=torch.float64, device="cuda")
+    Y = e.group_lift_rows_seg(P, xyz, new_xyz, idx, Wx, True, r, stats, seg, out_bf16=bf16)
+    inv = e.group_inverse_index(idx, N)
+    G = torch.randn(Y.shape, generator=g).cuda().to(Y.dtype)
+    consts = (torch.randn(len(clouds), 3, N0, generator=g) * 0.5).cuda().contiguous()
+    acc = torch.zeros(len(clouds), 3 * N0 + 9, device="cuda")
+    S = e.group_lift_rows_grad_seg(G, P, Wx, consts, xyz, new_xyz, inv, ns, True, r, acc, seg)
+    c0 = 0
+    for s_, nc in enumerate(clouds):
+        c1, r0, r1 = c0 + nc, c0 * m * ns, (c0 + nc) * m * ns
+        st = torch.zeros(2, N0, dtype=torch.float64, device="cuda")
+        y1 = e.group_lift_rows(P[c0:c1].contiguous(), xyz[c0:c1].contiguous(), new_xyz[c0:c1].contiguous(),
+                               idx[c0:c1].contiguous(), Wx, True, r, stats=st, out_bf16=bf16)
+        assert torch.equal(Y[r0:r1], y1), s_
+        torch.testing.assert_close(stats[s_], st, rtol=1e-14, atol=0)          # (fp64 atomics of identical fp32 partial sums)
+        inv1 = e.group_inverse_index(idx[c0:c1].contiguous(), N)
+        a1 = torch.zeros(3 * N0 + 9, device="cuda")
+        s1 = e.group_lift_rows_grad(G[r0:r1].contiguous(), P[c0:c1].contiguous(), Wx, consts[s_].contiguous(), xyz[c0:c1].contiguous(),
+                                    new_xyz[c0:c1].contiguous(), inv1, ns, True, r, a1)
+        heavy = int(((inv1[0][1:] - inv1[0][:-1]) > 192).sum())
+        if heavy == 0:                      # (heavy points are ADDED with atomics by sixteen waves each: not bit-reproducible)
+            assert torch.equal(S[c0:c1], s1), s_
+            assert torch.equal(acc[s_], a1), s_
+        else:
+            torch.testing.assert_close(S[c0:c1], s1, rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(acc[s_], a1, rtol=1e-5, atol=1e-4)
+        c0 = c1
