@@ -149,14 +149,17 @@ __global__ __launch_bounds__(512) void gcn_linear_kernel(const GcnFwdArgs a) {
     } else {
       const long long er = r0 + (rv ? row : 0);
       const int dn = a.t.dn, de = a.t.de;
-      // p[kg] is element kg of the virtual concatenated row (segment boundaries are multiples of 32: a block never straddles one)
-      const float *p0 = a.t.x + (size_t)a.t.dst[er] * dn;
-      const float *p1 = a.t.e + (size_t)er * de - dn;
-      const float *p2 = a.t.x + (size_t)a.t.src[er] * dn - dn - de;
+      // element kg of the virtual concatenated row is x[o0 + kg], x[o1 + kg] or x[o2 + kg] (offsets in floats from a.t.x, the
+      // edge features addressed relative to it; segment boundaries are multiples of 32: a block never straddles one).  The
+      // offset is combined with masks, not selects: a three-way select of loop-invariant pointers became a lookup table in
+      // SCRATCH (one dependent scratch load in front of every global load, 104 B per lane).
+      const long long o0 = (long long)a.t.dst[er] * dn;
+      const long long o1 = (long long)(a.t.e - a.t.x) + er * de - dn;
+      const long long o2 = (long long)a.t.src[er] * dn - dn - de;
       gcn_kloop(k_begin, k_begin + plen, rv, [&](int k) {
         const int kg = h * Kh + k;
-        const float *p = kg < dn ? p0 : (kg < dn + de ? p1 : p2);
-        return *reinterpret_cast<const f4 *>(p + kg);
+        const long long m0 = -(long long)(kg < dn), m2 = -(long long)(kg >= dn + de), m1 = ~(m0 | m2);
+        return *reinterpret_cast<const f4 *>(a.t.x + (((o0 & m0) | (o1 & m1) | (o2 & m2)) + kg));
       }, pb, acc);
     }
   }
@@ -227,123 +230,197 @@ struct GcnGradWArgs {
   int K, N;
 };
 
-// grid (N / 32, S, K / 128), 256 threads.  Every wave repeats the (cheap) BatchNorm backward of the 32-column tile — lane
-// (c, h) owns column c and the rows of parity h, which IS the A-operand layout of gz^T for the weight gradient — and takes ONE
-// 32-column tile of K (tile 4 z + w); its rows of A are requested BEFORE the BatchNorm backward, so one L2 round trip covers both.
-template <int AMODE, int GMODE, bool BN>
-__global__ __launch_bounds__(256) void gcn_linear_grad_w_kernel(const GcnGradWArgs a) {
-  __shared__ int s_dst[kGcnRows], s_src[kGcnRows];
+// Backward of a block up to the weights, two launches.
+//
+// (1) gcn_bn_bwd_kernel, grid (N / 32, S), 256 threads: ReLU mask + BatchNorm backward of one 32-column tile of ONE scan (its
+//     sums are local to the workgroup) -> Gz (R, N), which the input gradient needs anyway; dbias / dgamma / dbeta += (3 N
+//     atomics per scan).  Lane (c, h) of wave w owns column c0 + c and rows 32 w + 2 i + h, i < 16.
+// (2) gcn_wgrad_kernel, grid (N / 32, K / 32), 256 threads: dW tile += Gz^T A over ALL R rows of the batch — the scans only
+//     matter to BatchNorm, the weight gradient is one (N, R) x (R, K) product — each wave a quarter of the rows, partial tiles
+//     summed through LDS, ONE plain read-modify-write of the tile.  The first form of this kernel kept the per-scan structure
+//     and added every scan's 32 x 32 tile with fp32 atomics: S N K device-scope atomics (block 2 of a layer at 8 scans: 5.2 M)
+//     at ~90 G/s were 50-80 us of a 230 us backward, growing linearly with the scan count.
+template <int GMODE, bool BN>
+__global__ __launch_bounds__(256) void gcn_bn_bwd_kernel(const GcnGradWArgs a) {
+  __shared__ int s_dst[kGcnRows];
+  __shared__ float red[3][4][32];
   const int lane = pn2_lane(), w = threadIdx.x >> 6;
   const int h = lane >> 5, c = lane & 31;
   const int s = blockIdx.y, c0 = blockIdx.x * 32;
   const long long r0 = a.ptr[s];
   const int Rs = (int)(a.ptr[s + 1] - r0);
-  const int N = a.N, K = a.K, col = c0 + c;
-  if constexpr (AMODE == 1 || GMODE == 1) {
-    for (int i = threadIdx.x; i < kGcnRows; i += 256) {
-      s_dst[i] = i < Rs ? (int)a.t.dst[r0 + i] : 0;
-      s_src[i] = (i < Rs && a.t.src) ? (int)a.t.src[r0 + i] : 0;
-    }
+  const int N = a.N, col = c0 + c;
+  if (Rs <= 0) return;
+  if constexpr (GMODE == 1) {
+    for (int i = threadIdx.x; i < kGcnRows; i += 256) s_dst[i] = i < Rs ? (int)a.t.dst[r0 + i] : 0;
     __syncthreads();
   }
-  // this wave's tile of A: rows of parity h, column 32 t + c (requested first, consumed after the BatchNorm backward)
-  const int t = 4 * blockIdx.z + w;
-  float bv[64];
-  {
-    const int k = 32 * t + c;
-    int seg = 0;
-    if constexpr (AMODE == 1) seg = 32 * t < a.t.dn ? 0 : (32 * t < a.t.dn + a.t.de ? 1 : 2);
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      bv[i] = 0.f;
-      if (2 * i < Rs && t < K / 32) {                              // wave-uniform
-        const int r = 2 * i + h, rc = r < Rs ? r : Rs - 1;
-        if constexpr (AMODE == 0) bv[i] = a.A[(size_t)(r0 + rc) * a.lda + k];
-        else bv[i] = seg == 0 ? a.t.x[(size_t)s_dst[rc] * a.t.dn + k]
-                     : (seg == 1 ? a.t.e[(size_t)(r0 + rc) * a.t.de + (k - a.t.dn)]
-                                 : a.t.x[(size_t)s_src[rc] * a.t.dn + (k - a.t.dn - a.t.de)]);
-      }
-    }
-  }
-  float gz[64], xh[BN ? 64 : 1];
   float mean = 0.f, rstd = 1.f, gam = 1.f, bet = 0.f;
   if constexpr (BN) {
     mean = a.mean[(size_t)s * N + col]; rstd = a.rstd[(size_t)s * N + col];
     gam = a.gamma[col]; bet = a.beta[col];
   }
+  // every load unconditional (row clamped, value zeroed afterwards): all 32 are in flight together
+  float gv[16], yv[16];
+  int seg = 0, gcol = col;
+  if constexpr (GMODE == 1) {
+    seg = c0 < a.dh ? 0 : (c0 < a.dh + a.dE ? 1 : 2);                // (wave-uniform: dh, dE are multiples of 32)
+    gcol = seg == 0 ? col : (seg == 1 ? col - a.dh : col - a.dh - a.dE);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = 32 * w + 2 * i + h, rc = r < Rs ? r : Rs - 1;
+    if constexpr (GMODE == 0) gv[i] = a.G[(size_t)(r0 + rc) * N + col];
+    else gv[i] = seg == 1 ? a.gedge[(size_t)(r0 + rc) * a.dE + gcol] : a.gagg[(size_t)s_dst[rc] * a.dh + gcol];
+    yv[i] = (BN || a.relu) ? a.Ypre[(size_t)(r0 + rc) * N + col] : 1.f;
+  }
   float s1 = 0.f, s2 = 0.f;
-  // rows in batches of eight per lane, every load unconditional (row clamped, value zeroed afterwards): behind per-row
-  // branches the loads of a batch cannot be in flight together and each costs a full L2 round trip
 #pragma unroll
-  for (int ib = 0; ib < 8; ++ib) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { gz[8 * ib + j] = 0.f; if constexpr (BN) xh[8 * ib + j] = 0.f; }
-    if (16 * ib < Rs) {                                            // wave-uniform
-      float gv[8], yv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 2 * (8 * ib + j) + h, rc = r < Rs ? r : Rs - 1;
-        if constexpr (GMODE == 0) {
-          gv[j] = a.G[(size_t)(r0 + rc) * N + col];
-        } else {
-          gv[j] = col < a.dh ? a.gagg[(size_t)s_dst[rc] * a.dh + col]
-                  : (col < a.dh + a.dE ? a.gedge[(size_t)(r0 + rc) * a.dE + (col - a.dh)]
-                                       : a.gagg[(size_t)s_dst[rc] * a.dh + (col - a.dh - a.dE)]);
-        }
-        yv[j] = (BN || a.relu) ? a.Ypre[(size_t)(r0 + rc) * N + col] : 1.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = 8 * ib + j, r = 2 * i + h;
-        float g = r < Rs ? gv[j] : 0.f;
-        if constexpr (BN) {
-          const float x = r < Rs ? (yv[j] - mean) * rstd : 0.f;
-          if (a.relu && !(fmaf(x, gam, bet) > 0.f)) g = 0.f;
-          xh[i] = x;
-          s2 = fmaf(g, x, s2);
-        } else if (a.relu) {
-          if (!(yv[j] > 0.f)) g = 0.f;
-        }
-        gz[i] = g;
-        s1 += g;
-      }
+  for (int i = 0; i < 16; ++i) {
+    const bool ok = 32 * w + 2 * i + h < Rs;
+    float g = ok ? gv[i] : 0.f;
+    if constexpr (BN) {
+      const float x = ok ? (yv[i] - mean) * rstd : 0.f;
+      if (a.relu && !(fmaf(x, gam, bet) > 0.f)) g = 0.f;
+      yv[i] = x;
+      s2 = fmaf(g, x, s2);
+    } else if (a.relu) {
+      if (!(yv[i] > 0.f)) g = 0.f;
     }
+    gv[i] = g;
+    s1 += g;
   }
   s1 += __shfl_xor(s1, 32);
   s2 += __shfl_xor(s2, 32);
-  float sb = s1;                                                   // sum of gz over the rows (the Linear's bias gradient)
+  if (h == 0) { red[0][w][c] = s1; red[1][w][c] = s2; }
+  __syncthreads();
+  s1 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);       // sum of the masked gradient over the scan's rows
+  s2 = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);       // ... times the normalised value
+  float sb = s1;                                                            // sum of gz (the Linear's bias gradient)
   if constexpr (BN) {
     const float k1 = s1 / (float)Rs, k2 = s2 / (float)Rs, sc = gam * rstd;
     sb = 0.f;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      if (2 * i < Rs) {
-        gz[i] = 2 * i + h < Rs ? sc * (gz[i] - k1 - xh[i] * k2) : 0.f;
-        sb += gz[i];
-      }
+    for (int i = 0; i < 16; ++i) {
+      gv[i] = 32 * w + 2 * i + h < Rs ? sc * (gv[i] - k1 - yv[i] * k2) : 0.f;
+      sb += gv[i];
     }
     sb += __shfl_xor(sb, 32);
+    if (h == 0) red[2][w][c] = sb;
+    __syncthreads();
+    sb = (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]);
   }
-  if (w == 0 && blockIdx.z == 0) {
 #pragma unroll
-    for (int i = 0; i < 64; ++i)
-      if (2 * i < Rs && 2 * i + h < Rs) a.Gz[(size_t)(r0 + 2 * i + h) * N + col] = gz[i];
-    if (h == 0) {
-      if (a.dbias) atomicAdd(a.dbias + col, sb);
-      if constexpr (BN) { atomicAdd(a.dgamma + col, s2); atomicAdd(a.dbeta + col, s1); }
+  for (int i = 0; i < 16; ++i) {
+    const int r = 32 * w + 2 * i + h;
+    if (r < Rs) a.Gz[(size_t)(r0 + r) * N + col] = gv[i];
+  }
+  if (w == 0 && h == 0) {
+    if (a.dbias) atomicAdd(a.dbias + col, sb);
+    if constexpr (BN) { atomicAdd(a.dgamma + col, s2); atomicAdd(a.dbeta + col, s1); }
+  }
+}
+
+struct GcnWgradArgs {
+  const float *Gz;                // (R, N)
+  const float *A;                 // AMODE 0: (R, lda)
+  int lda;
+  GcnTriplet t;                   // AMODE 1: the virtual cat[x[dst], e, x[src]]
+  float *dW;                      // (N, K) +=
+  long long R;
+  int N, K;
+};
+
+// dW[n0 + i, k0 + j] += sum_r Gz[r, n0 + i] A[r, k0 + j].  One matrix-core step consumes two rows (lane (c, h): Gz[r + h, n0 + c]
+// and A[r + h, k0 + c], one coalesced 128-byte line per half wave); a wave walks its quarter of the rows in chunks of 16 with
+// a ring of four chunks in flight (AMODE 1: the gather's row numbers one chunk further ahead).
+template <int AMODE>
+__global__ __launch_bounds__(256) void gcn_wgrad_kernel(const GcnWgradArgs a) {
+  __shared__ float part[3][16][64];
+  const int lane = pn2_lane(), w = threadIdx.x >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int N = a.N, K = a.K;
+  const long long R = a.R;
+  const long long quarter = ((R + 3) / 4 + 15) / 16 * 16;          // whole chunks
+  const long long rb = w * quarter < R ? w * quarter : R;
+  const long long re = rb + quarter < R ? rb + quarter : R;
+  const int nchunk = (int)((re - rb + 15) >> 4);
+  float dwv[16];
+  if (w == 0) {                                                    // the tile's old value, requested before the walk
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dwv[q] = a.dW[(size_t)(n0 + acc_row(q, h)) * K + k0 + c];
+  }
+  f16v acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  int seg = 1, kcol = k0 + c;                                      // AMODE 1: which part of the concatenation the tile lies in
+  const int64_t *idx = nullptr;
+  if constexpr (AMODE == 1) {
+    seg = k0 < a.t.dn ? 0 : (k0 < a.t.dn + a.t.de ? 1 : 2);
+    kcol = seg == 0 ? k0 + c : (seg == 1 ? k0 - a.t.dn + c : k0 - a.t.dn - a.t.de + c);
+    idx = seg == 0 ? a.t.dst : a.t.src;
+  }
+  float gv[4][8], av[4][8];
+  int iv[2][8];
+  auto row_of = [&](int ch, int i) {                               // clamped: a real row of this wave's range
+    const long long r = rb + 16 * ch + 2 * i + h;
+    return r < re ? r : re - 1;
+  };
+  auto load_idx = [&](int u, int ch) {
+    if constexpr (AMODE == 1) {
+      if (seg != 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) iv[u][i] = (int)idx[row_of(ch, i)];
+      }
+    }
+  };
+  auto load_val = [&](int u, int ui, int ch) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long rc = row_of(ch, i);
+      gv[u][i] = a.Gz[(size_t)rc * N + n0 + c];
+      if constexpr (AMODE == 0) av[u][i] = a.A[(size_t)rc * a.lda + kcol];
+      else av[u][i] = seg == 1 ? a.t.e[(size_t)rc * a.t.de + kcol] : a.t.x[(size_t)iv[ui][i] * a.t.dn + kcol];
+    }
+  };
+  auto compute = [&](int u, int ch) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = rb + 16 * ch + 2 * i + h < re;
+      acc = mfma2(ok ? gv[u][i] : 0.f, av[u][i], acc);
+    }
+  };
+  if (nchunk > 0) {
+    // prologue: row numbers of chunks 0 .. 3, values of chunks 0 .. 2
+    load_idx(0, 0);
+    if (1 < nchunk) load_idx(1, 1);
+    load_val(0, 0, 0);
+    if (1 < nchunk) load_val(1, 1, 1);
+    if (2 < nchunk) load_idx(0, 2);
+    if (3 < nchunk) load_idx(1, 3);
+    if (2 < nchunk) load_val(2, 0, 2);
+    for (int ch = 0; ch < nchunk; ch += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // values of chunk ch + u + 3 (their row numbers arrived one step ago), row numbers of chunk ch + u + 4
+        if (ch + u + 3 < nchunk) load_val((u + 3) & 3, (u + 1) & 1, ch + u + 3);
+        if (ch + u + 4 < nchunk) load_idx(u & 1, ch + u + 4);
+        if (ch + u < nchunk) compute(u, ch + u);
+      }
     }
   }
-  // dW[c0 + i, k] += sum_r gz[r, c0 + i] A[r, k]
-  if (t < K / 32) {
-    f16v acc;
+  if (w != 0) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int q = 0; q < 16; ++q) part[w - 1][q][lane] = acc[q];
+  }
+  __syncthreads();
+  if (w == 0) {
 #pragma unroll
-    for (int i = 0; i < 64; ++i)
-      if (2 * i < Rs) acc = mfma2(gz[i], bv[i], acc);              // (gz is 0 beyond the scan's rows)
-    const int k = 32 * t + c;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) atomicAdd(a.dW + (size_t)(c0 + acc_row(q, h)) * K + k, acc[q]);
+    for (int q = 0; q < 16; ++q) {
+      const float v = (acc[q] + part[0][q][lane]) + (part[1][q][lane] + part[2][q][lane]);
+      a.dW[(size_t)(n0 + acc_row(q, h)) * K + k0 + c] = dwv[q] + v;
+    }
   }
 }
 
@@ -489,16 +566,19 @@ extern "C" int pn2_gcn_linear_grad_w(long long R, int S, int K, int N, const flo
   if (!gamma && relu && !Ypre) return PN2_ENULL;
   GcnGradWArgs a{G, gagg, gedge, dh, dE, Ypre, mean, rstd, gamma, beta, relu ? 1 : 0, (const int64_t *)ptr, A, lda,
                  {x, e, (const int64_t *)dst, (const int64_t *)src, dn, de}, Gz, dW, dbias, dgamma, dbeta, K, N};
-  const dim3 grid((unsigned)(N / 32), (unsigned)S, (unsigned)((K / 32 + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define PN2_GCN_GW(AM, GM)                                                                                  \
-  do {                                                                                                      \
-    if (gamma) hipLaunchKernelGGL((gcn_linear_grad_w_kernel<AM, GM, true>), grid, block, 0, s, a);          \
-    else hipLaunchKernelGGL((gcn_linear_grad_w_kernel<AM, GM, false>), grid, block, 0, s, a);               \
-  } while (0)
-  if (trip) { if (adj) PN2_GCN_GW(1, 1); else PN2_GCN_GW(1, 0); }
-  else { if (adj) PN2_GCN_GW(0, 1); else PN2_GCN_GW(0, 0); }
-#undef PN2_GCN_GW
+  const dim3 grid1((unsigned)(N / 32), (unsigned)S), block(256);
+  if (adj) {
+    if (gamma) hipLaunchKernelGGL((gcn_bn_bwd_kernel<1, true>), grid1, block, 0, s, a);
+    else hipLaunchKernelGGL((gcn_bn_bwd_kernel<1, false>), grid1, block, 0, s, a);
+  } else {
+    if (gamma) hipLaunchKernelGGL((gcn_bn_bwd_kernel<0, true>), grid1, block, 0, s, a);
+    else hipLaunchKernelGGL((gcn_bn_bwd_kernel<0, false>), grid1, block, 0, s, a);
+  }
+  GcnWgradArgs b{Gz, A, lda, {x, e, (const int64_t *)dst, (const int64_t *)src, dn, de}, dW, R, N, K};
+  const dim3 grid2((unsigned)(N / 32), (unsigned)(K / 32));
+  if (trip) hipLaunchKernelGGL((gcn_wgrad_kernel<1>), grid2, block, 0, s, b);
+  else hipLaunchKernelGGL((gcn_wgrad_kernel<0>), grid2, block, 0, s, b);
   return pn2_check_launch();
 }
 
@@ -532,4 +612,80 @@ extern "C" int pn2_gcn_edge_slice(long long R, int ld, int off, int de, int relu
   hipLaunchKernelGGL(gcn_edge_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total4, de / 4, ld / 4,
                      off / 4, relu ? 1 : 0, (const f4 *)hrows, (f4 *)out);
   return pn2_check_launch();
+}
+
+// ---- one layer per C call: the sequence _FusedTripletLayer issued block by block from python ------------------------------
+namespace {
+inline size_t gcn_pad(size_t floats) { return (floats + 63) / 64 * 64; }     // 256-byte pieces of the backward workspace
+static_assert(sizeof(pn2_gcn_layer) == 48 + 56 * sizeof(void *), "pn2_gcn_layer: two i64, five int, three float, 56 pointers (the python binding mirrors it)");
+}  // namespace
+
+extern "C" size_t pn2_gcn_layer_backward_workspace_bytes(long long nodes, long long edges, int dn, int de, int dh) {
+  if (nodes < 0 || edges < 0 || dn <= 0 || de <= 0 || dh <= 0) return 0;
+  const size_t n = (size_t)nodes, e = (size_t)edges;
+  // node side: gz4 (dn) | g_t (dh) | gz3 (dh) | g_agg (dh);  edge side: gz2 (2 dh + de) | g_h1 (dh) | gz1 (dh)
+  return 4 * (gcn_pad(n * dn) + 3 * gcn_pad(n * dh) + gcn_pad(e * (2 * (size_t)dh + de)) + 2 * gcn_pad(e * dh));
+}
+
+extern "C" int pn2_gcn_layer_forward(const pn2_gcn_layer *L, void *stream) {
+  if (!L) return PN2_ENULL;
+  if (L->nodes < 0 || L->edges < 0 || L->S < 0) return PN2_EINVAL;
+  if (L->nodes == 0 || L->edges == 0 || L->S == 0) return PN2_OK;
+  const int dn = L->dn, de = L->de, dh = L->dh, wide = 2 * dh + de;
+  if (!pn2_gcn_fused_supported(dn, de, dh, 0)) return PN2_EINVAL;
+  if (!L->order || !L->rowptr || !L->agg || !L->e_out || !L->h1 || !L->h2 || !L->t) return PN2_ENULL;
+  int rc = pn2_gcn_linear(L->edges, L->S, 2 * dn + de, dh, nullptr, 0, L->x, L->e, L->dst, L->src, dn, de, L->W1, L->b1, L->edge_ptr,
+                          L->g1, L->be1, L->eps1, 1, L->h1p, L->h1, L->m1, L->r1, stream);
+  if (rc) return rc;
+  rc = pn2_gcn_linear(L->edges, L->S, dh, wide, L->h1, dh, nullptr, nullptr, nullptr, nullptr, 0, 0, L->W2, L->b2, L->edge_ptr, L->g2,
+                      L->be2, L->eps2, 1, L->h2p, L->h2, L->m2, L->r2, stream);
+  if (rc) return rc;
+  rc = pn2_segment_sum2_rows(L->edges, dh, L->nodes, wide, 0, dh + de, L->h2, (const int64_t *)L->order, (const int64_t *)L->rowptr,
+                             L->agg, stream);
+  if (rc) return rc;
+  rc = pn2_gcn_edge_slice(L->edges, wide, dh, de, L->relu_out, L->h2, L->e_out, stream);
+  if (rc) return rc;
+  rc = pn2_gcn_linear(L->nodes, L->S, dh, dh, L->agg, dh, nullptr, nullptr, nullptr, nullptr, 0, 0, L->W3, L->b3, L->node_ptr, L->g3,
+                      L->be3, L->eps3, 1, L->tp, L->t, L->m3, L->r3, stream);
+  if (rc) return rc;
+  return pn2_gcn_linear(L->nodes, L->S, dh, dn, L->t, dh, nullptr, nullptr, nullptr, nullptr, 0, 0, L->W4, L->b4, L->node_ptr, nullptr,
+                        nullptr, 0.f, L->relu_out, nullptr, L->out, nullptr, nullptr, stream);
+}
+
+extern "C" int pn2_gcn_layer_backward(const pn2_gcn_layer *L, void *stream) {
+  if (!L) return PN2_ENULL;
+  if (L->nodes < 0 || L->edges < 0 || L->S < 0) return PN2_EINVAL;
+  if (L->nodes == 0 || L->edges == 0 || L->S == 0) return PN2_OK;
+  const int dn = L->dn, de = L->de, dh = L->dh, wide = 2 * dh + de;
+  if (!pn2_gcn_fused_supported(dn, de, dh, 0)) return PN2_EINVAL;
+  if (!L->work || !L->g_out || !L->g_e || !L->gx || !L->ge) return PN2_ENULL;
+  const size_t n = (size_t)L->nodes, e = (size_t)L->edges;
+  float *gz4 = (float *)L->work, *g_t = gz4 + gcn_pad(n * dn), *gz3 = g_t + gcn_pad(n * dh), *g_agg = gz3 + gcn_pad(n * dh);
+  float *gz2 = g_agg + gcn_pad(n * dh), *g_h1 = gz2 + gcn_pad(e * wide), *gz1 = g_h1 + gcn_pad(e * dh);
+  // nn2[3] (no BatchNorm; its ReLU is the model's between-layer one), nn2[0..2]
+  int rc = pn2_gcn_linear_grad_w(L->nodes, L->S, dh, dn, L->g_out, nullptr, nullptr, 0, 0, L->out, nullptr, nullptr, nullptr, nullptr,
+                                 L->relu_out, L->node_ptr, L->t, dh, nullptr, nullptr, nullptr, nullptr, 0, 0, gz4, L->dW4, L->db4,
+                                 nullptr, nullptr, stream);
+  if (rc) return rc;
+  rc = pn2_gcn_linear_grad_x(L->nodes, L->S, dh, dn, gz4, L->W4, L->node_ptr, g_t, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
+  if (rc) return rc;
+  rc = pn2_gcn_linear_grad_w(L->nodes, L->S, dh, dh, g_t, nullptr, nullptr, 0, 0, L->tp, L->m3, L->r3, L->g3, L->be3, 1, L->node_ptr,
+                             L->agg, dh, nullptr, nullptr, nullptr, nullptr, 0, 0, gz3, L->dW3, L->db3, L->dg3, L->dbe3, stream);
+  if (rc) return rc;
+  rc = pn2_gcn_linear_grad_x(L->nodes, L->S, dh, dh, gz3, L->W3, L->node_ptr, g_agg, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
+  if (rc) return rc;
+  // nn1[3..5]: its gradient is the adjoint of split + aggregate, [g_agg[dst] | g_e | g_agg[dst]], read in place.  A ReLU on
+  // e_out (relu_out) needs no mask of its own: e_out is a slice of h2 = ReLU(..), and this block's mask zeroes the same entries
+  rc = pn2_gcn_linear_grad_w(L->edges, L->S, dh, wide, nullptr, g_agg, L->g_e, dh, de, L->h2p, L->m2, L->r2, L->g2, L->be2, 1,
+                             L->edge_ptr, L->h1, dh, nullptr, nullptr, L->dst, nullptr, 0, 0, gz2, L->dW2, L->db2, L->dg2, L->dbe2,
+                             stream);
+  if (rc) return rc;
+  rc = pn2_gcn_linear_grad_x(L->edges, L->S, dh, wide, gz2, L->W2, L->edge_ptr, g_h1, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
+  if (rc) return rc;
+  // nn1[0..2] on the virtual concatenation; its input gradient scattered back through the gather
+  rc = pn2_gcn_linear_grad_w(L->edges, L->S, 2 * dn + de, dh, g_h1, nullptr, nullptr, 0, 0, L->h1p, L->m1, L->r1, L->g1, L->be1, 1,
+                             L->edge_ptr, nullptr, 0, L->x, L->e, L->dst, L->src, dn, de, gz1, L->dW1, L->db1, L->dg1, L->dbe1, stream);
+  if (rc) return rc;
+  return pn2_gcn_linear_grad_x(L->edges, L->S, 2 * dn + de, dh, gz1, L->W1, L->edge_ptr, nullptr, L->gx, L->ge, L->dst, L->src, dn, de,
+                               stream);
 }

@@ -38,8 +38,8 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.pn2_abi_version.restype = ctypes.c_int
-if int(_lib.pn2_abi_version()) != 5:
-    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 5: "
+if int(_lib.pn2_abi_version()) != 6:
+    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 6: "
                       f"rebuild it (`make -C {os.path.join(_PKG_DIR, 'csrc')}`)")
 
 _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -92,6 +92,8 @@ _SIGNATURES = {
                               _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int] + [_c_vp] * 5 + [_c_vp],
     "pn2_gcn_linear_grad_x": [_c_i64, _c_int, _c_int, _c_int] + [_c_vp] * 8 + [_c_int, _c_int, _c_vp],
     "pn2_gcn_edge_slice": [_c_i64, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp],
+    "pn2_gcn_layer_forward": [_c_vp, _c_vp],
+    "pn2_gcn_layer_backward": [_c_vp, _c_vp],
     "pn2_segment_bn_running_update": [_c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_prep_object_boxes": [_c_int, _c_int, _c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_prep_chunk_counts": [_c_int] * 4 + [_c_vp] * 6,
@@ -199,6 +201,8 @@ if os.environ.get("PN2_FPS_MULTI") == "0":           # measurement switch: one s
     _lib.pn2_fps_set_multi(0)
 _lib.pn2_gcn_fused_supported.argtypes = [_c_int, _c_int, _c_int, _c_int]
 _lib.pn2_gcn_fused_supported.restype = _c_int
+_lib.pn2_gcn_layer_backward_workspace_bytes.argtypes = [ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_int, _c_int]
+_lib.pn2_gcn_layer_backward_workspace_bytes.restype = _c_sz
 _lib.pn2_group_lift_rows_grad_seg_workspace_bytes.argtypes = [_c_int] * 6
 _lib.pn2_group_lift_rows_grad_seg_workspace_bytes.restype = _c_sz
 _lib.pn2_mlp_bwd_fused_supported.argtypes = [_c_int, _c_int]
@@ -223,10 +227,10 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 #: the header revision this binding was written against: a stale prebuilt libpn2_hip.so fails here with a version
 #: error instead of an AttributeError on the first missing symbol
-EXPECTED_ABI_VERSION = 5
+EXPECTED_ABI_VERSION = 6
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
-                                               "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_gcn_fused_supported", "pn2_group_lift_rows_grad_seg_workspace_bytes",
+                                               "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_gcn_fused_supported", "pn2_gcn_layer_backward_workspace_bytes", "pn2_group_lift_rows_grad_seg_workspace_bytes",
                                                "pn2_event_create", "pn2_event_record", "pn2_event_elapsed_ms", "pn2_event_destroy",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
@@ -1027,6 +1031,80 @@ def gcn_edge_slice(h, off, de, relu):
     out = torch.empty(R, int(de), dtype=torch.float32, device=h.device)
     _call("pn2_gcn_edge_slice", h, R, ld, int(off), int(de), int(bool(relu)), _ptr(h), _ptr(out), alg_bytes=8 * R * int(de))
     return out
+
+
+_GCN_PARAMS = ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "W3", "b3", "g3", "be3", "W4", "b4")
+_GCN_SAVED = ("h1", "h1p", "m1", "r1", "h2", "h2p", "m2", "r2", "agg", "e_out", "t", "tp", "m3", "r3", "out")
+
+
+class GcnLayer(ctypes.Structure):
+    """`pn2_gcn_layer` of include/pn2_hip.h, field for field."""
+    _fields_ = ([("nodes", ctypes.c_longlong), ("edges", ctypes.c_longlong)]
+                + [(k, _c_int) for k in ("S", "dn", "de", "dh", "relu_out")]
+                + [(k, _c_f32) for k in ("eps1", "eps2", "eps3")]
+                + [(k, _c_vp) for k in ("x", "e", "dst", "src", "order", "rowptr", "node_ptr", "edge_ptr")]
+                + [(k, _c_vp) for k in _GCN_PARAMS] + [(k, _c_vp) for k in _GCN_SAVED]
+                + [(k, _c_vp) for k in ("g_out", "g_e")] + [(k, _c_vp) for k in ("d" + k for k in _GCN_PARAMS)]
+                + [(k, _c_vp) for k in ("gx", "ge", "work")])
+
+
+def _gcn_saved_layout(nodes, edges, S, dn, de, dh):
+    """Float offsets of the forward's saved pieces (all but e_out / out, which are tensors of their own) in ONE allocation."""
+    wide = 2 * dh + de
+    sizes = (edges * dh, edges * dh, S * dh, S * dh, edges * wide, edges * wide, S * wide, S * wide, nodes * dh, 0,
+             nodes * dh, nodes * dh, S * dh, S * dh, 0)
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    return offs, total
+
+
+def gcn_layer_forward(x, e, dst, src, order, rowptr, node_ptr, edge_ptr, S, relu_out, eps, params):
+    """One TripletGCN layer (network_TripletGCN.py:40-58) in ONE C call (pn2_gcn_layer_forward: six launches).
+    -> (out (nodes, dn), e_out (edges, de), saved): `saved` holds the pre-BatchNorm values and the per-scan statistics
+    for gcn_layer_backward.  Thin binding: the autograd node validates dtypes / contiguity."""
+    nodes, dn = x.shape
+    edges, de = e.shape
+    dh = params[8].size(1)
+    offs, total = _gcn_saved_layout(nodes, edges, S, dn, de, dh)
+    saved = torch.empty(total, dtype=torch.float32, device=x.device)
+    out = torch.empty(nodes, dn, dtype=torch.float32, device=x.device)
+    e_out = torch.empty(edges, de, dtype=torch.float32, device=x.device)
+    base = saved.data_ptr()
+    sp = [base + 4 * o for o in offs]
+    sp[9], sp[14] = e_out.data_ptr(), out.data_ptr()
+    L = GcnLayer(nodes, edges, S, dn, de, dh, int(bool(relu_out)), eps[0], eps[1], eps[2],
+                 x.data_ptr(), e.data_ptr(), dst.data_ptr(), src.data_ptr(), order.data_ptr(), rowptr.data_ptr(),
+                 node_ptr.data_ptr(), edge_ptr.data_ptr(), *[p.data_ptr() for p in params], *sp)
+    wide = 2 * dh + de
+    _call("pn2_gcn_layer_forward", x, ctypes.byref(L),
+          alg_flops=2 * edges * ((2 * dn + de) * dh + dh * wide) + 2 * nodes * (dh * dh + dh * dn))
+    return out, e_out, saved
+
+
+def gcn_layer_backward(g_out, g_e, x, e, dst, src, order, rowptr, node_ptr, edge_ptr, S, relu_out, params, saved, out):
+    """Backward of gcn_layer_forward in ONE C call (nine launches) -> (gx, ge, [dW1, db1, dgamma1, dbeta1, ..., dW4, db4])."""
+    nodes, dn = x.shape
+    edges, de = e.shape
+    dh = params[8].size(1)
+    offs, _ = _gcn_saved_layout(nodes, edges, S, dn, de, dh)
+    f32 = torch.float32
+    grads = zero_arena(x.device, [(tuple(p.shape), f32) for p in params] + [((nodes, dn), f32)])
+    gx = grads.pop()
+    ge = torch.empty_like(e)
+    work = torch.empty(_lib.pn2_gcn_layer_backward_workspace_bytes(nodes, edges, dn, de, dh) // 4, dtype=f32, device=x.device)
+    base = saved.data_ptr()
+    sp = [base + 4 * o for o in offs]
+    sp[9], sp[14] = None, out.data_ptr()
+    L = GcnLayer(nodes, edges, S, dn, de, dh, int(bool(relu_out)), 0.0, 0.0, 0.0,
+                 x.data_ptr(), e.data_ptr(), dst.data_ptr(), src.data_ptr(), order.data_ptr(), rowptr.data_ptr(),
+                 node_ptr.data_ptr(), edge_ptr.data_ptr(), *[p.data_ptr() for p in params], *sp,
+                 g_out.data_ptr(), g_e.data_ptr(), *[g.data_ptr() for g in grads], gx.data_ptr(), ge.data_ptr(), work.data_ptr())
+    wide = 2 * dh + de
+    _call("pn2_gcn_layer_backward", x, ctypes.byref(L),
+          alg_flops=4 * edges * ((2 * dn + de) * dh + dh * wide) + 4 * nodes * (dh * dh + dh * dn))
+    return gx, ge, grads
 
 
 def segment_bn_rows(x, ptr, gamma, beta, eps, relu, h=None, col0=0):

@@ -314,14 +314,19 @@ class _AggregateAdd(Function):
         return _ext.gather_rows(g.contiguous(), ctx.csr.dst, check=False), None
 
 
-# The whole layer as ~7 launches forward / ~9 backward (csrc/gcn_fused.hip) instead of ~60 / ~180 through torch + the row
+# The whole layer as 6 launches forward / 12 backward (csrc/gcn_fused.hip) instead of ~60 / ~180 through torch + the row
 # kernels: scans of <= 128 edges and nodes (the dataset's scans have at most 110 / 11), dimensions multiples of 32.
 # PN2_GCN_FUSED=0 restores the unfused path (A/B); results agree within fp32 summation order.
 FUSED_LAYER = os.environ.get("PN2_GCN_FUSED") != "0"
-# ... up to this many scans per batch.  Measured on MI355X (tools/gcn_time.py, 2 layers, forward + backward): 1 scan 1.07 vs
-# 2.1 ms, 8 scans 0.76 vs 1.7 ms, 32 scans 1.87 vs 1.66 ms — the per-scan workgroups re-read the weights once per scan and
-# column tile (L2 traffic grows with the scan count), while the unfused path's library GEMMs see ONE tall matrix.
-FUSED_MAX_SCANS = 16
+# ... up to this many scans per batch.  Measured on MI355X (tools/gcn_time.py, 2 layers, forward + backward, fused vs the
+# better unfused form, two boxes): 1 scan 0.55-0.78 vs 1.8-2.1 ms, 8 scans 0.49-0.51 vs 1.6-2.0, 16 scans 0.60 vs 1.5,
+# 32 scans 0.96-1.0 vs 1.5, 64 scans 1.7-1.8 vs 1.6-2.2, 128 scans 3.4 vs 2.3 — the per-scan workgroups of the forward /
+# input-gradient kernels re-read the weights once per scan and column tile (L2 traffic grows with the scan count), while the
+# unfused path's library GEMMs see ONE tall matrix.
+FUSED_MAX_SCANS = 32
+# The layer's launches issued from ONE C call each way (pn2_gcn_layer_forward / _backward) instead of block by block from
+# python; PN2_GCN_LAYER_CALL=0 restores the block-by-block sequence (same kernels, same results; A/B of the host cost).
+LAYER_CALL = os.environ.get("PN2_GCN_LAYER_CALL") != "0"
 
 
 class _FusedTripletLayer(Function):
@@ -332,6 +337,15 @@ class _FusedTripletLayer(Function):
     def forward(ctx, x, e, csr, node_ptr, edge_ptr, S, relu_out, eps, *params):
         W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4 = params
         x, e = x.contiguous(), e.contiguous()
+        if LAYER_CALL:
+            # the whole layer from ONE C call each way (pn2_gcn_layer_forward / _backward): a scan-sized layer is bound by
+            # the host thread's python -> C round trips, not by its kernels
+            out, e_out, saved = _ext.gcn_layer_forward(x, e, csr.dst, csr.src, csr.order, csr.rowptr, node_ptr, edge_ptr, S,
+                                                       relu_out, eps, params)
+            ctx.csr, ctx.S, ctx.relu_out, ctx.layer_call = csr, S, relu_out, True
+            ctx.save_for_backward(x, e, node_ptr, edge_ptr, saved, out, *params)
+            return out, e_out
+        ctx.layer_call = False
         trip = (x, e, csr.dst, csr.src)
         dh, de = W3.size(1), e.size(1)
         h1, h1p, m1, r1 = _ext.gcn_linear(W1, b1, edge_ptr, S, triplet=trip, bn=(g1, be1, eps[0]), relu=True)
@@ -347,13 +361,18 @@ class _FusedTripletLayer(Function):
 
     @staticmethod
     def backward(ctx, g_out, g_e):
+        if ctx.layer_call:
+            x, e, node_ptr, edge_ptr, saved, out, *params = ctx.saved_tensors
+            csr = ctx.csr
+            gx, ge, grads = _ext.gcn_layer_backward(g_out.contiguous(), g_e.contiguous(), x, e, csr.dst, csr.src, csr.order,
+                                                    csr.rowptr, node_ptr, edge_ptr, ctx.S, ctx.relu_out, params, saved, out)
+            return (gx, ge, None, None, None, None, None, None, *grads)
         (x, e, node_ptr, edge_ptr, h1, h1p, m1, r1, h2p, m2, r2, agg, t, tp, m3, r3, out, e_out,
          W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4) = ctx.saved_tensors
         csr, S = ctx.csr, ctx.S
         dn, de, dh = x.size(1), e.size(1), W3.size(1)
         g_out, g_e = g_out.contiguous(), g_e.contiguous()
-        if ctx.relu_out:
-            g_e = torch.where(e_out > 0, g_e, torch.zeros((), device=g_e.device))
+        # (a ReLU on e_out needs no mask of its own: e_out is a slice of h2 = ReLU(..), block 2's mask zeroes the same entries)
         f32 = torch.float32
         shapes = [(tuple(p_.shape), f32) for p_ in (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4)]
         (dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2, dW3, db3, dg3, dbe3, dW4, db4, gx) = _ext.zero_arena(

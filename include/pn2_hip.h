@@ -693,6 +693,37 @@ int pn2_gcn_linear_grad_x(long long R, int S, int K, int N, const float *Gz, con
                           float *gx, float *ge, const long long *dst, const long long *src, int dn, int de, void *stream);
 int pn2_gcn_edge_slice(long long R, int ld, int off, int de, int relu, const float *hrows, float *out, void *stream);
 
+/* One TripletGCN layer per C call (round 4): the launch sequence of network_TripletGCN.py:40-58 issued from C, because a scan-
+ * sized layer is bound by the host thread — six (forward) / nine (backward) python -> C round trips cost more than the kernels.
+ *   forward : h1 = ReLU BN (cat[x[dst], e, x[src]] W1^T + b1)           (edges, dh)          nn1[0..2]   (:36, 45-47)
+ *             h2 = ReLU BN (h1 W2^T + b2)                               (edges, 2 dh + de)   nn1[3..5]
+ *             agg[n] = sum over the edges of `order[rowptr[n] : rowptr[n+1]]` of h2[:, :dh] + h2[:, dh+de:]    (:50, 54-58)
+ *             e_out = h2[:, dh : dh+de]  [ReLU: relu_out]                                    (:51)
+ *             t  = ReLU BN (agg W3^T + b3)                              (nodes, dh)          nn2[0..2]   (:38, 42-43)
+ *             out = [ReLU: relu_out] (t W4^T + b4)                      (nodes, dn)          nn2[3]
+ *   backward: g_out (nodes, dn), g_e (edges, de) -> gx (nodes, dn; ZERO on entry), ge (edges, de); the 14 parameter gradients
+ *             dW1 .. db4 += (zero on entry, like pn2_gcn_linear_grad_w).  `work`: pn2_gcn_layer_backward_workspace_bytes.
+ * `dst` = edge_index[1] (x_i: the target row, also the aggregation index, :46, 57), `src` = edge_index[0] (x_j); order /
+ * rowptr = the CSR of `dst` in edge order (stable); node_ptr / edge_ptr (S + 1): row offsets of the scans.  h1p / h2p / tp: pre-BatchNorm values,
+ * m* / r* (S, width): mean and 1/sqrt(var + eps) per scan — written by the forward, read by the backward.
+ * The same preconditions as the block entry points (pn2_gcn_fused_supported; every scan <= 128 rows). */
+typedef struct pn2_gcn_layer {
+  long long nodes, edges;
+  int S, dn, de, dh, relu_out;
+  float eps1, eps2, eps3;
+  const float *x, *e;
+  const long long *dst, *src, *order, *rowptr, *node_ptr, *edge_ptr;
+  const float *W1, *b1, *g1, *be1, *W2, *b2, *g2, *be2, *W3, *b3, *g3, *be3, *W4, *b4;
+  float *h1, *h1p, *m1, *r1, *h2, *h2p, *m2, *r2, *agg, *e_out, *t, *tp, *m3, *r3, *out;
+  const float *g_out, *g_e;
+  float *dW1, *db1, *dg1, *dbe1, *dW2, *db2, *dg2, *dbe2, *dW3, *db3, *dg3, *dbe3, *dW4, *db4;
+  float *gx, *ge;
+  void *work;
+} pn2_gcn_layer;
+int pn2_gcn_layer_forward(const pn2_gcn_layer *layer, void *stream);
+int pn2_gcn_layer_backward(const pn2_gcn_layer *layer, void *stream);
+size_t pn2_gcn_layer_backward_workspace_bytes(long long nodes, long long edges, int dn, int de, int dh);
+
 /* Running statistics of a BatchNorm1d WITH running statistics (the classification heads, network_PointNet.py:198-203) after
  * the S per-scan batches of pn2_segment_bn_rows, applied in scan order like S calls of F.batch_norm(training=True):
  * running <- (1 - momentum) running + momentum stat_s, variance unbiased (n_s / (n_s - 1)), num_batches_tracked += S. */

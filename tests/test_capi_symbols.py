@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
     lib.pn2_abi_version.restype = ctypes.c_int
-    assert lib.pn2_abi_version() == 5
+    assert lib.pn2_abi_version() == 6
     lib.pn2_strerror.restype = ctypes.c_char_p
     lib.pn2_strerror.argtypes = [ctypes.c_int]
     assert lib.pn2_strerror(-1) and lib.pn2_strerror(12345)
@@ -193,3 +193,40 @@ def test_segment_table_host_side():
     lib.pn2_bn_finalize_seg.argtypes = [i32, i32, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp, vp]
     assert lib.pn2_bn_finalize_seg(0, 64, dummy, dummy, None, None, 1e-5, 0.1, None, None, None, dummy, None) != 0
     assert lib.pn2_bn_finalize_seg(2, 64, dummy, dummy, None, None, 1e-5, 0.1, dummy, None, None, dummy, None) != 0  # mean w/o var
+
+
+def test_gcn_layer_struct_mirrors_the_header_and_argument_checks_need_no_gpu():
+    """pn2_gcn_layer (include/pn2_hip.h) against the ctypes mirror in _ext: same size, fields in the header's order; the
+    entry points reject a null layer / unsupported dimensions and accept an empty layer before any launch; the backward's
+    workspace holds its seven intermediate matrices in 256-byte pieces."""
+    import re
+    sys.path.insert(0, os.path.join(REPO, "4d-or_amd"))
+    from pointnet2_ops import _ext
+    header = open(os.path.join(REPO, "include", "pn2_hip.h")).read()
+    body = re.search(r"typedef struct pn2_gcn_layer \{(.*?)\} pn2_gcn_layer;", header, re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(long long|int|float|void)\s*", "", decl)
+        names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
+    assert names == [f[0] for f in _ext.GcnLayer._fields_]
+    assert ctypes.sizeof(_ext.GcnLayer) == 48 + 56 * ctypes.sizeof(ctypes.c_void_p)
+    lib = ctypes.CDLL(LIB)
+    for fn in (lib.pn2_gcn_layer_forward, lib.pn2_gcn_layer_backward):
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        assert fn(None, None) == -2                                   # PN2_ENULL
+        empty = _ext.GcnLayer(0, 0, 0, 256, 256, 512, 0)
+        assert fn(ctypes.byref(empty), None) == 0                     # nothing to do: no pointer is looked at
+        bad = _ext.GcnLayer(9, 72, 1, 250, 256, 512, 0)
+        assert fn(ctypes.byref(bad), None) == -1                      # PN2_EINVAL: dn not a multiple of 32
+        nul = _ext.GcnLayer(9, 72, 1, 256, 256, 512, 0)
+        assert fn(ctypes.byref(nul), None) == -2                      # required pointers missing
+    ws = lib.pn2_gcn_layer_backward_workspace_bytes
+    ws.argtypes = [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    ws.restype = ctypes.c_size_t
+    n, e, dn, de, dh = 9, 72, 256, 256, 512
+    assert ws(n, e, dn, de, dh) == 4 * (n * dn + 3 * n * dh + e * (2 * dh + de) + 2 * e * dh)      # every piece already a multiple of 64 floats
+    assert ws(3, 5, 32, 32, 32) == 4 * (128 + 3 * 128 + 512 + 2 * 192)                               # 96 -> 128, 480 -> 512, 160 -> 192 floats
+    assert ws(-1, 5, 32, 32, 32) == 0

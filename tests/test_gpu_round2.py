@@ -236,7 +236,7 @@ def test_three_layer_gcn_on_64_block_diagonal_scenes_matches_oracle(route, monke
     from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
     lifted = route == "lifted"
     monkeypatch.setattr(gcn, "FUSED_LAYER", route == "fused")
-    monkeypatch.setattr(gcn, "FUSED_MAX_SCANS", 64)        # (the default routes batches of more than 16 scans to the unfused path)
+    monkeypatch.setattr(gcn, "FUSED_MAX_SCANS", 64)        # (the default routes batches of more than 32 scans to the unfused path)
     monkeypatch.setattr(gcn, "LIFT_MIN_EDGES", 0 if lifted else 1 << 60)
     torch.manual_seed(5)
     model = gcn.TripletGCNModel(num_layers=3, dim_node=256, dim_edge=256, dim_hidden=512).train()
@@ -268,10 +268,10 @@ def test_three_layer_gcn_on_64_block_diagonal_scenes_matches_oracle(route, monke
     ref = run("cpu", oracle_ext.OracleRowsExt)
     calls = {"n": 0}
     if route == "fused":
-        real = _ext.gcn_linear
-        monkeypatch.setattr(_ext, "gcn_linear", lambda *a_, **k_: (calls.__setitem__("n", calls["n"] + 1), real(*a_, **k_))[1])
+        real = _ext.gcn_layer_forward
+        monkeypatch.setattr(_ext, "gcn_layer_forward", lambda *a_, **k_: (calls.__setitem__("n", calls["n"] + 1), real(*a_, **k_))[1])
     got = run("cuda", _ext)
-    assert calls["n"] == (12 if route == "fused" else 0)       # 3 layers x 4 Linear blocks went through the fused kernels
+    assert calls["n"] == (3 if route == "fused" else 0)        # the 3 layers went through the fused kernels (one C call each)
     for a, b, name in zip(got[:4], ref[:4], ("nodes", "edges", "grad nodes", "grad edges")):
         err = float((a - b).abs().max())
         print(f"\n[gcn x64 {route}] {name}: max abs err {err:.3e} (max |ref| {float(b.abs().max()):.3f})", end="")

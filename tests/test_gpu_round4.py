@@ -610,3 +610,37 @@ def test_one_scan_triplet_gcn_takes_the_fused_layer_and_matches_the_unfused_path
     for u, v in zip(a[4:], b[4:]):
         if float(v.norm()) > 1e-6 * top:
             assert float((u - v).norm() / v.norm()) <= 1e-2
+
+
+@pytest.mark.parametrize("n_objs", [[9], [4, 11, 3, 7]])
+def test_layer_call_issues_the_same_launches_as_the_block_by_block_sequence(n_objs):
+    """pn2_gcn_layer_forward / _backward (ONE C call each way) against the block entry points called one by one from python:
+    the same kernels on the same operands — features bit-equal, gradients equal up to the order of the fp32 atomics."""
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    torch.manual_seed(21)
+    model = gcn.TripletGCNModel(num_layers=2, dim_node=256, dim_edge=256, dim_hidden=512).cuda().train()
+    eis, node_ptr, edge_ptr = [], [0], [0]
+    for n in n_objs:
+        ei = torch.tensor([[a, b] for a in range(n) for b in range(n) if a != b]).t() + node_ptr[-1]
+        eis.append(ei); node_ptr.append(node_ptr[-1] + n); edge_ptr.append(edge_ptr[-1] + ei.size(1))
+    ei = torch.cat(eis, 1).contiguous().cuda()
+    scenes = gcn.SceneBatch(torch.tensor(node_ptr), torch.tensor(edge_ptr)).to("cuda") if len(n_objs) > 1 else None
+    g = torch.Generator().manual_seed(22)
+    x, ef = torch.randn(node_ptr[-1], 256, generator=g).cuda(), torch.randn(edge_ptr[-1], 256, generator=g).cuda()
+
+    def run(layer_call):
+        prev, gcn.LAYER_CALL = gcn.LAYER_CALL, layer_call
+        try:
+            m = copy.deepcopy(model)
+            xx, ee = x.clone().requires_grad_(True), ef.clone().requires_grad_(True)
+            ox, oe = m(xx, ee, ei, scenes=scenes)
+            assert type(ox.grad_fn).__name__.startswith("_FusedTripletLayer")
+            (ox.square().mean() + oe.square().mean()).backward()
+            return [ox.detach(), oe.detach(), xx.grad, ee.grad] + [q.grad for q in m.parameters()]
+        finally:
+            gcn.LAYER_CALL = prev
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for i, (u, v) in enumerate(zip(a[2:], b[2:])):
+        assert float((u - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), i

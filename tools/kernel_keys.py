@@ -21,7 +21,7 @@ ENTRY_OF_FAMILY = {
     "bq_fused_group_kernel": "pn2_ball_query_group", "bq_slab_query_kernel": "pn2_ball_query", "bq_slab_build_kernel": "pn2_ball_query",
     "fps_multi_kernel": "pn2_furthest_point_sampling", "fps_coop_kernel": "pn2_furthest_point_sampling",
     "fps_resident_kernel": "pn2_furthest_point_sampling", "fps_bucket_kernel": "pn2_furthest_point_sampling",
-    "gcn_linear_kernel": "pn2_gcn_linear", "gcn_linear_grad_w_kernel": "pn2_gcn_linear_grad_w",
+    "gcn_linear_kernel": "pn2_gcn_linear", "gcn_bn_bwd_kernel": "pn2_gcn_linear_grad_w", "gcn_wgrad_kernel": "pn2_gcn_linear_grad_w",
     "gcn_linear_grad_x_kernel": "pn2_gcn_linear_grad_x",
 }
 
