@@ -335,6 +335,7 @@ class _FusedTripletLayer(Function):
 
     @staticmethod
     def forward(ctx, x, e, csr, node_ptr, edge_ptr, S, relu_out, eps, *params):
+        params = tuple(p_.contiguous() for p_ in params)          # (the C side takes plain row-major pointers)
         W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4 = params
         x, e = x.contiguous(), e.contiguous()
         if LAYER_CALL:
