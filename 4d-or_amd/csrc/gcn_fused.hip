@@ -13,12 +13,14 @@
 // everything BatchNorm needs is local to the workgroup that owns a 32-column tile of a Linear's output:
 //   pn2_gcn_linear          gather (the concatenation is never built) -> Linear on the fp32 matrix cores -> + bias ->
 //                           per-scan batch statistics (two passes over the accumulators) -> BN -> ReLU, one launch;
-//   pn2_gcn_linear_grad_w   the block's backward up to the weights: ReLU mask + BatchNorm backward (per-scan sums in
-//                           registers) -> gz (kept for the input gradient), dgamma / dbeta / dbias, and dW += gz^T A on the
-//                           matrix cores; the adjoint of split + aggregate ([g_agg[dst] | g_edge | g_agg[dst]]) is read in
+//   pn2_gcn_linear_grad_w   the block's backward up to the weights, two launches: ReLU mask + BatchNorm backward per scan
+//                           (per-scan sums local to the workgroup) -> gz (kept for the input gradient), dgamma / dbeta /
+//                           dbias; then dW += gz^T A as ONE product over all rows of the batch on the matrix cores, no
+//                           atomics; the adjoint of split + aggregate ([g_agg[dst] | g_edge | g_agg[dst]]) is read in
 //                           place of a materialised gradient;
 //   pn2_gcn_linear_grad_x   input gradient gz W, written as rows or scattered through the triplet gather's adjoint
-//                           (x[dst] / e / x[src] column blocks).
+//                           (x[dst] / e / x[src] column blocks);
+//   pn2_gcn_layer_forward / _backward   the whole layer's launch sequence from one C call each way (pn2_gcn_layer).
 // v_mfma_f32_32x32x2_f32 throughout (exact fp32 products and sums, like the shared-MLP kernels); a wave's K loop splits the
 // reduction range in two halves, one per 32-lane group, so every lane streams CONTIGUOUS floats of its A row / W row
 // (16-byte loads).  Tested at 1e-4 against the oracle GCN (torch on the CPU restatement) like the unfused path.

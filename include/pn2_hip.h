@@ -669,9 +669,11 @@ int pn2_segment_bn_rows_grad(int64_t R, int C, int ldx, int col0, int64_t S, con
  *                          Ypre (R, N) pre-BN values, mean / rstd (S, N) for the backward.
  *   pn2_gcn_linear_grad_w  backward up to the weights: G (R, N) gradient of Out — or (gagg != NULL) the adjoint of split +
  *                          aggregate (:48-58) read in place: [gagg[dst] | gedge | gagg[dst]], N = 2 dh + dE — through the
- *                          ReLU mask and BatchNorm's backward -> Gz (R, N); dW (N, K) += Gz^T A, dbias (N) += column sums
- *                          of Gz, dgamma / dbeta (N) += (all zeroed by the caller once per step; fp32 atomics across scans).
- *                          gamma NULL: no BatchNorm (relu: Ypre = Out).
+ *                          ReLU mask and BatchNorm's backward -> Gz (R, N); dW (N, K) += Gz^T A over all R rows (one
+ *                          workgroup per 32 x 32 tile, plain read-modify-write: deterministic — do not run two calls on
+ *                          the same dW concurrently), dbias (N) += column sums of Gz, dgamma / dbeta (N) += (fp32 atomics
+ *                          across scans); all four zeroed by the caller once per step.  Two launches (BatchNorm backward
+ *                          per scan, then the product).  gamma NULL: no BatchNorm (relu: Ypre = Out).
  *   pn2_gcn_linear_grad_x  input gradient Gz W: Gin (R, K), or (gx != NULL) scattered through the adjoint of the triplet
  *                          gather: gx (nodes, dn) += columns [0, dn) at dst and [dn + de, K) at src, ge (R, de) = the middle.
  *   pn2_gcn_edge_slice     out (R, de) = [ReLU] h[:, off : off + de]  (the new edge feature, :51).
