@@ -367,7 +367,9 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   long long tprev = __builtin_readcyclecounter();
 #endif
   constexpr int K = 64, NW = 8, THREADS = 512;
-  constexpr int LDZ = K + 1, LDT = K + 4, LDW = K + 1;
+  // (LDW = K + 4: rows of W' 16-byte aligned for the S walk's ds_read_b128 — four reads per list slot instead of sixteen and
+  // three-way instead of four-to-five-way bank serialisation for random arg-max columns: 1.180 -> 1.150 ms at the SA1 shape)
+  constexpr int LDZ = K + 1, LDT = K + 4, LDW = K + 4;
   constexpr int CG = K / 4;           // 16 threads per row
   constexpr int RP = THREADS / CG;    // 32 rows per pass
   constexpr int NPASS = TM / RP;      // 2
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   __shared__ float zt[TM * LDZ];
   __shared__ __attribute__((aligned(16))) float st[TM * LDT];
   __shared__ __attribute__((aligned(16))) float prm[4 * K];
-  __shared__ float wl[NPAD * LDW];
+  __shared__ __attribute__((aligned(16))) float wl[NPAD * LDW];
   __shared__ int cnt[TM + 1];         // entries filed per row; [TM] = overflow count
   __shared__ int lst_n[TM * CAP];
   __shared__ float lst_c[TM * CAP];
@@ -408,9 +410,10 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   for (int s = 0; s < K / 2; ++s) Greg[s] = zrole ? a.G[(2 * s + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
   const float vreg = a.v[cb * 32 + (lane & 31)];
   const int tn0 = ((wave & 3) % NH) * 64, tk0 = ((wave & 3) / NH) * KQ;     // T (waves 4-7): first column n, first column k
-  float tacc[KQ];
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 tacc[KQ / 2];                                       // (pairs of columns: packed FMAs, see the S walk)
 #pragma unroll
-  for (int kk = 0; kk < KQ; ++kk) tacc[kk] = 0.f;
+  for (int kk = 0; kk < KQ / 2; ++kk) tacc[kk] = f2{0.f, 0.f};
 
   f32x16 acc;                                            // role 1: per-tile a G block; role 2: running Gram block
 #pragma unroll
@@ -431,14 +434,14 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   const int egi = tid / NPAD, en = tid % NPAD;
   int ea, ta[GMAX];
   float ec, tg[GMAX];
-  auto load_idx = [&](long long tile) {
+  auto load_entry = [&](long long tile) {
+    const long long g = tile * TM / ns + egi;
+    const bool ok = egi < ngt && g < R && en < N;
+    ea = ok ? a.arg[(size_t)(ok ? g : 0) * N + (ok ? en : 0)] : -(1 << 20);
+    ec = ok ? a.gPm[(size_t)(ok ? g : 0) * N + (ok ? en : 0)] : 0.f;
+  };
+  auto load_tcols = [&](long long tile) {
     const long long g_first = tile * TM / ns;
-    {
-      const long long g = g_first + egi;
-      const bool ok = egi < ngt && g < R && en < N;
-      ea = ok ? a.arg[(size_t)(ok ? g : 0) * N + (ok ? en : 0)] : -(1 << 20);
-      ec = ok ? a.gPm[(size_t)(ok ? g : 0) * N + (ok ? en : 0)] : 0.f;
-    }
 #pragma unroll
     for (int gi = 0; gi < GMAX; ++gi) {
       const long long g = g_first + gi;
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
       tg[gi] = ok ? a.gPm[(size_t)(ok ? g : 0) * N + (ok ? n : 0)] : 0.f;
     }
   };
+  auto load_idx = [&](long long tile) { load_entry(tile); load_tcols(tile); };     // (before the first tile)
 
   long long tile = blockIdx.x;
   if (tile < ntiles) {
@@ -499,30 +503,38 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
     if (zrole) {
       // S: lane = tile row, registers = this wave's KS columns.  The first CAP list slots of the row are read up front
       // (empty slots: coefficient 0), so the W' reads of all slots are independent and in flight together.
-      float sreg[KS];
+      // (packed fp32 FMAs — v_pk_fma_f32, the IEEE operation on two columns per instruction: fp32 matrix and vector
+      // instructions share the SIMD's datapath on this part, so every vector instruction saved is matrix time)
+      f2 sreg[KS / 2];
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) sreg[kk] = 0.f;
+      for (int kk = 0; kk < KS / 2; ++kk) sreg[kk] = f2{0.f, 0.f};
       const int filed = cnt[lane];
       const int mine = filed < CAP ? filed : CAP;
       // two list slots per step: their W' reads are independent and in flight together
       for (int c = 0; __ballot(c < mine) != 0ull; c += 2) {
         int n2[2];
-        float c2[2];
+        f2 c2[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const bool act = c + u < mine;
           n2[u] = act ? lst_n[lane * CAP + c + u] : 0;
-          c2[u] = act ? lst_c[lane * CAP + c + u] : 0.f;
+          const float cf = act ? lst_c[lane * CAP + c + u] : 0.f;
+          c2[u] = f2{cf, cf};
         }
-        float w[2][KS];
+        f2 w[2][KS / 2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int kk = 0; kk < KS; kk += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(&wl[n2[u] * LDW + wave * KS + kk]);
+            w[u][kk / 2] = f2{q[0], q[1]};
+            w[u][kk / 2 + 1] = f2{q[2], q[3]};
+          }
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int kk = 0; kk < KS; ++kk) w[u][kk] = wl[n2[u] * LDW + wave * KS + kk];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int kk = 0; kk < KS; ++kk) sreg[kk] = __fmaf_rn(c2[u], w[u][kk], sreg[kk]);
+          for (int kk = 0; kk < KS / 2; ++kk) sreg[kk] = __builtin_elementwise_fma(c2[u], w[u][kk], sreg[kk]);
       }
       const int nov = __builtin_amdgcn_readfirstlane(cnt[TM]);
       for (int o = 0; o < nov; ++o) {                      // rows with more than CAP entries: one lane at a time
@@ -530,39 +542,51 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
         const float cf = (rn >> 16) == lane ? ovf_c[o] : 0.f;
         const float *wr = &wl[(rn & 0xffff) * LDW + wave * KS];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) sreg[kk] = __fmaf_rn(cf, wr[kk], sreg[kk]);
+        for (int kk = 0; kk < KS / 2; ++kk) sreg[kk] = __builtin_elementwise_fma(f2{cf, cf}, f2{wr[2 * kk], wr[2 * kk + 1]}, sreg[kk]);
       }
 #pragma unroll
       for (int kk = 0; kk < KS; kk += 4) {
-        f32x4 o4 = {sreg[kk], sreg[kk + 1], sreg[kk + 2], sreg[kk + 3]};
+        f32x4 o4 = {sreg[kk / 2][0], sreg[kk / 2][1], sreg[kk / 2 + 1][0], sreg[kk / 2 + 1][1]};
         *reinterpret_cast<f32x4 *>(&st[lane * LDT + wave * KS + kk]) = o4;
       }
     }
     // T: lanes = columns n of this wave's half, registers = its KQ columns k; every lane walks along ITS arg-max row of
     // the activation tile (immediate offsets, independent loads)
+    auto t_walk = [&]() {
 #pragma unroll
-    for (int gi = 0; gi < GMAX; ++gi) {
-      if (!zrole && gi < ngt) {
-        const int base = (int)((g_first + gi) * ns - m0);
-        int rt = base + ta[gi];
-        const bool ok = (unsigned)rt < (unsigned)TM;
-        const float cf = ok ? tg[gi] : 0.f;
-        rt = ok ? rt : 0;
-        const float *zr = &zt[rt * LDZ + tk0];
+      for (int gi = 0; gi < GMAX; ++gi) {
+        if (!zrole && gi < ngt) {
+          const int base = (int)((g_first + gi) * ns - m0);
+          int rt = base + ta[gi];
+          const bool ok = (unsigned)rt < (unsigned)TM;
+          const float cf = ok ? tg[gi] : 0.f;
+          rt = ok ? rt : 0;
+          const float *zr = &zt[rt * LDZ + tk0];
 #pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) tacc[kk] = __fmaf_rn(cf, zr[kk], tacc[kk]);
+          for (int kk = 0; kk < KQ / 2; ++kk) tacc[kk] = __builtin_elementwise_fma(f2{cf, cf}, f2{zr[2 * kk], zr[2 * kk + 1]}, tacc[kk]);
+        }
       }
-    }
+    };
     PB_T(2)
-    load_idx(nt);
+    load_entry(nt);
 
     // ---- (C) matrix products: one 32 x 32 block per wave ----
     if (zrole) {
+      // A fragments from LDS, the operands of the next eight steps read while eight MFMAs issue (read-wait-issue per pair
+      // of steps made this phase wait for an LDS round trip sixteen times per tile: 3.3k cycles for 2.0k of matrix pipe)
       const float *za = &zt[(rb * 32 + (lane & 31)) * LDZ + (lane >> 5)];
+      float zp[2][8];
 #pragma unroll
-      for (int s = 0; s < K / 2; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[2 * s], Greg[s], acc, 0, 0, 0);
-        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < 8; ++u) zp[0][u] = za[2 * u];
+#pragma unroll
+      for (int g8 = 0; g8 < K / 16; ++g8) {
+        if (g8 + 1 < K / 16) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) zp[(g8 + 1) & 1][u] = za[2 * (8 * (g8 + 1) + u)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zp[g8 & 1][u], Greg[8 * g8 + u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       // Gram block: both fragments come from LDS — operands of the next eight steps are read while eight MFMAs issue
@@ -584,6 +608,10 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
         for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[g8 & 1][u], pb[g8 & 1][u], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      // T AFTER the Gram block (it only needs the activation tile): the matrix pipe starts while waves 0-3 still walk their
+      // row lists, and this walk runs in the shadow of their a G products (1.154 -> 1.146 ms at the SA1 shape)
+      t_walk();
+      load_tcols(nt);
     }
     PB_T(3)
     __syncthreads();
@@ -668,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   float *pt = prec + K * K + K;
   if (!zrole && tn0 + lane < N) {
 #pragma unroll
-    for (int kk = 0; kk < KQ; ++kk) pt[(size_t)(tn0 + lane) * K + tk0 + kk] = tacc[kk];
+    for (int kk = 0; kk < KQ; ++kk) pt[(size_t)(tn0 + lane) * K + tk0 + kk] = tacc[kk / 2][kk & 1];
   }
 }
 
