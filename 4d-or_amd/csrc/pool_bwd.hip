@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = __builtin_readcyclecounter();
 #endif
-  constexpr int K = 64, NW = 8, THREADS = 512;
+  constexpr int K = 64, THREADS = 512;
   // (LDW = K + 4: rows of W' 16-byte aligned for the S walk's ds_read_b128 — four reads per list slot instead of sixteen and
   // three-way instead of four-to-five-way bank serialisation for random arg-max columns: 1.180 -> 1.150 ms at the SA1 shape)
   constexpr int LDZ = K + 1, LDT = K + 4, LDW = K + 4;
@@ -719,7 +719,6 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
   constexpr int GMAX = 4;             // groups per tile (ns >= 16)
   constexpr int EPT = GMAX * NPAD / THREADS;   // entries a thread files per tile (2)
   constexpr int KQ = 64;              // T: wave = (64-column quarter of N) x (64-column half of K)
-  constexpr int KS = K / NW;          // S: 16-column slab of K per wave
   constexpr int CAP = 16;             // N / ns = 8 entries per row on average at the headline shape
   constexpr int OVC = GMAX * NPAD;
   __shared__ float zt[TM * LDZ];
@@ -836,7 +835,6 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
     __syncthreads();
     PB_T(1)
     const long long nt = (tile + gridDim.x) < ntiles ? tile + gridDim.x : tile;
-    load_tile(nt, ynxt);
 
     // ---- (B) sparse parts ----
     {
@@ -853,36 +851,57 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
       const bool va = c0 < mine, vb = c0 + 8 < mine;
       const int n_a = va ? lst_n[myrow * CAP + c0] : 0, n_b = vb ? lst_n[myrow * CAP + c0 + 8] : 0;
       const float c_a = va ? lst_c[myrow * CAP + c0] : 0.f, c_b = vb ? lst_c[myrow * CAP + c0 + 8] : 0.f;
-      const bool second = __ballot(vb) != 0ull;              // any of the wave's rows with more than eight entries
       const float *wl = a.Wp + 2 * lane;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        f2 acc = {0.f, 0.f};
-        f2 w[8];
+      for (int r = 0; r < 8; r += 2) {
+        // two rows per batch; only their filed slots are fetched (the counts are wave-uniform: a scalar branch per slot, no
+        // wait in between).  Fetching all sixteen slots of every row — an empty one read row 0 — kept the loads branch-free
+        // but moved 512 KB per tile through the CU's one 64-byte-per-clock vector memory path for 256 KB of entries: that
+        // path, not the L2 latency, was the phase's time.
+        int cr[2];
+        f2 acc[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        f2 w[2][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int n = __builtin_amdgcn_readlane(n_a, 8 * r + q);
-          w[q] = *reinterpret_cast<const f2 *>(wl + (size_t)n * K);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_a), 8 * r + q));
-          acc = __builtin_elementwise_fma(f2{cf, cf}, w[q], acc);
-        }
-        if (second) {
+        for (int u = 0; u < 2; ++u) {
+          cr[u] = __builtin_amdgcn_readlane(mine, 8 * (r + u));
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            const int n = __builtin_amdgcn_readlane(n_b, 8 * r + q);
-            w[q] = *reinterpret_cast<const f2 *>(wl + (size_t)n * K);
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_b), 8 * r + q));
-            acc = __builtin_elementwise_fma(f2{cf, cf}, w[q], acc);
+            w[u][q] = f2{0.f, 0.f};
+            if (q < cr[u]) {
+              const int n = __builtin_amdgcn_readlane(n_a, 8 * (r + u) + q);
+              w[u][q] = *reinterpret_cast<const f2 *>(wl + (size_t)n * K);
+            }
           }
         }
-        *reinterpret_cast<f2 *>(&st[(wave * 8 + r) * LDT + 2 * lane]) = acc;
-        __builtin_amdgcn_sched_barrier(0);                  // one row at a time (eight 8-byte loads in flight)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_a), 8 * (r + u) + q));
+            acc[u] = __builtin_elementwise_fma(f2{cf, cf}, w[u][q], acc[u]);
+          }
+        if (cr[0] > 8 || cr[1] > 8) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              w[u][q] = f2{0.f, 0.f};
+              if (q + 8 < cr[u]) {
+                const int n = __builtin_amdgcn_readlane(n_b, 8 * (r + u) + q);
+                w[u][q] = *reinterpret_cast<const f2 *>(wl + (size_t)n * K);
+              }
+            }
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_b), 8 * (r + u) + q));
+              acc[u] = __builtin_elementwise_fma(f2{cf, cf}, w[u][q], acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<f2 *>(&st[(wave * 8 + r + u) * LDT + 2 * lane]) = acc[u];
+        __builtin_amdgcn_sched_barrier(0);
       }
       const int nov = __builtin_amdgcn_readfirstlane(cnt[TM]);
       for (int o = 0; o < nov; ++o) {                      // rows with more than CAP entries: their wave, one entry at a time
@@ -897,6 +916,9 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
       }
     }
     PB_T(2)
+    // (the next tile's rows are requested only now: during the S walk their sixteen registers hold its second row of loads;
+    // T and the matrix products still cover the latency)
+    load_tile(nt, ynxt);
     // T: lanes = columns n of this wave's quarter, registers = its 64 columns k
 #pragma unroll
     for (int gi = 0; gi < GMAX; ++gi) {
