@@ -710,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
   long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = __builtin_readcyclecounter();
 #endif
-  constexpr int K = 128, NW = 8, THREADS = 512;
+  constexpr int K = 128, THREADS = 512;
   constexpr int LDZ = K + 1, LDT = K + 4, LDG = K + 1;
   constexpr int CG = K / 4;           // 32 threads per row
   constexpr int RP = THREADS / CG;    // 16 rows per pass
