@@ -744,7 +744,13 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
   for (int i = tid; i < K * K; i += THREADS) gl[(i / K) * LDG + (i % K)] = a.G[i];
   if (tid <= TM) cnt[tid] = 0;
   const int rb = wave >> 2, cb = wave & 3;               // a G block
-  const int ib = wave >> 1, jb0 = (wave & 1) * 2;        // Gram blocks (ib, jb0), (ib, jb0 + 1)
+  // Gram blocks: a^T a is symmetric — ten of its sixteen 32 x 32 blocks are computed (the flush mirrors the off-diagonal
+  // ones).  Every wave owns ONE block (waves 0-3 the diagonal, 4-7: (0,1) (2,3) (0,2) (1,3)) and a quarter of the tile's
+  // rows of one of the two remaining blocks ((0,3): waves 0-3, (1,2): waves 4-7; summed through LDS at the flush):
+  // 32 + 8 matrix instructions per tile and wave instead of 64.
+  const int oi = wave < 4 ? wave : (wave == 4 || wave == 6 ? 0 : (wave == 5 ? 2 : 1));
+  const int oj = wave < 4 ? wave : (wave == 4 ? 1 : (wave == 6 ? 2 : 3));
+  const int si = wave < 4 ? 0 : 1, sj = wave < 4 ? 3 : 2, sq = wave & 3;
   const float vreg = a.v[cb * 32 + (lane & 31)];
   const int tn0 = (wave & 3) * 64, tk0 = (wave >> 2) * KQ;
 
@@ -948,15 +954,18 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
         accZ = __builtin_amdgcn_mfma_f32_32x32x2f32(za[2 * s], gb_[2 * s * LDG], accZ, 0, 0, 0);
         if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
-      const float *ga = &zt[(lane >> 5) * LDZ + ib * 32 + (lane & 31)];
-      const float *gb = &zt[(lane >> 5) * LDZ + jb0 * 32 + (lane & 31)];
+      const float *ga = &zt[(lane >> 5) * LDZ + oi * 32 + (lane & 31)];
+      const float *gb = &zt[(lane >> 5) * LDZ + oj * 32 + (lane & 31)];
 #pragma unroll
       for (int s = 0; s < TM / 2; ++s) {
-        const float av = ga[2 * s * LDZ];
-        accG[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gb[2 * s * LDZ], accG[0], 0, 0, 0);
-        accG[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gb[2 * s * LDZ + 32], accG[1], 0, 0, 0);
-        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        accG[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[2 * s * LDZ], gb[2 * s * LDZ], accG[0], 0, 0, 0);
+        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
+      const float *sa = &zt[((lane >> 5) + 16 * sq) * LDZ + si * 32 + (lane & 31)];     // rows 16 sq .. 16 sq + 15
+      const float *sb = &zt[((lane >> 5) + 16 * sq) * LDZ + sj * 32 + (lane & 31)];
+#pragma unroll
+      for (int s = 0; s < TM / 8; ++s) accG[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[2 * s * LDZ], sb[2 * s * LDZ], accG[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     PB_T(3)
     __syncthreads();
@@ -1030,13 +1039,26 @@ __global__ __launch_bounds__(512, 2) void pool_bwd128_kernel(const PoolBwdArgs a
     atomicAdd(a.sums + tid, (double)t3[1]);
     atomicAdd(a.sums + K + tid, (double)t3[2]);
   }
+  // Gram blocks: the wave's own block and its mirror image; the quarter-partials of the two shared blocks meet in LDS
+  float *gq = st;                                        // [8 waves][16][64] (32 KB of the staging tile)
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 31;
+    prec[(oi * 32 + i) * K + oj * 32 + j] = accG[0][r];
+    if (oi != oj) prec[(oj * 32 + j) * K + oi * 32 + i] = accG[0][r];
+    gq[(wave * 16 + r) * 64 + lane] = accG[1][r];
+  }
+  __syncthreads();
+  if (sq == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      prec[i * K + (jb0 + b) * 32 + (lane & 31)] = accG[b][r];
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 31;
+      const float v = (gq[(wave * 16 + r) * 64 + lane] + gq[((wave + 1) * 16 + r) * 64 + lane]) +
+                      (gq[((wave + 2) * 16 + r) * 64 + lane] + gq[((wave + 3) * 16 + r) * 64 + lane]);
+      prec[(si * 32 + i) * K + sj * 32 + j] = v;
+      prec[(sj * 32 + j) * K + si * 32 + i] = v;
     }
+  }
   float *pt = prec + K * K + K;
   if (tn0 + lane < N) {
 #pragma unroll
