@@ -404,10 +404,17 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   if (tid <= TM) cnt[tid] = 0;
   const int blk = wave & 3;
   const int rb = blk >> 1, cb = blk & 1;                 // output block of a G (waves 0-3) / Gram block (waves 4-7)
-  // B fragments of a G (waves 0-3 only)
-  float Greg[K / 2];
+  // Role registers: waves 0-3 keep the B fragments of their a G block in them, waves 4-7 two of their three running Gram
+  // accumulators.  a^T a is symmetric: its blocks (0,0), (1,1), (0,1) are computed — every Gram wave a quarter of the tile's
+  // rows (16 wq .. 16 wq + 15) of each of the three: 24 matrix instructions per tile instead of 32, from two LDS operands per
+  // step instead of two per instruction — and summed / mirrored at the flush.
+  f32x16 rg0, rg1;
 #pragma unroll
-  for (int s = 0; s < K / 2; ++s) Greg[s] = zrole ? a.G[(2 * s + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
+  for (int s = 0; s < 16; ++s) {
+    rg0[s] = zrole ? a.G[(2 * s + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
+    rg1[s] = zrole ? a.G[(2 * (s + 16) + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
+  }
+  const int wq = wave & 3;
   const float vreg = a.v[cb * 32 + (lane & 31)];
   const int tn0 = ((wave & 3) % NH) * 64, tk0 = ((wave & 3) / NH) * KQ;     // T (waves 4-7): first column n, first column k
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -585,29 +592,24 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
           for (int u = 0; u < 8; ++u) zp[(g8 + 1) & 1][u] = za[2 * (8 * (g8 + 1) + u)];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zp[g8 & 1][u], Greg[8 * g8 + u], acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zp[g8 & 1][u], g8 < 2 ? rg0[8 * g8 + u] : rg1[8 * (g8 - 2) + u], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      // Gram block: both fragments come from LDS — operands of the next eight steps are read while eight MFMAs issue
-      const float *ga = &zt[(lane >> 5) * LDZ + rb * 32 + (lane & 31)];
-      const float *gb = &zt[(lane >> 5) * LDZ + cb * 32 + (lane & 31)];
-      float pa[2][8], pb[2][8];
+      // Gram: rows 16 wq .. 16 wq + 15 of the blocks (0,0), (1,1), (0,1) — both column halves of the eight row pairs are read
+      // up front (sixteen LDS operands for twenty-four matrix instructions)
+      const float *g0 = &zt[((lane >> 5) + 16 * wq) * LDZ + (lane & 31)];
+      float p0[8], p1[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { pa[0][u] = ga[2 * u * LDZ]; pb[0][u] = gb[2 * u * LDZ]; }
+      for (int u = 0; u < 8; ++u) { p0[u] = g0[2 * u * LDZ]; p1[u] = g0[2 * u * LDZ + 32]; }
 #pragma unroll
-      for (int g8 = 0; g8 < TM / 16; ++g8) {
-        if (g8 + 1 < TM / 16) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            pa[(g8 + 1) & 1][u] = ga[2 * (8 * (g8 + 1) + u) * LDZ];
-            pb[(g8 + 1) & 1][u] = gb[2 * (8 * (g8 + 1) + u) * LDZ];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[g8 & 1][u], pb[g8 & 1][u], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < 8; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[u], p0[u], acc, 0, 0, 0);
+        rg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[u], p1[u], rg0, 0, 0, 0);
+        rg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[u], p1[u], rg1, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
       // T AFTER the Gram block (it only needs the activation tile): the matrix pipe starts while waves 0-3 still walk their
       // row lists, and this walk runs in the shadow of their a G products (1.154 -> 1.146 ms at the SA1 shape)
       t_walk();
@@ -686,12 +688,27 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
     atomicAdd(a.sums + tid, (double)t3[1]);
     atomicAdd(a.sums + K + tid, (double)t3[2]);
   }
-  if (!zrole) {
+  // Gram: the four row-quarter partials of a block meet in LDS (one block per round), wave 4 + b writes block b and, for
+  // (0,1), its mirror image
+  float *gq = st;                                        // [4 waves][16][64] (16 KB of the staging tile)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      prec[i * K + cb * 32 + (lane & 31)] = acc[r];
+  for (int b = 0; b < 3; ++b) {
+    if (!zrole) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gq[(wq * 16 + r) * 64 + lane] = b == 0 ? acc[r] : (b == 1 ? rg0[r] : rg1[r]);
     }
+    __syncthreads();
+    if (wave == 4 + b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 31;
+        const float v = (gq[r * 64 + lane] + gq[(16 + r) * 64 + lane]) + (gq[(32 + r) * 64 + lane] + gq[(48 + r) * 64 + lane]);
+        if (b == 0) prec[i * K + j] = v;
+        else if (b == 1) prec[(32 + i) * K + 32 + j] = v;
+        else { prec[i * K + 32 + j] = v; prec[(32 + j) * K + i] = v; }
+      }
+    }
+    __syncthreads();
   }
   float *pt = prec + K * K + K;
   if (!zrole && tn0 + lane < N) {
