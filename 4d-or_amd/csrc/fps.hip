@@ -115,7 +115,8 @@ struct __attribute__((aligned(32))) FpsSlot2 {
 template <int BS, int PPT>
 __global__ __launch_bounds__(BS) void fps_resident_kernel(int N, int m, int L,
                                                          const float *__restrict__ xyz,
-                                                         int *__restrict__ idxs) {
+                                                         int *__restrict__ idxs,
+                                                         const int *__restrict__ ordered_fail) {
   constexpr int NW = BS / 64;
   constexpr bool LDSXYZ = PPT * BS * 12 <= 96 * 1024;      // coordinates copy fits next to the slots
   __shared__ FpsSlot2 slots[2][16];
@@ -123,6 +124,11 @@ __global__ __launch_bounds__(BS) void fps_resident_kernel(int N, int m, int L,
 
   const int b = blockIdx.x;
   const int t = threadIdx.x;
+  // pn2_furthest_point_sampling_ordered: this cloud was verified to be in sampling order — its samples are 0 .. m - 1
+  if (ordered_fail && ordered_fail[b] == 0) {
+    for (int k = t; k < m; k += BS) idxs[(size_t)b * m + k] = k;
+    return;
+  }
   const int lane = pn2_lane();
   const int wave = t >> 6;
   const float *P = xyz + (size_t)b * N * 3;
@@ -1529,9 +1535,71 @@ extern "C" int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz
   return pn2_furthest_point_sampling_ex(B, N, m, xyz, workspace, workspace_bytes, idxs, 0, stream);
 }
 
+namespace {
+int fps_launch(int B, int N, int m, const float *xyz, void *workspace, size_t workspace_bytes, int *idxs, int flags,
+               const int *ordered_fail, void *stream);
+}
+
 extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *xyz,
                                               void *workspace, size_t workspace_bytes,
                                               int *idxs, int flags, void *stream) {
+  return fps_launch(B, N, m, xyz, workspace, workspace_bytes, idxs, flags, nullptr, stream);
+}
+
+namespace {
+// ---- clouds that ARE a sampling order --------------------------------------------------------------------------------
+// The centres of SA level l + 1 are sampled from the centres of level l, and those are stored in the order level l's
+// sampling picked them (pointnet2_modules.py:38-48: gather_operation(xyz, furthest_point_sample(xyz, npoint))).  Sampling
+// m points from a cloud that is itself a farthest-point ORDER returns 0, 1, .., m - 1: point k was the farthest of ALL
+// original points from {0 .. k-1}, so it is the farthest of the subset, and the running distances of the subset evolve
+// exactly as in the first run.  Two things can break the identity — a tie (another point of the subset at exactly the same
+// running distance: the two runs break ties by different index orders) and degenerate rounds (no candidate, a NaN centre,
+// duplicates: distance 0) — so it is VERIFIED per cloud, with the kernel's own arithmetic: M[k] = running distance of point
+// k when it is picked (fps_order_m_kernel), then every point j replays its running distance against the centres 0 .. m-2
+// and must stay strictly below M[k] at every step k != j (fps_order_check_kernel).  No barriers, every point in parallel:
+// ~35 us for the three lower levels of the headline against 1.2 ms of sampling rounds; a cloud that fails takes the rounds.
+__global__ __launch_bounds__(256) void fps_order_m_kernel(int N, int m, const float *__restrict__ xyz,
+                                                         float *__restrict__ Mk, int *__restrict__ fail) {
+  extern __shared__ float cen[];                          // [3][kmax]: the centres this workgroup's points look back at
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float *P = xyz + (size_t)b * N * 3;
+  const int k = blockIdx.y * 256 + t, kmax = min(m, (int)(blockIdx.y + 1) * 256);
+  for (int i = t; i < kmax; i += 256) { cen[i] = P[(size_t)i * 3]; cen[kmax + i] = P[(size_t)i * 3 + 1]; cen[2 * kmax + i] = P[(size_t)i * 3 + 2]; }
+  if (blockIdx.y == 0 && t == 0) fail[b] = 0;
+  __syncthreads();
+  if (k >= m) return;
+  const float x = cen[k], y = cen[kmax + k], z = cen[2 * kmax + k];
+  float td = !((double)pn2_sq3(x, y, z) <= 1e-3) ? 1e10f : -1.f;          // (EXT/src/sampling_gpu.cu:100-101)
+  for (int i = 0; i < k; ++i) td = fps_min(pn2_sq3(x - cen[i], y - cen[kmax + i], z - cen[2 * kmax + i]), td);
+  Mk[(size_t)b * m + k] = td;
+}
+
+__global__ __launch_bounds__(256) void fps_order_check_kernel(int N, int m, const float *__restrict__ xyz,
+                                                             const float *__restrict__ Mk, int *__restrict__ fail) {
+  extern __shared__ float cen[];                          // [3][m] centres | [m] M
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float *P = xyz + (size_t)b * N * 3;
+  float *mk = cen + 3 * m;
+  for (int i = t; i < m; i += 256) {
+    cen[i] = P[(size_t)i * 3]; cen[m + i] = P[(size_t)i * 3 + 1]; cen[2 * m + i] = P[(size_t)i * 3 + 2];
+    mk[i] = Mk[(size_t)b * m + i];
+  }
+  __syncthreads();
+  const int j = blockIdx.y * 256 + t;
+  bool bad = false;
+  if (j < N) {
+    const float x = P[(size_t)j * 3], y = P[(size_t)j * 3 + 1], z = P[(size_t)j * 3 + 2];
+    float td = !((double)pn2_sq3(x, y, z) <= 1e-3) ? 1e10f : -1.f;
+    for (int k = 1; k < m; ++k) {                           // round k: the centre is sample k - 1, the pick must be point k
+      td = fps_min(pn2_sq3(x - cen[k - 1], y - cen[m + k - 1], z - cen[2 * m + k - 1]), td);
+      bad |= (j != k) & !(td < mk[k]);
+    }
+  }
+  if (__ballot(bad) != 0ull && pn2_lane() == 0) atomicOr(fail + b, 1);
+}
+
+int fps_launch(int B, int N, int m, const float *xyz, void *workspace, size_t workspace_bytes, int *idxs, int flags,
+               const int *ordered_fail, void *stream) {
   if (B < 0 || N < 0) return PN2_EINVAL;
   if (flags & ~(PN2_FPS_FEW_CUS | PN2_FPS_FEWEST_CUS)) return PN2_EINVAL;
   if (m <= 0 || B == 0) return PN2_OK;  // EXT/src/sampling_gpu.cu:73
@@ -1721,7 +1789,7 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
 #define PN2_FPS_RES(BS, PPT)                                                                   \
   case PPT:                                                                                    \
     hipLaunchKernelGGL((fps_resident_kernel<BS, PPT>), dim3(B), dim3(BS), 0, s, N, m, L, xyz,  \
-                       idxs);                                                                  \
+                       idxs, ordered_fail);                                                    \
     break;
   if (plan.mode == 2 || !fits) {
     hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(B), dim3(1024), 0, s, N, m, L, xyz, tail, idxs);
@@ -1750,6 +1818,43 @@ extern "C" int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *
   }
 #undef PN2_FPS_RES
   return pn2_check_launch();
+}
+}  // namespace
+
+// Sampling of clouds the caller believes to be in farthest-point ORDER (the centres of the SA level above): identical
+// results to pn2_furthest_point_sampling_ex for ANY input — the order is verified per cloud on the device (see
+// fps_order_m_kernel), a cloud that passes gets 0 .. m-1 without a single sampling round, one that fails takes the rounds.
+// Only plans with one workgroup per cloud and the points in registers take the shortcut (N <= 4096 or so: the lower SA
+// levels); other shapes run the plain call.  Workspace: pn2_fps_ordered_workspace_bytes.
+extern "C" size_t pn2_fps_ordered_workspace_bytes(int B, int N, int m) {
+  if (B <= 0 || N <= 0 || m <= 0) return 0;
+  return fps_align256(pn2_fps_workspace_bytes(B, N, m)) + fps_align256((size_t)B * m * sizeof(float)) + fps_align256((size_t)B * sizeof(int));
+}
+
+extern "C" int pn2_furthest_point_sampling_ordered(int B, int N, int m, const float *xyz, void *workspace,
+                                                   size_t workspace_bytes, int *idxs, int flags, void *stream) {
+  if (B < 0 || N < 0) return PN2_EINVAL;
+  if (flags & ~(PN2_FPS_FEW_CUS | PN2_FPS_FEWEST_CUS)) return PN2_EINVAL;
+  if (m <= 0 || B == 0) return PN2_OK;
+  if (N <= 0) return PN2_EINVAL;
+  if (!xyz || !idxs) return PN2_ENULL;
+  const FpsPlan plan = fps_plan(B, N, m, flags != 0, (flags & PN2_FPS_FEWEST_CUS) != 0);
+  const size_t base = fps_align256(pn2_fps_workspace_bytes(B, N, m));
+  // (m <= N: otherwise the samples are not a prefix; 16 m bytes of centres + M per workgroup in LDS)
+  if (plan.mode != 0 || m > N || m < 2 || (size_t)m * 16 > 60 * 1024)
+    return fps_launch(B, N, m, xyz, workspace, workspace_bytes < base ? workspace_bytes : base, idxs, flags, nullptr, stream);
+  if (!workspace) return PN2_ENULL;
+  if (workspace_bytes < pn2_fps_ordered_workspace_bytes(B, N, m)) return PN2_ENOSPC;
+  if (((uintptr_t)workspace & 255) != 0) return PN2_EINVAL;
+  float *Mk = (float *)((char *)workspace + base);
+  int *fail = (int *)((char *)Mk + fps_align256((size_t)B * m * sizeof(float)));
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned my = (unsigned)((m + 255) / 256), ny = (unsigned)((N + 255) / 256);
+  hipLaunchKernelGGL(fps_order_m_kernel, dim3((unsigned)B, my), dim3(256), (size_t)(3 * (m < 256 * (int)my ? m : 256 * my)) * sizeof(float), s, N, m,
+                     xyz, Mk, fail);
+  hipLaunchKernelGGL(fps_order_check_kernel, dim3((unsigned)B, ny), dim3(256), (size_t)4 * m * sizeof(float), s, N, m, xyz,
+                     (const float *)Mk, fail);
+  return fps_launch(B, N, m, xyz, workspace, base, idxs, flags, fail, stream);
 }
 
 // Byte offset of the int32 status word inside the workspace of a (B, N, m) call, or -1 when the plan has no

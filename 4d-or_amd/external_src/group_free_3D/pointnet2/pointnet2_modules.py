@@ -45,10 +45,7 @@ class PointnetSAModuleVotes(nn.Module):
         stream while the current batch trains (see Pointnet2Backbone.precompute_geometry).
         `inverse_index`: this level's features will need a gradient — also build the inverse of a crowded
         neighbourhood index (per-point sum instead of atomics in the backward, csrc/group_csr.hip)."""
-        if inds is None:
-            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-        new_xyz = pointnet2_utils.gather_operation(
-            xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        inds, new_xyz = pointnet2_utils.sample_centres(xyz, self.npoint, inds)
         # `feats_rows` (B,N,C): this level's input features are data (input colours: no gradient) -> the query kernel emits
         # the grouped rows as well where it covers them (pn2_ball_query_group), next to idx
         rows = None
@@ -83,14 +80,13 @@ class PointnetSAModuleVotes(nn.Module):
                                      rows=geometry.get("rows"))
             out = (geometry["new_xyz"], pointnet2_utils.rows_to_channels(rows), geometry["inds"])
             return out + (geometry.get("unique_cnt"),) if self.ret_unique_cnt else out
-        if inds is None:
-            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-        else:
+        if inds is not None:
             assert inds.shape[1] == self.npoint
         new_xyz = None
         if self.npoint is not None:
-            new_xyz = pointnet2_utils.gather_operation(
-                xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+            inds, new_xyz = pointnet2_utils.sample_centres(xyz, self.npoint, inds)
+        elif inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
 
         if self.npoint is not None and _pm._rows_path_ok(xyz, features):
             feats_rows = pointnet2_utils.as_rows(features)

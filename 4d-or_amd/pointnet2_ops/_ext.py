@@ -38,8 +38,8 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.pn2_abi_version.restype = ctypes.c_int
-if int(_lib.pn2_abi_version()) != 6:
-    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 6: "
+if int(_lib.pn2_abi_version()) != 7:
+    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 7: "
                       f"rebuild it (`make -C {os.path.join(_PKG_DIR, 'csrc')}`)")
 
 _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -49,6 +49,7 @@ _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_f
 _SIGNATURES = {
     "pn2_furthest_point_sampling": [_c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp],
     "pn2_furthest_point_sampling_ex": [_c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp, _c_int, _c_vp],
+    "pn2_furthest_point_sampling_ordered": [_c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp, _c_int, _c_vp],
     "pn2_gather_points": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_gather_points_grad": [_c_int] * 4 + [_c_vp] * 4,
     "pn2_ball_query": [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -199,6 +200,8 @@ _lib.pn2_fps_get_multi.argtypes = []
 _lib.pn2_fps_get_multi.restype = _c_int
 if os.environ.get("PN2_FPS_MULTI") == "0":           # measurement switch: one sample per cluster hand-off (round 3)
     _lib.pn2_fps_set_multi(0)
+_lib.pn2_fps_ordered_workspace_bytes.argtypes = [_c_int, _c_int, _c_int]
+_lib.pn2_fps_ordered_workspace_bytes.restype = _c_sz
 _lib.pn2_gcn_fused_supported.argtypes = [_c_int, _c_int, _c_int, _c_int]
 _lib.pn2_gcn_fused_supported.restype = _c_int
 _lib.pn2_gcn_layer_backward_workspace_bytes.argtypes = [ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_int, _c_int]
@@ -227,10 +230,10 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 #: the header revision this binding was written against: a stale prebuilt libpn2_hip.so fails here with a version
 #: error instead of an AttributeError on the first missing symbol
-EXPECTED_ABI_VERSION = 6
+EXPECTED_ABI_VERSION = 7
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
-                                               "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_gcn_fused_supported", "pn2_gcn_layer_backward_workspace_bytes", "pn2_group_lift_rows_grad_seg_workspace_bytes",
+                                               "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_fps_ordered_workspace_bytes", "pn2_gcn_fused_supported", "pn2_gcn_layer_backward_workspace_bytes", "pn2_group_lift_rows_grad_seg_workspace_bytes",
                                                "pn2_event_create", "pn2_event_record", "pn2_event_elapsed_ms", "pn2_event_destroy",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
@@ -404,13 +407,28 @@ def background_geometry(fewest=False):
 
 
 # ------------------------------------------------------------- the nine reference ops
-def furthest_point_sampling(points, nsamples):
-    """(B,N,3) f32 -> (B,nsamples) i32.  EXT/src/sampling.cpp:66-87."""
+#: pn2_furthest_point_sampling_ordered for clouds tagged as a sampling order (measurement switch; results never depend on it)
+FPS_ORDERED = os.environ.get("PN2_FPS_ORDERED") != "0"
+
+
+def furthest_point_sampling(points, nsamples, ordered=False):
+    """(B,N,3) f32 -> (B,nsamples) i32.  EXT/src/sampling.cpp:66-87.  `ordered`: the caller believes the clouds to be in
+    farthest-point order already (the centres of the SA level above) — verified on the device, identical results either way
+    (include/pn2_hip.h: pn2_furthest_point_sampling_ordered)."""
     _f32(points, "points")
     _same_device((points, "points"))
     B, N = points.size(0), points.size(1)
     nsamples = int(nsamples)
     out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
+    if ordered and FPS_ORDERED and 2 <= nsamples <= N and B > 0:
+        ws_bytes = int(_lib.pn2_fps_ordered_workspace_bytes(B, N, nsamples))
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=points.device)
+        _call("pn2_furthest_point_sampling_ordered", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
+              int(getattr(_sched, "few_cus", 0) or 0), alg_bytes=B * (12 * N + 4 * nsamples), label="pn2_furthest_point_sampling")
+        off = int(_lib.pn2_fps_status_offset(B, N, nsamples))
+        if off >= 0:
+            torch._assert_async(ws[off // 4:off // 4 + 1].view(torch.int32) == 0)
+        return out
     ws_bytes = int(_lib.pn2_fps_workspace_bytes(B, N, nsamples))
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=points.device) if ws_bytes else None
     if getattr(_sched, "few_cus", False):

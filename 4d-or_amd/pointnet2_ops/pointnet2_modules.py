@@ -261,9 +261,7 @@ class _PointnetSAModuleBase(nn.Module):
     def _sample(self, xyz: torch.Tensor) -> Optional[torch.Tensor]:
         if self.npoint is None:
             return None
-        sel = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-        picked = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), sel)
-        return picked.transpose(1, 2).contiguous()
+        return pointnet2_utils.sample_centres(xyz, self.npoint)[1]
 
     def sample_and_query(self, xyz: torch.Tensor, inverse_index: bool = False, feats_rows: Optional[torch.Tensor] = None):
         """The data-only part of the module (no parameters, no features): sampled centres and the ball-query

@@ -26,7 +26,7 @@ from torch.autograd import Function
 from pointnet2_ops import _ext
 
 __all__ = [
-    "FurthestPointSampling", "furthest_point_sample", "GatherOperation", "gather_operation",
+    "FurthestPointSampling", "furthest_point_sample", "sample_centres", "GatherOperation", "gather_operation",
     "ThreeNN", "three_nn", "ThreeInterpolate", "three_interpolate", "GroupingOperation",
     "grouping_operation", "BallQuery", "ball_query", "QueryAndGroup", "GroupAll",
     "group_concat_rows", "rows_max", "three_interpolate_rows", "as_rows", "rows_to_channels",
@@ -51,8 +51,13 @@ class FurthestPointSampling(Function):
     """xyz (B,N,3) -> (B,npoint) int32 indices; not differentiable."""
 
     @staticmethod
-    def forward(ctx, xyz, npoint):
-        sel = _ext.furthest_point_sampling(xyz, npoint)
+    def forward(ctx, xyz, npoint, ordered=False):
+        """`ordered`: the clouds are believed to be in farthest-point order (centres of the SA level above): the HIP
+        backend verifies that on the device and skips the sampling rounds where it holds — identical results."""
+        if ordered and getattr(_ext, "FPS_ORDERED", False):
+            sel = _ext.furthest_point_sampling(xyz, npoint, ordered=True)
+        else:
+            sel = _ext.furthest_point_sampling(xyz, npoint)
         ctx.mark_non_differentiable(sel)
         return sel
 
@@ -62,6 +67,21 @@ class FurthestPointSampling(Function):
 
 
 furthest_point_sample = FurthestPointSampling.apply
+
+
+def sample_centres(xyz, npoint, inds=None):
+    """The centre selection of an SA level (pointnet2_modules.py:38-48): -> (inds (B,npoint) i32, new_xyz (B,npoint,3)).
+    Centres sampled HERE come out in the order the sampling picked them and are tagged as such; a level that samples from
+    tagged centres tells the kernel (`ordered`: sampling a sampling order returns 0 .. npoint-1 unless a tie or a
+    degenerate round intervenes — verified on the device, identical results; include/pn2_hip.h).  Caller-provided `inds`
+    carry no such promise."""
+    sampled = inds is None
+    if sampled:
+        inds = furthest_point_sample(xyz, npoint, bool(getattr(xyz, "_pn2_fps_order", False)))
+    new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    if sampled:
+        new_xyz._pn2_fps_order = True
+    return inds, new_xyz
 
 
 class GatherOperation(Function):

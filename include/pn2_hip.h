@@ -79,6 +79,19 @@ int pn2_furthest_point_sampling(int B, int N, int m, const float *xyz,
 int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *xyz,
                                    void *workspace, size_t workspace_bytes,
                                    int *idxs, int flags, void *stream);
+/* Sampling of clouds the caller believes to be in farthest-point ORDER already — the centres of the SA level above, which
+ * pointnet2_modules.py:38-48 stores in the order its own sampling picked them.  Sampling m points from such a cloud returns
+ * 0 .. m-1 (point k was the farthest of ALL original points from the first k, so it is the farthest of the subset) unless a
+ * tie or a degenerate round (no candidate, NaN centre, duplicates) intervenes.  The entry point VERIFIES the order per
+ * cloud on the device with the kernel's own arithmetic (every point replays its running distance against the first m - 1
+ * centres and must stay strictly below the picked point's at every round: no barriers, ~35 us for the three lower levels
+ * of the headline against 1.2 ms of sampling rounds); a cloud that passes gets 0 .. m-1, one that fails takes the rounds —
+ * results identical to pn2_furthest_point_sampling_ex for ANY input.  Only shapes whose plan is one workgroup per cloud
+ * with the points in registers take the shortcut; the rest run the plain call.  workspace: 256-byte aligned,
+ * pn2_fps_ordered_workspace_bytes(B, N, m) bytes. */
+size_t pn2_fps_ordered_workspace_bytes(int B, int N, int m);
+int pn2_furthest_point_sampling_ordered(int B, int N, int m, const float *xyz, void *workspace, size_t workspace_bytes,
+                                        int *idxs, int flags, void *stream);
 
 /* Multi-workgroup ("cluster") FPS variants spin on their peers with BOUNDED waits.  A launch is only admitted when
  * the occupancy the runtime reports for the kernel covers the whole grid on the current device (otherwise the

