@@ -1826,6 +1826,8 @@ int fps_launch(int B, int N, int m, const float *xyz, void *workspace, size_t wo
 // fps_order_m_kernel), a cloud that passes gets 0 .. m-1 without a single sampling round, one that fails takes the rounds.
 // Only plans with one workgroup per cloud and the points in registers take the shortcut (N <= 4096 or so: the lower SA
 // levels); other shapes run the plain call.  Workspace: pn2_fps_ordered_workspace_bytes.
+namespace { constexpr int kFpsOrderedMinSamples = 256; }
+
 extern "C" size_t pn2_fps_ordered_workspace_bytes(int B, int N, int m) {
   if (B <= 0 || N <= 0 || m <= 0) return 0;
   return fps_align256(pn2_fps_workspace_bytes(B, N, m)) + fps_align256((size_t)B * m * sizeof(float)) + fps_align256((size_t)B * sizeof(int));
@@ -1841,7 +1843,9 @@ extern "C" int pn2_furthest_point_sampling_ordered(int B, int N, int m, const fl
   const FpsPlan plan = fps_plan(B, N, m, flags != 0, (flags & PN2_FPS_FEWEST_CUS) != 0);
   const size_t base = fps_align256(pn2_fps_workspace_bytes(B, N, m));
   // (m <= N: otherwise the samples are not a prefix; 16 m bytes of centres + M per workgroup in LDS)
-  if (plan.mode != 0 || m > N || m < 2 || (size_t)m * 16 > 60 * 1024)
+  // (fewer than 256 samples: the ~100 rounds cost less than the two verification launches do on a host-bound step —
+  // scene-graph encoders, 128 of 512 points: 1 scan/step 140-147 scans/s plain, 125-139 verified)
+  if (plan.mode != 0 || m > N || m < kFpsOrderedMinSamples || (size_t)m * 16 > 60 * 1024)
     return fps_launch(B, N, m, xyz, workspace, workspace_bytes < base ? workspace_bytes : base, idxs, flags, nullptr, stream);
   if (!workspace) return PN2_ENULL;
   if (workspace_bytes < pn2_fps_ordered_workspace_bytes(B, N, m)) return PN2_ENOSPC;

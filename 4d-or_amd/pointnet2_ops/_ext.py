@@ -409,6 +409,8 @@ def background_geometry(fewest=False):
 # ------------------------------------------------------------- the nine reference ops
 #: pn2_furthest_point_sampling_ordered for clouds tagged as a sampling order (measurement switch; results never depend on it)
 FPS_ORDERED = os.environ.get("PN2_FPS_ORDERED") != "0"
+#: ... from this many samples on (below, the sampling rounds cost less than the verification launches: csrc/fps.hip)
+FPS_ORDERED_MIN_SAMPLES = 256
 
 
 def furthest_point_sampling(points, nsamples, ordered=False):
@@ -420,7 +422,7 @@ def furthest_point_sampling(points, nsamples, ordered=False):
     B, N = points.size(0), points.size(1)
     nsamples = int(nsamples)
     out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
-    if ordered and FPS_ORDERED and 2 <= nsamples <= N and B > 0:
+    if ordered and FPS_ORDERED and FPS_ORDERED_MIN_SAMPLES <= nsamples <= N and B > 0:
         ws_bytes = int(_lib.pn2_fps_ordered_workspace_bytes(B, N, nsamples))
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=points.device)
         _call("pn2_furthest_point_sampling_ordered", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),

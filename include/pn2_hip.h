@@ -87,7 +87,8 @@ int pn2_furthest_point_sampling_ex(int B, int N, int m, const float *xyz,
  * centres and must stay strictly below the picked point's at every round: no barriers, ~35 us for the three lower levels
  * of the headline against 1.2 ms of sampling rounds); a cloud that passes gets 0 .. m-1, one that fails takes the rounds —
  * results identical to pn2_furthest_point_sampling_ex for ANY input.  Only shapes whose plan is one workgroup per cloud
- * with the points in registers take the shortcut; the rest run the plain call.  workspace: 256-byte aligned,
+ * with the points in registers, and at least 256 samples (below, the rounds are cheaper than the verification launches),
+ * take the shortcut; the rest run the plain call.  workspace: 256-byte aligned,
  * pn2_fps_ordered_workspace_bytes(B, N, m) bytes. */
 size_t pn2_fps_ordered_workspace_bytes(int B, int N, int m);
 int pn2_furthest_point_sampling_ordered(int B, int N, int m, const float *xyz, void *workspace, size_t workspace_bytes,
