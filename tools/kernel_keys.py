@@ -20,7 +20,7 @@ ENTRY_OF_FAMILY = {
     "bn_relu_rows_max_bf16_v8_kernel": "pn2_bn_relu_rows_max_bf16", "group_concat_rows_bf16_wide8_kernel": "pn2_group_concat_rows_bf16",
     "bq_fused_group_kernel": "pn2_ball_query_group", "bq_slab_query_kernel": "pn2_ball_query", "bq_slab_build_kernel": "pn2_ball_query",
     "fps_multi_kernel": "pn2_furthest_point_sampling", "fps_coop_kernel": "pn2_furthest_point_sampling",
-    "fps_resident_kernel": "pn2_furthest_point_sampling", "fps_bucket_kernel": "pn2_furthest_point_sampling",
+    "fps_resident_kernel": "pn2_furthest_point_sampling", "fps_order_m_kernel": "pn2_furthest_point_sampling", "fps_order_check_kernel": "pn2_furthest_point_sampling", "fps_bucket_kernel": "pn2_furthest_point_sampling",
     "gcn_linear_kernel": "pn2_gcn_linear", "gcn_bn_bwd_kernel": "pn2_gcn_linear_grad_w", "gcn_wgrad_kernel": "pn2_gcn_linear_grad_w",
     "gcn_linear_grad_x_kernel": "pn2_gcn_linear_grad_x",
 }
