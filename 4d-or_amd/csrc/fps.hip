@@ -124,10 +124,12 @@ __global__ __launch_bounds__(BS) void fps_resident_kernel(int N, int m, int L,
 
   const int b = blockIdx.x;
   const int t = threadIdx.x;
-  // pn2_furthest_point_sampling_ordered: this cloud was verified to be in sampling order — its samples are 0 .. m - 1
-  if (ordered_fail && ordered_fail[b] == 0) {
-    for (int k = t; k < m; k += BS) idxs[(size_t)b * m + k] = k;
-    return;
+  // pn2_furthest_point_sampling_ordered: rounds 1 .. r0 - 1 of this cloud were verified to pick points 1 .. r0 - 1 (r0 >= m: the
+  // whole cloud is a sampling order — its samples are 0 .. m - 1 and no round runs)
+  const int r0 = ordered_fail ? (ordered_fail[b] < m ? ordered_fail[b] : m) : 1;
+  if (r0 > 1) {
+    for (int k = t; k < r0; k += BS) idxs[(size_t)b * m + k] = k;
+    if (r0 >= m) return;
   }
   const int lane = pn2_lane();
   const int wave = t >> 6;
@@ -165,8 +167,18 @@ __global__ __launch_bounds__(BS) void fps_resident_kernel(int N, int m, int L,
   const float p0x = P[0], p0y = P[1], p0z = P[2];
   float ox = p0x, oy = p0y, oz = p0z;  // old = 0
   if (t == 0) out[0] = 0;
+  if (r0 > 1) {
+    // the state of round r0: running distances against the verified centres 0 .. r0 - 2 (no barrier: every point on its
+    // own), the centre of round r0 is sample r0 - 1
+    for (int c = 0; c + 1 < r0; ++c) {
+      const float cx = P[(size_t)c * 3], cy = P[(size_t)c * 3 + 1], cz = P[(size_t)c * 3 + 2];      // (wave-uniform address)
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) td[i] = fps_min(pn2_sq3(px[i] - cx, py[i] - cy, pz[i] - cz), td[i]);
+    }
+    ox = P[(size_t)(r0 - 1) * 3]; oy = P[(size_t)(r0 - 1) * 3 + 1]; oz = P[(size_t)(r0 - 1) * 3 + 2];
+  }
 
-  for (int j = 1; j < m; ++j) {
+  for (int j = r0; j < m; ++j) {
     float best = -1.f;
     int bi = 0;
 #pragma unroll
@@ -1565,16 +1577,24 @@ __global__ __launch_bounds__(256) void fps_order_m_kernel(int N, int m, const fl
   const float *P = xyz + (size_t)b * N * 3;
   const int k = blockIdx.y * 256 + t, kmax = min(m, (int)(blockIdx.y + 1) * 256);
   for (int i = t; i < kmax; i += 256) { cen[i] = P[(size_t)i * 3]; cen[kmax + i] = P[(size_t)i * 3 + 1]; cen[2 * kmax + i] = P[(size_t)i * 3 + 2]; }
-  if (blockIdx.y == 0 && t == 0) fail[b] = 0;
+  if (blockIdx.y == 0 && t == 0) fail[b] = m;             // first round that is NOT verified (m: none)
   __syncthreads();
   if (k >= m) return;
   const float x = cen[k], y = cen[kmax + k], z = cen[2 * kmax + k];
-  float td = !((double)pn2_sq3(x, y, z) <= 1e-3) ? 1e10f : -1.f;          // (EXT/src/sampling_gpu.cu:100-101)
-  for (int i = 0; i < k; ++i) td = fps_min(pn2_sq3(x - cen[i], y - cen[kmax + i], z - cen[2 * kmax + i]), td);
-  Mk[(size_t)b * m + k] = td;
+  const float init = !((double)pn2_sq3(x, y, z) <= 1e-3) ? 1e10f : -1.f;  // (EXT/src/sampling_gpu.cu:100-101)
+  // min over the centres 0 .. k-1: four independent chains (the minimum does not depend on the order — v_min skips a NaN
+  // distance wherever it stands, and a skipped point's -1 is below every distance)
+  float td[4] = {init, init, init, init};
+  int i = 0;
+  for (; i + 4 <= k; i += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) td[u] = fps_min(pn2_sq3(x - cen[i + u], y - cen[kmax + i + u], z - cen[2 * kmax + i + u]), td[u]);
+  }
+  for (; i < k; ++i) td[0] = fps_min(pn2_sq3(x - cen[i], y - cen[kmax + i], z - cen[2 * kmax + i]), td[0]);
+  Mk[(size_t)b * m + k] = fps_min(fps_min(td[0], td[1]), fps_min(td[2], td[3]));
 }
 
-__global__ __launch_bounds__(256) void fps_order_check_kernel(int N, int m, const float *__restrict__ xyz,
+__global__ __launch_bounds__(256) void fps_order_check_kernel(int N, int m, int L, const float *__restrict__ xyz,
                                                              const float *__restrict__ Mk, int *__restrict__ fail) {
   extern __shared__ float cen[];                          // [3][m] centres | [m] M
   const int b = blockIdx.x, t = threadIdx.x;
@@ -1586,16 +1606,39 @@ __global__ __launch_bounds__(256) void fps_order_check_kernel(int N, int m, cons
   }
   __syncthreads();
   const int j = blockIdx.y * 256 + t;
-  bool bad = false;
+  int first = m;                                            // first round this point would (or might) win against point k
   if (j < N) {
     const float x = P[(size_t)j * 3], y = P[(size_t)j * 3 + 1], z = P[(size_t)j * 3 + 2];
     float td = !((double)pn2_sq3(x, y, z) <= 1e-3) ? 1e10f : -1.f;
-    for (int k = 1; k < m; ++k) {                           // round k: the centre is sample k - 1, the pick must be point k
-      td = fps_min(pn2_sq3(x - cen[k - 1], y - cen[m + k - 1], z - cen[2 * m + k - 1]), td);
-      bad |= (j != k) & !(td < mk[k]);
+    // round k: the centre is sample k - 1, the pick must be point k.  Point k wins round k against point j iff its running
+    // distance is larger, or equal with the smaller rank (the order of the sampling kernel's key on ties; a negative M[k] —
+    // point k skipped — can never be picked).  Eight rounds per step: their distances and M are independent loads /
+    // arithmetic, only the eight v_min + compares form a chain; ties and failures take a branch
+    auto round = [&](int k, float d, float mkk) {
+      td = fps_min(d, td);
+      if (!(td < mkk)) {
+        const bool loses = td == mkk && mkk >= 0.f && fps_rank((unsigned)j, L) > fps_rank((unsigned)k, L);
+        if (j != k && !loses && first == m) first = k;
+      }
+    };
+    int k = 1;
+    for (; k + 8 <= m; k += 8) {
+      float d[8], mv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        d[u] = pn2_sq3(x - cen[k - 1 + u], y - cen[m + k - 1 + u], z - cen[2 * m + k - 1 + u]);
+        mv[u] = mk[k + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) round(k + u, d[u], mv[u]);
     }
+    for (; k < m; ++k) round(k, pn2_sq3(x - cen[k - 1], y - cen[m + k - 1], z - cen[2 * m + k - 1]), mk[k]);
   }
-  if (__ballot(bad) != 0ull && pn2_lane() == 0) atomicOr(fail + b, 1);
+  // (wave minimum, one atomic per wave that saw a failure)
+  int wmin = first;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmin = min(wmin, __shfl_xor(wmin, o));
+  if (wmin < m && pn2_lane() == 0) atomicMin(fail + b, wmin);
 }
 
 int fps_launch(int B, int N, int m, const float *xyz, void *workspace, size_t workspace_bytes, int *idxs, int flags,
@@ -1856,7 +1899,10 @@ extern "C" int pn2_furthest_point_sampling_ordered(int B, int N, int m, const fl
   const unsigned my = (unsigned)((m + 255) / 256), ny = (unsigned)((N + 255) / 256);
   hipLaunchKernelGGL(fps_order_m_kernel, dim3((unsigned)B, my), dim3(256), (size_t)(3 * (m < 256 * (int)my ? m : 256 * my)) * sizeof(float), s, N, m,
                      xyz, Mk, fail);
-  hipLaunchKernelGGL(fps_order_check_kernel, dim3((unsigned)B, ny), dim3(256), (size_t)4 * m * sizeof(float), s, N, m, xyz,
+  const int bs = ref_opt_n_threads(N);
+  int L = 0;
+  while ((1 << L) < bs) ++L;
+  hipLaunchKernelGGL(fps_order_check_kernel, dim3((unsigned)B, ny), dim3(256), (size_t)4 * m * sizeof(float), s, N, m, L, xyz,
                      (const float *)Mk, fail);
   return fps_launch(B, N, m, xyz, workspace, base, idxs, flags, fail, stream);
 }
