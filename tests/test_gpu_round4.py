@@ -742,3 +742,45 @@ def test_sa_levels_pass_the_sampling_order_down_and_the_backbone_is_unchanged():
         if k in a:
             assert torch.equal(a[k], b[k]), k
     assert torch.equal(a["sa2_inds"].cpu(), torch.arange(1024, dtype=a["sa2_inds"].dtype).expand(2, -1))      # (what the identity says)
+
+
+def test_ordered_sampling_resumes_the_rounds_where_an_exact_tie_goes_the_other_way():
+    """Random clouds DO have exact fp32 ties between running distances (about 2 % of 2048-point sampling orders within 1024
+    rounds): where the other point wins, the samples deviate from 0 .. m-1 from that round on.  The ordered entry point
+    must verify the rounds before it, resume the sampling rounds there and return the plain kernel's indices — checked on a
+    batch that contains such a cloud (found by its first unverified round in the workspace), against the oracle for it."""
+    from pointnet2_ops import _ext
+    lib = _ext._lib
+    found = None
+    for seed in range(6):
+        g = torch.Generator().manual_seed(seed)
+        p = torch.randn(32, 50000, 3, generator=g)
+        p = (p / p.norm(dim=2, keepdim=True) * torch.rand(32, 50000, 1, generator=g).pow(1 / 3)).cuda()
+        order = torch.gather(p, 1, _ext.furthest_point_sampling(p, 2048).long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        B, n, m = 32, 2048, 1024
+        nb = int(lib.pn2_fps_ordered_workspace_bytes(B, n, m))
+        ws = torch.zeros(nb // 4, dtype=torch.float32, device="cuda")
+        out = torch.zeros(B, m, dtype=torch.int32, device="cuda")
+        _ext._call("pn2_furthest_point_sampling_ordered", order, B, n, m, order.data_ptr(), ws.data_ptr(), nb, out.data_ptr(), 0)
+        plain = _ext.furthest_point_sampling(order, m)
+        assert torch.equal(out, plain), seed
+        base = (int(lib.pn2_fps_workspace_bytes(B, n, m)) + 255) // 256 * 256
+        off = (base + (B * m * 4 + 255) // 256 * 256) // 4
+        r0 = ws.view(torch.int32)[off:off + B].cpu()
+        ar = torch.arange(m, dtype=torch.int32)
+        for b in range(B):
+            dev = (plain[b].cpu() != ar).nonzero()
+            if int(r0[b]) < m:
+                # the first unverified round is where (or before) the samples leave the prefix; verified rounds are the prefix
+                assert dev.numel() == 0 or int(dev[0]) >= int(r0[b]), (seed, b)
+                if dev.numel() and 1 < int(r0[b]):
+                    found = (seed, b, int(r0[b]), order[b:b + 1].cpu())
+            else:
+                assert dev.numel() == 0, (seed, b)
+        if found:
+            break
+    assert found is not None, "no cloud with a deviating round in six batches (expected ~2 % of the clouds)"
+    seed, b, r, cloud = found
+    want = oracle_ext.OracleRowsExt.furthest_point_sampling(cloud, 1024)
+    got = _ext.furthest_point_sampling(cloud.cuda(), 1024, ordered=True)
+    assert torch.equal(got.cpu(), want) and not torch.equal(want[0], torch.arange(1024, dtype=want.dtype))
