@@ -1909,11 +1909,14 @@ extern "C" int pn2_furthest_point_sampling_ordered(int B, int N, int m, const fl
 
 // Byte offset of the int32 status word inside the workspace of a (B, N, m) call, or -1 when the plan has no
 // inter-workgroup waits.  0 after a clean run, 1 when a bounded wait expired (the remaining indices are then 0).
-extern "C" long long pn2_fps_status_offset(int B, int N, int m) {
-  if (B <= 0 || N <= 0 || m <= 1) return -1;
-  const FpsPlan p = fps_plan(B, N, m);
+extern "C" long long pn2_fps_status_offset_ex(int B, int N, int m, int flags) {
+  if (B <= 0 || N <= 0 || m <= 1 || (flags & ~(PN2_FPS_FEW_CUS | PN2_FPS_FEWEST_CUS))) return -1;
+  // the plan of the call that was made WITH these flags: the flag-less plan of the same shape can be a cluster mode where
+  // the flagged one is resident / streaming (no status word is written, the bytes there are workspace: ADVICE r04)
+  const FpsPlan p = fps_plan(B, N, m, flags != 0, (flags & PN2_FPS_FEWEST_CUS) != 0);
   return (p.mode == 1 || p.mode == 3 || p.mode == 5) ? (long long)((size_t)B * kCoopCloudBytes) : -1;
 }
+extern "C" long long pn2_fps_status_offset(int B, int N, int m) { return pn2_fps_status_offset_ex(B, N, m, 0); }
 
 // Test hook: status word of the last cooperative launch that used `workspace`
 // (0 = ok, 1 = a bounded spin expired).  Host-synchronous; not on the hot path.

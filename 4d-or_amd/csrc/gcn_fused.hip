@@ -134,6 +134,18 @@ __global__ __launch_bounds__(512) void gcn_linear_kernel(const GcnFwdArgs a) {
   const long long r0 = a.ptr[s];
   const int Rs = (int)(a.ptr[s + 1] - r0);
   const int K = a.K, Kh = K >> 1;
+  if (Rs > kGcnRows) {
+    // A scan this workgroup cannot cover (pn2_gcn_fused_supported says so for callers that know their sizes on the host;
+    // the pointer table lives on the device, so the C entry cannot check it): every result row of the scan is NaN instead
+    // of statistics over its first 128 rows and uninitialised memory behind them.  Block-uniform exit.
+    const float qnan = __builtin_nanf("");
+    for (int i = threadIdx.x; i < Rs * 32; i += blockDim.x) {
+      const size_t o = (size_t)(r0 + (i >> 5)) * a.N + c0 + (i & 31);
+      a.Out[o] = qnan;
+      if (BN) a.Ypre[o] = qnan;
+    }
+    return;
+  }
   const GcnSplit sp = gcn_split(Rs, wv, Kh);
   const int w = sp.tile;                                           // row tile of this wave
   const int row = 32 * w + c;
@@ -253,6 +265,10 @@ __global__ __launch_bounds__(256) void gcn_bn_bwd_kernel(const GcnGradWArgs a) {
   const int Rs = (int)(a.ptr[s + 1] - r0);
   const int N = a.N, col = c0 + c;
   if (Rs <= 0) return;
+  if (Rs > kGcnRows) {                                             // see gcn_linear_kernel: NaN, not a silent partial result
+    for (int i = threadIdx.x; i < Rs * 32; i += blockDim.x) a.Gz[(size_t)(r0 + (i >> 5)) * N + c0 + (i & 31)] = __builtin_nanf("");
+    return;
+  }
   if constexpr (GMODE == 1) {
     for (int i = threadIdx.x; i < kGcnRows; i += 256) s_dst[i] = i < Rs ? (int)a.t.dst[r0 + i] : 0;
     __syncthreads();

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from pointnet2_ops import pointnet2_utils
+from pointnet2_ops.pointnet2_modules import confirm_rows, rows_source
 from external_src.group_free_3D.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 
 
@@ -60,6 +61,8 @@ class Pointnet2Backbone(nn.Module):
                 # out of the ball query itself (pn2_ball_query_group) here, off the step's critical path
                 g = getattr(self, f"sa{i}").sample_and_query(levels[-1], inverse_index=i > 1,
                                                              feats_rows=feats0 if i == 1 else None)
+                if g.get("rows_src") is not None:
+                    g["rows_src"] = rows_source(pointcloud)     # (the rows come from THIS cloud's colour columns)
                 geo["sa"].append(g)
                 levels.append(g["new_xyz"])
             geo["fp"].append(self.fp1.interpolation(levels[3], levels[4]))
@@ -72,6 +75,8 @@ class Pointnet2Backbone(nn.Module):
         `geometry` = precompute_geometry(pointcloud) (optional; identical results)."""
         end_points = end_points or {}
         xyz, features = self._break_up_pc(pointcloud)
+        if geometry is not None:
+            geometry = dict(geometry, sa=confirm_rows(geometry["sa"], pointcloud))
         for i in (1, 2, 3, 4):
             xyz, features, inds = getattr(self, f"sa{i}")(
                 xyz, features, geometry=None if geometry is None else geometry["sa"][i - 1])

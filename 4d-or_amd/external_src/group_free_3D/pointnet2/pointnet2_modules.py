@@ -57,6 +57,7 @@ class PointnetSAModuleVotes(nn.Module):
         # sample_uniformly / ret_unique_cnt: the count belongs to THIS query (the grouper's last_unique_cnt is overwritten
         # by the next call — a geometry computed ahead of time must carry its own)
         return {"inds": inds, "new_xyz": new_xyz, "idx": idx, "inv": inv, "rows": rows, "n_src": xyz.size(1),
+                "rows_src": _pm.rows_source(feats_rows) if rows is not None else None,
                 "unique_cnt": getattr(self.grouper, "last_unique_cnt", None) if self.ret_unique_cnt else None}
 
     def _check_geometry(self, xyz, geometry):
@@ -75,9 +76,13 @@ class PointnetSAModuleVotes(nn.Module):
         `geometry` = result of sample_and_query(xyz) computed earlier (optional)."""
         if geometry is not None and self.pooling == "max" and _pm._rows_path_ok(xyz, features):
             self._check_geometry(xyz, geometry)
+            feats_rows = pointnet2_utils.as_rows(features)
+            pre = geometry.get("rows")
+            if pre is not None and (not _pm.rows_still_valid(geometry, feats_rows)
+                                    or pre.numel() != geometry["idx"].numel() * pre.size(-1)):
+                pre = None       # gathered from another (or since modified) feature tensor: group the given one instead
             rows = _pm.sa_scale_rows(self.grouper, self.mlp_module, xyz, geometry["new_xyz"],
-                                     pointnet2_utils.as_rows(features), idx=geometry["idx"], inv=geometry.get("inv"),
-                                     rows=geometry.get("rows"))
+                                     feats_rows, idx=geometry["idx"], inv=geometry.get("inv"), rows=pre)
             out = (geometry["new_xyz"], pointnet2_utils.rows_to_channels(rows), geometry["inds"])
             return out + (geometry.get("unique_cnt"),) if self.ret_unique_cnt else out
         if inds is not None:

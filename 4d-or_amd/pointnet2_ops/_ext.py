@@ -38,8 +38,8 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.pn2_abi_version.restype = ctypes.c_int
-if int(_lib.pn2_abi_version()) != 7:
-    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 7: "
+if int(_lib.pn2_abi_version()) != 8:
+    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 8: "
                       f"rebuild it (`make -C {os.path.join(_PKG_DIR, 'csrc')}`)")
 
 _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -178,6 +178,8 @@ _lib.pn2_ball_query_group_workspace_bytes.argtypes = [_c_int, _c_int]
 _lib.pn2_ball_query_group_workspace_bytes.restype = _c_sz
 _lib.pn2_fps_status_offset.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_fps_status_offset.restype = ctypes.c_longlong
+_lib.pn2_fps_status_offset_ex.argtypes = [_c_int, _c_int, _c_int, _c_int]
+_lib.pn2_fps_status_offset_ex.restype = ctypes.c_longlong
 _lib.pn2_fps_set_plan_override.argtypes = [_c_int] * 5
 _lib.pn2_fps_set_plan_override.restype = _c_int
 _lib.pn2_event_create.argtypes = []
@@ -230,9 +232,9 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 #: the header revision this binding was written against: a stale prebuilt libpn2_hip.so fails here with a version
 #: error instead of an AttributeError on the first missing symbol
-EXPECTED_ABI_VERSION = 7
+EXPECTED_ABI_VERSION = 8
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
-                                               "pn2_fps_status_offset", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
+                                               "pn2_fps_status_offset", "pn2_fps_status_offset_ex", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
                                                "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_fps_ordered_workspace_bytes", "pn2_gcn_fused_supported", "pn2_gcn_layer_backward_workspace_bytes", "pn2_group_lift_rows_grad_seg_workspace_bytes",
                                                "pn2_event_create", "pn2_event_record", "pn2_event_elapsed_ms", "pn2_event_destroy",
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
@@ -422,12 +424,15 @@ def furthest_point_sampling(points, nsamples, ordered=False):
     B, N = points.size(0), points.size(1)
     nsamples = int(nsamples)
     out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
+    flags = int(getattr(_sched, "few_cus", 0) or 0)
     if ordered and FPS_ORDERED and FPS_ORDERED_MIN_SAMPLES <= nsamples <= N and B > 0:
         ws_bytes = int(_lib.pn2_fps_ordered_workspace_bytes(B, N, nsamples))
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=points.device)
         _call("pn2_furthest_point_sampling_ordered", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
-              int(getattr(_sched, "few_cus", 0) or 0), alg_bytes=B * (12 * N + 4 * nsamples), label="pn2_furthest_point_sampling")
-        off = int(_lib.pn2_fps_status_offset(B, N, nsamples))
+              flags, alg_bytes=B * (12 * N + 4 * nsamples), label="pn2_furthest_point_sampling")
+        # (only shapes whose plan — WITH these flags — is a cluster mode write a status word; the verified-order shortcut
+        # itself is a one-workgroup-per-cloud plan and has none)
+        off = int(_lib.pn2_fps_status_offset_ex(B, N, nsamples, flags))
         if off >= 0:
             torch._assert_async(ws[off // 4:off // 4 + 1].view(torch.int32) == 0)
         return out
@@ -439,7 +444,7 @@ def furthest_point_sampling(points, nsamples, ordered=False):
     else:
         _call("pn2_furthest_point_sampling", points, B, N, nsamples, _ptr(points), _ptr(ws), ws_bytes, _ptr(out),
               alg_bytes=B * (12 * N + 4 * nsamples))
-    off = int(_lib.pn2_fps_status_offset(B, N, nsamples)) if ws is not None else -1
+    off = int(_lib.pn2_fps_status_offset_ex(B, N, nsamples, flags)) if ws is not None else -1
     if off >= 0:
         # a bounded inter-workgroup wait of the cluster kernels expired (CU-masked stream, another process on the GPU):
         # the remaining indices are zeros.  Checked on the device, asynchronously, in stream order before any consumer.

@@ -93,18 +93,34 @@ def _bf16_ok(layers, ns) -> bool:
             and (not ns or layers[-1][0].out_channels % 2 == 0))
 
 
-_PARSED = {}        # id(module) -> (weak reference, parsed stack): a module's structure does not change between steps
+_PARSED = {}        # id(module) -> (weak reference, structural fingerprint, parsed stack)
+
+
+def _fingerprint(mlp: nn.Module):
+    """Identity of every direct child slot, two levels deep (a stack is Sequential(conv, bn, relu, ...) or a Sequential of
+    such blocks): replacing a layer — convert_sync_batchnorm, conv/bn folding, a swapped module — changes it."""
+    fp = []
+    for c in mlp._modules.values():
+        fp.append(id(c))
+        sub = getattr(c, "_modules", None)
+        if sub:
+            fp.extend(id(g) for g in sub.values())
+    return tuple(fp)
 
 
 def parse_stack(mlp: nn.Module) -> Optional[List[Tuple[nn.Conv2d, nn.modules.batchnorm._BatchNorm]]]:
     """Flatten `mlp` into [(conv1x1, bn), ...] if it is exactly (conv, bn, relu)*; else None.  Cached per module object (the
-    walk is ~20 us of Python, paid 20 times per one-scan step of the scene-graph model)."""
-    hit = _PARSED.get(id(mlp))
-    if hit is not None and hit[0]() is mlp:
-        return hit[1]
+    walk is ~20 us of Python, paid 20 times per one-scan step of the scene-graph model) under a fingerprint of the
+    container's children, so a stack whose layers were replaced after its first call is parsed again; entries of dead
+    modules are purged by the weak reference's callback (an id can be reused)."""
+    key = id(mlp)
+    fp = _fingerprint(mlp)
+    hit = _PARSED.get(key)
+    if hit is not None and hit[0]() is mlp and hit[1] == fp:
+        return hit[2]
     layers = _parse_stack(mlp)
     import weakref
-    _PARSED[id(mlp)] = (weakref.ref(mlp), layers)
+    _PARSED[key] = (weakref.ref(mlp, lambda _r, key=key: _PARSED.pop(key, None)), fp, layers)
     return layers
 
 

@@ -210,6 +210,63 @@ def _query_maybe_fused(grouper, xyz, new_xyz, feats_rows):
     return grouper.query(xyz, new_xyz), None
 
 
+class RowsSource:
+    """Identity of the tensor the pre-grouped `rows` of a geometry were gathered from: storage address, shape, device and
+    version counter (bumped by every in-place operation).  `forward` compares it with what it is actually given and
+    drops the rows on a mismatch — augmentation, dropout or another tensor between the prefetch and the forward would
+    otherwise be ignored silently.  An opaque object on purpose: nested python scalars of a batch are part
+    of a captured graph's signature (runtime/graphed_step.py), addresses must not be.
+
+    Two levels: a module-level `sample_and_query(feats_rows=...)` records the (B, N, C) feature rows themselves; a model's
+    `precompute_geometry(pointcloud)` slices its own copy of the feature columns, so it records the POINT CLOUD
+    (`rows_source(pointcloud)`) and its forward confirms the match (`confirm_rows`) before the levels run."""
+    __slots__ = ("ptr", "shape", "version", "device", "confirmed")
+
+    def __init__(self, t: torch.Tensor):
+        self.ptr, self.shape, self.version, self.device = t.data_ptr(), tuple(t.shape), t._version, t.device
+        self.confirmed = False
+
+    def matches(self, t: Optional[torch.Tensor]) -> bool:
+        return (t is not None and t.data_ptr() == self.ptr and tuple(t.shape) == self.shape
+                and t._version == self.version and t.device == self.device)
+
+
+def rows_source(t: Optional[torch.Tensor]) -> Optional[RowsSource]:
+    return None if t is None else RowsSource(t)
+
+
+def _capturing() -> bool:
+    # inside a stream capture the batch is GraphedTrainStep's static clone of ONE consistent batch (geometry included):
+    # addresses differ from the prefetch by construction, the pairing is the capture's own
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def rows_still_valid(geometry, feats_rows: Optional[torch.Tensor]) -> bool:
+    """True when the geometry's pre-grouped rows belong to the features this forward was given."""
+    tok = geometry.get("rows_src")
+    if tok is None:
+        return False
+    return tok.confirmed or tok.matches(feats_rows) or _capturing()
+
+
+def confirm_rows(geometry_levels, pointcloud: torch.Tensor):
+    """Model level: `geometry_levels` (list of per-level geometry dicts) computed by `precompute_geometry(pointcloud)`.
+    Levels whose rows were gathered from exactly this point cloud are marked confirmed; otherwise the rows are dropped
+    (the level groups the features it is given)."""
+    out = []
+    for g in geometry_levels:
+        tok = None if g is None else g.get("rows_src")
+        if tok is not None and not tok.confirmed:
+            if tok.matches(pointcloud) or _capturing():
+                ok = RowsSource(pointcloud)
+                ok.confirmed = True
+                g = dict(g, rows_src=ok)
+            else:
+                g = dict(g, rows=None, rows_src=None)
+        out.append(g)
+    return out
+
+
 def crowded_balls(grouper, n_src: int) -> bool:
     """Density rule shared with the ball query's cell-list switch (csrc/ball_query.hip), inverted: with N r^3 > 4 nsample
     nearly every slot of a neighbourhood is a genuine hit and each point is gathered many times — the regime where the
@@ -282,7 +339,8 @@ class _PointnetSAModuleBase(nn.Module):
             else:
                 idx.append(g.query(xyz, new_xyz)), rows.append(None)
         inv = build_inverse_indices(self.groupers, idx, xyz.size(1)) if inverse_index else [None] * len(idx)
-        return {"new_xyz": new_xyz, "idx": idx, "inv": inv, "rows": rows, "n_src": xyz.size(1)}
+        return {"new_xyz": new_xyz, "idx": idx, "inv": inv, "rows": rows, "n_src": xyz.size(1),
+                "rows_src": rows_source(feats_rows) if any(r is not None for r in rows) else None}
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor], geometry=None
                 ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
@@ -292,7 +350,7 @@ class _PointnetSAModuleBase(nn.Module):
         if geometry is not None and _rows_path_ok(xyz, features):
             self._check_geometry(xyz, geometry)
             return geometry["new_xyz"], self._forward_rows(xyz, geometry["new_xyz"], features, geometry["idx"],
-                                                           geometry.get("inv"), geometry.get("rows"))
+                                                           geometry.get("inv"), geometry.get("rows"), geometry)
         new_xyz = self._sample(xyz)
         if _rows_path_ok(xyz, features):
             return new_xyz, self._forward_rows(xyz, new_xyz, features)
@@ -330,9 +388,19 @@ class _PointnetSAModuleBase(nn.Module):
             if (i.dtype != torch.int32 or i.device != xyz.device or i.dim() != 3
                     or tuple(i.shape[:2]) != (B, self.npoint) or i.size(2) != g.nsample):
                 raise RuntimeError(f"geometry: idx must be int32 ({B}, {self.npoint}, {g.nsample}) on {xyz.device}")
+        rows = geometry.get("rows")
+        if rows is not None:
+            if len(rows) != len(idx):
+                raise RuntimeError("geometry: one pre-grouped rows tensor (or None) per scale expected")
+            for i, r in zip(idx, rows):
+                if r is not None and (i is None or r.device != xyz.device or r.dim() < 2
+                                      or r.numel() != i.numel() * r.size(-1)):
+                    raise RuntimeError("geometry: pre-grouped rows do not belong to these neighbourhoods")
 
-    def _forward_rows(self, xyz, new_xyz, features, idx=None, inv=None, rows=None):
+    def _forward_rows(self, xyz, new_xyz, features, idx=None, inv=None, rows=None, geometry=None):
         feats_rows = pointnet2_utils.as_rows(features)
+        if rows is not None and (geometry is None or not rows_still_valid(geometry, feats_rows)):
+            rows = None          # gathered from another (or since modified) feature tensor: group the given one instead
         B = xyz.size(0)
         pooled = []
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):

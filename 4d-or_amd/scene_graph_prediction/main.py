@@ -196,6 +196,10 @@ def main(argv=None):
         torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
     device = torch.device(args.device if args.device != "cuda" else f"cuda:{torch.cuda.current_device()}")
     rank, world = setup_distributed(device) if args.mode == "train" else (0, 1)
+    if device.type == "cuda":
+        # one process per GPU: the enqueueing thread next to its GPU's NUMA node (runtime/affinity.py; PN2_PIN_NUMA=0: off)
+        from runtime.affinity import pin_to_gpu_numa
+        pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if args.mode == "evaluate" and (args.cache_dir or args.gt):
         evaluate_split(config, args, device)
         return

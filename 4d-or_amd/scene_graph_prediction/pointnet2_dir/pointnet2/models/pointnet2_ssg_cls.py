@@ -10,7 +10,7 @@ file are out of scope (SURVEY.md §2 #16)."""
 import torch
 import torch.nn as nn
 
-from pointnet2_ops.pointnet2_modules import PointnetSAModule
+from pointnet2_ops.pointnet2_modules import PointnetSAModule, confirm_rows, rows_source
 
 
 class PointNet2ClassificationSSG(nn.Module):
@@ -47,6 +47,8 @@ class PointNet2ClassificationSSG(nn.Module):
         geo = []
         for k, sa in enumerate(self.SA_modules):
             g = sa.sample_and_query(xyz, inverse_index=k > 0, feats_rows=feats0 if k == 0 else None)
+            if g.get("rows_src") is not None:
+                g["rows_src"] = rows_source(pointcloud)         # (the rows come from THIS cloud's feature columns)
             geo.append(g)
             xyz = g["new_xyz"]
             if xyz is None:                      # group-all level: nothing below depends on coordinates
@@ -58,6 +60,8 @@ class PointNet2ClassificationSSG(nn.Module):
         (B, C_last, 1) set features if `return_features` else class logits.
         `geometry` = precompute_geometry(pointcloud) (optional; identical results)."""
         xyz, features = self._break_up_pc(pointcloud)
+        if geometry is not None:
+            geometry = confirm_rows(geometry, pointcloud)
         for i, sa in enumerate(self.SA_modules):
             g = geometry[i] if geometry is not None and i < len(geometry) else None
             xyz, features = sa(xyz, features, geometry=g) if g is not None else sa(xyz, features)

@@ -37,9 +37,42 @@ def take_of(scan_id) -> int:
         return 0
 
 
+#: channel counts a stored cloud can have: xyz | xyz + rgb | xyz + rgb + mask (data_preparation_utils.py:110-125)
+_POINT_CHANNELS = (3, 6, 7)
+
+
+def _check_stored_layout(sample: Dict) -> None:
+    """A cache file holds the reference's PRE-collate layout: clouds (n, P, C) with C in {3, 6, 7} last, `edge_indices`
+    (E, 2).  Files written by rounds 1-3 of this build stored the post-collate layout (channel-first clouds, (2, E)
+    edges); permuting those a second time gives wrong edges without an error when E == 2, so a stale file is refused
+    here instead (delete it: `ORDataset` regenerates the sample)."""
+    sid = sample.get("scan_id", "?")
+    for k in ("obj_points", "rel_points"):
+        v = sample.get(k)
+        if v is None:
+            continue
+        shp = tuple(v.shape)
+        if len(shp) != 3 or shp[2] not in _POINT_CHANNELS or (shp[1] in _POINT_CHANNELS and shp[1] < shp[2]):
+            raise ValueError(f"cache sample {sid}: `{k}` has shape {shp}, expected the reference's pre-collate layout "
+                             f"(n, points, channels in {_POINT_CHANNELS}); the file predates the round-4 cache format — "
+                             "delete it so that it is regenerated")
+    ei = sample.get("edge_indices")
+    if ei is not None:
+        shp = tuple(ei.shape)
+        n_obj = None if sample.get("obj_points") is None else int(sample["obj_points"].shape[0])
+        n_edge = None if sample.get("rel_points") is None else int(sample["rel_points"].shape[0])
+        bad = len(shp) != 2 or shp[1] != 2 or (n_edge is not None and shp[0] != n_edge)
+        if not bad and n_obj is not None and shp[0]:
+            bad = int(torch.as_tensor(ei).max()) >= n_obj
+        if bad:
+            raise ValueError(f"cache sample {sid}: `edge_indices` has shape {shp}, expected (E, 2) with E = "
+                             f"{n_edge} pair clouds; the file predates the round-4 cache format — delete it")
+
+
 def collate_sample(sample: Dict) -> Dict:
     """``ORDataset.collate_fn`` (or_dataset.py:63-74) on one cached (pre-collate) sample; returns a new dict."""
     out = dict(sample)
+    _check_stored_layout(out)
     for k in ("obj_points", "rel_points"):
         if out.get(k) is not None:
             out[k] = torch.as_tensor(out[k]).permute(0, 2, 1).contiguous()      # (n, P, C) -> (n, C, P)

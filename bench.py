@@ -43,6 +43,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+from runtime.affinity import pin_to_gpu_numa  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md chip table (spec; ~6300 achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA (= fp32 vector peak), same table
@@ -399,6 +400,8 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
     trainable = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(trainable, lr=float(cfg["LR"]), weight_decay=float(cfg["W_DECAY"]), capturable=args.graphs, fused=True)
     S = max(1, int(args.scans_per_step))
+    # this step is bound by the ONE host thread that enqueues it: keep that thread next to the rank's GPU
+    affinity = pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     model.per_scan_statistics = not args.whole_batch_statistics
     if args.segment_streams is not None:
         from pointnet2_ops import fused_mlp
@@ -540,7 +543,7 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
                           "scans_per_step": S, "per_scan_statistics": bool(model.per_scan_statistics or S == 1),
                           "with_gpu_preparation": bool(args.with_prep),
                           "parallelism": f"dp{world}", "hip_graphs": bool(args.graphs),
-                          "host_enqueue_ms_per_step": round(enqueue_ms, 3),
+                          "host_enqueue_ms_per_step": round(enqueue_ms, 3), "host_affinity": affinity,
                           "geometry_pipeline": bool(args.geometry_pipeline and not args.graphs)}}
         if timer is not None:
             rows = kernel_table(timer.summary(), 1)
@@ -647,6 +650,10 @@ def main():
         sync = FlatGradSync(model.parameters(), world)
     opt = torch.optim.AdamW(model.parameters(), lr=3e-5, weight_decay=1e-3, fused=True)   # one kernel (the foreach form: ~12 launches; 1.1 ms per step on slow-host boxes)
     pc = synthetic_scenes(args.batch, args.points, seed=1000 + rank, device=device)   # resident in HBM
+    # the enqueueing thread (and the autograd thread it spawns at the first backward) next to this rank's GPU
+    # (runtime/affinity.py); the host threads torch already created keep the whole machine for the CPU baseline
+    host_cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    affinity = pin_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     prefetcher = GeometryPrefetcher(model, device) if args.geometry_pipeline else None
     run_steps(net, model, opt, pc, args.warmup, prefetcher, sync=sync)
@@ -760,6 +767,7 @@ def main():
                                      f"back-pressure: {enqueue_all_ms:.3f} ms",
                 "geometry_pipeline": "off" if prefetcher is None else
                 "on: FPS / ball-query / 3-NN of batch i+1 run on a side stream during step i (one geometry per timed step)",
+                "host_affinity": affinity,
             },
         }
         if serial_ms is not None:
@@ -796,6 +804,8 @@ def main():
                                            "not part of `value`"}
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 64)
+            if host_cpus and affinity.get("pinned"):
+                os.sched_setaffinity(0, host_cpus)        # the baseline runs on all host cores again
             try:
                 out["cpu_baseline"] = cpu_baseline(args.points, args.cpu_sample_scenes, threads, args.workload)
             except Exception as e:  # the baseline is informational; never lose the GPU number

@@ -102,6 +102,9 @@ int pn2_furthest_point_sampling_ordered(int B, int N, int m, const float *xyz, v
  * sets the int32 at pn2_fps_status_offset() bytes into `workspace` to 1 (-1: this shape has no such word); callers
  * must check it (the python binding asserts on the device, asynchronously). */
 long long pn2_fps_status_offset(int B, int N, int m);
+/* ... for a call made with `flags` (pn2_furthest_point_sampling_ex / _ordered): the flags take part in the choice of the
+ * kernel variant, so the word's presence has to be asked for with the flags the call was made with. */
+long long pn2_fps_status_offset_ex(int B, int N, int m, int flags);
 /* Test hook: force a kernel variant (mode: -1 heuristic | 0 resident | 1 cluster | 2 streaming | 3 cluster with a
  * streamed tail | 4 one workgroup over the binned cloud | 5 cluster with several samples per hand-off) and cluster
  * shape (0 = heuristic).  Process-global; results never depend on it. */
@@ -693,9 +696,11 @@ int pn2_segment_bn_rows_grad(int64_t R, int C, int ldx, int col0, int64_t S, con
  *                          gather: gx (nodes, dn) += columns [0, dn) at dst and [dn + de, K) at src, ge (R, de) = the middle.
  *   pn2_gcn_edge_slice     out (R, de) = [ReLU] h[:, off : off + de]  (the new edge feature, :51).
  * FLOPs 2 R K N each; every operand is read once per 32-column tile (L2-resident at these sizes).
- * PRECONDITION (the caller's, not checked on the device: `ptr` lives there): every scan has at most 128 rows — rows beyond
- * the 128th of a scan would be left out of its statistics and results.  pn2_gcn_fused_supported(dn, de, dh, longest scan) is
- * the host-side check; the python layer routes longer scans (and batches of more than 16 scans) to the unfused kernels. */
+ * PRECONDITION: every scan has at most 128 rows.  `ptr` lives on the device, so the entry points cannot return an error for
+ * it: a scan with more rows comes back with EVERY result row NaN (Out / Ypre of pn2_gcn_linear, Gz — and through it the
+ * weight gradients — of pn2_gcn_linear_grad_w), never with statistics over its first 128 rows.
+ * pn2_gcn_fused_supported(dn, de, dh, longest scan) is the host-side check; the python layer routes longer scans (and
+ * batches of more than 32 scans) to the unfused kernels. */
 int pn2_gcn_fused_supported(int dn, int de, int dh, int max_rows_per_scan);
 int pn2_gcn_linear(long long R, int S, int K, int N, const float *A, int lda, const float *x, const float *e,
                    const long long *dst, const long long *src, int dn, int de, const float *W, const float *bias,

@@ -207,3 +207,84 @@ def test_runner_train_mode_on_two_gloo_ranks(tmp_path):
     assert torch.equal(res["params"][0], res["params"][1])
     mean_local = (res["locals"][0] + res["locals"][1]) / 2
     torch.testing.assert_close(res["seen"], mean_local, atol=1e-6, rtol=1e-4)
+
+
+def _graphed_worker(rank, world, port, out):
+    """bench.py --workload sgp --graphs under torchrun: runtime.GraphedTrainStep over the full SGPN model's
+    `pure_training_step` with a process group — flat gradient buffer, ONE all-reduce between the backward and the optimizer
+    (on a CPU/gloo job the eager schedule of the same class: capture=False), two block-diagonal scans per step and rank."""
+    sys.path[:0] = [os.path.join(REPO, "4d-or_amd"), REPO, os.path.join(REPO, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_ext
+    from pointnet2_ops import pointnet2_utils as pu
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    pu._ext = gcn._ext = oracle_ext.OracleRowsExt
+    from runtime import GraphedTrainStep
+    from scene_graph_prediction import main as runner
+    from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan, to_device
+    from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+    device = torch.device("cpu")
+    cfg = runner.config_loader("no_gt.json")
+
+    def build():
+        torch.manual_seed(0)                     # bench_sgp seeds every rank alike: identical initial weights
+        m = SGPNModelWrapper(cfg, 12, 15, torch.ones(12), torch.ones(15), runner.RELATION_NAMES).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        for n, p in m.named_parameters():
+            if ".backbone.fc_layer." in n:
+                p.requires_grad_(False)
+        return m
+
+    model, ref = build(), build()
+    batch = to_device(collate_scans([synthetic_scan(3, 300, 400, seed=10 * rank + i, scan_id=f"s{rank}_{i}") for i in range(2)]),
+                      device)
+    # this rank's own gradient, no communication
+    loss, _ = ref.pure_training_step(batch)
+    loss.backward()
+    names = [n for n, p in ref.named_parameters() if p.requires_grad]
+    local = torch.cat([(dict(ref.named_parameters())[n].grad if dict(ref.named_parameters())[n].grad is not None
+                        else torch.zeros_like(dict(ref.named_parameters())[n])).flatten() for n in names])
+
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(trainable, lr=float(cfg["LR"]), weight_decay=float(cfg["W_DECAY"]))
+    stepper = GraphedTrainStep(model.pure_training_step, trainable, opt, capture=False)
+    assert stepper.distributed
+    seen = {}
+    orig_step = torch.optim.AdamW.step
+
+    def spy(self, *a, **k):
+        if "g" not in seen:
+            seen["g"] = stepper.grads.flat.clone()
+        return orig_step(self, *a, **k)
+
+    torch.optim.AdamW.step = spy
+    try:
+        for _ in range(2):
+            stepper(batch)
+    finally:
+        torch.optim.AdamW.step = orig_step
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    locals_ = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(locals_, local)
+    if rank == 0:
+        torch.save({"params": gathered, "seen": seen["g"], "locals": locals_}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_step_flat_gradients_on_two_gloo_ranks(tmp_path):
+    """The `--graphs` schedule of bench_sgp / main.py on two ranks: the optimizer sees the MEAN of the ranks' local
+    gradients (one flat all-reduce), and parameters stay identical across ranks."""
+    out = str(tmp_path / "graphed.pt")
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_graphed_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["params"][0], res["params"][1])
+    mean_local = (res["locals"][0] + res["locals"][1]) / 2
+    torch.testing.assert_close(res["seen"], mean_local, atol=1e-6, rtol=1e-4)
