@@ -992,6 +992,115 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(long long R, int C, 
   }
 }
 
+// ---- vectorised forms of the two prep kernels (round 5) -------------------------------------------------------------
+// The kernels above move 4 bytes per lane and end every 16-row block with 2 C fp64 atomics onto the same 2 C addresses:
+// at the headline shapes that is 4096 blocks x 256 atomics = 1 M atomics on sixteen cache lines, which — not the 92 MB of
+// rows — was their time (58 us = 1.6 TB/s).  Here a thread owns FOUR columns (16-byte accesses) and every fourth row group
+// of a block of `rpb` rows, four rows in flight per stream; the grid is capped at kPrepBlocks blocks so that the atomics
+// (<= 512 x 2 C) disappear behind the rows.  Same arithmetic per element; the per-column sums are fp32 over a thread's
+// rows, then fp32 over the block's row groups (LDS), then fp64 across blocks, as before.
+constexpr int kPrepBlocks = 512;
+
+// C % 4 == 0 and at most 256 threads per row
+__host__ __device__ inline bool prep_vec_ok(int C) { return C % 4 == 0 && C / 4 <= 256; }
+// rows per block for R rows of C columns: a multiple of (row groups x 4 rows in flight), at most kPrepBlocks blocks
+__host__ __device__ inline long long prep_vec_rpb(long long R, int C) {
+  const int groups = 256 / (C / 4);
+  const long long unit = (long long)groups * 4;
+  const long long want = (R + kPrepBlocks - 1) / kPrepBlocks;
+  return (want + unit - 1) / unit * unit;
+}
+
+// POOLED: gate = pooled > 0, yv = yraw (pn2_pool_bwd_prep);  else gate = relu(bn(y)) > 0, yv = y (pn2_bn_relu_bwd_prep)
+template <bool POOLED>
+__global__ __launch_bounds__(256) void prep_vec_kernel(long long R, int C, long long rpb, const float *__restrict__ yv,
+                                                       const float *__restrict__ pooled, const float *__restrict__ gin,
+                                                       const float *__restrict__ fin, float *__restrict__ gout,
+                                                       double *__restrict__ sums, const long long *__restrict__ seg,
+                                                       int ns) {
+  __shared__ float4 part[2][256];
+  if (seg) {                                     // blockIdx.y = scan: its rows, its (4,C) finalize block, its sums
+    const long long g0 = seg[blockIdx.y] / ns;
+    R = seg[blockIdx.y + 1] / ns - g0;
+    const size_t o = (size_t)g0 * C;
+    yv += o; gin += o; gout += o;
+    if (POOLED) pooled += o;
+    fin += (size_t)blockIdx.y * 4 * C;
+    sums += (size_t)blockIdx.y * 2 * C;
+    rpb = prep_vec_rpb(R, C);                    // the blocks — and with them the fp32 partial sums — of the scan's own call
+  }
+  const long long r0 = (long long)blockIdx.x * rpb;
+  if (r0 >= R) return;                           // (block-uniform)
+  const long long r1 = r0 + rpb < R ? r0 + rpb : R;
+  const int C4 = C >> 2;
+  const int groups = 256 / C4;
+  const int grp = threadIdx.x / C4, c4 = threadIdx.x - grp * C4;
+  const bool active = grp < groups;
+  float4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  if (active) {
+    const float4 mean = reinterpret_cast<const float4 *>(fin)[c4], rstd = reinterpret_cast<const float4 *>(fin + C)[c4];
+    float4 sc = mean, sh = mean;
+    if (!POOLED) { sc = reinterpret_cast<const float4 *>(fin + 2 * C)[c4]; sh = reinterpret_cast<const float4 *>(fin + 3 * C)[c4]; }
+    const float4 *Y = reinterpret_cast<const float4 *>(yv) + c4;
+    const float4 *P = reinterpret_cast<const float4 *>(POOLED ? pooled : yv) + c4;
+    const float4 *G = reinterpret_cast<const float4 *>(gin) + c4;
+    float4 *O = reinterpret_cast<float4 *>(gout) + c4;
+    for (long long r = r0 + grp; r < r1; r += 4 * groups) {
+      float4 y[4], p[4], g[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long row = r + (long long)u * groups;
+        ok[u] = row < r1;
+        const size_t o = (size_t)(ok[u] ? row : r) * C4;
+        y[u] = Y[o];
+        if (POOLED) p[u] = P[o];
+        g[u] = G[o];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        float4 o4;
+        const float ya[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
+        const float pa[4] = {POOLED ? p[u].x : 0.f, POOLED ? p[u].y : 0.f, POOLED ? p[u].z : 0.f, POOLED ? p[u].w : 0.f};
+        const float ga[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+        const float sca[4] = {sc.x, sc.y, sc.z, sc.w}, sha[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float ma[4] = {mean.x, mean.y, mean.z, mean.w}, ra[4] = {rstd.x, rstd.y, rstd.z, rstd.w};
+        float oa[4], a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool gate = POOLED ? pa[j] > 0.f : __fmaf_rn(ya[j], sca[j], sha[j]) > 0.f;
+          const float gv = gate ? ga[j] : 0.f;
+          oa[j] = gv;
+          a1[j] += gv;
+          a2[j] = __fmaf_rn(gv, (ya[j] - ma[j]) * ra[j], a2[j]);
+        }
+        o4 = float4{oa[0], oa[1], oa[2], oa[3]};
+        s1 = float4{a1[0], a1[1], a1[2], a1[3]};
+        s2 = float4{a2[0], a2[1], a2[2], a2[3]};
+        O[(size_t)(r + (long long)u * groups) * C4] = o4;
+      }
+    }
+  }
+  part[0][threadIdx.x] = s1;
+  part[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (grp == 0) {
+    for (int q = 1; q < groups; ++q) {
+      const float4 a = part[0][threadIdx.x + q * C4], b = part[1][threadIdx.x + q * C4];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    double *d1 = sums + 4 * c4, *d2 = sums + C + 4 * c4;
+    atomicAdd(d1 + 0, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y); atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
+    atomicAdd(d2 + 0, (double)s2.x); atomicAdd(d2 + 1, (double)s2.y); atomicAdd(d2 + 2, (double)s2.z); atomicAdd(d2 + 3, (double)s2.w);
+  }
+}
+
+inline bool aligned16(const void *a, const void *b, const void *c, const void *d, const void *e) {
+  return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d) | ((uintptr_t)e)) & 15) == 0;
+}
+
 inline unsigned capped_grid(size_t work, int block = 256, unsigned cap = 8192) {
   size_t g = (work + block - 1) / block;
   if (g > cap) g = cap;
@@ -1397,6 +1506,12 @@ extern "C" int pn2_bn_relu_bwd_prep(long long M, int N, const float *y, const fl
   if (M < 0 || N <= 0) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!y || !gout || !fin || !gpre || !sums) return PN2_ENULL;
+  if (prep_vec_ok(N) && aligned16(y, gout, fin, gpre, nullptr)) {
+    const long long rpbv = prep_vec_rpb(M, N);
+    hipLaunchKernelGGL(prep_vec_kernel<false>, dim3((unsigned)((M + rpbv - 1) / rpbv)), dim3(256), 0, (hipStream_t)stream, M, N,
+                       rpbv, y, (const float *)nullptr, gout, fin, gpre, sums, (const long long *)nullptr, 1);
+    return pn2_check_launch();
+  }
   const int rpb = prep_rows_per_block(M);
   hipLaunchKernelGGL(bn_relu_bwd_prep_kernel, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0,
                      (hipStream_t)stream, M, N, rpb, y, gout, fin, gpre, sums);
@@ -1426,6 +1541,12 @@ extern "C" int pn2_pool_bwd_prep(long long R, int C, const float *yraw, const fl
   if (R < 0 || C <= 0) return PN2_EINVAL;
   if (R == 0) return PN2_OK;
   if (!yraw || !pooled || !gP || !fin || !gPm || !sums) return PN2_ENULL;
+  if (prep_vec_ok(C) && aligned16(yraw, pooled, gP, fin, gPm)) {
+    const long long rpbv = prep_vec_rpb(R, C);
+    hipLaunchKernelGGL(prep_vec_kernel<true>, dim3((unsigned)((R + rpbv - 1) / rpbv)), dim3(256), 0, (hipStream_t)stream, R, C,
+                       rpbv, yraw, pooled, gP, fin, gPm, sums, (const long long *)nullptr, 1);
+    return pn2_check_launch();
+  }
   const int rpb = prep_rows_per_block(R);
   hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0,
                      (hipStream_t)stream, R, C, rpb, yraw, pooled, gP, fin, gPm, sums, (const long long *)nullptr, 1);
@@ -1445,6 +1566,16 @@ extern "C" int pn2_pool_bwd_prep_seg(long long R, int C, const float *yraw, cons
   // every scan is cut into the blocks of its own call (rows per block from ITS row count, in the kernel): at most 4096
   // blocks for any count, fewer than rows / 16
   const long long Rs = seg_max / ns;                                  // pooled rows of the longest scan
+  if (prep_vec_ok(C) && aligned16(yraw, pooled, gP, fin, gPm)) {
+    // (per-scan offsets g0 * C floats keep the 16-byte alignment: C % 4 == 0)
+    const long long unit = (long long)(256 / (C / 4)) * 4;
+    long long gxv = (Rs + unit - 1) / unit;
+    if (gxv > kPrepBlocks) gxv = kPrepBlocks;
+    if (gxv < 1) gxv = 1;
+    hipLaunchKernelGGL(prep_vec_kernel<true>, dim3((unsigned)gxv, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, R, C,
+                       unit, yraw, pooled, gP, fin, gPm, sums, seg, ns);
+    return pn2_check_launch();
+  }
   long long gx = (Rs + kPrepRows - 1) / kPrepRows;
   if (gx > 4096) gx = 4096;
   if (gx < 1) gx = 1;

@@ -1,0 +1,178 @@
+"""GPU cases added in round 5.
+
+* the vectorised backward-prep kernels (`prep_vec_kernel`: pn2_pool_bwd_prep / pn2_bn_relu_bwd_prep / the segment-table
+  form) against a float64 restatement, ragged shapes included, and segment table == one call per scan, bit for bit;
+* a TripletGCN scan longer than the fused kernels cover comes back NaN (not a silent partial result); the FPS
+  status word is asked for with the flags of the call; pre-grouped rows of a prefetched geometry are dropped when the
+  features changed in between;
+* VERDICT r04 parity hygiene (b): ONE oracle comparison at B = 32 for the XCD-aware paths — FPS 32 x 50k -> 256 and ball
+  query 32 x 50k / 2048 / r 0.2 / ns 64, four of the 32 clouds each through the CPU oracle.
+"""
+import pytest
+import torch
+
+import oracle_ext
+from pointnet2_ops import _ext
+from pointnet2_ops import pointnet2_modules as pm
+from pointnet2_ops import pointnet2_utils as pu
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _unit_ball(B, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.randn(B, N, 3, generator=g)
+    p = p / p.norm(dim=2, keepdim=True) * torch.rand(B, N, 1, generator=g).pow(1 / 3)
+    p = p - p.mean(dim=1, keepdim=True)
+    return (p / p.norm(dim=2).amax(dim=1).view(B, 1, 1)).contiguous()
+
+
+def _fin(C, seed):
+    g = torch.Generator().manual_seed(seed)
+    mean = torch.randn(C, generator=g) * 0.3
+    rstd = torch.rand(C, generator=g) + 0.5
+    scale = (torch.rand(C, generator=g) - 0.3) * rstd            # some negative gammas
+    shift = torch.randn(C, generator=g) * 0.2 - mean * scale
+    return torch.stack([mean, rstd, scale, shift]).contiguous().to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------ prep kernels
+@pytest.mark.parametrize("R,C", [(65536, 128), (32768, 256), (1000, 288), (37, 64), (70001, 32), (513, 4), (300, 130)])
+def test_pool_bwd_prep_matches_float64(R, C):
+    g = torch.Generator().manual_seed(R + C)
+    yraw = torch.randn(R, C, generator=g).to(DEV)
+    pooled = torch.relu(torch.randn(R, C, generator=g)).to(DEV)          # about half the entries are 0 (ReLU'd maxima)
+    gP = torch.randn(R, C, generator=g).to(DEV)
+    fin = _fin(C, 3)
+    gPm, sums = _ext.pool_bwd_prep(yraw, pooled, gP, fin)
+    ref = torch.where(pooled > 0, gP, torch.zeros_like(gP))
+    assert torch.equal(gPm, ref)
+    yhat = (yraw.double() - fin[0].double()) * fin[1].double()
+    torch.testing.assert_close(sums[0], ref.double().sum(0), rtol=1e-5, atol=1e-5 * R ** 0.5)
+    torch.testing.assert_close(sums[1], (ref.double() * yhat).sum(0), rtol=1e-5, atol=1e-5 * R ** 0.5)
+    # accumulates: a second call doubles the sums
+    _, sums2 = _ext.pool_bwd_prep(yraw, pooled, gP, fin, sums=sums.clone())
+    torch.testing.assert_close(sums2, 2 * sums, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("M,N", [(32768, 256), (32768, 288), (999, 128), (70001, 64), (50, 513)])
+def test_bn_relu_bwd_prep_matches_float64(M, N):
+    g = torch.Generator().manual_seed(M + N)
+    y = torch.randn(M, N, generator=g).to(DEV)
+    gout = torch.randn(M, N, generator=g).to(DEV)
+    fin = _fin(N, 5)
+    gpre, sums = _ext.bn_relu_bwd_prep(y, gout, fin)
+    gate = torch.addcmul(fin[3], y, fin[2]) > 0                       # fma(y, scale, shift): one rounding, like the kernel
+    gate64 = (y.double() * fin[2].double() + fin[3].double()) > 0
+    agree = gate == gate64                                            # (entries within an ulp of the ReLU kink may differ)
+    ref = torch.where(gate64, gout, torch.zeros_like(gout))
+    assert float((gpre != ref)[agree].sum()) == 0 and float((~agree).float().mean()) < 1e-5
+    yhat = (y.double() - fin[0].double()) * fin[1].double()
+    torch.testing.assert_close(sums[0], gpre.double().sum(0), rtol=1e-5, atol=1e-5 * M ** 0.5)
+    torch.testing.assert_close(sums[1], (gpre.double() * yhat).sum(0), rtol=1e-5, atol=1e-5 * M ** 0.5)
+
+
+@pytest.mark.parametrize("C", [128, 288, 130])
+def test_pool_bwd_prep_segment_table_equals_one_call_per_scan(C):
+    ns = 16
+    rows = [64 * ns, 1 * ns, 700 * ns, 33 * ns]                       # un-pooled rows per scan
+    R = sum(rows) // ns
+    g = torch.Generator().manual_seed(11)
+    yraw = torch.randn(R, C, generator=g).to(DEV)
+    pooled = torch.relu(torch.randn(R, C, generator=g)).to(DEV)
+    gP = torch.randn(R, C, generator=g).to(DEV)
+    fin = torch.stack([_fin(C, 20 + s) for s in range(len(rows))]).contiguous()
+    seg = _ext.SegTable.get(torch.device(DEV, torch.cuda.current_device()), rows)
+    gPm, sums = _ext.pool_bwd_prep(yraw, pooled, gP, fin, seg=seg, ns=ns)
+    o = 0
+    for s, r in enumerate(rows):
+        n = r // ns
+        a, b = _ext.pool_bwd_prep(yraw[o:o + n].contiguous(), pooled[o:o + n].contiguous(), gP[o:o + n].contiguous(), fin[s].contiguous())
+        assert torch.equal(gPm[o:o + n], a)
+        assert torch.equal(sums[s], b), f"scan {s}: the table's sums differ from the scan's own call"
+        o += n
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r04
+def test_gcn_scan_longer_than_the_fused_kernels_cover_is_nan_not_partial():
+    S, dn = 2, 64
+    rows = [40, 200]                                                  # the second scan exceeds the 128 rows a workgroup covers
+    ptr = torch.tensor([0, rows[0], sum(rows)], dtype=torch.int64, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(sum(rows), dn, generator=g).to(DEV)
+    W = torch.randn(dn, dn, generator=g).to(DEV)
+    bias = torch.zeros(dn, device=DEV)
+    gamma, beta = torch.ones(dn, device=DEV), torch.zeros(dn, device=DEV)
+    assert not _ext.gcn_fused_supported(dn, dn, dn, max(rows))
+    out, ypre, mean, rstd = _ext.gcn_linear(W, bias, ptr, S, A=A, bn=(gamma, beta, 1e-5), relu=True)
+    assert bool(torch.isfinite(out[:rows[0]]).all())                  # the scan that fits is computed
+    assert bool(torch.isnan(out[rows[0]:]).all()) and bool(torch.isnan(ypre[rows[0]:]).all())
+
+
+def test_fps_status_offset_follows_the_flags_of_the_call():
+    lib = _ext._lib
+    for B, N, m in [(32, 50000, 2048), (8, 20000, 512), (32, 2048, 1024), (4, 24000, 256), (64, 17000, 300)]:
+        assert lib.pn2_fps_status_offset_ex(B, N, m, 0) == lib.pn2_fps_status_offset(B, N, m)
+        for flags in (_ext.PN2_FPS_FEW_CUS, _ext.PN2_FPS_FEW_CUS | _ext.PN2_FPS_FEWEST_CUS):
+            off = lib.pn2_fps_status_offset_ex(B, N, m, flags)
+            assert off == -1 or off > 0                                 # a byte offset, or "this plan writes no word"
+    assert lib.pn2_fps_status_offset_ex(4, 1000, 16, 0x40) == -1     # unknown flag bits
+    # the flagged calls run clean whatever plan they pick (a spurious device assert would poison the context here)
+    xyz = _unit_ball(6, 20000, 3).to(DEV)
+    ref = _ext.furthest_point_sampling(xyz, 300)
+    with _ext.background_geometry(fewest=True):
+        assert torch.equal(_ext.furthest_point_sampling(xyz, 300), ref)
+    with _ext.background_geometry(fewest=False):
+        assert torch.equal(_ext.furthest_point_sampling(xyz, 300), ref)
+    torch.cuda.synchronize()
+
+
+def test_prefetched_rows_are_dropped_when_the_features_changed():
+    torch.manual_seed(0)
+    sa = pm.PointnetSAModule(mlp=[3, 32, 64], npoint=256, radius=0.25, nsample=32).to(DEV).train()
+    xyz = _unit_ball(2, 6000, 5).to(DEV)
+    feats_rows = torch.rand(2, 6000, 3, device=DEV)
+    geo = sa.sample_and_query(xyz, feats_rows=feats_rows)
+    features = feats_rows.transpose(1, 2)                              # (B, C, N) view of the same storage
+    assert geo["rows"][0] is not None and pm.rows_still_valid(geo, pu.as_rows(features))
+    with torch.no_grad():
+        _, same = sa(xyz, features, geometry=geo)
+        _, plain = sa(xyz, features)
+        torch.testing.assert_close(same, plain, atol=1e-5, rtol=1e-5)
+        feats_rows.mul_(0.5)                                           # augmentation after the prefetch
+        assert not pm.rows_still_valid(geo, pu.as_rows(features))
+        _, stale_guarded = sa(xyz, features, geometry=geo)             # rows dropped: grouped from the CURRENT features
+        _, fresh = sa(xyz, features)
+    torch.testing.assert_close(stale_guarded, fresh, atol=1e-5, rtol=1e-5)
+    assert float((fresh - plain).abs().max()) > 1e-3                   # (the change was visible in the result)
+
+
+# ------------------------------------------------------------------------------------------------ B = 32 vs the oracle
+def test_fps_at_32_clouds_matches_the_oracle_on_four_of_them():
+    xyz = _unit_ball(32, 50000, 41)
+    got = _ext.furthest_point_sampling(xyz.to(DEV), 256).cpu()
+    with _ext.background_geometry(fewest=True):                        # the shape the bench's prefetch stream runs
+        got_bg = _ext.furthest_point_sampling(xyz.to(DEV), 256).cpu()
+    assert torch.equal(got, got_bg)
+    pick = [0, 9, 18, 31]                                              # clouds of different XCDs / clusters
+    ref = oracle_ext.OracleRowsExt.furthest_point_sampling(xyz[pick].contiguous(), 256)
+    assert torch.equal(got[pick], ref)
+
+
+def test_ball_query_at_32_clouds_matches_the_oracle_on_four_of_them():
+    B, N, m, ns, r = 32, 50000, 2048, 64, 0.2
+    xyz = _unit_ball(B, N, 43)
+    sel = _ext.furthest_point_sampling(xyz.to(DEV), m).long()
+    new_xyz = torch.gather(xyz.to(DEV), 1, sel.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = _ext.ball_query(new_xyz, xyz.to(DEV), r, ns).cpu()
+    pick = [0, 11, 20, 31]
+    ref = oracle_ext.OracleRowsExt.ball_query(new_xyz[pick].cpu().contiguous(), xyz[pick].contiguous(), r, ns)
+    assert torch.equal(idx[pick], ref)
+    # the fused query + grouping entry (what the headline's SA1 runs) returns the same neighbourhoods and their rows
+    if getattr(_ext, "ball_query_group", None) is not None:
+        feats = torch.rand(B, N, 3, device=DEV)
+        idx2, rows = _ext.ball_query_group(new_xyz, xyz.to(DEV), feats, r, ns, True, True)
+        assert torch.equal(idx2.cpu()[pick], ref)
+        want = _ext.group_concat_rows(xyz.to(DEV), new_xyz, feats, idx2, True, True, r)
+        assert torch.equal(rows.view_as(want)[pick], want[pick])
