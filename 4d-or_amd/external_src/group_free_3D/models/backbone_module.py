@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from pointnet2_ops import pointnet2_utils
-from pointnet2_ops.pointnet2_modules import confirm_rows, rows_source
+from pointnet2_ops.pointnet2_modules import _capturing as capturing, confirm_rows, rows_source
 from external_src.group_free_3D.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 
 
@@ -49,6 +49,10 @@ class Pointnet2Backbone(nn.Module):
         xyz = pointcloud[..., 0:3].contiguous()
         geo = {"sa": [], "fp": []}
         levels = [xyz]
+        # the split cloud travels with the geometry: the forward takes these two tensors instead of slicing the cloud a
+        # second time on the critical path (two strided copies of 19 MB each at the headline shape), after the same
+        # identity check as the pre-grouped rows (`src`: storage, shape and version of the cloud they were cut from)
+        geo["xyz"], geo["src"] = xyz, rows_source(pointcloud)
         # FPS shape that leaves half of the CUs to the co-running step (include/pn2_hip.h: PN2_FPS_FEW_CUS)
         # fp32 steps (13+ ms of matrix kernels) are longer than the sampling chain: give the sampling as few CUs as possible;
         # the bf16 step is shorter than the chain and wants the faster 128-CU shape
@@ -56,6 +60,7 @@ class Pointnet2Backbone(nn.Module):
         bg = getattr(pointnet2_utils._ext, "background_geometry", None)
         with (bg(fewest=fused_mlp.mlp_dtype() == torch.float32) if bg is not None else contextlib.nullcontext()):
             feats0 = (pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 and not pointcloud.requires_grad else None)
+            geo["feats_rows"] = feats0
             for i in (1, 2, 3, 4):
                 # levels 2-4 gather features that carry a gradient; level 1 reads the input colours: its grouped rows come
                 # out of the ball query itself (pn2_ball_query_group) here, off the step's critical path
@@ -74,7 +79,12 @@ class Pointnet2Backbone(nn.Module):
         sa{1..4}_xyz / _features (/ _inds for 1,2) and fp2_{features,xyz,inds}.
         `geometry` = precompute_geometry(pointcloud) (optional; identical results)."""
         end_points = end_points or {}
-        xyz, features = self._break_up_pc(pointcloud)
+        src = None if geometry is None else geometry.get("src")
+        if (src is not None and geometry.get("feats_rows") is not None and not pointcloud.requires_grad
+                and (src.matches(pointcloud) or capturing())):
+            xyz, features = geometry["xyz"], geometry["feats_rows"].transpose(1, 2)      # cut from THIS cloud by the prefetch
+        else:
+            xyz, features = self._break_up_pc(pointcloud)
         if geometry is not None:
             geometry = dict(geometry, sa=confirm_rows(geometry["sa"], pointcloud))
         for i in (1, 2, 3, 4):
