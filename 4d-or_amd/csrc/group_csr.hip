@@ -123,6 +123,93 @@ __global__ __launch_bounds__(kBlock) void group_rows_grad_csr_any_kernel(int C, 
   }
 }
 
+// ---- the inverse index in ONE launch (round 5) ----------------------------------------------------------------------
+// The radix sort above is ~18 launches per call (47 rocPRIM passes per backbone step for three levels, 0.25 ms per call on
+// the prefetch stream).  The keys are bounded point indices and the rows of a cloud are contiguous, so the index is a
+// STABLE COUNTING SORT per cloud, done by one workgroup per cloud entirely in LDS:
+//   rows of the cloud are cut into W contiguous chunks, one per wave; every wave counts the keys of its chunk into its OWN
+//   histogram (cur[w][k]); a per-key prefix over the waves and a block scan over the keys turn the histograms into write
+//   cursors (and `ptr`); every wave then walks its chunk in row order, 64 rows per step, and places them: lanes with equal keys
+//   are found with a bit-sliced match (one ballot per key bit), their rank among equals is a masked popcount — rows of a
+//   point therefore land in ascending row order, exactly the stable sort's result, with no atomics in the placement and a
+//   summation order in the consumers that is fixed by construction (bit-reproducible like the sort's).
+// LDS: W x N cursors; W = min(16, 36864 / N) waves (N <= 36864 points per cloud; larger clouds keep the radix sort).
+constexpr int kInvLdsInts = 36864;      // 144 KB of cursors
+
+__global__ __launch_bounds__(1024) void inv_cloud_kernel(int N, int P, int W, int nbits, int last_cloud,
+                                                         const int *__restrict__ idx, int *__restrict__ ptr,
+                                                         int *__restrict__ refs) {
+  extern __shared__ int cur[];            // [W][N]
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, T = blockDim.x;
+  const int b = blockIdx.x;
+  const int *I = idx + (size_t)b * P;
+  const int chunk = (((P + W - 1) / W) + 63) & ~63;          // rows per wave, whole steps of 64
+  const int r0 = wv * chunk, r1 = r0 + chunk < P ? r0 + chunk : P;
+  for (int i = tid; i < W * N; i += T) cur[i] = 0;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  // (1) histogram of the wave's chunk (LDS integer atomics: order-free)
+  for (int r = r0 + lane; r < r1; r += 64) {
+    const unsigned k = (unsigned)I[r];
+    atomicAdd(&cur[wv * N + (int)(k < (unsigned)N ? k : (unsigned)N - 1u)], 1);
+  }
+  __syncthreads();
+  // (2) cursors: keys in tiles of T (thread = key: conflict-free), per key an exclusive prefix over the waves, over the keys a
+  //     block scan carried from tile to tile
+  int *P_ = ptr + (size_t)b * N;
+  for (int kb = 0; kb < N; kb += T) {
+    const int k = kb + tid;
+    int tot = 0;
+    if (k < N) {
+      for (int w = 0; w < W; ++w) {
+        const int c = cur[w * N + k];
+        cur[w * N + k] = tot;
+        tot += c;
+      }
+    }
+    int inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(inc, d);
+      if (lane >= d) inc += v;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = carry + inc - tot;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    if (k < N) {
+      P_[k] = b * P + base;
+      for (int w = 0; w < W; ++w) cur[w * N + k] += base;
+    }
+    __syncthreads();
+    if (tid == T - 1) carry = base + tot;                    // (the last thread's exclusive base + its own count = tile total)
+    __syncthreads();
+  }
+  if (b == last_cloud && tid == 0) ptr[(size_t)(b + 1) * N] = (b + 1) * P;
+  // (3) placement in row order
+  int *R = refs + (size_t)b * P;
+  for (int rb = r0; rb < r1; rb += 64) {                     // wave-uniform trip count
+    const int r = rb + lane;
+    const bool ok = r < r1;
+    unsigned k = ok ? (unsigned)I[r] : 0u;
+    k = k < (unsigned)N ? k : (unsigned)N - 1u;
+    u64 same = __ballot(ok);
+    for (int bit = 0; bit < nbits; ++bit) {
+      const bool set = (k >> bit) & 1u;
+      const u64 mb = __ballot(set);
+      same &= set ? mb : ~mb;
+    }
+    if (ok) {
+      const int rank = pn2_prefix_popc(same);
+      const int at = cur[wv * N + (int)k];
+      if (rank == 0) cur[wv * N + (int)k] = at + __popcll(same);
+      R[at + rank] = b * P + r;
+    }
+  }
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 inline int key_bits(size_t npoints) {
@@ -140,6 +227,7 @@ inline hipError_t sort_temp_bytes(size_t rows, int bits, size_t *bytes) {
 
 extern "C" size_t pn2_group_inverse_index_workspace_bytes(int B, int N, int m, int ns) {
   if (B <= 0 || N <= 0 || m <= 0 || ns <= 0) return 0;
+  if (N <= kInvLdsInts) return 256;                            // one-launch counting sort in LDS: no scratch (a token size)
   const size_t rows = (size_t)B * m * ns;
   size_t temp = 0;
   if (sort_temp_bytes(rows, key_bits((size_t)B * N), &temp) != hipSuccess) return 0;
@@ -157,10 +245,29 @@ extern "C" int pn2_group_inverse_index(int B, int N, int m, int ns, const int *i
   if (!idx || !refs || !workspace) return PN2_ENULL;
   const int bits = key_bits(npoints);
   size_t temp = 0;
-  if (sort_temp_bytes(rows, bits, &temp) != hipSuccess) return PN2_ELAUNCH;
   const size_t seg = align256(rows * 4);
   if ((((size_t)workspace) & 255) != 0) return PN2_EINVAL;
-  if (workspace_bytes < 3 * seg + align256(temp)) return PN2_ENOSPC;
+  if (N <= kInvLdsInts) {
+    if (workspace_bytes < 256) return PN2_ENOSPC;
+  } else {
+    if (sort_temp_bytes(rows, bits, &temp) != hipSuccess) return PN2_ELAUNCH;
+    if (workspace_bytes < 3 * seg + align256(temp)) return PN2_ENOSPC;
+  }
+  if (N <= kInvLdsInts) {
+    // one launch: a stable counting sort per cloud in LDS (inv_cloud_kernel); the workspace is not touched
+    const int P = m * ns;
+    int W = kInvLdsInts / N;
+    W = W > 16 ? 16 : W;
+    const int steps = (P + 63) / 64;                          // no more waves than 64-row steps
+    W = W > steps ? steps : W;
+    static bool lds_ok = hipFuncSetAttribute((const void *)inv_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             kInvLdsInts * 4) == hipSuccess;
+    if (lds_ok) {
+      hipLaunchKernelGGL(inv_cloud_kernel, dim3((unsigned)B), dim3(64u * W), (size_t)W * N * sizeof(int), (hipStream_t)stream, N,
+                         P, W, key_bits((size_t)N), B - 1, idx, ptr, refs);
+      return pn2_check_launch();
+    }
+  }
   unsigned *keys_in = (unsigned *)workspace;
   unsigned *keys_out = (unsigned *)((char *)workspace + seg);
   unsigned *vals_in = (unsigned *)((char *)workspace + 2 * seg);

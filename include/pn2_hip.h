@@ -628,7 +628,8 @@ int pn2_segment_sum_rows(int64_t E, int H, int64_t N, int lds, int col0,
 /* The feature-gradient scatter of QueryAndGroup as a gather (csrc/group_csr.hip; replaces the atomic form of
  * group_points_grad_kernel, src/group_points_gpu.cu:44-75, where a prefetched neighbourhood index is available).
  *   pn2_group_inverse_index : idx (B,m,ns) int32 -> refs (B*m*ns) = row ids (b*m + j)*ns + s sorted by
- *       (b*N + idx[row], row) [stable radix sort] and ptr (B*N + 1): refs[ptr[p] : ptr[p+1]] are the rows that gathered
+ *       (b*N + idx[row], row) [clouds of N <= 36864 points: ONE launch, a stable counting sort per cloud in LDS, idx values
+ *       clamped to [0, N); larger clouds: a stable radix sort] and ptr (B*N + 1): refs[ptr[p] : ptr[p+1]] are the rows that gathered
  *       point p = b*N + n.  `workspace`: 256-byte aligned device scratch of at least
  *       pn2_group_inverse_index_workspace_bytes(B, N, m, ns) bytes (PN2_ENOSPC if smaller); B*m*ns and B*N < 2^31.
  *   pn2_group_rows_grad_csr : grad_feats (B,N,C) = sum over refs of grad_out[row, col0 : col0+C]  (grad_out (rows, ldg)

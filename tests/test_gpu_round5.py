@@ -179,3 +179,25 @@ def test_ball_query_at_32_clouds_matches_the_oracle_on_four_of_them():
         assert torch.equal(idx2.cpu()[pick], ref)
         want = _ext.group_concat_rows(xyz.to(DEV), new_xyz, feats, idx2, True, True, r)
         assert torch.equal(rows.view_as(want)[pick], want[pick])
+
+
+# ------------------------------------------------------------------------------------------------ inverse index in one launch
+@pytest.mark.parametrize("B,N,m,ns", [(32, 2048, 1024, 32), (32, 1024, 512, 16), (32, 512, 256, 16), (72, 8000, 512, 32),
+                                      (9, 4000, 512, 16), (3, 36864, 100, 64), (2, 36865, 100, 64), (1, 1, 5, 3), (5, 7, 1, 1),
+                                      (4, 300, 3, 500), (2, 2048, 1024, 64)])
+def test_inverse_index_counting_sort_equals_a_stable_sort(B, N, m, ns):
+    g = torch.Generator().manual_seed(B * 1000 + N + m + ns)
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    idx[:, ::2, ns // 2:] = idx[:, ::2, :1]                           # ball-query style padding on half of the neighbourhoods
+    if B > 1:
+        idx[1] = 0                                                    # empty balls everywhere: ONE point holds every row of a cloud
+    idx[0, :, 0] = idx[0, 0, 0]                                       # a heavy point
+    ptr, refs = _ext.group_inverse_index(idx.to(DEV), N)
+    keys = (idx.long() + torch.arange(B).view(B, 1, 1) * N).flatten()
+    order = torch.sort(keys, stable=True).indices
+    assert torch.equal(refs.cpu().long(), order)
+    want_ptr = torch.zeros(B * N + 1, dtype=torch.long)
+    want_ptr[1:] = torch.cumsum(torch.bincount(keys, minlength=B * N), 0)
+    assert torch.equal(ptr.cpu().long(), want_ptr)
+    p2, r2 = _ext.group_inverse_index(idx.to(DEV), N)                 # deterministic
+    assert torch.equal(p2, ptr) and torch.equal(r2, refs)
