@@ -705,17 +705,27 @@ __global__ __launch_bounds__(256) void rows_gram_kernel(long long M, int K0, con
     for (int j = 0; j < 8; ++j) ds[i][j] = 0.0;
   }
   int n = 0;
-  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
-    float x[8];
+  // four rows in flight per thread (a row-at-a-time loop waits for one memory round trip per row: 64 rows per thread on
+  // one workgroup per CU were 61 us for 100 MB at the headline's SA1 — latency, not bandwidth)
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += 4 * stride) {
+    float xs[4][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = i < K0 ? X[(size_t)r * K0 + i] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const long long ru = r + u * stride;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      c[i] += x[i];
-#pragma unroll
-      for (int j = i; j < 8; ++j) s[i][j] = __fmaf_rn(x[i], x[j], s[i][j]);
+      for (int i = 0; i < 8; ++i) xs[u][i] = (i < K0 && ru < M) ? X[(size_t)ru * K0 + i] : 0.f;      // (a row past M adds zeros)
     }
-    if (++n == 64) {                               // bound the fp32 partial sums
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        c[i] += xs[u][i];
+#pragma unroll
+        for (int j = i; j < 8; ++j) s[i][j] = __fmaf_rn(xs[u][i], xs[u][j], s[i][j]);
+      }
+    }
+    if (++n == 16) {                               // bound the fp32 partial sums (64 rows)
       n = 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -796,7 +806,7 @@ extern "C" int pn2_rows_gram(long long M, int K0, const float *X, double *gram, 
   if (M < 0 || K0 < 1 || K0 > 8) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!X || !gram) return PN2_ENULL;
-  long long blocks = (M + 256 * 64 - 1) / (256 * 64);
+  long long blocks = (M + 256 * 16 - 1) / (256 * 16);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(rows_gram_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, K0, X, gram);
   return pn2_check_launch();

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "pn2_rows_max_grad": [_c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_three_interpolate_rows": [_c_int] * 6 + [_c_vp] * 5,
     "pn2_three_interpolate_rows_grad": [_c_int] * 6 + [_c_vp] * 5,
+    "pn2_three_interpolate_rows_grad_csr": [_c_int] * 6 + [_c_vp] * 6,
     "pn2_gather_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_scatter_add_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_segment_sum_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -886,10 +887,21 @@ def three_interpolate_rows(feats_rows, idx, weight, out=None, col0=0):
     return out
 
 
-def three_interpolate_rows_grad(grad_out, idx, weight, m, c, col0=0):
+def three_interpolate_rows_grad(grad_out, idx, weight, m, c, col0=0, inv=None):
+    """grad_out (B,n,ldg)[..., col0:col0+c] -> (B,m,c).  `inv` = group_inverse_index(idx, m): the atomic-free gather form
+    (every output row written, fixed summation order); without it three atomicAdds per element like the reference."""
     _f32(grad_out, "grad_out"); _i32(idx, "idx"); _f32(weight, "weight")
     _same_device((grad_out, "grad_out"), (idx, "idx"), (weight, "weight"))
     B, n, ldg = grad_out.shape
+    if inv is not None and int(c) % 4 == 0:
+        ptr, refs = inv
+        if ptr.numel() != B * int(m) + 1 or refs.numel() != idx.numel():
+            _fail("three_interpolate_rows_grad: inverse index does not belong to this idx")
+        out = torch.empty(B, int(m), int(c), dtype=torch.float32, device=grad_out.device)
+        _call("pn2_three_interpolate_rows_grad_csr", grad_out, B, int(c), int(m), n, ldg, int(col0), _ptr(grad_out), _ptr(weight),
+              _ptr(ptr), _ptr(refs), _ptr(out), alg_bytes=B * (4 * int(c) * n + 24 * n + 4 * int(c) * int(m)),
+              label="pn2_three_interpolate_rows_grad")
+        return out
     out = torch.zeros(B, int(m), int(c), dtype=torch.float32, device=grad_out.device)
     _call("pn2_three_interpolate_rows_grad", grad_out, B, int(c), int(m), n, ldg, int(col0),
           _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out),

@@ -455,8 +455,11 @@ class PointnetFPModule(nn.Module):
         return idx, recip / torch.sum(recip, dim=2, keepdim=True)
 
     def interpolation(self, unknown, known):
-        """Data-only part: (idx (B,n,3) int32, weight (B,n,3)) of the inverse-distance 3-NN interpolation."""
-        return self._weights(unknown, known)
+        """Data-only part: (idx (B,n,3) int32, weight (B,n,3), inverse of idx | None) of the inverse-distance 3-NN
+        interpolation.  The inverse index turns the backward's three atomicAdds per gradient element into a per-point sum
+        (csrc/interpolate.hip); it is data like idx, so a prefetched geometry carries it."""
+        idx, weight = self._weights(unknown, known)
+        return idx, weight, pointnet2_utils.interp_inverse(idx, known.size(1))
 
     def forward(self, unknown, known, unknow_feats, known_feats, interp=None):
         """unknown (B,n,3), known (B,m,3)|None, unknow_feats (B,C1,n)|None,
@@ -476,11 +479,14 @@ class PointnetFPModule(nn.Module):
         B, n = unknown.size(0), unknown.size(1)
         known_rows = pointnet2_utils.as_rows(known_feats)               # (B,m,C2)
         if known is not None:
-            idx, weight = interp if interp is not None else self._weights(unknown, known)
-            spread = pointnet2_utils.three_interpolate_rows(known_rows, idx, weight)
+            idx, weight, inv = (tuple(interp) + (None,))[:3] if interp is not None else self._weights(unknown, known) + (None,)
+            if inv is None and known_rows.requires_grad:
+                inv = pointnet2_utils.interp_inverse(idx, known.size(1))      # (not prefetched: built here, one launch)
+            spread = pointnet2_utils.interpolate_concat_rows(
+                known_rows, idx, weight, None if unknow_feats is None else pointnet2_utils.as_rows(unknow_feats), inv)
         else:
             spread = known_rows.expand(B, n, known_rows.size(2))
-        if unknow_feats is not None:
-            spread = torch.cat([spread, pointnet2_utils.as_rows(unknow_feats)], dim=2)
+            if unknow_feats is not None:
+                spread = torch.cat([spread, pointnet2_utils.as_rows(unknow_feats)], dim=2)
         h = mlp_rows(self.mlp, spread.reshape(B * n, -1))
         return pointnet2_utils.rows_to_channels(h.view(B, n, -1))

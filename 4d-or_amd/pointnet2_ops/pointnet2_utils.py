@@ -29,7 +29,8 @@ __all__ = [
     "FurthestPointSampling", "furthest_point_sample", "sample_centres", "GatherOperation", "gather_operation",
     "ThreeNN", "three_nn", "ThreeInterpolate", "three_interpolate", "GroupingOperation",
     "grouping_operation", "BallQuery", "ball_query", "QueryAndGroup", "GroupAll",
-    "group_concat_rows", "rows_max", "three_interpolate_rows", "as_rows", "rows_to_channels",
+    "group_concat_rows", "rows_max", "three_interpolate_rows", "interpolate_concat_rows", "interp_inverse", "as_rows",
+    "rows_to_channels",
 ]
 
 
@@ -261,6 +262,54 @@ class _ThreeInterpolateRows(Function):
 def three_interpolate_rows(feats_rows, idx, weight):
     """feats_rows (B,m,C), idx/weight (B,n,3) -> (B,n,C)."""
     return _ThreeInterpolateRows.apply(feats_rows.contiguous(), idx, weight)
+
+
+class _InterpolateConcatRows(Function):
+    """PointnetFPModule's `cat([three_interpolate(known_feats), unknow_feats])` (OPS/pointnet2_modules.py:197-204) on rows
+    as ONE node: the interpolation writes its columns of the (B, n, C2 + C1) result directly (no intermediate + concat
+    copy), the backward reads its columns of the incoming gradient in place and — given the inverse of `idx`
+    (`interp_inverse`) — sums them per known point without atomics."""
+
+    @staticmethod
+    def forward(ctx, known_rows, idx, weight, unknown_rows, inv):
+        B, m, C2 = known_rows.shape
+        n = idx.size(1)
+        C1 = 0 if unknown_rows is None else unknown_rows.size(2)
+        out = torch.empty(B, n, C2 + C1, dtype=known_rows.dtype, device=known_rows.device)
+        _ext.three_interpolate_rows(known_rows, idx, weight, out=out, col0=0)
+        if C1:
+            out[:, :, C2:].copy_(unknown_rows)
+        ctx.save_for_backward(idx, weight)
+        ctx.inv, ctx.m, ctx.c2, ctx.c1 = inv, m, C2, C1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gk = None
+        if ctx.needs_input_grad[0]:
+            gk = _ext.three_interpolate_rows_grad(g, idx, weight, ctx.m, ctx.c2, col0=0, inv=ctx.inv)
+        gu = g[:, :, ctx.c2:] if (ctx.c1 and ctx.needs_input_grad[3]) else None
+        return gk, None, None, gu, None
+
+
+def interp_inverse(idx, m):
+    """Inverse of a 3-NN index (B,n,3) into m known points — (ptr, refs) of group_inverse_index — where the backend
+    builds one (data only: goes next to idx / weight in a prefetched geometry)."""
+    build = getattr(_ext, "group_inverse_index", None)
+    if build is None or not idx.is_cuda:
+        return None
+    return tuple(build(idx, int(m)))
+
+
+def interpolate_concat_rows(known_rows, idx, weight, unknown_rows=None, inv=None):
+    """known_rows (B,m,C2), idx / weight (B,n,3), unknown_rows (B,n,C1) | None -> (B,n,C2+C1)."""
+    if getattr(_ext, "HAS_ROWS", False) and known_rows.is_cuda and known_rows.dtype == torch.float32 \
+            and (unknown_rows is None or unknown_rows.dtype == torch.float32):
+        return _InterpolateConcatRows.apply(known_rows.contiguous(), idx, weight, unknown_rows, inv)
+    spread = three_interpolate_rows(known_rows, idx, weight)
+    return spread if unknown_rows is None else torch.cat([spread, unknown_rows], dim=2)
 
 
 # ------------------------------------------------------------------- modules

@@ -336,6 +336,14 @@ int pn2_three_interpolate_rows_grad(int B, int C, int m, int n, int ldg,
                                     int col0, const float *grad_out,
                                     const int *idx, const float *weight,
                                     float *grad_feats, void *stream);
+/* The same gradient (EXT/src/interpolate_gpu.cu:120-154: three atomicAdds per gradient element) as a gather through the
+ * inverse of idx: (ptr, refs) = pn2_group_inverse_index(B, N = m, m' = n, ns = 3, idx) — flat slots (b n + j) 3 + t sorted
+ * by (known point, slot).  grad_feats (B, m, C) = sum over a point's slots, in slot order, of weight[slot] *
+ * grad_out[slot / 3][col0 : col0 + C]; EVERY output row is written (no zero fill), no atomics, bit-reproducible.
+ * C % 4 == 0, grad_feats 16-byte aligned. */
+int pn2_three_interpolate_rows_grad_csr(int B, int C, int m, int n, int ldg, int col0, const float *grad_out,
+                                        const float *weight, const int *ptr, const int *refs, float *grad_feats,
+                                        void *stream);
 
 
 /* ------------------------------------------------------------------ A10 ---

@@ -201,3 +201,53 @@ def test_inverse_index_counting_sort_equals_a_stable_sort(B, N, m, ns):
     assert torch.equal(ptr.cpu().long(), want_ptr)
     p2, r2 = _ext.group_inverse_index(idx.to(DEV), N)                 # deterministic
     assert torch.equal(p2, ptr) and torch.equal(r2, refs)
+
+
+# ------------------------------------------------------------------------------------------------ interpolation gradient as a gather
+@pytest.mark.parametrize("B,n,m,C,ldg,col0", [(32, 1024, 512, 256, 512, 0), (4, 512, 256, 256, 256, 0), (3, 100, 7, 64, 80, 12),
+                                              (2, 33, 1, 8, 8, 0), (2, 300, 40, 288, 300, 4)])
+def test_three_interpolate_rows_grad_csr_matches_the_atomic_form(B, n, m, C, ldg, col0):
+    g = torch.Generator().manual_seed(n + m + C)
+    idx = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    w = torch.rand(B, n, 3, generator=g).to(DEV)
+    go = torch.randn(B, n, ldg, generator=g).to(DEV)
+    inv = _ext.group_inverse_index(idx, m)
+    got = _ext.three_interpolate_rows_grad(go, idx, w, m, C, col0=col0, inv=inv)
+    want = _ext.three_interpolate_rows_grad(go, idx, w, m, C, col0=col0)
+    ref = torch.zeros(B, m, C, dtype=torch.float64, device=DEV)
+    src = (go[:, :, col0:col0 + C].double().unsqueeze(2) * w.double().unsqueeze(3)).reshape(B, n * 3, C)
+    ref.scatter_add_(1, idx.long().reshape(B, n * 3, 1).expand(-1, -1, C), src)
+    torch.testing.assert_close(got.double(), ref, atol=1e-4, rtol=1e-5)
+    torch.testing.assert_close(want.double(), ref, atol=1e-4, rtol=1e-5)
+    assert torch.equal(_ext.three_interpolate_rows_grad(go, idx, w, m, C, col0=col0, inv=inv), got)      # fixed order
+
+
+def test_fp_module_with_prefetched_interpolation_matches_the_oracle():
+    torch.manual_seed(3)
+    fp = pm.PointnetFPModule(mlp=[64 + 16, 32, 32]).to(DEV).train()
+    unknown, known = _unit_ball(2, 400, 1).to(DEV), _unit_ball(2, 90, 2).to(DEV)
+    uf = torch.randn(2, 16, 400, device=DEV, requires_grad=True)
+    kf = torch.randn(2, 64, 90, device=DEV, requires_grad=True)
+    interp = fp.interpolation(unknown, known)
+    assert len(interp) == 3 and interp[2] is not None
+    out = fp(unknown, known, uf, kf, interp=interp)
+    out.square().mean().backward()
+    g_u, g_k = uf.grad.clone(), kf.grad.clone()
+
+    import copy
+    fp_ref = copy.deepcopy(fp).cpu()
+    for p_ in fp_ref.parameters():
+        p_.grad = None
+    uf2, kf2 = uf.detach().cpu().requires_grad_(True), kf.detach().cpu().requires_grad_(True)
+    saved = pu._ext
+    pu._ext = oracle_ext.OracleRowsExt
+    try:
+        out_ref = fp_ref(unknown.cpu(), known.cpu(), uf2, kf2)
+        out_ref.square().mean().backward()
+    finally:
+        pu._ext = saved
+    torch.testing.assert_close(out.detach().cpu(), out_ref.detach(), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(g_u.cpu(), uf2.grad, atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(g_k.cpu(), kf2.grad, atol=1e-4, rtol=1e-3)
+    for a, b in zip(fp.parameters(), fp_ref.parameters()):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, atol=2e-4, rtol=1e-3)
