@@ -1089,14 +1089,26 @@ __global__ __launch_bounds__(128) void pool_bwd_setup_kernel(int N, int K, const
                                                             float *__restrict__ v, float *__restrict__ Wp) {
   const int j = blockIdx.x, k = threadIdx.x;             // grid K + 1 + N blocks, K threads
   if (k >= K) return;
+  // (four independent partial sums: as ONE chain the N dependent fp64 adds behind L2 loads were 60 us for a 128 x 128 matrix)
   if (j < K) {
-    double s = 0.0;
-    for (int n = 0; n < N; ++n) s += (double)consts[N + n] * (double)W[(size_t)n * K + j] * (double)W[(size_t)n * K + k];
-    G[j * K + k] = (float)s;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    int n = 0;
+    for (; n + 3 < N; n += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        s[u] += (double)consts[N + n + u] * (double)W[(size_t)(n + u) * K + j] * (double)W[(size_t)(n + u) * K + k];
+    }
+    for (; n < N; ++n) s[0] += (double)consts[N + n] * (double)W[(size_t)n * K + j] * (double)W[(size_t)n * K + k];
+    G[j * K + k] = (float)((s[0] + s[1]) + (s[2] + s[3]));
   } else if (j == K) {
-    double s = 0.0;
-    for (int n = 0; n < N; ++n) s += (double)consts[2 * N + n] * (double)W[(size_t)n * K + k];
-    v[k] = (float)s;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    int n = 0;
+    for (; n + 3 < N; n += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += (double)consts[2 * N + n + u] * (double)W[(size_t)(n + u) * K + k];
+    }
+    for (; n < N; ++n) s[0] += (double)consts[2 * N + n] * (double)W[(size_t)n * K + k];
+    v[k] = (float)((s[0] + s[1]) + (s[2] + s[3]));
   } else {
     const int n = j - K - 1;
     Wp[(size_t)n * K + k] = consts[n] * W[(size_t)n * K + k];
@@ -1130,8 +1142,12 @@ __global__ __launch_bounds__(128) void pool_bwd_assemble_kernel(int N, int K, co
   const int n = blockIdx.x, k = threadIdx.x;
   if (k >= K) return;
   const double *Z = red, *S = red + K * K, *T = red + K * K + K;
-  double wz = 0.0;
-  for (int j = 0; j < K; ++j) wz += (double)W[(size_t)n * K + j] * Z[j * K + k];
+  double w4[4] = {0.0, 0.0, 0.0, 0.0};                  // (K is 64 or 128: four independent chains, see the setup kernel)
+  for (int j = 0; j < K; j += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w4[u] += (double)W[(size_t)n * K + j + u] * Z[(j + u) * K + k];
+  }
+  const double wz = (w4[0] + w4[1]) + (w4[2] + w4[3]);
   dW[(size_t)n * K + k] =
       (float)((double)consts[n] * T[(size_t)n * K + k] + (double)consts[N + n] * wz + (double)consts[2 * N + n] * S[k]);
 }

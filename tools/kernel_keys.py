@@ -23,6 +23,9 @@ ENTRY_OF_FAMILY = {
     "fps_resident_kernel": "pn2_furthest_point_sampling", "fps_order_m_kernel": "pn2_furthest_point_sampling", "fps_order_check_kernel": "pn2_furthest_point_sampling", "fps_bucket_kernel": "pn2_furthest_point_sampling",
     "gcn_linear_kernel": "pn2_gcn_linear", "gcn_bn_bwd_kernel": "pn2_gcn_linear_grad_w", "gcn_wgrad_kernel": "pn2_gcn_linear_grad_w",
     "gcn_linear_grad_x_kernel": "pn2_gcn_linear_grad_x",
+    "inv_cloud_kernel": "pn2_group_inverse_index", "inv_keys_kernel": "pn2_group_inverse_index", "inv_ptr_kernel": "pn2_group_inverse_index",
+    "three_interpolate_rows_grad_csr_kernel": "pn2_three_interpolate_rows_grad", "three_interpolate_rows_grad_kernel": "pn2_three_interpolate_rows_grad",
+    "pool_bwd_prep_kernel": "pn2_pool_bwd_prep", "bn_relu_bwd_prep_kernel": "pn2_bn_relu_bwd_prep",
 }
 
 
@@ -44,6 +47,9 @@ def keys(name: str):
         # template <R, BF>: the bf16-row instantiations are launched by the _bf16 entry points
         bf = re.search(r"_kernel<\s*\d+,\s*true", name) is not None
         out.append("entry:" + ("pn2_group_lift_rows" if fam == "group_lift_rows_kernel" else "pn2_group_lift_rows_grad") + ("_bf16" if bf else ""))
+    elif fam == "prep_vec_kernel":
+        # template <POOLED>: true = pn2_pool_bwd_prep (and its segment-table form), false = pn2_bn_relu_bwd_prep
+        out.append("entry:" + ("pn2_pool_bwd_prep" if re.search(r"prep_vec_kernel<\s*true", name) else "pn2_bn_relu_bwd_prep"))
     elif fam in ENTRY_OF_FAMILY:
         out.append("entry:" + ENTRY_OF_FAMILY[fam])
     return out
