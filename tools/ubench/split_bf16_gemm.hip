@@ -147,6 +147,124 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(long long M, int K, 
   }
 }
 
+// ---- v2: the same product software-pipelined like the library's exact kernel -------------------------------------------
+// 512 threads = 8 waves (4 row blocks x 2 column blocks: a wave owns 32 rows x 64 columns), tile 128 x 128, K chunks of 32,
+// TWO LDS buffers: the registers of step s+1 (loaded while step s-1 ran) are split and written to the other buffer behind
+// the matrix instructions of step s, the loads of step s+2 are issued in front of them; one barrier per step; the
+// (tile, chunk) steps of a persistent workgroup form ONE pipeline (no drain between tiles).
+template <int P>
+__global__ __launch_bounds__(512, 2) void split_gemm_v2_kernel(long long M, int K, int N, const float *__restrict__ X,
+                                                              const unsigned *__restrict__ Wp, float *__restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];           // [2][P][(BM + BN) * AP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr_ = wave & 3, wc_ = wave >> 2;                           // row block / column block of this wave
+  const int n0 = blockIdx.y * BN;
+  const long long ntiles = (M + BM - 1) / BM;
+  const int nchunks = K / KC;
+  const size_t plane = (size_t)N * K / 2;
+  const int ar = tid >> 3, ak = (tid & 7) * 4;                         // A: rows ar, ar + 64; columns ak .. ak + 3
+  const int wn = tid >> 2, wk = (tid & 3) * 8;                         // W: row wn, columns wk .. wk + 7 (one 16-byte piece per plane)
+  auto sA = [&](int buf, int p) { return lds + ((size_t)(buf * P + p)) * ((BM + BN) * AP); };
+  auto sW = [&](int buf, int p) { return lds + ((size_t)(buf * P + p)) * ((BM + BN) * AP) + BM * AP; };
+  const long long my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  const long long total = my_tiles * nchunks;
+  long long l_tile = blockIdx.x;
+  int l_chunk = 0;
+  float4 ra[2];
+  u32x4 rw[P];
+  auto issue = [&]() {
+    const long long m0 = l_tile * BM;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long row = m0 + ar + 64 * i;
+      ra[i] = row < M ? *reinterpret_cast<const float4 *>(X + (size_t)row * K + l_chunk * KC + ak) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      rw[p] = *reinterpret_cast<const u32x4 *>(Wp + p * plane + ((size_t)(n0 + wn) * K + l_chunk * KC + wk) / 2);
+    if (++l_chunk == nchunks) { l_chunk = 0; l_tile += gridDim.x; if (l_tile >= ntiles) l_tile = blockIdx.x; }   // (surplus loads: harmless)
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned lo2[P], hi2[P];
+      split2<P>(ra[i].x, ra[i].y, lo2);
+      split2<P>(ra[i].z, ra[i].w, hi2);
+#pragma unroll
+      for (int p = 0; p < P; ++p) *reinterpret_cast<u32x2 *>(&sA(buf, p)[(ar + 64 * i) * AP + ak]) = u32x2{lo2[p], hi2[p]};
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4 *>(&sW(buf, p)[wn * AP + wk]) = rw[p];
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  issue();
+  commit(0);
+  issue();
+  __syncthreads();
+  long long c_tile = blockIdx.x;
+  int c_chunk = 0;
+  for (long long s = 0; s < total; ++s) {
+    const int buf = (int)(s & 1);
+    float4 na[2];
+    u32x4 nw[P];
+    // registers of step s+1 are in ra / rw; move them aside and issue step s+2
+#pragma unroll
+    for (int i = 0; i < 2; ++i) na[i] = ra[i];
+#pragma unroll
+    for (int p = 0; p < P; ++p) nw[p] = rw[p];
+    issue();
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+      bf16x8 af[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) af[p] = *(const bf16x8 *)&sA(buf, p)[(wr_ * 32 + (lane & 31)) * AP + ks * 16 + (lane >> 5) * 8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 bfr[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) bfr[p] = *(const bf16x8 *)&sW(buf, p)[((wc_ * 2 + t) * 32 + (lane & 31)) * AP + ks * 16 + (lane >> 5) * 8];
+#pragma unroll
+        for (int d = P - 1; d >= 0; --d)
+#pragma unroll
+          for (int i = 0; i <= d; ++i)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[d - i], acc[t], 0, 0, 0);
+      }
+    }
+    // step s+1 -> the other buffer (its readers finished at the previous barrier)
+    {
+      float4 keep[2];
+      u32x4 keepw[P];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { keep[i] = ra[i]; ra[i] = na[i]; }
+#pragma unroll
+      for (int p = 0; p < P; ++p) { keepw[p] = rw[p]; rw[p] = nw[p]; }
+      commit(buf ^ 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ra[i] = keep[i];
+#pragma unroll
+      for (int p = 0; p < P; ++p) rw[p] = keepw[p];
+    }
+    if (++c_chunk == nchunks) {
+      const long long m0 = c_tile * BM;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long row = m0 + wr_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < M) Y[(size_t)row * N + n0 + (wc_ * 2 + t) * 32 + (lane & 31)] = acc[t][r];
+          acc[t][r] = 0.f;
+        }
+      c_chunk = 0;
+      c_tile += gridDim.x;
+    }
+    __syncthreads();
+  }
+}
+
 typedef int (*gemm_fn)(long long, int, int, int, int, const float *, const float *, const float *, const float *, const float *,
                        const int *, const float *, int, const float *, float *, double *, const float *, const float *, void *);
 
@@ -187,7 +305,7 @@ static float time_ms(F f, int reps) {
   return ms / reps;
 }
 
-template <int P>
+template <int P, bool V2 = false>
 static void run_split(const char *name, long long M, int K, int N, const float *dX, const float *dW, float *dY, unsigned *dWp,
                       const std::vector<float> &X, const std::vector<float> &W, int nsample) {
   const int total2 = N * K / 2;
@@ -196,7 +314,14 @@ static void run_split(const char *name, long long M, int K, int N, const float *
   const unsigned ny = (unsigned)(N / BN);
   unsigned gx = 512 / ny;                                    // two workgroups per CU
   if (gx > ntiles) gx = (unsigned)ntiles;
-  auto f = [&]() { hipLaunchKernelGGL(split_gemm_kernel<P>, dim3(gx, ny), dim3(256), 0, 0, M, K, N, dX, dWp, dY); };
+  const size_t lds2 = (size_t)2 * P * (BM + BN) * AP * sizeof(bf16);
+  unsigned gx2 = 256 / ny;                                   // v2: one 8-wave workgroup per CU (two LDS buffers)
+  if (gx2 > ntiles) gx2 = (unsigned)ntiles;
+  if (V2) CK(hipFuncSetAttribute((const void *)split_gemm_v2_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+  auto f = [&]() {
+    if (V2) hipLaunchKernelGGL(split_gemm_v2_kernel<P>, dim3(gx2, ny), dim3(512), lds2, 0, M, K, N, dX, dWp, dY);
+    else hipLaunchKernelGGL(split_gemm_kernel<P>, dim3(gx, ny), dim3(256), 0, 0, M, K, N, dX, dWp, dY);
+  };
   const float ms = time_ms(f, 20);
   CK(hipGetLastError());
   std::vector<float> Yh((size_t)nsample * N);
@@ -252,6 +377,8 @@ int main(int argc, char **argv) {
       fflush(stdout);
     }
     run_split<3>("split3_bf16x6 (hi+mid+lo, six products)", M, K, N, dX, dW, dY, dWp, X, W, nsample);
+    run_split<3, true>("split3_bf16x6 v2 (pipelined, two LDS buffers)", M, K, N, dX, dW, dY, dWp, X, W, nsample);
+    run_split<1, true>("bf16x1 v2 (rate reference)", M, K, N, dX, dW, dY, dWp, X, W, nsample);
     run_split<2>("split2_bf16x3 (hi+lo, three products)", M, K, N, dX, dW, dY, dWp, X, W, nsample);
     run_split<1>("bf16x1 (one product: rate reference)", M, K, N, dX, dW, dY, dWp, X, W, nsample);
     CK(hipFree(dX)); CK(hipFree(dW)); CK(hipFree(dY)); CK(hipFree(dWp));
