@@ -134,7 +134,7 @@ def train_step(model, opt, pc, geometry=None, between=None, sync=None):
     # layout the rows path produced it in (`feats` is a transposed view): the same number, and the gradient comes back
     # in that layout instead of through torch's strided element-wise kernels + a 33 MB transposing copy (round 4 trace:
     # 53 + 52 us of the step were this synthetic loss's layout, not the path under test)
-    loss = feats.transpose(1, 2).square().mean()
+    loss = (feats.transpose(1, 2) if feats.dim() == 3 else feats).square().mean()
     nxt = between() if between is not None else None     # hook between forward and backward
     loss.backward()
     if sync is not None:
@@ -299,10 +299,10 @@ def roofline_of(top, pmc_applies=True, pmc_files=None):
     bf16 = "bf16" in top["kernel"]
     # newest committed counter summary of the command first (tools/profile_round.sh + tools/summarise_profile.py); the
     # fp32 and the bf16 default commands have their own files
-    files = ((("r04_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6),
+    files = ((("r05_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r04_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6),
               ("r02_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6))
              if bf16 else
-             (("r04_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_counters.json", "hbm_MB_per_launch", 1e6),
+             (("r05_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r04_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_counters.json", "hbm_MB_per_launch", 1e6),
               ("r02_backbone_counters.json", "hbm_MB_per_launch", 1e6),
               ("r01_hbm_traffic_per_kernel.json", "hbm_bytes_per_launch", 1.0)))
     if pmc_files is not None:
@@ -558,8 +558,10 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
             out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
             if main_rows:
                 # the one scene-graph command with committed counter passes (tools/profile_round.sh r04_sgp8_bf16 ...)
-                own = (["r04_sgp8_bf16_counters.json", "r03_sgp8_bf16_counters.json"] if (S == 8 and args.dtype == "bf16" and model.per_scan_statistics
-                                                           and not args.with_prep and world == 1) else None)
+                own = None
+                if S == 8 and model.per_scan_statistics and not args.with_prep and world == 1:
+                    own = (["r05_sgp8_bf16_counters.json", "r04_sgp8_bf16_counters.json", "r03_sgp8_bf16_counters.json"]
+                           if args.dtype == "bf16" else ["r05_sgp8_f32_counters.json"])
                 out["roofline"] = roofline_of(main_rows[0], False, own)
         emit_json(out, args)
     if distributed:
