@@ -689,7 +689,7 @@ extern "C" int pn2_ball_query(int B, int N, int m, float radius, int nsample,
 //   PN2_BQ_SCAN  : index-order scan with early exit — no workspace; small clouds, very crowded balls (short walks);
 //   PN2_BQ_CELLS : one cell list per cloud + rank sort — sparse balls, nsample <= 256 (round 2; by name only);
 //   PN2_BQ_SLABS : one cell list per 2048-index slab + bit-mask order — everything whose scan would walk >= 3072 points.
-// Results are identical whichever runs.  Measurements: DESIGN.md 4c.
+// Results are identical whichever runs.  Measurements: profiles/HISTORY.md 4c.
 namespace {
 bool bq_radius_ok(float radius) { return radius > 0.f && radius < 3.0e38f; }
 
@@ -704,7 +704,7 @@ size_t bq_cells_bytes(int B, int N, int nsample) {
 }
 
 // The scan walks L = N min(1, nsample / E) points per centre (E = N r^3: estimated hits per ball), the slab walk visits
-// ceil(L / 2048) slabs at a roughly constant price each: measured crossover L ~ 3000 (tools/bq_bench.py).
+// ceil(L / 2048) slabs at a roughly constant price each: measured crossover L ~ 3000 (tools/bq_bench.py, profiles/HISTORY.md 4c).
 // The per-cloud cell list is never the automatic choice any more (the slabs match or beat it on every measured shape but
 // one); it stays available by name.
 int bq_auto(int B, int N, int m, float radius, int nsample) {

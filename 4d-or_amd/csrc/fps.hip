@@ -1386,7 +1386,7 @@ FpsPlan fps_plan(int B, int N, int m, bool few_cus = false, bool fewest = false,
   if (want_hybrid && h.mode == 3) return h;
 
   // bucketed: one workgroup per cloud, 64 S records per bucket, at most 1024 buckets.  Chosen where a cluster would be
-  // (clouds beyond 16k points): 32 x 50k -> 2048 in 3.x ms on 32 CUs against 5.3 ms on 128 / 7.3 ms on 64
+  // (clouds beyond 16k points): 32 x 50k -> 2048 in 3.x ms on 32 CUs against 5.3 ms on 128 / 7.3 ms on 64 (profiles/HISTORY.md 4c)
   FpsPlan k = {-1, 1, 1024, 0, 1};
   {
     int S = 1;

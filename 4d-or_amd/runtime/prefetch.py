@@ -2,7 +2,7 @@
 
 The sampling / grouping geometry of a batch (FPS chains, ball queries, 3-NN weights) involves no parameters, so the
 loop can enqueue it for batch i+1 on a side HIP stream before it enqueues the optimisation step of batch i; the
-latency-bound sampling kernels then co-run with the MFMA kernels of the step (DESIGN.md section 4d).  The result is
+latency-bound sampling kernels then co-run with the MFMA kernels of the step (DESIGN.md 4d).  The result is
 handed to the model as ``batch["geometry"]`` — identical numbers, the work is only moved.
 
 Reference behaviour replaced: the DataLoader worker of scene_graph_prediction/main.py:54-56 prepares the next scan on

@@ -648,7 +648,7 @@ def main():
     net, sync = model, None
     if distributed and args.grad_sync == "ddp":
         # gradients only: one flat bucket (650k params = 2.6 MB, latency-bound over xGMI)
-        # BatchNorm statistics stay per rank (no SyncBN: the reference is single-GPU, DESIGN.md section 6), so the running
+        # BatchNorm statistics stay per rank (no SyncBN: the reference is single-GPU, DESIGN.md section 8), so the running
         # buffers are not re-broadcast from rank 0 before every forward either
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=64,
                                                         gradient_as_bucket_view=True, broadcast_buffers=False)

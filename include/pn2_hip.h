@@ -111,13 +111,13 @@ long long pn2_fps_status_offset_ex(int B, int N, int m, int flags);
 int pn2_fps_set_plan_override(int mode, int G, int NC, int coop_bs, int bs);
 /* Cluster variants with >= 8 point slots per lane first bin the cloud into spatially compact groups of 64 x slots points
  * (one extra launch, records in the workspace) so that a wave can skip a round's distance updates when the new sample is
- * farther from its bounding box than its largest running distance.  Test / measurement hook: 0 switches
+ * farther from its bounding box than its largest running distance (profiles/HISTORY.md 4c).  Test / measurement hook: 0 switches
  * that off.  Process-global; results never depend on it. */
 int pn2_fps_set_bucketing(int on);
 int pn2_fps_get_bucketing(void);   /* the current value (1 / 0), so that a scoped override can restore it */
 /* Clouds of cluster size (16k < N <= 106k points) run on two or four 1024-thread workgroups that exchange the arg-max
  * candidates of all 64 sub-blobs of the binned cloud per hand-off and accept SEVERAL samples from them whenever the next
- * ones are provably the reference's.  Measurement hook: 0 restores one sample per hand-off.
+ * ones are provably the reference's (profiles/HISTORY.md 4c, round 4).  Measurement hook: 0 restores one sample per hand-off.
  * Process-global; results never depend on it. */
 int pn2_fps_set_multi(int on);
 int pn2_fps_get_multi(void);

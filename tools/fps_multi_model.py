@@ -1,4 +1,4 @@
-"""Numpy model of the several-samples-per-hand-off rule of the cluster FPS (csrc/fps.hip, fps_multi_kernel): how
+"""Numpy model of the several-samples-per-hand-off rule of the cluster FPS (csrc/fps.hip, fps_multi_kernel; profiles/HISTORY.md 4c): how
 many samples can be accepted from ONE exchange of per-sub-blob candidates, with exact FPS as the referee.  CPU only.
 
 Two rules on a spatially binned 50k-point unit-ball cloud (16^3 Morton cells like fps_bucket_kernel), 2048 samples:
