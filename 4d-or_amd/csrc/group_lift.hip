@@ -631,3 +631,57 @@ extern "C" int pn2_group_lift_rows_grad_seg(int B, int N, int m, int ns, int N0,
   return lift_rows_grad_launch(B, N, m, ns, N0, normalize, radius, xyz, new_xyz, G, g_bf16 != 0, P, Wx, consts, ptr, refs, S_out,
                                acc, workspace, workspace_bytes, stream, seg, nseg, max_clouds);
 }
+
+// ---- the lifted layer's weight in pieces / its gradient in one piece (round 5) ------------------------------------------------
+// The first conv's weight W (N0, 3 + C) is used as Wx = W[:, :3] (coordinate columns), Wf = W[:, 3:] (per-point product) and
+// Wf^T (input gradient): three strided torch copies per level and direction became ONE launch in the forward, reused by the
+// backward.  The weight gradient dW = [dWx + c2 Wx RR | dWf] was a 3 x 3 vendor GEMM + addcmul + cat: one launch.
+namespace {
+__global__ __launch_bounds__(256) void lift_split_weight_kernel(int N0, int C, const float *__restrict__ W, float *__restrict__ Wx,
+                                                               float *__restrict__ Wf, float *__restrict__ WfT) {
+  const int K0 = C + 3;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < N0 * K0; e += gridDim.x * 256) {
+    const int n = e / K0, k = e - n * K0;
+    const float v = W[e];
+    if (k < 3) Wx[n * 3 + k] = v;
+    else { Wf[(size_t)n * C + (k - 3)] = v; WfT[(size_t)(k - 3) * N0 + n] = v; }
+  }
+}
+
+__global__ __launch_bounds__(256) void lift_dw_assemble_kernel(int N0, int C, const float *__restrict__ acc,
+                                                              const float *__restrict__ Wx, const float *__restrict__ c2,
+                                                              const float *__restrict__ dWf, float *__restrict__ dW) {
+  const int K0 = C + 3;
+  const float *RR = acc + 3 * N0;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < N0 * K0; e += gridDim.x * 256) {
+    const int n = e / K0, k = e - n * K0;
+    float v;
+    if (k < 3) {
+      const float t = __fmaf_rn(Wx[n * 3 + 2], RR[6 + k], __fmaf_rn(Wx[n * 3 + 1], RR[3 + k], __fmul_rn(Wx[n * 3], RR[k])));
+      v = __fmaf_rn(c2[n], t, acc[n * 3 + k]);
+    } else {
+      v = dWf[(size_t)n * C + (k - 3)];
+    }
+    dW[e] = v;
+  }
+}
+}  // namespace
+
+extern "C" int pn2_lift_split_weight(int N0, int C, const float *W, float *Wx, float *Wf, float *WfT, void *stream) {
+  if (N0 <= 0 || C <= 0) return PN2_EINVAL;
+  if (!W || !Wx || !Wf || !WfT) return PN2_ENULL;
+  const int total = N0 * (C + 3);
+  hipLaunchKernelGGL(lift_split_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N0, C, W, Wx,
+                     Wf, WfT);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_lift_dw_assemble(int N0, int C, const float *acc, const float *Wx, const float *c2, const float *dWf, float *dW,
+                                    void *stream) {
+  if (N0 <= 0 || C <= 0) return PN2_EINVAL;
+  if (!acc || !Wx || !c2 || !dWf || !dW) return PN2_ENULL;
+  const int total = N0 * (C + 3);
+  hipLaunchKernelGGL(lift_dw_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N0, C, acc, Wx,
+                     c2, dWf, dW);
+  return pn2_check_launch();
+}

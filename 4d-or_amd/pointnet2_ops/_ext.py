@@ -80,6 +80,8 @@ _SIGNATURES = {
     "pn2_three_interpolate_rows": [_c_int] * 6 + [_c_vp] * 5,
     "pn2_three_interpolate_rows_grad": [_c_int] * 6 + [_c_vp] * 5,
     "pn2_three_interpolate_rows_grad_csr": [_c_int] * 6 + [_c_vp] * 6,
+    "pn2_lift_split_weight": [_c_int] * 2 + [_c_vp] * 5,
+    "pn2_lift_dw_assemble": [_c_int] * 2 + [_c_vp] * 6,
     "pn2_gather_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_scatter_add_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_segment_sum_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -781,6 +783,25 @@ def group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, radius, stats=None, out
           _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(P), _ptr(Wx), _ptr(Y), _ptr(stats),
           alg_bytes=B * (4 * m * ns + 12 * N + 12 * m + 4 * N0 * N + (2 if out_bf16 else 4) * N0 * m * ns))
     return Y
+
+
+def lift_split_weight(W):
+    """W (N0, 3 + C) -> (Wx (N0,3), Wf (N0,C), WfT (C,N0)), one launch (pn2_lift_split_weight)."""
+    _f32(W, "W")
+    N0, K0 = W.shape
+    C = K0 - 3
+    buf = torch.empty(N0 * 3 + 2 * N0 * C, dtype=torch.float32, device=W.device)
+    Wx, Wf, WfT = buf[:N0 * 3].view(N0, 3), buf[N0 * 3:N0 * 3 + N0 * C].view(N0, C), buf[N0 * 3 + N0 * C:].view(C, N0)
+    _call("pn2_lift_split_weight", W, N0, C, _ptr(W), _ptr(Wx), _ptr(Wf), _ptr(WfT))
+    return Wx, Wf, WfT
+
+
+def lift_dw_assemble(acc, Wx, c2, dWf):
+    """dW (N0, 3 + C) = [acc[:3 N0] + diag(c2) Wx RR | dWf], one launch (pn2_lift_dw_assemble)."""
+    N0, C = dWf.shape
+    dW = torch.empty(N0, C + 3, dtype=torch.float32, device=dWf.device)
+    _call("pn2_lift_dw_assemble", dWf, N0, C, _ptr(acc), _ptr(Wx), _ptr(c2), _ptr(dWf), _ptr(dW))
+    return dW
 
 
 def group_lift_rows_grad(G, P, Wx, consts, xyz, new_xyz, inv, ns, normalize, radius, acc):

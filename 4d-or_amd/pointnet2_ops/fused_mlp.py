@@ -298,6 +298,7 @@ class _FusedMLP(Function):
         if ns:
             saved += [out, arg, yraw]
             ctx.mark_non_differentiable(arg)
+            ctx.set_materialize_grads(False)       # (no zeros_like(arg) — an int32 (R, C) fill per stack — for the index output)
         # (a piece of the shared zero slab: its version counter moves with every in-place op on a sibling piece, so it
         # travels as an attribute like the geometry tensors, not through save_for_backward)
         ctx.gram = gram
@@ -356,18 +357,17 @@ class _FusedMLP(Function):
                 xyz, new_xyz, idx, _u, normalize, radius = ctx.group[:6]
                 N0 = Ws[0].size(0)
                 inv = ctx.group[6] if (len(ctx.group) > 6 and ctx.group[6] is not None) else ctx.lift_inv
-                Wx = Ws[0][:, :3].contiguous()
-                S = e.group_lift_rows_grad(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2), normalize,
+                lift_P, Wx, WfT = ctx.lift_P
+                consts = consts.contiguous()
+                S = e.group_lift_rows_grad(G, lift_P, Wx, consts, xyz, new_xyz, inv, idx.size(2), normalize,
                                            radius, arena[-1]).view(-1, N0)
-                # dWx: the kernel left out c2 Wx RR (RR = sum_r rel rel^T is only complete after the launch)
-                dWx = torch.addcmul(arena[-1][:3 * N0].view(N0, 3), torch.mm(Wx, arena[-1][3 * N0:].view(3, 3)),
-                                    consts[1].unsqueeze(1))
                 # dWf = S^T f and dL/df = S Wf over the B N points, on the library's own kernels (a vendor GEMM picks a
                 # 32 x 32 tile for the 128 x 128 x 65 536 reduction: 0.18 ms; pn2_mlp_wgrad is built for long reductions)
                 dWf = e.mlp_wgrad(S, _unit_consts(S.device, N0), x.view(-1, K0 - 3), e.PRO_GY, e.PRO_NONE, G=S)
-                grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
+                # dW = [dWx + c2 Wx RR | dWf]: the kernel left out c2 Wx RR (RR = sum_r rel rel^T is only complete after the launch)
+                grads[0] = e.lift_dw_assemble(arena[-1], Wx, consts[1], dWf).view(ctx.shapes[0])
                 if need_dgrad0:
-                    gx = e.mlp_gemm(S, Ws[0][:, 3:].t().contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(ctx.feat_shape)
+                    gx = e.mlp_gemm(S, WfT, pro=e.PRO_NONE, epi=e.EPI_NONE).view(ctx.feat_shape)
                     dst = getattr(ctx, "gx_out", None)       # (a segmented call: this scan's slice of the batch's gradient)
                     if dst is not None:
                         gx = dst.copy_(gx)
@@ -468,10 +468,19 @@ def _lift_forward_scans(e, feats, W, group, stat_blocks, seg):
     xyz, new_xyz, idx, _use_xyz, normalize, radius = group[:6]
     B, N, C = feats.shape
     N0 = W.size(0)
-    P = e.mlp_gemm(feats.view(B * N, C), W[:, 3:].contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
+    Wx, Wf, WfT = _lift_weights(e, W)
+    P = e.mlp_gemm(feats.view(B * N, C), Wf, pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
     per = idx.size(1) * idx.size(2)
-    Y = e.group_lift_rows_seg(P, xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stat_blocks, seg, out_bf16=True)
-    return Y, P
+    Y = e.group_lift_rows_seg(P, xyz, new_xyz, idx, Wx, normalize, radius, stat_blocks, seg, out_bf16=True)
+    return Y, (P, Wx, WfT)
+
+
+def _lift_weights(e, W):
+    """(Wx, Wf, Wf^T) of the lifted layer's weight: one launch where the library has it, three strided copies otherwise."""
+    W = W.contiguous()
+    if getattr(e, "lift_split_weight", None) is not None and W.is_cuda:
+        return e.lift_split_weight(W)
+    return W[:, :3].contiguous(), W[:, 3:].contiguous(), W[:, 3:].t().contiguous()
 
 
 def _lift_forward(e, feats, W, group, stats, out_bf16=False):
@@ -480,9 +489,11 @@ def _lift_forward(e, feats, W, group, stats, out_bf16=False):
     xyz, new_xyz, idx, _use_xyz, normalize, radius = group[:6]
     B, N, C = feats.shape
     # (the library's own fp32-MFMA GEMM: bit-reproducible from call to call, which a vendor GEMM's kernel choice is not)
-    P = e.mlp_gemm(feats.view(B * N, C), W[:, 3:].contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
-    # (P travels to the backward as an attribute: 1/16 of y0's size, and the backward recomputes y0 from it)
-    return e.group_lift_rows(P, xyz, new_xyz, idx, W[:, :3].contiguous(), normalize, radius, stats=stats, out_bf16=out_bf16), P
+    Wx, Wf, WfT = _lift_weights(e, W)
+    P = e.mlp_gemm(feats.view(B * N, C), Wf, pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
+    # (P travels to the backward as an attribute: 1/16 of y0's size, and the backward recomputes y0 from it; the weight's
+    # pieces ride along: the parameters do not change between a step's forward and its backward)
+    return e.group_lift_rows(P, xyz, new_xyz, idx, Wx, normalize, radius, stats=stats, out_bf16=out_bf16), (P, Wx, WfT)
 
 
 class _FusedMLPBf16(Function):
@@ -597,6 +608,7 @@ class _FusedMLPBf16(Function):
         if ns:
             saved += [out, arg, yraw]
             ctx.mark_non_differentiable(arg)
+            ctx.set_materialize_grads(False)       # (no zeros_like(arg) — an int32 (R, C) fill per stack — for the index output)
         ctx.save_for_backward(*saved)
         return (out, arg) if ns else out
 
@@ -650,7 +662,7 @@ class _FusedMLPBf16(Function):
                 xyz, new_xyz, idx, _u, normalize, radius = ctx.group[:6]
                 N0, Kf = Ws[0].size(0), Ws[0].size(1) - 3
                 inv = ctx.group[6] if (len(ctx.group) > 6 and ctx.group[6] is not None) else ctx.lift_inv
-                Wx = Ws[0][:, :3].contiguous()
+                lift_P, Wx, WfT = ctx.lift_P
                 if seg is not None:
                     # per-scan constants, one launch sequence per scan on that scan's points (the whole batch's gradient
                     # rows, centres and row ids are indexed in place)
@@ -659,22 +671,23 @@ class _FusedMLPBf16(Function):
                     Bq, Nq = xyz.size(0), xyz.size(1)
                     per = idx.size(1) * idx.size(2)
                     accs = e.zero_arena(x.device, [((seg.nseg, 3 * N0 + 9), f32)])[0]
-                    S = e.group_lift_rows_grad_seg(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2),
+                    S = e.group_lift_rows_grad_seg(G, lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2),
                                                    normalize, radius, accs, seg)
                     S = S.view(-1, N0)
                     RR = accs[:, 3 * N0:].view(seg.nseg, 3, 3)
                     dWx = accs[:, :3 * N0].view(seg.nseg, N0, 3).sum(0) + torch.einsum("sn,nk,skj->nj", consts[:, 1], Wx, RR)
+                    dWf = e.mlp_wgrad(S, _unit_consts(S.device, N0), x.view(-1, Kf), e.PRO_GY, e.PRO_NONE, G=S)
+                    grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
                 else:
                     consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[0], fins[0], ctx.batch_flags[0])
                     grads[1], grads[2] = dgamma, dbeta
-                    S = e.group_lift_rows_grad(G, ctx.lift_P, Wx, consts.contiguous(), xyz, new_xyz, inv, idx.size(2), normalize,
+                    consts = consts.contiguous()
+                    S = e.group_lift_rows_grad(G, lift_P, Wx, consts, xyz, new_xyz, inv, idx.size(2), normalize,
                                                radius, arena[-1]).view(-1, N0)
-                    dWx = torch.addcmul(arena[-1][:3 * N0].view(N0, 3), torch.mm(Wx, arena[-1][3 * N0:].view(3, 3)),
-                                        consts[1].unsqueeze(1))
-                dWf = e.mlp_wgrad(S, _unit_consts(S.device, N0), x.view(-1, Kf), e.PRO_GY, e.PRO_NONE, G=S)
-                grads[0] = torch.cat([dWx, dWf], dim=1).view(ctx.shapes[0])
+                    dWf = e.mlp_wgrad(S, _unit_consts(S.device, N0), x.view(-1, Kf), e.PRO_GY, e.PRO_NONE, G=S)
+                    grads[0] = e.lift_dw_assemble(arena[-1], Wx, consts[1], dWf).view(ctx.shapes[0])
                 if need_dgrad0:
-                    gx = e.mlp_gemm(S, Ws[0][:, 3:].t().contiguous(), pro=e.PRO_NONE, epi=e.EPI_NONE).view(ctx.feat_shape)
+                    gx = e.mlp_gemm(S, WfT, pro=e.PRO_NONE, epi=e.EPI_NONE).view(ctx.feat_shape)
                     dst = getattr(ctx, "gx_out", None)
                     if dst is not None:
                         gx = dst.copy_(gx)
@@ -750,6 +763,9 @@ class _SegCtx:
         self.saved_tensors = tensors
 
     def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
         pass
 
 
@@ -917,6 +933,7 @@ class _SegmentedGroupMLP(Function):
         _update_running_stats(layers, fin_bufs, [n * m * ns for n in sizes])
         out, arg = torch.cat(outs, 0), torch.cat(args, 0)
         ctx.mark_non_differentiable(arg)
+        ctx.set_materialize_grads(False)       # (no zeros_like(arg) — an int32 (R, C) fill per stack — for the index output)
         return out, arg
 
     @staticmethod
@@ -985,6 +1002,7 @@ class _SegTableMLP(Function):
                                        for (_, bn), F in zip(layers, sub.saved_tensors[1 + L:1 + 2 * L])], list(rows_per_scan))
         ctx.sub, ctx.inner = sub, inner
         ctx.mark_non_differentiable(arg)
+        ctx.set_materialize_grads(False)       # (no zeros_like(arg) — an int32 (R, C) fill per stack — for the index output)
         return out, arg
 
     @staticmethod

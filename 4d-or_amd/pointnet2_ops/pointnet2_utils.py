@@ -231,6 +231,7 @@ class _RowsMax(Function):
         ctx.save_for_backward(arg)
         ctx.ns = x.size(1)
         ctx.mark_non_differentiable(arg)
+        ctx.set_materialize_grads(False)
         return out, arg
 
     @staticmethod

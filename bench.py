@@ -124,6 +124,21 @@ class FlatGradSync:
             self.flat.all_reduce_mean()
 
 
+class _MeanSquare(torch.autograd.Function):
+    """mean(x^2) of the synthetic loss as ONE node: the composite `x.square().mean()` costs the backward three full-size
+    element-wise launches (expand / divide, times two, times x) for what is x * (2 g / n)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return x.square().mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return x * (g * (2.0 / x.numel()))
+
+
 def train_step(model, opt, pc, geometry=None, between=None, sync=None):
     if sync is not None:
         sync.zero()
@@ -134,7 +149,7 @@ def train_step(model, opt, pc, geometry=None, between=None, sync=None):
     # layout the rows path produced it in (`feats` is a transposed view): the same number, and the gradient comes back
     # in that layout instead of through torch's strided element-wise kernels + a 33 MB transposing copy (round 4 trace:
     # 53 + 52 us of the step were this synthetic loss's layout, not the path under test)
-    loss = (feats.transpose(1, 2) if feats.dim() == 3 else feats).square().mean()
+    loss = _MeanSquare.apply(feats.transpose(1, 2) if feats.dim() == 3 else feats)
     nxt = between() if between is not None else None     # hook between forward and backward
     loss.backward()
     if sync is not None:

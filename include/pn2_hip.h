@@ -286,6 +286,15 @@ int pn2_group_lift_rows_grad(int B, int N, int m, int ns, int N0, int normalize,
                              const float *new_xyz, const float *G, const float *P, const float *Wx, const float *consts,
                              const int *ptr, const int *refs, float *S, float *acc, void *workspace,
                              size_t workspace_bytes, void *stream);
+/* The lifted layer's weight W (N0, 3 + C) in the pieces the kernels take — Wx (N0, 3) = W[:, :3], Wf (N0, C) = W[:, 3:],
+ * WfT (C, N0) = Wf^T (the input-gradient GEMM's weight) — in one launch, and its gradient in one piece:
+ * dW (N0, 3 + C) = [acc[:3 N0] + diag(c2) Wx RR | dWf] with acc = pn2_group_lift_rows_grad's (3 N0 + 9) result (RR = its last
+ * nine floats) and c2 = row 1 of the BatchNorm-backward constants.  Both replace strided torch copies / a 3 x 3 vendor GEMM +
+ * addcmul + cat around the first Conv2d of OPS/pointnet2_modules.py:9-19. */
+int pn2_lift_split_weight(int N0, int C, const float *W, float *Wx, float *Wf, float *WfT, void *stream);
+int pn2_lift_dw_assemble(int N0, int C, const float *acc, const float *Wx, const float *c2, const float *dWf, float *dW,
+                         void *stream);
+
 size_t pn2_group_lift_rows_grad_workspace_bytes(int B, int N, int m, int ns, int N0);
 /* The same pair for the mixed-precision stacks (round 4): Y (B m ns, N0) bf16 (rounded to nearest even; `stats` are the
  * column sums of the rounded values, the convention of pn2_mlp_gemm_bf16) and G (M, N0) bf16 (what pn2_mlp_bwd_bf16 /
