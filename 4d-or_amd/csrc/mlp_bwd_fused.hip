@@ -705,19 +705,21 @@ __global__ __launch_bounds__(256) void rows_gram_kernel(long long M, int K0, con
     for (int j = 0; j < 8; ++j) ds[i][j] = 0.0;
   }
   int n = 0;
-  // four rows in flight per thread (a row-at-a-time loop waits for one memory round trip per row: 64 rows per thread on
-  // one workgroup per CU were 61 us for 100 MB at the headline's SA1 — latency, not bandwidth)
+  // eight rows in flight per thread, at most 256 workgroups: every workgroup ends with 42 fp64 atomics onto the SAME 42
+  // addresses, and same-address atomics retire one per ~35 ns at the L2 (1024 workgroups: 36 us of the kernel's 76 were the
+  // queue in front of gram[0]); a row-at-a-time loop on the other hand waits for one memory round trip per row
+  constexpr int RU = 8;
   const long long stride = (long long)gridDim.x * 256;
-  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += 4 * stride) {
-    float xs[4][8];
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += RU * stride) {
+    float xs[RU][8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < RU; ++u) {
       const long long ru = r + u * stride;
 #pragma unroll
       for (int i = 0; i < 8; ++i) xs[u][i] = (i < K0 && ru < M) ? X[(size_t)ru * K0 + i] : 0.f;      // (a row past M adds zeros)
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < RU; ++u) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         c[i] += xs[u][i];
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(256) void rows_gram_kernel(long long M, int K0, con
         for (int j = i; j < 8; ++j) s[i][j] = __fmaf_rn(xs[u][i], xs[u][j], s[i][j]);
       }
     }
-    if (++n == 16) {                               // bound the fp32 partial sums (64 rows)
+    if (++n == 8) {                                // bound the fp32 partial sums (64 rows)
       n = 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -807,7 +809,7 @@ extern "C" int pn2_rows_gram(long long M, int K0, const float *X, double *gram, 
   if (M == 0) return PN2_OK;
   if (!X || !gram) return PN2_ENULL;
   long long blocks = (M + 256 * 16 - 1) / (256 * 16);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(rows_gram_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, K0, X, gram);
   return pn2_check_launch();
 }
