@@ -517,7 +517,6 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
         const float sg = (POOLE && a.sgn) ? a.sgn[col] : 1.f;
         atomicAdd(a.stats + col, (double)(red[0][i] * sg));
         atomicAdd(a.stats + N + col, (double)red[1][i]);
-
       }
     }
   }
