@@ -1129,6 +1129,85 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_prep_bf16_kernel(long long M,
   }
 }
 
+// The same with four columns per thread (8-byte bf16 / 16-byte fp32 accesses), four rows in flight and at most 256 blocks whose
+// 2 N sums leave through LDS as consecutive doubles — prep_vec_kernel of csrc/mlp_gemm.hip (round 5) for bf16 rows: the
+// 16-row blocks above end with 2 N same-address fp64 atomics each, which, not the rows, was the kernel's time (66 us at the
+// FP shapes of the backbone).
+constexpr int kPrepBlocksBf = 256;
+__host__ __device__ inline long long prep_vec_rpb_bf(long long R, int C) {
+  const long long unit = (long long)(256 / (C / 4)) * 4;
+  const long long want = (R + kPrepBlocksBf - 1) / kPrepBlocksBf;
+  return (want + unit - 1) / unit * unit;
+}
+__global__ __launch_bounds__(256) void prep_vec_bf16_kernel(long long M, int N, long long rpb, const bf16 *__restrict__ y,
+                                                           const float *__restrict__ gout, const float *__restrict__ fin,
+                                                           bf16 *__restrict__ gpre, double *__restrict__ sums) {
+  __shared__ float4 part[2][256];
+  const long long r0 = (long long)blockIdx.x * rpb;
+  if (r0 >= M) return;
+  const long long r1 = r0 + rpb < M ? r0 + rpb : M;
+  const int C4 = N >> 2;
+  const int groups = 256 / C4;
+  const int grp = threadIdx.x / C4, c4 = threadIdx.x - grp * C4;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (grp < groups) {
+    const float4 mean = reinterpret_cast<const float4 *>(fin)[c4], rstd = reinterpret_cast<const float4 *>(fin + N)[c4];
+    const float4 sc = reinterpret_cast<const float4 *>(fin + 2 * N)[c4], sh = reinterpret_cast<const float4 *>(fin + 3 * N)[c4];
+    const float ma[4] = {mean.x, mean.y, mean.z, mean.w}, ra[4] = {rstd.x, rstd.y, rstd.z, rstd.w};
+    const float sca[4] = {sc.x, sc.y, sc.z, sc.w}, sha[4] = {sh.x, sh.y, sh.z, sh.w};
+    const uint2 *Y = reinterpret_cast<const uint2 *>(y) + c4;
+    const float4 *G = reinterpret_cast<const float4 *>(gout) + c4;
+    uint2 *O = reinterpret_cast<uint2 *>(gpre) + c4;
+    for (long long r = r0 + grp; r < r1; r += 4 * groups) {
+      uint2 yv[4];
+      float4 gv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long row = r + (long long)u * groups;
+        ok[u] = row < r1;
+        const size_t o = (size_t)(ok[u] ? row : r) * C4;
+        yv[u] = Y[o];
+        gv[u] = G[o];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const float ya[4] = {bf_lo(yv[u].x), bf_hi(yv[u].x), bf_lo(yv[u].y), bf_hi(yv[u].y)};
+        const float ga[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+        float oa[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g = bf_round(fmaf(ya[j], sca[j], sha[j]) > 0.f ? ga[j] : 0.f);
+          oa[j] = g;
+          s1[j] += g;
+          s2[j] = fmaf(g, (ya[j] - ma[j]) * ra[j], s2[j]);
+        }
+        O[(size_t)(r + (long long)u * groups) * C4] = uint2{bf_pack(oa[0], oa[1]), bf_pack(oa[2], oa[3])};
+      }
+    }
+  }
+  part[0][threadIdx.x] = float4{s1[0], s1[1], s1[2], s1[3]};
+  part[1][threadIdx.x] = float4{s2[0], s2[1], s2[2], s2[3]};
+  __syncthreads();
+  float4 t1 = part[0][threadIdx.x], t2 = part[1][threadIdx.x];
+  if (grp == 0) {
+    for (int q = 1; q < groups; ++q) {
+      const float4 a = part[0][threadIdx.x + q * C4], b = part[1][threadIdx.x + q * C4];
+      t1.x += a.x; t1.y += a.y; t1.z += a.z; t1.w += a.w;
+      t2.x += b.x; t2.y += b.y; t2.z += b.z; t2.w += b.w;
+    }
+  }
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(&part[0][0]);
+  if (grp == 0) {
+    reinterpret_cast<float4 *>(red)[c4] = t1;
+    reinterpret_cast<float4 *>(red + N)[c4] = t2;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * N; t += 256) atomicAdd(sums + t, (double)red[t]);
+}
+
 // ReLU(BN(y)) + max over groups of ns rows (+ first arg-max, + raw value there): y bf16 -> fp32 / int32 (R, C)
 __global__ __launch_bounds__(256) void bn_relu_rows_max_bf16_kernel(size_t total /* R*C/2 */, int ns, int C,
                                                                    const bf16 *__restrict__ y,
@@ -1612,6 +1691,12 @@ extern "C" int pn2_bn_relu_bwd_prep_bf16(long long M, int N, const void *y, cons
   if (M < 0 || N <= 0) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!y || !gout || !fin || !gpre || !sums) return PN2_ENULL;
+  if (N % 4 == 0 && N / 4 <= 256 && ((((uintptr_t)y) | ((uintptr_t)gpre)) & 7) == 0 && ((((uintptr_t)gout) | ((uintptr_t)fin)) & 15) == 0) {
+    const long long rpbv = prep_vec_rpb_bf(M, N);
+    hipLaunchKernelGGL(prep_vec_bf16_kernel, dim3((unsigned)((M + rpbv - 1) / rpbv)), dim3(256), 0, (hipStream_t)stream, M, N, rpbv,
+                       (const bf16 *)y, gout, fin, (bf16 *)gpre, sums);
+    return pn2_check_launch();
+  }
   // rows per block as in pn2_bn_relu_bwd_prep (csrc/mlp_gemm.hip): 16 up to 64k rows, then ~4096 blocks
   int rpb = kPrepRowsBf;
   if (M > 65536) rpb = (int)(((M + 4095) / 4096 + kPrepRowsBf - 1) / kPrepRowsBf * kPrepRowsBf);
