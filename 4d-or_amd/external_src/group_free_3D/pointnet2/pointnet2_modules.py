@@ -50,7 +50,7 @@ class PointnetSAModuleVotes(nn.Module):
         # the grouped rows as well where it covers them (pn2_ball_query_group), next to idx
         rows = None
         if feats_rows is not None and self.pooling == "max":
-            idx, rows = _pm._query_maybe_fused(self.grouper, xyz, new_xyz, feats_rows)
+            idx, rows = _pm._query_maybe_fused(self.grouper, xyz, new_xyz, feats_rows, data_features=True)
         else:
             idx = self.grouper.query(xyz, new_xyz)
         inv = _pm.build_inverse_indices([self.grouper], [idx], xyz.size(1))[0] if inverse_index else None

@@ -513,6 +513,8 @@ class _FusedMLPBf16(Function):
             ctx.feat_shape = None if x is None else tuple(x.shape)
             k_in = (3 if use_xyz else 0) + (0 if x is None else x.size(2))
             pre = getattr(ctx, "x_rows", None)          # a segmented call groups the whole batch once and hands in the rows
+            if pre is None and len(group) > 8 and group[8] is not None and group[8].dtype == torch.bfloat16:
+                pre = group[8]                           # bf16 rows grouped next to the ball query (prefetched geometry)
             # first layer before the grouping, as on the fp32 node (csrc/group_lift.hip): per-point products in fp32, y0 and
             # the gradient rows in bf16 — no grouped tensor, no M-row first-layer GEMMs, no feature-gradient scatter
             has_inv = len(group) > 6 and group[6] is not None
@@ -898,7 +900,8 @@ class _SegmentedGroupMLP(Function):
         if lift_all:
             rows_all = None
         elif inner is _FusedMLPBf16:
-            rows_all = e.group_concat_rows_bf16(xyz, new_xyz, feats, idx, use_xyz, normalize, radius)
+            pre16 = group[8] if (len(group) > 8 and group[8] is not None and group[8].dtype == torch.bfloat16) else None
+            rows_all = pre16 if pre16 is not None else e.group_concat_rows_bf16(xyz, new_xyz, feats, idx, use_xyz, normalize, radius)
         elif len(group) > 8 and group[8] is not None:
             rows_all = group[8]                         # emitted by the fused query + grouping kernel
         else:
@@ -1057,9 +1060,18 @@ def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz,
     # last layer runs without its output tensor (csrc/pool_bwd.hip)
     if rows is not None:
         width = (3 if use_xyz else 0) + (0 if feats_rows is None else feats_rows.size(2))
-        if tuple(rows.shape) != (B, m, ns, width) or rows.dtype != torch.float32 or rows.device != idx.device:
+        if rows.dtype == torch.bfloat16:
+            # bf16 rows (pitch rounded up to 8 columns) grouped next to the ball query for the bf16 node; another node
+            # (the arithmetic was switched in between) groups for itself
+            if tuple(rows.shape) != (B, m, ns, (width + 7) // 8 * 8) or rows.device != idx.device:
+                raise RuntimeError(f"fused_group_mlp_pool: pre-grouped bf16 rows must be ({B}, {m}, {ns}, pad8({width})) on {idx.device}")
+            if _node(layers, ns) is not _FusedMLPBf16:
+                rows = None
+        elif tuple(rows.shape) != (B, m, ns, width) or rows.dtype != torch.float32 or rows.device != idx.device:
             raise RuntimeError(f"fused_group_mlp_pool: pre-grouped rows must be fp32 ({B}, {m}, {ns}, {width}) on {idx.device}")
-        rows = rows.contiguous()
+        elif _node(layers, ns) is _FusedMLPBf16:
+            rows = None                                   # (fp32 rows are of no use to the bf16 node)
+        rows = None if rows is None else rows.contiguous()
     # rows: the grouped rows (B, m, ns, [3+]C) fp32 if the query kernel already emitted them (pn2_ball_query_group)
     group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius, inv, crowded,
              None if rows is None else rows.detach())

@@ -201,13 +201,24 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
     return mlp_pool_rows(mlp, grouper.forward_rows(xyz, new_xyz, feats_rows))
 
 
-def _query_maybe_fused(grouper, xyz, new_xyz, feats_rows):
+def _query_maybe_fused(grouper, xyz, new_xyz, feats_rows, data_features=False):
     """(idx, rows | None) for a fused-MLP SA scale: the ball query and — where one kernel can do both (first levels: rows of
-    at most 16 floats, fp32 arithmetic) — the grouped rows from the same pass (pn2_ball_query_group)."""
+    at most 16 floats, fp32 arithmetic) — the grouped rows from the same pass (pn2_ball_query_group).
+    `data_features`: `feats_rows` is input data without a gradient (a prefetched geometry of a first level): on the bf16
+    node the grouped bf16 rows are then produced right here too (pn2_group_concat_rows_bf16) — next to the query, i.e. on
+    the prefetch stream, instead of in front of the stack's first GEMM on the critical path."""
     from pointnet2_ops import fused_mlp
+    _ext = pointnet2_utils._ext
     if fused_mlp.mlp_dtype() == torch.float32 and grouper.fused_query_ok(xyz, new_xyz, feats_rows):
         return grouper.query_rows(xyz, new_xyz, feats_rows)
-    return grouper.query(xyz, new_xyz), None
+    idx = grouper.query(xyz, new_xyz)
+    if (data_features and fused_mlp.mlp_dtype() == torch.bfloat16 and feats_rows is not None and xyz.is_cuda
+            and not grouper.sample_uniformly and feats_rows.size(2) < 16 and getattr(_ext, "group_concat_rows_bf16", None)):
+        with torch.no_grad():
+            rows = _ext.group_concat_rows_bf16(xyz, new_xyz, feats_rows.detach().contiguous(), idx, grouper.use_xyz,
+                                               grouper.normalize_xyz, grouper.radius)
+        return idx, rows
+    return idx, None
 
 
 class RowsSource:
@@ -334,7 +345,7 @@ class _PointnetSAModuleBase(nn.Module):
             elif feats_rows is not None:
                 # `feats_rows` (B,N,C): the level's input features are DATA (colours / masks of the input cloud, no
                 # gradient) -> the grouped rows can be produced right here, by the query kernel itself where it covers them
-                i, r = _query_maybe_fused(g, xyz, new_xyz, feats_rows)
+                i, r = _query_maybe_fused(g, xyz, new_xyz, feats_rows, data_features=True)
                 idx.append(i), rows.append(r)
             else:
                 idx.append(g.query(xyz, new_xyz)), rows.append(None)

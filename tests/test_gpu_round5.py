@@ -251,3 +251,32 @@ def test_fp_module_with_prefetched_interpolation_matches_the_oracle():
     torch.testing.assert_close(g_k.cpu(), kf2.grad, atol=1e-4, rtol=1e-3)
     for a, b in zip(fp.parameters(), fp_ref.parameters()):
         torch.testing.assert_close(a.grad.cpu(), b.grad, atol=2e-4, rtol=1e-3)
+
+
+def test_bf16_first_level_takes_the_rows_grouped_next_to_the_query():
+    """bf16 node: a prefetched geometry of a level whose features are data carries the grouped bf16 rows; same result as
+    grouping inside the stack (the same kernel on the same operands), and dropped when the arithmetic is fp32."""
+    from pointnet2_ops import fused_mlp
+    torch.manual_seed(1)
+    sa = pm.PointnetSAModule(mlp=[3, 32, 64], npoint=256, radius=0.3, nsample=32).to(DEV).train()
+    xyz = _unit_ball(3, 5000, 9).to(DEV)
+    feats_rows = torch.rand(3, 5000, 3, device=DEV)
+    features = feats_rows.transpose(1, 2)
+    prev = fused_mlp.set_mlp_dtype(torch.bfloat16)
+    try:
+        geo = sa.sample_and_query(xyz, feats_rows=feats_rows)
+        assert geo["rows"][0] is not None and geo["rows"][0].dtype == torch.bfloat16
+        with torch.no_grad():
+            _, a = sa(xyz, features, geometry=geo)
+            _, b = sa(xyz, features)
+        assert torch.equal(a, b)
+        out = sa(xyz, features, geometry=geo)[1]
+        out.square().mean().backward()                                   # the backward runs with the prefetched rows
+        assert all(torch.isfinite(p_.grad).all() for p_ in sa.parameters())
+        fused_mlp.set_mlp_dtype(torch.float32)
+        with torch.no_grad():
+            _, c = sa(xyz, features, geometry=geo)                       # bf16 rows are of no use to the fp32 node
+            _, d = sa(xyz, features)
+        torch.testing.assert_close(c, d, atol=1e-5, rtol=1e-5)          # (batch statistics through fp64 atomics: last-bit noise)
+    finally:
+        fused_mlp.set_mlp_dtype(prev)
