@@ -685,3 +685,158 @@ extern "C" int pn2_lift_dw_assemble(int N0, int C, const float *acc, const float
                      c2, dWf, dW);
   return pn2_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The lifted first layer WITHOUT its output tensor (round 5).  With the coordinate term split between the point and the
+// centre,
+//     y0[b, j, s, :] = Wx (x[idx] - c_j) / r + (Wf f)[idx] = Pq[b, idx[b, j, s]] - Q[b, j],
+//     Pq[b, n] = Wf f[b, n] + Wx x[b, n] / r   (B N rows),      Q[b, j] = Wx c[b, j] / r   (B m rows),
+// a row of y0 is ONE gathered row of Pq minus a per-centre row: cheap enough to re-form inside the consumers — the GEMM of the
+// layer above (mlp_gemm.hip PRO_LIFT), its weight gradient (pn2_mlp_wgrad_lift) and the mask / BatchNorm-backward sums of
+// its input gradient (EPI_MASKL) — so the (B m ns, N0) tensor (537 MB at the headline's SA2, written once and read three
+// times) is never stored.  What is left of the forward here is the BatchNorm statistics of y0: pn2_group_lift_stats gathers
+// like pn2_group_lift_rows but writes only the row ids (cloud offset included) the consumers index Pq with.
+// y0 is the same real number as before, rounded differently (the coordinate products are subtracted after the multiplication,
+// not before: |Wx x / r| eps ~ 1e-7 against 1e-4 asked of the features); the backward of the layer itself
+// (pn2_group_lift_rows_grad) is linear in y0 and keeps its own form.
+namespace {
+__global__ __launch_bounds__(256) void lift_points_kernel(int npoints, int ncentres, int N0, int normalize, float radius,
+                                                          const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                          const float *__restrict__ P, const float *__restrict__ Wx,
+                                                          float *__restrict__ Pq, float *__restrict__ Q) {
+  const int q4 = N0 >> 2;
+  const long long total = (long long)(npoints + ncentres) * q4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int row = (int)(e / q4), l = (int)(e - (long long)row * q4);
+    const bool pt = row < npoints;
+    const float *src = pt ? xyz + (size_t)row * 3 : new_xyz + (size_t)(row - npoints) * 3;
+    float x = src[0], y = src[1], z = src[2];
+    if (normalize) { x = __fdiv_rn(x, radius); y = __fdiv_rn(y, radius); z = __fdiv_rn(z, radius); }
+    f4v base = f4v{0.f, 0.f, 0.f, 0.f};
+    if (pt) base = *reinterpret_cast<const f4v *>(P + (size_t)row * N0 + 4 * l);
+    f4v o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float *w = Wx + (size_t)(4 * l + c) * 3;
+      o[c] = __fmaf_rn(w[2], z, __fmaf_rn(w[1], y, __fmaf_rn(w[0], x, base[c])));
+    }
+    float *dst = pt ? Pq + (size_t)row * N0 + 4 * l : Q + (size_t)(row - npoints) * N0 + 4 * l;
+    *reinterpret_cast<f4v *>(dst) = o;
+  }
+}
+
+struct LiftStatArgs {
+  const int *idx;        // (B, m, ns)
+  const float *Pq;       // (B N, N0)
+  const float *Q;        // (B m, N0)
+  int *gidx;             // (B m ns)   b N + idx: the row of Pq every grouped row reads
+  double *stats;         // (2, N0) += column sums of y0, y0^2
+  int N, m, ns, N0, centres, chunks;
+};
+
+// the walk of group_lift_rows_kernel (a wave per centre, XCD-aware order), reading only
+template <int R>
+__global__ __launch_bounds__(kLiftBlock) void group_lift_stats_kernel(const LiftStatArgs a) {
+  constexpr int LPR = 64 / R;
+  __shared__ float red[2][4][4 * LPR];
+  const int lane = pn2_lane(), wv = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const int N0 = a.N0, ns = a.ns;
+  const bool live = 4 * l < N0;
+  f4v s1 = f4v{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  const int per = (a.chunks + 7) >> 3;
+  const int nwg = gridDim.x >> 3;
+  for (int ck = (int)(blockIdx.x >> 3); ck < per; ck += nwg) {
+    const int chunk = (int)(blockIdx.x & 7) * per + ck;
+    const int g = chunk * 4 + wv;
+    if (chunk >= a.chunks || g >= a.centres) continue;       // wave-uniform
+    const int b = (int)((unsigned)g / (unsigned)a.m);
+    const float *Pb = a.Pq + (size_t)b * a.N * N0;
+    const int *row_idx = a.idx + (size_t)g * ns;
+    f4v q = f4v{0.f, 0.f, 0.f, 0.f};
+    if (live) q = *reinterpret_cast<const f4v *>(a.Q + (size_t)g * N0 + 4 * l);
+    for (int s0 = 0; s0 < ns; s0 += 64) {
+      const int cnt = ns - s0 < 64 ? ns - s0 : 64;
+      int mi = 0;
+      if (lane < cnt) {
+        mi = row_idx[s0 + lane];
+        a.gidx[(size_t)g * ns + s0 + lane] = b * a.N + mi;
+      }
+      for (int t = 0; t * R < cnt; t += 4) {
+        f4v v[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = (t + u) * R + sub;
+          const int pi = __shfl(mi, i & 63);
+          ok[u] = i < cnt && live;
+          v[u] = f4v{0.f, 0.f, 0.f, 0.f};
+          if (ok[u]) v[u] = *reinterpret_cast<const f4v *>(Pb + (size_t)pi * N0 + 4 * l);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!ok[u]) continue;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float y = __fsub_rn(v[u][c], q[c]);
+            s1[c] = __fadd_rn(s1[c], y);
+            s2[c] = __fmaf_rn(y, y, s2[c]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= LPR; d >>= 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      s1[c] = __fadd_rn(s1[c], __shfl_xor(s1[c], d));
+      s2[c] = __fadd_rn(s2[c], __shfl_xor(s2[c], d));
+    }
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { red[0][wv][4 * l + c] = s1[c]; red[1][wv][4 * l + c] = s2[c]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * N0; c += kLiftBlock) {
+    const int which = c >= N0, col = which ? c - N0 : c;
+    const double t = (double)red[which][0][col] + (double)red[which][1][col] + (double)red[which][2][col] +
+                     (double)red[which][3][col];
+    atomicAdd(a.stats + (size_t)which * N0 + col, t);
+  }
+}
+}  // namespace
+
+extern "C" int pn2_lift_points(int B, int N, int m, int N0, int normalize, float radius, const float *xyz, const float *new_xyz,
+                               const float *P, const float *Wx, float *Pq, float *Q, void *stream) {
+  if (B < 0 || N < 0 || m < 0 || !lift_shape_ok(N0) || (normalize && !(radius > 0.f))) return PN2_EINVAL;
+  const long long np = (long long)B * N, nc = (long long)B * m;
+  if (np + nc == 0) return PN2_OK;
+  if (np + nc >= 0x7fffffffLL) return PN2_EINVAL;
+  if (!xyz || !new_xyz || !P || !Wx || !Pq || !Q) return PN2_ENULL;
+  if ((((uintptr_t)P) | ((uintptr_t)Pq) | ((uintptr_t)Q)) & 15) return PN2_EINVAL;
+  const long long total = (np + nc) * (N0 >> 2);
+  long long grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(lift_points_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (int)np, (int)nc, N0,
+                     normalize ? 1 : 0, radius, xyz, new_xyz, P, Wx, Pq, Q);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_group_lift_stats(int B, int N, int m, int ns, int N0, const int *idx, const float *Pq, const float *Q,
+                                    int *gidx, double *stats, void *stream) {
+  if (B < 0 || N < 0 || m < 0 || ns < 0 || !lift_shape_ok(N0)) return PN2_EINVAL;
+  const long long centres = (long long)B * m;
+  if (centres == 0 || ns == 0) return PN2_OK;
+  if (centres > 0x7fffffffLL - 64 || (long long)B * N >= 0x7fffffffLL || centres * ns >= 0x7fffffffLL) return PN2_EINVAL;
+  if (!idx || !Pq || !Q || !gidx || !stats) return PN2_ENULL;
+  if ((((uintptr_t)Pq) | ((uintptr_t)Q)) & 15) return PN2_EINVAL;
+  const LiftStatArgs a{idx, Pq, Q, gidx, stats, N, m, ns, N0, (int)centres, (int)((centres + 3) / 4)};
+  const dim3 grid((unsigned)lift_fwd_grid(centres)), block(kLiftBlock);
+  hipStream_t s = (hipStream_t)stream;
+  if (N0 <= 64) hipLaunchKernelGGL((group_lift_stats_kernel<4>), grid, block, 0, s, a);
+  else if (N0 <= 128) hipLaunchKernelGGL((group_lift_stats_kernel<2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((group_lift_stats_kernel<1>), grid, block, 0, s, a);
+  return pn2_check_launch();
+}

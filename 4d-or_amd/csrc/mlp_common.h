@@ -6,8 +6,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_GY = 2, PRO_POOLG = 3, PRO_FIRST = 4 };
-enum { EPI_NONE = 0, EPI_STATS = 1, EPI_MASK = 2, EPI_POOL = 3 };
+enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_GY = 2, PRO_POOLG = 3, PRO_FIRST = 4, PRO_LIFT = 5 };
+enum { EPI_NONE = 0, EPI_STATS = 1, EPI_MASK = 2, EPI_POOL = 3, EPI_MASKL = 4 };
 
 // ---- raw buffer access (gfx950) ------------------------------------------------
 // Every global access of the GEMM goes through a buffer descriptor built from wave-uniform

@@ -19,10 +19,15 @@
 //     PRO_POOLG   same, with g gathered from the pooled gradient through the arg-max
 //     PRO_FIRST   relu((X0 W0^T) * p0[k] + p1[k])    = the stack's FIRST layer recomputed from its <= 8-column input rows
 //                                                      X0 [M][K0] (the grouped xyz / colour rows): y_0 is never stored
+//     PRO_LIFT    relu((Pq[gidx[row]][k] - Q[row / ns][k]) * p0[k] + p1[k])
+//                                                    = a LIFTED first layer (group_lift.hip) re-formed from its per-point
+//                                                      products: y_0 = Pq[point] - Q[centre] is never stored either; the
+//                                                      rows of Pq (a cloud's share: 1 MB at the headline's SA2) come out of L2
 //   epilogue:
 //     EPI_STATS   column sums of out and out^2 (fp64 atomics)  -> BatchNorm batch statistics
 //     EPI_MASK    out *= [BN(yprev) > 0]; column sums of out and out * yhat_prev
 //                                                             -> ReLU backward + BN-backward reductions
+//     EPI_MASKL   EPI_MASK with yprev[row] = Pq[gidx[row]] - Q[row / ns] (the lifted first layer below, not stored)
 //     EPI_POOL    column sums as EPI_STATS, and per group of `ns` consecutive rows the maximum of every column
 //                 with its row index; `out` is NOT stored (the max-pooled last layer of an SA stack: BatchNorm with
 //                 a positive scale and ReLU are monotone, so max(relu(bn(y))) = relu(bn(max y)); columns with a
@@ -65,6 +70,11 @@ struct GemmArgs {
   // PRO_FIRST: X = X0 [M][K0] (input rows of the stack), W0 [K][K0] (first layer's weight), p0 / p1 = its BatchNorm scale / shift
   const float *W0;
   int K0;
+  // PRO_LIFT / EPI_MASKL: X (PRO_LIFT) resp. Yprev (EPI_MASKL) = Pq [lrows][K resp. N] per-point products incl. the coordinate
+  // term, lidx [M] row of Pq every grouped row reads (cloud offset included), lQ [M/ns][K resp. N] per-centre term
+  const int *lidx;
+  const float *lQ;
+  long long lrows;
 };
 
 constexpr int BM = 128;
@@ -90,8 +100,11 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   constexpr int APT = BM * KC / THREADS;       // A elements per thread per chunk
   constexpr int WPT = NTT * 32 * KC / THREADS; // W elements per thread per chunk
   constexpr int RSTEP = THREADS / KC;          // rows covered by one pass of the workgroup
-  constexpr bool MASKE = EPI == EPI_MASK;
+  constexpr bool MASKL = EPI == EPI_MASKL;     // EPI_MASK whose previous layer is a lifted first layer (gathered, not stored)
+  constexpr bool MASKE = EPI == EPI_MASK || MASKL;
   constexpr bool TWO = PRO == PRO_GY;          // second A matrix (y) needed
+  constexpr bool LIFT = PRO == PRO_LIFT;       // A rows gathered from the per-point products, minus the per-centre term
+  constexpr bool RB = TWO || LIFT;             // a second value per A element rides the ring
   constexpr bool POOL = PRO == PRO_POOLG;      // dense c2*y+c3 from ONE matrix + sparse arg-max patch in LDS
   __shared__ float As[2][BM * LD];
   __shared__ float Ws[2][NTT * 32 * LD];
@@ -174,9 +187,26 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   constexpr int PGR = POOL ? (((BM / 16 + 1) * KC + THREADS - 1) / THREADS) : 1;   // supports ns >= 16
   const long long ngroups = POOL ? (M + a.ns - 1) / a.ns : 0;
 
-  float ra0[ARN], rb0[TWO ? APT : 1], rw0[WPT], pg0[PGR];
-  float ra1[ARN], rb1[TWO ? APT : 1], rw1[WPT], pg1[PGR];
+  float ra0[ARN], rb0[RB ? APT : 1], rw0[WPT], pg0[PGR];
+  float ra1[ARN], rb1[RB ? APT : 1], rw1[WPT], pg1[PGR];
   int pa0[PGR], pa1[PGR];
+
+  // PRO_LIFT: pass i of thread (r0, kk) stages row r0 + RSTEP i of the tile: its row of Pq (gi, loaded one step ahead) and
+  // its centre's row of Q — group (r0 + RSTEP i) / ns of the tile = r0 / ns + (RSTEP i) / ns (ns and RSTEP powers of two,
+  // ns >= 16; BM % ns == 0: checked by the caller), the second term wave-uniform
+  int gi[LIFT ? APT : 1];
+  int qstep[LIFT ? APT : 1];
+  const long long lgroups = LIFT ? (M + a.ns - 1) / a.ns : 0;
+  const int qoff = LIFT ? ((r0 / a.ns) * K + kk) * 4 : 0;
+  if (LIFT) {
+    const long long fm0 = (long long)blockIdx.x * BM;
+    const rsrc_t rsi = make_rsrc(a.lidx + fm0, (M - fm0) * 4);
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      gi[LIFT ? i : 0] = bload_i(rsi, r0 * 4, i * RSTEP * 4);
+      qstep[LIFT ? i : 0] = ((RSTEP * i) / a.ns) * K * 4;
+    }
+  }
 
   // (tile, chunk) cursors: L = next step to LOAD, S = next step to STORE to LDS, C = step computed.
   // Past the end the L/S cursors stay on the last tile: the surplus loads / LDS writes are
@@ -184,7 +214,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   long long l_tile = blockIdx.x, s_tile = blockIdx.x, c_tile = blockIdx.x;
   int l_chunk = 0, s_chunk = 0, c_chunk = 0;
 
-  auto load_step = [&](float (&ra)[ARN], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int (&pa)[PGR],
+  auto load_step = [&](float (&ra)[ARN], float (&rb)[RB ? APT : 1], float (&rw)[WPT], int (&pa)[PGR],
                        float (&pg)[PGR]) {
     const long long m0 = l_tile * BM;
     const long long left = (M - m0) * K * 4;                // bytes from the tile's first row to the end
@@ -201,6 +231,26 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
         pa[e] = bload_i(rsa, aoff, soff + e * apass);
         pg[e] = bload(rsg, aoff, soff + e * apass);
       }
+    } else if (LIFT) {
+      // byte offsets of this step's rows of Pq from the indices that arrived with the PREVIOUS step's loads, then — before
+      // this step's loads, so that waiting for them next time does not wait for these — the indices of the NEXT step's tile
+      int vo[APT];
+#pragma unroll
+      for (int i = 0; i < APT; ++i) vo[LIFT ? i : 0] = gi[LIFT ? i : 0] * (K * 4) + kk * 4;
+      const bool nwrap = l_chunk + 1 == nchunks;
+      const long long nt_ = l_tile + (nwrap ? (long long)gridDim.x : 0ll);
+      const long long nm0 = (nt_ < ntiles ? nt_ : last_tile) * BM;
+      const rsrc_t rsi = make_rsrc(a.lidx + nm0, (M - nm0) * 4);
+#pragma unroll
+      for (int i = 0; i < APT; ++i) gi[LIFT ? i : 0] = bload_i(rsi, r0 * 4, i * RSTEP * 4);
+      __builtin_amdgcn_sched_barrier(0);
+      const rsrc_t rsp = make_rsrc(a.X, a.lrows * K * 4);
+#pragma unroll
+      for (int i = 0; i < APT; ++i) ra[i] = bload(rsp, vo[LIFT ? i : 0], soff);
+      const long long g_first = m0 / a.ns;
+      const rsrc_t rsq = make_rsrc(a.lQ + (size_t)g_first * K, (lgroups - g_first) * K * 4);
+#pragma unroll
+      for (int i = 0; i < APT; ++i) rb[RB ? i : 0] = bload(rsq, qoff, soff + qstep[LIFT ? i : 0]);
     } else if (!FIRST) {
       const rsrc_t rs = make_rsrc(a.X + (size_t)m0 * K, left);
 #pragma unroll
@@ -234,7 +284,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
   long long p_tile = blockIdx.x;   // cursor of the step whose sparse patch is pending (PRO_POOLG)
   int p_chunk = 0;
   int s_par = 0;                   // PRO_FIRST: parity of the tile the store cursor is in (selects the input-tile copy)
-  auto store_step = [&](float (&ra)[ARN], float (&rb)[TWO ? APT : 1], float (&rw)[WPT], int buf) {
+  auto store_step = [&](float (&ra)[ARN], float (&rb)[RB ? APT : 1], float (&rw)[WPT], int buf) {
     p_tile = s_tile;
     p_chunk = s_chunk;
     const int k = s_chunk * KC + kk;
@@ -269,6 +319,7 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
       }
       if (PRO == PRO_NONE) v = kin ? v : 0.f;
       if (PRO == PRO_BNRELU) v = fmaxf(__fmaf_rn(v, q0, q1), 0.f);
+      if (LIFT) v = fmaxf(__fmaf_rn(__fsub_rn(v, rb[RB ? i : 0]), q0, q1), 0.f);
       if (TWO) v = __fmaf_rn(q0, v, __fmaf_rn(q1, rb[TWO ? i : 0], q2));
       if (POOL) v = __fmaf_rn(q1, v, q2);
       Ad[RSTEP * i * LD] = v;
@@ -332,6 +383,20 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
     }
   }
   float yp[MASKE ? NT : 1][16];
+  // EPI_MASKL: Pq rows of the lane's 16 accumulator rows (four runs of four consecutive rows), the per-centre terms of the
+  // wave's two 16-row halves (ns >= 16: a half lies in one group), lane-constant column offsets
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t ge[MASKL ? 4 : 1];
+  float qa[MASKL ? NT : 1], qb[MASKL ? NT : 1];
+  int ycol[MASKL ? NT : 1];
+  const long long egroups = MASKL ? (M + a.ns - 1) / a.ns : 0;
+  if (MASKL) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = n0 + (wcol * NT + t) * 32 + cl;
+      ycol[MASKL ? t : 0] = col < N ? col * 4 : kOobOffset;
+    }
+  }
   // EPI_MASK constants of this lane's output columns (fixed for the whole kernel)
   float e_s[MASKE ? NT : 1], e_h[MASKE ? NT : 1], e_m[MASKE ? NT : 1], e_r[MASKE ? NT : 1];
   if (MASKE) {
@@ -346,14 +411,39 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
 
   // one pipeline iteration: compute the current step from LDS buffer `buf`; (la, lb, lw) receive
   // the loads of two steps ahead, (sa, sb, sw) hold the next step and are written to buffer buf^1
-  auto iteration = [&](int buf, float (&la)[ARN], float (&lb)[TWO ? APT : 1], float (&lw)[WPT], int (&lpa)[PGR],
-                       float (&lpg)[PGR], float (&sa)[ARN], float (&sb)[TWO ? APT : 1], float (&sw)[WPT],
+  auto iteration = [&](int buf, float (&la)[ARN], float (&lb)[RB ? APT : 1], float (&lw)[WPT], int (&lpa)[PGR],
+                       float (&lpg)[PGR], float (&sa)[ARN], float (&sb)[RB ? APT : 1], float (&sw)[WPT],
                        int (&spa)[PGR], float (&spg)[PGR]) {
     const bool last_chunk = c_chunk == nchunks - 1;
     const long long m0 = c_tile * BM;
     // Yprev first: vmcnt retires in order, so the epilogue's wait for these loads must not also
     // cover the ring loads issued after them
-    if (MASKE) {
+    if (MASKL) {
+      if (c_chunk + 2 == nchunks) {            // (the caller guarantees two chunks or more)
+        const rsrc_t rsi = make_rsrc(a.lidx + m0, (M - m0) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          ge[MASKL ? q : 0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsi, rbase * 4, q * 32, 0));
+      }
+      if (last_chunk) {
+        const rsrc_t rsp = make_rsrc(a.Yprev, a.lrows * N * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            yp[MASKE ? t : 0][r] = bload(rsp, (int)ge[MASKL ? (r >> 2) : 0][r & 3] * (N * 4) + ycol[MASKL ? t : 0], 0);
+        long long g0 = (m0 + wave * 32) / a.ns, g1 = (m0 + wave * 32 + 16) / a.ns;
+        g0 = g0 < egroups ? g0 : egroups - 1;      // (halves past M of a partial last tile: any valid row, never used)
+        g1 = g1 < egroups ? g1 : egroups - 1;
+        const rsrc_t rq0 = make_rsrc(a.lQ + (size_t)g0 * N, (egroups - g0) * N * 4);
+        const rsrc_t rq1 = make_rsrc(a.lQ + (size_t)g1 * N, (egroups - g1) * N * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          qa[MASKL ? t : 0] = bload(rq0, ycol[MASKL ? t : 0], 0);
+          qb[MASKL ? t : 0] = bload(rq1, ycol[MASKL ? t : 0], 0);
+        }
+      }
+    } else if (MASKE) {
       if (last_chunk) {
         const rsrc_t rsp = make_rsrc(a.Yprev + (size_t)m0 * N, (M - m0) * N * 4);
 #pragma unroll
@@ -456,7 +546,8 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_kernel(const GemmArgs a)
         for (int r = 0; r < 16; ++r) {
           float v = acc[t][r];
           if (MASKE) {
-            const float y = yp[MASKE ? t : 0][r];
+            float y = yp[MASKE ? t : 0][r];
+            if (MASKL) y = __fsub_rn(y, r < 8 ? qa[MASKL ? t : 0] : qb[MASKL ? t : 0]);
             v = (__fmaf_rn(y, es, eh) > 0.f) ? v : 0.f;
             s1 += v;
             s2 = __fmaf_rn(v, (y - em) * er, s2);
@@ -540,6 +631,10 @@ struct WgradArgs {
   long long M, rows_per_wg;
   int N, K, ns, gmode /* PRO_GY | PRO_POOLG */, amode /* PRO_NONE | PRO_BNRELU */;
   int koff;          // leading activation columns (<= 3) reduced on the VALU side, MFMA part = columns [koff, K)
+  // amode PRO_LIFT: the activation is relu(bn(Pq[lidx[row]] - lQ[row / ns])) — X = Pq [lrows][K] (mlp_gemm_kernel PRO_LIFT)
+  const int *lidx;
+  const float *lQ;
+  long long lrows;
 };
 
 
@@ -604,7 +699,29 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   const int kx = kb0 + xk;
   const int kxc = kx < K ? kx : (K - 1);
   float a_sc = 1.f, a_sh = 0.f;
-  if (AMODE == PRO_BNRELU) { a_sc = a.a_scale[kxc]; a_sh = a.a_shift[kxc]; }
+  constexpr bool LIFT = AMODE == PRO_LIFT;
+  if (AMODE == PRO_BNRELU || LIFT) { a_sc = a.a_scale[kxc]; a_sh = a.a_shift[kxc]; }
+  // PRO_LIFT: row xr0 + XRP i of a tile lies in its 16-row piece (XRP i) / 16 (xr0 < XRP <= 16), a piece in ONE group (ns >= 16,
+  // tiles start at multiples of WR): one per-centre value per piece and thread; the rows' indices arrive one tile ahead
+  constexpr int QN = LIFT ? (WR + 15) / 16 : 1;
+  const long long lgroups = LIFT ? (M + a.ns - 1) / a.ns : 0;
+  // (a wave stages ONE row per pass — xr0 = tid / WKB is wave-uniform for WKB >= 64 —, so the rows' indices are scalar
+  // loads and the row offsets ride in the SGPR operand of the gathers: no vector register, no vector memory instruction)
+  const int xr0u = __builtin_amdgcn_readfirstlane(xr0);
+  int xi[LIFT ? XPT : 1];
+  // (read through the constant address space: the index was written by an earlier kernel, a uniform address then loads on the
+  // scalar unit)
+  typedef const int __attribute__((address_space(4))) *const_int_p;
+  const const_int_p lidx_c = (const_int_p)(unsigned long long)a.lidx;
+  auto load_indices = [&](long long rt) {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      long long r = rt + xr0u + XRP * i;
+      r = r < M ? r : M - 1;
+      xi[LIFT ? i : 0] = lidx_c[r];
+    }
+  };
+  if (LIFT) load_indices(row_begin);
   // Addressing as in mlp_gemm_kernel: buffer descriptors per tile, kernel-constant per-lane byte
   // offsets, no clamps and no masks.  A gy column past N or an activation column past K reads a
   // neighbouring (finite) element or zero and only ever reaches dW entries that are not stored; rows
@@ -620,8 +737,8 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   constexpr int RGN = POOL ? 1 : GPT;          // the G matrix is only read in PRO_GY mode
   const long long ngroups = POOL ? (M + a.ns - 1) / a.ns : 0;
 
-  float rg0[RGN], ry0[GPT], rx0[XPT], pg0[WPG];
-  float rg1[RGN], ry1[GPT], rx1[XPT], pg1[WPG];
+  float rg0[RGN], ry0[GPT], rx0[XPT], pg0[WPG], rq0[QN];
+  float rg1[RGN], ry1[GPT], rx1[XPT], pg1[WPG], rq1[QN];
   int pa0[WPG], pa1[WPG];
   float rz0 = 0.f, rz1 = 0.f;                      // LEAD: one element of the WR x koff leading block per thread
   float lead_acc[LEAD ? 3 : 1];
@@ -631,8 +748,16 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
   long long l_rt = row_begin;     // next tile to load (clamped to the last tile past the end)
   long long s_rt = row_begin;     // next tile to write to LDS
 
-  auto load_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG], float &rz) {
+  auto load_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG], float &rz,
+                       float (&rq)[QN]) {
     const long long rt = l_rt;
+    int vo[LIFT ? XPT : 1];
+    if (LIFT) {
+      // (scalar) offsets of this tile's rows of Pq from the indices loaded with the previous tile, then the next tile's indices
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) vo[LIFT ? i : 0] = xi[LIFT ? i : 0] * (K * 4);
+      load_indices(rt + WR < row_end ? rt + WR : last_rt);
+    }
     const rsrc_t rsy = make_rsrc(a.Yl + (size_t)rt * N, (M - rt) * N * 4);
 #pragma unroll
     for (int i = 0; i < GPT; ++i) ry[i] = bload(rsy, goff, i * gpass);
@@ -650,16 +775,24 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < GPT; ++i) rg[POOL ? 0 : i] = bload(rsgy, goff, i * gpass);
     }
-    const rsrc_t rsx = make_rsrc(a.X + (size_t)rt * K, (M - rt) * K * 4);
+    const rsrc_t rsx = LIFT ? make_rsrc(a.X, a.lrows * K * 4) : make_rsrc(a.X + (size_t)rt * K, (M - rt) * K * 4);
 #pragma unroll
-    for (int i = 0; i < XPT; ++i) rx[i] = bload(rsx, xoff, i * xpass);
+    for (int i = 0; i < XPT; ++i) rx[i] = LIFT ? bload(rsx, kx * 4, vo[LIFT ? i : 0]) : bload(rsx, xoff, i * xpass);
+    if (LIFT) {
+#pragma unroll
+      for (int h = 0; h < QN; ++h) {
+        long long g = (rt + 16 * h) / a.ns;
+        g = g < lgroups ? g : lgroups - 1;
+        rq[h] = bload(make_rsrc(a.lQ + (size_t)g * K, (lgroups - g) * K * 4), kx * 4, 0);
+      }
+    }
     if (LEAD) rz = bload(rsx, (zr < WR && zc < koff) ? (zr * K + zc) * 4 : kOobOffset, 0);
     const long long nt = rt + WR;
     l_rt = nt < row_end ? nt : last_rt;
   };
 
   long long p_rt = row_begin;
-  auto store_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], float rz) {
+  auto store_tile = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], float rz, float (&rq)[QN]) {
     const long long rt = s_rt;
     p_rt = rt;
     if (tid < GRP * GN) {
@@ -675,6 +808,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     for (int i = 0; i < XPT; ++i) {
       xv[i] = rx[i];
       if (AMODE == PRO_BNRELU) xv[i] = fmaxf(__fmaf_rn(xv[i], a_sc, a_sh), 0.f);
+      if (LIFT) xv[i] = fmaxf(__fmaf_rn(__fsub_rn(xv[i], rq[LIFT ? (XRP * i) / 16 : 0]), a_sc, a_sh), 0.f);
     }
     if (rt + WR > M) {
       // the tile that crosses M (wave-uniform, at most one per kernel): its surplus rows carry
@@ -702,14 +836,15 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     }
   };
 
-  auto iteration = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG], float &rz) {
-    store_tile(rg, ry, rx, rz);      // tile t (loaded two iterations ago) -> LDS
+  auto iteration = [&](float (&rg)[RGN], float (&ry)[GPT], float (&rx)[XPT], int (&pa)[WPG], float (&pg)[WPG], float &rz,
+                       float (&rq)[QN]) {
+    store_tile(rg, ry, rx, rz, rq);  // tile t (loaded two iterations ago) -> LDS
     if (POOL) {
       __syncthreads();
       patch_tile(pa, pg);
     }
     __syncthreads();
-    load_tile(rg, ry, rx, pa, pg, rz);   // tile t+2 into the registers just freed
+    load_tile(rg, ry, rx, pa, pg, rz, rq);   // tile t+2 into the registers just freed
     if (lead_blk && tid < GRP * GN) {
       // leading columns: this thread's gy elements (column gn, rows gr0 + GRP*i, patched values from LDS).
       // Deliberately a rolled loop: unrolled, its hoisted LDS reads cost 60 VGPRs and the second workgroup per CU.
@@ -739,14 +874,14 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     __syncthreads();
   };
 
-  load_tile(rg0, ry0, rx0, pa0, pg0, rz0);
-  load_tile(rg1, ry1, rx1, pa1, pg1, rz1);
+  load_tile(rg0, ry0, rx0, pa0, pg0, rz0, rq0);
+  load_tile(rg1, ry1, rx1, pa1, pg1, rz1, rq1);
   // single-exit pair loop + peeled odd tile (see mlp_gemm_kernel)
   for (long long pair = ntile >> 1; pair > 0; --pair) {
-    iteration(rg0, ry0, rx0, pa0, pg0, rz0);
-    iteration(rg1, ry1, rx1, pa1, pg1, rz1);
+    iteration(rg0, ry0, rx0, pa0, pg0, rz0, rq0);
+    iteration(rg1, ry1, rx1, pa1, pg1, rz1, rq1);
   }
-  if (ntile & 1) iteration(rg0, ry0, rx0, pa0, pg0, rz0);
+  if (ntile & 1) iteration(rg0, ry0, rx0, pa0, pg0, rz0, rq0);
   if (lead_blk && g_thr) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -1203,6 +1338,54 @@ extern "C" int pn2_mlp_gemm(long long M, int K, int N, int pro, int epi, const f
   return pn2_check_launch();
 }
 
+// ---- the layer ABOVE a lifted first layer, with that layer's output re-formed on the fly (PRO_LIFT / EPI_MASKL) ----
+// K = width of the lifted layer (columns of Pq / Q), N = width of the layer above.  ns: rows per centre, a power of two in
+// [16, 128] (a 128-row tile holds whole groups, a 16-row piece lies in one).
+extern "C" int pn2_mlp_lift_supported(int K, int N, int ns) {
+  return K >= 64 && K <= 2048 && N >= 1 && N <= 256 && ns >= 16 && ns <= 128 && (ns & (ns - 1)) == 0;
+}
+
+static int lift_args_ok(long long M, int K, int N, long long lrows, int ns) {
+  if (M < 0 || lrows <= 0 || !pn2_mlp_lift_supported(K, N, ns)) return 0;
+  if (M % ns != 0 || M >= 0x7fffffffLL || lrows * (long long)(K > N ? K : N) * 4 >= 0x40000000LL) return 0;
+  return 1;
+}
+
+// forward: Y[M][N] = relu(bn_0(Pq[gidx] - Q[row / ns])) W^T, column sums of Y and Y^2 into stats
+extern "C" int pn2_mlp_gemm_lift(long long M, int K, int N, long long lrows, const float *Pq, const int *gidx, const float *Q,
+                                 int ns, const float *fin0 /* [4][K] */, const float *W, float *Y, double *stats,
+                                 void *stream) {
+  if (!lift_args_ok(M, K, N, lrows, ns)) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Pq || !gidx || !Q || !fin0 || !W || !Y || !stats) return PN2_ENULL;
+  GemmArgs a = {};
+  a.X = Pq; a.lidx = gidx; a.lQ = Q; a.lrows = lrows; a.p0 = fin0 + 2 * (size_t)K; a.p1 = fin0 + 3 * (size_t)K;
+  a.W = W; a.Y = Y; a.stats = stats; a.M = M; a.K = K; a.N = N; a.ns = ns; a.pro = PRO_LIFT; a.epi = EPI_STATS;
+  launch_one<2, 16, 2, PRO_LIFT, EPI_STATS>(a, (hipStream_t)stream, 512);   // (97 VGPRs: two workgroups per CU)
+  return pn2_check_launch();
+}
+
+// input gradient of that layer: Gout[M][K] = (c1 G + c2 Yl + c3) Wt^T masked by [bn_0(y0) > 0], with the column sums of
+// Gout and Gout yhat_0 (BatchNorm backward of the lifted layer), y0 = Pq[gidx] - Q[row / ns]
+extern "C" int pn2_mlp_dgrad_lift(long long M, int K, int N, long long lrows, const float *G, const float *Yl,
+                                  const float *consts /* [3][N] */, const float *Wt /* [K][N] */, float *Gout, double *sums,
+                                  const float *Pq, const int *gidx, const float *Q, int ns, const float *e_fin /* [4][K] */,
+                                  void *stream) {
+  if (!lift_args_ok(M, K, N, lrows, ns) || N < 64) return PN2_EINVAL;       // (two 32-wide reduction chunks or more)
+  if (M == 0) return PN2_OK;
+  if (!G || !Yl || !consts || !Wt || !Gout || !sums || !Pq || !gidx || !Q || !e_fin) return PN2_ENULL;
+  GemmArgs a = {};
+  // the GEMM's reduction runs over the layer's N output channels, its output has the lifted layer's K columns
+  a.X = G; a.X2 = Yl; a.p0 = consts; a.p1 = consts + N; a.p2 = consts + 2 * (size_t)N; a.W = Wt; a.Y = Gout; a.stats = sums;
+  a.Yprev = Pq; a.lidx = gidx; a.lQ = Q; a.lrows = lrows;
+  a.e_mean = e_fin; a.e_rstd = e_fin + K; a.e_scale = e_fin + 2 * (size_t)K; a.e_shift = e_fin + 3 * (size_t)K;
+  a.M = M; a.K = N; a.N = K; a.ns = ns; a.pro = PRO_GY; a.epi = EPI_MASKL;
+  const int tiles = (K + 31) / 32;
+  if (tiles <= 2) launch_one<1, 32, 2, PRO_GY, EPI_MASKL>(a, (hipStream_t)stream);
+  else launch_one<2, 32, 2, PRO_GY, EPI_MASKL>(a, (hipStream_t)stream);
+  return pn2_check_launch();
+}
+
 namespace {
 // Batch statistics of the first layer from the Gram matrix of its input: y_0 = X0 W0^T is linear in X0, so
 //   sum_r y_0[r][n] = W0[n] . (1^T X0),   sum_r y_0[r][n]^2 = W0[n] (X0^T X0) W0[n]^T   (fp64; gram as rows_gram_kernel
@@ -1348,19 +1531,21 @@ extern "C" int pn2_pool_finalize(long long R, int C, int ns, const float *pmax, 
   return pn2_check_launch();
 }
 
-extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, const float *G,
-                             const float *Yl, const float *consts /* [3][N] */, const int *arg,
-                             const float *gP, int ns, const float *X, const float *a_fin /* [4][K] or NULL */,
-                             float *dW, void *stream) {
+static int wgrad_impl(long long M, int N, int K, int gmode, int amode, const float *G,
+                      const float *Yl, const float *consts /* [3][N] */, const int *arg,
+                      const float *gP, int ns, const float *X, const float *a_fin /* [4][K] or NULL */,
+                      float *dW, const int *lidx, const float *lQ, long long lrows, void *stream) {
   if (M < 0 || N <= 0 || K <= 0 || N > WMAXN) return PN2_EINVAL;
   if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
-  if (amode != PRO_NONE && amode != PRO_BNRELU) return PN2_EINVAL;
+  if (amode != PRO_NONE && amode != PRO_BNRELU && amode != PRO_LIFT) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!Yl || !consts || !X || !dW) return PN2_ENULL;
   if (gmode == PRO_GY && !G) return PN2_ENULL;
   if (gmode == PRO_POOLG && (!arg || !gP || ns < 16 || M >= 0x7fffffffLL)) return PN2_EINVAL;
-  if (amode == PRO_BNRELU && !a_fin) return PN2_ENULL;
+  if (amode != PRO_NONE && !a_fin) return PN2_ENULL;
+  if (amode == PRO_LIFT && (gmode != PRO_GY || !lidx || !lQ || N > 128 || !lift_args_ok(M, K, N, lrows, ns))) return PN2_EINVAL;
   WgradArgs a;
+  a.lidx = lidx; a.lQ = lQ; a.lrows = lrows;
   a.G = G; a.Yl = Yl; a.c1 = consts; a.c2 = consts + N; a.c3 = consts + 2 * (size_t)N;
   a.arg = arg; a.gP = gP; a.X = X;
   a.a_scale = a_fin ? a_fin + 2 * (size_t)K : nullptr;
@@ -1373,7 +1558,7 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
   // cannot share a CU with a workgroup of the cooperative FPS kernel that the geometry prefetch keeps resident on every
   // CU — as the first kernel of the backward it waited 1.6 ms for the FPS to end (kernel-trace timeline) — and capping
   // its registers spills (0.13 -> 1.6 ms).  The price is 64-column K blocks, i.e. more passes over a SMALL gy.
-  const int kt = ((K <= 64 && N > 64) || N > 256) ? 2 : 4;
+  const int kt = (amode != PRO_LIFT && ((K <= 64 && N > 64) || N > 256)) ? 2 : 4;
   // K = 32j + (1..3) raw-input columns (relative xyz in front of the features): reduce the leading columns on the
   // VALU side and give the MFMA part the aligned rest, instead of a whole extra pass over g and y for 3 columns
   // (measured: K = 131, M = 1M 0.79 -> 0.55 ms; K = 259, M = 256k 0.31 -> 0.28; below that the extra pass is cheaper)
@@ -1415,7 +1600,9 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
     else                                                                                               \
       hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, PRO_POOLG, PRO_NONE, 4, true>), grid, dim3(512), 0, s, a); \
   } while (0)
-  if (koff) {
+  if (amode == PRO_LIFT) {
+    hipLaunchKernelGGL((mlp_wgrad_kernel<2, PRO_GY, PRO_LIFT, 4>), grid, dim3(512), 0, s, a);
+  } else if (koff) {
     if (ntiles <= 2) PN2_WGRAD_LEAD(1);
     else if (ntiles <= 4) PN2_WGRAD_LEAD(2);
     else if (ntiles <= 8) PN2_WGRAD_LEAD(4);
@@ -1433,6 +1620,21 @@ extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, co
 #undef PN2_WGRAD
 #undef PN2_WGRAD_LEAD
   return pn2_check_launch();
+}
+
+extern "C" int pn2_mlp_wgrad(long long M, int N, int K, int gmode, int amode, const float *G,
+                             const float *Yl, const float *consts /* [3][N] */, const int *arg,
+                             const float *gP, int ns, const float *X, const float *a_fin /* [4][K] or NULL */,
+                             float *dW, void *stream) {
+  if (amode == PRO_LIFT) return PN2_EINVAL;
+  return wgrad_impl(M, N, K, gmode, amode, G, Yl, consts, arg, gP, ns, X, a_fin, dW, nullptr, nullptr, 0, stream);
+}
+
+// weight gradient of the layer above a lifted first layer: dW[N][K] += (c1 G + c2 Yl + c3)^T relu(bn_0(Pq[gidx] - Q[row / ns]))
+extern "C" int pn2_mlp_wgrad_lift(long long M, int N, int K, long long lrows, const float *G, const float *Yl,
+                                  const float *consts /* [3][N] */, const float *Pq, const int *gidx, const float *Q, int ns,
+                                  const float *a_fin /* [4][K] */, float *dW, void *stream) {
+  return wgrad_impl(M, N, K, PRO_GY, PRO_LIFT, G, Yl, consts, nullptr, nullptr, ns, Pq, a_fin, dW, gidx, Q, lrows, stream);
 }
 
 extern "C" int pn2_bn_finalize(int N, double count, const double *stats, const float *gamma,

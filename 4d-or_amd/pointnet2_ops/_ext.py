@@ -38,8 +38,8 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.pn2_abi_version.restype = ctypes.c_int
-if int(_lib.pn2_abi_version()) != 8:
-    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 8: "
+if int(_lib.pn2_abi_version()) != 9:
+    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 9: "
                       f"rebuild it (`make -C {os.path.join(_PKG_DIR, 'csrc')}`)")
 
 _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -82,6 +82,11 @@ _SIGNATURES = {
     "pn2_three_interpolate_rows_grad_csr": [_c_int] * 6 + [_c_vp] * 6,
     "pn2_lift_split_weight": [_c_int] * 2 + [_c_vp] * 5,
     "pn2_lift_dw_assemble": [_c_int] * 2 + [_c_vp] * 6,
+    "pn2_lift_points": [_c_int] * 5 + [_c_f32] + [_c_vp] * 7,
+    "pn2_group_lift_stats": [_c_int] * 5 + [_c_vp] * 6,
+    "pn2_mlp_gemm_lift": [ctypes.c_longlong, _c_int, _c_int, ctypes.c_longlong] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 5,
+    "pn2_mlp_wgrad_lift": [ctypes.c_longlong, _c_int, _c_int, ctypes.c_longlong] + [_c_vp] * 6 + [_c_int] + [_c_vp] * 3,
+    "pn2_mlp_dgrad_lift": [ctypes.c_longlong, _c_int, _c_int, ctypes.c_longlong] + [_c_vp] * 9 + [_c_int] + [_c_vp] * 2,
     "pn2_gather_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_scatter_add_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_segment_sum_rows": [_c_i64, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -173,6 +178,8 @@ _lib.pn2_ball_query_auto.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int]
 _lib.pn2_ball_query_auto.restype = _c_int
 _lib.pn2_group_lift_supported.argtypes = [_c_int]
 _lib.pn2_group_lift_supported.restype = _c_int
+_lib.pn2_mlp_lift_supported.argtypes = [_c_int] * 3
+_lib.pn2_mlp_lift_supported.restype = _c_int
 _lib.pn2_group_lift_rows_grad_workspace_bytes.argtypes = [_c_int] * 5
 _lib.pn2_group_lift_rows_grad_workspace_bytes.restype = _c_sz
 _lib.pn2_ball_query_group_supported.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_int, _c_int]
@@ -235,7 +242,7 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 #: the header revision this binding was written against: a stale prebuilt libpn2_hip.so fails here with a version
 #: error instead of an AttributeError on the first missing symbol
-EXPECTED_ABI_VERSION = 8
+EXPECTED_ABI_VERSION = 9
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_status_offset_ex", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
                                                "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_fps_ordered_workspace_bytes", "pn2_gcn_fused_supported", "pn2_gcn_layer_backward_workspace_bytes", "pn2_group_lift_rows_grad_seg_workspace_bytes",
@@ -243,7 +250,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_ball_query_group_supported", "pn2_ball_query_group_workspace_bytes",
-                                               "pn2_group_lift_supported", "pn2_group_lift_rows_grad_workspace_bytes",
+                                               "pn2_group_lift_supported", "pn2_mlp_lift_supported", "pn2_group_lift_rows_grad_workspace_bytes",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
@@ -794,6 +801,83 @@ def lift_split_weight(W):
     Wx, Wf, WfT = buf[:N0 * 3].view(N0, 3), buf[N0 * 3:N0 * 3 + N0 * C].view(N0, C), buf[N0 * 3 + N0 * C:].view(C, N0)
     _call("pn2_lift_split_weight", W, N0, C, _ptr(W), _ptr(Wx), _ptr(Wf), _ptr(WfT))
     return Wx, Wf, WfT
+
+
+def mlp_lift_supported(K, N, ns) -> bool:
+    """Shapes the layer above a lifted first layer can take with that layer's output re-formed on the fly
+    (pn2_mlp_gemm_lift / pn2_mlp_wgrad_lift / pn2_mlp_dgrad_lift): K = lifted width, N = width above, ns rows per centre."""
+    return N <= 128 and bool(_lib.pn2_mlp_lift_supported(int(K), int(N), int(ns)))
+
+
+def lift_points(P, xyz, new_xyz, Wx, normalize, radius):
+    """(Pq (B N, N0), Q (B m, N0)): the lifted first layer's per-point products with the coordinate term of the point folded in,
+    and the per-centre term — y0[b, j, s] = Pq[b, idx[b, j, s]] - Q[b, j] (include/pn2_hip.h)."""
+    _f32(P, "P"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(Wx, "Wx")
+    _same_device((P, "P"), (xyz, "xyz"), (new_xyz, "new_xyz"), (Wx, "Wx"))
+    B, N, _ = xyz.shape
+    m, N0 = new_xyz.size(1), P.size(-1)
+    if P.numel() != B * N * N0 or tuple(Wx.shape) != (N0, 3) or tuple(new_xyz.shape) != (B, m, 3):
+        _fail("lift_points: P must be (B, N, N0), Wx (N0, 3), new_xyz (B, m, 3)")
+    buf = torch.empty(B * (N + m), N0, dtype=torch.float32, device=P.device)
+    Pq, Q = buf[:B * N], buf[B * N:]
+    _call("pn2_lift_points", P, B, N, m, N0, int(bool(normalize)), float(radius if radius is not None else 1.0), _ptr(xyz),
+          _ptr(new_xyz), _ptr(P), _ptr(Wx), _ptr(Pq), _ptr(Q), alg_bytes=4 * B * (2 * N * N0 + m * N0 + 3 * N + 3 * m))
+    return Pq, Q
+
+
+def group_lift_stats(Pq, Q, idx, N, stats):
+    """stats (2, N0) f64 += column sums of y0 = Pq[idx] - Q and y0^2; returns gidx (B m ns) int32 = b N + idx, the row of Pq
+    every grouped row reads.  Nothing of y0 is stored."""
+    _f32(Pq, "Pq"); _f32(Q, "Q"); _i32(idx, "idx")
+    _same_device((Pq, "Pq"), (Q, "Q"), (idx, "idx"), (stats, "stats"))
+    B, m, ns = idx.shape
+    N0 = Pq.size(-1)
+    if Pq.numel() != B * int(N) * N0 or Q.numel() != B * m * N0 or stats is None:
+        _fail("group_lift_stats: Pq must be (B N, N0), Q (B m, N0), stats (2, N0) float64")
+    gidx = torch.empty(B * m * ns, dtype=torch.int32, device=Pq.device)
+    _call("pn2_group_lift_stats", Pq, B, int(N), m, ns, N0, _ptr(idx), _ptr(Pq), _ptr(Q), _ptr(gidx), _ptr(stats),
+          alg_bytes=B * (8 * m * ns + 4 * N0 * (int(N) + m)), label="pn2_group_lift_rows")
+    return gidx
+
+
+def mlp_gemm_lift(Pq, gidx, Q, ns, fin0, W, stats):
+    """Y (M, N) = relu(bn_0(Pq[gidx] - Q[row // ns])) W^T with the column sums of Y, Y^2 in `stats` (csrc/mlp_gemm.hip PRO_LIFT)."""
+    _f32(W, "W"); _f32(fin0, "fin0")
+    N, K = W.shape
+    M, lrows = gidx.numel(), Pq.size(0)
+    if Pq.size(1) != K or tuple(fin0.shape) != (4, K) or Q.numel() != (M // ns) * K:
+        _fail("mlp_gemm_lift: Pq (rows, K), Q (M / ns, K), fin0 (4, K), W (N, K) expected")
+    Y = torch.empty(M, N, dtype=torch.float32, device=W.device)
+    _call("pn2_mlp_gemm_lift", W, M, K, N, lrows, _ptr(Pq), _ptr(gidx), _ptr(Q), int(ns), _ptr(fin0), _ptr(W), _ptr(Y),
+          _ptr(stats), alg_bytes=4 * (lrows * K + M + (M // ns) * K + M * N + N * K), alg_flops=2 * M * N * K,
+          tag=(f"M{M},K{K},N{N},lift" if DETAIL_TAGS else None), label="pn2_mlp_gemm")
+    return Y
+
+
+def mlp_wgrad_lift(Yl, consts, G, Pq, gidx, Q, ns, a_fin, dW=None):
+    """dW (N, K) += (c1 G + c2 Yl + c3)^T relu(bn_0(Pq[gidx] - Q[row // ns])) (pn2_mlp_wgrad with the activation re-formed)."""
+    M, N = Yl.shape
+    K, lrows = Pq.size(1), Pq.size(0)
+    if dW is None:
+        dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
+    _call("pn2_mlp_wgrad_lift", Yl, M, N, K, lrows, _ptr(G), _ptr(Yl), _ptr(consts), _ptr(Pq), _ptr(gidx), _ptr(Q), int(ns),
+          _ptr(a_fin), _ptr(dW), alg_bytes=4 * (2 * M * N + lrows * K + M + (M // ns) * K + N * K), alg_flops=2 * M * N * K,
+          tag=(f"M{M},N{N},K{K},lift" if DETAIL_TAGS else None), label="pn2_mlp_wgrad")
+    return dW
+
+
+def mlp_dgrad_lift(G, Yl, consts, Wt, sums, Pq, gidx, Q, ns, e_fin):
+    """Gout (M, K) = [(c1 G + c2 Yl + c3) Wt^T] masked by bn_0(y0) > 0, `sums` (2, K) += column sums of Gout, Gout yhat_0;
+    y0 = Pq[gidx] - Q[row // ns] re-formed in the epilogue (csrc/mlp_gemm.hip EPI_MASKL).  Wt (K, N)."""
+    M, N = Yl.shape
+    K, lrows = Pq.size(1), Pq.size(0)
+    if tuple(Wt.shape) != (K, N) or tuple(e_fin.shape) != (4, K):
+        _fail("mlp_dgrad_lift: Wt (K, N), e_fin (4, K) expected")
+    Gout = torch.empty(M, K, dtype=torch.float32, device=Yl.device)
+    _call("pn2_mlp_dgrad_lift", Yl, M, K, N, lrows, _ptr(G), _ptr(Yl), _ptr(consts), _ptr(Wt), _ptr(Gout), _ptr(sums), _ptr(Pq),
+          _ptr(gidx), _ptr(Q), int(ns), _ptr(e_fin), alg_bytes=4 * (2 * M * N + M * K + lrows * K + M + (M // ns) * K + N * K),
+          alg_flops=2 * M * N * K, tag=(f"M{M},K{N},N{K},pro2,maskl" if DETAIL_TAGS else None), label="pn2_mlp_gemm")
+    return Gout
 
 
 def lift_dw_assemble(acc, Wx, c2, dWf):

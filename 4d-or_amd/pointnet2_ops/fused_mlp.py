@@ -60,6 +60,19 @@ LIFT_SPARSE = _os.environ.get("PN2_LIFT_SPARSE") != "0"
 #: ... and on the bf16 node (same kernels with bf16 rows: y0 and the gradient rows in bf16, per-point products and every sum
 #: in fp32).  PN2_BF16_LIFT=0 restores the grouped bf16 route (A/B).
 BF16_LIFT = _os.environ.get("PN2_BF16_LIFT") != "0"
+#: the lifted layer's OUTPUT is not stored either (fp32 node, training mode, stacks of three layers or more): y0[row] =
+#: Pq[point] - Q[centre] is re-formed by the layer above — its GEMM (pn2_mlp_gemm_lift), its weight gradient
+#: (pn2_mlp_wgrad_lift) and the mask / BatchNorm sums of its input gradient (pn2_mlp_dgrad_lift); the rows of Pq (a cloud's
+#: share: 1 MB at the headline's SA2) come out of L2.  OFF by default: it removes 2.1 GB (SA2) of HBM traffic per headline step and
+#: is 0.11 ms faster kernel by kernel (tools/lift_free_bench.py), but the step does not get shorter (three same-box A/B pairs,
+#: tools/ab_lift_free.sh: 10.78-10.79 ms stored, 10.81-10.82 re-formed) — the kernels involved sit at their instruction-issue
+#: limit, not at HBM's, the stored tensor's tail is still in the 256 MB MALL when the next kernel reads it, and the gathering
+#: variants hold more registers next to the resident sampling workgroups.  PN2_LIFT_FREE=1 switches it on.
+LIFT_FREE = _os.environ.get("PN2_LIFT_FREE") == "1"
+#: ... from this many grouped rows on (tools/lift_free_bench.py, profiles/r05_lift_free.jsonl: 1M rows 1.34 -> 1.24 ms for the
+#: four kernels involved, 262k rows 0.400 -> 0.398, 131k rows 0.228 -> 0.241: below, the two extra launches cost more than
+#: the tensor)
+LIFT_FREE_MIN_ROWS = int(_os.environ.get("PN2_LIFT_FREE_MIN_ROWS", str(1 << 17 | 1 << 16)))
 #: ... also inside segment-table stacks (per-scan statistics at the whole-batch launch count): the lifted layer is issued once
 #: per scan (the launches of single-scan steps), the rest of the stack through the table.  PN2_BF16_LIFT_SEG=0: grouped route.
 BF16_LIFT_SEG = _os.environ.get("PN2_BF16_LIFT_SEG") != "0"
@@ -229,6 +242,13 @@ class _FusedMLP(Function):
             and (not needs_grad or ((bn0.training or bn0.running_mean is None) and FUSED_BACKWARD and not need_dgrad0
                                     and e.mlp_bwd_fused_fold_supported(layers[1][0].out_channels,
                                                                        layers[0][0].out_channels, K0))))
+        # lifted first layer without its output: the layer above re-forms it (module comment at LIFT_FREE)
+        lift_free = bool(
+            lift and LIFT_FREE and L >= 3 and M >= LIFT_FREE_MIN_ROWS and not isinstance(ctx, _SegCtx)
+            and getattr(e, "mlp_gemm_lift", None) is not None and feats.is_cuda
+            and all((bn.training or bn.running_mean is None) for _c, bn in layers[:2])
+            and M % idx.size(2) == 0 and e.mlp_lift_supported(layers[0][0].out_channels, layers[1][0].out_channels, idx.size(2)))
+        ctx.lift_free = None
         gram = W0c = None
         if first_free:
             gram = e.rows_gram(x, e.zero_arena(x.device, [((K0 * K0 + K0,), torch.float64)])[0])
@@ -244,7 +264,11 @@ class _FusedMLP(Function):
                 pooled_parts = e.mlp_gemm_pool(cur, Wf, sgn, ns, p=p, stats=stat_bufs[l]) + (sgn,)
             if use_batch:
                 stats = stat_bufs[l]
-                if lift and l == 0:
+                if lift_free and l == 0:
+                    y, ctx.lift_P, ctx.lift_free = _lift_forward_free(e, feats, W, group, stats)
+                elif lift_free and l == 1:
+                    y = e.mlp_gemm_lift(*ctx.lift_free, idx.size(2), fins[0], W.contiguous(), stats)
+                elif lift and l == 0:
                     y, ctx.lift_P = _lift_forward(e, feats, W, group, stats)
                 elif first_free and l == 0:
                     y = None
@@ -381,6 +405,21 @@ class _FusedMLP(Function):
                 sums = sums_in[l]
                 gmode, arg, gPm = e.PRO_GY, None, None
                 continue
+            lift_free = getattr(ctx, "lift_free", None)
+            if l == 1 and lift_free is not None:
+                # the layer above a lifted first layer whose output was not stored: weight gradient and input gradient with
+                # y0 = Pq[point] - Q[centre] re-formed in the kernels (csrc/mlp_gemm.hip PRO_LIFT / EPI_MASKL)
+                if gmode != e.PRO_GY:
+                    raise RuntimeError("fused_mlp: the layer above a lifted first layer expects a dense gradient")
+                consts, dgamma, dbeta, Wt = e.bn_bwd_consts(sums, M, gammas[1], fins[1], ctx.batch_flags[1],
+                                                            W=Ws[1].contiguous(), k0=0)
+                grads[4], grads[5] = dgamma, dbeta
+                Pq, gidx, Q = lift_free
+                nsl = ctx.group[2].size(2)
+                grads[3] = e.mlp_wgrad_lift(ys[1], consts, G, Pq, gidx, Q, nsl, fins[0], dW=dWs[1]).view(ctx.shapes[1])
+                sums = sums_in[1]
+                G = e.mlp_dgrad_lift(G, ys[1], consts, Wt, sums, Pq, gidx, Q, nsl, fins[0])
+                continue
             one_pass = (l <= 1 and fold) or (l > 0 and FUSED_BACKWARD and
                                              e.mlp_bwd_fused_supported(Ws[l].size(0), Ws[l].size(1)))
             Wt = None
@@ -481,6 +520,18 @@ def _lift_weights(e, W):
     if getattr(e, "lift_split_weight", None) is not None and W.is_cuda:
         return e.lift_split_weight(W)
     return W[:, :3].contiguous(), W[:, 3:].contiguous(), W[:, 3:].t().contiguous()
+
+
+def _lift_forward_free(e, feats, W, group, stats):
+    """The lifted first layer without its output: (None, (P, Wx, WfT), (Pq, gidx, Q)) — P as _lift_forward, Pq = P + Wx x / r and
+    Q = Wx c / r (y0[row] = Pq[gidx[row]] - Q[row // ns]), the batch statistics of y0 accumulated into `stats`."""
+    xyz, new_xyz, idx, _use_xyz, normalize, radius = group[:6]
+    B, N, C = feats.shape
+    Wx, Wf, WfT = _lift_weights(e, W)
+    P = e.mlp_gemm(feats.view(B * N, C), Wf, pro=e.PRO_NONE, epi=e.EPI_NONE).view(B, N, -1)
+    Pq, Q = e.lift_points(P, xyz, new_xyz, Wx, normalize, radius)
+    gidx = e.group_lift_stats(Pq, Q, idx, N, stats)
+    return None, (P, Wx, WfT), (Pq, gidx, Q)
 
 
 def _lift_forward(e, feats, W, group, stats, out_bf16=False):

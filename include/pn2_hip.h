@@ -295,6 +295,33 @@ int pn2_lift_split_weight(int N0, int C, const float *W, float *Wx, float *Wf, f
 int pn2_lift_dw_assemble(int N0, int C, const float *acc, const float *Wx, const float *c2, const float *dWf, float *dW,
                          void *stream);
 
+/* The lifted first layer WITHOUT its output tensor (round 5; csrc/group_lift.hip, csrc/mlp_gemm.hip PRO_LIFT / EPI_MASKL).
+ * With the coordinate term of the first Conv2d (OPS/pointnet2_modules.py:9-19 over OPS/pointnet2_utils.py:317-328's
+ * [rel | features]) split between the point and the centre, y0[b, j, s] = Pq[b, idx[b, j, s]] - Q[b, j]:
+ *   pn2_lift_points       Pq (B N, N0) = P + Wx x / r (r = radius when `normalize`, else 1), Q (B m, N0) = Wx c / r;
+ *   pn2_group_lift_stats  stats (2, N0) += column sums of y0 and y0^2 (BatchNorm batch statistics), gidx (B m ns) = b N + idx
+ *                         (the row of Pq every grouped row reads);
+ *   pn2_mlp_gemm_lift     Y (M, N) = relu(bn_0(y0)) W^T with the column sums of Y, Y^2 — the layer ABOVE, fin0 (4, K) the lifted
+ *                         layer's mean | rstd | scale | shift; K = N0;
+ *   pn2_mlp_wgrad_lift    dW (N, K) += (c1 G + c2 Yl + c3)^T relu(bn_0(y0))     (pn2_mlp_wgrad with the activation re-formed);
+ *   pn2_mlp_dgrad_lift    Gout (M, K) = [(c1 G + c2 Yl + c3) Wt^T] masked by bn_0(y0) > 0, sums (2, K) += column sums of Gout and
+ *                         Gout yhat_0 (pn2_mlp_gemm PRO_GY / EPI_MASK with Yprev re-formed); Wt (K, N) rows.
+ * The (M, N0) tensor y0 is never stored.  Preconditions (pn2_mlp_lift_supported): 64 <= K <= 2048, N <= 256 (wgrad: <= 128),
+ * ns a power of two in [16, 128], M % ns == 0, Pq below 1 GiB.  Same real numbers as pn2_group_lift_rows, rounded in another
+ * order (tests: 1e-4 against the oracle like every MLP kernel). */
+int pn2_mlp_lift_supported(int K, int N, int ns);
+int pn2_lift_points(int B, int N, int m, int N0, int normalize, float radius, const float *xyz, const float *new_xyz,
+                    const float *P, const float *Wx, float *Pq, float *Q, void *stream);
+int pn2_group_lift_stats(int B, int N, int m, int ns, int N0, const int *idx, const float *Pq, const float *Q, int *gidx,
+                         double *stats, void *stream);
+int pn2_mlp_gemm_lift(long long M, int K, int N, long long lrows, const float *Pq, const int *gidx, const float *Q, int ns,
+                      const float *fin0, const float *W, float *Y, double *stats, void *stream);
+int pn2_mlp_wgrad_lift(long long M, int N, int K, long long lrows, const float *G, const float *Yl, const float *consts,
+                       const float *Pq, const int *gidx, const float *Q, int ns, const float *a_fin, float *dW, void *stream);
+int pn2_mlp_dgrad_lift(long long M, int K, int N, long long lrows, const float *G, const float *Yl, const float *consts,
+                       const float *Wt, float *Gout, double *sums, const float *Pq, const int *gidx, const float *Q, int ns,
+                       const float *e_fin, void *stream);
+
 size_t pn2_group_lift_rows_grad_workspace_bytes(int B, int N, int m, int ns, int N0);
 /* The same pair for the mixed-precision stacks (round 4): Y (B m ns, N0) bf16 (rounded to nearest even; `stats` are the
  * column sums of the rounded values, the convention of pn2_mlp_gemm_bf16) and G (M, N0) bf16 (what pn2_mlp_bwd_bf16 /

@@ -280,3 +280,111 @@ def test_bf16_first_level_takes_the_rows_grouped_next_to_the_query():
         torch.testing.assert_close(c, d, atol=1e-5, rtol=1e-5)          # (batch statistics through fp64 atomics: last-bit noise)
     finally:
         fused_mlp.set_mlp_dtype(prev)
+
+
+# --------------------------------------------------------------- lifted first layer without its output (PRO_LIFT / EPI_MASKL)
+def _lift_case(B, N, m, ns, C, N0, normalize, r, seed):
+    g = torch.Generator().manual_seed(seed)
+    xyz = (_unit_ball(B, N, seed + 1) * 3.0 + 1.5).to(DEV)           # coordinates of a few metres, off-centre
+    sel = torch.stack([torch.randperm(N, generator=g)[:m] for _ in range(B)]).to(DEV)
+    new_xyz = xyz[torch.arange(B, device=DEV)[:, None], sel].contiguous()
+    idx = _ext.ball_query(new_xyz, xyz, r, ns)
+    f = torch.randn(B, N, C, generator=g).to(DEV)
+    W = (torch.randn(N0, 3 + C, generator=g) * 0.2).to(DEV)
+    P = torch.mm(f.view(-1, C), W[:, 3:].t()).view(B, N, N0).contiguous()
+    return xyz, new_xyz, idx, f, W, P, g
+
+
+@pytest.mark.parametrize("B,N,m,ns,C,N0,N1,normalize,r", [(2, 2048, 1024, 32, 128, 128, 128, True, 0.4 * 3),
+                                                           (3, 700, 130, 16, 256, 128, 128, True, 0.4 * 3),
+                                                           (2, 1000, 77, 64, 32, 64, 64, False, 0.4 * 3),
+                                                           (1, 513, 5, 16, 20, 128, 96, True, 1.0),
+                                                           (2, 1024, 512, 16, 256, 128, 128, True, 1.2 * 3)])
+def test_lifted_layer_without_its_output_matches_the_stored_form(B, N, m, ns, C, N0, N1, normalize, r):
+    """pn2_lift_points / pn2_group_lift_stats / pn2_mlp_gemm_lift / pn2_mlp_wgrad_lift / pn2_mlp_dgrad_lift: y0 = Pq[gidx] - Q
+    equals W [rel | f[idx]] (float64) to 1e-5; the three consumers equal the library's own kernels run on the MATERIALISED
+    y0 = Pq[gidx] - Q — bit for bit where nothing is summed with atomics (the GEMM outputs), to summation order elsewhere.
+    Ragged tiles (M = 80), 16 / 32 / 64 rows per centre, a 64-wide lifted layer."""
+    e = _ext
+    xyz, new_xyz, idx, f, W, P, g = _lift_case(B, N, m, ns, C, N0, normalize, r, B * N + C)
+    Wx = W[:, :3].contiguous()
+    Pq, Q = e.lift_points(P, xyz, new_xyz, Wx, normalize, r)
+    stats = torch.zeros(2, N0, dtype=torch.float64, device=DEV)
+    gidx = e.group_lift_stats(Pq, Q, idx, N, stats)
+    flat = (idx.long() + (torch.arange(B, device=DEV) * N).view(B, 1, 1)).view(-1)
+    assert torch.equal(gidx.long(), flat)
+    M = flat.numel()
+    y0 = Pq[flat] - Q.repeat_interleave(ns, dim=0)                    # the same fp32 subtraction the kernels make
+    rows = e.group_concat_rows(xyz, new_xyz, f, idx, True, normalize, r).view(-1, 3 + C)
+    want = rows.double() @ W.double().t()
+    assert float((y0.double() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+    torch.testing.assert_close(stats[0], y0.double().sum(0), rtol=1e-6, atol=1e-6 * M)
+    torch.testing.assert_close(stats[1], y0.double().square().sum(0), rtol=1e-6, atol=1e-6 * M)
+    assert e.mlp_lift_supported(N0, N1, ns)
+    # forward of the layer above
+    fin0 = _fin(N0, 5)
+    W1 = (torch.randn(N1, N0, generator=g) * 0.1).to(DEV)
+    st_a = torch.zeros(2, N1, dtype=torch.float64, device=DEV)
+    st_b = torch.zeros_like(st_a)
+    Ya = e.mlp_gemm_lift(Pq, gidx, Q, ns, fin0, W1, st_a)
+    Yb = e.mlp_gemm(y0, W1, pro=e.PRO_BNRELU, epi=e.EPI_STATS, p=(fin0[2], fin0[3]), stats=st_b)
+    assert torch.equal(Ya, Yb)
+    torch.testing.assert_close(st_a, st_b, rtol=1e-6, atol=1e-6 * M)
+    # weight gradient
+    G = torch.randn(M, N1, generator=g).to(DEV)
+    consts = (torch.randn(3, N1, generator=g) * 0.5).to(DEV).contiguous()
+    dWa = e.mlp_wgrad_lift(Ya, consts, G, Pq, gidx, Q, ns, fin0)
+    dWb = e.mlp_wgrad(Ya, consts, y0, e.PRO_GY, e.PRO_BNRELU, G=G, a_fin=fin0)
+    torch.testing.assert_close(dWa, dWb, rtol=1e-4, atol=1e-4 * float(dWb.abs().max()))
+    a0 = torch.relu(y0.double() * fin0[2].double() + fin0[3].double())
+    gy = consts[0].double() * G.double() + consts[1].double() * Ya.double() + consts[2].double()
+    dW_want = gy.t() @ a0
+    assert float((dWa.double() - dW_want).abs().max()) < 1e-5 * float(dW_want.abs().max()) + 1e-6
+    # input gradient + mask + BatchNorm-backward sums of the lifted layer
+    Wt = W1.t().contiguous()                                           # (K, N) rows
+    su_a = torch.zeros(2, N0, dtype=torch.float64, device=DEV)
+    su_b = torch.zeros_like(su_a)
+    Ga = e.mlp_dgrad_lift(G, Ya, consts, Wt, su_a, Pq, gidx, Q, ns, fin0)
+    Gb = e.mlp_gemm(G, Wt, pro=e.PRO_GY, epi=e.EPI_MASK, X2=Ya, p=(consts[0], consts[1], consts[2]), stats=su_b, Yprev=y0,
+                    e_fin=fin0, M=M)
+    assert torch.equal(Ga, Gb)
+    torch.testing.assert_close(su_a, su_b, rtol=1e-6, atol=1e-6 * M)
+
+
+def test_sa_level_without_the_lifted_layers_output_equals_the_stored_route():
+    """One SA level (SA2 of the backbone: 131 -> 128 -> 128 -> 256, 32 rows per centre) with LIFT_FREE on and off: same features,
+    feature gradients and parameter gradients up to fp32 rounding; the free route stores no (M, 128) first-layer output."""
+    import copy
+    from external_src.group_free_3D.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from pointnet2_ops import fused_mlp
+    from test_gpu_round4 import _Calls, _same_up_to_sparse_argmax_flips
+    torch.manual_seed(11)
+    sa = PointnetSAModuleVotes(npoint=1024, radius=0.4, nsample=32, mlp=[128, 128, 128, 256], use_xyz=True,
+                               normalize_xyz=True).cuda().train()
+    xyz = _unit_ball(4, 2048, 51).to(DEV)
+    feats = torch.randn(4, 128, 2048, generator=torch.Generator().manual_seed(52)).to(DEV)
+    gout = torch.randn(4, 256, 1024, generator=torch.Generator().manual_seed(53)).to(DEV)
+
+    def run(free):
+        prev, fused_mlp.LIFT_FREE = fused_mlp.LIFT_FREE, free
+        prev_rows, fused_mlp.LIFT_FREE_MIN_ROWS = fused_mlp.LIFT_FREE_MIN_ROWS, 0      # (131 072 rows here: below the default)
+        try:
+            m = copy.deepcopy(sa)
+            f = feats.clone().requires_grad_(True)
+            geo = m.sample_and_query(xyz, inverse_index=True)
+            with _Calls(_ext, ["group_lift_rows", "group_lift_stats", "mlp_gemm_lift", "mlp_wgrad_lift", "mlp_dgrad_lift"]) as calls:
+                _nx, nf, _i = m(xyz, f, geometry=geo)
+                (nf * gout).sum().backward()
+            want = (0, 1, 1, 1, 1) if free else (1, 0, 0, 0, 0)
+            got = tuple(calls.count[k] for k in ("group_lift_rows", "group_lift_stats", "mlp_gemm_lift", "mlp_wgrad_lift", "mlp_dgrad_lift"))
+            assert got == want, got
+            return nf.detach(), f.grad, {n: p.grad for n, p in m.named_parameters()}
+        finally:
+            fused_mlp.LIFT_FREE, fused_mlp.LIFT_FREE_MIN_ROWS = prev, prev_rows
+
+    nf_a, gf_a, g_a = run(True)
+    nf_b, gf_b, g_b = run(False)
+    torch.testing.assert_close(nf_a, nf_b, atol=2e-5, rtol=1e-5)
+    _same_up_to_sparse_argmax_flips("d features", gf_a, gf_b)
+    for k in g_b:
+        assert float((g_a[k] - g_b[k]).norm()) <= 1e-2 * float(g_b[k].norm()) + 1e-6, k

@@ -7,8 +7,8 @@ per launch) and `alg_bytes_per_launch` (bench.py, per entry point) describe the 
 (the family average mixed the pooled and first-layer variants into `pn2_mlp_gemm`)."""
 import re
 
-PRO = {0: "PRO_NONE", 1: "PRO_BNRELU", 2: "PRO_GY", 3: "PRO_POOLG", 4: "PRO_FIRST"}      # csrc/mlp_common.h
-EPI = {0: "EPI_NONE", 1: "EPI_STATS", 2: "EPI_MASK", 3: "EPI_POOL"}
+PRO = {0: "PRO_NONE", 1: "PRO_BNRELU", 2: "PRO_GY", 3: "PRO_POOLG", 4: "PRO_FIRST", 5: "PRO_LIFT"}      # csrc/mlp_common.h
+EPI = {0: "EPI_NONE", 1: "EPI_STATS", 2: "EPI_MASK", 3: "EPI_POOL", 4: "EPI_MASKL"}
 
 ENTRY_OF_FAMILY = {
     "mlp_wgrad_kernel": "pn2_mlp_wgrad", "mlp_bwd_fused_kernel": "pn2_mlp_bwd_fused", "mlp_bwd_fused2_kernel": "pn2_mlp_bwd_fused_fold",
@@ -23,6 +23,7 @@ ENTRY_OF_FAMILY = {
     "fps_resident_kernel": "pn2_furthest_point_sampling", "fps_order_m_kernel": "pn2_furthest_point_sampling", "fps_order_check_kernel": "pn2_furthest_point_sampling", "fps_bucket_kernel": "pn2_furthest_point_sampling",
     "gcn_linear_kernel": "pn2_gcn_linear", "gcn_bn_bwd_kernel": "pn2_gcn_linear_grad_w", "gcn_wgrad_kernel": "pn2_gcn_linear_grad_w",
     "gcn_linear_grad_x_kernel": "pn2_gcn_linear_grad_x",
+    "group_lift_stats_kernel": "pn2_group_lift_rows", "lift_points_kernel": "pn2_lift_points",
     "inv_cloud_kernel": "pn2_group_inverse_index", "inv_keys_kernel": "pn2_group_inverse_index", "inv_ptr_kernel": "pn2_group_inverse_index",
     "three_interpolate_rows_grad_csr_kernel": "pn2_three_interpolate_rows_grad", "three_interpolate_rows_grad_kernel": "pn2_three_interpolate_rows_grad",
     "pool_bwd_prep_kernel": "pn2_pool_bwd_prep", "bn_relu_bwd_prep_kernel": "pn2_bn_relu_bwd_prep",
