@@ -73,6 +73,12 @@ struct GemmBf16Args {
   long long seg_max;  // host: rows of the longest segment (grid)
   int nseg, pstride, sstride, estride;
   int vcap;           // the persistent grid a call of ONE scan would get at most (see the virtual workgroups of the kernel)
+  // EPI_POOL (the max-pooled last layer without its output, as csrc/mlp_gemm.hip EPI_POOL): per partial group of
+  // psz = min(ns, 32) rows and column the maximum of the fp32 accumulators and its row; W arrives with the rows of
+  // negative-gamma columns negated, sgn restores the column sums.  Y is not written.
+  float *pmax;        // [M/psz][N]
+  int *parg;          // [M/psz][N]
+  const float *sgn;   // [N]
 };
 
 // ---------------------------------------------------------------------------------------------- forward / dgrad
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
 
     // ---- epilogue: C layout — lane holds column nt*32 + (lane & 31), rows (i&3) + 8*(i>>2) + 4*(lane>>5) of its wave
     const int ys = YF32 ? 4 : 2;
-    const rsrc_t rY = make_rsrc((char *)a.Y + (size_t)row0 * a.ldy * ys, rows_left * a.ldy * ys);
+    const rsrc_t rY = EPI == EPI_POOL ? make_rsrc((const void *)a.pmax, 4)
+                                      : make_rsrc((char *)a.Y + (size_t)row0 * a.ldy * ys, rows_left * a.ldy * ys);
     rsrc_t rYp = rY;
     if constexpr (EPI == EPI_MASK) rYp = make_rsrc((const char *)a.Yprev + (size_t)row0 * a.ldy * 2, rows_left * a.ldy * 2);
     if constexpr (EPI == EPI_MASK) {
@@ -376,6 +383,58 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
       for (int t = tid; t < TM * CGn; t += NTH) {
         const int r = t / CGn, cg = t - r * CGn;
         bstore128(*(const u32x4 *)&sY[r * YP + cg * 8], rY, (r * a.ldy + cg * 8) * 2, 0);
+      }
+    } else if constexpr (EPI == EPI_POOL) {
+      // statistics + group maxima of the fp32 accumulators; nothing is stored to Y (see csrc/mlp_gemm.hip EPI_POOL: the C
+      // layout is the same — registers 0-7 of a lane are one 16-row sub-group of the wave's 32 rows, 8-15 the other)
+      const bool psz16 = a.ns == 16;
+      const int psh = psz16 ? 4 : 5;
+      const long long npart = a.M >> psh, pfirst = row0 >> psh;
+      const long long pleft = npart > pfirst ? npart - pfirst : 0;
+      const rsrc_t rspv = make_rsrc(pleft ? (const void *)(a.pmax + (size_t)pfirst * N) : (const void *)a.pmax, pleft ? pleft * N * 4 : 4);
+      const rsrc_t rspr = make_rsrc(pleft ? (const void *)(a.parg + (size_t)pfirst * N) : (const void *)a.parg, pleft ? pleft * N * 4 : 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = (wc * NT + nt) * 32 + (lane & 31);
+        float bst[2];
+        int bi[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          bst[q] = acc[nt][8 * q];
+          bi[q] = 0;
+          s1[nt] += bst[q];
+          s2[nt] = fmaf(bst[q], bst[q], s2[nt]);
+#pragma unroll
+          for (int r = 1; r < 8; ++r) {
+            const float v = acc[nt][8 * q + r];
+            const bool gt = v > bst[q];
+            bst[q] = gt ? v : bst[q];
+            bi[q] = gt ? r : bi[q];
+            s1[nt] += v;
+            s2[nt] = fmaf(v, v, s2[nt]);
+          }
+        }
+        float b[2];
+        int rw[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {        // the two half-waves interleave in blocks of four rows: larger value, then smaller row
+          const int row = (bi[q] & 3) + 8 * (bi[q] >> 2) + 4 * (lane >> 5);
+          const float ob = __shfl_xor(bst[q], 32);
+          const int orow = __shfl_xor(row, 32);
+          const bool take = ob > bst[q] || (ob == bst[q] && orow < row);
+          b[q] = take ? ob : bst[q];
+          rw[q] = take ? orow : row;
+        }
+        const bool second = b[1] > b[0];
+        const float b32 = second ? b[1] : b[0];
+        const int r32 = second ? 16 + rw[1] : rw[0];
+        const bool hi = (lane >> 5) != 0;
+        const float vout = psz16 ? (hi ? b[1] : b[0]) : b32;
+        const int rout = psz16 ? (hi ? rw[1] : rw[0]) : r32;
+        const int pl = psz16 ? wave * 2 + (lane >> 5) : wave;
+        const int poff = (pleft && c < N && (psz16 || lane < 32)) ? (pl * N + c) * 4 : kOobOffset;
+        bstore(vout, rspv, poff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)rout, rspr, poff, 0, 0);
       }
     } else {
 #pragma unroll
@@ -423,7 +482,9 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
       const int which = e / (NTT * 32), c = e - which * NTT * 32;
       if (c < N) {
         const float *p = red + which * 4 * NTT * 32 + c;
-        atomicAdd(a.stats + (size_t)which * a.Nfull + c, (double)p[0] + (double)p[NTT * 32] + (double)p[2 * NTT * 32] + (double)p[3 * NTT * 32]);
+        double tsum = (double)p[0] + (double)p[NTT * 32] + (double)p[2 * NTT * 32] + (double)p[3 * NTT * 32];
+        if constexpr (EPI == EPI_POOL) { if (which == 0) tsum *= (double)a.sgn[c]; }
+        atomicAdd(a.stats + (size_t)which * a.Nfull + c, tsum);
       }
     }
   }
@@ -709,12 +770,15 @@ struct BwdBf16Args {
   int vcap;                 // grid cap of a single-scan call (virtual workgroups, see mlp_gemm_bf16_kernel)
 };
 
-template <int NTN, int KTK, int GMODE, bool FOLD = false>
+// RECOMP (GMODE PRO_POOLG: the layer is a max-pooled LAST layer whose output was never stored, pn2_mlp_gemm_pool_bf16): the
+// y_l tile is re-formed from the y_{l-1} tile the kernel stages anyway — the forward's own matrix product (same operands, same
+// MFMA order: the fp32 accumulators the forward took its maxima and statistics from, bit for bit) — instead of loaded.
+template <int NTN, int KTK, int GMODE, bool FOLD = false, bool RECOMP = false>
 // (HIP's second launch-bounds argument is waves per SIMD, not workgroups per CU.  The FOLD variants took 144-156 registers
 // under "2": three waves per SIMD, i.e. ONE eight-wave workgroup per CU.  Capped at 128 they spill 24-88 bytes outside
 // the tile loop's matrix products and two workgroups share a CU: 4.2M x 64 x 64 fold 0.59 -> 0.48 ms.  The 128 x 128
 // non-fold variants lose with the same cap (0.22 -> 0.25 ms; pooled form at 18.9M rows 5.06 -> 5.23 ms) and keep their registers.)
-__global__ __launch_bounds__(512, FOLD ? 4 : 2) void mlp_bwd_bf16_kernel(const BwdBf16Args a_in) {
+__global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void mlp_bwd_bf16_kernel(const BwdBf16Args a_in) {
   BwdBf16Args a = a_in;
   if (a.seg) {
     const int sg = blockIdx.y;
@@ -772,6 +836,23 @@ __global__ __launch_bounds__(512, FOLD ? 4 : 2) void mlp_bwd_bf16_kernel(const B
     }
   }
 
+  // RECOMP: the wave's block of the re-formed y_l tile has the same columns in every tile (2 NTN <= 8 blocks, one per wave):
+  // its weight fragments — 8 consecutive k of column n, gathered from the k-major LDS image — are formed ONCE
+  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+  constexpr bool RC1 = RECOMP && 2 * NTN <= 8;
+  bf16x8 wfrag[RC1 ? KB / 16 : 1];
+  if constexpr (RC1) {
+    __syncthreads();                                   // the weights are in LDS
+    const int ct = wave % NTN;
+#pragma unroll
+    for (int ks = 0; ks < KB / 16; ++ks) {
+      us8 bw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        bw[j] = __builtin_bit_cast(unsigned short, sWt[(ks * 16 + (lane >> 5) * 8 + j) * NP + ct * 32 + (lane & 31)]);
+      wfrag[ks] = __builtin_bit_cast(bf16x8, bw);
+    }
+  }
   f32x16 accw[WT];
 #pragma unroll
   for (int i = 0; i < WT; ++i)
@@ -797,11 +878,11 @@ __global__ __launch_bounds__(512, FOLD ? 4 : 2) void mlp_bwd_bf16_kernel(const B
       const rsrc_t rX0 = make_rsrc((const char *)a.X + (size_t)row0 * 16, left * 16);
       rxr = bload128(rX0, tid < MT ? tid * 16 : kOobOffset, 0);
     }
-    const rsrc_t rG = make_rsrc((const char *)(GMODE == PRO_GY ? a.G : a.Yl) + (size_t)row0 * N * 2, left * N * 2);
-    const rsrc_t rY = make_rsrc((const char *)a.Yl + (size_t)row0 * N * 2, left * N * 2);
     const rsrc_t rX = make_rsrc((const char *)a.Yprev + (size_t)row0 * K * 2, left * K * 2);
+    const rsrc_t rG = RECOMP ? rX : make_rsrc((const char *)(GMODE == PRO_GY ? a.G : a.Yl) + (size_t)row0 * N * 2, left * N * 2);
+    const rsrc_t rY = RECOMP ? rX : make_rsrc((const char *)a.Yl + (size_t)row0 * N * 2, left * N * 2);
 #pragma unroll
-    for (int i = 0; i < GT; ++i) {
+    for (int i = 0; i < (RECOMP ? 0 : GT); ++i) {
       const int t = tid + 512 * i;
       const int rp = t / CGn, cg = t - rp * CGn;
       const int off = t < 32 * CGn ? (2 * rp * N + cg * 8) * 2 : kOobOffset;
@@ -837,7 +918,7 @@ __global__ __launch_bounds__(512, FOLD ? 4 : 2) void mlp_bwd_bf16_kernel(const B
     }
     // ---- commit: gy tile (row-major + transposed), activation tile (raw row-major + activated transposed)
 #pragma unroll
-    for (int i = 0; i < GT; ++i) {
+    for (int i = 0; i < (RECOMP ? 0 : GT); ++i) {
       const int t = tid + 512 * i;
       if (t < 32 * CGn) {
         const int rp = t / CGn, cg = t - rp * CGn, m = 2 * rp, n = cg * 8;
@@ -881,6 +962,58 @@ __global__ __launch_bounds__(512, FOLD ? 4 : 2) void mlp_bwd_bf16_kernel(const B
           const float aa = ok0 ? fmaxf(fmaf(xa, sc, sh), 0.f) : 0.f;
           const float ab = ok1 ? fmaxf(fmaf(xb, sc, sh), 0.f) : 0.f;
           *(unsigned *)&sXT[(k + e) * MP + swz<MT>(k + e, m)] = bf_pack(aa, ab);
+        }
+      }
+    }
+    if constexpr (RECOMP) {
+      // y_l tile = relu(bn(y_{l-1})) W^T on the matrix pipe (one 32 x 32 block per wave and pass), then the dense part of
+      // dL/dy_l = c2 y_l + c3 into the row-major and the transposed gy tiles; the arg-max patch below adds c1 gP
+      __syncthreads();                               // the raw y_{l-1} tile is in sO
+      typedef unsigned u2r __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int yi = 0; yi < (2 * NTN + 7) / 8; ++yi) {
+        const int t = wave + 8 * yi;
+        if (t < 2 * NTN) {                           // wave-uniform
+          const int rt = t / NTN, ct = t - rt * NTN;
+          f32x16 acc;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KB / 16; ++ks) {
+            const int k0 = ks * 16 + (lane >> 5) * 8;
+            const u32x4 raw = *(const u32x4 *)&sO[(rt * 32 + (lane & 31)) * KP + k0];
+            u32x4 aw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = fmaxf(fmaf(bf_lo(raw[e]), sF[2 * KB + k0 + 2 * e], sF[3 * KB + k0 + 2 * e]), 0.f);
+              const float hi = fmaxf(fmaf(bf_hi(raw[e]), sF[2 * KB + k0 + 2 * e + 1], sF[3 * KB + k0 + 2 * e + 1]), 0.f);
+              aw[e] = bf_pack(lo, hi);
+            }
+            bf16x8 bfr;
+            if constexpr (RC1) {
+              bfr = wfrag[ks];
+            } else {
+              us8 bw;
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                bw[j] = __builtin_bit_cast(unsigned short, sWt[(k0 + j) * NP + ct * 32 + (lane & 31)]);
+              bfr = __builtin_bit_cast(bf16x8, bw);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw), bfr, acc, 0, 0, 0);
+          }
+          const int n = ct * 32 + (lane & 31);
+          const float c2 = sC[NB + n], c3 = sC[2 * NB + n];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m0 = rt * 32 + 8 * q + 4 * (lane >> 5);
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = row0 + m0 + j < a.M ? fmaf(c2, acc[4 * q + j], c3) : 0.f;
+              sGY[(m0 + j) * NP + n] = (bf16)v[j];
+            }
+            *(u2r *)&sGT[n * MP + swz<MT>(n, m0)] = u2r{bf_pack(v[0], v[1]), bf_pack(v[2], v[3])};
+          }
         }
       }
     }
@@ -1026,12 +1159,12 @@ __global__ __launch_bounds__(512, FOLD ? 4 : 2) void mlp_bwd_bf16_kernel(const B
   }
 }
 
-template <int NTN, int KTK, int GMODE, bool FOLD = false>
+template <int NTN, int KTK, int GMODE, bool FOLD = false, bool RECOMP = false>
 int launch_bwd(const BwdBf16Args &a, hipStream_t s) {
   constexpr int MT = 64, MP = MT + 8, NB = NTN * 32, KB = KTK * 32, NP = NB + 8, KP = KB + 8;
   const size_t lds = (size_t)(KB * NP + MT * NP + NB * MP + KB * MP + MT * KP) * 2 + (size_t)(3 * NB + 4 * KB) * 4 +
                      (FOLD ? (size_t)(MT > KB ? MT : KB) * 8 * 4 : 0);
-  auto kfn = mlp_bwd_bf16_kernel<NTN, KTK, GMODE, FOLD>;
+  auto kfn = mlp_bwd_bf16_kernel<NTN, KTK, GMODE, FOLD, RECOMP>;
   static bool big_lds = false;
   if (lds > 64 * 1024 && !big_lds) {
     if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1434,6 +1567,34 @@ extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, in
                         SegTab{nullptr, 1, 0, 0}, stream);
 }
 
+// The max-pooled last layer of a stack on the bf16 path WITHOUT its (M, N) output (the bf16 counterpart of pn2_mlp_gemm_pool):
+// X (M, ldx) bf16 = y_{L-1}, p0 / p1 its BatchNorm scale / shift, Wf (N, K) fp32 with the rows of negative-gamma columns negated
+// (pn2_pool_flip_rows; sgn (N)), ns rows per group (16, 32, 64 or 128; M % ns == 0) -> pmax / parg (M / min(ns, 32), N): maximum
+// of the fp32 accumulators over each partial group and its row, stats (2, N) += column sums of y_L and y_L^2 (un-flipped, of
+// the fp32 accumulators: nothing is rounded to bf16 because nothing is stored).  pn2_pool_finalize turns pmax / parg into the
+// pooled activations; the backward re-forms y_L from y_{L-1} (pn2_mlp_bwd_bf16_pool).  N in {64, 128}, K <= 128.
+extern "C" int pn2_mlp_gemm_pool_bf16_supported(int K, int N, int ns) {
+  return (N == 64 || N == 128) && K >= 1 && K <= 128 && (ns == 16 || ns == 32 || ns == 64 || ns == 128);
+}
+
+extern "C" int pn2_mlp_gemm_pool_bf16(long long M, int K, int N, int ldx, const void *X, const float *p0, const float *p1,
+                                      const float *Wf, const float *sgn, int ns, double *stats, float *pmax, int *parg,
+                                      void *stream) {
+  if (M < 0 || !pn2_mlp_gemm_pool_bf16_supported(K, N, ns) || ldx < K || ldx % 8 != 0) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (M % ns != 0) return PN2_EINVAL;
+  if (!X || !p0 || !p1 || !Wf || !sgn || !stats || !pmax || !parg) return PN2_ENULL;
+  if ((uintptr_t)X & 15) return PN2_EINVAL;
+  GemmBf16Args a = {};
+  a.X = X; a.p0 = p0; a.p1 = p1; a.W = Wf; a.Y = nullptr; a.stats = stats; a.M = M; a.K = K; a.N = N; a.ldx = ldx; a.ldy = N;
+  a.ns = ns; a.Kp = (K + KC - 1) / KC * KC; a.wres = 0; a.Nfull = N;
+  a.seg = nullptr; a.nseg = 1; a.seg_max = 0; a.pstride = 0; a.sstride = 2 * N; a.estride = 4 * N; a.vcap = 0;
+  a.pmax = pmax; a.parg = parg; a.sgn = sgn;
+  hipStream_t s = (hipStream_t)stream;
+  return N == 64 ? launch_gemm<2, 1, PRO_BNRELU, EPI_POOL, false, false>(a, s)
+                 : launch_gemm<4, 1, PRO_BNRELU, EPI_POOL, false, false>(a, s);
+}
+
 // Batched scans with per-scan BatchNorm statistics in ONE launch: the M rows are nseg scans, scan s = rows
 // [seg[s], seg[s+1]) (device array of nseg + 1 offsets, multiples of ns for PRO_POOLG; seg_max = the longest scan, for the
 // grid); every per-channel operand is an array of per-scan blocks — p0 / p1 / p2 at a pitch of `pstride` floats (forward:
@@ -1547,6 +1708,33 @@ extern "C" int pn2_mlp_bwd_bf16(long long M, int N, int K, int gmode, const void
   a.ns = ns; a.X = nullptr; a.P1 = nullptr; a.K0 = 0;
   a.seg = nullptr; a.nseg = 1; a.seg_max = 0;
   return gmode == PRO_GY ? dispatch_bwd<PRO_GY>(a, (hipStream_t)stream) : dispatch_bwd<PRO_POOLG>(a, (hipStream_t)stream);
+}
+
+// ... of a max-pooled LAST layer whose output pn2_mlp_gemm_pool_bf16 never stored: y_l is re-formed from y_{l-1} (Yprev) and
+// Wt inside the kernel (RECOMP above); consts / arg / gP / sums / dW as pn2_mlp_bwd_bf16 with gmode PRO_POOLG.  N in {64, 128}.
+extern "C" int pn2_mlp_bwd_bf16_pool_supported(int N, int K) { return (N == 64 || N == 128) && (K == 32 || K == 64 || K == 128) && pn2_mlp_bwd_bf16_supported(N, K); }
+
+extern "C" int pn2_mlp_bwd_bf16_pool(long long M, int N, int K, const float *consts, const int *arg, const float *gP, int ns,
+                                     const float *Wt, const void *Yprev, const float *a_fin, void *Gout, double *sums,
+                                     float *dW, void *stream) {
+  if (M < 0 || !pn2_mlp_bwd_bf16_pool_supported(N, K) || ns < 16) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!consts || !arg || !gP || !Wt || !Yprev || !a_fin || !Gout || !sums || !dW) return PN2_ENULL;
+  if (((uintptr_t)Yprev & 15) || ((uintptr_t)Gout & 15)) return PN2_EINVAL;
+  BwdBf16Args a;
+  a.G = nullptr; a.Yl = nullptr; a.consts = consts; a.arg = arg; a.gP = gP; a.Wt = Wt;
+  a.Yprev = (const bf16 *)Yprev; a.a_fin = a_fin; a.Gout = (bf16 *)Gout; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K;
+  a.ns = ns; a.X = nullptr; a.P1 = nullptr; a.K0 = 0;
+  a.seg = nullptr; a.nseg = 1; a.seg_max = 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch ((N / 32) * 8 + K / 32) {
+    case 2 * 8 + 1: return launch_bwd<2, 1, PRO_POOLG, false, true>(a, s);
+    case 2 * 8 + 2: return launch_bwd<2, 2, PRO_POOLG, false, true>(a, s);
+    case 2 * 8 + 4: return launch_bwd<2, 4, PRO_POOLG, false, true>(a, s);
+    case 4 * 8 + 2: return launch_bwd<4, 2, PRO_POOLG, false, true>(a, s);
+    case 4 * 8 + 4: return launch_bwd<4, 4, PRO_POOLG, false, true>(a, s);
+    default: return PN2_EINVAL;
+  }
 }
 
 // pn2_mlp_bwd_bf16 over nseg scans (see pn2_mlp_gemm_bf16_seg): consts (S,3,N), a_fin (S,4,K), sums (S,2,K); dW = the SUM.

@@ -127,6 +127,8 @@ _SIGNATURES = {
     "pn2_rows_gram_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp],
     "pn2_mlp_wgrad_bf16": [ctypes.c_longlong] + [_c_int] * 6 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
+    "pn2_mlp_gemm_pool_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
+    "pn2_mlp_bwd_bf16_pool": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 7,
     "pn2_bn_relu_apply_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_bwd_prep_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_bn_relu_rows_max_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -180,6 +182,10 @@ _lib.pn2_group_lift_supported.argtypes = [_c_int]
 _lib.pn2_group_lift_supported.restype = _c_int
 _lib.pn2_mlp_lift_supported.argtypes = [_c_int] * 3
 _lib.pn2_mlp_lift_supported.restype = _c_int
+_lib.pn2_mlp_gemm_pool_bf16_supported.argtypes = [_c_int] * 3
+_lib.pn2_mlp_gemm_pool_bf16_supported.restype = _c_int
+_lib.pn2_mlp_bwd_bf16_pool_supported.argtypes = [_c_int] * 2
+_lib.pn2_mlp_bwd_bf16_pool_supported.restype = _c_int
 _lib.pn2_group_lift_rows_grad_workspace_bytes.argtypes = [_c_int] * 5
 _lib.pn2_group_lift_rows_grad_workspace_bytes.restype = _c_sz
 _lib.pn2_ball_query_group_supported.argtypes = [_c_int, _c_int, _c_int, _c_f32, _c_int, _c_int, _c_int]
@@ -250,7 +256,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_ball_query_group_supported", "pn2_ball_query_group_workspace_bytes",
-                                               "pn2_group_lift_supported", "pn2_mlp_lift_supported", "pn2_group_lift_rows_grad_workspace_bytes",
+                                               "pn2_group_lift_supported", "pn2_mlp_lift_supported", "pn2_mlp_gemm_pool_bf16_supported", "pn2_mlp_bwd_bf16_pool_supported", "pn2_group_lift_rows_grad_workspace_bytes",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
@@ -1842,6 +1848,43 @@ def mlp_bwd_bf16(Yl, consts, Wt, Yprev, a_fin, gmode, G=None, arg=None, gP=None,
           _ptr(Wt), _ptr(Yprev), _ptr(a_fin), _ptr(Gout), _ptr(sums), _ptr(dW),
           alg_bytes=2 * (M * N * (2 if gmode == PRO_GY else 1) + 2 * M * K) + 4 * N * K, alg_flops=4 * M * N * K,
           tag=(f"M{M},N{N},K{K},g{int(gmode)}" if DETAIL_TAGS else None))
+    return Gout, sums, dW
+
+
+def pool_layer_bf16_supported(K, N, ns) -> bool:
+    """Shapes the pooled last layer of a bf16 stack can take without its output (forward AND backward)."""
+    return bool(_lib.pn2_mlp_gemm_pool_bf16_supported(int(K), int(N), int(ns))) and bool(_lib.pn2_mlp_bwd_bf16_pool_supported(int(N), int(K)))
+
+
+def mlp_gemm_pool_bf16(X, Wf, sgn, ns, p, stats):
+    """bf16 counterpart of mlp_gemm_pool: X (M, K) bf16 = y_{L-1}, p = (scale, shift) of its BatchNorm -> (pmax, parg) partial
+    maxima (M / min(ns, 32), N) of the fp32 accumulators of relu(bn(X)) @ Wf^T; nothing of the (M, N) output is stored."""
+    _bf16(X, "X"); _f32(Wf, "Wf")
+    N, K = Wf.shape
+    M = X.size(0)
+    psz = min(int(ns), 32)
+    pmax = torch.empty(M // psz, N, dtype=torch.float32, device=X.device)
+    parg = torch.empty(M // psz, N, dtype=torch.int32, device=X.device)
+    _call("pn2_mlp_gemm_pool_bf16", X, M, K, N, X.size(1), _ptr(X), _ptr(p[0]), _ptr(p[1]), _ptr(Wf), _ptr(sgn), int(ns),
+          _ptr(stats), _ptr(pmax), _ptr(parg), alg_bytes=2 * M * K + 4 * N * K + 8 * (M // psz) * N, alg_flops=2 * M * N * K,
+          tag=(f"M{M},K{K},N{N},ns{int(ns)}" if DETAIL_TAGS else None))
+    return pmax, parg
+
+
+def mlp_bwd_bf16_pool(consts, Wt, Yprev, a_fin, arg, gP, ns, sums=None, dW=None):
+    """mlp_bwd_bf16 (gmode PRO_POOLG) for a pooled last layer whose output was not stored: y_L is re-formed from Yprev inside
+    the kernel -> (Gout (M, K) bf16, sums (2, K) f64, dW (N, K) f32)."""
+    _bf16(Yprev, "Yprev")
+    M, K = Yprev.shape
+    N = Wt.size(1)
+    Gout = torch.empty(M, K, dtype=torch.bfloat16, device=Yprev.device)
+    if sums is None:
+        sums = torch.zeros(2, K, dtype=torch.float64, device=Yprev.device)
+    if dW is None:
+        dW = torch.zeros(N, K, dtype=torch.float32, device=Yprev.device)
+    _call("pn2_mlp_bwd_bf16_pool", Yprev, M, N, K, _ptr(consts), _ptr(arg), _ptr(gP), int(ns), _ptr(Wt), _ptr(Yprev), _ptr(a_fin),
+          _ptr(Gout), _ptr(sums), _ptr(dW), alg_bytes=2 * (2 * M * K) + 4 * N * K + 8 * (M // int(ns)) * N, alg_flops=6 * M * N * K,
+          tag=(f"M{M},N{N},K{K},pool" if DETAIL_TAGS else None))
     return Gout, sums, dW
 
 

@@ -73,6 +73,10 @@ LIFT_FREE = _os.environ.get("PN2_LIFT_FREE") == "1"
 #: four kernels involved, 262k rows 0.400 -> 0.398, 131k rows 0.228 -> 0.241: below, the two extra launches cost more than
 #: the tensor)
 LIFT_FREE_MIN_ROWS = int(_os.environ.get("PN2_LIFT_FREE_MIN_ROWS", str(1 << 17 | 1 << 16)))
+#: bf16 node: the max-pooled last layer never stores its (M, C_out) output either (pn2_mlp_gemm_pool_bf16: maxima of the fp32
+#: accumulators in the GEMM's epilogue; the backward re-forms y_L from y_{L-1} on the matrix pipe, pn2_mlp_bwd_bf16_pool) — stacks
+#: of three layers or more whose last layer is at most 128 wide (the backbone's SA1).  PN2_BF16_POOL=0: stored route (A/B).
+BF16_POOL = _os.environ.get("PN2_BF16_POOL") != "0"
 #: ... also inside segment-table stacks (per-scan statistics at the whole-batch launch count): the lifted layer is issued once
 #: per scan (the launches of single-scan steps), the rest of the stack through the table.  PN2_BF16_LIFT_SEG=0: grouped route.
 BF16_LIFT_SEG = _os.environ.get("PN2_BF16_LIFT_SEG") != "0"
@@ -597,12 +601,20 @@ class _FusedMLPBf16(Function):
         stat_bufs = e.zero_arena((feats if lift else x).device,
                                  [(lead + (2, conv.out_channels), torch.float64) for conv, _ in layers])
         cur = x
+        bnL = layers[-1][1]
+        pool_bf = bool(BF16_POOL and ns and L >= 3 and seg is None and not isinstance(ctx, _SegCtx) and M % ns == 0
+                       and (bnL.training or bnL.running_mean is None) and getattr(e, "mlp_gemm_pool_bf16", None) is not None
+                       and e.pool_layer_bf16_supported(layers[-1][0].in_channels, layers[-1][0].out_channels, ns))
+        pooled_parts = None
         for l, (conv, bn) in enumerate(layers):
             W = params[3 * l].view(conv.out_channels, conv.in_channels)
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
             use_batch = bn.training or bn.running_mean is None
             pro = e.PRO_NONE if l == 0 else e.PRO_BNRELU
             p = None if l == 0 else ((fins[-1][2], fins[-1][3]) if seg is None else (fins[-1][:, 2], fins[-1][:, 3]))
+            if pool_bf and l == L - 1:
+                Wfl, sgn = e.pool_flip_rows(W.contiguous(), gamma)
+                pooled_parts = e.mlp_gemm_pool_bf16(cur, Wfl, sgn, ns, p, stat_bufs[l]) + (sgn,)
             if seg is not None:
                 if not use_batch:
                     raise RuntimeError("fused_mlp: a segment table needs training-mode BatchNorm in every layer")
@@ -620,6 +632,8 @@ class _FusedMLPBf16(Function):
                 stats = stat_bufs[l]
                 if lift and l == 0:
                     y, ctx.lift_P = _lift_forward(e, feats, W, group, stats, out_bf16=True)
+                elif pooled_parts is not None:
+                    y = None
                 else:
                     y = e.mlp_gemm_bf16(cur, W, pro=pro, epi=e.EPI_STATS, p=p, stats=stats)
                 momentum = 0.0
@@ -648,7 +662,10 @@ class _FusedMLPBf16(Function):
             batch_flags.append(use_batch)
             cur = y
         yraw = None
-        if ns:
+        ctx.pool_bf = pooled_parts is not None
+        if pooled_parts is not None:
+            out, arg, yraw = e.pool_finalize(pooled_parts[0], pooled_parts[1], fins[-1], pooled_parts[2], ns)
+        elif ns:
             out, arg, yraw = e.bn_relu_rows_max_bf16(ys[-1], fins[-1], ns, seg=seg)
         elif seg is not None:
             raise RuntimeError("fused_mlp: a segment table needs a pooled stack")
@@ -744,6 +761,15 @@ class _FusedMLPBf16(Function):
                     dst = getattr(ctx, "gx_out", None)
                     if dst is not None:
                         gx = dst.copy_(gx)
+                continue
+            if l == L - 1 and getattr(ctx, "pool_bf", False):
+                # pooled last layer whose output was not stored: y_L is re-formed inside the kernel (csrc/mlp_bf16.hip RECOMP)
+                consts, dgamma, dbeta, Wt = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l],
+                                                            W=Ws[l].contiguous(), k0=0)
+                grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+                G, sums, dW = e.mlp_bwd_bf16_pool(consts, Wt, ys[l - 1], fins[l - 1], arg, gPm, ns, sums=sums_in[l], dW=dWs[l])
+                grads[3 * l] = dW.view(ctx.shapes[l])
+                gmode, arg, gPm = e.PRO_GY, None, None
                 continue
             need_dgrad = l > 0 or need_dgrad0
             k0 = 3 if (l == 0 and ctx.group is not None and ctx.group[3]) else 0

@@ -556,6 +556,24 @@ int pn2_mlp_bwd_bf16_supported(int N, int K);
 int pn2_mlp_bwd_bf16(long long M, int N, int K, int gmode, const void *G, const void *Yl, const float *consts,
                      const int *arg, const float *gP, int ns, const float *Wt, const void *Yprev,
                      const float *a_fin, void *Gout, double *sums, float *dW, void *stream);
+/* The max-pooled LAST layer of a bf16 stack without its (M, N) output (round 5; the bf16 counterpart of pn2_mlp_gemm_pool /
+ * pn2_pool_bwd — Conv2d 1x1 + BatchNorm2d + ReLU + F.max_pool2d of OPS/pointnet2_modules.py:9-19,67-70 under the reference's
+ * 16-bit AMP, scene_graph_prediction/main.py:64):
+ *   pn2_mlp_gemm_pool_bf16  X (M, ldx) bf16 = y_{L-1}, p0 / p1 its BatchNorm scale / shift, Wf (N, K) fp32 with the rows of
+ *                           negative-gamma columns negated (pn2_pool_flip_rows, sgn (N)) -> pmax / parg (M / min(ns, 32), N):
+ *                           maximum of the fp32 accumulators per partial group and its row; stats (2, N) += column sums of
+ *                           y_L, y_L^2 (of the accumulators: nothing is stored, so nothing is rounded).  pn2_pool_finalize
+ *                           turns pmax / parg into the pooled activations, the arg-max rows and their raw values;
+ *   pn2_mlp_bwd_bf16_pool   pn2_mlp_bwd_bf16 with gmode 3 for that layer: y_L is RE-FORMED from y_{L-1} (Yprev) and Wt on the
+ *                           matrix pipe inside the kernel — the forward's own product, bit for bit — instead of read.
+ * N in {64, 128}; K <= 128 (backward: 32, 64 or 128); ns in {16, 32, 64, 128}, M % ns == 0. */
+int pn2_mlp_gemm_pool_bf16_supported(int K, int N, int ns);
+int pn2_mlp_gemm_pool_bf16(long long M, int K, int N, int ldx, const void *X, const float *p0, const float *p1,
+                           const float *Wf, const float *sgn, int ns, double *stats, float *pmax, int *parg, void *stream);
+int pn2_mlp_bwd_bf16_pool_supported(int N, int K);
+int pn2_mlp_bwd_bf16_pool(long long M, int N, int K, const float *consts, const int *arg, const float *gP, int ns,
+                          const float *Wt, const void *Yprev, const float *a_fin, void *Gout, double *sums, float *dW,
+                          void *stream);
 int pn2_bn_relu_apply_bf16(long long M, int N, const void *y, const float *fin, float *out, void *stream);
 int pn2_bn_relu_bwd_prep_bf16(long long M, int N, const void *y, const float *gout, const float *fin,
                               void *gpre, double *sums, void *stream);

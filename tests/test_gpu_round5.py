@@ -388,3 +388,138 @@ def test_sa_level_without_the_lifted_layers_output_equals_the_stored_route():
     _same_up_to_sparse_argmax_flips("d features", gf_a, gf_b)
     for k in g_b:
         assert float((g_a[k] - g_b[k]).norm()) <= 1e-2 * float(g_b[k].norm()) + 1e-6, k
+
+
+# ------------------------------------------------------------------ bf16: pooled last layer without its output
+@pytest.mark.parametrize("M,K,N,ns", [(64 * 300, 64, 128, 64), (32 * 257, 128, 128, 32), (16 * 111, 64, 64, 16), (128 * 9, 64, 128, 128),
+                                      (16 * 5, 96, 128, 16)])
+def test_bf16_pooled_last_layer_forward_takes_the_maxima_of_its_accumulators(M, K, N, ns):
+    """pn2_mlp_gemm_pool_bf16 + pn2_pool_finalize against float64 on the operands the kernel sees (bf16 activations formed
+    with the kernel's fma, bf16 weights): group maxima within fp32 accumulation noise, the arg-max row holds the maximum,
+    among bit-identical rows (duplicated on purpose) the FIRST one wins; column sums; negative gammas (flipped weight rows),
+    ragged last tiles, 16 .. 128 rows per group."""
+    e = _ext
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(M + K + N)
+    X = torch.randn(M, K, generator=g).to(BF)
+    Xg = X.view(M // ns, ns, K)
+    Xg[:, 7] = Xg[:, 3]                       # rows 3, 7 and 11 of every group are the same row: ties
+    Xg[:, 11] = Xg[:, 3]
+    X = X.to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    finp = _fin(K, 7)
+    gamma = (torch.rand(N, generator=g) - 0.3).to(DEV)
+    assert e.pool_layer_bf16_supported(K, N, ns) == (K in (32, 64, 128))
+    Wf, sgn = e.pool_flip_rows(W.contiguous(), gamma)
+    stats = torch.zeros(2, N, dtype=torch.float64, device=DEV)
+    pmax, parg = e.mlp_gemm_pool_bf16(X, Wf, sgn, ns, (finp[2], finp[3]), stats)
+    # fma(x, scale, shift) in fp32 = the float64 expression rounded once (x is bf16: the product is exact in float64)
+    pre = (X.double() * finp[2].double() + finp[3].double()).float()
+    A = torch.relu(pre).to(BF).double()
+    Y = A @ Wf.to(BF).double().t()                                           # flipped accumulators, float64
+    psz = min(ns, 32)
+    Yg = Y.view(M // psz, psz, N)
+    want_max = Yg.max(dim=1)[0]
+    scale = float(Y.abs().max())
+    assert float((pmax.double() - want_max).abs().max()) <= 2e-6 * scale
+    at_arg = Yg.gather(1, parg.long().unsqueeze(1)).squeeze(1)
+    assert float((want_max - at_arg).max()) <= 4e-6 * scale
+    sub = torch.arange(M // psz, device=DEV) % max(ns // psz, 1)              # partial group inside its group
+    dup = (parg == 7) | (parg == 11)
+    assert not bool((dup & (sub == 0).unsqueeze(1)).any()), "a later copy of a bit-identical row won the maximum"
+    Yt = Y * sgn.double()
+    torch.testing.assert_close(stats[0], Yt.sum(0), rtol=1e-5, atol=1e-5 * scale * M ** 0.5)
+    torch.testing.assert_close(stats[1], Yt.square().sum(0), rtol=1e-5, atol=1e-5 * scale * scale * M ** 0.5)
+    # pooled activations as bn_relu_rows_max would give them on the un-flipped values
+    fin = e.bn_finalize(stats, M, gamma, torch.zeros_like(gamma), 1e-5, 0.0, None, None, None)
+    out, arg, yraw = e.pool_finalize(pmax, parg, fin, sgn, ns)
+    z = torch.relu(Yt * fin[2].double() + fin[3].double()).view(M // ns, ns, N).max(dim=1)[0]
+    torch.testing.assert_close(out.double(), z, rtol=1e-4, atol=1e-4)
+    assert not bool(((arg == 7) | (arg == 11)).any())
+
+
+@pytest.mark.parametrize("M,N,K,ns", [(64 * 300, 128, 64, 64), (32 * 257, 128, 128, 32), (16 * 111, 64, 64, 16), (16 * 5, 64, 32, 16),
+                                      (128 * 9, 128, 64, 128)])
+def test_bf16_pooled_last_layer_backward_reforms_its_output(M, N, K, ns):
+    """pn2_mlp_bwd_bf16_pool (y_L re-formed from y_{L-1} inside the kernel) against float64 formulas on the same bf16 operands,
+    and against pn2_mlp_bwd_bf16 fed the STORED bf16 y_L: at least as close to the float64 result."""
+    e = _ext
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    yprev = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    Wt = W.t().contiguous()
+    c = torch.stack([torch.randn(N, generator=g), torch.randn(N, generator=g) * 0.1, torch.randn(N, generator=g) * 0.05]).to(DEV)
+    fin = torch.stack([torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5, torch.rand(K, generator=g) + 0.5,
+                       torch.randn(K, generator=g) * 0.3]).to(DEV).contiguous()
+    R = M // ns
+    arg = torch.randint(0, ns, (R, N), generator=g, dtype=torch.int32).to(DEV)
+    gP = torch.randn(R, N, generator=g).to(DEV)
+    assert e.pool_layer_bf16_supported(K, N, ns)
+    Gout, sums, dW = e.mlp_bwd_bf16_pool(c, Wt, yprev, fin, arg, gP, ns)
+    # float64 on the operands the kernel sees: bf16 activations and weights, fp32 accumulation ~ float64 here
+    act = torch.relu(yprev.float() * fin[2] + fin[3]).to(BF).double()
+    Wb = W.to(BF).double()
+    Y = act @ Wb.t()
+    dense = torch.zeros(R, ns, N, dtype=torch.float64, device=DEV)
+    dense.scatter_(1, arg.long().unsqueeze(1), gP.double().unsqueeze(1))
+    gy = c[0].double() * dense.view(M, N) + c[1].double() * Y + c[2].double()
+    mask = (yprev.float() * fin[2] + fin[3]) > 0
+    G64 = (gy @ Wb) * mask
+    dW64 = gy.t() @ act
+
+    def err(a, b):
+        return float((a.double() - b).abs().max() / (b.abs().max() + 1e-12))
+    e_g, e_w = err(Gout, G64), err(dW, dW64)
+    assert e_g <= 1.0 / 64 and e_w <= 4e-3, (e_g, e_w)
+    o = Gout.float().double()
+    torch.testing.assert_close(sums[0], o.sum(0), rtol=1e-4, atol=1e-5 * M)
+    torch.testing.assert_close(sums[1], (o * ((yprev.float() - fin[0]) * fin[1]).double()).sum(0), rtol=1e-4, atol=1e-5 * M)
+    # the stored route on the rounded y_L
+    G2, _s2, dW2 = e.mlp_bwd_bf16(Y.float().to(BF), c, Wt, yprev, fin, e.PRO_POOLG, arg=arg, gP=gP, ns=ns)
+    assert e_g <= 1.5 * err(G2, G64) + 1e-3 and e_w <= 1.5 * err(dW2, dW64) + 1e-4, (e_g, err(G2, G64), e_w, err(dW2, dW64))
+
+
+def test_bf16_stack_with_the_pooled_layer_not_stored_matches_the_stored_route():
+    """The backbone's SA1 stack ([3+3, 64, 64, 128], 64 rows per centre) on the bf16 node with BF16_POOL on and off: pooled
+    features within bf16 rounding of each other (the un-stored route is the one that rounds LESS), gradients in norm; the route
+    taken is checked by the entry points called."""
+    import copy
+    from external_src.group_free_3D.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from pointnet2_ops import fused_mlp
+    from test_gpu_round4 import _Calls
+    torch.manual_seed(13)
+    sa = PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=64, mlp=[3, 64, 64, 128], use_xyz=True,
+                               normalize_xyz=True).cuda().train()
+    xyz = _unit_ball(3, 20000, 61).to(DEV)
+    feats = torch.randn(3, 3, 20000, generator=torch.Generator().manual_seed(62)).to(DEV)
+    gout = torch.randn(3, 128, 512, generator=torch.Generator().manual_seed(63)).to(DEV)
+
+    def run(dtype, pool):
+        prev_d = fused_mlp.set_mlp_dtype(dtype)
+        prev, fused_mlp.BF16_POOL = fused_mlp.BF16_POOL, pool
+        try:
+            m = copy.deepcopy(sa)
+            with _Calls(_ext, ["mlp_gemm_pool_bf16", "mlp_bwd_bf16_pool", "bn_relu_rows_max_bf16"]) as calls:
+                _nx, nf, _i = m(xyz, feats)
+                (nf * gout).sum().backward()
+            if dtype == torch.bfloat16:
+                want = (1, 1, 0) if pool else (0, 0, 1)
+                assert tuple(calls.count[k] for k in ("mlp_gemm_pool_bf16", "mlp_bwd_bf16_pool", "bn_relu_rows_max_bf16")) == want, calls.count
+            return nf.detach(), {n: p.grad for n, p in m.named_parameters()}
+        finally:
+            fused_mlp.BF16_POOL = prev
+            fused_mlp.set_mlp_dtype(prev_d)
+
+    ref, gref = run(torch.float32, False)
+    a, ga = run(torch.bfloat16, True)
+    b, gb = run(torch.bfloat16, False)
+    ea = float((a - ref).abs().max() / ref.abs().max())
+    eb = float((b - ref).abs().max() / ref.abs().max())
+    print(f"\n[bf16 pooled layer] forward rel-max vs fp32: not stored {ea:.3e}, stored {eb:.3e}", end="")
+    assert ea <= 2e-2 and ea <= 1.5 * eb + 1e-3
+    for k in gref:
+        na = float((ga[k] - gref[k]).norm() / (gref[k].norm() + 1e-12))
+        nb = float((gb[k] - gref[k]).norm() / (gref[k].norm() + 1e-12))
+        print(f"\n[bf16 pooled layer] d{k}: rel-L2 vs fp32 not stored {na:.3e}, stored {nb:.3e}", end="")
+        assert na <= max(1.5 * nb, 5e-2), k
