@@ -79,6 +79,11 @@ struct GemmBf16Args {
   float *pmax;        // [M/psz][N]
   int *parg;          // [M/psz][N]
   const float *sgn;   // [N]
+  // PRO_FIRST (the stack's FIRST layer re-formed from its input rows, as csrc/mlp_gemm.hip PRO_FIRST): X = the rows [M][8]
+  // bf16 (K0 <= 8 real columns, zero padded), W0 [K][K0] fp32 the first layer's weight, p0 / p1 its BatchNorm scale / shift;
+  // y_0 is never stored — the A tile is relu(bn_0(X W0^T)) formed in fp32 and rounded to bf16 once
+  const float *W0;
+  int K0;
 };
 
 // ---------------------------------------------------------------------------------------------- forward / dgrad
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
   const int WP = a.wres ? Kp + 8 : AP;
   bf16 *sW = (bf16 *)smem;                          // [NTT*32][WP]
   float *sP = (float *)(smem + NTT * 32 * WP * 2);  // [3][Kp] prologue parameters, zero padded
-  bf16 *sA = (bf16 *)((unsigned char *)sP + (PRO != PRO_NONE ? 3 * Kp * 4 : 0));   // [TM][AP]
+  float *sW0 = sP + 3 * Kp;                         // PRO_FIRST: [Kp] first-layer weight rows as bf16x8 (16 bytes each), zero padded
+  bf16 *sA = (bf16 *)((unsigned char *)sP + (PRO != PRO_NONE ? 3 * Kp * 4 : 0) + (PRO == PRO_FIRST ? Kp * 16 : 0));   // [TM][AP]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) & 3, wc = tid >> 8;
@@ -118,7 +124,16 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
     for (int k = tid; k < Kp; k += NTH) {
       sP[k] = k < K ? a.p0[k] : 0.f;
       sP[Kp + k] = k < K ? a.p1[k] : 0.f;
-      sP[2 * Kp + k] = (PRO != PRO_BNRELU && k < K) ? a.p2[k] : 0.f;
+      sP[2 * Kp + k] = (PRO != PRO_BNRELU && PRO != PRO_FIRST && k < K) ? a.p2[k] : 0.f;
+    }
+    if constexpr (PRO == PRO_FIRST) {
+      // first-layer weight rows as bf16 fragments: row k = eight input columns (K0 real ones), 16 bytes
+      for (int k = tid; k < Kp; k += NTH) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (k < K && j < a.K0) ? a.W0[(size_t)k * a.K0 + j] : 0.f;
+        ((u32x4 *)sW0)[k] = u32x4{bf_pack(w[0], w[1]), bf_pack(w[2], w[3]), bf_pack(w[4], w[5]), bf_pack(w[6], w[7])};
+      }
     }
   }
   auto stage_w = [&](int k0, int kw) {              // sW[n][0..kw) = bf16(W[n][k0..k0+kw)), zero outside N x K
@@ -214,7 +229,10 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
     const long long plast = (row0 + TM - 1 < a.M - 1 ? row0 + TM - 1 : a.M - 1);
     const int ngr = PRO == PRO_POOLG ? (int)(plast / a.ns - pg0) + 1 : 0;
     auto issue = [&](int kc) {
-      if constexpr (!XF32) {
+      if constexpr (PRO == PRO_FIRST) {
+        // the 32 input rows of this wave's row block (pitch 8 bf16 = 16 bytes); lanes 32-63 supply the zero half of the k step
+        ra[0] = lane < 32 ? bload128(rX, (wave * 32 + lane) * 16, 0) : u32x4{0u, 0u, 0u, 0u};
+      } else if constexpr (!XF32) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
           const int k = kc * KC + lk + 8 * j;
@@ -251,8 +269,30 @@ __global__ __launch_bounds__(256 * CW, 2) void mlp_gemm_bf16_kernel(const GemmBf
         }
       } else {
         const long long grow = row0 + lr;
+        if constexpr (PRO == PRO_FIRST) {
+          // y_0 = X W0^T on the matrix pipe (K0 <= 8 input columns zero-padded to ONE 16-wide step: one instruction per
+          // 32 x 32 block, bf16 operands like the first layer's own GEMM on this path), BatchNorm + ReLU on the accumulators,
+          // rounded to bf16 once into the A chunk.  Wave (row block, column wave wc) takes the 32-column blocks wc, wc + CW, ..
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
+          for (int cb = 0; cb < KC / 32; ++cb) {
+            if (cb % CW != wc) continue;                // wave-uniform
+            const int k = kc * KC + cb * 32 + (lane & 31);
+            const u32x4 wf = lane < 32 ? ((const u32x4 *)sW0)[k] : u32x4{0u, 0u, 0u, 0u};
+            f32x16 y;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) y[e] = 0.f;
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[0]), __builtin_bit_cast(bf16x8, wf), y, 0, 0, 0);
+            const float q0 = sP[k], q1 = sP[Kp + k];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+              const float v = row0 + r < a.M ? fmaxf(fmaf(y[e], q0, q1), 0.f) : 0.f;
+              sA[r * AP + cb * 32 + (lane & 31)] = (bf16)v;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < (PRO == PRO_FIRST ? 0 : J); ++j) {
           const int k = kc * KC + lk + 8 * j;
           float v[8];
           if constexpr (PRO == PRO_NONE) {
@@ -763,6 +803,7 @@ struct BwdBf16Args {
   const bf16 *X;
   float *P1;
   int K0;
+  const float *W0;          // FY (FOLD with the first layer's output NOT stored): its weight [K][K0]; y_0 = X W0^T is re-formed per tile
   // segment table (see GemmBf16Args): blockIdx.y = scan; consts + s*3N, a_fin + s*4K, sums + s*2K; dW is the scans' SUM
   const long long *seg;
   long long seg_max;
@@ -773,7 +814,7 @@ struct BwdBf16Args {
 // RECOMP (GMODE PRO_POOLG: the layer is a max-pooled LAST layer whose output was never stored, pn2_mlp_gemm_pool_bf16): the
 // y_l tile is re-formed from the y_{l-1} tile the kernel stages anyway — the forward's own matrix product (same operands, same
 // MFMA order: the fp32 accumulators the forward took its maxima and statistics from, bit for bit) — instead of loaded.
-template <int NTN, int KTK, int GMODE, bool FOLD = false, bool RECOMP = false>
+template <int NTN, int KTK, int GMODE, bool FOLD = false, bool RECOMP = false, bool FY = false>
 // (HIP's second launch-bounds argument is waves per SIMD, not workgroups per CU.  The FOLD variants took 144-156 registers
 // under "2": three waves per SIMD, i.e. ONE eight-wave workgroup per CU.  Capped at 128 they spill 24-88 bytes outside
 // the tile loop's matrix products and two workgroups share a CU: 4.2M x 64 x 64 fold 0.59 -> 0.48 ms.  The 128 x 128
@@ -813,6 +854,7 @@ __global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void m
   for (int k = tid; k < KB; k += 512) {
     sF[k] = a.a_fin[k]; sF[KB + k] = a.a_fin[K + k]; sF[2 * KB + k] = a.a_fin[2 * K + k]; sF[3 * KB + k] = a.a_fin[3 * K + k];
   }
+
   {
     // transposed weights -> LDS: a thread per four consecutive n (16-byte load, 8-byte store), four rows in flight
     // (N = NB is a multiple of 32: aligned).  One float per lane and row at a time cost every workgroup ~30 us.
@@ -872,13 +914,29 @@ __global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void m
 
   u32x4 rg0[GT], rg1[GT], ry0[GT], ry1[GT], rx0[XT], rx1[XT];
   u32x4 rxr = {0u, 0u, 0u, 0u};
+  u32x4 rxa = {0u, 0u, 0u, 0u};
+  // FY: y_0 = X W0^T on the matrix pipe — K0 <= 8 input columns zero-padded to one 16-wide step: ONE instruction per 32 x 32 block
+  // of the tile (2 KTK <= 4 blocks, waves 0 .. 2 KTK - 1), bf16 operands like the first layer's own GEMM on this path.  The
+  // weight fragment (row n = this lane's column of the block, eight k) is formed once.
+  bf16x8 w0frag = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+  if constexpr (FY) {
+    static_assert(!FY || 2 * KTK <= 8, "one y_0 block per wave");
+    const int n = (wave % KTK) * 32 + (lane & 31);
+    if (wave < 2 * KTK && lane < 32 && n < K) {
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = j < a.K0 ? a.W0[(size_t)n * a.K0 + j] : 0.f;
+      w0frag = __builtin_bit_cast(bf16x8, u32x4{bf_pack(w[0], w[1]), bf_pack(w[2], w[3]), bf_pack(w[4], w[5]), bf_pack(w[6], w[7])});
+    }
+  }
   auto issue = [&](long long tile) {
     const long long row0 = tile * MT, left = a.M - row0;
     if constexpr (FOLD) {
       const rsrc_t rX0 = make_rsrc((const char *)a.X + (size_t)row0 * 16, left * 16);
       rxr = bload128(rX0, tid < MT ? tid * 16 : kOobOffset, 0);
     }
-    const rsrc_t rX = make_rsrc((const char *)a.Yprev + (size_t)row0 * K * 2, left * K * 2);
+    const rsrc_t rX = FY ? make_rsrc((const char *)a.X + (size_t)row0 * 16, left * 16)
+                         : make_rsrc((const char *)a.Yprev + (size_t)row0 * K * 2, left * K * 2);
     const rsrc_t rG = RECOMP ? rX : make_rsrc((const char *)(GMODE == PRO_GY ? a.G : a.Yl) + (size_t)row0 * N * 2, left * N * 2);
     const rsrc_t rY = RECOMP ? rX : make_rsrc((const char *)a.Yl + (size_t)row0 * N * 2, left * N * 2);
 #pragma unroll
@@ -891,12 +949,17 @@ __global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void m
       if constexpr (GMODE == PRO_GY) { rg0[i] = bload128(rG, off, 0); rg1[i] = bload128(rG, off, N * 2); }
     }
 #pragma unroll
-    for (int i = 0; i < XT; ++i) {
+    for (int i = 0; i < (FY ? 0 : XT); ++i) {
       const int t = tid + 512 * i;
       const int rp = t / CGk, cg = t - rp * CGk;
       const int off = t < 32 * CGk ? (2 * rp * K + cg * 8) * 2 : kOobOffset;
       rx0[i] = bload128(rX, off, 0);
       rx1[i] = bload128(rX, off, K * 2);
+    }
+    if constexpr (FY) {
+      // the 32 input rows of this wave's block of the y_0 tile (16 bytes per row), lanes 32-63 supply the zero half of k
+      const int t = wave;
+      rxa = (t < 2 * KTK && lane < 32) ? bload128(rX, ((t / KTK) * 32 + lane) * 16, 0) : u32x4{0u, 0u, 0u, 0u};
     }
   };
 
@@ -946,8 +1009,33 @@ __global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void m
         for (int e = 0; e < 8; ++e) *(unsigned *)&sGT[(n + e) * MP + swz<MT>(n + e, m)] = bf_pack(v0[e], v1[e]);
       }
     }
+    if constexpr (FY) {
+      const int t = wave;
+      if (t < 2 * KTK) {                               // wave-uniform
+        const int rt = t / KTK, ct = t - rt * KTK;
+        f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < XT; ++i) {
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rxa), w0frag, acc, 0, 0, 0);
+        const int n = ct * 32 + (lane & 31);
+        const float sc = sF[2 * KB + n], sh = sF[3 * KB + n];
+        typedef unsigned u2f __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+          const int m0 = rt * 32 + 8 * q + 4 * (lane >> 5);
+          float av[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float y = acc[4 * q + j];
+            sO[(m0 + j) * KP + n] = (bf16)y;                                   // raw y_0 (rows past M: zero input rows -> 0)
+            av[j] = row0 + m0 + j < a.M ? fmaxf(fmaf(y, sc, sh), 0.f) : 0.f;
+          }
+          *(u2f *)&sXT[n * MP + swz<MT>(n, m0)] = u2f{bf_pack(av[0], av[1]), bf_pack(av[2], av[3])};
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (FY ? 0 : XT); ++i) {
       const int t = tid + 512 * i;
       if (t < 32 * CGk) {
         const int rp = t / CGk, cg = t - rp * CGk, m = 2 * rp, k = cg * 8;
@@ -1159,12 +1247,12 @@ __global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void m
   }
 }
 
-template <int NTN, int KTK, int GMODE, bool FOLD = false, bool RECOMP = false>
+template <int NTN, int KTK, int GMODE, bool FOLD = false, bool RECOMP = false, bool FY = false>
 int launch_bwd(const BwdBf16Args &a, hipStream_t s) {
   constexpr int MT = 64, MP = MT + 8, NB = NTN * 32, KB = KTK * 32, NP = NB + 8, KP = KB + 8;
   const size_t lds = (size_t)(KB * NP + MT * NP + NB * MP + KB * MP + MT * KP) * 2 + (size_t)(3 * NB + 4 * KB) * 4 +
                      (FOLD ? (size_t)(MT > KB ? MT : KB) * 8 * 4 : 0);
-  auto kfn = mlp_bwd_bf16_kernel<NTN, KTK, GMODE, FOLD, RECOMP>;
+  auto kfn = mlp_bwd_bf16_kernel<NTN, KTK, GMODE, FOLD, RECOMP, FY>;
   static bool big_lds = false;
   if (lds > 64 * 1024 && !big_lds) {
     if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1397,7 +1485,7 @@ inline size_t gemm_lds_need(int n, int Kp, int pro, int epi) {      // with resi
   const int cols = gemm_tile_columns(n);
   size_t tile = (size_t)TM * AP * 2;
   if (epi == EPI_MASK && (size_t)TM * (cols + 8) * 2 > tile) tile = (size_t)TM * (cols + 8) * 2;
-  return (size_t)cols * (Kp + 8) * 2 + tile + (pro != PRO_NONE ? 3 * (size_t)Kp * 4 : 0);
+  return (size_t)cols * (Kp + 8) * 2 + tile + (pro != PRO_NONE ? 3 * (size_t)Kp * 4 : 0) + (pro == PRO_FIRST ? (size_t)Kp * 16 : 0);
 }
 
 template <int NT, int CW, int PRO, int EPI, bool XF32, bool YF32>
@@ -1408,7 +1496,7 @@ int launch_gemm(GemmBf16Args a, hipStream_t s) {
   if (EPI == EPI_MASK && a.N % 8 != 0) return PN2_EINVAL;
   size_t tile = (size_t)TM * AP * 2;                        // A chunk, aliased by the epilogue tile of EPI_MASK
   if (EPI == EPI_MASK && (size_t)TM * (NTT * 32 + 8) * 2 > tile) tile = (size_t)TM * (NTT * 32 + 8) * 2;
-  const size_t fixed = tile + (PRO != PRO_NONE ? 3 * (size_t)a.Kp * 4 : 0);
+  const size_t fixed = tile + (PRO != PRO_NONE ? 3 * (size_t)a.Kp * 4 : 0) + (PRO == PRO_FIRST ? (size_t)a.Kp * 16 : 0);
   if (fixed + wbytes_res > kLdsBudget) a.wres = 0;          // (the host wrapper picks column blocks that fit)
   const size_t wbytes = a.wres ? wbytes_res : (size_t)NTT * 32 * AP * 2;
   size_t lds = fixed + wbytes;
@@ -1565,6 +1653,30 @@ extern "C" int pn2_mlp_gemm_bf16(long long M, int K, int N, int pro, int epi, in
                                  const void *Yprev, const float *e_fin, void *stream) {
   return gemm_bf16_impl(M, K, N, pro, epi, x_f32, y_f32, ldx, ldy, X, X2, p0, p1, p2, arg, gP, ns, W, Y, stats, Yprev, e_fin,
                         SegTab{nullptr, 1, 0, 0}, stream);
+}
+
+// The SECOND layer of a bf16 stack with the first one re-formed from its input rows (the bf16 counterpart of pn2_mlp_gemm_first):
+// X0 (M, 8) bf16 rows (K0 <= 8 real columns, zero padded), W0 (K, K0) fp32, fin0 (4, K) = the first layer's mean | rstd |
+// scale | shift, W (N, K) fp32 -> Y (M, N) bf16 = relu(bn_0(X0 W0^T)) W^T with the column sums of the ROUNDED Y, Y^2 in stats.
+// y_0 is never stored (its batch statistics: pn2_rows_gram_bf16 + pn2_first_layer_stats).  K <= 128 a multiple of 8; N in {32, 64, 128}.
+extern "C" int pn2_mlp_gemm_first_bf16_supported(int K0, int K, int N) {
+  return K0 >= 1 && K0 <= 8 && K >= 8 && K <= 128 && K % 8 == 0 && (N == 32 || N == 64 || N == 128);
+}
+
+extern "C" int pn2_mlp_gemm_first_bf16(long long M, int K0, int K, int N, const void *X0, const float *W0, const float *fin0,
+                                       const float *W, void *Y, double *stats, void *stream) {
+  if (M < 0 || !pn2_mlp_gemm_first_bf16_supported(K0, K, N)) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!X0 || !W0 || !fin0 || !W || !Y || !stats) return PN2_ENULL;
+  if (((uintptr_t)X0 & 15) || ((uintptr_t)Y & 15)) return PN2_EINVAL;
+  GemmBf16Args a = {};
+  a.X = X0; a.p0 = fin0 + 2 * (size_t)K; a.p1 = fin0 + 3 * (size_t)K; a.W = W; a.Y = Y; a.stats = stats; a.M = M; a.K = K; a.N = N;
+  a.ldx = 8; a.ldy = N; a.Kp = (K + KC - 1) / KC * KC; a.wres = 0; a.Nfull = N;
+  a.seg = nullptr; a.nseg = 1; a.sstride = 2 * N; a.estride = 4 * N; a.W0 = W0; a.K0 = K0;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 32) return launch_gemm<1, 1, PRO_FIRST, EPI_STATS, false, false>(a, s);
+  if (N == 64) return launch_gemm<2, 1, PRO_FIRST, EPI_STATS, false, false>(a, s);
+  return launch_gemm<4, 1, PRO_FIRST, EPI_STATS, false, false>(a, s);
 }
 
 // The max-pooled last layer of a stack on the bf16 path WITHOUT its (M, N) output (the bf16 counterpart of pn2_mlp_gemm_pool):
@@ -1782,6 +1894,38 @@ extern "C" int pn2_mlp_bwd_bf16_fold(long long M, int N, int K, int gmode, const
   a.seg = nullptr; a.nseg = 1; a.seg_max = 0;
   return gmode == PRO_GY ? dispatch_bwd_fold<PRO_GY>(a, (hipStream_t)stream)
                          : dispatch_bwd_fold<PRO_POOLG>(a, (hipStream_t)stream);
+}
+
+// ... when the first layer's output was NOT stored (pn2_mlp_gemm_first_bf16): y_0 = X W0^T is re-formed per tile from the input
+// rows the fold reads anyway; W0 (K, K0) fp32 replaces Yprev.
+extern "C" int pn2_mlp_bwd_bf16_fold_first(long long M, int N, int K, int gmode, const void *G, const void *Yl, const float *consts,
+                                           const int *arg, const float *gP, int ns, const float *Wt, const float *W0,
+                                           const float *a_fin, const void *X, int K0, double *sums, float *dW, float *P1,
+                                           void *stream) {
+  if (M < 0 || !pn2_mlp_bwd_bf16_fold_supported(N, K, K0)) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!Yl || !consts || !Wt || !W0 || !a_fin || !X || !sums || !dW || !P1) return PN2_ENULL;
+  if (gmode == PRO_GY && !G) return PN2_ENULL;
+  if (gmode == PRO_POOLG && (!arg || !gP || ns <= 0)) return PN2_ENULL;
+  if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
+  if (((uintptr_t)Yl & 15) || ((uintptr_t)G & 15) || ((uintptr_t)X & 15)) return PN2_EINVAL;
+  BwdBf16Args a;
+  a.G = (const bf16 *)G; a.Yl = (const bf16 *)Yl; a.consts = consts; a.arg = arg; a.gP = gP; a.Wt = Wt;
+  a.Yprev = nullptr; a.a_fin = a_fin; a.Gout = nullptr; a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K;
+  a.ns = ns; a.X = (const bf16 *)X; a.P1 = P1; a.K0 = K0; a.W0 = W0;
+  a.seg = nullptr; a.nseg = 1; a.seg_max = 0;
+  hipStream_t s = (hipStream_t)stream;
+#define PN2_FY(NTN_, KTK_)                                                                                   \
+  (gmode == PRO_GY ? launch_bwd<NTN_, KTK_, PRO_GY, true, false, true>(a, s)                                  \
+                   : launch_bwd<NTN_, KTK_, PRO_POOLG, true, false, true>(a, s))
+  switch ((N / 32) * 8 + K / 32) {
+    case 1 * 8 + 1: return PN2_FY(1, 1);
+    case 1 * 8 + 2: return PN2_FY(1, 2);
+    case 2 * 8 + 1: return PN2_FY(2, 1);
+    case 2 * 8 + 2: return PN2_FY(2, 2);
+    default: return PN2_EINVAL;
+  }
+#undef PN2_FY
 }
 
 namespace {

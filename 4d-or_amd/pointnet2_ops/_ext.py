@@ -127,6 +127,9 @@ _SIGNATURES = {
     "pn2_rows_gram_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp],
     "pn2_mlp_wgrad_bf16": [ctypes.c_longlong] + [_c_int] * 6 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 7,
+    "pn2_mlp_gemm_first_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 7,
+    "pn2_mlp_bwd_bf16_fold_first": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 + [_c_int] +
+                                   [_c_vp] * 4,
     "pn2_mlp_gemm_pool_bf16": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_mlp_bwd_bf16_pool": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 7,
     "pn2_bn_relu_apply_bf16": [ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_vp, _c_vp],
@@ -182,6 +185,8 @@ _lib.pn2_group_lift_supported.argtypes = [_c_int]
 _lib.pn2_group_lift_supported.restype = _c_int
 _lib.pn2_mlp_lift_supported.argtypes = [_c_int] * 3
 _lib.pn2_mlp_lift_supported.restype = _c_int
+_lib.pn2_mlp_gemm_first_bf16_supported.argtypes = [_c_int] * 3
+_lib.pn2_mlp_gemm_first_bf16_supported.restype = _c_int
 _lib.pn2_mlp_gemm_pool_bf16_supported.argtypes = [_c_int] * 3
 _lib.pn2_mlp_gemm_pool_bf16_supported.restype = _c_int
 _lib.pn2_mlp_bwd_bf16_pool_supported.argtypes = [_c_int] * 2
@@ -256,7 +261,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_ball_query_workspace_bytes", "pn2_ball_query_grid_bytes",
                                                "pn2_ball_query_algo_bytes", "pn2_ball_query_auto",
                                                "pn2_ball_query_group_supported", "pn2_ball_query_group_workspace_bytes",
-                                               "pn2_group_lift_supported", "pn2_mlp_lift_supported", "pn2_mlp_gemm_pool_bf16_supported", "pn2_mlp_bwd_bf16_pool_supported", "pn2_group_lift_rows_grad_workspace_bytes",
+                                               "pn2_group_lift_supported", "pn2_mlp_lift_supported", "pn2_mlp_gemm_pool_bf16_supported", "pn2_mlp_gemm_first_bf16_supported", "pn2_mlp_bwd_bf16_pool_supported", "pn2_group_lift_rows_grad_workspace_bytes",
                                                "pn2_prep_num_chunks", "pn2_group_inverse_index_workspace_bytes",
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
@@ -1788,6 +1793,36 @@ def mlp_bwd_bf16_fold(Yl, consts, Wt, Yprev, a_fin, X, K0, gmode, G=None, arg=No
           _ptr(Wt), _ptr(Yprev), _ptr(a_fin), _ptr(X), int(K0), _ptr(sums), _ptr(dW), _ptr(P1),
           alg_bytes=2 * (M * N * (2 if gmode == PRO_GY else 1) + M * K + 8 * M) + 4 * N * K, alg_flops=4 * M * N * K,
           tag=(f"M{M},N{N},K{K},g{int(gmode)},fold{int(K0)}" if DETAIL_TAGS else None))
+    return sums, dW, P1
+
+
+def mlp_gemm_first_bf16_supported(K0, K, N) -> bool:
+    return bool(_lib.pn2_mlp_gemm_first_bf16_supported(int(K0), int(K), int(N)))
+
+
+def mlp_gemm_first_bf16(X0, K0, W0, fin0, W, stats):
+    """Y (M, N) bf16 = relu(bn_0(X0 W0^T)) W^T, X0 (M, 8) bf16 rows with K0 real columns: the second layer of a bf16 stack with
+    the first one re-formed while the A tile is staged — y_0 is never stored (csrc/mlp_bf16.hip PRO_FIRST)."""
+    _bf16(X0, "X0"); _f32(W0, "W0"); _f32(W, "W"); _f32(fin0, "fin0")
+    M = X0.size(0)
+    N, K = W.shape
+    if X0.size(1) != 8 or tuple(W0.shape) != (K, int(K0)) or tuple(fin0.shape) != (4, K):
+        raise RuntimeError("mlp_gemm_first_bf16: X0 (M,8) bf16, W0 (K,K0), fin0 (4,K), W (N,K) expected")
+    Y = torch.empty(M, N, dtype=torch.bfloat16, device=W.device)
+    _call("pn2_mlp_gemm_first_bf16", W, M, int(K0), K, N, _ptr(X0), _ptr(W0), _ptr(fin0), _ptr(W), _ptr(Y), _ptr(stats),
+          alg_bytes=16 * M + 2 * M * N + 4 * N * K, alg_flops=2 * M * N * K + 2 * M * K * int(K0),
+          tag=(f"M{M},K0{int(K0)},K{K},N{N}" if DETAIL_TAGS else None))
+    return Y
+
+
+def mlp_bwd_bf16_fold_first(Yl, consts, Wt, W0, a_fin, X, K0, gmode, G=None, arg=None, gP=None, ns=0, sums=None, dW=None, P1=None):
+    """mlp_bwd_bf16_fold when the forward was mlp_gemm_first_bf16: y_0 is re-formed from X and W0 (K, K0) -> (sums, dW, P1)."""
+    M, N = Yl.shape
+    K = W0.size(0)
+    _call("pn2_mlp_bwd_bf16_fold_first", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP), int(ns),
+          _ptr(Wt), _ptr(W0), _ptr(a_fin), _ptr(X), int(K0), _ptr(sums), _ptr(dW), _ptr(P1),
+          alg_bytes=2 * (M * N * (2 if gmode == PRO_GY else 1) + 8 * M) + 4 * N * K, alg_flops=4 * M * N * K + 2 * M * K * int(K0),
+          tag=(f"M{M},N{N},K{K},g{int(gmode)},first{int(K0)}" if DETAIL_TAGS else None))
     return sums, dW, P1
 
 

@@ -77,6 +77,10 @@ LIFT_FREE_MIN_ROWS = int(_os.environ.get("PN2_LIFT_FREE_MIN_ROWS", str(1 << 17 |
 #: accumulators in the GEMM's epilogue; the backward re-forms y_L from y_{L-1} on the matrix pipe, pn2_mlp_bwd_bf16_pool) — stacks
 #: of three layers or more whose last layer is at most 128 wide (the backbone's SA1).  PN2_BF16_POOL=0: stored route (A/B).
 BF16_POOL = _os.environ.get("PN2_BF16_POOL") != "0"
+#: ... nor does a first layer with <= 8 input columns (grouped xyz / colour rows): statistics from the Gram matrix of the rows,
+#: the second layer re-forms it while staging its A tiles (pn2_mlp_gemm_first_bf16), the fold of the backward likewise
+#: (pn2_mlp_bwd_bf16_fold_first).  PN2_BF16_FIRST=0: stored route (A/B).
+BF16_FIRST = _os.environ.get("PN2_BF16_FIRST") != "0"
 #: ... also inside segment-table stacks (per-scan statistics at the whole-batch launch count): the lifted layer is issued once
 #: per scan (the launches of single-scan steps), the rest of the stack through the table.  PN2_BF16_LIFT_SEG=0: grouped route.
 BF16_LIFT_SEG = _os.environ.get("PN2_BF16_LIFT_SEG") != "0"
@@ -606,6 +610,18 @@ class _FusedMLPBf16(Function):
                        and (bnL.training or bnL.running_mean is None) and getattr(e, "mlp_gemm_pool_bf16", None) is not None
                        and e.pool_layer_bf16_supported(layers[-1][0].in_channels, layers[-1][0].out_channels, ns))
         pooled_parts = None
+        # first layer without its output: when gradients are needed, only if the backward will take the fold path
+        need_dgrad0 = ctx.needs_input_grad[0] and (group is None or ctx.feat_shape is not None)
+        first_bf = bool(
+            BF16_FIRST and not lift and seg is None and not isinstance(ctx, _SegCtx) and L >= 2 and not (pool_bf and L == 2)
+            and x.dtype == torch.bfloat16 and x.size(1) == 8 and k_in <= 8
+            and all((bn_.training or bn_.running_mean is None) for _c, bn_ in layers[:2])
+            and getattr(e, "mlp_gemm_first_bf16", None) is not None
+            and e.mlp_gemm_first_bf16_supported(k_in, layers[0][0].out_channels, layers[1][0].out_channels)
+            and (not any(ctx.needs_input_grad) or (BF16_FOLD and FUSED_BACKWARD and not need_dgrad0 and e.mlp_bwd_bf16_fold_supported(
+                layers[1][0].out_channels, layers[0][0].out_channels, k_in))))
+        ctx.first_bf, ctx.gram_bf = first_bf, None
+        W0c = params[0].view(layers[0][0].out_channels, -1)[:, :k_in].contiguous() if first_bf else None
         for l, (conv, bn) in enumerate(layers):
             W = params[3 * l].view(conv.out_channels, conv.in_channels)
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
@@ -632,6 +648,12 @@ class _FusedMLPBf16(Function):
                 stats = stat_bufs[l]
                 if lift and l == 0:
                     y, ctx.lift_P = _lift_forward(e, feats, W, group, stats, out_bf16=True)
+                elif first_bf and l == 0:
+                    y = None
+                    ctx.gram_bf = e.rows_gram_bf16(x, k_in, e.zero_arena(x.device, [((k_in * k_in + k_in,), torch.float64)])[0])
+                    e.first_layer_stats(W0c, ctx.gram_bf, stats)
+                elif first_bf and l == 1:
+                    y = e.mlp_gemm_first_bf16(x, k_in, W0c, fins[0], W.contiguous(), stats)
                 elif pooled_parts is not None:
                     y = None
                 else:
@@ -712,6 +734,8 @@ class _FusedMLPBf16(Function):
                              ([((Ws[0].size(0), k_in), f32), ((k_in * k_in + k_in,), f64)] if fold else []) +
                              ([((3 * Ws[0].size(0) + 9,), f32)] if lift else []))
         sums0, sums_in, dWs = arena[0], arena[1:1 + L], arena[1 + L:1 + 2 * L]
+        if getattr(ctx, "first_bf", False) and not fold:
+            raise RuntimeError("fused_mlp: the bf16 first layer's output was not stored but the backward cannot fold it")
         if ns:
             pooled, arg, yraw = saved[1 + 4 * L], saved[2 + 4 * L], saved[3 + 4 * L]
             gPm, sums = e.pool_bwd_prep(yraw, pooled, g_out, fins[-1], sums=sums0, seg=seg, ns=ns)
@@ -784,6 +808,13 @@ class _FusedMLPBf16(Function):
             else:
                 consts, dgamma, dbeta = e.bn_bwd_consts(sums, M, gammas[l], fins[l], ctx.batch_flags[l])
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            if l == 1 and fold and getattr(ctx, "first_bf", False):
+                W0c = Ws[0][:, :k_in].contiguous()
+                sums, dW, P1 = e.mlp_bwd_bf16_fold_first(ys[1], consts, Wt, W0c, fins[0], x, k_in, gmode, G=G, arg=arg, gP=gPm,
+                                                         ns=ns, sums=sums_in[1], dW=dWs[1], P1=arena[1 + 2 * L])
+                grads[3] = dW.view(ctx.shapes[1])
+                gmode, arg, gPm, G = e.PRO_GY, None, None, None
+                continue
             if l == 1 and fold:
                 sums, dW, P1 = e.mlp_bwd_bf16_fold(ys[1], consts, Wt, ys[0], fins[0], x, k_in, gmode, G=G, arg=arg, gP=gPm, ns=ns,
                                                    sums=sums_in[1], dW=dWs[1], P1=arena[1 + 2 * L])
@@ -791,7 +822,7 @@ class _FusedMLPBf16(Function):
                 gmode, arg, gPm, G = e.PRO_GY, None, None, None
                 continue
             if l == 0 and fold:
-                gram = e.rows_gram_bf16(x, k_in, arena[2 + 2 * L])
+                gram = ctx.gram_bf if getattr(ctx, "gram_bf", None) is not None else e.rows_gram_bf16(x, k_in, arena[2 + 2 * L])
                 grads[0] = e.first_layer_dw(consts, P1, Ws[0].contiguous(), gram).view(ctx.shapes[0])
                 continue
             if l > 0 and FUSED_BACKWARD and e.mlp_bwd_bf16_supported(Ws[l].size(0), Ws[l].size(1)):

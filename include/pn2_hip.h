@@ -567,6 +567,17 @@ int pn2_mlp_bwd_bf16(long long M, int N, int K, int gmode, const void *G, const 
  *   pn2_mlp_bwd_bf16_pool   pn2_mlp_bwd_bf16 with gmode 3 for that layer: y_L is RE-FORMED from y_{L-1} (Yprev) and Wt on the
  *                           matrix pipe inside the kernel — the forward's own product, bit for bit — instead of read.
  * N in {64, 128}; K <= 128 (backward: 32, 64 or 128); ns in {16, 32, 64, 128}, M % ns == 0. */
+/* ... and the FIRST layer of a bf16 stack without its output (the counterpart of pn2_mlp_gemm_first / pn2_mlp_bwd_fused_fold_first):
+ *   pn2_mlp_gemm_first_bf16     Y (M, N) bf16 = relu(bn_0(X0 W0^T)) W^T with the column sums of the rounded Y, Y^2: the second layer
+ *                               with the first one re-formed from its input rows X0 (M, 8) bf16 (K0 <= 8 real columns), W0 (K, K0),
+ *                               fin0 (4, K); y_0 is never stored (statistics: pn2_rows_gram_bf16 + pn2_first_layer_stats);
+ *   pn2_mlp_bwd_bf16_fold_first pn2_mlp_bwd_bf16_fold with y_0 re-formed per tile from X and W0 instead of read (Yprev). */
+int pn2_mlp_gemm_first_bf16_supported(int K0, int K, int N);
+int pn2_mlp_gemm_first_bf16(long long M, int K0, int K, int N, const void *X0, const float *W0, const float *fin0,
+                            const float *W, void *Y, double *stats, void *stream);
+int pn2_mlp_bwd_bf16_fold_first(long long M, int N, int K, int gmode, const void *G, const void *Yl, const float *consts,
+                                const int *arg, const float *gP, int ns, const float *Wt, const float *W0, const float *a_fin,
+                                const void *X, int K0, double *sums, float *dW, float *P1, void *stream);
 int pn2_mlp_gemm_pool_bf16_supported(int K, int N, int ns);
 int pn2_mlp_gemm_pool_bf16(long long M, int K, int N, int ldx, const void *X, const float *p0, const float *p1,
                            const float *Wf, const float *sgn, int ns, double *stats, float *pmax, int *parg, void *stream);

@@ -523,3 +523,84 @@ def test_bf16_stack_with_the_pooled_layer_not_stored_matches_the_stored_route():
         nb = float((gb[k] - gref[k]).norm() / (gref[k].norm() + 1e-12))
         print(f"\n[bf16 pooled layer] d{k}: rel-L2 vs fp32 not stored {na:.3e}, stored {nb:.3e}", end="")
         assert na <= max(1.5 * nb, 5e-2), k
+
+
+# ------------------------------------------------------------------ bf16: first layer without its output
+@pytest.mark.parametrize("M,K0,K,N", [(64 * 333, 6, 64, 64), (5000, 3, 64, 128), (777, 8, 32, 32), (128 * 20 + 5, 4, 128, 64)])
+def test_bf16_second_layer_reforms_the_first_from_its_input_rows(M, K0, K, N):
+    """pn2_mlp_gemm_first_bf16 against float64 on the operands the kernel sees, and against the stored route (first layer's
+    GEMM -> bf16 y_0 -> second layer): the re-formed route rounds once less and must be at least as close."""
+    e = _ext
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(M + K0 + K + N)
+    X = torch.zeros(M, 8)
+    X[:, :K0] = torch.randn(M, K0, generator=g)
+    X = X.to(BF).to(DEV)
+    W0 = (torch.randn(K, K0, generator=g) * 0.5).to(DEV)
+    W1 = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    fin0 = _fin(K, 9)
+    assert e.mlp_gemm_first_bf16_supported(K0, K, N)
+    st = torch.zeros(2, N, dtype=torch.float64, device=DEV)
+    Y = e.mlp_gemm_first_bf16(X, K0, W0, fin0, W1, st)
+    y0 = X[:, :K0].double() @ W0.to(BF).double().t()          # (bf16 operands on the matrix pipe, like the first layer's own GEMM)
+    a = torch.relu(y0 * fin0[2].double() + fin0[3].double()).float().to(BF).double()
+    want = a @ W1.to(BF).double().t()
+    scale = float(want.abs().max())
+    err = float((Y.double() - want).abs().max())
+    assert err <= scale / 128, (err, scale)
+    torch.testing.assert_close(st[0], Y.double().sum(0), rtol=1e-5, atol=1e-4 * M ** 0.5)
+    torch.testing.assert_close(st[1], Y.double().square().sum(0), rtol=1e-5, atol=1e-4 * M ** 0.5)
+    # stored route
+    y0s = e.mlp_gemm_bf16(X, W0, pro=e.PRO_NONE, epi=e.EPI_NONE)
+    Y2 = e.mlp_gemm_bf16(y0s, W1, pro=e.PRO_BNRELU, epi=e.EPI_NONE, p=(fin0[2], fin0[3]))
+    err2 = float((Y2.double() - want).abs().max())
+    assert err <= 1.5 * err2 + scale / 512, (err, err2)
+
+
+def test_bf16_stack_without_first_and_last_layer_outputs_matches_fp32():
+    """The backbone's SA1 stack on the bf16 node with BF16_FIRST / BF16_POOL on and off against the fp32 node: the routes are
+    checked by the entry points called; the un-stored routes are at least as close to fp32 as the stored ones."""
+    import copy
+    from external_src.group_free_3D.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from pointnet2_ops import fused_mlp
+    from test_gpu_round4 import _Calls
+    torch.manual_seed(17)
+    sa = PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=64, mlp=[3, 64, 64, 128], use_xyz=True,
+                               normalize_xyz=True).cuda().train()
+    xyz = _unit_ball(3, 20000, 71).to(DEV)
+    feats = torch.randn(3, 3, 20000, generator=torch.Generator().manual_seed(72)).to(DEV)
+    gout = torch.randn(3, 128, 512, generator=torch.Generator().manual_seed(73)).to(DEV)
+    names = ["mlp_gemm_first_bf16", "mlp_bwd_bf16_fold_first", "mlp_bwd_bf16_fold", "mlp_gemm_pool_bf16", "mlp_bwd_bf16_pool"]
+
+    def run(dtype, free):
+        prev_d = fused_mlp.set_mlp_dtype(dtype)
+        prev = (fused_mlp.BF16_FIRST, fused_mlp.BF16_POOL)
+        fused_mlp.BF16_FIRST = fused_mlp.BF16_POOL = free
+        try:
+            m = copy.deepcopy(sa)
+            with _Calls(_ext, names) as calls:
+                _nx, nf, _i = m(xyz, feats)
+                (nf * gout).sum().backward()
+            if dtype == torch.bfloat16:
+                want = (1, 1, 0, 1, 1) if free else (0, 0, 1, 0, 0)
+                assert tuple(calls.count[k] for k in names) == want, calls.count
+            return nf.detach(), {n: p.grad for n, p in m.named_parameters()}, {n: b.clone() for n, b in m.named_buffers()}
+        finally:
+            fused_mlp.BF16_FIRST, fused_mlp.BF16_POOL = prev
+            fused_mlp.set_mlp_dtype(prev_d)
+
+    ref, gref, bref = run(torch.float32, False)
+    a, ga, ba = run(torch.bfloat16, True)
+    b, gb, _bb = run(torch.bfloat16, False)
+    ea = float((a - ref).abs().max() / ref.abs().max())
+    eb = float((b - ref).abs().max() / ref.abs().max())
+    print(f"\n[bf16 SA1, nothing stored at its ends] forward rel-max vs fp32: {ea:.3e} (stored {eb:.3e})", end="")
+    assert ea <= 2e-2 and ea <= 1.5 * eb + 1e-3
+    for k in gref:
+        na = float((ga[k] - gref[k]).norm() / (gref[k].norm() + 1e-12))
+        nb = float((gb[k] - gref[k]).norm() / (gref[k].norm() + 1e-12))
+        print(f"\n[bf16 SA1] d{k}: rel-L2 vs fp32 {na:.3e} (stored {nb:.3e})", end="")
+        assert na <= max(1.5 * nb, 5e-2), k
+    for k in bref:
+        if "running" in k:
+            assert float((ba[k] - bref[k]).abs().max()) <= 2e-2 * float(bref[k].abs().max()) + 1e-3, k
