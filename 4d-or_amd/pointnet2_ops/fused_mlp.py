@@ -606,14 +606,16 @@ class _FusedMLPBf16(Function):
                                  [(lead + (2, conv.out_channels), torch.float64) for conv, _ in layers])
         cur = x
         bnL = layers[-1][1]
-        pool_bf = bool(BF16_POOL and ns and L >= 3 and seg is None and not isinstance(ctx, _SegCtx) and M % ns == 0
+        per_scan = group is not None and len(group) > 9 and bool(group[9])
+        pool_bf = bool(BF16_POOL and ns and L >= 3 and seg is None and not per_scan and not isinstance(ctx, _SegCtx) and M % ns == 0
                        and (bnL.training or bnL.running_mean is None) and getattr(e, "mlp_gemm_pool_bf16", None) is not None
                        and e.pool_layer_bf16_supported(layers[-1][0].in_channels, layers[-1][0].out_channels, ns))
         pooled_parts = None
         # first layer without its output: when gradients are needed, only if the backward will take the fold path
         need_dgrad0 = ctx.needs_input_grad[0] and (group is None or ctx.feat_shape is not None)
         first_bf = bool(
-            BF16_FIRST and not lift and seg is None and not isinstance(ctx, _SegCtx) and L >= 2 and not (pool_bf and L == 2)
+            BF16_FIRST and not lift and seg is None and not per_scan and not isinstance(ctx, _SegCtx) and L >= 2
+            and not (pool_bf and L == 2)
             and x.dtype == torch.bfloat16 and x.size(1) == 8 and k_in <= 8
             and all((bn_.training or bn_.running_mean is None) for _c, bn_ in layers[:2])
             and getattr(e, "mlp_gemm_first_bf16", None) is not None
@@ -1157,7 +1159,7 @@ def fused_shared_mlp(mlp: nn.Module, x: torch.Tensor, ns: int = 0, rows_per_scan
 
 def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz, normalize, radius,
                          clouds_per_scan: Optional[Sequence[int]] = None, inv=None, crowded: Optional[bool] = None,
-                         rows=None) -> torch.Tensor:
+                         rows=None, per_scan_caller: bool = False) -> torch.Tensor:
     """Ball-query neighbourhoods -> shared MLP -> max, one autograd node:
     xyz (B,N,3), new_xyz (B,m,3), feats_rows (B,N,C)|None, idx (B,m,ns) -> (B, m, C_out).
     `clouds_per_scan` (sums to B): BatchNorm batch statistics per scan (see _SegmentedGroupMLP)."""
@@ -1181,8 +1183,11 @@ def fused_group_mlp_pool(mlp: nn.Module, xyz, new_xyz, feats_rows, idx, use_xyz,
             rows = None                                   # (fp32 rows are of no use to the bf16 node)
         rows = None if rows is None else rows.contiguous()
     # rows: the grouped rows (B, m, ns, [3+]C) fp32 if the query kernel already emitted them (pn2_ball_query_group)
+    # [9]: the caller batches scans with per-scan statistics (inside pointnet2_modules.per_scan_statistics, which single-scan
+    # steps of the scene-graph model enter too): the bf16 node then keeps the routes its segment-table form has, so that a
+    # batched step stays the arithmetic of its single-scan steps
     group = (xyz, new_xyz, idx, bool(use_xyz), bool(normalize), radius, inv, crowded,
-             None if rows is None else rows.detach())
+             None if rows is None else rows.detach(), bool(per_scan_caller) or clouds_per_scan is not None)
     if clouds_per_scan is not None and len(clouds_per_scan) > 1:
         if sum(clouds_per_scan) != B:
             raise RuntimeError("fused_group_mlp_pool: clouds_per_scan must sum to the number of clouds")

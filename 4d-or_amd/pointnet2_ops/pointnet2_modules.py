@@ -123,6 +123,7 @@ class _ScanSegments(threading.local):
 
     def __init__(self):
         self.table = {}
+        self.active = 0          # nesting depth of per_scan_statistics (entered for batches of ONE scan too)
 
 
 _SEG = _ScanSegments()
@@ -134,6 +135,7 @@ def per_scan_statistics(*clouds_per_scan):
     relation encoder of the scene-graph model.  Batches of one scan need no entry."""
     table = _SEG.table
     saved = dict(table)
+    _SEG.active += 1
     try:
         for sizes in clouds_per_scan:
             sizes = tuple(int(v) for v in sizes)
@@ -145,6 +147,7 @@ def per_scan_statistics(*clouds_per_scan):
             table[total] = sizes
         yield
     finally:
+        _SEG.active -= 1
         table.clear()
         table.update(saved)
 
@@ -193,7 +196,8 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
             idx, rows = _query_maybe_fused(grouper, xyz, new_xyz, feats_rows)
         return fused_mlp.fused_group_mlp_pool(mlp, xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
                                               grouper.normalize_xyz, grouper.radius, inv=inv,
-                                              crowded=crowded_balls(grouper, xyz.size(1)), rows=rows)
+                                              crowded=crowded_balls(grouper, xyz.size(1)), rows=rows,
+                                              per_scan_caller=_SEG.active > 0)
     if idx is not None:
         g = pointnet2_utils.group_concat_rows(xyz, new_xyz, feats_rows, idx, grouper.use_xyz,
                                               grouper.normalize_xyz, grouper.radius, inv=inv)

@@ -147,7 +147,11 @@ class SGPNModelWrapper(nn.Module):
         per_scan = scenes is not None and scenes.num_scenes > 1 and self.training and self.per_scan_statistics
         node_ptr = scenes.node_ptr if per_scan else None
         edge_ptr = scenes.edge_ptr if per_scan else None
-        with (per_scan_statistics(scenes.nodes_per_scene, scenes.edges_per_scene) if per_scan else contextlib.nullcontext()):
+        # (a step of ONE scan enters the context too, without a table: the encoders then keep the kernel routes a batch of
+        # scans takes, so that S scans per step stay the arithmetic of S single-scan steps — pointnet2_ops/fused_mlp.py group[9])
+        one_scan = self.training and self.per_scan_statistics and not per_scan
+        with (per_scan_statistics(scenes.nodes_per_scene, scenes.edges_per_scene) if per_scan
+              else (per_scan_statistics() if one_scan else contextlib.nullcontext())):
             if self.encoder_streams and batch["obj_points"].is_cuda and not torch.cuda.is_current_stream_capturing():
                 # (inside a stream capture the fork only adds graph edges: replay of the one-scan step 135 -> 68 scans/s)
                 # the two encoders share nothing until the GCN: the object encoder (9 small clouds per scan: kernels that
