@@ -915,6 +915,12 @@ __global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void m
   u32x4 rg0[GT], rg1[GT], ry0[GT], ry1[GT], rx0[XT], rx1[XT];
   u32x4 rxr = {0u, 0u, 0u, 0u};
   u32x4 rxa = {0u, 0u, 0u, 0u};
+  // PRO_POOLG: the (arg-max row, pooled gradient) entries of a tile's groups travel with its row loads (entry t = tid + 512 e
+  // of the ngr x NB entries; ns >= 16: at most MT / 16 + 1 groups) — fetched inside the patch they were two dependent global
+  // loads between two barriers, once per tile
+  constexpr int PFE = GMODE == PRO_POOLG ? ((MT / 16 + 1) * NB + 511) / 512 : 1;
+  int pfa[PFE];
+  float pfg[PFE];
   // FY: y_0 = X W0^T on the matrix pipe — K0 <= 8 input columns zero-padded to one 16-wide step: ONE instruction per 32 x 32 block
   // of the tile (2 KTK <= 4 blocks, waves 0 .. 2 KTK - 1), bf16 operands like the first layer's own GEMM on this path.  The
   // weight fragment (row n = this lane's column of the block, eight k) is formed once.
@@ -955,6 +961,22 @@ __global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void m
       const int off = t < 32 * CGk ? (2 * rp * K + cg * 8) * 2 : kOobOffset;
       rx0[i] = bload128(rX, off, 0);
       rx1[i] = bload128(rX, off, K * 2);
+    }
+    if constexpr (GMODE == PRO_POOLG) {
+      const long long q0 = row0 / a.ns;
+      const long long last = (row0 + MT - 1 < a.M - 1 ? row0 + MT - 1 : a.M - 1);
+      const int ngr = (int)(last / a.ns - q0) + 1;
+#pragma unroll
+      for (int e = 0; e < PFE; ++e) {
+        const int t = tid + 512 * e, gi = t / NB, n = t - gi * NB;
+        pfa[e] = -1;
+        pfg[e] = 0.f;
+        if (gi < ngr) {
+          const size_t o = (size_t)(q0 + gi) * N + n;
+          pfa[e] = a.arg[o];
+          pfg[e] = a.gP[o];
+        }
+      }
     }
     if constexpr (FY) {
       // the 32 input rows of this wave's block of the y_0 tile (16 bytes per row), lanes 32-63 supply the zero half of k
@@ -1110,6 +1132,21 @@ __global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void m
       const long long q0 = row0 / a.ns;
       const long long last = (row0 + MT - 1 < a.M - 1 ? row0 + MT - 1 : a.M - 1);
       const int ngr = (int)(last / a.ns - q0) + 1;
+      if (a.ns >= 16) {
+#pragma unroll
+        for (int e = 0; e < PFE; ++e) {                  // the prefetched entries
+          const int t = tid + 512 * e, gi = t / NB, n = t - gi * NB;
+          if (pfa[e] >= 0) {
+            const long long row = (q0 + gi) * a.ns + pfa[e] - row0;
+            if (row >= 0 && row < MT && row0 + row < a.M) {
+              bf16 *c0 = &sGY[(int)row * NP + n];
+              const bf16 nv = (bf16)fmaf(sC[n], pfg[e], (float)*c0);
+              *c0 = nv;
+              sGT[n * MP + swz<MT>(n, (int)row)] = nv;
+            }
+          }
+        }
+      } else {
       for (int t = tid; t < ngr * NB; t += 512) {
         const int gi = t / NB, n = t - gi * NB;
         const size_t o = (size_t)(q0 + gi) * N + n;
@@ -1120,6 +1157,7 @@ __global__ __launch_bounds__(512, (FOLD || (RECOMP && KTK <= 2)) ? 4 : 2) void m
           *c0 = nv;
           sGT[n * MP + swz<MT>(n, (int)row)] = nv;
         }
+      }
       }
     }
     __syncthreads();
