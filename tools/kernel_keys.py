@@ -16,7 +16,7 @@ ENTRY_OF_FAMILY = {
     "bn_relu_rows_max_kernel": "pn2_bn_relu_rows_max", "group_concat_rows_wide4_kernel": "pn2_group_concat_rows",
     "group_concat_rows_narrow_kernel": "pn2_group_concat_rows", "group_concat_rows_kernel": "pn2_group_concat_rows",
     "group_rows_grad_csr_kernel": "pn2_group_rows_grad", "group_rows_grad_kernel": "pn2_group_rows_grad",
-    "mlp_gemm_bf16_kernel": "pn2_mlp_gemm_bf16", "mlp_wgrad_bf16_kernel": "pn2_mlp_wgrad_bf16", "mlp_bwd_bf16_kernel": "pn2_mlp_bwd_bf16",
+    "mlp_wgrad_bf16_kernel": "pn2_mlp_wgrad_bf16", "mlp_bwd_bf16x_kernel": "pn2_mlp_bwd_bf16",
     "bn_relu_rows_max_bf16_v8_kernel": "pn2_bn_relu_rows_max_bf16", "group_concat_rows_bf16_wide8_kernel": "pn2_group_concat_rows_bf16",
     "bq_fused_group_kernel": "pn2_ball_query_group", "bq_slab_query_kernel": "pn2_ball_query", "bq_slab_build_kernel": "pn2_ball_query",
     "fps_multi_kernel": "pn2_furthest_point_sampling", "fps_coop_kernel": "pn2_furthest_point_sampling",
@@ -48,6 +48,16 @@ def keys(name: str):
         # template <R, BF>: the bf16-row instantiations are launched by the _bf16 entry points
         bf = re.search(r"_kernel<\s*\d+,\s*true", name) is not None
         out.append("entry:" + ("pn2_group_lift_rows" if fam == "group_lift_rows_kernel" else "pn2_group_lift_rows_grad") + ("_bf16" if bf else ""))
+    elif fam == "mlp_bwd_bf16_kernel":
+        # template <NTN, KTK, GMODE, FOLD, RECOMP, FY>: the fold / re-forming instantiations are launched by their own entry points
+        m = re.search(r"mlp_bwd_bf16_kernel<\s*\d+,\s*\d+,\s*\d+,\s*(true|false)(?:,\s*(true|false))?(?:,\s*(true|false))?", name)
+        fold, recomp, fy = (m.group(1) == "true", m.group(2) == "true", m.group(3) == "true") if m else (False, False, False)
+        out.append("entry:" + ("pn2_mlp_bwd_bf16_pool" if recomp else "pn2_mlp_bwd_bf16_fold_first" if fy else
+                               "pn2_mlp_bwd_bf16_fold" if fold else "pn2_mlp_bwd_bf16"))
+    elif fam == "mlp_gemm_bf16_kernel":
+        m = re.search(r"mlp_gemm_bf16_kernel<\s*\d+,\s*\d+,\s*(\d+),\s*(\d+)", name)
+        pro, epi = (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+        out.append("entry:" + ("pn2_mlp_gemm_pool_bf16" if epi == 3 else "pn2_mlp_gemm_first_bf16" if pro == 4 else "pn2_mlp_gemm_bf16"))
     elif fam == "prep_vec_kernel":
         # template <POOLED>: true = pn2_pool_bwd_prep (and its segment-table form), false = pn2_bn_relu_bwd_prep
         out.append("entry:" + ("pn2_pool_bwd_prep" if re.search(r"prep_vec_kernel<\s*true", name) else "pn2_bn_relu_bwd_prep"))
