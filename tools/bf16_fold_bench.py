@@ -23,4 +23,14 @@ def timed(fn, reps=20):
     b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / reps
 t1 = timed(lambda: e.mlp_bwd_bf16_fold(y1, c, Wt, y0, fin, X, K0, e.PRO_GY, G=G, sums=sums, dW=dW, P1=P1))
 t2 = timed(lambda: e.mlp_bwd_bf16_fold_first(y1, c, Wt, W0, fin, X, K0, e.PRO_GY, G=G, sums=sums, dW=dW, P1=P1))
-print(json.dumps({"fold_ms": round(t1, 4), "fold_first_ms": round(t2, 4)}))
+# pooled last layer (N = 128, K = 64, 64 rows per group): stored y_L vs re-formed
+N2, ns = 128, 64
+W2 = (torch.randn(N2, K, generator=g) / 8).to(dev); W2t = W2.t().contiguous()
+c2 = (torch.randn(3, N2, generator=g) * 0.3).to(dev).contiguous()
+y2 = torch.randn(M, N2, generator=g).to(BF).to(dev)
+arg = torch.randint(0, ns, (M // ns, N2), generator=g, dtype=torch.int32).to(dev)
+gP = torch.randn(M // ns, N2, generator=g).to(dev)
+dW2 = torch.zeros(N2, K, device=dev)
+t3 = timed(lambda: e.mlp_bwd_bf16(y2, c2, W2t, y0, fin, e.PRO_POOLG, arg=arg, gP=gP, ns=ns, sums=sums, dW=dW2))
+t4 = timed(lambda: e.mlp_bwd_bf16_pool(c2, W2t, y0, fin, arg, gP, ns, sums=sums, dW=dW2))
+print(json.dumps({"fold_ms": round(t1, 4), "fold_first_ms": round(t2, 4), "pool_bwd_stored_ms": round(t3, 4), "pool_bwd_reformed_ms": round(t4, 4)}))
