@@ -68,13 +68,15 @@ class SGPNModelWrapper(nn.Module):
         self.full_image_model = None
         self.obj_encoder = PointNetfeat2(input_dim=6, out_size=m["point_feature_size"], input_dropout=m["INPUT_DROPOUT"])
         self.rel_encoder = PointNetfeat2(input_dim=7, out_size=m["edge_feature_size"], input_dropout=m["INPUT_DROPOUT"])
-        self.gcn = TripletGCNModel(num_layers=m["N_LAYERS"], dim_node=m["point_feature_size"],
-                                   dim_edge=m["edge_feature_size"], dim_hidden=m["gcn_hidden_feature_size"])
-        self.obj_predictor = PointNetCls(num_class, in_size=m["point_feature_size"], batch_norm=False, drop_out=True)
         if self.with_images:
+            # registered BEFORE the GCN, like the reference (:47-57): state_dict key order and the order the constructor
+            # draws from the RNG are the reference's (tests/golden/sgpn.npz, generated from the reference class).
             # EfficientNet-B5's `num_features` (2048) unless the config says otherwise (reference :57)
             self.full_image_feature_reduction = nn.Linear(int(m.get("IMAGE_MODEL_NUM_FEATURES", 2048)),
                                                           m["FULL_IMAGE_EMBEDDING_SIZE"] // 6)
+        self.gcn = TripletGCNModel(num_layers=m["N_LAYERS"], dim_node=m["point_feature_size"],
+                                   dim_edge=m["edge_feature_size"], dim_hidden=m["gcn_hidden_feature_size"])
+        self.obj_predictor = PointNetCls(num_class, in_size=m["point_feature_size"], batch_norm=False, drop_out=True)
         self.rel_predictor = PointNetRelCls(num_rel, in_size=m["edge_feature_size"], batch_norm=False, drop_out=True,
                                             image_embedding_size=m["FULL_IMAGE_EMBEDDING_SIZE"] if self.with_images else None,
                                             n_object_types=self.n_object_types)

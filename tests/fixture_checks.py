@@ -1,0 +1,148 @@
+"""Checks of the product against tests/golden/triplet_gcn.npz and sgpn.npz — fixtures produced by the REFERENCE's own
+`network_TripletGCN.py` / `scene_graph_prediction_model.py` (tests/golden/make_golden.py; torch_geometric's
+MessagePassing.propagate and torch_scatter.scatter restated there, the rest is the reference running unchanged).
+Shared by the CPU run (oracle backend: pins the python layer) and the GPU run (HIP kernels: pins the arithmetic)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(REPO, "tests", "golden")
+CONFIGS = os.path.join(REPO, "4d-or_amd/scene_graph_prediction/scene_graph_helpers/configs")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def check_manifest(module, z, prefix):
+    """ORDERED keys, shapes and per-tensor sums of a module built under the fixture's seed == the reference's."""
+    sd = module.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z[prefix + "keys"]], "state_dict key order differs from the reference's"
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in z[prefix + "shapes"]]
+    got = np.array([float(v.double().sum()) for v in sd.values()])
+    np.testing.assert_allclose(got, z[prefix + "sums"], rtol=1e-9, atol=1e-9)
+
+
+def _t(z, key, dev):
+    return torch.from_numpy(z[key]).to(dev)
+
+
+def check_gcn_model(z, tag, layers, dims, seed, dev, atol=1e-4, rtol=1e-3):
+    """TripletGCNModel: manifest, train-mode forward + gradients, eval-mode forward (BatchNorm keeps batch statistics)."""
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    dn, de, dh = dims
+    torch.manual_seed(seed)
+    model = gcn.TripletGCNModel(num_layers=layers, dim_node=dn, dim_edge=de, dim_hidden=dh)
+    check_manifest(model, z, f"{tag}/")
+    model = model.to(dev)
+    ei = _t(z, f"{tag}/ei", dev)
+    names = [str(k) for k in z[f"{tag}/grad_names"]]
+    assert [k for k, _ in model.named_parameters()] == names
+    for route in (None,):
+        x = _t(z, f"{tag}/x", dev).requires_grad_(True)
+        e = _t(z, f"{tag}/e", dev).requires_grad_(True)
+        model.zero_grad()
+        model.train()
+        kw = {}
+        ox, oe = model(x, e, ei, **kw)
+        wx = torch.linspace(0.5, 1.5, ox.numel(), device=dev).view_as(ox)
+        we = torch.linspace(-1.0, 1.0, oe.numel(), device=dev).view_as(oe)
+        ((ox * wx).sum() + (oe * we).sum()).backward()
+        np.testing.assert_allclose(ox.detach().cpu().numpy(), z[f"{tag}/out_x"], atol=atol, rtol=rtol, err_msg=str(route))
+        np.testing.assert_allclose(oe.detach().cpu().numpy(), z[f"{tag}/out_e"], atol=atol, rtol=rtol, err_msg=str(route))
+        gscale = float(np.abs(z[f"{tag}/grad_x"]).max())
+        np.testing.assert_allclose(x.grad.cpu().numpy(), z[f"{tag}/grad_x"], atol=2e-3 * gscale, rtol=1e-2)
+        gscale = float(np.abs(z[f"{tag}/grad_e"]).max())
+        np.testing.assert_allclose(e.grad.cpu().numpy(), z[f"{tag}/grad_e"], atol=2e-3 * gscale, rtol=1e-2)
+        params = dict(model.named_parameters())
+        norms = np.array([float(params[k].grad.double().norm()) for k in names])
+        ref = z[f"{tag}/grad_norms"]
+        # a bias in front of a BatchNorm has an exactly-zero true gradient: rounding noise on both sides
+        live = ref > 1e-3 * ref.max()
+        np.testing.assert_allclose(norms[live], ref[live], rtol=5e-3)
+        last = params[f"gconvs.{layers - 1}.nn2.3.weight"].grad.cpu().numpy()[::4, ::8]
+        np.testing.assert_allclose(last, z[f"{tag}/grad_last_w"], atol=2e-3 * float(np.abs(z[f"{tag}/grad_last_w"]).max()), rtol=1e-2)
+        first = params["gconvs.0.nn1.0.weight"].grad.cpu().numpy()[::16, ::16]
+        np.testing.assert_allclose(first, z[f"{tag}/grad_first_w"], atol=2e-3 * float(np.abs(z[f"{tag}/grad_first_w"]).max()), rtol=1e-2)
+        model.eval()
+        with torch.no_grad():
+            ex, ee = model(x.detach(), e.detach(), ei, **kw)
+        np.testing.assert_allclose(ex.cpu().numpy(), z[f"{tag}/eval_x"], atol=atol, rtol=rtol)
+        np.testing.assert_allclose(ee.cpu().numpy(), z[f"{tag}/eval_e"], atol=atol, rtol=rtol)
+
+
+def check_gcn_layer_cases(z, dev, atol=1e-5, rtol=1e-4):
+    """One TripletGCN layer on an irregular edge list (isolated target, repeated edge) and the hand case of
+    network_util.py:86-94 (edge_index [[0,1,2],[2,1,0]])."""
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as gcn
+    torch.manual_seed(73)
+    layer = gcn.TripletGCN(dim_node=16, dim_edge=12, dim_hidden=24)
+    check_manifest(layer, z, "one/")
+    layer = layer.to(dev)
+    for tag in ("irr", "hand"):
+        x = _t(z, f"one/{tag}/x", dev).requires_grad_(True)
+        e = _t(z, f"one/{tag}/e", dev).requires_grad_(True)
+        ei = _t(z, f"one/{tag}/ei", dev)
+        layer.zero_grad()
+        ox, oe = layer(x, e, ei)
+        (ox.square().sum() + 2 * oe.sum()).backward()
+        for got, key in ((ox, "out_x"), (oe, "out_e"), (x.grad, "grad_x"), (e.grad, "grad_e"), (layer.nn1[0].weight.grad, "grad_w")):
+            ref = z[f"one/{tag}/{key}"]
+            np.testing.assert_allclose(got.detach().cpu().numpy(), ref, atol=atol * max(1.0, float(np.abs(ref).max())), rtol=rtol,
+                                       err_msg=f"{tag}/{key}")
+
+
+def sgpn_batch(z, dev, with_images):
+    keys = ["obj_points", "rel_points", "edge_indices", "relation_objects_one_hot", "gt_class", "gt_rels"]
+    b = {k: _t(z, "batch/" + k, dev) for k in keys}
+    if with_images:
+        b["full_image_features"] = _t(z, "batch/full_image_features", dev)
+    b["take_idx"] = 4
+    return b
+
+
+def build_sgpn(z, tag, seed):
+    from scene_graph_prediction.scene_graph_helpers.model import scene_graph_prediction_model as sgm
+    cfg = json.load(open(os.path.join(CONFIGS, tag + ".json")))
+    names = [f"r{i}" for i in range(14)] + ["none"]
+    torch.manual_seed(seed)
+    model = sgm.SGPNModelWrapper(cfg, 12, 15, torch.from_numpy(z["weights_obj"]), torch.from_numpy(z["weights_rel"]), names)
+    return model
+
+
+def check_sgpn(z, tag, seed, dev, atol, rtol, loss_tol):
+    """SGPNModelWrapper: ordered manifest, requires_grad flags, eval-mode forward, train-mode loss + gradient norms."""
+    model = build_sgpn(z, tag, seed)
+    check_manifest(model, z, f"{tag}/")
+    names = [str(k) for k in z[f"{tag}/param_names"]]
+    assert [k for k, _ in model.named_parameters()] == names
+    model = model.to(dev)
+    b = sgpn_batch(z, dev, tag == "no_gt_image")
+    model.eval()
+    with torch.no_grad():
+        obj, rel, of, rf, gof, grf, _ = model(b, return_meta_data=True)
+    for got, key in ((of, "obj_feature"), (rf, "rel_feature"), (gof, "gcn_obj_feature"), (grf, "gcn_rel_feature"),
+                     (obj, "obj_cls"), (rel, "rel_cls")):
+        # behind the GCN: its BatchNorm1d layers normalise with the statistics of THREE node rows (six edge rows), which
+        # amplifies the encoders' last-bit differences (measured: 3e-6 in, 6e-5 out on the CPU) — ten times the tolerance
+        k = 1.0 if key in ("obj_feature", "rel_feature") else 10.0
+        np.testing.assert_allclose(got.cpu().numpy(), z[f"{tag}/eval/{key}"], atol=k * atol, rtol=k * rtol, err_msg=key)
+    model.train()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.eval()
+    loss = model.training_step(b, 1)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(z[f"{tag}/train/loss"][0])) < loss_tol
+    gnames = [str(k) for k in z[f"{tag}/train/grad_names"]]
+    params = dict(model.named_parameters())
+    # the reference back-propagates into the dead `fc_layer` of both encoders never (no gradient there either)
+    got_names = [k for k, p in model.named_parameters() if p.grad is not None]
+    assert got_names == gnames, set(got_names) ^ set(gnames)
+    ref = z[f"{tag}/train/grad_norms"]
+    norms = np.array([float(params[k].grad.double().norm()) for k in gnames])
+    live = ref > 1e-3 * ref.max()
+    np.testing.assert_allclose(norms[live], ref[live], rtol=2e-2)

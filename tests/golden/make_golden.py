@@ -265,7 +265,203 @@ def fixture_sample_uniformly():
          grouped=grouped.numpy(), grouped_xyz=grouped_xyz.numpy())
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# third-party semantics the reference's GCN / model files import at module scope and that are absent from the image AND
+# from /root/reference (pins: torch_geometric 2.0.2, torch_scatter 2.0.9 — README.md:87; pytorch_lightning 1.6.0,
+# timm 0.4.12 — SGP/requirements.txt:17,19).  They are RESTATED here from their published behaviour, in the few lines
+# the reference's call sites use (network_TripletGCN.py:7-8,30-32,41,57); everything else in the fixtures below is the
+# reference's own python (network_TripletGCN.py, scene_graph_prediction_model.py, network_PointNet*.py) running unchanged.
+def _third_party_stubs():
+    import inspect
+
+    class MessagePassing(torch.nn.Module):
+        """torch_geometric.nn.conv.MessagePassing 2.0.2, the part `propagate` runs for a dense `edge_index`:
+        flow='source_to_target' => (i, j) = (1, 0); an argument `<name>_i` / `<name>_j` of `message` receives
+        `kwargs[name].index_select(node_dim, edge_index[i | j])`; other arguments pass through; `aggregate(msg, index =
+        edge_index[i], ptr=None, dim_size = number of nodes)`; `update` is the identity."""
+
+        def __init__(self, aggr="add", flow="source_to_target", node_dim=-2):
+            super().__init__()
+            self.aggr, self.flow, self.node_dim = aggr, flow, node_dim
+
+        def propagate(self, edge_index, size=None, **kwargs):
+            i, j = (1, 0) if self.flow == "source_to_target" else (0, 1)
+            n_nodes = None
+            args = {}
+            for name in inspect.signature(self.message).parameters:
+                if name.endswith(("_i", "_j")):
+                    data = kwargs[name[:-2]]
+                    n_nodes = data.size(self.node_dim)
+                    args[name] = data.index_select(self.node_dim, edge_index[i if name.endswith("_i") else j])
+                else:
+                    args[name] = kwargs[name]
+            out = self.message(**args)
+            out = self.aggregate(out, index=edge_index[i], ptr=None, dim_size=n_nodes)
+            return self.update(out)
+
+        def update(self, inputs):
+            return inputs
+
+    def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
+        """torch_scatter.scatter 2.0.9 for reduce in {'add', 'sum'} along a leading node dimension."""
+        assert reduce in ("add", "sum") and src.dim() == 2 and dim in (0, -2)
+        res = torch.zeros(dim_size, src.size(1), dtype=src.dtype)
+        return res.index_add_(0, index, src)
+
+    tg = _stub("torch_geometric")
+    tg.nn = _stub("torch_geometric.nn")
+    tg.nn.conv = _stub("torch_geometric.nn.conv", MessagePassing=MessagePassing)
+    _stub("torch_scatter", scatter=scatter)
+
+    class _NoCNN(torch.nn.Module):
+        """Stands where timm's EfficientNet-B5 would: `num_features` and a parameter-free `conv_head`, so that building it
+        draws nothing from the RNG and adds no state_dict entry (the product skips `full_image_model.*` the same way)."""
+        num_features = 2048
+
+        def __init__(self):
+            super().__init__()
+            self.conv_head = torch.nn.Identity()
+
+        def forward(self, x):
+            raise RuntimeError("the 2-D CNN is out of scope: the fixture feeds pre-computed image features")
+
+    timm = _stub("timm", create_model=lambda *a, **k: _NoCNN())
+    timm.data = _stub("timm.data", resolve_data_config=lambda *a, **k: {}, create_transform=lambda **k: None)
+
+
+def _ref_gcn():
+    _third_party_stubs()
+    from scene_graph_prediction.scene_graph_helpers.model.gcns import network_TripletGCN as ref_gcn
+    assert ref_gcn.__file__.startswith(REF)
+    return ref_gcn
+
+
+def _full_edges(n):
+    return torch.tensor([[a, b] for a in range(n) for b in range(n) if a != b]).t().contiguous()
+
+
+def fixture_triplet_gcn():
+    """The reference's TripletGCN / TripletGCNModel (SGH/model/gcns/network_TripletGCN.py:30-80) on the restated
+    MessagePassing / scatter: initialisation order, forward, gradients; 2 and 3 layers; eval mode (BatchNorm1d with
+    track_running_stats=False keeps batch statistics); the survey's hand case edge_index = [[0,1,2],[2,1,0]]
+    (network_util.py:86-94) and an irregular edge list with an isolated node and a repeated edge."""
+    ref_gcn = _ref_gcn()
+    out = {}
+    for tag, layers, n, dn, de, dh, seed in (("l2", 2, 9, 256, 256, 512, 71), ("l3", 3, 6, 64, 48, 96, 72)):
+        torch.manual_seed(seed)
+        model = ref_gcn.TripletGCNModel(num_layers=layers, dim_node=dn, dim_edge=de, dim_hidden=dh)
+        sd0 = model.state_dict()
+        out.update(sd_manifest(sd0, f"{tag}/"))
+        g = torch.Generator().manual_seed(seed + 100)
+        ei = _full_edges(n)
+        x = torch.randn(n, dn, generator=g).requires_grad_(True)
+        e = torch.randn(ei.size(1), de, generator=g).requires_grad_(True)
+        model.train()
+        ox, oe = model(x, e, ei)
+        wx = torch.linspace(0.5, 1.5, ox.numel()).view_as(ox)
+        we = torch.linspace(-1.0, 1.0, oe.numel()).view_as(oe)
+        ((ox * wx).sum() + (oe * we).sum()).backward()
+        out[f"{tag}/x"], out[f"{tag}/e"], out[f"{tag}/ei"] = x.detach().numpy(), e.detach().numpy(), ei.numpy()
+        out[f"{tag}/out_x"], out[f"{tag}/out_e"] = ox.detach().numpy(), oe.detach().numpy()
+        out[f"{tag}/grad_x"], out[f"{tag}/grad_e"] = x.grad.numpy(), e.grad.numpy()
+        names = [k for k, _ in model.named_parameters()]
+        out[f"{tag}/grad_names"] = np.array(names)
+        out[f"{tag}/grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+        out[f"{tag}/grad_sums"] = np.array([float(p.grad.double().sum()) for _, p in model.named_parameters()])
+        last = f"gconvs.{layers - 1}.nn2.3.weight"
+        out[f"{tag}/grad_last_w"] = dict(model.named_parameters())[last].grad.numpy()[::4, ::8]
+        out[f"{tag}/grad_first_w"] = dict(model.named_parameters())["gconvs.0.nn1.0.weight"].grad.numpy()[::16, ::16]
+        model.eval()
+        with torch.no_grad():
+            ex, ee = model(x.detach(), e.detach(), ei)
+        out[f"{tag}/eval_x"], out[f"{tag}/eval_e"] = ex.numpy(), ee.numpy()
+    # one layer, small, irregular edges (node 4 isolated as a target, edge (0 -> 2) twice) + the hand case
+    torch.manual_seed(73)
+    layer = ref_gcn.TripletGCN(dim_node=16, dim_edge=12, dim_hidden=24)
+    out.update(sd_manifest(layer.state_dict(), "one/"))
+    g = torch.Generator().manual_seed(173)
+    for tag, ei in (("irr", torch.tensor([[0, 1, 0, 3, 4, 2, 0], [2, 0, 2, 1, 0, 3, 1]])),
+                    ("hand", torch.tensor([[0, 1, 2], [2, 1, 0]]))):
+        n = 5 if tag == "irr" else 3
+        x = torch.randn(n, 16, generator=g).requires_grad_(True)
+        e = torch.randn(ei.size(1), 12, generator=g).requires_grad_(True)
+        layer.zero_grad()
+        ox, oe = layer(x, e, ei)
+        (ox.square().sum() + 2 * oe.sum()).backward()
+        out[f"one/{tag}/x"], out[f"one/{tag}/e"], out[f"one/{tag}/ei"] = x.detach().numpy(), e.detach().numpy(), ei.numpy()
+        out[f"one/{tag}/out_x"], out[f"one/{tag}/out_e"] = ox.detach().numpy(), oe.detach().numpy()
+        out[f"one/{tag}/grad_x"], out[f"one/{tag}/grad_e"] = x.grad.numpy(), e.grad.numpy()
+        out[f"one/{tag}/grad_w"] = layer.nn1[0].weight.grad.numpy().copy()
+    save("triplet_gcn.npz", **out)
+
+
+def _scan_batch(n_obj, pts_obj, pts_rel, seed):
+    """A synthetic scan with the batch-dict keys of ORDataset.collate_fn (or_dataset.py:63-74)."""
+    g = torch.Generator().manual_seed(seed)
+    E = n_obj * (n_obj - 1)
+    obj = torch.rand(n_obj, 6, pts_obj, generator=g) * 2 - 1
+    rel = torch.rand(E, 7, pts_rel, generator=g) * 2 - 1
+    rel[:, 6] = torch.randint(0, 3, (E, pts_rel), generator=g).float()
+    onehot = torch.zeros(E, 12)
+    onehot[torch.arange(E), torch.randint(0, 6, (E,), generator=g)] = 1
+    onehot[torch.arange(E), 6 + torch.randint(0, 6, (E,), generator=g)] = 1
+    return dict(obj_points=obj, rel_points=rel, edge_indices=_full_edges(n_obj), relation_objects_one_hot=onehot,
+                gt_class=torch.randint(0, 12, (n_obj,), generator=g), gt_rels=torch.randint(0, 15, (E,), generator=g),
+                full_image_features=torch.randn(6, 2048, generator=g))
+
+
+def fixture_sgpn():
+    """The reference's SGPNModelWrapper (SGH/model/scene_graph_prediction_model.py:31-109,134-141) for `no_gt.json` and
+    `no_gt_image.json`: ORDERED state_dict keys / shapes / sums under a fixed seed (registration order = RNG consumption
+    order), an eval-mode forward and a train-mode forward + loss + gradients (Dropout modules switched off: the device
+    draws other random numbers) of one small synthetic scan.  Image config: the CNN is replaced by pre-computed features
+    `(6, num_features)` fed through `full_image_feature_reduction` exactly as :97-99 does after the CNN."""
+    import json
+    _third_party_stubs()
+    from scene_graph_prediction.scene_graph_helpers.model import scene_graph_prediction_model as ref_sgm
+    assert ref_sgm.__file__.startswith(REF)
+    names = [f"r{i}" for i in range(14)] + ["none"]
+    out = {}
+    batch = _scan_batch(3, 640, 768, 81)
+    for k, v in batch.items():
+        out["batch/" + k] = v.numpy()
+    w_obj = torch.linspace(0.5, 2.0, 12)
+    w_rel = torch.linspace(0.25, 3.0, 15)
+    out["weights_obj"], out["weights_rel"] = w_obj.numpy(), w_rel.numpy()
+    for tag, cfg_name, seed in (("no_gt", "no_gt.json", 82), ("no_gt_image", "no_gt_image.json", 83)):
+        cfg = json.load(open(os.path.join(REF, "scene_graph_prediction/scene_graph_helpers/configs", cfg_name)))
+        torch.manual_seed(seed)
+        model = ref_sgm.SGPNModelWrapper(cfg, 12, 15, w_obj, w_rel, names)
+        out.update(sd_manifest(model.state_dict(), f"{tag}/"))
+        out[f"{tag}/param_names"] = np.array([k for k, _ in model.named_parameters()])
+        out[f"{tag}/requires_grad"] = np.array([p.requires_grad for _, p in model.named_parameters()])
+        if tag == "no_gt_image":
+            # the reference calls the CNN on batch['full_image'] (:97); the features it would return are the input here
+            model.full_image_model.forward = lambda img: batch["full_image_features"]
+            model.freeze_image_model_batchnorm = lambda: None
+            b = dict(batch, full_image=torch.zeros(6, 3, 8, 8), take_idx=4)
+        else:
+            b = dict(batch, take_idx=4)
+        model.eval()
+        with torch.no_grad():
+            obj, rel, of, rf, gof, grf, _ = model(b, return_meta_data=True)
+        out[f"{tag}/eval/obj_cls"], out[f"{tag}/eval/rel_cls"] = obj.numpy(), rel.numpy()
+        out[f"{tag}/eval/obj_feature"], out[f"{tag}/eval/rel_feature"] = of.numpy(), rf.numpy()
+        out[f"{tag}/eval/gcn_obj_feature"], out[f"{tag}/eval/gcn_rel_feature"] = gof.numpy(), grf.numpy()
+        model.train()
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.eval()
+        loss = model.training_step(b, 1)
+        loss.backward()
+        out[f"{tag}/train/loss"] = np.array([float(loss)])
+        named = [(k, p) for k, p in model.named_parameters() if p.grad is not None]
+        out[f"{tag}/train/grad_names"] = np.array([k for k, _ in named])
+        out[f"{tag}/train/grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in named])
+    save("sgpn.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sa_msg", "fp", "msg_encoder", "gf3d_backbone", "votes_pooling", "heads", "sample_uniformly"]
+    which = sys.argv[1:] or ["sa_msg", "fp", "msg_encoder", "gf3d_backbone", "votes_pooling", "heads", "sample_uniformly", "triplet_gcn", "sgpn"]
     for name in which:
         globals()["fixture_" + name]()
