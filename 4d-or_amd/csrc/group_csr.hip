@@ -12,6 +12,7 @@
 // loads, one plain store per output row, no zero fill, and a summation order fixed by the sort — the result is
 // bit-reproducible run to run (the atomic form is not).
 #include "pn2_common.h"
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -223,11 +224,24 @@ inline hipError_t sort_temp_bytes(size_t rows, int bits, size_t *bytes) {
   return rocprim::radix_sort_pairs(nullptr, *bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
                                    (const unsigned *)nullptr, (unsigned *)nullptr, rows, 0, bits, (hipStream_t)0);
 }
+
+// Which algorithm a call takes is decided in ONE place, before any size check, for the workspace query and the entry alike
+// (the query used to promise 256 bytes for N <= kInvLdsInts while the entry could still fall through to the
+// radix sort when the 144 KB dynamic-LDS attribute was refused, and sort into a 256-byte workspace).  The attribute is asked
+// for once per process; PN2_INVERSE_INDEX_RADIX=1 (read on every call: tests flip it) forces the sort route.
+bool inv_use_lds(int N) {
+  if (N > kInvLdsInts) return false;
+  static const bool lds_ok = hipFuncSetAttribute((const void *)inv_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 kInvLdsInts * 4) == hipSuccess;
+  if (!lds_ok) return false;
+  const char *force = getenv("PN2_INVERSE_INDEX_RADIX");
+  return !(force && force[0] == '1');
+}
 }  // namespace
 
 extern "C" size_t pn2_group_inverse_index_workspace_bytes(int B, int N, int m, int ns) {
   if (B <= 0 || N <= 0 || m <= 0 || ns <= 0) return 0;
-  if (N <= kInvLdsInts) return 256;                            // one-launch counting sort in LDS: no scratch (a token size)
+  if (inv_use_lds(N)) return 256;                              // one-launch counting sort in LDS: no scratch (a token size)
   const size_t rows = (size_t)B * m * ns;
   size_t temp = 0;
   if (sort_temp_bytes(rows, key_bits((size_t)B * N), &temp) != hipSuccess) return 0;
@@ -247,26 +261,23 @@ extern "C" int pn2_group_inverse_index(int B, int N, int m, int ns, const int *i
   size_t temp = 0;
   const size_t seg = align256(rows * 4);
   if ((((size_t)workspace) & 255) != 0) return PN2_EINVAL;
-  if (N <= kInvLdsInts) {
+  const bool lds = inv_use_lds(N);
+  if (lds) {
     if (workspace_bytes < 256) return PN2_ENOSPC;
   } else {
     if (sort_temp_bytes(rows, bits, &temp) != hipSuccess) return PN2_ELAUNCH;
     if (workspace_bytes < 3 * seg + align256(temp)) return PN2_ENOSPC;
   }
-  if (N <= kInvLdsInts) {
+  if (lds) {
     // one launch: a stable counting sort per cloud in LDS (inv_cloud_kernel); the workspace is not touched
     const int P = m * ns;
     int W = kInvLdsInts / N;
     W = W > 16 ? 16 : W;
     const int steps = (P + 63) / 64;                          // no more waves than 64-row steps
     W = W > steps ? steps : W;
-    static bool lds_ok = hipFuncSetAttribute((const void *)inv_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             kInvLdsInts * 4) == hipSuccess;
-    if (lds_ok) {
-      hipLaunchKernelGGL(inv_cloud_kernel, dim3((unsigned)B), dim3(64u * W), (size_t)W * N * sizeof(int), (hipStream_t)stream, N,
-                         P, W, key_bits((size_t)N), B - 1, idx, ptr, refs);
-      return pn2_check_launch();
-    }
+    hipLaunchKernelGGL(inv_cloud_kernel, dim3((unsigned)B), dim3(64u * W), (size_t)W * N * sizeof(int), (hipStream_t)stream, N,
+                       P, W, key_bits((size_t)N), B - 1, idx, ptr, refs);
+    return pn2_check_launch();
   }
   unsigned *keys_in = (unsigned *)workspace;
   unsigned *keys_out = (unsigned *)((char *)workspace + seg);

@@ -43,3 +43,32 @@ def test_sgpn_matches_reference_class_on_gpu(tag, seed):
     """Whole model, both configs: ordered manifest, eval forward (encoder features at 1e-4; behind the 3-row BatchNorms of
     the GCN at 1e-3, see fixture_checks.check_sgpn), train-mode loss and gradient norms."""
     fc.check_sgpn(fc.load("sgpn.npz"), tag, seed, "cuda", atol=1e-4, rtol=1e-3, loss_tol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r05 (medium)
+def test_inverse_index_forced_radix_route_sizes_its_workspace(monkeypatch):
+    """csrc/group_csr.hip: the algorithm (one-launch LDS counting sort | rocPRIM radix sort) is chosen before the size
+    checks, for the workspace query and the entry alike.  With the LDS route refused (here: PN2_INVERSE_INDEX_RADIX=1; on a
+    device that denies 144 KB of dynamic LDS: the attribute call) the query reports the SORT's workspace, a 256-byte
+    workspace is PN2_ENOSPC — not an out-of-bounds sort — and both routes give the same (ptr, refs)."""
+    import ctypes
+    from pointnet2_ops import _ext
+    g = torch.Generator().manual_seed(3)
+    B, N, m, ns = 3, 500, 40, 8
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32).cuda()
+    ptr_lds, refs_lds = _ext.group_inverse_index(idx, N)
+    lib = _ext._lib
+    assert int(lib.pn2_group_inverse_index_workspace_bytes(B, N, m, ns)) == 256
+    monkeypatch.setenv("PN2_INVERSE_INDEX_RADIX", "1")
+    need = int(lib.pn2_group_inverse_index_workspace_bytes(B, N, m, ns))
+    assert need >= 3 * B * m * ns * 4
+    ptr = torch.empty(B * N + 1, dtype=torch.int32, device="cuda")
+    refs = torch.empty(B * m * ns, dtype=torch.int32, device="cuda")
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.pn2_group_inverse_index(B, N, m, ns, p(idx), p(ptr), p(refs), p(ws), 256, None) == -4        # PN2_ENOSPC
+    ptr_rx, refs_rx = _ext.group_inverse_index(idx, N)
+    torch.cuda.synchronize()
+    assert torch.equal(ptr_rx, ptr_lds) and torch.equal(refs_rx, refs_lds)
+    monkeypatch.delenv("PN2_INVERSE_INDEX_RADIX")
+    assert int(lib.pn2_group_inverse_index_workspace_bytes(B, N, m, ns)) == 256
