@@ -1,0 +1,335 @@
+// x3_chain.hip — a set-abstraction level in EVAL mode as ONE kernel (reference OPS/pointnet2_modules.py:29-74:
+// group -> [Conv1x1 + BatchNorm + ReLU] x k -> max over the neighbourhood).
+//
+// In eval mode BatchNorm is an affine map with constant (running) statistics: it folds into the convolution's weight and a
+// bias, so nothing between the gather and the pooled maximum depends on the batch.  The kernel keeps every activation in
+// REGISTERS from the gathered input rows to the maximum (x3_common.h: hidden layers are computed transposed, so an
+// accumulator tile is directly the next layer's operand fragment); no (rows x channels) tensor exists in HBM or LDS.
+// Arithmetic: the split-bf16 ("f32x3") product — fp32-grade error at 6/16 of the exact fp32 MFMA's matrix time.
+//
+//   workgroup = 8 waves; a wave owns 32 consecutive rows (row = (centre, sample)) of a 256-row pass; persistent workgroups
+//   walk the passes.  Per pass:
+//     input stage   IN_SMALL: gather [xyz[idx] - centre | feats[idx] | 1] (<= 15 columns + the bias column) and apply the
+//                             first layer (one 16-wide chunk, weights resident in LDS)
+//                   IN_LIFT : the first layer was applied per POINT before the grouping (Pq = W_f f + W_x x / r per point,
+//                             Q = W_x c / r - b per centre: csrc/group_lift.hip); gather relu(Pq[idx] - Q[centre])
+//     middle layer  (optional) transposed product, bias in the accumulator's initial value, ReLU + split in registers
+//     last layer    row-major product (lane = channel, registers = rows): maximum over the rows of a centre in the
+//                   epilogue, ReLU, one coalesced 128-byte store per (centre, 32 channels)
+//   The weights of the middle and last layer stream through a 3-slot LDS ring (24 KB slots = 8 (chunk, tile) units) filled
+//   by global_load_lds (direct global -> LDS, no registers) two steps ahead; one barrier per step.
+#include "pn2_common.h"
+#include "x3_common.h"
+
+namespace {
+
+struct EvalArgs {
+  const float *xyz;       // (B, N, 3)
+  const float *new_xyz;   // (B, m, 3)
+  const int *idx;         // (B, m, ns)
+  const float *feats;     // IN_SMALL: (B, N, C) rows | IN_LIFT: Pq (B N, c1)
+  const float *Q;         // IN_LIFT: (B m, c1)
+  const unsigned char *w0;        // IN_SMALL: first layer's fragments, c1 / 32 units
+  const unsigned char *wstream;   // middle layer's units, then the last layer's
+  const float *bias_mid;  // (c_mid)
+  const float *bias_fin;  // (c_out)
+  float *out;             // (B m, ldo), columns [0, c_out)
+  long long Mrows;        // B m ns
+  long long ncentres;     // B m
+  int N, m, ns_shift, C, c_out, ldo, steps_fin, spp;
+};
+
+constexpr int kRing = 3;
+
+template <int IN, int KA, int KB>      // KA = c1 / 16; KB = c_mid / 16 (0: no middle layer)
+__global__ __launch_bounds__(512, 2) void sa_eval_kernel(const EvalArgs a) {
+  constexpr bool SMALL = IN == 0;
+  constexpr int KF = KB ? KB : KA;                      // chunks of the last layer's input
+  constexpr int TPS_MID = kX3SlotUnits / KA;            // tiles per ring slot
+  constexpr int TPS_FIN = kX3SlotUnits / KF;
+  constexpr int STEPS_MID = KB ? (KB / 2) * KA / kX3SlotUnits : 0;
+  constexpr int W0_BYTES = SMALL ? (KA / 2) * kX3UnitBytes : 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *ring = lds;
+  unsigned char *w0s = lds + kRing * kX3SlotBytes;
+  float *bmid = reinterpret_cast<float *>(w0s + W0_BYTES);     // permuted: [(tile, half)][16]
+  float *bfin = bmid + (KB ? KB * 16 : 16);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
+  const long long npass = (a.Mrows + 255) >> 8;
+  const long long my_passes = (npass - blockIdx.x + gridDim.x - 1) / gridDim.x;
+
+  // resident tables
+  if (SMALL)
+    for (int i = tid; i < W0_BYTES / 16; i += 512)
+      reinterpret_cast<x3_u32x4 *>(w0s)[i] = reinterpret_cast<const x3_u32x4 *>(a.w0)[i];
+  if (KB)
+    for (int i = tid; i < KB * 16; i += 512) {
+      const int r = i & 15, hh = (i >> 4) & 1, T = i >> 5;
+      bmid[i] = a.bias_mid[32 * T + (r & 3) + 8 * (r >> 2) + 4 * hh];
+    }
+  for (int i = tid; i < a.c_out; i += 512) bfin[i] = a.bias_fin[i];
+
+  // weight stream: global step g reads slot (g mod spp) of the stream into ring slot (g mod 3)
+  int dma_j = 0, dma_slot = 0;
+  auto issue_dma = [&]() {
+    const unsigned char *src = a.wstream + (size_t)dma_j * kX3SlotBytes + lane * 16;
+    unsigned char *dst = ring + dma_slot * kX3SlotBytes;
+#pragma unroll
+    for (int i = 0; i < kX3SlotBytes / 1024 / 8; ++i) {
+      const int piece = wave + 8 * i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024),
+                                       (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+    }
+    dma_j = dma_j + 1 == a.spp ? 0 : dma_j + 1;
+    dma_slot = dma_slot + 1 == kRing ? 0 : dma_slot + 1;
+  };
+  issue_dma();
+  issue_dma();
+  __syncthreads();
+
+  int slot = 0;                                          // ring slot of the step being computed
+  x3_frag actA[KA];
+  x3_frag actB[KB ? KB : 1];
+
+  auto load_w = [&](const unsigned char *base, int unit) {
+    x3_frag f;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      f.p[s] = *reinterpret_cast<const x3_u32x4 *>(base + unit * kX3UnitBytes + s * 1024 + lane * 16);
+    return f;
+  };
+  // a transposed accumulator tile -> the two operand fragments it holds (ReLU, split)
+  auto acc_to_frags = [&](const x3_f32x16 &acc, x3_frag &f0, x3_frag &f1) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      x3_split_pair(fmaxf(acc[2 * d], 0.f), fmaxf(acc[2 * d + 1], 0.f), f0, d);
+      x3_split_pair(fmaxf(acc[8 + 2 * d], 0.f), fmaxf(acc[8 + 2 * d + 1], 0.f), f1, d);
+    }
+  };
+
+  for (long long pi = 0; pi < my_passes; ++pi) {
+    const long long row0 = ((long long)blockIdx.x + pi * gridDim.x) * 256 + wave * 32;     // wave-uniform
+    // ------------------------------------------------------------------ input stage
+    {
+      const long long row = row0 + l32;
+      const bool valid = row < a.Mrows;
+      int p = 0, b = 0;
+      long long centre = 0;
+      if (valid) {
+        p = a.idx[row];
+        centre = row >> a.ns_shift;
+        b = (int)(centre / a.m);
+      }
+      const size_t pt = (size_t)b * a.N + p;
+      if (SMALL) {
+        const int K0 = 3 + a.C;                           // bias column
+        const float *fx = a.xyz + pt * 3, *cx = a.new_xyz + (size_t)centre * 3, *ff = a.feats + pt * a.C;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int col = 8 * h + i;
+          float val = 0.f;
+          if (valid) {
+            if (col < 3) val = fx[col] - cx[col];         // the reference's in-place subtraction (OPS/pointnet2_utils.py:321)
+            else if (col < K0) val = ff[col - 3];
+            else if (col == K0) val = 1.f;
+          }
+          v[i] = val;
+        }
+        x3_frag xin;
+        x3_split8(v, xin);
+#pragma unroll
+        for (int T = 0; T < KA / 2; ++T) {
+          x3_f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          const x3_frag w = load_w(w0s, T);
+          x3_mma(w, xin, acc);                            // transposed: lane = row, registers = channels
+          acc_to_frags(acc, actA[2 * T], actA[2 * T + 1]);
+        }
+      } else {
+        const float *pq = a.feats + pt * (size_t)(KA * 16) + 8 * h;
+        const float *qq = a.Q + (size_t)centre * (KA * 16) + 8 * h;
+#pragma unroll
+        for (int c = 0; c < KA; ++c) {
+          float4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0, q0 = x0, q1 = x0;
+          if (valid) {
+            x0 = *reinterpret_cast<const float4 *>(pq + 16 * c);
+            x1 = *reinterpret_cast<const float4 *>(pq + 16 * c + 4);
+            q0 = *reinterpret_cast<const float4 *>(qq + 16 * c);
+            q1 = *reinterpret_cast<const float4 *>(qq + 16 * c + 4);
+          }
+          const float v[8] = {fmaxf(x0.x - q0.x, 0.f), fmaxf(x0.y - q0.y, 0.f), fmaxf(x0.z - q0.z, 0.f), fmaxf(x0.w - q0.w, 0.f),
+                              fmaxf(x1.x - q1.x, 0.f), fmaxf(x1.y - q1.y, 0.f), fmaxf(x1.z - q1.z, 0.f), fmaxf(x1.w - q1.w, 0.f)};
+          x3_split8(v, actA[c]);
+        }
+      }
+    }
+    // ------------------------------------------------------------------ middle layer (transposed), compile-time tiles
+#pragma unroll
+    for (int jm = 0; jm < STEPS_MID; ++jm) {
+      issue_dma();
+      const unsigned char *sb = ring + slot * kX3SlotBytes;
+#pragma unroll
+      for (int tl = 0; tl < TPS_MID; ++tl) {
+        const int T = jm * TPS_MID + tl;
+        x3_f32x16 acc;
+        const float4 *bt = reinterpret_cast<const float4 *>(bmid + (T * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bv = bt[q];
+          acc[4 * q] = bv.x; acc[4 * q + 1] = bv.y; acc[4 * q + 2] = bv.z; acc[4 * q + 3] = bv.w;
+        }
+#pragma unroll
+        for (int c = 0; c < KA; ++c) {
+          const x3_frag w = load_w(sb, tl * KA + c);
+          x3_mma(w, actA[c], acc);
+        }
+        acc_to_frags(acc, actB[KB ? 2 * T : 0], actB[KB ? 2 * T + 1 : 0]);
+      }
+      __syncthreads();
+      slot = slot + 1 == kRing ? 0 : slot + 1;
+    }
+    // ------------------------------------------------------------------ last layer + maximum over each centre's rows
+    for (int jf = 0; jf < a.steps_fin; ++jf) {
+      issue_dma();
+      const unsigned char *sb = ring + slot * kX3SlotBytes;
+#pragma unroll
+      for (int tl = 0; tl < TPS_FIN; ++tl) {
+        const int t = jf * TPS_FIN + tl;
+        const float bv = bfin[32 * t + l32];
+        x3_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bv;
+#pragma unroll
+        for (int c = 0; c < KF; ++c) {
+          const x3_frag w = load_w(sb, tl * KF + c);
+          if (KB) x3_mma(actB[KB ? c : 0], w, acc);
+          else x3_mma(actA[c < KA ? c : 0], w, acc);
+        }
+        // lane = channel 32 t + l32; registers 0-7: rows 0-15 of the wave's 32 (this half's share), 8-15: rows 16-31
+        float m0 = acc[0], m1 = acc[8];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, acc[r]); m1 = fmaxf(m1, acc[8 + r]); }
+        m0 = fmaxf(m0, __shfl_xor(m0, 32));
+        m1 = fmaxf(m1, __shfl_xor(m1, 32));
+        const int col = 32 * t + l32;
+        if (a.ns_shift == 4) {                             // two centres per wave: lower half stores the first, upper the second
+          const long long centre = (row0 >> 4) + h;
+          if (centre < a.ncentres) a.out[(size_t)centre * a.ldo + col] = fmaxf(h ? m1 : m0, 0.f);
+        } else {
+          const long long centre = row0 >> a.ns_shift;
+          const float v = fmaxf(fmaxf(m0, m1), 0.f);
+          if (h == 0 && centre < a.ncentres) {
+            float *o = a.out + (size_t)centre * a.ldo + col;
+            if (a.ns_shift == 5) *o = v;
+            else atomicMax(reinterpret_cast<int *>(o), __builtin_bit_cast(int, v));   // v >= 0: integer order = float order; out zero-filled
+          }
+        }
+      }
+      __syncthreads();
+      slot = slot + 1 == kRing ? 0 : slot + 1;
+    }
+  }
+}
+
+// W [N][ldw] fp32 (columns [0, K) used) -> (N / 32) (K / 16) units, unit (t, c) at index t (K / 16) + c:
+// [piece][lane] 16 bytes = the 8 bf16 of weight row 32 t + (lane & 31), contraction indices kmap(c, lane >> 5, 0..7)
+__global__ __launch_bounds__(256) void x3_pack_kernel(int N, int K, int ldw, int perm, const float *__restrict__ W,
+                                                      x3_u32x4 *__restrict__ out) {
+  const int cpt = K / 16;
+  const int total = (N / 32) * cpt * 64;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int lane = e & 63, unit = e >> 6, c = unit % cpt, t = unit / cpt;
+    const float *row = W + (size_t)(32 * t + (lane & 31)) * ldw;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = row[x3_kmap(c, lane >> 5, i, perm != 0)];
+    x3_frag f;
+    x3_split8(v, f);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) out[(size_t)unit * 192 + s * 64 + lane] = f.p[s];
+  }
+}
+
+template <int IN, int KA, int KB>
+int launch_eval(const EvalArgs &a, hipStream_t stream) {
+  constexpr int W0_BYTES = IN == 0 ? (KA / 2) * kX3UnitBytes : 0;
+  const size_t lds = (size_t)kRing * kX3SlotBytes + W0_BYTES + ((KB ? KB * 16 : 16) + a.c_out) * sizeof(float);
+  static const bool ok = hipFuncSetAttribute((const void *)sa_eval_kernel<IN, KA, KB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             160 * 1024) == hipSuccess;
+  if (!ok || lds > 160 * 1024) return PN2_ELAUNCH;
+  const long long npass = (a.Mrows + 255) >> 8;
+  const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
+  hipLaunchKernelGGL((sa_eval_kernel<IN, KA, KB>), dim3(grid), dim3(512), lds, stream, a);
+  return pn2_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t pn2_x3_weight_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || (N & 31) || (K & 15)) return 0;
+  // rounded up to whole ring slots: the kernels' weight stream is read slot by slot
+  const size_t units = (size_t)(N / 32) * (K / 16);
+  return (units + kX3SlotUnits - 1) / kX3SlotUnits * kX3SlotBytes;
+}
+
+extern "C" int pn2_x3_pack_weight(int N, int K, int ldw, int perm, const float *W, void *frags, void *stream) {
+  if (N <= 0 || K <= 0 || (N & 31) || (K & 15) || ldw < K) return PN2_EINVAL;
+  if (!W || !frags) return PN2_ENULL;
+  if ((((size_t)frags) & 15) != 0) return PN2_EINVAL;
+  const int total = (N / 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(x3_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K, ldw, perm, W,
+                     (x3_u32x4 *)frags);
+  return pn2_check_launch();
+}
+
+// Shapes the fused eval level covers: neighbourhoods of 16 / 32 / 64 k rows, a first layer of <= 12 feature columns
+// (mode 0) or a lifted first layer (mode 1), layer widths 64 or 128 in front of the last layer, any last width that is a
+// multiple of 32 and fills whole ring slots.
+extern "C" int pn2_sa_eval_x3_supported(int mode, int ns, int C, int c1, int c_mid, int c_out) {
+  if (mode != 0 && mode != 1) return 0;
+  if (ns < 16 || (ns & (ns - 1)) != 0) return 0;
+  if (mode == 0 && (C < 0 || C > 12)) return 0;
+  const bool inst = (mode == 0 && c1 == 64 && (c_mid == 0 || c_mid == 64)) || (mode == 1 && c1 == 128 && (c_mid == 0 || c_mid == 128));
+  if (!inst) return 0;
+  const int kf = (c_mid ? c_mid : c1) / 16;
+  if (c_out <= 0 || (c_out & 31) || ((c_out / 32) * kf) % kX3SlotUnits != 0 || c_out > 4096) return 0;
+  return 1;
+}
+
+extern "C" int pn2_sa_eval_x3(int mode, int B, int N, int m, int ns, int C, const float *xyz, const float *new_xyz,
+                              const int *idx, const float *feats, const float *Q, int c1, const void *w0_frags, int c_mid,
+                              const void *wstream, const float *bias_mid, int c_out, const float *bias_fin, float *out, int ldo,
+                              void *stream) {
+  if (B < 0 || N <= 0 || m <= 0 || ldo < c_out) return PN2_EINVAL;
+  if (!pn2_sa_eval_x3_supported(mode, ns, C, c1, c_mid, c_out)) return PN2_EINVAL;
+  if (B == 0) return PN2_OK;
+  if (!new_xyz || !idx || !feats || !wstream || !bias_fin || !out || (mode == 0 && (!xyz || !w0_frags)) || (mode == 1 && !Q) ||
+      (c_mid && !bias_mid))
+    return PN2_ENULL;
+  EvalArgs a{};
+  a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.feats = feats; a.Q = Q;
+  a.w0 = (const unsigned char *)w0_frags; a.wstream = (const unsigned char *)wstream;
+  a.bias_mid = bias_mid; a.bias_fin = bias_fin; a.out = out;
+  a.ncentres = (long long)B * m;
+  a.Mrows = a.ncentres * ns;
+  a.N = N; a.m = m; a.C = C; a.c_out = c_out; a.ldo = ldo;
+  int sh = 0;
+  while ((1 << sh) < ns) ++sh;
+  a.ns_shift = sh;
+  const int kf = (c_mid ? c_mid : c1) / 16;
+  a.steps_fin = (c_out / 32) * kf / kX3SlotUnits;
+  const int steps_mid = c_mid ? (c_mid / 32) * (c1 / 16) / kX3SlotUnits : 0;
+  a.spp = steps_mid + a.steps_fin;
+  hipStream_t st = (hipStream_t)stream;
+  if (ns >= 64) {
+    // the rows of a centre span several waves: they meet in an integer atomic maximum over the zero-filled result
+    if (hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)c_out * 4, (size_t)a.ncentres, st) != hipSuccess) return PN2_ELAUNCH;
+  }
+  if (mode == 0 && c_mid == 64) return launch_eval<0, 4, 4>(a, st);
+  if (mode == 0) return launch_eval<0, 4, 0>(a, st);
+  if (c_mid == 128) return launch_eval<1, 8, 8>(a, st);
+  return launch_eval<1, 8, 0>(a, st);
+}

@@ -38,8 +38,8 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.pn2_abi_version.restype = ctypes.c_int
-if int(_lib.pn2_abi_version()) != 9:
-    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 9: "
+if int(_lib.pn2_abi_version()) != 10:
+    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 10: "
                       f"rebuild it (`make -C {os.path.join(_PKG_DIR, 'csrc')}`)")
 
 _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -66,6 +66,8 @@ _SIGNATURES = {
     "pn2_group_rows_grad": [_c_int] * 7 + [_c_vp] * 4,
     "pn2_bn_running_update": [_c_int, _c_int, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
+    "pn2_x3_pack_weight": [_c_int] * 4 + [_c_vp] * 3,
+    "pn2_sa_eval_x3": [_c_int] * 6 + [_c_vp] * 5 + [_c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp],
     "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_lift_rows": [_c_int] * 6 + [_c_f32] + [_c_vp] * 8,
     "pn2_group_lift_rows_grad": [_c_int] * 6 + [_c_f32] + [_c_vp] * 11 + [_c_sz, _c_vp],
@@ -245,6 +247,10 @@ _lib.pn2_pool_bwd_supported.argtypes = [_c_int, _c_int, _c_int]
 _lib.pn2_pool_bwd_supported.restype = _c_int
 _lib.pn2_pool_bwd_workspace_bytes.argtypes = [ctypes.c_longlong, _c_int, _c_int]
 _lib.pn2_pool_bwd_workspace_bytes.restype = _c_sz
+_lib.pn2_x3_weight_bytes.argtypes = [_c_int, _c_int]
+_lib.pn2_x3_weight_bytes.restype = _c_sz
+_lib.pn2_sa_eval_x3_supported.argtypes = [_c_int] * 6
+_lib.pn2_sa_eval_x3_supported.restype = _c_int
 _lib.pn2_abi_version.restype = _c_int
 _lib.pn2_last_hip_error.restype = _c_int
 _lib.pn2_strerror.argtypes = [_c_int]
@@ -253,7 +259,7 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 #: the header revision this binding was written against: a stale prebuilt libpn2_hip.so fails here with a version
 #: error instead of an AttributeError on the first missing symbol
-EXPECTED_ABI_VERSION = 9
+EXPECTED_ABI_VERSION = 10
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_status_offset_ex", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
                                                "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_fps_ordered_workspace_bytes", "pn2_gcn_fused_supported", "pn2_gcn_layer_backward_workspace_bytes", "pn2_group_lift_rows_grad_seg_workspace_bytes",
@@ -266,7 +272,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
                                                "pn2_mlp_bwd_bf16_supported", "pn2_pool_bwd_supported",
-                                               "pn2_pool_bwd_workspace_bytes",
+                                               "pn2_pool_bwd_workspace_bytes", "pn2_x3_weight_bytes", "pn2_sa_eval_x3_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
 HAS_ROWS = True
@@ -834,6 +840,69 @@ def lift_points(P, xyz, new_xyz, Wx, normalize, radius):
     _call("pn2_lift_points", P, B, N, m, N0, int(bool(normalize)), float(radius if radius is not None else 1.0), _ptr(xyz),
           _ptr(new_xyz), _ptr(P), _ptr(Wx), _ptr(Pq), _ptr(Q), alg_bytes=4 * B * (2 * N * N0 + m * N0 + 3 * N + 3 * m))
     return Pq, Q
+
+
+# ------------------------------------------------------------------ round 6: eval-mode SA level in one kernel (f32x3)
+def x3_weight_bytes(N, K):
+    return int(_lib.pn2_x3_weight_bytes(int(N), int(K)))
+
+
+def x3_pack_weight(W, perm, out=None):
+    """W (N, K) fp32 (N % 32 == 0, K % 16 == 0) -> uint8 fragments of the split-bf16 product (include/pn2_hip.h).
+    `out`: a uint8 view of x3_weight_bytes(N, K) bytes to write into (a slice of a level's weight stream)."""
+    _f32(W, "W")
+    _check_cuda(W, "W")
+    N, K = W.shape
+    nbytes = x3_weight_bytes(N, K)
+    if nbytes == 0:
+        _fail("x3_pack_weight: N must be a multiple of 32 and K a multiple of 16")
+    if out is None:
+        out = torch.zeros(nbytes, dtype=torch.uint8, device=W.device)
+    elif out.numel() < nbytes or out.dtype != torch.uint8 or not out.is_contiguous():
+        _fail("x3_pack_weight: `out` must be a contiguous uint8 tensor of x3_weight_bytes(N, K) bytes")
+    _call("pn2_x3_pack_weight", W, N, K, K, int(bool(perm)), _ptr(W), _ptr(out))
+    return out
+
+
+def sa_eval_x3_supported(mode, ns, C, c1, c_mid, c_out):
+    return bool(_lib.pn2_sa_eval_x3_supported(int(mode), int(ns), int(C), int(c1), int(c_mid), int(c_out)))
+
+
+def sa_eval_x3(mode, xyz, new_xyz, idx, feats, Q, c1, w0_frags, c_mid, wstream, bias_mid, bias_fin, out, col0=0):
+    """One scale of an eval-mode SA level in one kernel (pn2_sa_eval_x3): writes columns [col0, col0 + c_out) of the rows
+    tensor `out` (B, m, width).  mode 0: feats (B, N, C) rows or None; mode 1: feats = Pq (B N, c1), Q (B m, c1)."""
+    _f32(new_xyz, "new_xyz"); _i32(idx, "idx"); _f32(out, "out"); _f32(bias_fin, "bias_fin")
+    _same_device((new_xyz, "new_xyz"), (idx, "idx"), (xyz, "xyz"), (feats, "feats"), (Q, "Q"), (out, "out"),
+                 (wstream, "wstream"), (w0_frags, "w0_frags"), (bias_mid, "bias_mid"), (bias_fin, "bias_fin"))
+    B, m, ns = idx.shape
+    N = xyz.size(1)
+    c_out = bias_fin.numel()
+    ldo = out.size(-1)
+    if out.numel() != B * m * ldo or col0 < 0 or col0 + c_out > ldo:
+        _fail("sa_eval_x3: out must be (B, m, width) with col0 + c_out <= width")
+    if mode == 0:
+        C = 0 if feats is None else feats.size(2)
+        if feats is not None:
+            _f32(feats, "feats")
+            if tuple(feats.shape[:2]) != (B, N):
+                _fail("sa_eval_x3: feats must be (B, N, C) point-major rows")
+        fptr = _ptr(feats) if feats is not None else _ptr(xyz)
+    else:
+        C = 0
+        _f32(feats, "Pq"); _f32(Q, "Q")
+        if feats.numel() != B * N * c1 or Q.numel() != B * m * c1:
+            _fail("sa_eval_x3: Pq must be (B N, c1) and Q (B m, c1)")
+        fptr = _ptr(feats)
+    if not sa_eval_x3_supported(mode, ns, C, c1, c_mid, c_out):
+        _fail(f"sa_eval_x3: unsupported shape (mode {mode}, ns {ns}, C {C}, widths {c1}/{c_mid}/{c_out})")
+    rows = B * m * ns
+    flops = 2 * rows * ((16 * c1 if mode == 0 else 0) + c1 * c_mid + (c_mid or c1) * c_out)
+    nbytes = B * (4 * m * ns + 12 * m + 4 * c_out * m) + (B * (12 * N + 4 * C * N) if mode == 0 else 4 * c1 * B * (N + m))
+    _call("pn2_sa_eval_x3", idx, int(mode), B, N, m, ns, C, _ptr(xyz), _ptr(new_xyz), _ptr(idx), fptr, _ptr(Q), int(c1),
+          _ptr(w0_frags), int(c_mid), _ptr(wstream), _ptr(bias_mid), int(c_out), _ptr(bias_fin),
+          out.data_ptr() + 4 * int(col0), int(ldo), alg_bytes=nbytes, alg_flops=flops,
+          tag=(f"ns{ns},{c1}/{c_mid}/{c_out}" if DETAIL_TAGS else None))
+    return out
 
 
 def group_lift_stats(Pq, Q, idx, N, stats):

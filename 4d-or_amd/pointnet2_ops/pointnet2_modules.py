@@ -162,7 +162,13 @@ def sa_scale_rows(grouper, mlp: nn.Module, xyz, new_xyz, feats_rows, idx=None, _
     """One SA scale on the rows path: group -> shared MLP -> max -> (B, npoint, C_out).
     Ball-query groupers with a fusable MLP run as a single autograd node (gather, MLP, pool and
     the scatter of the feature gradient); anything else goes through forward_rows + mlp_pool_rows."""
-    from pointnet2_ops import fused_mlp
+    from pointnet2_ops import eval_fused, fused_mlp
+    # inference (eval-mode BatchNorm, no gradient recorded): the whole scale as ONE kernel, activations in registers
+    plan = eval_fused.applicable(grouper, mlp, xyz, new_xyz, feats_rows)
+    if plan is not None:
+        if idx is None:
+            idx = grouper.query(xyz, new_xyz)
+        return eval_fused.sa_scale_eval(plan, grouper, xyz, new_xyz, feats_rows, idx)
     sizes = None if _whole_batch else _SEG.table.get(xyz.size(0))
     if sizes is not None and _trains_batchnorm(mlp):
         if (_FUSED_MLP and isinstance(grouper, pointnet2_utils.QueryAndGroup) and new_xyz is not None

@@ -841,6 +841,39 @@ int pn2_floyd_warshall(int B, int n, const long long *adjacency, long long *dist
 int pn2_gen_edge_input(int B, int n, int max_dist, int F, const long long *path, const long long *edge_feat,
                        long long *out, void *stream);
 
+/* ------------------------------------------------------------- round 6: eval-mode set-abstraction level as ONE kernel ---
+ * The "f32x3" product (csrc/x3_common.h): every fp32 operand = hi + mid + lo (three bf16, round to nearest), six partial
+ * products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-grade error (1.0-1.5x the exact fp32 MFMA kernel's
+ * error against fp64, profiles/r05_split_bf16_gemm.jsonl) at 6/16 of its matrix time.
+ *
+ *   pn2_x3_pack_weight : W (N, ldw) fp32, columns [0, K) -> operand fragments, (N / 32)(K / 16) units of 3 KB, unit
+ *       (tile t, chunk c) at index t (K / 16) + c = [piece][lane] 16 bytes: the 8 bf16 of weight row 32 t + (lane & 31) at
+ *       the contraction indices of (c, lane >> 5) — natural order (perm = 0: the layer reads gathered rows) or the order in
+ *       which a transposed accumulator tile holds them (perm = 1: the layer reads the previous layer's registers).
+ *       N % 32 == 0, K % 16 == 0; `frags` holds pn2_x3_weight_bytes(N, K) bytes (whole 24 KB ring slots), 16-byte aligned.
+ *   pn2_sa_eval_x3 : one scale of a set-abstraction level in EVAL mode (OPS/pointnet2_modules.py:29-74 with every
+ *       BatchNorm2d folded into its Conv2d as W' = diag(gamma / sqrt(var + eps)) W, b' = beta - gamma mean / sqrt(var + eps)):
+ *         out[b m + j][0:c_out] = max_s relu(L_last(... relu(L_1(row(b, j, s))))),  row = grouped input of sample s of centre j
+ *       mode 0: the first layer sees [xyz[idx] - centre | feats[idx]] (3 + C <= 15 columns; feats (B, N, C) point-major rows);
+ *               `w0_frags` = pn2_x3_pack_weight of the (c1, 16) matrix [W'_x (/ radius when the grouper normalises) | W'_f |
+ *               b' | 0], perm 0 — the bias rides in the padding column 3 + C.
+ *       mode 1: the first layer was applied per point (pn2_lift_points on folded weights): feats = Pq (B N, c1), Q (B m, c1)
+ *               with the bias already SUBTRACTED from Q: first activation = relu(Pq[idx] - Q[centre]).
+ *       then an optional middle layer c1 -> c_mid (bias_mid) and the last layer -> c_out (bias_fin); `wstream` = the middle
+ *       layer's fragments followed by the last layer's (perm 1 wherever the layer's input is the previous layer's
+ *       accumulators, i.e. everywhere except the last layer of a mode-1 stack without a middle layer).
+ *       Nothing of size rows x channels is written: the activations stay in registers from the gather to the maximum.
+ *       `out` rows have pitch ldo >= c_out (a multi-scale level writes its scales side by side).  ns in {16, 32, 64 k};
+ *       covered widths: pn2_sa_eval_x3_supported.  idx as written by pn2_ball_query.  Indices bit-exact by construction
+ *       (they are inputs); features within 1e-4 of the fp32 reference (tests/test_gpu_round6.py, against the oracle).
+ * Algorithmic bytes: B (4 m ns + 12 N + 12 m + 4 C N + 4 c_out m)  (mode 1: 4 c1 (N + m) instead of 12 N + 4 C N). */
+size_t pn2_x3_weight_bytes(int N, int K);
+int pn2_x3_pack_weight(int N, int K, int ldw, int perm, const float *W, void *frags, void *stream);
+int pn2_sa_eval_x3_supported(int mode, int ns, int C, int c1, int c_mid, int c_out);
+int pn2_sa_eval_x3(int mode, int B, int N, int m, int ns, int C, const float *xyz, const float *new_xyz, const int *idx,
+                   const float *feats, const float *Q, int c1, const void *w0_frags, int c_mid, const void *wstream,
+                   const float *bias_mid, int c_out, const float *bias_fin, float *out, int ldo, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }
