@@ -7,7 +7,7 @@
 // accumulator tile is directly the next layer's operand fragment); no (rows x channels) tensor exists in HBM or LDS.
 // Arithmetic: the split-bf16 ("f32x3") product — fp32-grade error at 6/16 of the exact fp32 MFMA's matrix time.
 //
-//   workgroup = 8 waves; a wave owns 32 consecutive rows (row = (centre, sample)) of a 256-row pass; persistent workgroups
+//   workgroup = 4 or 8 waves; a wave owns 32 consecutive rows (row = (centre, sample)) of a pass; persistent workgroups
 //   walk the passes.  Per pass:
 //     input stage   IN_SMALL: gather [xyz[idx] - centre | feats[idx] | 1] (<= 15 columns + the bias column) and apply the
 //                             first layer (one 16-wide chunk, weights resident in LDS)
@@ -16,8 +16,8 @@
 //     middle layer  (optional) transposed product, bias in the accumulator's initial value, ReLU + split in registers
 //     last layer    row-major product (lane = channel, registers = rows): maximum over the rows of a centre in the
 //                   epilogue, ReLU, one coalesced 128-byte store per (centre, 32 channels)
-//   The weights of the middle and last layer stream through a 3-slot LDS ring (24 KB slots = 8 (chunk, tile) units) filled
-//   by global_load_lds (direct global -> LDS, no registers) two steps ahead; one barrier per step.
+//   The weights of the middle and last layer stream through a 2-slot LDS ring (24 KB slots = 8 (chunk, tile) units) filled
+//   by global_load_lds (direct global -> LDS, no registers) one step ahead; one barrier per step.
 #include "pn2_common.h"
 #include "x3_common.h"
 
@@ -39,10 +39,14 @@ struct EvalArgs {
   int N, m, ns_shift, C, c_out, ldo, steps_fin, spp;
 };
 
-constexpr int kRing = 3;
+constexpr int kRing = 2;
 
-template <int IN, int KA, int KB>      // KA = c1 / 16; KB = c_mid / 16 (0: no middle layer)
-__global__ __launch_bounds__(512, 2) void sa_eval_kernel(const EvalArgs a) {
+// WAVES = waves per workgroup (each owns 32 rows of a pass of 32 WAVES rows).  Two workgroups share a CU (2 x 55 KB of LDS)
+// and run out of phase: one's gather / split phases under the other's matrix phases.  16 waves per CU at <= 128 registers
+// (IN_SMALL instances, WAVES = 8), 8 waves at <= 256 (IN_LIFT: 96 registers of operand fragments per layer, WAVES = 4).
+template <int IN, int KA, int KB, int WAVES>      // KA = c1 / 16; KB = c_mid / 16 (0: no middle layer)
+__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const EvalArgs a) {
+  constexpr int THREADS = 64 * WAVES, PASS = 32 * WAVES;
   constexpr bool SMALL = IN == 0;
   constexpr int KF = KB ? KB : KA;                      // chunks of the last layer's input
   constexpr int TPS_MID = kX3SlotUnits / KA;            // tiles per ring slot
@@ -56,39 +60,57 @@ __global__ __launch_bounds__(512, 2) void sa_eval_kernel(const EvalArgs a) {
   float *bfin = bmid + (KB ? KB * 16 : 16);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
-  const long long npass = (a.Mrows + 255) >> 8;
+  const long long npass = (a.Mrows + PASS - 1) / PASS;
   const long long my_passes = (npass - blockIdx.x + gridDim.x - 1) / gridDim.x;
 
   // resident tables
   if (SMALL)
-    for (int i = tid; i < W0_BYTES / 16; i += 512)
+    for (int i = tid; i < W0_BYTES / 16; i += THREADS)
       reinterpret_cast<x3_u32x4 *>(w0s)[i] = reinterpret_cast<const x3_u32x4 *>(a.w0)[i];
   if (KB)
-    for (int i = tid; i < KB * 16; i += 512) {
+    for (int i = tid; i < KB * 16; i += THREADS) {
       const int r = i & 15, hh = (i >> 4) & 1, T = i >> 5;
       bmid[i] = a.bias_mid[32 * T + (r & 3) + 8 * (r >> 2) + 4 * hh];
     }
-  for (int i = tid; i < a.c_out; i += 512) bfin[i] = a.bias_fin[i];
+  for (int i = tid; i < a.c_out; i += THREADS) bfin[i] = a.bias_fin[i];
 
-  // weight stream: global step g reads slot (g mod spp) of the stream into ring slot (g mod 3)
+  // weight stream: global step g reads slot (g mod spp) of the stream into ring slot (g mod 2), one step ahead
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring);
+  auto step_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
+    __syncthreads();
+  };
   int dma_j = 0, dma_slot = 0;
   auto issue_dma = [&]() {
+    // global_load_lds_dwordx4 through inline asm: issued by the builtin, hipcc counts the DMA into lgkmcnt as well and every
+    // ds_read of the matrix loops then waits lgkmcnt(0) (measured on the ISA: 65 such waits against fine-grained lgkmcnt(3-5)
+    // without it).  The asm form is invisible to the compiler's counters: its completion is awaited by the explicit
+    // s_waitcnt vmcnt(0) in front of every step barrier (step_barrier below).
     const unsigned char *src = a.wstream + (size_t)dma_j * kX3SlotBytes + lane * 16;
-    unsigned char *dst = ring + dma_slot * kX3SlotBytes;
+    const unsigned dst = ring_base + dma_slot * kX3SlotBytes;          // wave-uniform LDS byte address
 #pragma unroll
-    for (int i = 0; i < kX3SlotBytes / 1024 / 8; ++i) {
-      const int piece = wave + 8 * i;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024),
-                                       (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+    for (int i = 0; i < kX3SlotBytes / 1024 / WAVES; ++i) {
+      const int piece = wave_u + WAVES * i;
+      const unsigned char *g = src + piece * 1024;
+      const unsigned l = dst + piece * 1024;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(g), "s"(l) : "memory");
     }
     dma_j = dma_j + 1 == a.spp ? 0 : dma_j + 1;
     dma_slot = dma_slot + 1 == kRing ? 0 : dma_slot + 1;
   };
   issue_dma();
-  issue_dma();
-  __syncthreads();
+  step_barrier();
 
   int slot = 0;                                          // ring slot of the step being computed
+  // neighbourhood index of this lane's row, loaded one pass ahead (the gathers depend on it: one L2 round trip less per pass)
+  auto load_idx = [&](long long pi) {
+    const long long row = ((long long)blockIdx.x + pi * gridDim.x) * PASS + wave * 32 + l32;
+    return (pi < my_passes && row < a.Mrows) ? a.idx[row] : 0;
+  };
+  int p_next = load_idx(0);
   x3_frag actA[KA];
   x3_frag actB[KB ? KB : 1];
 
@@ -109,15 +131,16 @@ __global__ __launch_bounds__(512, 2) void sa_eval_kernel(const EvalArgs a) {
   };
 
   for (long long pi = 0; pi < my_passes; ++pi) {
-    const long long row0 = ((long long)blockIdx.x + pi * gridDim.x) * 256 + wave * 32;     // wave-uniform
+    const long long row0 = ((long long)blockIdx.x + pi * gridDim.x) * PASS + wave * 32;     // wave-uniform
     // ------------------------------------------------------------------ input stage
     {
       const long long row = row0 + l32;
       const bool valid = row < a.Mrows;
-      int p = 0, b = 0;
+      int b = 0;
       long long centre = 0;
+      const int p = p_next;
+      p_next = load_idx(pi + 1);
       if (valid) {
-        p = a.idx[row];
         centre = row >> a.ns_shift;
         b = (int)(centre / a.m);
       }
@@ -181,14 +204,21 @@ __global__ __launch_bounds__(512, 2) void sa_eval_kernel(const EvalArgs a) {
           const float4 bv = bt[q];
           acc[4 * q] = bv.x; acc[4 * q + 1] = bv.y; acc[4 * q + 2] = bv.z; acc[4 * q + 3] = bv.w;
         }
+        // weight fragments one chunk ahead of the matrix instructions that read them
+        x3_frag wq[2];
+        wq[0] = load_w(sb, tl * KA);
+        __builtin_amdgcn_sched_barrier(0);      // (the bias reads above must not be counted into the loop's ds_read groups)
 #pragma unroll
         for (int c = 0; c < KA; ++c) {
-          const x3_frag w = load_w(sb, tl * KA + c);
-          x3_mma(w, actA[c], acc);
+          if (c + 1 < KA) wq[(c + 1) & 1] = load_w(sb, tl * KA + c + 1);
+          x3_mma(wq[c & 1], actA[c], acc);
+          // pin the order (hipcc otherwise sinks every ds_read to its first use and waits lgkmcnt(0) three times per chunk)
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
         }
         acc_to_frags(acc, actB[KB ? 2 * T : 0], actB[KB ? 2 * T + 1 : 0]);
       }
-      __syncthreads();
+      step_barrier();
       slot = slot + 1 == kRing ? 0 : slot + 1;
     }
     // ------------------------------------------------------------------ last layer + maximum over each centre's rows
@@ -202,11 +232,16 @@ __global__ __launch_bounds__(512, 2) void sa_eval_kernel(const EvalArgs a) {
         x3_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bv;
+        x3_frag wq[2];
+        wq[0] = load_w(sb, tl * KF);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < KF; ++c) {
-          const x3_frag w = load_w(sb, tl * KF + c);
-          if (KB) x3_mma(actB[KB ? c : 0], w, acc);
-          else x3_mma(actA[c < KA ? c : 0], w, acc);
+          if (c + 1 < KF) wq[(c + 1) & 1] = load_w(sb, tl * KF + c + 1);
+          if (KB) x3_mma(actB[KB ? c : 0], wq[c & 1], acc);
+          else x3_mma(actA[c < KA ? c : 0], wq[c & 1], acc);
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
         }
         // lane = channel 32 t + l32; registers 0-7: rows 0-15 of the wave's 32 (this half's share), 8-15: rows 16-31
         float m0 = acc[0], m1 = acc[8];
@@ -228,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void sa_eval_kernel(const EvalArgs a) {
           }
         }
       }
-      __syncthreads();
+      step_barrier();
       slot = slot + 1 == kRing ? 0 : slot + 1;
     }
   }
@@ -253,16 +288,16 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(int N, int K, int ldw, int
   }
 }
 
-template <int IN, int KA, int KB>
+template <int IN, int KA, int KB, int WAVES>
 int launch_eval(const EvalArgs &a, hipStream_t stream) {
   constexpr int W0_BYTES = IN == 0 ? (KA / 2) * kX3UnitBytes : 0;
   const size_t lds = (size_t)kRing * kX3SlotBytes + W0_BYTES + ((KB ? KB * 16 : 16) + a.c_out) * sizeof(float);
-  static const bool ok = hipFuncSetAttribute((const void *)sa_eval_kernel<IN, KA, KB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             160 * 1024) == hipSuccess;
-  if (!ok || lds > 160 * 1024) return PN2_ELAUNCH;
-  const long long npass = (a.Mrows + 255) >> 8;
-  const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
-  hipLaunchKernelGGL((sa_eval_kernel<IN, KA, KB>), dim3(grid), dim3(512), lds, stream, a);
+  static const bool ok = hipFuncSetAttribute((const void *)sa_eval_kernel<IN, KA, KB, WAVES>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+  if (!ok || lds > 80 * 1024) return PN2_ELAUNCH;
+  const long long npass = (a.Mrows + 32 * WAVES - 1) / (32 * WAVES);
+  const unsigned grid = (unsigned)(npass < 512 ? npass : 512);         // two workgroups per CU
+  hipLaunchKernelGGL((sa_eval_kernel<IN, KA, KB, WAVES>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
   return pn2_check_launch();
 }
 
@@ -328,8 +363,8 @@ extern "C" int pn2_sa_eval_x3(int mode, int B, int N, int m, int ns, int C, cons
     // the rows of a centre span several waves: they meet in an integer atomic maximum over the zero-filled result
     if (hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)c_out * 4, (size_t)a.ncentres, st) != hipSuccess) return PN2_ELAUNCH;
   }
-  if (mode == 0 && c_mid == 64) return launch_eval<0, 4, 4>(a, st);
-  if (mode == 0) return launch_eval<0, 4, 0>(a, st);
-  if (c_mid == 128) return launch_eval<1, 8, 8>(a, st);
-  return launch_eval<1, 8, 0>(a, st);
+  if (mode == 0 && c_mid == 64) return launch_eval<0, 4, 4, 8>(a, st);
+  if (mode == 0) return launch_eval<0, 4, 0, 8>(a, st);
+  if (c_mid == 128) return launch_eval<1, 8, 8, 4>(a, st);
+  return launch_eval<1, 8, 0, 4>(a, st);
 }

@@ -56,16 +56,21 @@ class Pointnet2Backbone(nn.Module):
         # FPS shape that leaves half of the CUs to the co-running step (include/pn2_hip.h: PN2_FPS_FEW_CUS)
         # fp32 steps (13+ ms of matrix kernels) are longer than the sampling chain: give the sampling as few CUs as possible;
         # the bf16 step is shorter than the chain and wants the faster 128-CU shape
-        from pointnet2_ops import fused_mlp
+        from pointnet2_ops import eval_fused, fused_mlp
         bg = getattr(pointnet2_utils._ext, "background_geometry", None)
-        with (bg(fewest=fused_mlp.mlp_dtype() == torch.float32) if bg is not None else contextlib.nullcontext()):
+        # inference (eval mode, no gradient recorded): no backward will ask for the inverse neighbourhood indices, and the
+        # one-kernel SA levels (pointnet2_ops/eval_fused.py) gather their own rows from idx — the query kernel need not emit
+        # level 1's grouped rows (117 MB at the headline shape); the forward is short, so the sampling gets the faster shape
+        infer = not self.training and not torch.is_grad_enabled()
+        with (bg(fewest=fused_mlp.mlp_dtype() == torch.float32 and not infer) if bg is not None else contextlib.nullcontext()):
             feats0 = (pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 and not pointcloud.requires_grad else None)
             geo["feats_rows"] = feats0
+            pregroup = not (infer and eval_fused.eval_fused_enabled())
             for i in (1, 2, 3, 4):
                 # levels 2-4 gather features that carry a gradient; level 1 reads the input colours: its grouped rows come
                 # out of the ball query itself (pn2_ball_query_group) here, off the step's critical path
-                g = getattr(self, f"sa{i}").sample_and_query(levels[-1], inverse_index=i > 1,
-                                                             feats_rows=feats0 if i == 1 else None)
+                g = getattr(self, f"sa{i}").sample_and_query(levels[-1], inverse_index=i > 1 and not infer,
+                                                             feats_rows=feats0 if i == 1 and pregroup else None)
                 if g.get("rows_src") is not None:
                     g["rows_src"] = rows_source(pointcloud)     # (the rows come from THIS cloud's colour columns)
                 geo["sa"].append(g)

@@ -134,7 +134,8 @@ def applicable(grouper, mlp, xyz, new_xyz, feats_rows) -> Optional[_Plan]:
     if not _ENABLED or torch.is_grad_enabled() and (
             (feats_rows is not None and feats_rows.requires_grad) or any(p.requires_grad for p in mlp.parameters())):
         return None
-    if not isinstance(grouper, _pu.QueryAndGroup) or new_xyz is None or grouper.sample_uniformly or grouper.ret_grouped_xyz:
+    # (ret_grouped_xyz only matters to the literal forward(): the rows path returns pooled features either way)
+    if not isinstance(grouper, _pu.QueryAndGroup) or new_xyz is None:
         return None
     if not xyz.is_cuda or xyz.dtype != torch.float32 or (feats_rows is not None and feats_rows.dtype != torch.float32):
         return None

@@ -583,6 +583,143 @@ def bench_sgp(args, device, rank, world, distributed, _ext):
         dist.destroy_process_group()
 
 
+X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0     # six bf16 partial products per fp32-grade product (csrc/x3_common.h)
+
+
+def bench_forward_eval(args, device, rank, world, distributed, _ext):
+    """Inference: eval-mode forward (running-statistic BatchNorm, no autograd) of the workload's model on a resident batch,
+    one full geometry (FPS chain, ball queries, 3-NN) per step — prefetched for the NEXT batch on the side stream like the
+    training steps, or inside the step with --no-geometry-pipeline.  `value` = scenes/s through the one-kernel SA levels
+    (pn2_sa_eval_x3); the same model through the layer-by-layer exact-fp32 kernels is timed beside it."""
+    from pointnet2_ops import eval_fused
+    sgp = args.workload == "sgp"
+    if sgp:
+        from scene_graph_prediction.main import RELATION_NAMES, config_loader
+        from scene_graph_prediction.scene_graph_helpers.dataset.synthetic import collate_scans, synthetic_scan, to_device
+        from scene_graph_prediction.scene_graph_helpers.model.scene_graph_prediction_model import SGPNModelWrapper
+        torch.manual_seed(0)
+        model = SGPNModelWrapper(config_loader("no_gt.json"), 12, len(RELATION_NAMES), torch.ones(12),
+                                 torch.ones(len(RELATION_NAMES)), RELATION_NAMES).to(device).eval()
+        S = max(1, int(args.scans_per_step))
+        batch = (to_device(synthetic_scan(9, 4000, 8000, seed=100 + rank), device) if S == 1 else
+                 to_device(collate_scans([synthetic_scan(9, 4000, 8000, seed=100 + rank * S + i, scan_id=f"synthetic_{i:06d}")
+                                          for i in range(S)]), device))
+        units, unit_name = S, "scans"
+
+        def geometry():
+            return model.precompute_geometry(batch)
+
+        def forward(geo):
+            b = batch if geo is None else dict(batch, geometry=geo)
+            return model(b)
+    else:
+        model = build_model(device, args.workload).eval()
+        batch = synthetic_scenes(args.batch, args.points, seed=1000 + rank, device=device)
+        units, unit_name = args.batch, "scenes"
+
+        def geometry():
+            return model.precompute_geometry(batch)
+
+        def forward(geo):
+            return model(batch, geometry=geo)
+
+    affinity = pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    side = side_stream(device) if args.geometry_pipeline else None
+    main = torch.cuda.current_stream(device)
+    state = {"geo": None}
+
+    def launch_geometry():
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            return geometry()
+
+    def run(k, on_step=None):
+        with torch.no_grad():
+            for i in range(k):
+                if on_step is not None:
+                    on_step(i)
+                if side is None:
+                    forward(None)
+                    continue
+                geo = state["geo"] if state["geo"] is not None else launch_geometry()
+                main.wait_stream(side)
+                record_stream_tree(geo, main)
+                state["geo"] = launch_geometry()          # the next batch's geometry co-runs with this forward
+                forward(geo)
+
+    def timed(k):
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(k)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # the layer-by-layer exact route first (same model, same batch), then the one-kernel route = `value`
+    prev = eval_fused.set_eval_fused(False)
+    run(args.warmup)
+    layers_s = timed(max(3, args.steps // 2)) / max(3, args.steps // 2)
+    eval_fused.set_eval_fused(True)
+    run(args.warmup)
+    with _NoCollectorPauses():
+        elapsed = timed(args.steps)
+    rows = None
+    if not args.no_kernel_timing and rank == 0:
+        timer = _ext.KernelTimer(main.cuda_stream)
+        _ext.TIMER = timer
+        run(2)
+        _ext.TIMER = None
+        rows = kernel_table(timer.summary(), 2)
+        for r in rows:
+            if r["kernel"].startswith("pn2_sa_eval_x3"):      # priced against what six bf16 products per product allow
+                r["mfma_peak_TFLOPps"] = round(X3_PEAK_TFLOPS, 1)
+                r["bound"] = "mfma"
+                r["frac"] = round(r["TFLOPps"] / X3_PEAK_TFLOPS, 5)
+    eval_fused.set_eval_fused(prev)
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": f"OR {unit_name}/sec forward, eval mode" + ("" if sgp else f" ({args.points // 1000}k pts, batch {args.batch})"),
+            "value": round(units * world * args.steps / elapsed, 3), "unit": f"{unit_name}/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32x3", "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE configs[2] shape, inference: SGPNModelWrapper.eval() on synthetic scans (9 objects x 4000 pts + "
+                             f"72 pairs x 8000 pts), {units} scan(s) per step" if sgp else
+                             f"BASELINE configs[1] shape, inference: {args.batch} scenes/GPU x {args.points} pts x (3 xyz + 3 rgb), "
+                             + ("Pointnet2Backbone" if args.workload == "backbone" else "MSG object encoder (PointNetfeat)")
+                             + ".eval() forward under no_grad"),
+                "arithmetic": "SA levels: split-bf16 (f32x3) product, fp32 accumulation, fp32-grade error (1e-6 against the oracle, "
+                              "tests/test_gpu_round6.py); sampling / grouping geometry and FP levels: fp32",
+                "global_batch": units * world, "parallelism": f"dp{world}",
+                "geometry_pipeline": "off: geometry inside the step" if side is None else
+                "on: FPS / ball-query / 3-NN of batch i+1 on a side stream during forward i (one geometry per timed step)",
+                "host_affinity": affinity,
+                "layer_by_layer_exact_fp32_ms_per_step": round(layers_s * 1e3, 3),
+                "layer_by_layer_exact_fp32_per_s": round(units * world / layers_s, 1),
+            },
+        }
+        if rows is not None:
+            out["kernels"] = rows
+            main_rows = [r for r in rows if not r["kernel"].endswith("@side")]
+            out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
+            top = next((r for r in main_rows if r["kernel"].startswith("pn2_sa_eval_x3")), main_rows[0] if main_rows else None)
+            if top is not None:
+                out["roofline"] = roofline_of(top, False)
+                out["roofline"]["note"] = ("pn2_sa_eval_x3 aggregated over the step's launches; peak = dense bf16 MFMA / 6 (the f32x3 "
+                                           "product issues six bf16 matrix instructions per fp32-grade product)")
+        emit_json(out, args)
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -625,6 +762,10 @@ def main():
     ap.add_argument("--graphs", action="store_true",
                     help="sgp workload: replay the whole step as one hipGraph (runtime.GraphedTrainStep); gradients are "
                          "averaged with one flat all-reduce between the backward and the optimizer graph when N > 1")
+    ap.add_argument("--forward-eval", action="store_true",
+                    help="inference instead of training: model.eval() forward under no_grad (running-statistic BatchNorm), every "
+                         "SA scale as ONE kernel (pn2_sa_eval_x3: gather -> folded-BatchNorm MLP chain in registers on the bf16 matrix "
+                         "cores, f32x3 split product -> max); reports scenes/s forward, the layer-by-layer route beside it")
     ap.add_argument("--no-geometry-pipeline", dest="geometry_pipeline", action="store_false",
                     help="run the sampling/grouping geometry inside the step on the main stream instead of prefetching "
                          "the NEXT batch's geometry on a side stream during the step (25.0 vs 20.7 ms/step on MI355X)")
@@ -656,6 +797,8 @@ def main():
     from pointnet2_ops import _ext, fused_mlp
     fused_mlp.set_mlp_dtype(args.dtype)
 
+    if args.forward_eval:
+        return bench_forward_eval(args, device, rank, world, distributed, _ext)
     if args.workload == "sgp":
         return bench_sgp(args, device, rank, world, distributed, _ext)
 
