@@ -7,6 +7,7 @@ same parameter names."""
 import contextlib
 
 import torch
+from typing import Optional
 import torch.nn as nn
 
 from pointnet2_ops import pointnet2_utils
@@ -40,8 +41,15 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].contiguous().transpose(1, 2) if pc.size(-1) > 3 else None
         return xyz, features
 
+    def precompute_geometry(self, pointcloud: torch.Tensor, inference: Optional[bool] = None):
+        """`inference` (default: eval mode AND the caller records no gradient): the geometry will feed a forward without a
+        backward — no inverse neighbourhood indices, no pre-grouped rows (see _precompute_geometry)."""
+        if inference is None:
+            inference = not self.training and not torch.is_grad_enabled()
+        return self._precompute_geometry(pointcloud, bool(inference))
+
     @torch.no_grad()
-    def precompute_geometry(self, pointcloud: torch.Tensor):
+    def _precompute_geometry(self, pointcloud: torch.Tensor, infer: bool):
         """Everything in the forward that depends on the coordinates only — the FPS chain, the sampled
         centres, the ball-query neighbourhoods and the 3-NN interpolation weights of the FP levels.
         No parameters are involved, so a training pipeline can run this for batch i+1 on a side stream
@@ -61,7 +69,6 @@ class Pointnet2Backbone(nn.Module):
         # inference (eval mode, no gradient recorded): no backward will ask for the inverse neighbourhood indices, and the
         # one-kernel SA levels (pointnet2_ops/eval_fused.py) gather their own rows from idx — the query kernel need not emit
         # level 1's grouped rows (117 MB at the headline shape); the forward is short, so the sampling gets the faster shape
-        infer = not self.training and not torch.is_grad_enabled()
         with (bg(fewest=fused_mlp.mlp_dtype() == torch.float32 and not infer) if bg is not None else contextlib.nullcontext()):
             feats0 = (pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 and not pointcloud.requires_grad else None)
             geo["feats_rows"] = feats0

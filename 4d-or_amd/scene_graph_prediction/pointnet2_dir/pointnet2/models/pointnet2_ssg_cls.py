@@ -44,9 +44,15 @@ class PointNet2ClassificationSSG(nn.Module):
         # the first level groups the INPUT features (colours / instance mask: data, no gradient): its grouped rows can be
         # emitted by the ball query itself (pn2_ball_query_group), ahead of the step like the rest of the geometry
         feats0 = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 and not pointcloud.requires_grad else None
+        # inference (eval mode, no gradient recorded): no backward will need the inverse neighbourhood indices, and the
+        # one-kernel SA levels (pointnet2_ops/eval_fused.py) gather their own rows from idx
+        from pointnet2_ops import eval_fused
+        infer = not self.training and not torch.is_grad_enabled()
+        if infer and eval_fused.eval_fused_enabled():
+            feats0 = None
         geo = []
         for k, sa in enumerate(self.SA_modules):
-            g = sa.sample_and_query(xyz, inverse_index=k > 0, feats_rows=feats0 if k == 0 else None)
+            g = sa.sample_and_query(xyz, inverse_index=k > 0 and not infer, feats_rows=feats0 if k == 0 else None)
             if g.get("rows_src") is not None:
                 g["rows_src"] = rows_source(pointcloud)         # (the rows come from THIS cloud's feature columns)
             geo.append(g)
