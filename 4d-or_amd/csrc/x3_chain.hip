@@ -19,6 +19,7 @@
 //   The weights of the middle and last layer stream through a 2-slot LDS ring (24 KB slots = 8 (chunk, tile) units) filled
 //   by global_load_lds (direct global -> LDS, no registers) one step ahead; one barrier per step.
 #include "pn2_common.h"
+#include "mlp_common.h"
 #include "x3_common.h"
 
 namespace {
@@ -34,20 +35,40 @@ struct EvalArgs {
   const float *bias_mid;  // (c_mid)
   const float *bias_fin;  // (c_out)
   float *out;             // (B m, ldo), columns [0, c_out)
-  long long Mrows;        // B m ns
+  long long Mrows;        // B m ns  (IN_ROWS: rows of X)
   long long ncentres;     // B m
   int N, m, ns_shift, C, c_out, ldo, steps_fin, spp;
+  // IN_ROWS (training GEMM, pn2_x3_gemm): A = pro(X) rows [Mrows][16 KA]
+  const float *X, *X2;    // PRO_GY: X = g, X2 = y
+  const float *p0, *p1, *p2;
+  // epilogues of the training GEMM
+  float *Y;               // EPI_STATS / EPI_MASK: [Mrows][c_out]
+  double *stats;          // [2][c_out] (ACCUMULATES)
+  const float *Yprev;     // EPI_MASK: [Mrows][c_out]
+  const float *e_fin;     // EPI_MASK: [4][c_out] mean | rstd | scale | shift
+  float *pmax;            // EPI_POOL: [Mrows / psz][c_out]
+  int *parg;
+  const float *sgn;       // EPI_POOL: [c_out] or NULL
 };
+
+enum { X3_IN_SMALL = 0, X3_IN_LIFT = 1, X3_IN_ROWS = 2 };
+enum { X3_EPI_MAX = 0, X3_EPI_STATS = 1, X3_EPI_MASK = 2, X3_EPI_POOL = 3 };
+enum { X3_PRO_NONE = 0, X3_PRO_BNRELU = 1, X3_PRO_GY = 2 };
 
 constexpr int kRing = 2;
 
 // WAVES = waves per workgroup (each owns 32 rows of a pass of 32 WAVES rows).  Two workgroups share a CU (2 x 55 KB of LDS)
 // and run out of phase: one's gather / split phases under the other's matrix phases.  16 waves per CU at <= 128 registers
 // (IN_SMALL instances, WAVES = 8), 8 waves at <= 256 (IN_LIFT: 96 registers of operand fragments per layer, WAVES = 4).
-template <int IN, int KA, int KB, int WAVES>      // KA = c1 / 16; KB = c_mid / 16 (0: no middle layer)
+// IN_ROWS turns the same kernel into the TRAINING GEMM of a shared-MLP layer (pn2_x3_gemm): the input stage reads plain rows
+// X [M][K] with the prologue of pn2_mlp_gemm applied before the split, there is no middle layer, and the last layer's
+// epilogue is one of pn2_mlp_gemm's: store + column sums (EPI_STATS), ReLU mask + BatchNorm-backward sums (EPI_MASK), or
+// group maxima + arg-max without a store (EPI_POOL = pn2_mlp_gemm_pool).
+template <int IN, int KA, int KB, int WAVES, int PRO = 0, int EPI = 0>      // KA = c1 / 16; KB = c_mid / 16 (0: no middle layer)
 __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const EvalArgs a) {
   constexpr int THREADS = 64 * WAVES, PASS = 32 * WAVES;
-  constexpr bool SMALL = IN == 0;
+  constexpr bool SMALL = IN == X3_IN_SMALL, ROWS = IN == X3_IN_ROWS;
+  constexpr bool SUMS = EPI != X3_EPI_MAX;
   constexpr int KF = KB ? KB : KA;                      // chunks of the last layer's input
   constexpr int TPS_MID = kX3SlotUnits / KA;            // tiles per ring slot
   constexpr int TPS_FIN = kX3SlotUnits / KF;
@@ -58,6 +79,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
   unsigned char *w0s = lds + kRing * kX3SlotBytes;
   float *bmid = reinterpret_cast<float *>(w0s + W0_BYTES);     // permuted: [(tile, half)][16]
   float *bfin = bmid + (KB ? KB * 16 : 16);
+  float *prm = bfin + (ROWS ? 0 : a.c_out);                    // IN_ROWS: [3][16 KA] prologue constants (no bias table then)
+  float *csum = prm + (ROWS ? 3 * 16 * KA : 0);                // EPI with sums: [2][c_out] fp32 partial column sums of this workgroup
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
   const long long npass = (a.Mrows + PASS - 1) / PASS;
@@ -72,7 +95,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
       const int r = i & 15, hh = (i >> 4) & 1, T = i >> 5;
       bmid[i] = a.bias_mid[32 * T + (r & 3) + 8 * (r >> 2) + 4 * hh];
     }
-  for (int i = tid; i < a.c_out; i += THREADS) bfin[i] = a.bias_fin[i];
+  if (!ROWS)
+    for (int i = tid; i < a.c_out; i += THREADS) bfin[i] = a.bias_fin[i];
+  if (ROWS && PRO != X3_PRO_NONE)
+    for (int i = tid; i < 16 * KA; i += THREADS) {
+      prm[i] = a.p0[i];
+      prm[16 * KA + i] = a.p1[i];
+      prm[32 * KA + i] = PRO == X3_PRO_GY ? a.p2[i] : 0.f;
+    }
+  if (SUMS)
+    for (int i = tid; i < 2 * a.c_out; i += THREADS) csum[i] = 0.f;
 
   // weight stream: global step g reads slot (g mod spp) of the stream into ring slot (g mod 2), one step ahead
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -108,7 +140,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
   // neighbourhood index of this lane's row, loaded one pass ahead (the gathers depend on it: one L2 round trip less per pass)
   auto load_idx = [&](long long pi) {
     const long long row = ((long long)blockIdx.x + pi * gridDim.x) * PASS + wave * 32 + l32;
-    return (pi < my_passes && row < a.Mrows) ? a.idx[row] : 0;
+    return (!ROWS && pi < my_passes && row < a.Mrows) ? a.idx[row] : 0;
   };
   int p_next = load_idx(0);
   x3_frag actA[KA];
@@ -145,7 +177,51 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
         b = (int)(centre / a.m);
       }
       const size_t pt = (size_t)b * a.N + p;
-      if (SMALL) {
+      if (ROWS) {
+        // plain rows with pn2_mlp_gemm's prologue: PRO_BNRELU relu(x p0[k] + p1[k]) = ReLU(BatchNorm(y_{l-1})),
+        // PRO_GY p0[k] g + p1[k] y + p2[k] = dL/dy_l from dL/dz_l; rows past M stay zero (they must not reach the sums)
+        // (straight-line loads from a clamped row: a branch around them would collect every chunk's loads in one block)
+        const long long rsafe = valid ? row : a.Mrows - 1;
+        const float *xr = a.X + (size_t)rsafe * (16 * KA) + 8 * h;
+        const float *yr = PRO == X3_PRO_GY ? a.X2 + (size_t)rsafe * (16 * KA) + 8 * h : xr;
+#pragma unroll
+        for (int c = 0; c < KA; ++c) {
+          float4 x0 = *reinterpret_cast<const float4 *>(xr + 16 * c);
+          float4 x1 = *reinterpret_cast<const float4 *>(xr + 16 * c + 4);
+          float4 y0 = x0, y1 = x1;
+          if (PRO == X3_PRO_GY) {
+            y0 = *reinterpret_cast<const float4 *>(yr + 16 * c);
+            y1 = *reinterpret_cast<const float4 *>(yr + 16 * c + 4);
+          }
+          float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+          if (PRO == X3_PRO_NONE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = valid ? v[i] : 0.f;
+          }
+          if (PRO != X3_PRO_NONE) {
+            const float4 *q0 = reinterpret_cast<const float4 *>(prm + 16 * c + 8 * h);
+            const float4 *q1 = reinterpret_cast<const float4 *>(prm + 16 * KA + 16 * c + 8 * h);
+            const float4 *q2 = reinterpret_cast<const float4 *>(prm + 32 * KA + 16 * c + 8 * h);
+            const float4 a0 = q0[0], a1 = q0[1], b0 = q1[0], b1 = q1[1];
+            const float s0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float s1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            if (PRO == X3_PRO_BNRELU) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] = valid ? fmaxf(__fmaf_rn(v[i], s0[i], s1[i]), 0.f) : 0.f;
+            } else {
+              const float4 c0 = q2[0], c1 = q2[1];
+              const float s2[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+              const float w[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] = valid ? __fmaf_rn(s0[i], v[i], __fmaf_rn(s1[i], w[i], s2[i])) : 0.f;
+            }
+          }
+          x3_split8(v, actA[c]);
+          // PRO_GY reads two matrices: all of a 128-wide row's loads in flight at once (128 registers) next to the 96 of the
+          // fragments spills; in halves it fits
+          if (PRO == X3_PRO_GY && KA == 8 && c == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (SMALL) {
         const int K0 = 3 + a.C;                           // bias column
         const float *fx = a.xyz + pt * 3, *cx = a.new_xyz + (size_t)centre * 3, *ff = a.feats + pt * a.C;
         float v[8];
@@ -228,10 +304,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
 #pragma unroll
       for (int tl = 0; tl < TPS_FIN; ++tl) {
         const int t = jf * TPS_FIN + tl;
-        const float bv = bfin[32 * t + l32];
+        const float bv = ROWS ? 0.f : bfin[32 * t + l32];
         x3_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bv;
+        // EPI_MASK: the previous layer's raw output at this tile's positions and its BatchNorm constants, ahead of the matrix loop
+        float yp[EPI == X3_EPI_MASK ? 16 : 1];
+        float es = 0.f, eh = 0.f, em = 0.f, er = 0.f;
+        if (EPI == X3_EPI_MASK) {
+          const int col = 32 * t + l32;
+          em = a.e_fin[col]; er = a.e_fin[a.c_out + col]; es = a.e_fin[2 * a.c_out + col]; eh = a.e_fin[3 * a.c_out + col];
+          // buffer loads: wave-uniform base (the wave's first row) and row offsets, one lane-constant column offset; rows past M
+          // are out of range and read 0
+          const long long left = a.Mrows - row0;
+          const rsrc_t rsp = make_rsrc(a.Yprev + (size_t)(left > 0 ? row0 : 0) * a.c_out, (left > 0 ? left : 1) * a.c_out * 4);
+          const int voff = left > 0 ? (4 * h * a.c_out + col) * 4 : kOobOffset;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yp[EPI == X3_EPI_MASK ? r : 0] = bload(rsp, voff, ((r & 3) + 8 * (r >> 2)) * a.c_out * 4);
+        }
         x3_frag wq[2];
         wq[0] = load_w(sb, tl * KF);
         __builtin_amdgcn_sched_barrier(0);
@@ -242,6 +332,88 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
           else x3_mma(actA[c < KA ? c : 0], wq[c & 1], acc);
           __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
+        if (EPI == X3_EPI_STATS || EPI == X3_EPI_MASK) {
+          // lane = column 32 t + l32, register r = row 4h + (r & 3) + 8 (r >> 2) of the wave's 32: one 128-byte row segment per
+          // half-wave and register; column sums over the lane's 16 rows, the other half's added, one LDS atomic per column
+          const int col = 32 * t + l32;
+          float s1 = 0.f, s2 = 0.f;
+          const long long left = a.Mrows - row0;
+          const rsrc_t rsy = make_rsrc(a.Y + (size_t)(left > 0 ? row0 : 0) * a.c_out, (left > 0 ? left : 1) * a.c_out * 4);
+          const int voff = left > 0 ? (4 * h * a.c_out + col) * 4 : kOobOffset;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+            if (EPI == X3_EPI_MASK) {
+              const float y = yp[EPI == X3_EPI_MASK ? r : 0];
+              v = (__fmaf_rn(y, es, eh) > 0.f) ? v : 0.f;
+              s1 += v;
+              s2 = __fmaf_rn(v, (y - em) * er, s2);
+            } else {
+              s1 += v;
+              s2 = __fmaf_rn(v, v, s2);
+            }
+            bstore(v, rsy, voff, ((r & 3) + 8 * (r >> 2)) * a.c_out * 4);     // rows past M: out of range, dropped
+          }
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (h == 0 && a.stats) {
+            atomicAdd(&csum[col], s1);
+            atomicAdd(&csum[a.c_out + col], s2);
+          }
+          continue;
+        }
+        if (EPI == X3_EPI_POOL) {
+          // pn2_mlp_gemm_pool's epilogue: column sums, and per partial group of psz = min(ns, 32) rows the maximum of every
+          // column with its row inside the partial group (first one among equals); nothing of the output is stored
+          const int col = 32 * t + l32;
+          float s1 = 0.f, s2 = 0.f, bst[2];
+          int bi[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            bst[q] = acc[8 * q];
+            bi[q] = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const float v = acc[8 * q + r];
+              if (r > 0 && v > bst[q]) { bst[q] = v; bi[q] = r; }
+              s1 += v;
+              s2 = __fmaf_rn(v, v, s2);
+            }
+          }
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (h == 0 && a.stats) {
+            atomicAdd(&csum[col], s1);
+            atomicAdd(&csum[a.c_out + col], s2);
+          }
+          float b2[2];
+          int rw[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {                    // rows of the two halves interleave in blocks of four
+            const int row = (bi[q] & 3) + 8 * (bi[q] >> 2) + 4 * h;       // row inside the 16-row sub-group + 8 q .. (r = 8 q + bi)
+            const float ob = __shfl_xor(bst[q], 32);
+            const int orow = __shfl_xor(row, 32);
+            const bool take = ob > bst[q] || (ob == bst[q] && orow < row);
+            b2[q] = take ? ob : bst[q];
+            rw[q] = take ? orow : row;
+          }
+          const long long npart = a.Mrows >> (a.ns_shift == 4 ? 4 : 5);
+          if (a.ns_shift == 4) {
+            const long long part = (row0 >> 4) + h;
+            if (part < npart) {
+              a.pmax[(size_t)part * a.c_out + col] = h ? b2[1] : b2[0];
+              a.parg[(size_t)part * a.c_out + col] = h ? rw[1] : rw[0];
+            }
+          } else if (h == 0) {
+            const long long part = row0 >> 5;
+            const bool second = b2[1] > b2[0];
+            if (part < npart) {
+              a.pmax[(size_t)part * a.c_out + col] = second ? b2[1] : b2[0];
+              a.parg[(size_t)part * a.c_out + col] = second ? 16 + rw[1] : rw[0];
+            }
+          }
+          continue;
         }
         // lane = channel 32 t + l32; registers 0-7: rows 0-15 of the wave's 32 (this half's share), 8-15: rows 16-31
         float m0 = acc[0], m1 = acc[8];
@@ -267,6 +439,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
       slot = slot + 1 == kRing ? 0 : slot + 1;
     }
   }
+  if (SUMS && a.stats) {
+    // (the last step_barrier made every wave's LDS atomics visible)
+    for (int i = tid; i < a.c_out; i += THREADS) {
+      const float sg = (EPI == X3_EPI_POOL && a.sgn) ? a.sgn[i] : 1.f;
+      atomicAdd(a.stats + i, (double)(csum[i] * sg));
+      atomicAdd(a.stats + a.c_out + i, (double)csum[a.c_out + i]);
+    }
+  }
 }
 
 // W [N][ldw] fp32 (columns [0, K) used) -> (N / 32) (K / 16) units, unit (t, c) at index t (K / 16) + c:
@@ -288,16 +468,17 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(int N, int K, int ldw, int
   }
 }
 
-template <int IN, int KA, int KB, int WAVES>
+template <int IN, int KA, int KB, int WAVES, int PRO = 0, int EPI = 0>
 int launch_eval(const EvalArgs &a, hipStream_t stream) {
   constexpr int W0_BYTES = IN == 0 ? (KA / 2) * kX3UnitBytes : 0;
-  const size_t lds = (size_t)kRing * kX3SlotBytes + W0_BYTES + ((KB ? KB * 16 : 16) + a.c_out) * sizeof(float);
-  static const bool ok = hipFuncSetAttribute((const void *)sa_eval_kernel<IN, KA, KB, WAVES>,
+  const size_t lds = (size_t)kRing * kX3SlotBytes + W0_BYTES +
+                     ((KB ? KB * 16 : 16) + (IN == X3_IN_ROWS ? 3 * 16 * KA : a.c_out) + (EPI != X3_EPI_MAX ? 2 * a.c_out : 0)) * sizeof(float);
+  static const bool ok = hipFuncSetAttribute((const void *)sa_eval_kernel<IN, KA, KB, WAVES, PRO, EPI>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
   if (!ok || lds > 80 * 1024) return PN2_ELAUNCH;
   const long long npass = (a.Mrows + 32 * WAVES - 1) / (32 * WAVES);
   const unsigned grid = (unsigned)(npass < 512 ? npass : 512);         // two workgroups per CU
-  hipLaunchKernelGGL((sa_eval_kernel<IN, KA, KB, WAVES>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
+  hipLaunchKernelGGL((sa_eval_kernel<IN, KA, KB, WAVES, PRO, EPI>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
   return pn2_check_launch();
 }
 
@@ -367,4 +548,51 @@ extern "C" int pn2_sa_eval_x3(int mode, int B, int N, int m, int ns, int C, cons
   if (mode == 0) return launch_eval<0, 4, 0, 8>(a, st);
   if (c_mid == 128) return launch_eval<1, 8, 8, 4>(a, st);
   return launch_eval<1, 8, 0, 4>(a, st);
+}
+
+// ---------------------------------------------------------------------------------------------- training GEMM on the f32x3 product
+// Y[M][N] = pro(X)[M][K] W[N][K]^T with pn2_mlp_gemm's prologues / epilogues (and pn2_mlp_gemm_pool's as epi 3), W given as
+// the fragments of pn2_x3_pack_weight(N, K, perm 0).  K in {64, 128}, N a multiple of 32 that fills whole ring slots.
+extern "C" int pn2_x3_gemm_supported(int K, int N, int pro, int epi, int ns) {
+  if (K != 64 && K != 128) return 0;
+  if (N <= 0 || (N & 31) || ((N / 32) * (K / 16)) % kX3SlotUnits != 0 || N > 4096) return 0;
+  const bool combo = (pro == X3_PRO_BNRELU && (epi == X3_EPI_STATS || epi == X3_EPI_POOL)) || (pro == X3_PRO_GY && epi == X3_EPI_MASK) ||
+                     (pro == X3_PRO_NONE && epi == X3_EPI_STATS);
+  if (!combo) return 0;
+  if (epi == X3_EPI_POOL && (ns < 16 || (ns & (ns - 1)) != 0)) return 0;
+  return 1;
+}
+
+extern "C" int pn2_x3_gemm(long long M, int K, int N, int pro, int epi, const float *X, const float *X2, const float *p0,
+                           const float *p1, const float *p2, const void *wfrags, float *Y, double *stats, const float *Yprev,
+                           const float *e_fin, float *pmax, int *parg, const float *sgn, int ns, void *stream) {
+  if (M < 0 || !pn2_x3_gemm_supported(K, N, pro, epi, ns)) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!X || !wfrags || (pro != X3_PRO_NONE && (!p0 || !p1)) || (pro == X3_PRO_GY && (!X2 || !p2)) ||
+      (epi != X3_EPI_POOL && !Y) || (epi == X3_EPI_MASK && (!Yprev || !e_fin)) || (epi == X3_EPI_POOL && (!pmax || !parg)))
+    return PN2_ENULL;
+  if (epi == X3_EPI_POOL && M % (ns < 32 ? ns : 32) != 0) return PN2_EINVAL;
+  EvalArgs a{};
+  a.X = X; a.X2 = X2; a.p0 = p0; a.p1 = p1; a.p2 = p2;
+  a.wstream = (const unsigned char *)wfrags;
+  a.Y = Y; a.stats = stats; a.Yprev = Yprev; a.e_fin = e_fin; a.pmax = pmax; a.parg = parg; a.sgn = sgn;
+  a.Mrows = M; a.c_out = N;
+  int sh = 0;
+  while ((1 << sh) < ns) ++sh;
+  a.ns_shift = epi == X3_EPI_POOL ? sh : 5;
+  a.steps_fin = (N / 32) * (K / 16) / kX3SlotUnits;
+  a.spp = a.steps_fin;
+  hipStream_t st = (hipStream_t)stream;
+#define PN2_X3G(KA_, PRO_, EPI_) return launch_eval<X3_IN_ROWS, KA_, 0, 4, PRO_, EPI_>(a, st)
+  if (K == 64) {
+    if (pro == X3_PRO_BNRELU && epi == X3_EPI_STATS) PN2_X3G(4, X3_PRO_BNRELU, X3_EPI_STATS);
+    if (pro == X3_PRO_BNRELU && epi == X3_EPI_POOL) PN2_X3G(4, X3_PRO_BNRELU, X3_EPI_POOL);
+    if (pro == X3_PRO_GY) PN2_X3G(4, X3_PRO_GY, X3_EPI_MASK);
+    PN2_X3G(4, X3_PRO_NONE, X3_EPI_STATS);
+  }
+  if (pro == X3_PRO_BNRELU && epi == X3_EPI_STATS) PN2_X3G(8, X3_PRO_BNRELU, X3_EPI_STATS);
+  if (pro == X3_PRO_BNRELU && epi == X3_EPI_POOL) PN2_X3G(8, X3_PRO_BNRELU, X3_EPI_POOL);
+  if (pro == X3_PRO_GY) PN2_X3G(8, X3_PRO_GY, X3_EPI_MASK);
+  PN2_X3G(8, X3_PRO_NONE, X3_EPI_STATS);
+#undef PN2_X3G
 }

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "pn2_bn_running_update": [_c_int, _c_int, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
     "pn2_x3_pack_weight": [_c_int] * 4 + [_c_vp] * 3,
+    "pn2_x3_gemm": [ctypes.c_longlong] + [_c_int] * 4 + [_c_vp] * 13 + [_c_int, _c_vp],
     "pn2_sa_eval_x3": [_c_int] * 6 + [_c_vp] * 5 + [_c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp],
     "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_lift_rows": [_c_int] * 6 + [_c_f32] + [_c_vp] * 8,
@@ -251,6 +252,8 @@ _lib.pn2_x3_weight_bytes.argtypes = [_c_int, _c_int]
 _lib.pn2_x3_weight_bytes.restype = _c_sz
 _lib.pn2_sa_eval_x3_supported.argtypes = [_c_int] * 6
 _lib.pn2_sa_eval_x3_supported.restype = _c_int
+_lib.pn2_x3_gemm_supported.argtypes = [_c_int] * 5
+_lib.pn2_x3_gemm_supported.restype = _c_int
 _lib.pn2_abi_version.restype = _c_int
 _lib.pn2_last_hip_error.restype = _c_int
 _lib.pn2_strerror.argtypes = [_c_int]
@@ -272,7 +275,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
                                                "pn2_mlp_bwd_bf16_supported", "pn2_pool_bwd_supported",
-                                               "pn2_pool_bwd_workspace_bytes", "pn2_x3_weight_bytes", "pn2_sa_eval_x3_supported",
+                                               "pn2_pool_bwd_workspace_bytes", "pn2_x3_weight_bytes", "pn2_sa_eval_x3_supported", "pn2_x3_gemm_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
 HAS_ROWS = True
@@ -905,6 +908,47 @@ def sa_eval_x3(mode, xyz, new_xyz, idx, feats, Q, c1, w0_frags, c_mid, wstream, 
     return out
 
 
+#: route the shared-MLP GEMMs of the fp32 node through the split-bf16 product where it covers the shape (csrc/x3_chain.hip):
+#: opt-in arithmetic "f32x3" (fused_mlp.set_x3 / bench.py --dtype f32x3 / PN2_X3=1); the exact fp32 MFMA kernels are the default
+X3_GEMM = os.environ.get("PN2_X3") == "1"
+#: ... from this many rows on (below, the exact kernels' launch is as fast and saves the weight packing)
+X3_MIN_ROWS = int(os.environ.get("PN2_X3_MIN_ROWS", "16384"))
+#: ... the input-gradient form (pro 2, epi 2) too.  Off by default: at the shapes it covers (K = N = 128) that GEMM moves four
+#: (M, 128) tensors and is HBM-bound in both arithmetics — measured 0.442 ms exact vs 0.480 ms f32x3 at M = 1M
+#: (profiles/r06_x3_gemm.jsonl); PN2_X3_DGRAD=1 routes it as well (the whole-suite run with the route forced does).
+X3_DGRAD = os.environ.get("PN2_X3_DGRAD") == "1"
+
+
+def x3_gemm_supported(K, N, pro, epi, ns=0):
+    return bool(_lib.pn2_x3_gemm_supported(int(K), int(N), int(pro), int(epi), int(ns)))
+
+
+def x3_gemm(X, W, pro, epi, X2=None, p=None, stats=None, Yprev=None, e_fin=None, sgn=None, ns=0, M=None):
+    """pn2_x3_gemm: Y (M, N) [epi 1, 2] or (pmax, parg) [epi 3] of pro(X) @ W^T on the split-bf16 product; arguments as
+    mlp_gemm / mlp_gemm_pool."""
+    _f32(W, "W"); _f32(X, "X")
+    N, K = W.shape
+    M = int(M if M is not None else X.size(0))
+    frags = x3_pack_weight(W.contiguous(), perm=False)
+    p0 = p1 = p2 = None
+    if p is not None:
+        p0, p1 = p[0], p[1]
+        p2 = p[2] if len(p) > 2 else None
+    Y = pmax = parg = None
+    if epi == 3:
+        psz = min(int(ns), 32)
+        pmax = torch.empty(M // psz, N, dtype=torch.float32, device=X.device)
+        parg = torch.empty(M // psz, N, dtype=torch.int32, device=X.device)
+    else:
+        Y = torch.empty(M, N, dtype=torch.float32, device=X.device)
+    nbytes = 4 * (M * K * (2 if pro == PRO_GY else 1) + N * K) + (8 * (M // min(int(ns) or 32, 32)) * N if epi == 3 else
+                                                                   4 * M * N * (2 if epi == 2 else 1))
+    _call("pn2_x3_gemm", X, M, K, N, int(pro), int(epi), _ptr(X), _ptr(X2), _ptr(p0), _ptr(p1), _ptr(p2), _ptr(frags), _ptr(Y),
+          _ptr(stats), _ptr(Yprev), _ptr(e_fin), _ptr(pmax), _ptr(parg), _ptr(sgn), int(ns), alg_bytes=nbytes,
+          alg_flops=2 * M * N * K, tag=(f"M{M},K{K},N{N},pro{int(pro)},epi{int(epi)}" if DETAIL_TAGS else None))
+    return (pmax, parg) if epi == 3 else Y
+
+
 def group_lift_stats(Pq, Q, idx, N, stats):
     """stats (2, N0) f64 += column sums of y0 = Pq[idx] - Q and y0^2; returns gidx (B m ns) int32 = b N + idx, the row of Pq
     every grouped row reads.  Nothing of y0 is stored."""
@@ -1388,6 +1432,11 @@ def mlp_gemm(X, W, pro=PRO_NONE, epi=EPI_NONE, X2=None, p=None, arg=None, gP=Non
     N, K = W.shape
     ref = X if X is not None else X2
     M = int(M if M is not None else ref.size(0))
+    if X3_GEMM and X is not None and arg is None and M >= X3_MIN_ROWS and (epi != EPI_NONE or stats is None):
+        # f32x3: epi 0 (no reductions) is epi 1 without a statistics buffer
+        xepi = 1 if epi == EPI_NONE else int(epi)
+        if (pro != PRO_GY or X3_DGRAD) and x3_gemm_supported(K, N, pro, xepi):
+            return x3_gemm(X, W, int(pro), xepi, X2=X2, p=p, stats=stats, Yprev=Yprev, e_fin=e_fin, M=M)
     Y = torch.empty(M, N, dtype=torch.float32, device=W.device)
     p0 = p1 = p2 = None
     if p is not None:
@@ -1713,6 +1762,8 @@ def mlp_gemm_pool(X, Wf, sgn, ns, p=None, stats=None):
     _f32(X, "X"); _f32(Wf, "Wf")
     N, K = Wf.shape
     M = X.size(0)
+    if X3_GEMM and p is not None and M >= X3_MIN_ROWS and x3_gemm_supported(K, N, PRO_BNRELU, 3, ns):
+        return x3_gemm(X, Wf, PRO_BNRELU, 3, p=p, stats=stats, sgn=sgn, ns=ns)
     psz = min(int(ns), 32)
     pmax = torch.empty(M // psz, N, dtype=torch.float32, device=X.device)
     parg = torch.empty(M // psz, N, dtype=torch.int32, device=X.device)

@@ -107,6 +107,16 @@ def mlp_dtype() -> torch.dtype:
     return _MLP_DTYPE
 
 
+def set_x3(enabled: bool) -> bool:
+    """Opt-in arithmetic "f32x3" of the fp32 node: the shared-MLP GEMMs the split-bf16 product covers (K in {64, 128}: hidden
+    layers, input gradients, pooled last layers of the SA stacks) run on the bf16 matrix cores as hi/mid/lo pieces with six
+    partial products and fp32 accumulation (csrc/x3_common.h) — fp32-grade error (tests/test_gpu_round6.py), not the exact
+    fp32 MFMA arithmetic of the default path.  Returns the previous setting.  (PN2_X3=1 switches it on at import.)"""
+    e = _ext()
+    prev, e.X3_GEMM = bool(getattr(e, "X3_GEMM", False)), bool(enabled)
+    return prev
+
+
 def _bf16_ok(layers, ns) -> bool:
     """Shapes the bf16 kernels cover (csrc/mlp_bf16.hip): output widths that are multiples of 8 (16-byte bf16 row
     groups) up to 320, any input width."""

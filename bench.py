@@ -747,9 +747,11 @@ def main():
     ap.add_argument("--with-prep", action="store_true",
                     help="sgp workload: include the GPU data preparation (object / pair crops of 300k-point fused scans, "
                          "re-sampling, zero_mean) of every step's scans in the timed region")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3"], default="f32",
                     help="arithmetic of the shared-MLP stacks: f32 = exact fp32 MFMA (the headline / parity path); bf16 = the "
-                         "counterpart of the reference's 16-bit AMP (bf16 activations and MFMA, fp32 weights and statistics)")
+                         "counterpart of the reference's 16-bit AMP (bf16 activations and MFMA, fp32 weights and statistics); "
+                         "f32x3 = fp32 tensors, the GEMMs the split-bf16 product covers on the bf16 matrix cores as hi/mid/lo "
+                         "pieces (fp32-grade error, NOT the exact fp32 arithmetic: reported under its own dtype label)")
     ap.add_argument("--scans-per-step", type=int, default=1,
                     help="sgp workload: scans per step and rank, collated block-diagonally (BASELINE configs[2] names 32)")
     ap.add_argument("--whole-batch-statistics", action="store_true",
@@ -795,7 +797,8 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     from pointnet2_ops import _ext, fused_mlp
-    fused_mlp.set_mlp_dtype(args.dtype)
+    fused_mlp.set_mlp_dtype("f32" if args.dtype == "f32x3" else args.dtype)
+    fused_mlp.set_x3(args.dtype == "f32x3")
 
     if args.forward_eval:
         return bench_forward_eval(args, device, rank, world, distributed, _ext)

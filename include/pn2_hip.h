@@ -874,6 +874,21 @@ int pn2_sa_eval_x3(int mode, int B, int N, int m, int ns, int C, const float *xy
                    const float *feats, const float *Q, int c1, const void *w0_frags, int c_mid, const void *wstream,
                    const float *bias_mid, int c_out, const float *bias_fin, float *out, int ldo, void *stream);
 
+/* The same product as the TRAINING GEMM of a shared-MLP layer (opt-in arithmetic "f32x3": bench.py --dtype f32x3, PN2_X3=1;
+ * the exact fp32 MFMA kernels stay the default).  pn2_x3_gemm = pn2_mlp_gemm / pn2_mlp_gemm_pool with W given as
+ * pn2_x3_pack_weight(N, K, perm 0) fragments:
+ *     pro 0 none | 1 relu(X p0[k] + p1[k]) | 2 p0[k] X + p1[k] X2 + p2[k]
+ *     epi 1 store Y, stats (2, N) f64 += column sums of Y, Y^2 (stats may be NULL: plain store)
+ *         2 Y *= [Yprev scale + shift > 0], stats += column sums of Y, Y (Yprev - mean) rstd      (e_fin (4, N) as pn2_mlp_gemm)
+ *         3 nothing stored: stats as epi 1 (x sgn), pmax / parg (M / min(ns, 32), N) partial maxima + rows (pn2_mlp_gemm_pool)
+ * covered: K in {64, 128}; N % 32 == 0 filling whole ring slots; (pro, epi) in {(0,1), (1,1), (1,3), (2,2)}
+ * (pn2_x3_gemm_supported).  A is read straight into registers in operand layout (each row once), split there; one wave owns
+ * 32 rows x all N columns.  Error: fp32-grade (tests/test_gpu_round6.py: <= 1e-4 against the exact kernels and the oracle). */
+int pn2_x3_gemm_supported(int K, int N, int pro, int epi, int ns);
+int pn2_x3_gemm(long long M, int K, int N, int pro, int epi, const float *X, const float *X2, const float *p0, const float *p1,
+                const float *p2, const void *wfrags, float *Y, double *stats, const float *Yprev, const float *e_fin, float *pmax,
+                int *parg, const float *sgn, int ns, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

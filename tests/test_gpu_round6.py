@@ -142,3 +142,67 @@ def test_sa_level_eval_one_kernel_matches_oracle(case, monkeypatch):
     # and the layer-by-layer HIP route agrees with the fused one at the same tolerance
     _, nf_layers = run("cuda", _ext, False)
     torch.testing.assert_close(nf, nf_layers, atol=1e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ f32x3 training GEMM
+X3_GEMM_CASES = [(40000, 64, 64), (40000, 64, 128), (33000, 128, 128), (20016, 128, 256)]     # (M, K, N); M % 32 != 0 included
+
+
+def _x3_err(a, ref64, scale):
+    return float((a.double() - ref64).abs().max() / scale)
+
+
+@pytest.mark.parametrize("M,K,N", X3_GEMM_CASES)
+def test_x3_gemm_matches_exact_kernels_and_fp64(M, K, N):
+    """pn2_x3_gemm (csrc/x3_chain.hip, IN_ROWS) against pn2_mlp_gemm / pn2_mlp_gemm_pool (exact fp32 MFMA) and a float64
+    product: forward layer (relu(bn(x)) W^T + column sums), input gradient (c1 g + c2 y + c3) Wt^T with ReLU mask and
+    BatchNorm-backward sums, pooled last layer (partial maxima + arg-max rows identical where the maxima are distinct)."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(M + K + N)
+    dev = "cuda"
+    X = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    p0, p1 = (torch.rand(K, generator=g) + 0.5).to(dev), (torch.randn(K, generator=g) * 0.3).to(dev)
+    prev = e.X3_GEMM
+    try:
+        # --- forward hidden layer: PRO_BNRELU + EPI_STATS
+        e.X3_GEMM = False
+        st0 = torch.zeros(2, N, dtype=torch.float64, device=dev)
+        Y0 = e.mlp_gemm(X, W, pro=e.PRO_BNRELU, epi=e.EPI_STATS, p=(p0, p1), stats=st0)
+        st1 = torch.zeros(2, N, dtype=torch.float64, device=dev)
+        Y1 = e.x3_gemm(X, W, e.PRO_BNRELU, 1, p=(p0, p1), stats=st1)
+        A64 = torch.relu(X.double() * p0.double() + p1.double())
+        R64 = A64 @ W.double().t()
+        scale = float((A64.abs() @ W.double().abs().t()).max())
+        err_exact, err_x3 = _x3_err(Y0, R64, scale), _x3_err(Y1, R64, scale)
+        print(f"\n[x3 gemm M{M} K{K} N{N}] fwd err / sum|x||w|: exact {err_exact:.2e}, f32x3 {err_x3:.2e}", end="")
+        assert err_x3 <= max(2.0 * err_exact, 5e-7)
+        torch.testing.assert_close(Y1, Y0, atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(st1, st0, rtol=1e-5, atol=1e-3)
+        # --- input gradient: PRO_GY + EPI_MASK
+        G = torch.randn(M, K, generator=g).to(dev)
+        Yl = torch.randn(M, K, generator=g).to(dev)
+        c = (torch.randn(3, K, generator=g) * 0.5).to(dev)
+        Yprev = torch.randn(M, N, generator=g).to(dev)
+        e_fin = torch.stack([torch.randn(N, generator=g) * 0.1, torch.rand(N, generator=g) + 0.5,
+                             torch.randn(N, generator=g), torch.randn(N, generator=g) * 0.2]).to(dev).contiguous()
+        s0 = torch.zeros(2, N, dtype=torch.float64, device=dev)
+        D0 = e.mlp_gemm(G, W, pro=e.PRO_GY, epi=e.EPI_MASK, X2=Yl, p=(c[0], c[1], c[2]), stats=s0, Yprev=Yprev, e_fin=e_fin)
+        s1 = torch.zeros(2, N, dtype=torch.float64, device=dev)
+        D1 = e.x3_gemm(G, W, e.PRO_GY, 2, X2=Yl, p=(c[0], c[1], c[2]), stats=s1, Yprev=Yprev, e_fin=e_fin)
+        torch.testing.assert_close(D1, D0, atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(s1, s0, rtol=1e-5, atol=2e-3)
+        # --- pooled last layer: PRO_BNRELU + EPI_POOL, ns = 16 / 32 / 64
+        for ns in (16, 32, 64):
+            Mp = M // ns * ns
+            sgn = torch.where(torch.rand(N, generator=g) < 0.3, -1.0, 1.0).to(dev)
+            q0 = torch.zeros(2, N, dtype=torch.float64, device=dev)
+            pm0, pa0 = e.mlp_gemm_pool(X[:Mp], W, sgn, ns, p=(p0, p1), stats=q0)
+            q1 = torch.zeros(2, N, dtype=torch.float64, device=dev)
+            pm1, pa1 = e.x3_gemm(X[:Mp], W, e.PRO_BNRELU, 3, p=(p0, p1), stats=q1, sgn=sgn, ns=ns)
+            torch.testing.assert_close(pm1, pm0, atol=1e-4, rtol=1e-4)
+            torch.testing.assert_close(q1, q0, rtol=1e-5, atol=1e-3)
+            same = float((pa1 == pa0).float().mean())
+            assert same > 0.999, (ns, same)            # a different row only where two rows tie within rounding
+    finally:
+        e.X3_GEMM = prev
