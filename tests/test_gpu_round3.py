@@ -1,6 +1,7 @@
 """Round-3 kernels on the GPU, through the C ABI: the max-pooled last layer without its materialised output
 (pn2_mlp_gemm_pool + pn2_pool_finalize) and the Gram-form backward of that layer (pn2_pool_bwd_*)."""
 import pytest
+from conftest import assert_same_product
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -47,14 +48,25 @@ def test_pooled_layer_without_materialised_output_equals_gemm_plus_rows_max(ns, 
     assert torch.allclose(stats, stats_ref, rtol=1e-5, atol=1e-3)         # fp32 partial sums, other association
     assert torch.allclose(fin2, fin, rtol=1e-4, atol=1e-5)
     out_chk, _, _ = e.pool_finalize(pmax, parg, fin, sgn, ns)          # same constants: bit-identical pooled values
-    assert torch.equal(out_chk, out_ref)
-    # the picked row holds the extreme raw value of its column in the direction of the scale's sign
-    assert torch.equal((y.view(R, ns, N) * sgn).max(1).values, yraw * sgn)
+    # (exact fp32 MFMA: a product with a negated weight row is the negated product, bit for bit.  With the f32x3 route forced
+    # on — PN2_X3=1 — the bf16 matrix unit's internal accumulation is not sign-symmetric: x (-W)^T differs from -(x W^T) in the
+    # last bit, measured 4.8e-7 (tools/diag/x3_pool_vs_store.py); the two routes are then compared at fp32 rounding level)
+    x3 = bool(getattr(e, "X3_GEMM", False)) and e.x3_gemm_supported(K, N, e.PRO_BNRELU, 3, ns) and M >= e.X3_MIN_ROWS
+    if x3:
+        torch.testing.assert_close(out_chk, out_ref, atol=2e-6, rtol=1e-5)
+        torch.testing.assert_close((y.view(R, ns, N) * sgn).max(1).values, yraw * sgn, atol=2e-6, rtol=1e-5)
+    else:
+        assert torch.equal(out_chk, out_ref)
+        # the picked row holds the extreme raw value of its column in the direction of the scale's sign
+        assert torch.equal((y.view(R, ns, N) * sgn).max(1).values, yraw * sgn)
     live = (out_ref > 0) & (gamma != 0)
     same = (arg == arg_ref) | ~live
     assert same.float().mean() > 0.999
     yr = y.view(R, ns, N).gather(1, arg.long().unsqueeze(1)).squeeze(1)
-    assert torch.equal(yr, yraw)
+    if x3:
+        torch.testing.assert_close(yr[same], yraw[same], atol=2e-6, rtol=1e-5)
+    else:
+        assert torch.equal(yr, yraw)
     # first maximum among exact ties (padding rows repeat row 0): never an index in the padded half unless row 0 lost
     assert int((arg[live] >= ns // 2).sum()) == 0
 
@@ -290,10 +302,10 @@ def test_second_layer_gemm_recomputing_the_first_matches_the_two_gemms(M, K0, N0
     ref = e.mlp_gemm(y0, W1, pro=e.PRO_BNRELU, epi=e.EPI_STATS, p=(fin0[2], fin0[3]), stats=st_ref)
     got = e.mlp_gemm_first(X0, W0, fin0, W1, epi=e.EPI_STATS, stats=st_new)
     # the recomputation runs the MFMA's FMA chain over the input columns: identical activations, identical products
-    assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert_same_product(got, ref)
     torch.testing.assert_close(st_new, st_ref, rtol=1e-6, atol=1e-6)
     got2 = e.mlp_gemm_first(X0, W0, fin0, W1, epi=e.EPI_NONE)
-    assert torch.equal(got2, ref)
+    assert_same_product(got2, ref)
 
 
 @pytest.mark.parametrize("M,K0,N0,N1,ns", [(64 * 37, 6, 64, 64, 0), (1000, 3, 48, 40, 0), (64 * 4096 + 192, 6, 64, 64, 64),
