@@ -583,16 +583,18 @@ extern "C" int pn2_x3_gemm(long long M, int K, int N, int pro, int epi, const fl
   a.steps_fin = (N / 32) * (K / 16) / kX3SlotUnits;
   a.spp = a.steps_fin;
   hipStream_t st = (hipStream_t)stream;
-#define PN2_X3G(KA_, PRO_, EPI_) return launch_eval<X3_IN_ROWS, KA_, 0, 4, PRO_, EPI_>(a, st)
+#define PN2_X3G(KA_, W_, PRO_, EPI_) return launch_eval<X3_IN_ROWS, KA_, 0, W_, PRO_, EPI_>(a, st)
   if (K == 64) {
-    if (pro == X3_PRO_BNRELU && epi == X3_EPI_STATS) PN2_X3G(4, X3_PRO_BNRELU, X3_EPI_STATS);
-    if (pro == X3_PRO_BNRELU && epi == X3_EPI_POOL) PN2_X3G(4, X3_PRO_BNRELU, X3_EPI_POOL);
-    if (pro == X3_PRO_GY) PN2_X3G(4, X3_PRO_GY, X3_EPI_MASK);
-    PN2_X3G(4, X3_PRO_NONE, X3_EPI_STATS);
+    // 64-wide rows: <= 128 registers -> workgroups of 8 waves, 16 waves per CU (the split and the epilogue are vector work:
+    // more waves keep the matrix pipe fed); the two-matrix input-gradient form needs more registers
+    if (pro == X3_PRO_BNRELU && epi == X3_EPI_STATS) PN2_X3G(4, 8, X3_PRO_BNRELU, X3_EPI_STATS);
+    if (pro == X3_PRO_BNRELU && epi == X3_EPI_POOL) PN2_X3G(4, 8, X3_PRO_BNRELU, X3_EPI_POOL);
+    if (pro == X3_PRO_GY) PN2_X3G(4, 4, X3_PRO_GY, X3_EPI_MASK);
+    PN2_X3G(4, 8, X3_PRO_NONE, X3_EPI_STATS);
   }
-  if (pro == X3_PRO_BNRELU && epi == X3_EPI_STATS) PN2_X3G(8, X3_PRO_BNRELU, X3_EPI_STATS);
-  if (pro == X3_PRO_BNRELU && epi == X3_EPI_POOL) PN2_X3G(8, X3_PRO_BNRELU, X3_EPI_POOL);
-  if (pro == X3_PRO_GY) PN2_X3G(8, X3_PRO_GY, X3_EPI_MASK);
-  PN2_X3G(8, X3_PRO_NONE, X3_EPI_STATS);
+  if (pro == X3_PRO_BNRELU && epi == X3_EPI_STATS) PN2_X3G(8, 4, X3_PRO_BNRELU, X3_EPI_STATS);
+  if (pro == X3_PRO_BNRELU && epi == X3_EPI_POOL) PN2_X3G(8, 4, X3_PRO_BNRELU, X3_EPI_POOL);
+  if (pro == X3_PRO_GY) PN2_X3G(8, 4, X3_PRO_GY, X3_EPI_MASK);
+  PN2_X3G(8, 4, X3_PRO_NONE, X3_EPI_STATS);
 #undef PN2_X3G
 }

@@ -386,7 +386,9 @@ def cpu_baseline(points, sample_scenes, threads, workload="backbone", repeats=5)
     finally:
         pu._ext = saved
     dt, df = statistics.median(step_s), statistics.median(fwd_s)
+    # `value` is a per-scene rate measured on `sample_scenes` scenes (the GPU line runs 32 per step): an extrapolation, said so
     return {"value": round(sample_scenes / dt, 4), "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample_scenes": int(sample_scenes), "extrapolated": True,
             "forward_only_value": round(sample_scenes / df, 4), "cpu_model": cpu_model_name(),
             "median_step_s": round(dt, 3), "median_forward_s": round(df, 3), "repeats": repeats,
             "sample": f"{sample_scenes} scenes x {points} pts; 1 warm-up + median of {repeats} fwd+bwd+AdamW steps and of "
