@@ -1153,7 +1153,9 @@ __global__ __launch_bounds__(256) void prep_vec_kernel(long long R, int C, long 
                                                        const float *__restrict__ fin, float *__restrict__ gout,
                                                        double *__restrict__ sums, const long long *__restrict__ seg,
                                                        int ns) {
-  __shared__ float4 part[2][256];
+  // per-thread sums: fp32 over at most 16 rows of a column, then folded into fp64 (with <= 256 blocks a thread walks
+  // up to 512 rows of a 1M-row call; a plain fp32 running sum over them lost digits the 16-row blocks of round 4 kept)
+  __shared__ double dpart[2][256][4];
   if (seg) {                                     // blockIdx.y = scan: its rows, its (4,C) finalize block, its sums
     const long long g0 = seg[blockIdx.y] / ns;
     R = seg[blockIdx.y + 1] / ns - g0;
@@ -1172,6 +1174,8 @@ __global__ __launch_bounds__(256) void prep_vec_kernel(long long R, int C, long 
   const int grp = threadIdx.x / C4, c4 = threadIdx.x - grp * C4;
   const bool active = grp < groups;
   float4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};
+  int since = 0;
   if (active) {
     const float4 mean = reinterpret_cast<const float4 *>(fin)[c4], rstd = reinterpret_cast<const float4 *>(fin + C)[c4];
     float4 sc = mean, sh = mean;
@@ -1215,29 +1219,35 @@ __global__ __launch_bounds__(256) void prep_vec_kernel(long long R, int C, long 
         s2 = float4{a2[0], a2[1], a2[2], a2[3]};
         O[(size_t)(r + (long long)u * groups) * C4] = o4;
       }
+      if (++since == 4) {                          // 16 rows of fp32, then fp64
+        since = 0;
+        d1[0] += s1.x; d1[1] += s1.y; d1[2] += s1.z; d1[3] += s1.w;
+        d2[0] += s2.x; d2[1] += s2.y; d2[2] += s2.z; d2[3] += s2.w;
+        s1 = float4{0.f, 0.f, 0.f, 0.f}; s2 = s1;
+      }
     }
   }
-  part[0][threadIdx.x] = s1;
-  part[1][threadIdx.x] = s2;
+  d1[0] += s1.x; d1[1] += s1.y; d1[2] += s1.z; d1[3] += s1.w;
+  d2[0] += s2.x; d2[1] += s2.y; d2[2] += s2.z; d2[3] += s2.w;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dpart[0][threadIdx.x][j] = d1[j]; dpart[1][threadIdx.x][j] = d2[j]; }
   __syncthreads();
   if (grp == 0) {
-    for (int q = 1; q < groups; ++q) {
-      const float4 a = part[0][threadIdx.x + q * C4], b = part[1][threadIdx.x + q * C4];
-      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
-    }
+    for (int q = 1; q < groups; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d1[j] += dpart[0][threadIdx.x + q * C4][j]; d2[j] += dpart[1][threadIdx.x + q * C4][j]; }
   }
   __syncthreads();
   // the block's 2 C sums leave through LDS so that consecutive lanes add to consecutive doubles: the L2 retires an atomic
   // instruction per 128-byte line it touches (16 doubles) — four columns per lane straight from the registers is a 32-byte
   // lane stride, four times the line visits (measured: 48 instead of 18 us for 512 blocks x 512 sums)
-  float *red = reinterpret_cast<float *>(&part[0][0]);            // [2][C] floats (C <= 1024: 8 KB of the 8 KB)
+  double *red = &dpart[0][0][0];                                  // [2][C] doubles (C <= 1024: the 16 KB of dpart)
   if (grp == 0) {
-    reinterpret_cast<float4 *>(red)[c4] = s1;
-    reinterpret_cast<float4 *>(red + C)[c4] = s2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[4 * c4 + j] = d1[j]; red[C + 4 * c4 + j] = d2[j]; }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < 2 * C; t += 256) atomicAdd(sums + t, (double)red[t]);
+  for (int t = threadIdx.x; t < 2 * C; t += 256) atomicAdd(sums + t, red[t]);
 }
 
 inline bool aligned16(const void *a, const void *b, const void *c, const void *d, const void *e) {

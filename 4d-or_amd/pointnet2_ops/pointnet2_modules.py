@@ -241,11 +241,15 @@ class RowsSource:
     Two levels: a module-level `sample_and_query(feats_rows=...)` records the (B, N, C) feature rows themselves; a model's
     `precompute_geometry(pointcloud)` slices its own copy of the feature columns, so it records the POINT CLOUD
     (`rows_source(pointcloud)`) and its forward confirms the match (`confirm_rows`) before the levels run."""
-    __slots__ = ("ptr", "shape", "version", "device", "confirmed")
+    __slots__ = ("ptr", "shape", "version", "device", "confirmed", "storage")
 
     def __init__(self, t: torch.Tensor):
         self.ptr, self.shape, self.version, self.device = t.data_ptr(), tuple(t.shape), t._version, t.device
         self.confirmed = False
+        # the token keeps the source's STORAGE alive (ADVICE r05): a cloud replaced out of place after the prefetch frees its
+        # memory, the caching allocator hands the same address to an equal-shaped new tensor with version 0, and address +
+        # shape + version would match it.  With the storage held, the address cannot be recycled while the token lives.
+        self.storage = t.untyped_storage()
 
     def matches(self, t: Optional[torch.Tensor]) -> bool:
         return (t is not None and t.data_ptr() == self.ptr and tuple(t.shape) == self.shape

@@ -95,8 +95,13 @@ def plan_affinity(allowed: Iterable[int], node_cpus: Iterable[int], local_rank: 
     return even_slice(allowed, local_rank, local_world) if local_world > 1 else allowed
 
 
+#: a process is never pinned to fewer cores than this: the DataLoader workers and RCCL's proxy threads inherit
+#: the mask, and an even slice of a small host (len(cpus) // local_world) can be a single core
+MIN_CORES = 4
+
+
 def pin_to_gpu_numa(local_rank: int = 0, local_world: int = 1, device_index: Optional[int] = None,
-                    sysfs: str = "/sys") -> dict:
+                    sysfs: str = "/sys", min_cores: int = MIN_CORES) -> dict:
     """Restrict this process to the cores next to its GPU.  Returns what was done (for the job's log / bench JSON):
     {"numa_node": n, "cpus": k, "pinned": bool, "why": "..."}.  PN2_PIN_NUMA=0 switches it off."""
     info = {"numa_node": -1, "cpus": 0, "pinned": False, "why": ""}
@@ -123,6 +128,10 @@ def pin_to_gpu_numa(local_rank: int = 0, local_world: int = 1, device_index: Opt
         if local_rank in peers:
             ranks_on_node, index_on_node = len(peers), peers.index(local_rank)
     target = plan_affinity(allowed, node_cpus, local_rank, local_world, ranks_on_node, index_on_node)
+    if target and target != allowed and len(target) < min(int(min_cores), len(allowed)):
+        info["cpus"] = len(allowed)
+        info["why"] = f"slice of {len(target)} core(s) is below the minimum of {int(min_cores)}: affinity left as it is"
+        return info
     if not target or target == allowed:
         info["cpus"] = len(allowed)
         info["why"] = "one rank, no NUMA information: affinity left as it is" if not node_cpus else "already on the node's cores"

@@ -199,7 +199,12 @@ def main(argv=None):
     if device.type == "cuda":
         # one process per GPU: the enqueueing thread next to its GPU's NUMA node (runtime/affinity.py; PN2_PIN_NUMA=0: off)
         from runtime.affinity import pin_to_gpu_numa
-        pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        # the GPU is the SELECTED device (--device cuda:3 in a single-process run), not the local rank's ordinal; with
+        # HIP_VISIBLE_DEVICES narrowing every rank to one device the peer lookup finds nothing and the even-slice fallback
+        # applies, which never goes below affinity.MIN_CORES cores (num_workers + the RCCL threads inherit the mask)
+        pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                        device_index=device.index if device.index is not None else torch.cuda.current_device(),
+                        min_cores=max(4, int(config.get("NUM_WORKERS", 0)) + 2))
     if args.mode == "evaluate" and (args.cache_dir or args.gt):
         evaluate_split(config, args, device)
         return

@@ -41,7 +41,7 @@ def take_of(scan_id) -> int:
 _POINT_CHANNELS = (3, 6, 7)
 
 
-def _check_stored_layout(sample: Dict) -> None:
+def _check_stored_layout(sample: Dict, from_disk: bool = True) -> None:
     """A cache file holds the reference's PRE-collate layout: clouds (n, P, C) with C in {3, 6, 7} last, `edge_indices`
     (E, 2).  Files written by rounds 1-3 of this build stored the post-collate layout (channel-first clouds, (2, E)
     edges); permuting those a second time gives wrong edges without an error when E == 2, so a stale file is refused
@@ -52,11 +52,16 @@ def _check_stored_layout(sample: Dict) -> None:
         if v is None:
             continue
         shp = tuple(v.shape)
-        if len(shp) != 3 or shp[2] not in _POINT_CHANNELS or (shp[1] in _POINT_CHANNELS and shp[1] < shp[2]):
+        # (a cloud of P in {3, 6, 7} POINTS with P < C is not evidence of the old layout when the sample is fresh: the stale-
+        # layout heuristic only applies to samples that came from a file — `from_disk`)
+        stale = from_disk and shp[1] in _POINT_CHANNELS and shp[1] < shp[2] if len(shp) == 3 else False
+        if len(shp) != 3 or shp[2] not in _POINT_CHANNELS or stale:
             raise ValueError(f"cache sample {sid}: `{k}` has shape {shp}, expected the reference's pre-collate layout "
                              f"(n, points, channels in {_POINT_CHANNELS}); the file predates the round-4 cache format — "
                              "delete it so that it is regenerated")
     ei = sample.get("edge_indices")
+    if ei is not None and int(torch.as_tensor(ei).numel()) == 0:
+        ei = None                    # a scan without edges: torch.tensor([]) is 1-D (0,), and the reference's .t() accepts it
     if ei is not None:
         shp = tuple(ei.shape)
         n_obj = None if sample.get("obj_points") is None else int(sample["obj_points"].shape[0])
@@ -72,14 +77,15 @@ def _check_stored_layout(sample: Dict) -> None:
 def collate_sample(sample: Dict) -> Dict:
     """``ORDataset.collate_fn`` (or_dataset.py:63-74) on one cached (pre-collate) sample; returns a new dict."""
     out = dict(sample)
-    _check_stored_layout(out)
+    _check_stored_layout(out, from_disk=bool(out.pop("_from_cache", True)))
     for k in ("obj_points", "rel_points"):
         if out.get(k) is not None:
             out[k] = torch.as_tensor(out[k]).permute(0, 2, 1).contiguous()      # (n, P, C) -> (n, C, P)
     if out.get("gt_class") is not None:
         out["gt_class"] = torch.as_tensor(out["gt_class"]).flatten().long()
     if out.get("edge_indices") is not None:
-        out["edge_indices"] = torch.as_tensor(out["edge_indices"]).t().contiguous()   # (E, 2) -> (2, E)
+        ei_t = torch.as_tensor(out["edge_indices"])
+        out["edge_indices"] = (ei_t.reshape(0, 2) if ei_t.numel() == 0 else ei_t).t().contiguous()   # (E, 2) -> (2, E)
     for k in ("gt_rels", "relation_objects_one_hot"):
         if out.get(k) is not None:
             out[k] = torch.as_tensor(out[k])

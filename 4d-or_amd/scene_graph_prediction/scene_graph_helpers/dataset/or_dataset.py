@@ -150,6 +150,7 @@ class ORDataset:
             if self.caching_folder is not None:
                 cache.save_sample(self.caching_folder, ready)
             sample = cache.uncollate_sample(ready)
+            sample["_from_cache"] = False            # fresh: the stale-file heuristic of collate_sample does not apply
         return sample
 
     def collate_fn(self, batch):

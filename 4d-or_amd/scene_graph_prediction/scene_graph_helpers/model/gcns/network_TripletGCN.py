@@ -323,7 +323,10 @@ FUSED_LAYER = os.environ.get("PN2_GCN_FUSED") != "0"
 # 32 scans 0.96-1.0 vs 1.5, 64 scans 1.7-1.8 vs 1.6-2.2, 128 scans 3.4 vs 2.3 — the per-scan workgroups of the forward /
 # input-gradient kernels re-read the weights once per scan and column tile (L2 traffic grows with the scan count), while the
 # unfused path's library GEMMs see ONE tall matrix.
-FUSED_MAX_SCANS = 32
+# Round 6: 64 (was 32) — BASELINE configs[4] names 64 scenes and the two routes measure the same there (1.7-1.8 vs 1.6-2.2 ms
+# above, profiles/r06_gcn_time.jsonl), so the batch stays on the hand-written kernels instead of the library GEMMs; beyond
+# 64 scans the unfused route is faster (128 scans: 2.3 vs 3.4 ms) and keeps being chosen.
+FUSED_MAX_SCANS = 64
 # The layer's launches issued from ONE C call each way (pn2_gcn_layer_forward / _backward) instead of block by block from
 # python; PN2_GCN_LAYER_CALL=0 restores the block-by-block sequence (same kernels, same results; A/B of the host cost).
 LAYER_CALL = os.environ.get("PN2_GCN_LAYER_CALL") != "0"

@@ -206,3 +206,35 @@ def test_x3_gemm_matches_exact_kernels_and_fp64(M, K, N):
             assert same > 0.999, (ns, same)            # a different row only where two rows tie within rounding
     finally:
         e.X3_GEMM = prev
+
+
+# ------------------------------------------------------------------------------------------------ prep sums at M >= 1M
+def test_prep_sums_at_a_million_rows_match_float64():
+    """pn2_bn_relu_bwd_prep / pn2_pool_bwd_prep (csrc/mlp_gemm.hip prep_vec_kernel): a thread walks up to 512 rows of a 1M-row call;
+    its column sums are fp32 over 16 rows at a time, then fp64 — the BatchNorm-backward sums stay at fp32-input precision
+    against a float64 reduction (an fp32 running sum over 4096 rows of a column with a non-zero mean loses 3 digits)."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(5)
+    M, C = 1 << 20, 128
+    y = (torch.randn(M, C, generator=g) + 0.5).cuda()
+    gout = (torch.randn(M, C, generator=g) * 0.1 + 1.0).cuda()            # gradients with a common sign: long same-sign sums
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    gamma = torch.ones(C, device="cuda")
+    fin = torch.stack([mean, rstd, gamma * rstd, -mean * gamma * rstd]).contiguous()
+    gpre, sums = e.bn_relu_bwd_prep(y, gout, fin)
+    gate = (y * fin[2] + fin[3]) > 0
+    ref_g = torch.where(gate, gout, torch.zeros_like(gout))
+    assert torch.equal(gpre, ref_g)
+    want1 = ref_g.double().sum(0)
+    want2 = (ref_g.double() * ((y.double() - mean.double()) * rstd.double())).sum(0)
+    torch.testing.assert_close(sums[0], want1, rtol=2e-7, atol=1e-3)
+    torch.testing.assert_close(sums[1], want2, rtol=2e-6, atol=2e-2)
+    # pooled form: R pooled rows
+    R = 1 << 20
+    yraw = y[:R].contiguous()
+    pooled = torch.relu(yraw * fin[2] + fin[3])
+    gPm, s2 = e.pool_bwd_prep(yraw, pooled, gout[:R].contiguous(), fin)
+    ref = torch.where(pooled > 0, gout[:R], torch.zeros_like(pooled))
+    assert torch.equal(gPm, ref)
+    torch.testing.assert_close(s2[0], ref.double().sum(0), rtol=2e-7, atol=1e-3)

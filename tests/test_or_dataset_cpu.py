@@ -167,3 +167,23 @@ def test_the_in_tree_validation_json_of_the_reference_parses():
     g = ds.gt_rels(sid)
     n = len(ds.objs_json[sid])
     assert g.numel() == n * (n - 1) and int((g != 14).sum()) >= 1
+
+
+def test_collate_accepts_a_scan_without_edges_and_fresh_tiny_clouds():
+    """`torch.tensor([])` edge lists are 1-D (0,) and the reference's collate `.t()` accepts them; a FRESH sample
+    whose clouds have 3 / 6 points with fewer points than channels is not a stale cache file."""
+    import numpy as np
+    import torch
+    from scene_graph_prediction.scene_graph_helpers.dataset import cache
+    lonely = {"scan_id": "1_000001", "obj_points": np.zeros((1, 40, 6), np.float32), "rel_points": np.zeros((0, 50, 7), np.float32),
+              "edge_indices": torch.tensor([]), "gt_class": np.array([3]), "gt_rels": np.zeros((0,), np.int64),
+              "relation_objects_one_hot": np.zeros((0, 12), np.float32)}
+    out = cache.collate_sample(lonely)
+    assert tuple(out["edge_indices"].shape) == (2, 0) and tuple(out["obj_points"].shape) == (1, 6, 40)
+    tiny = {"scan_id": "1_000002", "obj_points": np.zeros((2, 3, 6), np.float32), "rel_points": np.zeros((2, 6, 7), np.float32),
+            "edge_indices": np.array([[0, 1], [1, 0]]), "_from_cache": False}
+    out = cache.collate_sample(tiny)
+    assert tuple(out["obj_points"].shape) == (2, 6, 3) and "_from_cache" not in out
+    import pytest
+    with pytest.raises(ValueError, match="predates"):
+        cache.collate_sample(dict(tiny, _from_cache=True))          # the same shapes read from a FILE are refused
