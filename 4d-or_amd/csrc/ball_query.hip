@@ -718,6 +718,8 @@ int bq_auto(int B, int N, int m, float radius, int nsample) {
 // on, slabs of 8192 indices walk the dependent table -> records -> mask chain less often (and a sparse ball in a cloud of up
 // to 8192 points sees the whole cloud as ONE cell list).  Results never depend on it.
 int bq_slab_w(int N, float radius, int nsample) {
+  const char *force = getenv("PN2_BQ_SLAB_W");                 // test / measurement hook: 1 or 4 (results never depend on it)
+  if (force && (force[0] == '1' || force[0] == '4') && force[1] == 0) return force[0] - '0';
   if (N <= kSlab) return 1;
   const double per = (double)nsample / (2048.0 * (double)radius * radius * radius);
   return per > 1.5 ? 4 : 1;

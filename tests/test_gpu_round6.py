@@ -239,3 +239,37 @@ def test_prep_sums_at_a_million_rows_match_float64():
     ref = torch.where(pooled > 0, gout[:R], torch.zeros_like(pooled))
     assert torch.equal(gPm, ref)                               # (this gate reads the stored pooled value: exact)
     torch.testing.assert_close(s2[0], ref.double().sum(0), rtol=2e-7, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ slab widths of the cell-list ball query
+@pytest.mark.parametrize("w", ["1", "4"])
+@pytest.mark.parametrize("B,N,m,r,ns,kind", [(3, 40000, 300, 0.2, 64, "ball"), (2, 20000, 128, 0.12, 32, "ball"), (2, 17000, 64, 0.3, 16, "dups"),
+                                              (1, 50000, 64, 0.05, 48, "ball"), (2, 33000, 100, 0.25, 200, "wild"), (2, 9000, 50, 0.4, 8, "ball")])
+def test_ball_query_slab_widths_are_bit_exact(B, N, m, r, ns, kind, w, monkeypatch):
+    """Both slab widths of the cell-list ball query (2048 / 8192 consecutive indices, forced through PN2_BQ_SLAB_W) return
+    the oracle's indices (EXT/src/ball_query_gpu.cu:9-44:
+    first nsample hits in ascending index, first-hit padding, zero row), on crowded and sparse balls, exact duplicates,
+    centres outside the cloud and coordinates beyond the hash grid's range ('wild': every record of the slab is tested)."""
+    import oracle_ext
+    from pointnet2_ops import _ext
+    monkeypatch.setenv("PN2_BQ_SLAB_W", w)
+    g = torch.Generator().manual_seed(B * 100 + N + ns)
+    p = torch.randn(B, N, 3, generator=g)
+    xyz = p / p.norm(dim=2, keepdim=True) * torch.rand(B, N, 1, generator=g).pow(1 / 3)
+    if kind == "dups":
+        xyz[:, N // 2:] = xyz[:, :N - N // 2]                          # every point twice: ties in distance, order by index
+    if kind == "wild":
+        xyz[0, 5] = torch.tensor([3.0e9, 0.0, 0.0])                    # beyond 2^32 cells: its slab is walked record by record
+        xyz[1, 20000] = torch.tensor([float("inf"), 0.0, 1.0])
+    centres = xyz[:, torch.randperm(N, generator=g)[:m]].contiguous()
+    centres[:, 0] = torch.tensor([5.0, 5.0, 5.0])                      # empty ball: zero row
+    if kind == "wild":
+        centres[0, 1] = torch.tensor([3.0e9, 0.0, 0.0])                # a wild centre next to the wild point
+    want = oracle_ext.OracleRowsExt.ball_query(centres, xyz, r, ns)
+    prev = _ext.BALL_QUERY_GRID
+    _ext.BALL_QUERY_GRID = "slabs"
+    try:
+        got = _ext.ball_query(centres.cuda(), xyz.cuda(), r, ns)
+    finally:
+        _ext.BALL_QUERY_GRID = prev
+    assert torch.equal(got.cpu(), want)
