@@ -626,14 +626,21 @@ def bench_forward_eval(args, device, rank, world, distributed, _ext):
             return model(batch, geometry=geo)
 
     affinity = pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-    side = side_stream(device) if args.geometry_pipeline else None
+    # inference pipeline: the sampling chain (latency-bound, a fraction of the CUs) of the NEXT `depth` batches runs on `depth`
+    # side streams while the current batch's forward runs on the main stream; depth 2 keeps two sampling chains in flight —
+    # at the headline shape one chain (2.7 ms) is longer than the forward (2.0 ms) and would bound the rate
+    depth = max(1, int(args.eval_prefetch_depth)) if args.geometry_pipeline else 0
+    sides = [side_stream(device) for _ in range(depth)]
+    side = sides[0] if sides else None
     main = torch.cuda.current_stream(device)
-    state = {"geo": None}
+    state = {"queue": [], "n": 0}
 
     def launch_geometry():
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            return geometry()
+        st = sides[state["n"] % depth]
+        state["n"] += 1
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            return st, geometry()
 
     def run(k, on_step=None):
         with torch.no_grad():
@@ -643,10 +650,12 @@ def bench_forward_eval(args, device, rank, world, distributed, _ext):
                 if side is None:
                     forward(None)
                     continue
-                geo = state["geo"] if state["geo"] is not None else launch_geometry()
-                main.wait_stream(side)
+                while len(state["queue"]) < depth:
+                    state["queue"].append(launch_geometry())
+                st, geo = state["queue"].pop(0)
+                main.wait_stream(st)
                 record_stream_tree(geo, main)
-                state["geo"] = launch_geometry()          # the next batch's geometry co-runs with this forward
+                state["queue"].append(launch_geometry())          # the geometry `depth` batches ahead co-runs with this forward
                 forward(geo)
 
     def timed(k):
@@ -702,7 +711,8 @@ def bench_forward_eval(args, device, rank, world, distributed, _ext):
                               "tests/test_gpu_round6.py); sampling / grouping geometry and FP levels: fp32",
                 "global_batch": units * world, "parallelism": f"dp{world}",
                 "geometry_pipeline": "off: geometry inside the step" if side is None else
-                "on: FPS / ball-query / 3-NN of batch i+1 on a side stream during forward i (one geometry per timed step)",
+                f"on: FPS / ball-query / 3-NN of batches i+1 .. i+{depth} on {depth} side stream(s) during forward i (one geometry per "
+                "timed step)",
                 "host_affinity": affinity,
                 "layer_by_layer_exact_fp32_ms_per_step": round(layers_s * 1e3, 3),
                 "layer_by_layer_exact_fp32_per_s": round(units * world / layers_s, 1),
@@ -770,6 +780,8 @@ def main():
                     help="inference instead of training: model.eval() forward under no_grad (running-statistic BatchNorm), every "
                          "SA scale as ONE kernel (pn2_sa_eval_x3: gather -> folded-BatchNorm MLP chain in registers on the bf16 matrix "
                          "cores, f32x3 split product -> max); reports scenes/s forward, the layer-by-layer route beside it")
+    ap.add_argument("--eval-prefetch-depth", type=int, default=2,
+                    help="--forward-eval: batches whose sampling / grouping geometry is in flight on side streams ahead of the forward")
     ap.add_argument("--no-geometry-pipeline", dest="geometry_pipeline", action="store_false",
                     help="run the sampling/grouping geometry inside the step on the main stream instead of prefetching "
                          "the NEXT batch's geometry on a side stream during the step (25.0 vs 20.7 ms/step on MI355X)")
