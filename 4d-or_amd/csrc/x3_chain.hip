@@ -35,6 +35,7 @@ struct EvalArgs {
   const float *bias_mid;  // (c_mid)
   const float *bias_fin;  // (c_out)
   float *out;             // (B m, ldo), columns [0, c_out)
+  unsigned *next_pass;    // [0] the next unclaimed pass (workgroups take passes as they get to run), [1] workgroups done; both zero between launches
   long long Mrows;        // B m ns  (IN_ROWS: rows of X)
   long long ncentres;     // B m
   int N, m, ns_shift, C, c_out, ldo, steps_fin, spp;
@@ -84,7 +85,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
   const long long npass = (a.Mrows + PASS - 1) / PASS;
-  const long long my_passes = (npass - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  // Passes are CLAIMED, not dealt: under a co-running kernel (the sampling chain of the next batch on its side stream holds
+  // 64-128 CUs) part of the grid starts late, and a static share per workgroup made the kernel as slow as its last starter
+  // (1.83 ms contended against 1.40 alone for the four levels of the headline shape).  Thread 0 claims one pass ahead; the id
+  // travels through LDS behind the step barriers the pass has anyway.
+  // (the first two passes of a workgroup are its static ones — a burst of 2 x grid same-address atomics at kernel start is
+  // serialised by the L2: +35 us on the 1024-pass level; the counter counts the claims BEHIND those 2 x grid passes)
+  __shared__ unsigned s_claim[2];
+  const unsigned claim0 = 2u * gridDim.x;
 
   // resident tables
   if (SMALL)
@@ -138,11 +146,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
 
   int slot = 0;                                          // ring slot of the step being computed
   // neighbourhood index of this lane's row, loaded one pass ahead (the gathers depend on it: one L2 round trip less per pass)
-  auto load_idx = [&](long long pi) {
-    const long long row = ((long long)blockIdx.x + pi * gridDim.x) * PASS + wave * 32 + l32;
-    return (!ROWS && pi < my_passes && row < a.Mrows) ? a.idx[row] : 0;
+  auto load_idx = [&](long long pass) {
+    const long long row = pass * PASS + wave * 32 + l32;
+    return (!ROWS && pass < npass && row < a.Mrows) ? a.idx[row] : 0;
   };
-  int p_next = load_idx(0);
+  long long cur = blockIdx.x, nxt = (long long)blockIdx.x + gridDim.x;
+  int parity = 0;
+  int p_next = load_idx(cur);
   x3_frag actA[KA];
   x3_frag actB[KB ? KB : 1];
 
@@ -162,8 +172,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
     }
   };
 
-  for (long long pi = 0; pi < my_passes; ++pi) {
-    const long long row0 = ((long long)blockIdx.x + pi * gridDim.x) * PASS + wave * 32;     // wave-uniform
+  while (cur < npass) {
+    const long long row0 = cur * PASS + wave * 32;     // wave-uniform
+    if (tid == 0) s_claim[parity] = claim0 + atomicAdd(a.next_pass, 1u);      // the pass after next (read behind this pass's barriers)
     // ------------------------------------------------------------------ input stage
     {
       const long long row = row0 + l32;
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
       int b = 0;
       long long centre = 0;
       const int p = p_next;
-      p_next = load_idx(pi + 1);
+      p_next = load_idx(nxt);
       if (valid) {
         centre = row >> a.ns_shift;
         b = (int)(centre / a.m);
@@ -438,6 +449,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
       step_barrier();
       slot = slot + 1 == kRing ? 0 : slot + 1;
     }
+    cur = nxt;
+    nxt = s_claim[parity];
+    parity ^= 1;
+  }
+  // the last workgroup to leave re-arms the counters for the stream's next launch (no memset launch per call: it cost the
+  // small levels 20-35 us); everybody's claims are behind them when they get here
+  if (tid == 0) {
+    const unsigned done = atomicAdd(a.next_pass + 1, 1u);
+    if (done == gridDim.x - 1) {
+      a.next_pass[0] = 0u;
+      a.next_pass[1] = 0u;
+    }
   }
   if (SUMS && a.stats) {
     // (the last step_barrier made every wave's LDS atomics visible)
@@ -477,6 +500,7 @@ int launch_eval(const EvalArgs &a, hipStream_t stream) {
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
   if (!ok || lds > 80 * 1024) return PN2_ELAUNCH;
   const long long npass = (a.Mrows + 32 * WAVES - 1) / (32 * WAVES);
+  if (npass >= 0xffffffffll - 2048) return PN2_EINVAL;                 // (32-bit pass counter, every workgroup over-claims two)
   const unsigned grid = (unsigned)(npass < 512 ? npass : 512);         // two workgroups per CU
   hipLaunchKernelGGL((sa_eval_kernel<IN, KA, KB, WAVES, PRO, EPI>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
   return pn2_check_launch();
@@ -518,14 +542,15 @@ extern "C" int pn2_sa_eval_x3_supported(int mode, int ns, int C, int c1, int c_m
 extern "C" int pn2_sa_eval_x3(int mode, int B, int N, int m, int ns, int C, const float *xyz, const float *new_xyz,
                               const int *idx, const float *feats, const float *Q, int c1, const void *w0_frags, int c_mid,
                               const void *wstream, const float *bias_mid, int c_out, const float *bias_fin, float *out, int ldo,
-                              void *stream) {
+                              void *workspace, void *stream) {
   if (B < 0 || N <= 0 || m <= 0 || ldo < c_out) return PN2_EINVAL;
   if (!pn2_sa_eval_x3_supported(mode, ns, C, c1, c_mid, c_out)) return PN2_EINVAL;
   if (B == 0) return PN2_OK;
   if (!new_xyz || !idx || !feats || !wstream || !bias_fin || !out || (mode == 0 && (!xyz || !w0_frags)) || (mode == 1 && !Q) ||
-      (c_mid && !bias_mid))
+      (c_mid && !bias_mid) || !workspace)
     return PN2_ENULL;
   EvalArgs a{};
+  a.next_pass = (unsigned *)workspace;
   a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.feats = feats; a.Q = Q;
   a.w0 = (const unsigned char *)w0_frags; a.wstream = (const unsigned char *)wstream;
   a.bias_mid = bias_mid; a.bias_fin = bias_fin; a.out = out;
@@ -565,14 +590,15 @@ extern "C" int pn2_x3_gemm_supported(int K, int N, int pro, int epi, int ns) {
 
 extern "C" int pn2_x3_gemm(long long M, int K, int N, int pro, int epi, const float *X, const float *X2, const float *p0,
                            const float *p1, const float *p2, const void *wfrags, float *Y, double *stats, const float *Yprev,
-                           const float *e_fin, float *pmax, int *parg, const float *sgn, int ns, void *stream) {
+                           const float *e_fin, float *pmax, int *parg, const float *sgn, int ns, void *workspace, void *stream) {
   if (M < 0 || !pn2_x3_gemm_supported(K, N, pro, epi, ns)) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!X || !wfrags || (pro != X3_PRO_NONE && (!p0 || !p1)) || (pro == X3_PRO_GY && (!X2 || !p2)) ||
-      (epi != X3_EPI_POOL && !Y) || (epi == X3_EPI_MASK && (!Yprev || !e_fin)) || (epi == X3_EPI_POOL && (!pmax || !parg)))
+      (epi != X3_EPI_POOL && !Y) || (epi == X3_EPI_MASK && (!Yprev || !e_fin)) || (epi == X3_EPI_POOL && (!pmax || !parg)) || !workspace)
     return PN2_ENULL;
   if (epi == X3_EPI_POOL && M % (ns < 32 ? ns : 32) != 0) return PN2_EINVAL;
   EvalArgs a{};
+  a.next_pass = (unsigned *)workspace;
   a.X = X; a.X2 = X2; a.p0 = p0; a.p1 = p1; a.p2 = p2;
   a.wstream = (const unsigned char *)wfrags;
   a.Y = Y; a.stats = stats; a.Yprev = Yprev; a.e_fin = e_fin; a.pmax = pmax; a.parg = parg; a.sgn = sgn;

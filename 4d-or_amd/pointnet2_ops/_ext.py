@@ -67,8 +67,8 @@ _SIGNATURES = {
     "pn2_bn_running_update": [_c_int, _c_int, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
     "pn2_x3_pack_weight": [_c_int] * 4 + [_c_vp] * 3,
-    "pn2_x3_gemm": [ctypes.c_longlong] + [_c_int] * 4 + [_c_vp] * 13 + [_c_int, _c_vp],
-    "pn2_sa_eval_x3": [_c_int] * 6 + [_c_vp] * 5 + [_c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp],
+    "pn2_x3_gemm": [ctypes.c_longlong] + [_c_int] * 4 + [_c_vp] * 13 + [_c_int, _c_vp, _c_vp],
+    "pn2_sa_eval_x3": [_c_int] * 6 + [_c_vp] * 5 + [_c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp],
     "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
     "pn2_group_lift_rows": [_c_int] * 6 + [_c_f32] + [_c_vp] * 8,
     "pn2_group_lift_rows_grad": [_c_int] * 6 + [_c_f32] + [_c_vp] * 11 + [_c_sz, _c_vp],
@@ -846,6 +846,19 @@ def lift_points(P, xyz, new_xyz, Wx, normalize, radius):
 
 
 # ------------------------------------------------------------------ round 6: eval-mode SA level in one kernel (f32x3)
+_X3_WS = {}
+
+
+def _x3_workspace(device):
+    """256 bytes per (device, stream): the pass counter of the persistent x3 kernels (launches of one stream run in order; two
+    streams must not share it)."""
+    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
+    ws = _X3_WS.get(key)
+    if ws is None:
+        ws = _X3_WS[key] = torch.zeros(64, dtype=torch.int32, device=device)
+    return ws
+
+
 def x3_weight_bytes(N, K):
     return int(_lib.pn2_x3_weight_bytes(int(N), int(K)))
 
@@ -903,7 +916,7 @@ def sa_eval_x3(mode, xyz, new_xyz, idx, feats, Q, c1, w0_frags, c_mid, wstream, 
     nbytes = B * (4 * m * ns + 12 * m + 4 * c_out * m) + (B * (12 * N + 4 * C * N) if mode == 0 else 4 * c1 * B * (N + m))
     _call("pn2_sa_eval_x3", idx, int(mode), B, N, m, ns, C, _ptr(xyz), _ptr(new_xyz), _ptr(idx), fptr, _ptr(Q), int(c1),
           _ptr(w0_frags), int(c_mid), _ptr(wstream), _ptr(bias_mid), int(c_out), _ptr(bias_fin),
-          out.data_ptr() + 4 * int(col0), int(ldo), alg_bytes=nbytes, alg_flops=flops,
+          out.data_ptr() + 4 * int(col0), int(ldo), _ptr(_x3_workspace(idx.device)), alg_bytes=nbytes, alg_flops=flops,
           tag=(f"ns{ns},{c1}/{c_mid}/{c_out}" if DETAIL_TAGS else None))
     return out
 
@@ -944,7 +957,8 @@ def x3_gemm(X, W, pro, epi, X2=None, p=None, stats=None, Yprev=None, e_fin=None,
     nbytes = 4 * (M * K * (2 if pro == PRO_GY else 1) + N * K) + (8 * (M // min(int(ns) or 32, 32)) * N if epi == 3 else
                                                                    4 * M * N * (2 if epi == 2 else 1))
     _call("pn2_x3_gemm", X, M, K, N, int(pro), int(epi), _ptr(X), _ptr(X2), _ptr(p0), _ptr(p1), _ptr(p2), _ptr(frags), _ptr(Y),
-          _ptr(stats), _ptr(Yprev), _ptr(e_fin), _ptr(pmax), _ptr(parg), _ptr(sgn), int(ns), alg_bytes=nbytes,
+          _ptr(stats), _ptr(Yprev), _ptr(e_fin), _ptr(pmax), _ptr(parg), _ptr(sgn), int(ns), _ptr(_x3_workspace(X.device)),
+          alg_bytes=nbytes,
           alg_flops=2 * M * N * K, tag=(f"M{M},K{K},N{N},pro{int(pro)},epi{int(epi)}" if DETAIL_TAGS else None))
     return (pmax, parg) if epi == 3 else Y
 

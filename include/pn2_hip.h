@@ -864,6 +864,9 @@ int pn2_gen_edge_input(int B, int n, int max_dist, int F, const long long *path,
  *       accumulators, i.e. everywhere except the last layer of a mode-1 stack without a middle layer).
  *       Nothing of size rows x channels is written: the activations stay in registers from the gather to the maximum.
  *       `out` rows have pitch ldo >= c_out (a multi-scale level writes its scales side by side).  ns in {16, 32, 64 k};
+ *       `workspace`: 256 bytes of device memory owned by the call's stream (the kernels' pass counter: persistent workgroups
+ *       CLAIM passes, so a grid that starts late under a co-running kernel does not hold the others back).  ZERO before its
+ *       first use; every launch leaves it zero again (the last workgroup re-arms it).
  *       covered widths: pn2_sa_eval_x3_supported.  idx as written by pn2_ball_query.  Indices bit-exact by construction
  *       (they are inputs); features within 1e-4 of the fp32 reference (tests/test_gpu_round6.py, against the oracle).
  * Algorithmic bytes: B (4 m ns + 12 N + 12 m + 4 C N + 4 c_out m)  (mode 1: 4 c1 (N + m) instead of 12 N + 4 C N). */
@@ -872,7 +875,7 @@ int pn2_x3_pack_weight(int N, int K, int ldw, int perm, const float *W, void *fr
 int pn2_sa_eval_x3_supported(int mode, int ns, int C, int c1, int c_mid, int c_out);
 int pn2_sa_eval_x3(int mode, int B, int N, int m, int ns, int C, const float *xyz, const float *new_xyz, const int *idx,
                    const float *feats, const float *Q, int c1, const void *w0_frags, int c_mid, const void *wstream,
-                   const float *bias_mid, int c_out, const float *bias_fin, float *out, int ldo, void *stream);
+                   const float *bias_mid, int c_out, const float *bias_fin, float *out, int ldo, void *workspace, void *stream);
 
 /* The same product as the TRAINING GEMM of a shared-MLP layer (opt-in arithmetic "f32x3": bench.py --dtype f32x3, PN2_X3=1;
  * the exact fp32 MFMA kernels stay the default).  pn2_x3_gemm = pn2_mlp_gemm / pn2_mlp_gemm_pool with W given as
@@ -887,7 +890,7 @@ int pn2_sa_eval_x3(int mode, int B, int N, int m, int ns, int C, const float *xy
 int pn2_x3_gemm_supported(int K, int N, int pro, int epi, int ns);
 int pn2_x3_gemm(long long M, int K, int N, int pro, int epi, const float *X, const float *X2, const float *p0, const float *p1,
                 const float *p2, const void *wfrags, float *Y, double *stats, const float *Yprev, const float *e_fin, float *pmax,
-                int *parg, const float *sgn, int ns, void *stream);
+                int *parg, const float *sgn, int ns, void *workspace, void *stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus
