@@ -314,10 +314,10 @@ def roofline_of(top, pmc_applies=True, pmc_files=None):
     bf16 = "bf16" in top["kernel"]
     # newest committed counter summary of the command first (tools/profile_round.sh + tools/summarise_profile.py); the
     # fp32 and the bf16 default commands have their own files
-    files = ((("r05_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r04_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6),
+    files = ((("r06_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r05_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r04_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6),
               ("r02_backbone_bf16_counters.json", "hbm_MB_per_launch", 1e6))
              if bf16 else
-             (("r05_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r04_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_counters.json", "hbm_MB_per_launch", 1e6),
+             (("r06_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r05_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r04_backbone_counters.json", "hbm_MB_per_launch", 1e6), ("r03_backbone_counters.json", "hbm_MB_per_launch", 1e6),
               ("r02_backbone_counters.json", "hbm_MB_per_launch", 1e6),
               ("r01_hbm_traffic_per_kernel.json", "hbm_bytes_per_launch", 1.0)))
     if pmc_files is not None:
@@ -724,7 +724,8 @@ def bench_forward_eval(args, device, rank, world, distributed, _ext):
             out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
             top = next((r for r in main_rows if r["kernel"].startswith("pn2_sa_eval_x3")), main_rows[0] if main_rows else None)
             if top is not None:
-                out["roofline"] = roofline_of(top, False)
+                pmc = ["r06_eval_counters.json"] if (not sgp and args.workload == "backbone" and args.batch == 32 and args.points == 50000) else None
+                out["roofline"] = roofline_of(top, False, pmc_files=pmc)
                 out["roofline"]["note"] = ("pn2_sa_eval_x3 aggregated over the step's launches; peak = dense bf16 MFMA / 6 (the f32x3 "
                                            "product issues six bf16 matrix instructions per fp32-grade product)")
         emit_json(out, args)
@@ -970,7 +971,8 @@ def main():
             main_rows = [r for r in rows if not r["kernel"].endswith("@side")]
             out["hip_kernel_ms_per_step"] = round(sum(r["ms_per_step"] for r in main_rows), 3)
             if main_rows:
-                out["roofline"] = roofline_of(main_rows[0], pmc_default)
+                out["roofline"] = roofline_of(main_rows[0], pmc_default,
+                                              pmc_files=["r06_backbone_f32x3_counters.json"] if (pmc_default and args.dtype == "f32x3") else None)
         if serial_rows is not None:
             keep = ("kernel", "calls_per_step", "ms_per_step", "avg_launch_us", "GBps", "TFLOPps", "bound", "frac")
             out["kernels_without_geometry_pipeline"] = [{k: r[k] for k in keep} for r in serial_rows]

@@ -27,6 +27,7 @@ ENTRY_OF_FAMILY = {
     "inv_cloud_kernel": "pn2_group_inverse_index", "inv_keys_kernel": "pn2_group_inverse_index", "inv_ptr_kernel": "pn2_group_inverse_index",
     "three_interpolate_rows_grad_csr_kernel": "pn2_three_interpolate_rows_grad", "three_interpolate_rows_grad_kernel": "pn2_three_interpolate_rows_grad",
     "pool_bwd_prep_kernel": "pn2_pool_bwd_prep", "bn_relu_bwd_prep_kernel": "pn2_bn_relu_bwd_prep",
+    "x3_pack_kernel": "pn2_x3_pack_weight",
 }
 
 
@@ -58,6 +59,13 @@ def keys(name: str):
         m = re.search(r"mlp_gemm_bf16_kernel<\s*\d+,\s*\d+,\s*(\d+),\s*(\d+)", name)
         pro, epi = (int(m.group(1)), int(m.group(2))) if m else (0, 0)
         out.append("entry:" + ("pn2_mlp_gemm_pool_bf16" if epi == 3 else "pn2_mlp_gemm_first_bf16" if pro == 4 else "pn2_mlp_gemm_bf16"))
+    elif fam == "sa_eval_kernel":
+        # template <IN, KA, KB, WAVES, PRO, EPI> (csrc/x3_chain.hip): IN 0 / 1 = the eval-mode SA level, IN 2 = the f32x3 training GEMM
+        m = re.search(r"sa_eval_kernel<\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)(?:,\s*(\d+),\s*(\d+))?", name)
+        mode = int(m.group(1)) if m else 0
+        if m:
+            out.append(f"sa_eval_kernel<IN{mode},K{16 * int(m.group(2))},mid{16 * int(m.group(3))},pro{m.group(5) or 0},epi{m.group(6) or 0}>")
+        out.append("entry:" + ("pn2_x3_gemm" if mode == 2 else "pn2_sa_eval_x3"))
     elif fam == "prep_vec_kernel":
         # template <POOLED>: true = pn2_pool_bwd_prep (and its segment-table form), false = pn2_bn_relu_bwd_prep
         out.append("entry:" + ("pn2_pool_bwd_prep" if re.search(r"prep_vec_kernel<\s*true", name) else "pn2_bn_relu_bwd_prep"))
