@@ -82,6 +82,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
   float *bfin = bmid + (KB ? KB * 16 : 16);
   float *prm = bfin + (ROWS ? 0 : a.c_out);                    // IN_ROWS: [3][16 KA] prologue constants (no bias table then)
   float *csum = prm + (ROWS ? 3 * 16 * KA : 0);                // EPI with sums: [2][c_out] fp32 partial column sums of this workgroup
+  // EPI_MAX, neighbourhoods of 64 .. 32 WAVES rows: the waves of a centre meet here (two buffers by step parity)
+  float *spart = csum + (SUMS ? 2 * a.c_out : 0);              // [2][WAVES][TPS_FIN][32]
+  const int wpc = 1 << (a.ns_shift > 5 ? a.ns_shift - 5 : 0);  // waves per centre
+  const bool meet = EPI == X3_EPI_MAX && a.ns_shift > 5 && wpc <= WAVES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
   const long long npass = (a.Mrows + PASS - 1) / PASS;
@@ -439,7 +443,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
         } else {
           const long long centre = row0 >> a.ns_shift;
           const float v = fmaxf(fmaxf(m0, m1), 0.f);
-          if (h == 0 && centre < a.ncentres) {
+          if (meet) {
+            if (h == 0) spart[(((jf & 1) * WAVES + wave) * TPS_FIN + tl) * 32 + l32] = v;      // combined behind the step barrier
+          } else if (h == 0 && centre < a.ncentres) {
             float *o = a.out + (size_t)centre * a.ldo + col;
             if (a.ns_shift == 5) *o = v;
             else atomicMax(reinterpret_cast<int *>(o), __builtin_bit_cast(int, v));   // v >= 0: integer order = float order; out zero-filled
@@ -448,6 +454,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
       }
       step_barrier();
       slot = slot + 1 == kRing ? 0 : slot + 1;
+      if (meet && (wave & (wpc - 1)) == 0 && h == 0) {
+        // the first wave of every centre: maximum over the centre's waves, one plain 128-byte store per tile — no zero fill,
+        // no atomics (they doubled the level's HBM traffic: 193 MB measured against 89 MB algorithmic at the headline's SA1)
+        const long long centre = row0 >> a.ns_shift;
+        if (centre < a.ncentres) {
+#pragma unroll
+          for (int tl = 0; tl < TPS_FIN; ++tl) {
+            float v = 0.f;
+            for (int w = 0; w < wpc; ++w) v = fmaxf(v, spart[(((jf & 1) * WAVES + wave + w) * TPS_FIN + tl) * 32 + l32]);
+            a.out[(size_t)centre * a.ldo + 32 * (jf * TPS_FIN + tl) + l32] = v;
+          }
+        }
+      }
     }
     cur = nxt;
     nxt = s_claim[parity];
@@ -495,7 +514,8 @@ template <int IN, int KA, int KB, int WAVES, int PRO = 0, int EPI = 0>
 int launch_eval(const EvalArgs &a, hipStream_t stream) {
   constexpr int W0_BYTES = IN == 0 ? (KA / 2) * kX3UnitBytes : 0;
   const size_t lds = (size_t)kRing * kX3SlotBytes + W0_BYTES +
-                     ((KB ? KB * 16 : 16) + (IN == X3_IN_ROWS ? 3 * 16 * KA : a.c_out) + (EPI != X3_EPI_MAX ? 2 * a.c_out : 0)) * sizeof(float);
+                     ((KB ? KB * 16 : 16) + (IN == X3_IN_ROWS ? 3 * 16 * KA : a.c_out) + (EPI != X3_EPI_MAX ? 2 * a.c_out : 0) +
+                      (EPI == X3_EPI_MAX ? 2 * WAVES * (kX3SlotUnits / (KB ? KB : KA)) * 32 : 0)) * sizeof(float);
   static const bool ok = hipFuncSetAttribute((const void *)sa_eval_kernel<IN, KA, KB, WAVES, PRO, EPI>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
   if (!ok || lds > 80 * 1024) return PN2_ELAUNCH;
@@ -565,8 +585,10 @@ extern "C" int pn2_sa_eval_x3(int mode, int B, int N, int m, int ns, int C, cons
   const int steps_mid = c_mid ? (c_mid / 32) * (c1 / 16) / kX3SlotUnits : 0;
   a.spp = steps_mid + a.steps_fin;
   hipStream_t st = (hipStream_t)stream;
-  if (ns >= 64) {
-    // the rows of a centre span several waves: they meet in an integer atomic maximum over the zero-filled result
+  const int waves = mode == 0 ? 8 : 4;
+  if (ns > 32 * waves) {
+    // more waves per centre than a workgroup has (group-all sized neighbourhoods): they meet in an integer atomic maximum over
+    // the zero-filled result; up to 32 x waves rows the waves of a centre meet in LDS and the result is stored once
     if (hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)c_out * 4, (size_t)a.ncentres, st) != hipSuccess) return PN2_ELAUNCH;
   }
   if (mode == 0 && c_mid == 64) return launch_eval<0, 4, 4, 8>(a, st);

@@ -96,6 +96,9 @@ SA_EVAL_CASES = [
     ("gf3d_sa3_lift16", 400, 256, 40, [0.8], [16], [[256, 128, 128, 256]], True),
     ("msg_sa2_lift", 512, 192, 48, [0.3, 0.5], [32, 64], [[192, 128, 128], [192, 128, 128]], False),
     ("ragged_tail", 700, 3, 37, [0.35], [16], [[3, 64, 64, 128]], False),     # 37 * 16 rows: a partial last pass
+    ("ns128_lift", 600, 128, 21, [0.9], [128], [[128, 128, 128, 256]], False),  # 4 waves per centre meet in LDS (4-wave workgroups)
+    ("ns256_small", 900, 3, 13, [1.2], [256], [[3, 64, 64, 128]], True),        # 8 waves per centre = the whole workgroup
+    ("ns512_small", 1200, 3, 5, [1.5], [512], [[3, 64, 64]], False),            # more than a workgroup: atomic maximum route
 ]
 
 
