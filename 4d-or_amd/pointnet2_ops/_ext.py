@@ -873,7 +873,9 @@ def x3_pack_weight(W, perm, out=None):
     if nbytes == 0:
         _fail("x3_pack_weight: N must be a multiple of 32 and K a multiple of 16")
     if out is None:
-        out = torch.zeros(nbytes, dtype=torch.uint8, device=W.device)
+        # (every unit is written by the kernel; the padding up to a whole ring slot is read by the weight stream's DMA but
+        # never used: no fill launch per call — the training GEMMs pack their weight on every call)
+        out = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
     elif out.numel() < nbytes or out.dtype != torch.uint8 or not out.is_contiguous():
         _fail("x3_pack_weight: `out` must be a contiguous uint8 tensor of x3_weight_bytes(N, K) bytes")
     _call("pn2_x3_pack_weight", W, N, K, K, int(bool(perm)), _ptr(W), _ptr(out))
