@@ -319,7 +319,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
 #pragma unroll
       for (int tl = 0; tl < TPS_FIN; ++tl) {
         const int t = jf * TPS_FIN + tl;
-        const float bv = ROWS ? 0.f : bfin[32 * t + l32];
+        // the last layer's bias is per channel = per LANE here: max_rows(x + b) = max_rows(x) + b, so it is added once behind
+        // the maximum (EPI_MAX) instead of initialising 16 accumulator registers per tile with it; the accumulators start at the
+        // matrix instruction's inline zero
+        const float bv = (ROWS || EPI == X3_EPI_MAX) ? 0.f : bfin[32 * t + l32];
+        const float bmax = (!ROWS && EPI == X3_EPI_MAX) ? bfin[32 * t + l32] : 0.f;
         x3_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bv;
@@ -434,8 +438,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
         float m0 = acc[0], m1 = acc[8];
 #pragma unroll
         for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, acc[r]); m1 = fmaxf(m1, acc[8 + r]); }
-        m0 = fmaxf(m0, __shfl_xor(m0, 32));
-        m1 = fmaxf(m1, __shfl_xor(m1, 32));
+        m0 = fmaxf(m0, __shfl_xor(m0, 32)) + bmax;
+        m1 = fmaxf(m1, __shfl_xor(m1, 32)) + bmax;
         const int col = 32 * t + l32;
         if (a.ns_shift == 4) {                             // two centres per wave: lower half stores the first, upper the second
           const long long centre = (row0 >> 4) + h;
