@@ -157,6 +157,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
   long long cur = blockIdx.x, nxt = (long long)blockIdx.x + gridDim.x;
   int parity = 0;
   int p_next = load_idx(cur);
+  int fstep = 0;       // last-layer steps so far, over all passes: its parity picks the meeting buffer (consecutive steps alternate
+                       // even across a pass boundary with an odd number of steps per pass)
   x3_frag actA[KA];
   x3_frag actB[KB ? KB : 1];
 
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
           const long long centre = row0 >> a.ns_shift;
           const float v = fmaxf(fmaxf(m0, m1), 0.f);
           if (meet) {
-            if (h == 0) spart[(((jf & 1) * WAVES + wave) * TPS_FIN + tl) * 32 + l32] = v;      // combined behind the step barrier
+            if (h == 0) spart[(((fstep & 1) * WAVES + wave) * TPS_FIN + tl) * 32 + l32] = v;      // combined behind the step barrier
           } else if (h == 0 && centre < a.ncentres) {
             float *o = a.out + (size_t)centre * a.ldo + col;
             if (a.ns_shift == 5) *o = v;
@@ -466,11 +468,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
 #pragma unroll
           for (int tl = 0; tl < TPS_FIN; ++tl) {
             float v = 0.f;
-            for (int w = 0; w < wpc; ++w) v = fmaxf(v, spart[(((jf & 1) * WAVES + wave + w) * TPS_FIN + tl) * 32 + l32]);
+            for (int w = 0; w < wpc; ++w) v = fmaxf(v, spart[(((fstep & 1) * WAVES + wave + w) * TPS_FIN + tl) * 32 + l32]);
             a.out[(size_t)centre * a.ldo + 32 * (jf * TPS_FIN + tl) + l32] = v;
           }
         }
       }
+      ++fstep;
     }
     cur = nxt;
     nxt = s_claim[parity];

@@ -99,6 +99,8 @@ SA_EVAL_CASES = [
     ("ns128_lift", 600, 128, 21, [0.9], [128], [[128, 128, 128, 256]], False),  # 4 waves per centre meet in LDS (4-wave workgroups)
     ("ns256_small", 900, 3, 13, [1.2], [256], [[3, 64, 64, 128]], True),        # 8 waves per centre = the whole workgroup
     ("ns512_small", 1200, 3, 5, [1.5], [512], [[3, 64, 64]], False),            # more than a workgroup: atomic maximum route
+    ("ns64_one_step", 2000, 3, 150, [0.6], [64], [[3, 64, 64]], False),         # ONE last-layer step per pass, no middle layer: the
+                                                                                # meeting buffers must alternate across passes
 ]
 
 
