@@ -134,39 +134,69 @@ __global__ __launch_bounds__(kBlock) void group_rows_grad_csr_any_kernel(int C, 
 //   are found with a bit-sliced match (one ballot per key bit), their rank among equals is a masked popcount — rows of a
 //   point therefore land in ascending row order, exactly the stable sort's result, with no atomics in the placement and a
 //   summation order in the consumers that is fixed by construction (bit-reproducible like the sort's).
-// LDS: W x N cursors; W = min(16, 36864 / N) waves (N <= 36864 points per cloud; larger clouds keep the radix sort).
+// LDS: W x Ns cursors, W = min(16, 36864 / Ns) waves, Ns = the points of one slice of the cloud (round 6; the radix sort
+// remains as the route when the 144 KB LDS attribute is refused or PN2_INVERSE_INDEX_RADIX=1).
 constexpr int kInvLdsInts = 36864;      // 144 KB of cursors
+constexpr int kInvBatch = 8;            // 64-row steps whose index loads are in flight together
 
-__global__ __launch_bounds__(1024) void inv_cloud_kernel(int N, int P, int W, int nbits, int last_cloud,
+__global__ __launch_bounds__(1024) void inv_cloud_kernel(int N, int P, int W, int nbits, int last_cloud, int S, int Ns,
                                                          const int *__restrict__ idx, int *__restrict__ ptr,
                                                          int *__restrict__ refs) {
-  extern __shared__ int cur[];            // [W][N]
+  // round 6: a cloud's POINTS are cut into S slices of Ns, one workgroup per (cloud, slice).  Every workgroup walks all rows
+  // of its cloud but counts / places only the keys of its slice; where its slice starts in `refs` is the number of rows with
+  // a smaller key, which it counts on the way — no dependency between workgroups.  S = 1 is the round-5 kernel.  Slices put
+  // B S workgroups on the chip instead of B and lift the 36864-point limit (LDS holds W x Ns cursors).
+  extern __shared__ int cur[];            // [W][Ns]
   __shared__ int wsum[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, T = blockDim.x;
-  const int b = blockIdx.x;
+  // workgroups are dealt to the 8 XCDs round-robin: the slices of a cloud are given ids that share an XCD, so the cloud's rows
+  // are read into ONE L2 (not eight) and found there by the other slices
+  const int nwg = gridDim.x, per = nwg >> 3;
+  const int v = (int)blockIdx.x < 8 * per ? ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int b = v / S, sl = v - b * S;
+  const int k0 = sl * Ns, nk = N - k0 < Ns ? N - k0 : Ns;
   const int *I = idx + (size_t)b * P;
   const int chunk = (((P + W - 1) / W) + 63) & ~63;          // rows per wave, whole steps of 64
   const int r0 = wv * chunk, r1 = r0 + chunk < P ? r0 + chunk : P;
-  for (int i = tid; i < W * N; i += T) cur[i] = 0;
+  for (int i = tid; i < W * Ns; i += T) cur[i] = 0;
   if (tid == 0) carry = 0;
   __syncthreads();
-  // (1) histogram of the wave's chunk (LDS integer atomics: order-free)
-  for (int r = r0 + lane; r < r1; r += 64) {
-    const unsigned k = (unsigned)I[r];
-    atomicAdd(&cur[wv * N + (int)(k < (unsigned)N ? k : (unsigned)N - 1u)], 1);
+  // (1) histogram of the wave's chunk (LDS integer atomics: order-free); rows below the slice are only counted
+  //     (kInvBatch steps of 64 rows per trip, their loads issued together: the walk is latency-bound — 16 waves on a CU)
+  int below = 0;
+  for (int rb = r0; rb < r1; rb += 64 * kInvBatch) {
+    unsigned kq[kInvBatch];
+#pragma unroll
+    for (int j = 0; j < kInvBatch; ++j) {
+      const int r = rb + 64 * j + lane;
+      kq[j] = r < r1 ? (unsigned)I[r] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int j = 0; j < kInvBatch; ++j) {
+      if (rb + 64 * j + lane >= r1) continue;
+      const unsigned k = kq[j] < (unsigned)N ? kq[j] : (unsigned)N - 1u;
+      const unsigned kk = k - (unsigned)k0;
+      if (kk < (unsigned)nk) atomicAdd(&cur[wv * Ns + (int)kk], 1);
+      below += (int)k < k0;
+    }
+  }
+  if (S > 1) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
+    if (lane == 0 && below) atomicAdd(&carry, below);
   }
   __syncthreads();
   // (2) cursors: keys in tiles of T (thread = key: conflict-free), per key an exclusive prefix over the waves, over the keys a
   //     block scan carried from tile to tile
-  int *P_ = ptr + (size_t)b * N;
-  for (int kb = 0; kb < N; kb += T) {
+  int *P_ = ptr + (size_t)b * N + k0;
+  for (int kb = 0; kb < nk; kb += T) {
     const int k = kb + tid;
     int tot = 0;
-    if (k < N) {
+    if (k < nk) {
       for (int w = 0; w < W; ++w) {
-        const int c = cur[w * N + k];
-        cur[w * N + k] = tot;
+        const int c = cur[w * Ns + k];
+        cur[w * Ns + k] = tot;
         tot += c;
       }
     }
@@ -180,22 +210,20 @@ __global__ __launch_bounds__(1024) void inv_cloud_kernel(int N, int P, int W, in
     __syncthreads();
     int base = carry + inc - tot;
     for (int w = 0; w < wv; ++w) base += wsum[w];
-    if (k < N) {
+    if (k < nk) {
       P_[k] = b * P + base;
-      for (int w = 0; w < W; ++w) cur[w * N + k] += base;
+      for (int w = 0; w < W; ++w) cur[w * Ns + k] += base;
     }
     __syncthreads();
     if (tid == T - 1) carry = base + tot;                    // (the last thread's exclusive base + its own count = tile total)
     __syncthreads();
   }
-  if (b == last_cloud && tid == 0) ptr[(size_t)(b + 1) * N] = (b + 1) * P;
+  if (b == last_cloud && sl == S - 1 && tid == 0) ptr[(size_t)(b + 1) * N] = (b + 1) * P;
   // (3) placement in row order
   int *R = refs + (size_t)b * P;
-  for (int rb = r0; rb < r1; rb += 64) {                     // wave-uniform trip count
-    const int r = rb + lane;
-    const bool ok = r < r1;
-    unsigned k = ok ? (unsigned)I[r] : 0u;
-    k = k < (unsigned)N ? k : (unsigned)N - 1u;
+  // One step: up to 64 (key, row) pairs of the slice, in row order: lanes with equal keys are found with a bit-sliced match, ranked
+  // by a masked popcount and placed behind the key's cursor.
+  auto place = [&](unsigned k, int r, bool ok) {
     u64 same = __ballot(ok);
     for (int bit = 0; bit < nbits; ++bit) {
       const bool set = (k >> bit) & 1u;
@@ -204,11 +232,77 @@ __global__ __launch_bounds__(1024) void inv_cloud_kernel(int N, int P, int W, in
     }
     if (ok) {
       const int rank = pn2_prefix_popc(same);
-      const int at = cur[wv * N + (int)k];
-      if (rank == 0) cur[wv * N + (int)k] = at + __popcll(same);
+      const int at = cur[wv * Ns + (int)k];
+      if (rank == 0) cur[wv * Ns + (int)k] = at + __popcll(same);
       R[at + rank] = b * P + r;
     }
+  };
+  // With slices only 1 / S of the rows belong to this workgroup: they are first COMPACTED (order kept) into a 128-entry queue of
+  // the wave in LDS — a ballot and a popcount per step — and a placement step runs per 64 queued rows (the match costs ~100
+  // instructions per step, the walk is issue-bound: without the queue S workgroups would each pay it for every row).
+  int2 *queue = (int2 *)(cur + ((W * Ns + 1) & ~1)) + wv * 128;
+  int qn = 0;
+  for (int rb4 = r0; rb4 < r1; rb4 += 64 * kInvBatch) {                 // wave-uniform trip count; kInvBatch steps' keys loaded together
+    unsigned kq[kInvBatch];
+#pragma unroll
+    for (int j = 0; j < kInvBatch; ++j) {
+      const int r = rb4 + 64 * j + lane;
+      kq[j] = r < r1 ? (unsigned)I[r] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kInvBatch; ++j) {
+      const int r = rb4 + 64 * j + lane;
+      const unsigned k = (kq[j] < (unsigned)N ? kq[j] : (unsigned)N - 1u) - (unsigned)k0;
+      const bool ok = r < r1 && k < (unsigned)nk;
+      if (S == 1) {
+        place(k, r, ok);
+        continue;
+      }
+      const u64 in = __ballot(ok);
+      if (in == 0) continue;                                 // (wave-uniform)
+      if (ok) queue[qn + pn2_prefix_popc(in)] = make_int2((int)k, r);
+      qn += __popcll(in);
+      __builtin_amdgcn_wave_barrier();
+      if (qn >= 64) {
+        const int2 e = queue[lane];
+        const int2 up = queue[64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        qn -= 64;
+        if (lane < qn) queue[lane] = up;
+        __builtin_amdgcn_wave_barrier();
+        place((unsigned)e.x, e.y, true);
+      }
+    }
   }
+  if (qn > 0) {
+    const int2 e = lane < qn ? queue[lane] : make_int2(0, 0);
+    place((unsigned)e.x, e.y, lane < qn);
+  }
+}
+
+// Slices of a cloud's points: B S workgroups of about one per CU when the cloud has rows enough to share out (a workgroup
+// walks every row of its cloud: slices of fewer than 256 points or clouds of fewer than 8192 rows stay whole), W x Ns cursors
+// + the waves' queues within the 144 KB of LDS.
+constexpr int kInvQueueInts = 16 * 128 * 2 + 2;   // (+ the padding that aligns the queues to 8 bytes)
+inline void inv_slices(int B, int N, int P, int *S, int *Ns) {
+  int s = 1;
+  if (P >= 8192) {
+    s = 256 / B;                                               // about a workgroup per CU ...
+    const int full = (N + 2046) / 2047;                        // ... and 16 waves in each (16 x 2047 cursors fill the LDS)
+    s = s > full ? s : full;
+  }
+  const char *e = getenv("PN2_INVERSE_INDEX_SLICES");
+  if (e && e[0] >= '1' && e[0] <= '9') s = atoi(e);
+  if (s > (N + 255) / 256) s = (N + 255) / 256;
+  while (s > 1 && (long)B * s > 4096) --s;
+  if (s < 1) s = 1;
+  int ns = (N + s - 1) / s;
+  while (ns > (s > 1 ? kInvLdsInts - kInvQueueInts : kInvLdsInts)) {
+    ++s;
+    ns = (N + s - 1) / s;
+  }
+  *S = (N + ns - 1) / ns;
+  *Ns = ns;
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -229,8 +323,11 @@ inline hipError_t sort_temp_bytes(size_t rows, int bits, size_t *bytes) {
 // (the query used to promise 256 bytes for N <= kInvLdsInts while the entry could still fall through to the
 // radix sort when the 144 KB dynamic-LDS attribute was refused, and sort into a 256-byte workspace).  The attribute is asked
 // for once per process; PN2_INVERSE_INDEX_RADIX=1 (read on every call: tests flip it) forces the sort route.
-bool inv_use_lds(int N) {
-  if (N > kInvLdsInts) return false;
+bool inv_use_lds(int B, int N, double P) {
+  // every slice's workgroup walks all P rows of its cloud: B N P / (64 x 32768 cursors x 256 CUs) steps of ~0.55 us per CU
+  // (measured, tools/diag/inv_slices_time.py: 8 x 50000 x 131072 -> 55 us, 32 x 50000 x 131072 -> 217 us) against the
+  // sort's ~160 us + 2.5 us per million rows: beyond 1.2e11 the sort is the faster route
+  if ((double)B * (double)N * P > 1.2e11) return false;
   static const bool lds_ok = hipFuncSetAttribute((const void *)inv_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  kInvLdsInts * 4) == hipSuccess;
   if (!lds_ok) return false;
@@ -241,7 +338,7 @@ bool inv_use_lds(int N) {
 
 extern "C" size_t pn2_group_inverse_index_workspace_bytes(int B, int N, int m, int ns) {
   if (B <= 0 || N <= 0 || m <= 0 || ns <= 0) return 0;
-  if (inv_use_lds(N)) return 256;                              // one-launch counting sort in LDS: no scratch (a token size)
+  if (inv_use_lds(B, N, (double)m * ns)) return 256;                              // one-launch counting sort in LDS: no scratch (a token size)
   const size_t rows = (size_t)B * m * ns;
   size_t temp = 0;
   if (sort_temp_bytes(rows, key_bits((size_t)B * N), &temp) != hipSuccess) return 0;
@@ -261,7 +358,7 @@ extern "C" int pn2_group_inverse_index(int B, int N, int m, int ns, const int *i
   size_t temp = 0;
   const size_t seg = align256(rows * 4);
   if ((((size_t)workspace) & 255) != 0) return PN2_EINVAL;
-  const bool lds = inv_use_lds(N);
+  const bool lds = inv_use_lds(B, N, (double)m * ns);
   if (lds) {
     if (workspace_bytes < 256) return PN2_ENOSPC;
   } else {
@@ -271,12 +368,16 @@ extern "C" int pn2_group_inverse_index(int B, int N, int m, int ns, const int *i
   if (lds) {
     // one launch: a stable counting sort per cloud in LDS (inv_cloud_kernel); the workspace is not touched
     const int P = m * ns;
-    int W = kInvLdsInts / N;
+    int S, Ns;
+    inv_slices(B, N, P, &S, &Ns);
+    const int room = S > 1 ? kInvLdsInts - kInvQueueInts : kInvLdsInts;
+    int W = room / Ns;
     W = W > 16 ? 16 : W;
     const int steps = (P + 63) / 64;                          // no more waves than 64-row steps
     W = W > steps ? steps : W;
-    hipLaunchKernelGGL(inv_cloud_kernel, dim3((unsigned)B), dim3(64u * W), (size_t)W * N * sizeof(int), (hipStream_t)stream, N,
-                       P, W, key_bits((size_t)N), B - 1, idx, ptr, refs);
+    hipLaunchKernelGGL(inv_cloud_kernel, dim3((unsigned)(B * S)), dim3(64u * W),
+                       ((size_t)W * Ns + (S > 1 ? kInvQueueInts : 0)) * sizeof(int), (hipStream_t)stream, N, P, W,
+                       key_bits((size_t)Ns), B - 1, S, Ns, idx, ptr, refs);
     return pn2_check_launch();
   }
   unsigned *keys_in = (unsigned *)workspace;
@@ -333,4 +434,41 @@ extern "C" int pn2_group_rows_grad_csr(int B, int N, int C, int ldg, int col0, i
 extern "C" int pn2_group_rows_grad_csr_bf16(int B, int N, int C, int ldg, int col0, int64_t rows, const void *grad_out,
                                             const int *ptr, const int *refs, float *grad_feats, void *stream) {
   return launch_rows_grad_csr<true>(B, N, C, ldg, col0, rows, grad_out, ptr, refs, grad_feats, stream);
+}
+
+// ---- the LITERAL op's gradient as a gather (round 6) ------------------------------------------------------------------
+// group_points_grad_kernel of the reference (EXT/src/group_points_gpu.cu:43-64) adds every gradient element to its point with
+// an fp32 atomic: B C m ns device-scope atomics (12.6 M at the C = 3 micro shape: 0.62 ms = 0.0175 of 8 TB/s), in an order that
+// changes from run to run.  Through the inverse index (ptr / refs of pn2_group_inverse_index over idx (B, m ns)) every point
+// sums ITS rows in ascending row order: no atomics, every output element written once, bit-reproducible.
+// Channel-major layouts of the reference: grad_out (B, C, S = m ns), grad_points (B, C, N).  Lane = point (coalesced stores).
+__global__ __launch_bounds__(256) void group_points_grad_csr_kernel(int C, int N, unsigned S, unsigned npoints,
+                                                                   const float *__restrict__ grad_out,
+                                                                   const int *__restrict__ ptr, const int *__restrict__ refs,
+                                                                   float *__restrict__ grad_points) {
+  for (unsigned g = blockIdx.x * 256 + threadIdx.x; g < npoints; g += gridDim.x * 256) {
+    const unsigned b = g / (unsigned)N, n = g - b * (unsigned)N;
+    const int p0 = ptr[g], p1 = ptr[g + 1];
+    const float *G = grad_out + (size_t)b * C * S;
+    float *O = grad_points + (size_t)b * C * N + n;
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+      for (int p = p0; p < p1; ++p) acc = __fadd_rn(acc, G[(size_t)c * S + ((unsigned)refs[p] - b * S)]);
+      O[(size_t)c * N] = acc;
+    }
+  }
+}
+
+extern "C" int pn2_group_points_grad_csr(int B, int C, int N, int npoints, int nsample, const float *grad_out, const int *ptr,
+                                         const int *refs, float *grad_points, void *stream) {
+  if (B < 0 || C < 0 || N < 0 || npoints < 0 || nsample < 0) return PN2_EINVAL;
+  const size_t S = (size_t)npoints * nsample, total = (size_t)B * N;
+  if (total == 0 || C == 0) return PN2_OK;
+  if (total >= 0x7fffffffull || (size_t)B * S >= 0x7fffffffull) return PN2_EINVAL;
+  if (!ptr || !grad_points || (S > 0 && (!grad_out || !refs))) return PN2_ENULL;
+  unsigned grid = (unsigned)((total + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(group_points_grad_csr_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, (unsigned)S, (unsigned)total,
+                     grad_out, ptr, refs, grad_points);
+  return pn2_check_launch();
 }

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "pn2_bn_running_update": [_c_int, _c_int, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
     "pn2_x3_pack_weight": [_c_int] * 4 + [_c_vp] * 3,
+    "pn2_group_points_grad_csr": [_c_int] * 5 + [_c_vp] * 5,
     "pn2_x3_gemm": [ctypes.c_longlong] + [_c_int] * 4 + [_c_vp] * 13 + [_c_int, _c_vp, _c_vp],
     "pn2_sa_eval_x3": [_c_int] * 6 + [_c_vp] * 5 + [_c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp],
     "pn2_group_rows_grad_csr": [_c_int] * 5 + [_c_i64] + [_c_vp] * 5,
@@ -633,11 +634,23 @@ def group_points(points, idx):
     return out
 
 
+#: the literal group_points_grad through the inverse neighbourhood index (bit-reproducible, no atomics); PN2_GROUP_GRAD_CSR=0
+#: restores the reference's atomic scatter
+GROUP_GRAD_CSR = os.environ.get("PN2_GROUP_GRAD_CSR", "1") != "0"
+
+
 def group_points_grad(grad_out, idx, n):
     """(B,C,npoints,nsample) -> (B,C,n).  EXT/src/group_points.cpp:39-62."""
     _f32(grad_out, "grad_out"); _i32(idx, "idx")
     _same_device((grad_out, "grad_out"), (idx, "idx"))
     B, C, npoints, nsample = grad_out.shape
+    if GROUP_GRAD_CSR and B * C * npoints * nsample > 0 and int(n) > 0:
+        # deterministic form: every point sums its rows in row order through the inverse index (no atomics, no zero fill)
+        ptr, refs = group_inverse_index(idx, int(n))
+        out = torch.empty(B, C, int(n), dtype=torch.float32, device=grad_out.device)
+        _call("pn2_group_points_grad_csr", grad_out, B, C, int(n), npoints, nsample, _ptr(grad_out), _ptr(ptr), _ptr(refs), _ptr(out),
+              alg_bytes=B * (4 * npoints * nsample + 4 * C * npoints * nsample + 4 * C * int(n)), label="pn2_group_points_grad")
+        return out
     out = torch.zeros(B, C, int(n), dtype=torch.float32, device=grad_out.device)
     _call("pn2_group_points_grad", grad_out, B, C, int(n), npoints, nsample,
           _ptr(grad_out), _ptr(idx), _ptr(out),

@@ -701,8 +701,9 @@ int pn2_segment_sum_rows(int64_t E, int H, int64_t N, int lds, int col0,
 /* The feature-gradient scatter of QueryAndGroup as a gather (csrc/group_csr.hip; replaces the atomic form of
  * group_points_grad_kernel, src/group_points_gpu.cu:44-75, where a prefetched neighbourhood index is available).
  *   pn2_group_inverse_index : idx (B,m,ns) int32 -> refs (B*m*ns) = row ids (b*m + j)*ns + s sorted by
- *       (b*N + idx[row], row) [clouds of N <= 36864 points: ONE launch, a stable counting sort per cloud in LDS, idx values
- *       clamped to [0, N); larger clouds: a stable radix sort] and ptr (B*N + 1): refs[ptr[p] : ptr[p+1]] are the rows that gathered
+ *       (b*N + idx[row], row) [ONE launch: a stable counting sort in LDS, one workgroup per (cloud, slice of its points), idx
+ *       values clamped to [0, N); a stable radix sort when B N m ns > 1.2e11 or the 144 KB of LDS are refused — the workspace
+ *       query tells which] and ptr (B*N + 1): refs[ptr[p] : ptr[p+1]] are the rows that gathered
  *       point p = b*N + n.  `workspace`: 256-byte aligned device scratch of at least
  *       pn2_group_inverse_index_workspace_bytes(B, N, m, ns) bytes (PN2_ENOSPC if smaller); B*m*ns and B*N < 2^31.
  *   pn2_group_rows_grad_csr : grad_feats (B,N,C) = sum over refs of grad_out[row, col0 : col0+C]  (grad_out (rows, ldg)
@@ -891,6 +892,13 @@ int pn2_x3_gemm_supported(int K, int N, int pro, int epi, int ns);
 int pn2_x3_gemm(long long M, int K, int N, int pro, int epi, const float *X, const float *X2, const float *p0, const float *p1,
                 const float *p2, const void *wfrags, float *Y, double *stats, const float *Yprev, const float *e_fin, float *pmax,
                 int *parg, const float *sgn, int ns, void *workspace, void *stream);
+
+/* The literal op's gradient (EXT/src/group_points_gpu.cu:43-64: one fp32 atomicAdd per gradient element) as a gather through
+ * the inverse of idx: (ptr, refs) = pn2_group_inverse_index(B, N, npoints, nsample, idx).  grad_out (B, C, npoints, nsample),
+ * grad_points (B, C, N): EVERY element written (no zero fill), a point's rows summed in ascending row order — no atomics,
+ * bit-reproducible.  What `pointnet2_ops._ext.group_points_grad` runs (the atomic form stays exported as pn2_group_points_grad). */
+int pn2_group_points_grad_csr(int B, int C, int N, int npoints, int nsample, const float *grad_out, const int *ptr,
+                              const int *refs, float *grad_points, void *stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

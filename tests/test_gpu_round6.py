@@ -278,3 +278,58 @@ def test_ball_query_slab_widths_are_bit_exact(B, N, m, r, ns, kind, w, monkeypat
     finally:
         _ext.BALL_QUERY_GRID = prev
     assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("B,C,N,m,ns", [(2, 3, 100, 10, 4), (3, 7, 5000, 640, 16), (2, 131, 300, 40, 8), (2, 3, 50000, 4096, 32),
+                                        (1, 16, 36864, 2048, 64), (2, 5, 40000, 37, 3)])
+def test_literal_group_points_grad_is_a_gather_and_bit_reproducible(B, C, N, m, ns):
+    """`_ext.group_points_grad` (EXT/src/group_points_gpu.cu:43-64) through the inverse index: the oracle's sums (float64
+    here: the reference's atomic order is not defined), identical bits from run to run and from the clustered to the uniform
+    index pattern's both routes of the inverse index (LDS histogram up to 36864 points, radix sort beyond), points no
+    neighbourhood references left at zero; the atomic form of the C ABI agrees to rounding."""
+    from pointnet2_ops import _ext
+    g = torch.Generator().manual_seed(B * C + N)
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    idx[:, : m // 2] = idx[:, : m // 2] % max(1, N // 50)               # crowded points: long reference lists
+    go = torch.randn(B, C, m, ns, generator=g)
+    want = torch.zeros(B, C, N, dtype=torch.float64)
+    want.scatter_add_(2, idx.view(B, 1, -1).expand(-1, C, -1).long(), go.view(B, C, -1).double())
+    a = _ext.group_points_grad(go.cuda(), idx.cuda(), N)
+    b = _ext.group_points_grad(go.cuda(), idx.cuda(), N)
+    assert torch.equal(a, b)
+    scale = float(want.abs().max())
+    assert float((a.cpu().double() - want).abs().max()) < 2e-6 * scale * max(1.0, (m * ns / max(1, N // 50)) ** 0.5)
+    untouched = torch.ones(B, N, dtype=torch.bool)
+    untouched.scatter_(1, idx.view(B, -1).long(), False)
+    assert float(a.cpu().transpose(1, 2)[untouched].abs().max() if untouched.any() else 0.0) == 0.0
+    prev = _ext.GROUP_GRAD_CSR
+    _ext.GROUP_GRAD_CSR = False
+    try:
+        c = _ext.group_points_grad(go.cuda(), idx.cuda(), N)
+    finally:
+        _ext.GROUP_GRAD_CSR = prev
+    torch.testing.assert_close(c, a, atol=1e-4 * scale, rtol=1e-4)
+
+
+@pytest.mark.parametrize("slices", [None, "1", "3", "9"])
+@pytest.mark.parametrize("B,N,m,ns", [(8, 50000, 2048, 64), (32, 50000, 2048, 64), (2, 36865, 100, 64), (3, 8193, 512, 16), (2, 100000, 333, 20), (5, 4000, 512, 16),
+                                      (2, 9, 4, 3), (700, 9000, 4, 8)])
+def test_inverse_index_point_slices_equal_a_stable_sort(B, N, m, ns, slices, monkeypatch):
+    """csrc/group_csr.hip inv_cloud_kernel with a cloud's points cut into slices (one workgroup per (cloud, slice); default
+    above 8192 points, forced here through PN2_INVERSE_INDEX_SLICES — more slices than points, more workgroups than the 4096
+    cap and slices wider than the LDS are all corrected by the launcher): (ptr, refs) of a stable sort by (cloud, point)."""
+    from pointnet2_ops import _ext
+    if slices is not None:
+        monkeypatch.setenv("PN2_INVERSE_INDEX_SLICES", slices)
+    g = torch.Generator().manual_seed(B * 1000 + N + m + ns)
+    idx = torch.randint(0, N, (B, m, ns), generator=g, dtype=torch.int32)
+    idx[:, ::2, ns // 2:] = idx[:, ::2, :1]
+    if B > 1:
+        idx[1] = N - 1                                                # one point (of the LAST slice) holds every row of a cloud
+    idx[0, :, 0] = idx[0, 0, 0]
+    ptr, refs = _ext.group_inverse_index(idx.cuda(), N)
+    keys = (idx.long() + torch.arange(B).view(B, 1, 1) * N).flatten()
+    assert torch.equal(refs.cpu().long(), torch.sort(keys, stable=True).indices)
+    want_ptr = torch.zeros(B * N + 1, dtype=torch.long)
+    want_ptr[1:] = torch.cumsum(torch.bincount(keys, minlength=B * N), 0)
+    assert torch.equal(ptr.cpu().long(), want_ptr)
