@@ -3,7 +3,7 @@
 
 thread_local int pn2_tls_hip_error = 0;
 
-extern "C" int pn2_abi_version(void) { return 10; }   // bumped whenever entry points are added (round number)
+extern "C" int pn2_abi_version(void) { return 11; }   // bumped whenever entry points are added
 
 extern "C" int pn2_last_hip_error(void) { return pn2_tls_hip_error; }
 

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
       bmid[i] = a.bias_mid[32 * T + (r & 3) + 8 * (r >> 2) + 4 * hh];
     }
   if (!ROWS)
-    for (int i = tid; i < a.c_out; i += THREADS) bfin[i] = a.bias_fin[i];
+    for (int i = tid; i < a.c_out; i += THREADS) bfin[i] = a.bias_fin ? a.bias_fin[i] : 0.f;
   if (ROWS && PRO != X3_PRO_NONE)
     for (int i = tid; i < 16 * KA; i += THREADS) {
       prm[i] = a.p0[i];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
   // neighbourhood index of this lane's row, loaded one pass ahead (the gathers depend on it: one L2 round trip less per pass)
   auto load_idx = [&](long long pass) {
     const long long row = pass * PASS + wave * 32 + l32;
-    return (!ROWS && pass < npass && row < a.Mrows) ? a.idx[row] : 0;
+    return (!ROWS && a.idx && pass < npass && row < a.Mrows) ? a.idx[row] : 0;
   };
   long long cur = blockIdx.x, nxt = (long long)blockIdx.x + gridDim.x;
   int parity = 0;
@@ -240,18 +240,28 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void sa_eval_kernel(const Ev
         }
       } else if (SMALL) {
         const int K0 = 3 + a.C;                           // bias column
-        const float *fx = a.xyz + pt * 3, *cx = a.new_xyz + (size_t)centre * 3, *ff = a.feats + pt * a.C;
         float v[8];
+        if (a.X) {
+          // pn2_x3_gemm_first: the grouped rows are given ([rel xyz | features] x K0 <= 8 columns, (M, K0) row-major)
+          const float *xr = a.X + (size_t)(valid ? row : 0) * K0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int col = 8 * h + i;
-          float val = 0.f;
-          if (valid) {
-            if (col < 3) val = fx[col] - cx[col];         // the reference's in-place subtraction (OPS/pointnet2_utils.py:321)
-            else if (col < K0) val = ff[col - 3];
-            else if (col == K0) val = 1.f;
+          for (int i = 0; i < 8; ++i) {
+            const int col = 8 * h + i;
+            v[i] = !valid ? 0.f : (col < K0 ? xr[col < K0 ? col : 0] : (col == K0 ? 1.f : 0.f));
           }
-          v[i] = val;
+        } else {
+          const float *fx = a.xyz + pt * 3, *cx = a.new_xyz + (size_t)centre * 3, *ff = a.feats + pt * a.C;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int col = 8 * h + i;
+            float val = 0.f;
+            if (valid) {
+              if (col < 3) val = fx[col] - cx[col];         // the reference's in-place subtraction (OPS/pointnet2_utils.py:321)
+              else if (col < K0) val = ff[col - 3];
+              else if (col == K0) val = 1.f;
+            }
+            v[i] = val;
+          }
         }
         x3_frag xin;
         x3_split8(v, xin);
@@ -517,6 +527,24 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(int N, int K, int ldw, int
   }
 }
 
+// The FIRST layer of a training stack with its BatchNorm folded in: M0 (N0, 16) = [diag(scale) W0 | shift | 0] -> N0 / 32 units
+// (one chunk, natural contraction order), the resident first-layer table of the IN_SMALL input stage.
+__global__ __launch_bounds__(64) void x3_pack_first_kernel(int N0, int K0, const float *__restrict__ W0,
+                                                           const float *__restrict__ scale, const float *__restrict__ shift,
+                                                           x3_u32x4 *__restrict__ out) {
+  const int t = blockIdx.x, lane = threadIdx.x, n = 32 * t + (lane & 31), h = lane >> 5;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int col = 8 * h + i;
+    v[i] = col < K0 ? W0[(size_t)n * K0 + col] * scale[n] : (col == K0 ? shift[n] : 0.f);
+  }
+  x3_frag f;
+  x3_split8(v, f);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) out[(size_t)t * 192 + s * 64 + lane] = f.p[s];
+}
+
 template <int IN, int KA, int KB, int WAVES, int PRO = 0, int EPI = 0>
 int launch_eval(const EvalArgs &a, hipStream_t stream) {
   constexpr int W0_BYTES = IN == 0 ? (KA / 2) * kX3UnitBytes : 0;
@@ -652,4 +680,41 @@ extern "C" int pn2_x3_gemm(long long M, int K, int N, int pro, int epi, const fl
   if (pro == X3_PRO_GY) PN2_X3G(8, 4, X3_PRO_GY, X3_EPI_MASK);
   PN2_X3G(8, 4, X3_PRO_NONE, X3_EPI_STATS);
 #undef PN2_X3G
+}
+
+// pn2_mlp_gemm_first on the f32x3 product: Y (M, N) = relu(bn_0(X0 W0^T)) W^T + the column sums of Y, Y^2 — the second layer of a
+// training stack with the first one re-formed from the grouped input rows (y_0 is never stored).  bn_0 is folded into the first
+// layer's fragments (`w0_frags` of pn2_x3_pack_first: scale_0 W0 | shift_0 in the bias column), the products run through the
+// eval level's chain (IN_SMALL input stage on stored rows, no middle layer, store + sums epilogue).
+extern "C" int pn2_x3_gemm_first_supported(int K0, int K, int N) {
+  if (K0 < 1 || K0 > 8 || K != 64) return 0;
+  if (N <= 0 || (N & 31) || ((N / 32) * (K / 16)) % kX3SlotUnits != 0 || N > 4096) return 0;
+  return 1;
+}
+
+extern "C" int pn2_x3_pack_first(int N0, int K0, const float *W0, const float *scale, const float *shift, void *frags,
+                                 void *stream) {
+  if (N0 <= 0 || (N0 & 31) || K0 < 1 || K0 > 8) return PN2_EINVAL;
+  if (!W0 || !scale || !shift || !frags) return PN2_ENULL;
+  if ((((size_t)frags) & 15) != 0) return PN2_EINVAL;
+  hipLaunchKernelGGL(x3_pack_first_kernel, dim3(N0 / 32), dim3(64), 0, (hipStream_t)stream, N0, K0, W0, scale, shift,
+                     (x3_u32x4 *)frags);
+  return pn2_check_launch();
+}
+
+extern "C" int pn2_x3_gemm_first(long long M, int K0, int K, int N, const float *X0, const void *w0_frags, const void *wfrags,
+                                 float *Y, double *stats, void *workspace, void *stream) {
+  if (M < 0 || !pn2_x3_gemm_first_supported(K0, K, N)) return PN2_EINVAL;
+  if (M == 0) return PN2_OK;
+  if (!X0 || !w0_frags || !wfrags || !Y || !workspace) return PN2_ENULL;
+  EvalArgs a{};
+  a.next_pass = (unsigned *)workspace;
+  a.X = X0;
+  a.w0 = (const unsigned char *)w0_frags; a.wstream = (const unsigned char *)wfrags;
+  a.Y = Y; a.stats = stats;
+  a.Mrows = M; a.ncentres = M; a.m = 1; a.N = 1; a.C = K0 - 3; a.c_out = N; a.ldo = N;
+  a.ns_shift = 5;
+  a.steps_fin = (N / 32) * (K / 16) / kX3SlotUnits;
+  a.spp = a.steps_fin;
+  return launch_eval<X3_IN_SMALL, 4, 0, 8, X3_PRO_NONE, X3_EPI_STATS>(a, (hipStream_t)stream);
 }

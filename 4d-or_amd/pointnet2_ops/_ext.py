@@ -38,8 +38,9 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.pn2_abi_version.restype = ctypes.c_int
-if int(_lib.pn2_abi_version()) != 10:
-    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs 10: "
+_ABI = 11
+if int(_lib.pn2_abi_version()) != _ABI:
+    raise ImportError(f"pointnet2_ops._ext: {LIB_PATH} has ABI version {int(_lib.pn2_abi_version())}, this binding needs {_ABI}: "
                       f"rebuild it (`make -C {os.path.join(_PKG_DIR, 'csrc')}`)")
 
 _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -67,6 +68,8 @@ _SIGNATURES = {
     "pn2_bn_running_update": [_c_int, _c_int, _c_vp, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp],
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
     "pn2_x3_pack_weight": [_c_int] * 4 + [_c_vp] * 3,
+    "pn2_x3_pack_first": [_c_int] * 2 + [_c_vp] * 5,
+    "pn2_x3_gemm_first": [ctypes.c_longlong] + [_c_int] * 3 + [_c_vp] * 7,
     "pn2_group_points_grad_csr": [_c_int] * 5 + [_c_vp] * 5,
     "pn2_x3_gemm": [ctypes.c_longlong] + [_c_int] * 4 + [_c_vp] * 13 + [_c_int, _c_vp, _c_vp],
     "pn2_sa_eval_x3": [_c_int] * 6 + [_c_vp] * 5 + [_c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp],
@@ -255,6 +258,8 @@ _lib.pn2_sa_eval_x3_supported.argtypes = [_c_int] * 6
 _lib.pn2_sa_eval_x3_supported.restype = _c_int
 _lib.pn2_x3_gemm_supported.argtypes = [_c_int] * 5
 _lib.pn2_x3_gemm_supported.restype = _c_int
+_lib.pn2_x3_gemm_first_supported.argtypes = [_c_int] * 3
+_lib.pn2_x3_gemm_first_supported.restype = _c_int
 _lib.pn2_abi_version.restype = _c_int
 _lib.pn2_last_hip_error.restype = _c_int
 _lib.pn2_strerror.argtypes = [_c_int]
@@ -263,7 +268,7 @@ _lib.pn2_strerror.restype = ctypes.c_char_p
 ABI_VERSION = int(_lib.pn2_abi_version())
 #: the header revision this binding was written against: a stale prebuilt libpn2_hip.so fails here with a version
 #: error instead of an AttributeError on the first missing symbol
-EXPECTED_ABI_VERSION = 10
+EXPECTED_ABI_VERSION = _ABI
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_abi_version", "pn2_fps_coop_status",
                                                "pn2_fps_status_offset", "pn2_fps_status_offset_ex", "pn2_fps_set_plan_override", "pn2_fps_set_bucketing", "pn2_fps_get_bucketing",
                                                "pn2_fps_set_multi", "pn2_fps_get_multi", "pn2_fps_ordered_workspace_bytes", "pn2_gcn_fused_supported", "pn2_gcn_layer_backward_workspace_bytes", "pn2_group_lift_rows_grad_seg_workspace_bytes",
@@ -276,7 +281,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["pn2_fps_workspace_bytes", "pn2_a
                                                "pn2_mlp_bwd_fused_supported", "pn2_mlp_bwd_fused_fold_supported",
                                                "pn2_mlp_gemm_first_supported", "pn2_mlp_bwd_bf16_fold_supported",
                                                "pn2_mlp_bwd_bf16_supported", "pn2_pool_bwd_supported",
-                                               "pn2_pool_bwd_workspace_bytes", "pn2_x3_weight_bytes", "pn2_sa_eval_x3_supported", "pn2_x3_gemm_supported",
+                                               "pn2_pool_bwd_workspace_bytes", "pn2_x3_weight_bytes", "pn2_sa_eval_x3_supported", "pn2_x3_gemm_supported", "pn2_x3_gemm_first_supported",
                                                "pn2_last_hip_error", "pn2_strerror"])
 #: the python layer may use the point-major fused entry points of this backend
 HAS_ROWS = True
@@ -1600,10 +1605,27 @@ def mlp_gemm_first(X0, W0, fin0, W, epi=EPI_NONE, stats=None):
     N, K = W.shape
     if tuple(W0.shape) != (K, K0) or tuple(fin0.shape) != (4, K):
         raise RuntimeError("mlp_gemm_first: W0 (K,K0), fin0 (4,K), W (N,K) expected")
+    if X3_GEMM and M >= X3_MIN_ROWS and (epi != EPI_NONE or stats is None) and _lib.pn2_x3_gemm_first_supported(K0, K, N):
+        return x3_gemm_first(X0, W0, fin0, W, stats if epi != EPI_NONE else None)
     Y = torch.empty(M, N, dtype=torch.float32, device=W.device)
     _call("pn2_mlp_gemm_first", W, M, K0, K, N, int(epi), _ptr(X0), _ptr(W0), _ptr(fin0[2]), _ptr(fin0[3]), _ptr(W), _ptr(Y),
           _ptr(stats), alg_bytes=4 * (M * K0 + M * N + N * K), alg_flops=2 * M * N * K + 2 * M * K * K0,
           tag=(f"M{M},K0{K0},K{K},N{N},epi{int(epi)}" if DETAIL_TAGS else None))
+    return Y
+
+
+def x3_gemm_first(X0, W0, fin0, W, stats=None):
+    """mlp_gemm_first on the split-bf16 product (csrc/x3_chain.hip: the eval level's chain on stored input rows, the first
+    layer's BatchNorm folded into its fragments): Y (M, N) and, with `stats`, += the column sums of Y, Y^2."""
+    M, K0 = X0.shape
+    N, K = W.shape
+    w0 = torch.empty((K // 32) * 3072, dtype=torch.uint8, device=W.device)
+    _call("pn2_x3_pack_first", W0, K, K0, _ptr(W0), _ptr(fin0[2]), _ptr(fin0[3]), _ptr(w0))
+    frags = x3_pack_weight(W.contiguous(), perm=True)      # the layer reads the first layer's accumulators: permuted contraction order
+    Y = torch.empty(M, N, dtype=torch.float32, device=W.device)
+    _call("pn2_x3_gemm_first", W, M, K0, K, N, _ptr(X0), _ptr(w0), _ptr(frags), _ptr(Y), _ptr(stats), _ptr(_x3_workspace(W.device)),
+          alg_bytes=4 * (M * K0 + M * N + N * K), alg_flops=2 * M * N * K + 2 * M * K * K0, label="pn2_mlp_gemm_first",
+          tag=(f"M{M},K0{K0},K{K},N{N},x3" if DETAIL_TAGS else None))
     return Y
 
 

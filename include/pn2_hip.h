@@ -900,6 +900,15 @@ int pn2_x3_gemm(long long M, int K, int N, int pro, int epi, const float *X, con
 int pn2_group_points_grad_csr(int B, int C, int N, int npoints, int nsample, const float *grad_out, const int *ptr,
                               const int *refs, float *grad_points, void *stream);
 
+/* pn2_mlp_gemm_first on the f32x3 product (csrc/x3_chain.hip): Y (M, N) = relu(bn_0(X0 W0^T)) W^T and stats (2, N) += the column
+ * sums of Y, Y^2 (NULL: none).  X0 (M, K0 <= 8) the grouped input rows; w0_frags = pn2_x3_pack_first(N0 = K, K0, W0, scale_0,
+ * shift_0): the first layer with its BatchNorm folded in, (K / 32) x 3072 bytes; wfrags = pn2_x3_pack_weight(N, K, K, perm 1, W).
+ * K = 64, N a multiple of 32 filling whole ring slots (pn2_x3_gemm_first_supported).  `workspace` as pn2_sa_eval_x3. */
+int pn2_x3_gemm_first_supported(int K0, int K, int N);
+int pn2_x3_pack_first(int N0, int K0, const float *W0, const float *scale, const float *shift, void *frags, void *stream);
+int pn2_x3_gemm_first(long long M, int K0, int K, int N, const float *X0, const void *w0_frags, const void *wfrags, float *Y,
+                      double *stats, void *workspace, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

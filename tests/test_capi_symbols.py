@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
     lib.pn2_abi_version.restype = ctypes.c_int
-    assert lib.pn2_abi_version() == 10
+    assert lib.pn2_abi_version() == 11
     lib.pn2_strerror.restype = ctypes.c_char_p
     lib.pn2_strerror.argtypes = [ctypes.c_int]
     assert lib.pn2_strerror(-1) and lib.pn2_strerror(12345)

@@ -213,6 +213,42 @@ def test_x3_gemm_matches_exact_kernels_and_fp64(M, K, N):
         e.X3_GEMM = prev
 
 
+@pytest.mark.parametrize("M,K0,N", [(70000, 6, 64), (33, 6, 64), (100001, 3, 128), (20000, 8, 64), (4096, 7, 128), (65536, 1, 64)])
+def test_x3_gemm_first_matches_the_exact_kernel_and_fp64(M, K0, N):
+    """pn2_x3_gemm_first (the eval chain's IN_SMALL stage on stored rows + store / sums epilogue) against pn2_mlp_gemm_first
+    (exact fp32 MFMA, first layer recomputed) and float64: Y = relu(bn_0(X0 W0^T)) W^T with the column sums of Y, Y^2; row
+    counts that end inside a wave's 32 rows, K0 = 8 (bias column in the second half-chunk) and K0 = 1."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(M + K0 + N)
+    dev, K = "cuda", 64
+    X0 = torch.randn(M, K0, generator=g).to(dev)
+    W0 = (torch.randn(K, K0, generator=g) / K0 ** 0.5).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    fin0 = torch.stack([torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5,
+                        torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3]).to(dev).contiguous()
+    assert e._lib.pn2_x3_gemm_first_supported(K0, K, N)
+    prev = e.X3_GEMM
+    try:
+        e.X3_GEMM = False
+        st0 = torch.zeros(2, N, dtype=torch.float64, device=dev)
+        Y0 = e.mlp_gemm_first(X0, W0, fin0, W, epi=e.EPI_STATS, stats=st0)
+    finally:
+        e.X3_GEMM = prev
+    st1 = torch.zeros(2, N, dtype=torch.float64, device=dev)
+    Y1 = e.x3_gemm_first(X0, W0, fin0, W, st1)
+    Y2 = e.x3_gemm_first(X0, W0, fin0, W, None)
+    assert torch.equal(Y1, Y2)
+    A64 = torch.relu((X0.double() @ W0.double().t()) * fin0[2].double() + fin0[3].double())
+    R64 = A64 @ W.double().t()
+    scale = float((A64.abs() @ W.double().abs().t()).max())
+    err_exact, err_x3 = _x3_err(Y0, R64, scale), _x3_err(Y1, R64, scale)
+    print(f"\n[x3 gemm_first M{M} K0{K0} N{N}] err / sum|a||w|: exact {err_exact:.2e}, f32x3 {err_x3:.2e}", end="")
+    assert err_x3 <= max(2.0 * err_exact, 5e-7)
+    torch.testing.assert_close(Y1, Y0, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(st1, st0, rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(st1[0], R64.sum(0), rtol=1e-5, atol=1e-2)
+
+
 # ------------------------------------------------------------------------------------------------ ADVICE r05 (low): prep sums at M >= 1M
 def test_prep_sums_at_a_million_rows_match_float64():
     """pn2_bn_relu_bwd_prep / pn2_pool_bwd_prep (csrc/mlp_gemm.hip prep_vec_kernel): a thread walks up to 512 rows of a 1M-row call;

@@ -29,7 +29,8 @@ def timed(fn, reps=20):
 SHAPES = [("SA1 pooled last layer", 4194304, 64, 128, "pool", 64), ("SA2 pooled last layer", 1048576, 128, 256, "pool", 32),
           ("SA2 hidden layer", 1048576, 128, 128, "fwd", 0), ("SA2 input gradient", 1048576, 128, 128, "dgrad", 0),
           ("SA3 pooled last layer", 262144, 128, 256, "pool", 16), ("SA3 hidden layer", 262144, 128, 128, "fwd", 0),
-          ("SA1 hidden layer (stored y0)", 4194304, 64, 64, "fwd", 0)]
+          ("SA1 hidden layer (stored y0)", 4194304, 64, 64, "fwd", 0),
+          ("SA1 second layer, first one re-formed (gemm_first, K0 6)", 4194304, 64, 64, "first", 6)]
 rows = []
 e.X3_GEMM = False
 for name, M, K, N, kind, ns in SHAPES:
@@ -40,7 +41,19 @@ for name, M, K, N, kind, ns in SHAPES:
     st = torch.zeros(2, N, dtype=torch.float64, device=dev)
     t = {"layer": name, "M": M, "K": K, "N": N, "kind": kind}
     pick = torch.randint(0, M, (256,), generator=g).to(dev)
-    if kind == "fwd":
+    if kind == "first":
+        K0 = ns
+        X0 = torch.randn(M, K0, generator=g).to(dev)
+        W0 = (torch.randn(K, K0, generator=g) / K0 ** 0.5).to(dev)
+        fin0 = torch.stack([torch.zeros(K), torch.ones(K), p[0].cpu(), p[1].cpu()]).to(dev).contiguous()
+        ex = lambda: e.mlp_gemm_first(X0, W0, fin0, W, epi=e.EPI_STATS, stats=st)
+        x3 = lambda: e.x3_gemm_first(X0, W0, fin0, W, st)
+        A64 = torch.relu((X0[pick].double() @ W0.double().t()) * fin0[2].double() + fin0[3].double())
+        R64 = A64 @ W.double().t()
+        scale = float((A64.abs() @ W.double().abs().t()).max())
+        t["err_exact"] = float((ex()[pick].double() - R64).abs().max() / scale)
+        t["err_f32x3"] = float((x3()[pick].double() - R64).abs().max() / scale)
+    elif kind == "fwd":
         ex = lambda: e.mlp_gemm(X, W, pro=e.PRO_BNRELU, epi=e.EPI_STATS, p=p, stats=st)
         x3 = lambda: e.x3_gemm(X, W, e.PRO_BNRELU, 1, p=p, stats=st)
         A64 = torch.relu(X[pick].double() * p[0].double() + p[1].double())
