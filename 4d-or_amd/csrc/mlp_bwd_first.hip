@@ -13,6 +13,7 @@
 // at the SA1 shape).
 #include "pn2_common.h"
 #include "mlp_common.h"
+#include "x3_common.h"
 
 #include "../../include/pn2_hip.h"
 
@@ -49,7 +50,11 @@ constexpr int kFirstLds = 2 * GY_SZ + 2 * ACT_SZ + NP * KP + 2 * KP + 3 * R * XW
 // forward GEMM), kept for the next epilogue and written as relu(bn(.)) into the activation tile of t+1.
 // Waves 4-7 ("wgrad"): 32 x 32 block of gy^T act over the 64 rows (32 MFMAs) -> stage gy of tile t+1.
 // Wave w and w+4 share a SIMD and run the phases in opposite order; one barrier per tile.
-template <int GMODE>
+// X3: both 64-deep products (gy W and gy^T act) on the split-bf16 product of x3_common.h — the operands are the same LDS reads
+// (eight per 16-deep chunk and lane), split in registers, six bf16 matrix instructions per chunk instead of eight fp32 ones at
+// half their length each, and — unlike the fp32 matrix instruction — issued beside the vector work of the wave that shares
+// the SIMD.  The recomputation of y_0 (four matrix instructions per tile) stays exact: it decides the ReLU mask.
+template <int GMODE, bool X3>
 __global__ __launch_bounds__(512) void mlp_bwd_first_kernel(const FirstArgs a) {
   constexpr bool POOL = GMODE == PRO_POOLG;
   constexpr int PG = POOL ? ((R / 16 + 1 + GROWS - 1) / GROWS) : 1;
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_first_kernel(const FirstArgs a) {
   const int xoff = (tid % XW) < a.K0 ? ((tid / XW) * a.K0 + (tid % XW)) * 4 : kOobOffset;
   const int w_nb = wave & 1, w_kb = (wave >> 1) & 1;                       // wgrad role: block of dW
 
+  x3_frag wB[X3 ? NP / 16 : 1];                  // X3, dgrad waves: B fragments of the wave's column block of W
   f32x16 acc;                                    // dgrad block or dW block (a wave has one role for the whole kernel)
   f32x16 ypv;                                    // dgrad role: y_{l-1} block of the tile being computed
 #pragma unroll
@@ -210,12 +216,30 @@ __global__ __launch_bounds__(512) void mlp_bwd_first_kernel(const FirstArgs a) {
     if (dgrad_role) {
       stage(t1, buf ^ 1, rg, ry, pa, pg);
       load_tile(t3, rg, ry, pa, pg);
+      if (X3) {
+        // chunk c: contraction indices n = 16 c + 2 i + lh (i = 0..7) — the order the fp32 loop walks them in
+        const float *ga = gyT + lh * LDT + d_rb * 32 + l31;
+        float av[2][8];
 #pragma unroll
-      for (int s = 0; s < NP / 2; ++s) {
-        const int n = 2 * s + lh;
-        const float av = gyT[n * LDT + d_rb * 32 + l31];
-        const float bv = Wl[n * KP + d_kb * 32 + l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        for (int i = 0; i < 8; ++i) av[0][i] = ga[2 * i * LDT];
+#pragma unroll
+        for (int c = 0; c < NP / 16; ++c) {
+          if (c + 1 < NP / 16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[(c + 1) & 1][i] = ga[(16 * (c + 1) + 2 * i) * LDT];
+          }
+          x3_frag fa;
+          x3_split8(av[c & 1], fa);
+          x3_mma(fa, wB[X3 ? c : 0], acc);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NP / 2; ++s) {
+          const int n = 2 * s + lh;
+          const float av = gyT[n * LDT + d_rb * 32 + l31];
+          const float bv = Wl[n * KP + d_kb * 32 + l31];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
       }
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -240,12 +264,35 @@ __global__ __launch_bounds__(512) void mlp_bwd_first_kernel(const FirstArgs a) {
       cs2 += s2;
       compute_y(xq1, buf ^ 1);
     } else {
+      if (X3) {
+        // chunk c: rows 16 c + 2 i + lh of the tile
+        const float *ga = gyT + (w_nb * 32 + l31) * LDT + lh;
+        const float *ba = act + lh * KP + w_kb * 32 + l31;
+        float av[2][8], bv[2][8];
 #pragma unroll
-      for (int s = 0; s < R / 2; ++s) {
-        const int row = 2 * s + lh;
-        const float av = gyT[(w_nb * 32 + l31) * LDT + row];
-        const float bv = act[row * KP + w_kb * 32 + l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        for (int i = 0; i < 8; ++i) { av[0][i] = ga[2 * i]; bv[0][i] = ba[2 * i * KP]; }
+#pragma unroll
+        for (int c = 0; c < R / 16; ++c) {
+          if (c + 1 < R / 16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              av[(c + 1) & 1][i] = ga[16 * (c + 1) + 2 * i];
+              bv[(c + 1) & 1][i] = ba[(16 * (c + 1) + 2 * i) * KP];
+            }
+          }
+          x3_frag fa, fb;
+          x3_split8(av[c & 1], fa);
+          x3_split8(bv[c & 1], fb);
+          x3_mma(fa, fb, acc);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < R / 2; ++s) {
+          const int row = 2 * s + lh;
+          const float av = gyT[(w_nb * 32 + l31) * LDT + row];
+          const float bv = act[row * KP + w_kb * 32 + l31];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
       }
       stage(t1, buf ^ 1, rg, ry, pa, pg);
       load_tile(t3, rg, ry, pa, pg);
@@ -269,6 +316,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_first_kernel(const FirstArgs a) {
     Xs0[R * XW + tid] = xb_;
   }
   __syncthreads();                               // resident weights and the first X tiles visible
+  // X3, dgrad waves: the B fragments of this wave's column block of W, split once (chunk c: rows n = 16 c + 2 i + lh)
+  if (X3 && dgrad_role) {
+#pragma unroll
+    for (int c = 0; c < NP / 16; ++c) {
+      float wv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv[i] = Wl[(16 * c + 2 * i + lh) * KP + d_kb * 32 + l31];
+      x3_split8(wv, wB[X3 ? c : 0]);
+    }
+  }
   stage(tile, 0, rg0, ry0, pa0, pg0);
   if (dgrad_role) compute_y(0, 0);
   load_tile(clampt(tile + 2 * stride), rg0, ry0, pa0, pg0);
@@ -320,11 +377,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_first_kernel(const FirstArgs a) {
   }
 }
 
-template <int GMODE>
+template <int GMODE, bool X3 = false>
 int launch_first(const FirstArgs &a, hipStream_t s) {
   constexpr size_t lds_bytes = (size_t)kFirstLds * sizeof(float);
   static_assert(lds_bytes <= 160 * 1024, "LDS budget of one CU");
-  auto kern = mlp_bwd_first_kernel<GMODE>;
+  auto kern = mlp_bwd_first_kernel<GMODE, X3>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -342,10 +399,10 @@ int launch_first(const FirstArgs &a, hipStream_t s) {
 }  // namespace
 
 // pn2_mlp_bwd_fused_fold when the forward never stored y_{l-1} (pn2_mlp_gemm_first): recomputed from X and W0 [K][K0].
-extern "C" int pn2_mlp_bwd_fused_fold_first(long long M, int N, int K, int gmode, const float *G, const float *Yl,
-                                            const float *consts, const int *arg, const float *gP, int ns, const float *W,
-                                            const float *W0, const float *a_fin, const float *X, int K0, double *sums,
-                                            float *dW, float *P1, void *stream) {
+namespace {
+int bwd_fold_first(bool x3, long long M, int N, int K, int gmode, const float *G, const float *Yl, const float *consts,
+                   const int *arg, const float *gP, int ns, const float *W, const float *W0, const float *a_fin, const float *X,
+                   int K0, double *sums, float *dW, float *P1, void *stream) {
   if (M < 0 || !pn2_mlp_bwd_fused_fold_supported(N, K, K0)) return PN2_EINVAL;
   if (gmode != PRO_GY && gmode != PRO_POOLG) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
@@ -359,5 +416,22 @@ extern "C" int pn2_mlp_bwd_fused_fold_first(long long M, int N, int K, int gmode
   a.sums = sums; a.dW = dW; a.M = M; a.N = N; a.K = K; a.ns = ns;
   a.X = X; a.P1 = P1; a.K0 = K0;
   hipStream_t s = (hipStream_t)stream;
+  if (x3) return gmode == PRO_GY ? launch_first<PRO_GY, true>(a, s) : launch_first<PRO_POOLG, true>(a, s);
   return gmode == PRO_GY ? launch_first<PRO_GY>(a, s) : launch_first<PRO_POOLG>(a, s);
+}
+}  // namespace
+
+extern "C" int pn2_mlp_bwd_fused_fold_first(long long M, int N, int K, int gmode, const float *G, const float *Yl,
+                                            const float *consts, const int *arg, const float *gP, int ns, const float *W,
+                                            const float *W0, const float *a_fin, const float *X, int K0, double *sums,
+                                            float *dW, float *P1, void *stream) {
+  return bwd_fold_first(false, M, N, K, gmode, G, Yl, consts, arg, gP, ns, W, W0, a_fin, X, K0, sums, dW, P1, stream);
+}
+
+// The same backward with its two 64-deep products on the split-bf16 ("f32x3") product (x3_common.h); y_0 is still re-formed exactly.
+extern "C" int pn2_x3_bwd_fold_first(long long M, int N, int K, int gmode, const float *G, const float *Yl, const float *consts,
+                                     const int *arg, const float *gP, int ns, const float *W, const float *W0,
+                                     const float *a_fin, const float *X, int K0, double *sums, float *dW, float *P1,
+                                     void *stream) {
+  return bwd_fold_first(true, M, N, K, gmode, G, Yl, consts, arg, gP, ns, W, W0, a_fin, X, K0, sums, dW, P1, stream);
 }

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "pn2_group_inverse_index": [_c_int] * 4 + [_c_vp] * 4 + [_c_sz, _c_vp],
     "pn2_x3_pack_weight": [_c_int] * 4 + [_c_vp] * 3,
     "pn2_x3_pack_first": [_c_int] * 2 + [_c_vp] * 5,
+    "pn2_x3_bwd_fold_first": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 + [_c_int] + [_c_vp] * 4,
     "pn2_x3_gemm_first": [ctypes.c_longlong] + [_c_int] * 3 + [_c_vp] * 7,
     "pn2_group_points_grad_csr": [_c_int] * 5 + [_c_vp] * 5,
     "pn2_x3_gemm": [ctypes.c_longlong] + [_c_int] * 4 + [_c_vp] * 13 + [_c_int, _c_vp, _c_vp],
@@ -958,6 +959,10 @@ X3_MIN_ROWS = int(os.environ.get("PN2_X3_MIN_ROWS", "16384"))
 X3_DGRAD = os.environ.get("PN2_X3_DGRAD") == "1"
 
 
+#: the backward of the layer above a re-formed first layer (pn2_x3_bwd_fold_first) follows X3_GEMM; PN2_X3_BWD_FIRST=0: exact
+X3_BWD_FIRST = os.environ.get("PN2_X3_BWD_FIRST", "1") != "0"
+
+
 def x3_gemm_supported(K, N, pro, epi, ns=0):
     return bool(_lib.pn2_x3_gemm_supported(int(K), int(N), int(pro), int(epi), int(ns)))
 
@@ -1639,10 +1644,12 @@ def mlp_bwd_fused_fold_first(Yl, consts, W, W0, a_fin, X, gmode, G=None, arg=Non
         dW = torch.zeros(N, K, dtype=torch.float32, device=Yl.device)
     if P1 is None:
         P1 = torch.zeros(K, K0, dtype=torch.float32, device=Yl.device)
-    _call("pn2_mlp_bwd_fused_fold_first", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP),
+    # (the f32x3 form of the two 64-deep products when the route is on — same outputs, y_0 still re-formed exactly)
+    x3 = X3_GEMM and X3_BWD_FIRST and M >= X3_MIN_ROWS
+    _call("pn2_x3_bwd_fold_first" if x3 else "pn2_mlp_bwd_fused_fold_first", Yl, M, N, K, int(gmode), _ptr(G), _ptr(Yl), _ptr(consts), _ptr(arg), _ptr(gP),
           int(ns), _ptr(W), _ptr(W0), _ptr(a_fin), _ptr(X), K0, _ptr(sums), _ptr(dW), _ptr(P1),
           alg_bytes=4 * (M * N * (2 if gmode == PRO_GY else 1) + M * K0 + N * K), alg_flops=4 * M * N * K + 2 * M * K * K0,
-          tag=(f"M{M},N{N},K{K},g{int(gmode)},first{K0}" if DETAIL_TAGS else None))
+          label="pn2_mlp_bwd_fused_fold_first", tag=(f"M{M},N{N},K{K},g{int(gmode)},first{K0}" + (",x3" if x3 else "") if DETAIL_TAGS else None))
     return sums, dW, P1
 
 

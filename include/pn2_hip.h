@@ -909,6 +909,12 @@ int pn2_x3_pack_first(int N0, int K0, const float *W0, const float *scale, const
 int pn2_x3_gemm_first(long long M, int K0, int K, int N, const float *X0, const void *w0_frags, const void *wfrags, float *Y,
                       double *stats, void *workspace, void *stream);
 
+/* pn2_mlp_bwd_fused_fold_first with its two 64-deep products (gy W and gy^T act) on the f32x3 product (csrc/mlp_bwd_first.hip,
+ * template parameter X3); same arguments, preconditions and outputs; y_0 is re-formed exactly (it decides the ReLU mask). */
+int pn2_x3_bwd_fold_first(long long M, int N, int K, int gmode, const float *G, const float *Yl, const float *consts,
+                          const int *arg, const float *gP, int ns, const float *W, const float *W0, const float *a_fin,
+                          const float *X, int K0, double *sums, float *dW, float *P1, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -73,10 +73,14 @@ def _closer_than_the_fp32_oracle(name, got, ref32, truth, slack=3.0, floor=1e-4)
     k = max(1, int(d_got.numel() * 0.999))
     q_got, q_ref = float(d_got.kthvalue(k).values), float(d_ref.kthvalue(k).values)
     off = float((d_got > 1e-3 * scale).double().mean())
+    # (the same count for the fp32 oracle: where ITS max-pool routing differs from float64's it is off by as much — under the
+    # forced f32x3 route the first conv's 384-entry gradient has ONE such entry, 0.577 against the oracle's own 0.569 at a bound
+    # of 0.566: the HIP result may be as far off as the oracle is)
+    off_ref = float((d_ref > 1e-3 * scale).double().mean())
     print(f"\n[{name}] p99.9 |hip - f64| {q_got:.3e} (max {float(d_got.max()):.3e}), p99.9 |oracle fp32 - f64| {q_ref:.3e} "
           f"(max {float(d_ref.max()):.3e}), max|f64| {scale:.3e}, entries off by > 1e-3 max: {off:.2e}", end="")
     assert q_got <= max(slack * q_ref, floor * scale), (name, q_got, q_ref, scale)
-    assert off <= 1e-3, (name, off)
+    assert off <= max(1e-3, 2.0 * off_ref), (name, off, off_ref)
 
 
 def _same_up_to_sparse_argmax_flips(name, a, b, tol=2e-4):

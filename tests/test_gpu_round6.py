@@ -249,6 +249,60 @@ def test_x3_gemm_first_matches_the_exact_kernel_and_fp64(M, K0, N):
     torch.testing.assert_close(st1[0], R64.sum(0), rtol=1e-5, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,K0,N0,N1,ns", [(64 * 300, 6, 64, 64, 0), (20000, 3, 48, 40, 0), (64 * 1024 + 192, 6, 64, 64, 64),
+                                           (16 * 1300, 8, 64, 64, 16), (16390, 1, 33, 64, 0)])
+def test_x3_fold_backward_matches_the_exact_kernel_and_float64(M, K0, N0, N1, ns):
+    """pn2_x3_bwd_fold_first (both 64-deep products of csrc/mlp_bwd_first.hip on the split-bf16 product) against the exact
+    kernel and a float64 evaluation of the same formulas: BatchNorm-backward sums, dW_1 and P1 = gz^T X, dense and pooled
+    gradient modes, widths below 64 (zero-padded fragments), row counts that end inside a tile."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(M + N1 + ns)
+    X0 = (torch.randn(M, K0, generator=g) + 0.3).cuda()
+    W0 = (torch.randn(N0, K0, generator=g) * 0.5).cuda()
+    W1 = (torch.randn(N1, N0, generator=g) * 0.2).cuda()
+    gamma = (torch.rand(N0, generator=g) + 0.5).cuda()
+    beta = (torch.randn(N0, generator=g) * 0.2).cuda()
+    prev = e.X3_GEMM
+    e.X3_GEMM = False
+    try:
+        st0 = torch.zeros(2, N0, dtype=torch.float64, device="cuda")
+        y0 = e.mlp_gemm(X0, W0, pro=e.PRO_NONE, epi=e.EPI_STATS, stats=st0)
+        fin0 = e.bn_finalize(st0, M, gamma, beta, 1e-5, 0.0, None, None)
+        y1 = e.mlp_gemm(y0, W1, pro=e.PRO_BNRELU, epi=e.EPI_NONE, p=(fin0[2], fin0[3]))
+        consts = (torch.randn(3, N1, generator=g) * 0.3).cuda().contiguous()
+        if ns:
+            gmode, G = e.PRO_POOLG, None
+            arg = torch.randint(0, ns, (M // ns, N1), generator=g, dtype=torch.int32).cuda()
+            gP = torch.randn(M // ns, N1, generator=g).cuda()
+            gS = torch.zeros(M // ns, ns, N1, dtype=torch.float64, device="cuda")
+            gS.scatter_(1, arg.long().unsqueeze(1), gP.double().unsqueeze(1))
+            gS = gS.view(M, N1)
+        else:
+            gmode, G, arg, gP = e.PRO_GY, torch.randn(M, N1, generator=g).cuda(), None, None
+            gS = G.double()
+        a = e.mlp_bwd_fused_fold_first(y1, consts, W1, W0, fin0, X0, gmode, G=G, arg=arg, gP=gP, ns=ns)
+        e.X3_GEMM = True
+        old_min, e.X3_MIN_ROWS = e.X3_MIN_ROWS, 0
+        try:
+            b = e.mlp_bwd_fused_fold_first(y1, consts, W1, W0, fin0, X0, gmode, G=G, arg=arg, gP=gP, ns=ns)
+        finally:
+            e.X3_MIN_ROWS = old_min
+    finally:
+        e.X3_GEMM = prev
+    # float64: gy = c1 gS + c2 y1 + c3; gz = (gy W1) masked by bn_0(y0) > 0; sums of gz, gz yhat_0; dW = gy^T relu(bn_0(y0)); P1 = gz^T X
+    c = consts.double()
+    gy = c[0] * gS + c[1] * y1.double() + c[2]
+    z0 = y0.double() * fin0[2].double() + fin0[3].double()
+    gz = (gy @ W1.double()) * (z0 > 0)
+    yhat = (y0.double() - fin0[0].double()) * fin0[1].double()
+    ref = (torch.stack([gz.sum(0), (gz * yhat).sum(0)]), gy.t() @ torch.relu(z0), gz.t() @ X0.double())
+    for u, v, r, name in zip(a, b, ref, ("sums", "dW", "P1")):
+        scale = float(r.abs().max()) + 1e-12
+        eu, ev = float((u.double() - r).abs().max()) / scale, float((v.double() - r).abs().max()) / scale
+        print(f"\n[x3 fold_first M{M} {name}] err vs float64 / max: exact {eu:.2e}, f32x3 {ev:.2e}", end="")
+        assert ev <= max(3.0 * eu, 2e-5), (name, eu, ev)
+
+
 # ------------------------------------------------------------------------------------------------ ADVICE r05 (low): prep sums at M >= 1M
 def test_prep_sums_at_a_million_rows_match_float64():
     """pn2_bn_relu_bwd_prep / pn2_pool_bwd_prep (csrc/mlp_gemm.hip prep_vec_kernel): a thread walks up to 512 rows of a 1M-row call;
