@@ -23,6 +23,7 @@
 // y_{L-1} registers already have.
 #include "pn2_common.h"
 #include "mlp_common.h"
+#include "x3_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -360,8 +361,11 @@ __global__ __launch_bounds__(128 * KT, 2) void pool_bwd_kernel(const PoolBwdArgs
 #else
 #define PB_T(i)
 #endif
-template <int NH>
-__global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a) {
+// X3: the two matrix products (a G and the Gram blocks) on the split-bf16 product of x3_common.h: the same LDS operand reads,
+// eight per 16-deep chunk, split in registers; 6 bf16 matrix instructions per chunk instead of 8 fp32 ones at half their length,
+// and they issue beside the vector work (row lists, S / T walks) of the wave that shares the SIMD — the fp32 ones do not.
+template <int NH, bool X3 = false>
+__global__ __launch_bounds__(512, X3 ? 1 : 2) void pool_bwd64_kernel(const PoolBwdArgs a) {
 #ifdef PB_PROF
   long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = __builtin_readcyclecounter();
@@ -408,11 +412,40 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   // accumulators.  a^T a is symmetric: its blocks (0,0), (1,1), (0,1) are computed — every Gram wave a quarter of the tile's
   // rows (16 wq .. 16 wq + 15) of each of the three: 24 matrix instructions per tile instead of 32, from two LDS operands per
   // step instead of two per instruction — and summed / mirrored at the flush.
+  // (X3: ONE register array for both roles — the compiler cannot know that a wave keeps its role, two sets would both stay
+  // live: waves 0-3 hold the twelve pieces of their four B fragments of G in it, chunk c = rows k = 16 c + 2 i + h, the fp32
+  // loop's order; waves 4-7 the bits of the two running Gram accumulators)
   f32x16 rg0, rg1;
+  f32x4 rr[X3 ? 12 : 1];
+  auto rr_get = [&](int base) {
+    f32x16 v;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    rg0[s] = zrole ? a.G[(2 * s + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
-    rg1[s] = zrole ? a.G[(2 * (s + 16) + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * q + j] = rr[X3 ? base + q : 0][j];
+    return v;
+  };
+  auto rr_put = [&](int base, const f32x16 &v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rr[X3 ? base + q : 0] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  };
+  if (X3) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float gv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gv[i] = zrole ? a.G[(16 * c + 2 * i + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
+      x3_frag f;
+      x3_split8(gv, f);                                  // (waves 4-7: zeros split into zeros)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) rr[X3 ? 3 * c + q : 0] = __builtin_bit_cast(f32x4, f.p[q]);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      rg0[s] = zrole ? a.G[(2 * s + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
+      rg1[s] = zrole ? a.G[(2 * (s + 16) + (lane >> 5)) * K + cb * 32 + (lane & 31)] : 0.f;
+    }
   }
   const int wq = wave & 3;
   const float vreg = a.v[cb * 32 + (lane & 31)];
@@ -591,9 +624,17 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
 #pragma unroll
           for (int u = 0; u < 8; ++u) zp[(g8 + 1) & 1][u] = za[2 * (8 * (g8 + 1) + u)];
         }
+        if (X3) {
+          x3_frag fa, fb;
+          x3_split8(zp[g8 & 1], fa);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zp[g8 & 1][u], g8 < 2 ? rg0[8 * g8 + u] : rg1[8 * (g8 - 2) + u], acc, 0, 0, 0);
+          for (int q = 0; q < 3; ++q) fb.p[q] = __builtin_bit_cast(x3_u32x4, rr[X3 ? 3 * g8 + q : 0]);
+          x3_mma(fa, fb, acc);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zp[g8 & 1][u], g8 < 2 ? rg0[8 * g8 + u] : rg1[8 * (g8 - 2) + u], acc, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -603,11 +644,23 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
       float p0[8], p1[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) { p0[u] = g0[2 * u * LDZ]; p1[u] = g0[2 * u * LDZ + 32]; }
+      if (X3) {
+        x3_frag f0, f1;
+        x3_split8(p0, f0);
+        x3_split8(p1, f1);
+        f32x16 r0 = rr_get(0), r1 = rr_get(4);
+        x3_mma(f0, f0, acc);
+        x3_mma(f1, f1, r0);
+        x3_mma(f0, f1, r1);
+        rr_put(0, r0);
+        rr_put(4, r1);
+      } else {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[u], p0[u], acc, 0, 0, 0);
-        rg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[u], p1[u], rg0, 0, 0, 0);
-        rg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[u], p1[u], rg1, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[u], p0[u], acc, 0, 0, 0);
+          rg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[u], p1[u], rg0, 0, 0, 0);
+          rg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[u], p1[u], rg1, 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // T AFTER the Gram block (it only needs the activation tile): the matrix pipe starts while waves 0-3 still walk their
@@ -691,11 +744,12 @@ __global__ __launch_bounds__(512, 2) void pool_bwd64_kernel(const PoolBwdArgs a)
   // Gram: the four row-quarter partials of a block meet in LDS (one block per round), wave 4 + b writes block b and, for
   // (0,1), its mirror image
   float *gq = st;                                        // [4 waves][16][64] (16 KB of the staging tile)
+  const f32x16 g0f = X3 ? rr_get(0) : rg0, g1f = X3 ? rr_get(4) : rg1;
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     if (!zrole) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gq[(wq * 16 + r) * 64 + lane] = b == 0 ? acc[r] : (b == 1 ? rg0[r] : rg1[r]);
+      for (int r = 0; r < 16; ++r) gq[(wq * 16 + r) * 64 + lane] = b == 0 ? acc[r] : (b == 1 ? g0f[r] : g1f[r]);
     }
     __syncthreads();
     if (wave == 4 + b) {
@@ -1186,9 +1240,10 @@ extern "C" size_t pn2_pool_bwd_workspace_bytes(long long M, int N, int K) {
 // F.max_pool2d + BatchNorm2d + Conv2d backward (autograd of OPS/pointnet2_modules.py:58-70) for that layer.
 //   consts [3][N] from pn2_bn_bwd_consts of this layer; arg / gPm [M/ns][N] from pn2_pool_finalize / pn2_pool_bwd_prep;
 //   Yp [M][K], fin_p [4][K] of the layer below; Gout [M][K]; sums [2][K] fp64 ACCUMULATES; dW [N][K] is written.
-extern "C" int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, const float *fin_p, const float *W,
-                            const float *consts, const int *arg, const float *gPm, float *Gout, double *sums,
-                            float *dW, void *workspace, size_t workspace_bytes, void *stream) {
+namespace {
+int pool_bwd_impl(bool x3, long long M, int N, int K, int ns, const float *Yp, const float *fin_p, const float *W,
+                  const float *consts, const int *arg, const float *gPm, float *Gout, double *sums, float *dW, void *workspace,
+                  size_t workspace_bytes, void *stream) {
   if (M < 0 || !pn2_pool_bwd_supported(N, K, ns) || M % ns) return PN2_EINVAL;
   if (M == 0) return PN2_OK;
   if (!Yp || !fin_p || !W || !consts || !arg || !gPm || !Gout || !sums || !dW || !workspace) return PN2_ENULL;
@@ -1210,7 +1265,9 @@ extern "C" int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, 
   a.Yp = Yp; a.finp = fin_p; a.G = G; a.v = v; a.Wp = Wp; a.arg = arg; a.gPm = gPm; a.Gout = Gout; a.sums = sums;
   a.part = part; a.M = M; a.N = N; a.ns = ns;
   if (K == 64) {
-    if (N <= 64) hipLaunchKernelGGL((pool_bwd64_kernel<1>), dim3(grid), dim3(512), 0, s, a);
+    if (N <= 64 && x3) hipLaunchKernelGGL((pool_bwd64_kernel<1, true>), dim3(grid), dim3(512), 0, s, a);
+    else if (N <= 64) hipLaunchKernelGGL((pool_bwd64_kernel<1>), dim3(grid), dim3(512), 0, s, a);
+    else if (N <= 128 && x3) hipLaunchKernelGGL((pool_bwd64_kernel<2, true>), dim3(grid), dim3(512), 0, s, a);
     else if (N <= 128) hipLaunchKernelGGL((pool_bwd64_kernel<2>), dim3(grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((pool_bwd_kernel<2, 64, false>), dim3(grid), dim3(256), 0, s, a);
   } else {
@@ -1221,4 +1278,19 @@ extern "C" int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, 
                      part, red);
   hipLaunchKernelGGL(pool_bwd_assemble_kernel, dim3(N), dim3(128), 0, s, N, K, W, consts, red, dW);
   return pn2_check_launch();
+}
+}  // namespace
+
+extern "C" int pn2_pool_bwd(long long M, int N, int K, int ns, const float *Yp, const float *fin_p, const float *W,
+                            const float *consts, const int *arg, const float *gPm, float *Gout, double *sums,
+                            float *dW, void *workspace, size_t workspace_bytes, void *stream) {
+  return pool_bwd_impl(false, M, N, K, ns, Yp, fin_p, W, consts, arg, gPm, Gout, sums, dW, workspace, workspace_bytes, stream);
+}
+
+// pn2_pool_bwd with the matrix products of the K = 64, N <= 128 kernel (a G, a^T a) on the f32x3 product (x3_common.h); every
+// other shape runs the exact kernels.  Same arguments, workspace and outputs.
+extern "C" int pn2_x3_pool_bwd(long long M, int N, int K, int ns, const float *Yp, const float *fin_p, const float *W,
+                               const float *consts, const int *arg, const float *gPm, float *Gout, double *sums,
+                               float *dW, void *workspace, size_t workspace_bytes, void *stream) {
+  return pool_bwd_impl(true, M, N, K, ns, Yp, fin_p, W, consts, arg, gPm, Gout, sums, dW, workspace, workspace_bytes, stream);
 }

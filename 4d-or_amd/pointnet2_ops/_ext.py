@@ -156,6 +156,7 @@ _SIGNATURES = {
     "pn2_mlp_gemm_pool": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4,
     "pn2_pool_finalize": [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 8,
     "pn2_pool_bwd": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 10 + [_c_sz, _c_vp],
+    "pn2_x3_pool_bwd": [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 10 + [_c_sz, _c_vp],
     # batched scans with per-scan statistics (segment table)
     "pn2_mlp_gemm_bf16_seg": [ctypes.c_longlong] + [_c_int] * 8 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 2 + [_c_int] +
                              [_c_vp] * 6 + [_c_int, ctypes.c_longlong, _c_vp],
@@ -961,6 +962,8 @@ X3_DGRAD = os.environ.get("PN2_X3_DGRAD") == "1"
 
 #: the backward of the layer above a re-formed first layer (pn2_x3_bwd_fold_first) follows X3_GEMM; PN2_X3_BWD_FIRST=0: exact
 X3_BWD_FIRST = os.environ.get("PN2_X3_BWD_FIRST", "1") != "0"
+#: ... and so does the pooled last layer's backward at K = 64 (pn2_x3_pool_bwd); PN2_X3_POOL_BWD=0: exact
+X3_POOL_BWD = os.environ.get("PN2_X3_POOL_BWD", "1") != "0"
 
 
 def x3_gemm_supported(K, N, pro, epi, ns=0):
@@ -1866,9 +1869,11 @@ def pool_bwd(Yp, fin_p, W, consts, arg, gPm, ns, sums):
     dW = torch.empty(N, K, dtype=torch.float32, device=Yp.device)
     nb = int(_lib.pn2_pool_bwd_workspace_bytes(M, N, K))
     ws = torch.empty(nb, dtype=torch.uint8, device=Yp.device)
-    _call("pn2_pool_bwd", Yp, M, N, K, int(ns), _ptr(Yp), _ptr(fin_p), _ptr(W), _ptr(consts), _ptr(arg), _ptr(gPm),
+    # (X3: the K = 64 kernel's matrix products on the f32x3 product; other shapes run the exact kernels behind the same entry)
+    x3 = X3_GEMM and X3_POOL_BWD and M >= X3_MIN_ROWS and K == 64 and N <= 128
+    _call("pn2_x3_pool_bwd" if x3 else "pn2_pool_bwd", Yp, M, N, K, int(ns), _ptr(Yp), _ptr(fin_p), _ptr(W), _ptr(consts), _ptr(arg), _ptr(gPm),
           _ptr(Gout), _ptr(sums), _ptr(dW), _ptr(ws), nb, alg_bytes=4 * (2 * M * K + 2 * (M // int(ns)) * N + N * K),
-          alg_flops=4 * M * K * K, tag=(f"M{M},N{N},K{K},ns{int(ns)}" if DETAIL_TAGS else None))
+          alg_flops=4 * M * K * K, label="pn2_pool_bwd", tag=(f"M{M},N{N},K{K},ns{int(ns)}" + (",x3" if x3 else "") if DETAIL_TAGS else None))
     return Gout, dW
 
 

@@ -915,6 +915,13 @@ int pn2_x3_bwd_fold_first(long long M, int N, int K, int gmode, const float *G, 
                           const int *arg, const float *gP, int ns, const float *W, const float *W0, const float *a_fin,
                           const float *X, int K0, double *sums, float *dW, float *P1, void *stream);
 
+/* pn2_pool_bwd with the matrix products of its K = 64, N <= 128 kernel (a G and the Gram blocks of a^T a) on the f32x3 product
+ * (csrc/pool_bwd.hip, template parameter X3); every other supported shape runs the exact kernels.  Same arguments, workspace
+ * (pn2_pool_bwd_workspace_bytes) and outputs. */
+int pn2_x3_pool_bwd(long long M, int N, int K, int ns, const float *Yp, const float *fin_p, const float *W, const float *consts,
+                    const int *arg, const float *gPm, float *Gout, double *sums, float *dW, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

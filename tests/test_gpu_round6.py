@@ -303,6 +303,48 @@ def test_x3_fold_backward_matches_the_exact_kernel_and_float64(M, K0, N0, N1, ns
         assert ev <= max(3.0 * eu, 2e-5), (name, eu, ev)
 
 
+@pytest.mark.parametrize("M,N,ns", [(64 * 700, 128, 64), (32 * 1501, 64, 32), (16 * 3000, 128, 16), (128 * 260, 96, 128), (64 * 257 + 64, 33, 64)])
+def test_x3_pool_bwd_matches_the_exact_kernel_and_float64(M, N, ns):
+    """pn2_x3_pool_bwd (K = 64: a G and the Gram blocks on the split-bf16 product) against pn2_pool_bwd and a float64
+    evaluation of the Gram-form formulas of csrc/pool_bwd.hip: Gout = [a > 0] (a G + v + S), its BatchNorm-backward sums, dW."""
+    from pointnet2_ops import _ext as e
+    g = torch.Generator().manual_seed(M + N + ns)
+    K, R = 64, M // ns
+    yp = torch.randn(M, K, generator=g).cuda()
+    fin = torch.stack([torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5,
+                       torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3]).cuda().contiguous()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    consts = (torch.randn(3, N, generator=g) * 0.1).cuda().contiguous()
+    arg = torch.randint(0, ns, (R, N), generator=g, dtype=torch.int32).cuda()
+    gPm = (torch.randn(R, N, generator=g) * (torch.rand(R, N, generator=g) > 0.3)).cuda()
+    prev, old_min = e.X3_GEMM, e.X3_MIN_ROWS
+    try:
+        e.X3_GEMM = False
+        s0 = torch.zeros(2, K, dtype=torch.float64, device="cuda")
+        G0, dW0 = e.pool_bwd(yp, fin, W, consts, arg, gPm, ns, s0)
+        e.X3_GEMM, e.X3_MIN_ROWS = True, 0
+        s1 = torch.zeros(2, K, dtype=torch.float64, device="cuda")
+        G1, dW1 = e.pool_bwd(yp, fin, W, consts, arg, gPm, ns, s1)
+    finally:
+        e.X3_GEMM, e.X3_MIN_ROWS = prev, old_min
+    # float64: y_L = a W^T; dL/dy_L = c1 gS + c2 y_L + c3; g = [a > 0] (dL/dy_L W); dW = dL/dy_L^T a
+    z = yp.double() * fin[2].double() + fin[3].double()
+    act = torch.relu(z)
+    yL = act @ W.double().t()
+    gS = torch.zeros(R, ns, N, dtype=torch.float64, device="cuda")
+    gS.scatter_(1, arg.long().unsqueeze(1), gPm.double().unsqueeze(1))
+    c = consts.double()
+    gy = c[0] * gS.view(M, N) + c[1] * yL + c[2]
+    gz = (gy @ W.double()) * (z > 0)
+    yhat = (yp.double() - fin[0].double()) * fin[1].double()
+    ref = (gz, torch.stack([gz.sum(0), (gz * yhat).sum(0)]), gy.t() @ act)
+    for u, v, r, name in zip((G0, s0, dW0), (G1, s1, dW1), ref, ("Gout", "sums", "dW")):
+        scale = float(r.abs().max()) + 1e-12
+        eu, ev = float((u.double() - r).abs().max()) / scale, float((v.double() - r).abs().max()) / scale
+        print(f"\n[x3 pool_bwd M{M} N{N} ns{ns} {name}] err vs float64 / max: exact {eu:.2e}, f32x3 {ev:.2e}", end="")
+        assert ev <= max(3.0 * eu, 2e-5), (name, eu, ev)
+
+
 # ------------------------------------------------------------------------------------------------ ADVICE r05 (low): prep sums at M >= 1M
 def test_prep_sums_at_a_million_rows_match_float64():
     """pn2_bn_relu_bwd_prep / pn2_pool_bwd_prep (csrc/mlp_gemm.hip prep_vec_kernel): a thread walks up to 512 rows of a 1M-row call;

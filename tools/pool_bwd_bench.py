@@ -19,6 +19,7 @@ for M, K, N, ns in SHAPES:
     sums = torch.zeros(2, K, dtype=torch.float64, device=dev)
     def run():
         return e.pool_bwd(yp, fin, W, consts, arg, gPm, ns, sums)
+    e.X3_GEMM = len(sys.argv) > 1 and sys.argv[1] == "x3"
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -30,4 +31,4 @@ for M, K, N, ns in SHAPES:
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / 10
     print(json.dumps({"op": "pool_bwd", "M": M, "K": K, "N": N, "ns": ns, "ms": round(ms, 4),
-                      "TFLOPs_4MKK": round(4 * M * K * K / ms / 1e9, 1), "lib": os.path.basename(e.LIB_PATH)}))
+                      "TFLOPs_4MKK": round(4 * M * K * K / ms / 1e9, 1), "f32x3_route": bool(e.X3_GEMM and K == 64), "lib": os.path.basename(e.LIB_PATH)}))
