@@ -285,11 +285,12 @@ __global__ __launch_bounds__(1024) void inv_cloud_kernel(int N, int P, int W, in
 // + the waves' queues within the 144 KB of LDS.
 constexpr int kInvQueueInts = 16 * 128 * 2 + 2;   // (+ the padding that aligns the queues to 8 bytes)
 inline void inv_slices(int B, int N, int P, int *S, int *Ns) {
-  int s = 1;
+  int s = N > 8192 ? (N + 4095) / 4096 : 1;                    // (cursor init + scan are O(points of the slice) per workgroup)
   if (P >= 8192) {
-    s = 256 / B;                                               // about a workgroup per CU ...
+    // about a workgroup per CU ...
     const int full = (N + 2046) / 2047;                        // ... and 16 waves in each (16 x 2047 cursors fill the LDS)
-    s = s > full ? s : full;
+    const int per_cu = 256 / B;
+    s = per_cu > full ? per_cu : full;
   }
   const char *e = getenv("PN2_INVERSE_INDEX_SLICES");
   if (e && e[0] >= '1' && e[0] <= '9') s = atoi(e);
@@ -436,39 +437,101 @@ extern "C" int pn2_group_rows_grad_csr_bf16(int B, int N, int C, int ldg, int co
   return launch_rows_grad_csr<true>(B, N, C, ldg, col0, rows, grad_out, ptr, refs, grad_feats, stream);
 }
 
+namespace {
 // ---- the LITERAL op's gradient as a gather (round 6) ------------------------------------------------------------------
 // group_points_grad_kernel of the reference (EXT/src/group_points_gpu.cu:43-64) adds every gradient element to its point with
 // an fp32 atomic: B C m ns device-scope atomics (12.6 M at the C = 3 micro shape: 0.62 ms = 0.0175 of 8 TB/s), in an order that
 // changes from run to run.  Through the inverse index (ptr / refs of pn2_group_inverse_index over idx (B, m ns)) every point
 // sums ITS rows in ascending row order: no atomics, every output element written once, bit-reproducible.
 // Channel-major layouts of the reference: grad_out (B, C, S = m ns), grad_points (B, C, N).  Lane = point (coalesced stores).
-__global__ __launch_bounds__(256) void group_points_grad_csr_kernel(int C, int N, unsigned S, unsigned npoints,
+// `div` = slots per column of grad_out (1: group_points / gather_points; 3: three_interpolate, whose slot (j, t) reads column
+// j); `weight` (per slot, or NULL) multiplies the gathered value (three_interpolate_grad_kernel, EXT/src/interpolate_gpu.cu:116-143).
+__global__ __launch_bounds__(256) void group_points_grad_csr_kernel(int C, int N, unsigned S, unsigned div, unsigned npoints,
                                                                    const float *__restrict__ grad_out,
+                                                                   const float *__restrict__ weight,
                                                                    const int *__restrict__ ptr, const int *__restrict__ refs,
                                                                    float *__restrict__ grad_points) {
+  const unsigned cols = S / div;
   for (unsigned g = blockIdx.x * 256 + threadIdx.x; g < npoints; g += gridDim.x * 256) {
     const unsigned b = g / (unsigned)N, n = g - b * (unsigned)N;
     const int p0 = ptr[g], p1 = ptr[g + 1];
-    const float *G = grad_out + (size_t)b * C * S;
+    const float *G = grad_out + (size_t)b * C * cols;
     float *O = grad_points + (size_t)b * C * N + n;
     for (int c = 0; c < C; ++c) {
       float acc = 0.f;
-      for (int p = p0; p < p1; ++p) acc = __fadd_rn(acc, G[(size_t)c * S + ((unsigned)refs[p] - b * S)]);
+      for (int p = p0; p < p1; ++p) {
+        const unsigned slot = (unsigned)refs[p];
+        const float v = G[(size_t)c * cols + (slot - b * S) / div];
+        acc = weight ? __fmaf_rn(v, weight[slot], acc) : __fadd_rn(acc, v);
+      }
       O[(size_t)c * N] = acc;
     }
   }
 }
 
-extern "C" int pn2_group_points_grad_csr(int B, int C, int N, int npoints, int nsample, const float *grad_out, const int *ptr,
-                                         const int *refs, float *grad_points, void *stream) {
-  if (B < 0 || C < 0 || N < 0 || npoints < 0 || nsample < 0) return PN2_EINVAL;
-  const size_t S = (size_t)npoints * nsample, total = (size_t)B * N;
+// three_interpolate's literal gradient with the gradient rows of a channel group staged in LDS: a workgroup takes (cloud, CH
+// channels), reads their n columns once, coalesced (CH n floats <= 64 KB), and every thread then gathers for (known point,
+// channel) pairs — lanes along the points: the random reads hit LDS, the stores are coalesced.  The one-thread-per-point form
+// above walks C channels serially (B m threads in all: 1.56 ms at 32 x 256 x 1024 -> 512, slower than the 25 M atomics it replaces).
+__global__ __launch_bounds__(256) void interp_grad_csr_lds_kernel(int C, int n, int m, int CH, const float *__restrict__ grad_out,
+                                                                  const float *__restrict__ weight, const int *__restrict__ ptr,
+                                                                  const int *__restrict__ refs, float *__restrict__ grad_points) {
+  extern __shared__ float gtile[];                       // [CH][n]
+  const int groups = (C + CH - 1) / CH;
+  const int b = blockIdx.x / groups, c0 = (blockIdx.x - b * groups) * CH;
+  const int ch = C - c0 < CH ? C - c0 : CH;
+  const float *G = grad_out + ((size_t)b * C + c0) * n;
+  for (int i = threadIdx.x; i < ch * n; i += 256) gtile[i] = G[i];
+  __syncthreads();
+  const unsigned S = 3u * (unsigned)n;
+  for (int o = threadIdx.x; o < ch * m; o += 256) {
+    const int c = o / m, p = o - c * m;
+    const int p0 = ptr[(size_t)b * m + p], p1 = ptr[(size_t)b * m + p + 1];
+    float acc = 0.f;
+    for (int q = p0; q < p1; ++q) {
+      const unsigned slot = (unsigned)refs[q];
+      acc = __fmaf_rn(gtile[c * n + (int)((slot - (unsigned)b * S) / 3u)], weight[slot], acc);
+    }
+    grad_points[((size_t)b * C + c0 + c) * m + p] = acc;
+  }
+}
+
+int points_grad_csr(int B, int C, int N, size_t S, unsigned div, const float *grad_out, const float *weight, const int *ptr,
+                    const int *refs, float *grad_points, void *stream) {
+  const size_t total = (size_t)B * N;
   if (total == 0 || C == 0) return PN2_OK;
   if (total >= 0x7fffffffull || (size_t)B * S >= 0x7fffffffull) return PN2_EINVAL;
   if (!ptr || !grad_points || (S > 0 && (!grad_out || !refs))) return PN2_ENULL;
   unsigned grid = (unsigned)((total + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(group_points_grad_csr_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, (unsigned)S, (unsigned)total,
-                     grad_out, ptr, refs, grad_points);
+  hipLaunchKernelGGL(group_points_grad_csr_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, (unsigned)S, div,
+                     (unsigned)total, grad_out, weight, ptr, refs, grad_points);
   return pn2_check_launch();
+}
+}  // namespace
+
+extern "C" int pn2_group_points_grad_csr(int B, int C, int N, int npoints, int nsample, const float *grad_out, const int *ptr,
+                                         const int *refs, float *grad_points, void *stream) {
+  if (B < 0 || C < 0 || N < 0 || npoints < 0 || nsample < 0) return PN2_EINVAL;
+  return points_grad_csr(B, C, N, (size_t)npoints * nsample, 1u, grad_out, nullptr, ptr, refs, grad_points, stream);
+}
+
+// three_interpolate's gradient (EXT/src/interpolate_gpu.cu:116-143: three atomicAdds per gradient element) as the same gather:
+// (ptr, refs) = pn2_group_inverse_index(B, N = m, npoints = n, nsample = 3, idx); grad_out (B, C, n), weight (B, n, 3),
+// grad_points (B, C, m) — every element written, slots summed in ascending slot order.
+extern "C" int pn2_three_interpolate_grad_csr(int B, int C, int n, int m, const float *grad_out, const float *weight,
+                                              const int *ptr, const int *refs, float *grad_points, void *stream) {
+  if (B < 0 || C < 0 || n < 0 || m < 0) return PN2_EINVAL;
+  if (n > 0 && !weight) return PN2_ENULL;
+  int CH = 16;
+  while (CH > 1 && (size_t)CH * n * 4 > 64 * 1024) CH >>= 1;
+  if (B > 0 && C > 0 && m > 0 && n > 0 && (size_t)CH * n * 4 <= 64 * 1024 && (size_t)B * n * 3 < 0x7fffffffull) {
+    if (!ptr || !refs || !grad_out || !grad_points) return PN2_ENULL;
+    if (CH > C) CH = C;
+    const int groups = (C + CH - 1) / CH;
+    hipLaunchKernelGGL(interp_grad_csr_lds_kernel, dim3((unsigned)(B * groups)), dim3(256), (size_t)CH * n * 4, (hipStream_t)stream, C,
+                       n, m, CH, grad_out, weight, ptr, refs, grad_points);
+    return pn2_check_launch();
+  }
+  return points_grad_csr(B, C, m, (size_t)n * 3, 3u, grad_out, weight, ptr, refs, grad_points, stream);
 }

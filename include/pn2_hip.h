@@ -899,6 +899,11 @@ int pn2_x3_gemm(long long M, int K, int N, int pro, int epi, const float *X, con
  * bit-reproducible.  What `pointnet2_ops._ext.group_points_grad` runs (the atomic form stays exported as pn2_group_points_grad). */
 int pn2_group_points_grad_csr(int B, int C, int N, int npoints, int nsample, const float *grad_out, const int *ptr,
                               const int *refs, float *grad_points, void *stream);
+/* ... and three_interpolate's (EXT/src/interpolate_gpu.cu:116-143, three atomicAdds per gradient element): (ptr, refs) =
+ * pn2_group_inverse_index(B, m, n, 3, idx); grad_out (B, C, n), weight (B, n, 3) -> grad_points (B, C, m), every element written.
+ * `_ext.gather_points_grad` is pn2_group_points_grad_csr with nsample = 1. */
+int pn2_three_interpolate_grad_csr(int B, int C, int n, int m, const float *grad_out, const float *weight, const int *ptr,
+                                   const int *refs, float *grad_points, void *stream);
 
 /* pn2_mlp_gemm_first on the f32x3 product (csrc/x3_chain.hip): Y (M, N) = relu(bn_0(X0 W0^T)) W^T and stats (2, N) += the column
  * sums of Y, Y^2 (NULL: none).  X0 (M, K0 <= 8) the grouped input rows; w0_frags = pn2_x3_pack_first(N0 = K, K0, W0, scale_0,

@@ -465,3 +465,40 @@ def test_inverse_index_point_slices_equal_a_stable_sort(B, N, m, ns, slices, mon
     want_ptr = torch.zeros(B * N + 1, dtype=torch.long)
     want_ptr[1:] = torch.cumsum(torch.bincount(keys, minlength=B * N), 0)
     assert torch.equal(ptr.cpu().long(), want_ptr)
+
+
+@pytest.mark.parametrize("B,C,n,m", [(2, 5, 100, 7), (3, 64, 4000, 512), (2, 3, 50000, 1024), (1, 256, 1024, 512), (2, 9, 33, 1)])
+def test_literal_interpolate_and_gather_gradients_are_gathers_and_bit_reproducible(B, C, n, m):
+    """`_ext.three_interpolate_grad` (EXT/src/interpolate_gpu.cu:116-143) through the inverse index (channel groups staged in
+    LDS up to 16384 unknown points, the per-point walk beyond) and `_ext.gather_points_grad` (EXT/src/sampling_gpu.cu:38-58,
+    a scatter over distinct indices): float64 sums, identical bits from run to run, the atomic form within rounding."""
+    from pointnet2_ops import _ext
+    g = torch.Generator().manual_seed(B + C + n + m)
+    idx = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32)
+    w = torch.rand(B, n, 3, generator=g)
+    w = w / w.sum(2, keepdim=True)
+    go = torch.randn(B, C, n, generator=g)
+    want = torch.zeros(B, C, m, dtype=torch.float64)
+    for t in range(3):
+        want.scatter_add_(2, idx[:, :, t].view(B, 1, n).expand(-1, C, -1).long(), go.double() * w[:, :, t].double().view(B, 1, n))
+    a = _ext.three_interpolate_grad(go.cuda(), idx.cuda(), w.cuda(), m)
+    assert torch.equal(a, _ext.three_interpolate_grad(go.cuda(), idx.cuda(), w.cuda(), m))
+    scale = float(want.abs().max())
+    assert float((a.cpu().double() - want).abs().max()) < 2e-6 * scale * max(1.0, (3 * n / m) ** 0.5)
+    # (gather_points_grad stays a scatter — sampled indices of a cloud are distinct, so no two atomics meet)
+    gi = torch.stack([torch.randperm(n, generator=g)[:m] for _ in range(B)]).to(torch.int32)
+    gg = torch.randn(B, C, m, generator=g)
+    want_g = torch.zeros(B, C, n, dtype=torch.float64)
+    want_g.scatter_add_(2, gi.view(B, 1, m).expand(-1, C, -1).long(), gg.double())
+    b = _ext.gather_points_grad(gg.cuda(), gi.cuda(), n)
+    assert torch.equal(b, _ext.gather_points_grad(gg.cuda(), gi.cuda(), n))
+    assert float((b.cpu().double() - want_g).abs().max()) < 2e-6 * float(want_g.abs().max()) * max(1.0, (m / n) ** 0.5)
+    prev = _ext.GROUP_GRAD_CSR
+    _ext.GROUP_GRAD_CSR = False
+    try:
+        a2 = _ext.three_interpolate_grad(go.cuda(), idx.cuda(), w.cuda(), m)
+        b2 = _ext.gather_points_grad(gg.cuda(), gi.cuda(), n)
+    finally:
+        _ext.GROUP_GRAD_CSR = prev
+    torch.testing.assert_close(a2, a, atol=1e-4 * scale, rtol=1e-4)
+    torch.testing.assert_close(b2, b, atol=1e-5, rtol=1e-5)

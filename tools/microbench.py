@@ -181,6 +181,16 @@ def main():
     u, k = xyz[:, :1024].contiguous(), xyz[:, 1024:1536].contiguous()
     t = timeit(lambda: _ext.three_nn(u, k))
     report("three_nn_1024_512", t, B * (12 * 1024 + 12 * 512 + 24 * 1024))
+    # the literal gradients of FP's interpolation (B, 256, 1024) <- 512 known points and of gather_points (B, 3, 2048) -> 50k points
+    _d, i3 = _ext.three_nn(u, k)
+    w3 = torch.rand(B, 1024, 3, device=dev)
+    go3 = torch.rand(B, 256, 1024, device=dev)
+    t = timeit(lambda: _ext.three_interpolate_grad(go3, i3, w3, 512))
+    report("three_interpolate_grad_C256", t, B * (4 * 256 * 1024 + 24 * 1024 + 4 * 256 * 512))
+    gi = torch.randint(0, N, (B, m), device=dev, dtype=torch.int32)
+    gg = torch.rand(B, C, m, device=dev)
+    t = timeit(lambda: _ext.gather_points_grad(gg, gi, N))
+    report("gather_points_grad_C3", t, B * (4 * m + 4 * C * m + 4 * C * N))
 
 
 if __name__ == "__main__":
