@@ -303,7 +303,8 @@ def test_second_layer_gemm_recomputing_the_first_matches_the_two_gemms(M, K0, N0
     got = e.mlp_gemm_first(X0, W0, fin0, W1, epi=e.EPI_STATS, stats=st_new)
     # the recomputation runs the MFMA's FMA chain over the input columns: identical activations, identical products
     assert_same_product(got, ref)
-    torch.testing.assert_close(st_new, st_ref, rtol=1e-6, atol=1e-6)
+    # (forced f32x3 route: both sides sum fp32 partials per workgroup, over different partitions of the rows — 1e-6 apart)
+    torch.testing.assert_close(st_new, st_ref, rtol=1e-5 if e.X3_GEMM else 1e-6, atol=1e-6)
     got2 = e.mlp_gemm_first(X0, W0, fin0, W1, epi=e.EPI_NONE)
     assert_same_product(got2, ref)
 

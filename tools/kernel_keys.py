@@ -27,7 +27,8 @@ ENTRY_OF_FAMILY = {
     "inv_cloud_kernel": "pn2_group_inverse_index", "inv_keys_kernel": "pn2_group_inverse_index", "inv_ptr_kernel": "pn2_group_inverse_index",
     "three_interpolate_rows_grad_csr_kernel": "pn2_three_interpolate_rows_grad", "three_interpolate_rows_grad_kernel": "pn2_three_interpolate_rows_grad",
     "pool_bwd_prep_kernel": "pn2_pool_bwd_prep", "bn_relu_bwd_prep_kernel": "pn2_bn_relu_bwd_prep",
-    "x3_pack_kernel": "pn2_x3_pack_weight",
+    "x3_pack_kernel": "pn2_x3_pack_weight", "x3_pack_first_kernel": "pn2_x3_pack_first",
+    "group_points_grad_csr_kernel": "pn2_group_points_grad", "interp_grad_csr_lds_kernel": "pn2_three_interpolate_grad",
 }
 
 
@@ -65,7 +66,9 @@ def keys(name: str):
         mode = int(m.group(1)) if m else 0
         if m:
             out.append(f"sa_eval_kernel<IN{mode},K{16 * int(m.group(2))},mid{16 * int(m.group(3))},pro{m.group(5) or 0},epi{m.group(6) or 0}>")
-        out.append("entry:" + ("pn2_x3_gemm" if mode == 2 else "pn2_sa_eval_x3"))
+        # (IN 0 with the store + sums epilogue is pn2_x3_gemm_first: bench.py lists it under the entry it replaces)
+        first = m is not None and mode == 0 and (m.group(6) or "0") == "1"
+        out.append("entry:" + ("pn2_x3_gemm" if mode == 2 else "pn2_mlp_gemm_first" if first else "pn2_sa_eval_x3"))
     elif fam == "prep_vec_kernel":
         # template <POOLED>: true = pn2_pool_bwd_prep (and its segment-table form), false = pn2_bn_relu_bwd_prep
         out.append("entry:" + ("pn2_pool_bwd_prep" if re.search(r"prep_vec_kernel<\s*true", name) else "pn2_bn_relu_bwd_prep"))
