@@ -267,7 +267,8 @@ def kernel_table(table, steps):
     """Per-entry-point rows from a KernelTimer summary, sorted by time."""
     rows = []
     for name, d in table.items():
-        peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS
+        # (f32x3 kernels run six bf16 partial products per fp32-grade product: their ceiling is a sixth of the bf16 peak)
+        peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else (BF16_MFMA_PEAK_TFLOPS / 6.0 if "x3" in name else F32_MFMA_PEAK_TFLOPS)
         ridge = peak * 1e12 / (HBM_PEAK_GBPS * 1e9)                   # flop/byte where the rooflines cross
         per_launch_ms = d["ms"] / d["calls"]
         per_launch_bytes = d["alg_bytes"] / d["calls"]
