@@ -55,6 +55,18 @@ host = time.perf_counter() - t0
 torch.cuda.synchronize()
 tot = time.perf_counter() - t0
 print(json.dumps({"host_ms": host / N * 1e3, "wall_ms": tot / N * 1e3, **{k: round(v / N * 1e3, 3) for k, v in acc.items()}}))
+if len(sys.argv) > 1 and sys.argv[1] == "profile":
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(N): step(False)
+    pr.disable()
+    torch.cuda.synchronize()
+    for key in ("tottime", "cumulative"):
+        st = io.StringIO()
+        pstats.Stats(pr, stream=st).sort_stats(key).print_stats(60)
+        print(st.getvalue())
+    sys.exit(0)
 # forward detail by module: hooks on top-level children
 import collections
 times = collections.defaultdict(float)
