@@ -522,6 +522,7 @@ extern "C" int pn2_group_points_grad_csr(int B, int C, int N, int npoints, int n
 extern "C" int pn2_three_interpolate_grad_csr(int B, int C, int n, int m, const float *grad_out, const float *weight,
                                               const int *ptr, const int *refs, float *grad_points, void *stream) {
   if (B < 0 || C < 0 || n < 0 || m < 0) return PN2_EINVAL;
+  if (B == 0 || C == 0 || m == 0) return PN2_OK;
   if (n > 0 && !weight) return PN2_ENULL;
   int CH = 16;
   while (CH > 1 && (size_t)CH * n * 4 > 64 * 1024) CH >>= 1;

@@ -502,3 +502,36 @@ def test_literal_interpolate_and_gather_gradients_are_gathers_and_bit_reproducib
         _ext.GROUP_GRAD_CSR = prev
     torch.testing.assert_close(a2, a, atol=1e-4 * scale, rtol=1e-4)
     torch.testing.assert_close(b2, b, atol=1e-5, rtol=1e-5)
+
+
+def test_round6_entry_points_validate_their_arguments():
+    """The C entry points added this round return the library's status codes instead of launching on bad arguments
+    (PN2_EINVAL -1, PN2_ENULL -2) and do nothing on empty problems."""
+    import ctypes
+    from pointnet2_ops import _ext
+    lib = _ext._lib
+    t = torch.zeros(4096, dtype=torch.float32, device="cuda")
+    it = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+    nul = ctypes.c_void_p(0)
+    # group_points_grad_csr / three_interpolate_grad_csr
+    assert lib.pn2_group_points_grad_csr(0, 3, 10, 4, 2, nul, nul, nul, nul, None) == 0
+    assert lib.pn2_group_points_grad_csr(-1, 3, 10, 4, 2, p(t), p(it), p(it), p(t), None) == -1
+    assert lib.pn2_group_points_grad_csr(1, 3, 10, 4, 2, p(t), nul, p(it), p(t), None) == -2
+    assert lib.pn2_three_interpolate_grad_csr(1, 3, 8, 4, p(t), nul, p(it), p(it), p(t), None) == -2
+    assert lib.pn2_three_interpolate_grad_csr(0, 3, 8, 4, nul, nul, nul, nul, nul, None) == 0
+    # f32x3 first layer
+    assert lib.pn2_x3_gemm_first_supported(6, 64, 64) == 1 and lib.pn2_x3_gemm_first_supported(9, 64, 64) == 0
+    assert lib.pn2_x3_gemm_first_supported(6, 128, 64) == 0 and lib.pn2_x3_gemm_first_supported(6, 64, 48) == 0
+    ws = _ext._x3_workspace(t.device)
+    assert lib.pn2_x3_gemm_first(0, 6, 64, 64, nul, nul, nul, nul, nul, p(ws), None) == 0
+    assert lib.pn2_x3_gemm_first(128, 6, 96, 64, p(t), p(t), p(t), p(t), nul, p(ws), None) == -1
+    assert lib.pn2_x3_gemm_first(128, 6, 64, 64, p(t), nul, p(t), p(t), nul, p(ws), None) == -2
+    assert lib.pn2_x3_pack_first(48, 6, p(t), p(t), p(t), p(t), None) == -1
+    assert lib.pn2_x3_pack_first(64, 6, p(t), nul, p(t), p(t), None) == -2
+    # the f32x3 forms of the two backward kernels share the exact entries' checks
+    assert lib.pn2_x3_bwd_fold_first(64, 64, 64, 7, p(t), p(t), p(t), nul, nul, 0, p(t), p(t), p(t), p(t), 6,
+                                     p(t), p(t), p(t), None) == -1                                        # unknown gradient mode
+    assert lib.pn2_x3_pool_bwd(64, 128, 64, 48, p(t), p(t), p(t), p(t), p(it), p(t), p(t), p(t), p(t), p(t), 1 << 20, None) == -1   # ns 48
+    assert lib.pn2_x3_pool_bwd(0, 128, 64, 64, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, 0, None) == 0
+    torch.cuda.synchronize()
