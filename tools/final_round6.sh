@@ -28,6 +28,9 @@ rune --workload sgp --scans-per-step 8
 python tools/microbench.py 2>/dev/null | grep '^{' > gpurun_out/r06_microbench.jsonl
 python tools/sa_eval_bench.py gpurun_out/r06_sa_eval.jsonl > /dev/null 2>&1
 python tools/x3_gemm_bench.py gpurun_out/r06_x3_gemm.jsonl > /dev/null 2>&1
+# the two backward kernels with an f32x3 form (exact | f32x3), and the inverse index by slice count
+{ python tools/diag/fold_first_time.py 2>/dev/null | tail -1; python tools/pool_bwd_bench.py 2>/dev/null | grep '^{' | head -1; python tools/pool_bwd_bench.py x3 2>/dev/null | grep '^{' | head -1; } > gpurun_out/r06_x3_backward.jsonl
+python tools/diag/inv_slices_time.py 2>/dev/null | grep '^(' > gpurun_out/r06_inverse_index_slices.txt
 python - <<'PY'
 import json
 for f in ("r06_driver_runs.jsonl", "r06_other_workloads.jsonl", "r06_eval_runs.jsonl"):
