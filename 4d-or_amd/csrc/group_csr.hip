@@ -457,14 +457,23 @@ __global__ __launch_bounds__(256) void group_points_grad_csr_kernel(int C, int N
     const int p0 = ptr[g], p1 = ptr[g + 1];
     const float *G = grad_out + (size_t)b * C * cols;
     float *O = grad_points + (size_t)b * C * N + n;
-    for (int c = 0; c < C; ++c) {
-      float acc = 0.f;
+    // four channels per walk of the point's references: a reference (and its weight) is read once for them, and their four
+    // gathers are independent loads (C = 3, 2.6 references per point: the one-channel walk re-read the list per channel)
+    for (int c = 0; c < C; c += 4) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
       for (int p = p0; p < p1; ++p) {
         const unsigned slot = (unsigned)refs[p];
-        const float v = G[(size_t)c * cols + (slot - b * S) / div];
-        acc = weight ? __fmaf_rn(v, weight[slot], acc) : __fadd_rn(acc, v);
+        const size_t col = (slot - b * S) / div;
+        const float w = weight ? weight[slot] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = c + j < C ? G[(size_t)(c + j) * cols + col] : 0.f;
+          acc[j] = weight ? __fmaf_rn(v, w, acc[j]) : __fadd_rn(acc[j], v);
+        }
       }
-      O[(size_t)c * N] = acc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < C) O[(size_t)(c + j) * N] = acc[j];
     }
   }
 }
