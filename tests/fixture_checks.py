@@ -146,3 +146,35 @@ def check_sgpn(z, tag, seed, dev, atol, rtol, loss_tol):
     norms = np.array([float(params[k].grad.double().norm()) for k in gnames])
     live = ref > 1e-3 * ref.max()
     np.testing.assert_allclose(norms[live], ref[live], rtol=2e-2)
+
+
+def seed_running_stats(module, seed):
+    """Deterministic, non-trivial BatchNorm running statistics from a HOST generator (the same numbers on every device and in the
+    fixture generator): running_mean ~ 0.2 N(0,1), running_var ~ U(0.5, 1.5), affine weight ~ U(0.7, 1.3), bias ~ 0.1 N(0,1),
+    in module order."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.running_mean is not None:
+                n = m.num_features
+                m.running_mean.copy_((torch.randn(n, generator=g) * 0.2).to(m.running_mean.device))
+                m.running_var.copy_((torch.rand(n, generator=g) + 0.5).to(m.running_var.device))
+                m.weight.copy_((torch.rand(n, generator=g) * 0.6 + 0.7).to(m.weight.device))
+                m.bias.copy_((torch.randn(n, generator=g) * 0.1).to(m.bias.device))
+
+
+def check_gf3d_eval(z, dev, atol, rtol):
+    """Pointnet2Backbone in EVAL mode (running statistics of seed_running_stats) against the reference's own class run on the
+    oracle (tests/golden/gf3d_backbone_eval.npz): sampled indices bit-exact, SA4 / FP2 features."""
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    torch.manual_seed(31)
+    net = Pointnet2Backbone(input_feature_dim=3)
+    seed_running_stats(net, 77)
+    net = net.to(dev).eval()
+    with torch.no_grad():
+        ep = net(_t(z, "pc", dev))
+    assert np.array_equal(ep["sa1_inds"][:, :256].cpu().numpy(), z["sa1_inds"])
+    assert np.array_equal(ep["sa4_xyz"].cpu().numpy(), z["sa4_xyz"])
+    np.testing.assert_allclose(ep["sa4_features"].cpu().numpy()[:, ::4], z["sa4_features"], atol=atol, rtol=rtol)
+    np.testing.assert_allclose(ep["fp2_features"].cpu().numpy()[:, ::8, ::4], z["fp2_features"], atol=atol, rtol=rtol)
+    return ep

@@ -177,6 +177,30 @@ def fixture_gf3d_backbone():
          grad_sa1_conv0=gw.numpy(), grad_fp2_conv1=gw2.numpy()[::4])
 
 
+def fixture_gf3d_backbone_eval():
+    """The reference's Pointnet2Backbone in EVAL mode (BatchNorm on running statistics: the inference path, main.py:84-117):
+    weights from the seed, running statistics / affine parameters from tests/fixture_checks.py::seed_running_stats (a host
+    generator: the consumer rebuilds the same module instead of loading megabytes)."""
+    import external_src.group_free_3D  # noqa: F401
+    pkg = sys.modules.get("external_src.group_free_3D.models") or _stub("external_src.group_free_3D.models")
+    pkg.__path__ = [os.path.join(REF, "external_src/group_free_3D/models")]
+    from external_src.group_free_3D.models.backbone_module import Pointnet2Backbone
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fixture_checks", os.path.join(REPO, "tests", "fixture_checks.py"))
+    fc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fc)
+    torch.manual_seed(31)
+    net = Pointnet2Backbone(input_feature_dim=3)
+    assert type(net).__module__.startswith("external_src") and sys.modules[type(net).__module__].__file__.startswith(REF)
+    fc.seed_running_stats(net, 77)
+    net.eval()
+    pc = cloud(2, 2600, 3, 33)
+    with torch.no_grad():
+        ep = net(pc.clone())
+    save("gf3d_backbone_eval.npz", pc=pc.numpy(), sa1_inds=ep["sa1_inds"][:, :256].numpy(), sa4_xyz=ep["sa4_xyz"].numpy(),
+         sa4_features=ep["sa4_features"].numpy()[:, ::4], fp2_features=ep["fp2_features"].numpy()[:, ::8, ::4])
+
+
 def fixture_votes_pooling():
     """GF3D PointnetSAModuleVotes with the three pooling modes (GF3D/pointnet2/pointnet2_modules.py:236-248), the
     normalize_xyz flag and a caller-supplied `inds`; train-mode forward + backward."""
@@ -495,6 +519,6 @@ def fixture_sgpn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sa_msg", "fp", "msg_encoder", "gf3d_backbone", "votes_pooling", "heads", "sample_uniformly", "triplet_gcn", "sgpn"]
+    which = sys.argv[1:] or ["sa_msg", "fp", "msg_encoder", "gf3d_backbone", "gf3d_backbone_eval", "votes_pooling", "heads", "sample_uniformly", "triplet_gcn", "sgpn"]
     for name in which:
         globals()["fixture_" + name]()

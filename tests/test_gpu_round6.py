@@ -535,3 +535,21 @@ def test_round6_entry_points_validate_their_arguments():
     assert lib.pn2_x3_pool_bwd(64, 128, 64, 48, p(t), p(t), p(t), p(t), p(it), p(t), p(t), p(t), p(t), p(t), 1 << 20, None) == -1   # ns 48
     assert lib.pn2_x3_pool_bwd(0, 128, 64, 64, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, 0, None) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_gf3d_backbone_eval_mode_matches_reference_class_on_gpu(fused):
+    """bench.py --forward-eval's model against the reference's own Pointnet2Backbone in eval mode
+    (tests/golden/gf3d_backbone_eval.npz): every SA level through the one-kernel f32x3 route (`fused`) and through the
+    layer-by-layer exact kernels — sampled indices bit-exact, features within 1e-4."""
+    from pointnet2_ops import eval_fused, _ext
+    calls = []
+    real = _ext.sa_eval_x3
+    prev = eval_fused.set_eval_fused(fused)
+    _ext.sa_eval_x3 = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        fc.check_gf3d_eval(fc.load("gf3d_backbone_eval.npz"), "cuda", atol=1e-4, rtol=1e-3)
+    finally:
+        _ext.sa_eval_x3 = real
+        eval_fused.set_eval_fused(prev)
+    assert (len(calls) == 4) == fused, calls           # the four SA levels, one kernel each

@@ -32,3 +32,16 @@ def test_sgpn_manifest_is_the_reference_order(tag, seed):
 @pytest.mark.parametrize("tag,seed", [("no_gt", 82), ("no_gt_image", 83)])
 def test_sgpn_forward_loss_gradients_match_reference_class(oracle_backend, tag, seed):
     fc.check_sgpn(fc.load("sgpn.npz"), tag, seed, "cpu", atol=2e-5, rtol=1e-4, loss_tol=1e-4)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_gf3d_backbone_eval_mode_matches_reference_class(oracle_backend, fast):
+    """The inference path (eval-mode BatchNorm on running statistics, EXT/GF3D models/backbone_module.py:95-135 under
+    main.py:84-117) of the headline backbone against the reference's own class (tests/golden/make_golden.py
+    `gf3d_backbone_eval`), literal and rows python paths on the oracle backend."""
+    from pointnet2_ops import pointnet2_modules as pm
+    prev = pm.set_fast_path(fast)
+    try:
+        fc.check_gf3d_eval(fc.load("gf3d_backbone_eval.npz"), "cpu", atol=2e-5, rtol=1e-4)
+    finally:
+        pm.set_fast_path(prev)
